@@ -1,0 +1,341 @@
+"""CPU ORACLE -- test infrastructure, NOT product code.
+
+numpy front-end of ``oracle/splat_oracle.c`` (a scalar float32 restatement of the reference's
+``dptr.gs._C`` CUDA extension, see the header of that file for pinning status).  The function
+names mirror the 18 entry points of the reference's pybind module
+(reference: src/submodules/dptr/dptr/gs/src/ext.cpp:14-33) plus the two orthographic torch
+twins of src/pointrix/renderer/dptr_ortho_enhanced.py.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package.  ``splatter_a_video_amd`` never does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with the committed Makefile (gcc only)."""
+    src = os.path.join(_HERE, "splat_oracle.c")
+    if force or (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_get_threads.restype = ctypes.c_int
+        _lib.oracle_has_openmp.restype = ctypes.c_int
+    return _lib
+
+
+def set_threads(n: int) -> None:
+    lib().oracle_set_threads(ctypes.c_int(int(n)))
+
+
+def get_threads() -> int:
+    return int(lib().oracle_get_threads())
+
+
+def has_openmp() -> bool:
+    return bool(lib().oracle_has_openmp())
+
+
+def _f(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _b(a):
+    return np.ascontiguousarray(np.asarray(a).astype(bool).reshape(-1), dtype=np.uint8)
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _extr12(extr):
+    e = _f(extr).reshape(-1)
+    assert e.size >= 12, "extr must hold at least 3x4 floats"
+    return np.ascontiguousarray(e[:12])
+
+
+def _tiles(W, H):
+    return ((W + 15) // 16) * ((H + 15) // 16)
+
+
+# ------------------------------------------------------------------ project_point
+def project_point_forward(xyz, intr, extr, W, H, nearest=0.2, extent=1.3):
+    xyz = _f(xyz, (-1, 3)); intr = _f(intr); extr = _extr12(extr)
+    P = xyz.shape[0]
+    uv = np.zeros((P, 2), np.float32); depth = np.zeros((P, 1), np.float32)
+    lib().oracle_project_point_forward(P, _p(xyz, _f32p), _p(intr, _f32p), _p(extr, _f32p), int(W), int(H),
+                                       ctypes.c_float(nearest), ctypes.c_float(extent),
+                                       _p(uv, _f32p), _p(depth, _f32p))
+    return uv, depth
+
+
+def project_point_backward(xyz, intr, extr, W, H, uv, depth, dL_duv, dL_ddepth,
+                           need_intr=True, need_extr=True):
+    xyz = _f(xyz, (-1, 3)); intr = _f(intr); extr = _extr12(extr)
+    P = xyz.shape[0]
+    uv = _f(uv); depth = _f(depth); dL_duv = _f(dL_duv); dL_ddepth = _f(dL_ddepth)
+    dxyz = np.zeros((P, 3), np.float32)
+    dintr = np.zeros(4, np.float32); dextr = np.zeros((3, 4), np.float32)
+    lib().oracle_project_point_backward(P, _p(xyz, _f32p), _p(intr, _f32p), _p(extr, _f32p), int(W), int(H),
+                                        _p(uv, _f32p), _p(depth, _f32p), _p(dL_duv, _f32p), _p(dL_ddepth, _f32p),
+                                        _p(dxyz, _f32p), _p(dintr if need_intr else None, _f32p),
+                                        _p(dextr if need_extr else None, _f32p))
+    return dxyz, dintr, dextr
+
+
+def project_point_ortho_forward(xyz, extr, W, H, nearest=0.2, extent=1.3):
+    xyz = _f(xyz, (-1, 3)); extr = _extr12(extr)
+    P = xyz.shape[0]
+    uv = np.zeros((P, 2), np.float32); depth = np.zeros((P, 1), np.float32)
+    lib().oracle_project_point_ortho_forward(P, _p(xyz, _f32p), _p(extr, _f32p), int(W), int(H),
+                                             ctypes.c_float(nearest), ctypes.c_float(extent),
+                                             _p(uv, _f32p), _p(depth, _f32p))
+    return uv, depth
+
+
+def project_point_ortho_backward(extr, W, H, depth, dL_duv, dL_ddepth):
+    extr = _extr12(extr); depth = _f(depth); dL_duv = _f(dL_duv); dL_ddepth = _f(dL_ddepth)
+    P = depth.size
+    dxyz = np.zeros((P, 3), np.float32)
+    lib().oracle_project_point_ortho_backward(P, _p(extr, _f32p), int(W), int(H), _p(depth, _f32p),
+                                              _p(dL_duv, _f32p), _p(dL_ddepth, _f32p), _p(dxyz, _f32p))
+    return dxyz
+
+
+# ------------------------------------------------------------------ compute_cov3d
+def compute_cov3d_forward(scales, uquats, visible=None):
+    scales = _f(scales, (-1, 3)); uquats = _f(uquats, (-1, 4))
+    P = scales.shape[0]
+    vis = _b(np.ones(P, bool) if visible is None else visible)
+    cov = np.zeros((P, 6), np.float32)
+    lib().oracle_compute_cov3d_forward(P, _p(scales, _f32p), _p(uquats, _f32p), _p(vis, _u8p), _p(cov, _f32p))
+    return cov
+
+
+def compute_cov3d_backward(scales, uquats, visible, dL_dcov3d):
+    scales = _f(scales, (-1, 3)); uquats = _f(uquats, (-1, 4)); g = _f(dL_dcov3d, (-1, 6))
+    P = scales.shape[0]
+    vis = _b(np.ones(P, bool) if visible is None else visible)
+    ds = np.zeros((P, 3), np.float32); dq = np.zeros((P, 4), np.float32)
+    lib().oracle_compute_cov3d_backward(P, _p(scales, _f32p), _p(uquats, _f32p), _p(vis, _u8p), _p(g, _f32p),
+                                        _p(ds, _f32p), _p(dq, _f32p))
+    return ds, dq
+
+
+# ------------------------------------------------------------------ ewa_project
+def ewa_project_forward(xyz, cov3d, intr, extr, uv, W, H, visible=None, ortho=False):
+    xyz = _f(xyz, (-1, 3)); cov3d = _f(cov3d, (-1, 6)); extr = _extr12(extr); uv = _f(uv, (-1, 2))
+    intr = _f(np.zeros(4) if intr is None else intr)
+    P = xyz.shape[0]
+    vis = _b(np.ones(P, bool) if visible is None else visible)
+    conic = np.zeros((P, 3), np.float32); radius = np.zeros(P, np.int32); tiles = np.zeros(P, np.int32)
+    lib().oracle_ewa_project_forward(int(bool(ortho)), P, _p(xyz, _f32p), _p(cov3d, _f32p), _p(intr, _f32p),
+                                     _p(extr, _f32p), _p(uv, _f32p), int(W), int(H), _p(vis, _u8p),
+                                     _p(conic, _f32p), _p(radius, _i32p), _p(tiles, _i32p))
+    return conic, radius, tiles
+
+
+def ewa_project_backward(xyz, cov3d, intr, extr, radius, dL_dconic, W=0, H=0, ortho=False,
+                         need_intr=True, need_extr=True):
+    xyz = _f(xyz, (-1, 3)); cov3d = _f(cov3d, (-1, 6)); extr = _extr12(extr)
+    intr = _f(np.zeros(4) if intr is None else intr)
+    radius = _i(radius); g = _f(dL_dconic, (-1, 3))
+    P = xyz.shape[0]
+    dxyz = np.zeros((P, 3), np.float32); dcov = np.zeros((P, 6), np.float32)
+    dintr = np.zeros(4, np.float32); dextr = np.zeros((3, 4), np.float32)
+    lib().oracle_ewa_project_backward(int(bool(ortho)), P, _p(xyz, _f32p), _p(cov3d, _f32p), _p(intr, _f32p),
+                                      _p(extr, _f32p), int(W), int(H), _p(radius, _i32p), _p(g, _f32p),
+                                      _p(dxyz, _f32p), _p(dcov, _f32p),
+                                      _p(dintr if need_intr else None, _f32p),
+                                      _p(dextr if need_extr else None, _f32p))
+    return dxyz, dcov, dintr, dextr
+
+
+# ------------------------------------------------------------------ compute_sh
+def compute_sh_forward(shs, degree, view_dirs, visible=None, free=False):
+    shs = _f(shs); dirs = _f(view_dirs, (-1, 3))
+    P = shs.shape[0]
+    assert shs.size >= P * (degree + 1) ** 2 * 3
+    vis = _b(np.ones(P, bool) if visible is None else visible)
+    colors = np.zeros((P, 3), np.float32)
+    clamped = np.ones((P, 3), np.uint8)
+    lib().oracle_compute_sh_forward(int(bool(free)), P, _p(shs, _f32p), int(degree), _p(dirs, _f32p), _p(vis, _u8p),
+                                    _p(colors, _f32p), _p(clamped, _u8p))
+    if free:
+        return colors
+    return colors, clamped.astype(bool)
+
+
+def compute_sh_backward(shs, degree, view_dirs, visible, clamped, dL_dcolors, free=False):
+    shs = _f(shs); dirs = _f(view_dirs, (-1, 3)); g = _f(dL_dcolors, (-1, 3))
+    P = shs.shape[0]
+    vis = _b(np.ones(P, bool) if visible is None else visible)
+    cl = None if free else np.ascontiguousarray(np.asarray(clamped).astype(np.uint8))
+    dshs = np.zeros_like(shs); ddirs = np.zeros((P, 3), np.float32)
+    lib().oracle_compute_sh_backward(int(bool(free)), P, _p(shs, _f32p), int(degree), _p(dirs, _f32p), _p(vis, _u8p),
+                                     _p(cl, _u8p), _p(g, _f32p), _p(dshs, _f32p), _p(ddirs, _f32p))
+    return dshs, ddirs
+
+
+# ------------------------------------------------------------------ sort_gaussian
+def cumsum_i32(tiles):
+    tiles = _i(tiles)
+    out = np.zeros_like(tiles)
+    lib().oracle_cumsum_i32(tiles.size, _p(tiles, _i32p), _p(out, _i32p))
+    return out
+
+
+def compute_gaussian_key(uv, depth, W, H, radius, tiles_cumsum):
+    uv = _f(uv, (-1, 2)); depth = _f(depth).reshape(-1); radius = _i(radius); cs = _i(tiles_cumsum)
+    P = uv.shape[0]
+    M = int(cs[-1]) if P > 0 else 0
+    key = np.zeros(M, np.int64); idx = np.zeros(M, np.int32)
+    if P > 0:
+        lib().oracle_compute_gaussian_key(P, _p(uv, _f32p), _p(depth, _f32p), int(W), int(H), _p(radius, _i32p),
+                                          _p(cs, _i32p), _p(key, _i64p), _p(idx, _i32p))
+    return key, idx
+
+
+def compute_tile_gaussian_range(W, H, key_sorted):
+    key_sorted = np.ascontiguousarray(key_sorted, dtype=np.int64)
+    tr = np.zeros((_tiles(W, H), 2), np.int32)
+    lib().oracle_compute_tile_range(key_sorted.size, _p(key_sorted, _i64p), _p(tr, _i32p))
+    return tr
+
+
+def sort_gaussian(uv, depth, W, H, radius, tiles) -> Tuple[np.ndarray, np.ndarray]:
+    """Python-level glue of the reference op (dptr/gs/sort_gaussian.py:42-52), stable order."""
+    cs = cumsum_i32(tiles)
+    key, idx = compute_gaussian_key(uv, depth, W, H, radius, cs)
+    lib().oracle_sort_pairs(key.size, _p(key, _i64p), _p(idx, _i32p))
+    tr = compute_tile_gaussian_range(W, H, key)
+    return idx, tr
+
+
+# ------------------------------------------------------------------ alpha blending
+def alpha_blending_forward(uv, conic, opacity, feature, idx_sorted, tile_range, bg, W, H,
+                           K: int = 0, enable_truncation: bool = False, opacity_bias=None):
+    """Returns (out[C,H,W], final_T[H,W], ncontrib[H,W]) and gs_idx[H,W,K] when K>0 (enhanced)."""
+    uv = _f(uv, (-1, 2)); conic = _f(conic, (-1, 3)); opacity = _f(opacity).reshape(-1)
+    feature = _f(feature); feature = feature.reshape(uv.shape[0], -1)
+    idx_sorted = _i(idx_sorted); tile_range = _i(tile_range)
+    bias = None if opacity_bias is None else _f(opacity_bias).reshape(-1)
+    P, C = feature.shape
+    out = np.zeros((C, H, W), np.float32); fT = np.zeros((H, W), np.float32); nc = np.zeros((H, W), np.int32)
+    gi = None
+    if K > 0:
+        gi = np.full((H, W, K), -1, np.int32)
+    lib().oracle_alpha_blending_forward(P, C, _p(uv, _f32p), _p(conic, _f32p), _p(opacity, _f32p),
+                                        _p(feature, _f32p), _p(bias, _f32p), _p(idx_sorted, _i32p),
+                                        _p(tile_range, _i32p), ctypes.c_float(bg), int(W), int(H), int(K),
+                                        int(bool(enable_truncation)), _p(out, _f32p), _p(fT, _f32p),
+                                        _p(nc, _i32p), _p(gi, _i32p))
+    if K > 0:
+        return out, fT, nc, gi
+    return out, fT, nc
+
+
+def alpha_blending_backward(uv, conic, opacity, feature, idx_sorted, tile_range, bg, W, H,
+                            final_T, ncontrib, dL_dout, opacity_bias=None):
+    """Returns (dL_duv, dL_dconic, dL_dopacity, dL_dfeature, dL_dabs_uv[, dL_dbias])."""
+    uv = _f(uv, (-1, 2)); conic = _f(conic, (-1, 3)); opacity = _f(opacity).reshape(-1)
+    feature = _f(feature); feature = feature.reshape(uv.shape[0], -1)
+    idx_sorted = _i(idx_sorted); tile_range = _i(tile_range)
+    bias = None if opacity_bias is None else _f(opacity_bias).reshape(-1)
+    fT = _f(final_T); nc = _i(ncontrib); g = _f(dL_dout)
+    P, C = feature.shape
+    duv = np.zeros((P, 2), np.float32); dabs = np.zeros((P, 2), np.float32)
+    dcon = np.zeros((P, 3), np.float32); dop = np.zeros((P, 1), np.float32)
+    df = np.zeros((P, C), np.float32); db = np.zeros((P, 1), np.float32)
+    lib().oracle_alpha_blending_backward(P, C, _p(uv, _f32p), _p(conic, _f32p), _p(opacity, _f32p),
+                                         _p(feature, _f32p), _p(bias, _f32p), _p(idx_sorted, _i32p),
+                                         _p(tile_range, _i32p), ctypes.c_float(bg), int(W), int(H),
+                                         _p(fT, _f32p), _p(nc, _i32p), _p(g, _f32p),
+                                         _p(duv, _f32p), _p(dabs, _f32p), _p(dcon, _f32p), _p(dop, _f32p),
+                                         _p(df, _f32p), _p(db, _f32p))
+    if bias is not None:
+        return duv, dcon, dop, df, dabs, db
+    return duv, dcon, dop, df, dabs
+
+
+# ------------------------------------------------------------------ composed pipelines
+def render_forward(xyz, scale, rotate, opacity, feature, intr, extr, W, H, bg,
+                   ortho=False, nearest=None, shs=None, sh_degree=3, K=0):
+    """5-op chain of dptr.gs.rasterization (dptr/gs/__init__.py:28-100); with ``shs`` the colours
+    come from compute_sh with direction (0,0,1) as the video renderer does
+    (dptr_ortho_enhanced.py:270-272) and are prepended to ``feature``."""
+    xyz = _f(xyz, (-1, 3))
+    P = xyz.shape[0]
+    saved = {}
+    if shs is not None:
+        dirs = np.zeros((P, 3), np.float32); dirs[:, 2] = 1.0
+        rgb, clamped = compute_sh_forward(shs, sh_degree, dirs)
+        saved.update(dirs=dirs, clamped=clamped, rgb=rgb)
+        feature = rgb if feature is None else np.concatenate([rgb, _f(feature).reshape(P, -1)], axis=1)
+    if ortho:
+        uv, depth = project_point_ortho_forward(xyz, extr, W, H, 0.01 if nearest is None else nearest)
+    else:
+        uv, depth = project_point_forward(xyz, intr, extr, W, H, 0.2 if nearest is None else nearest)
+    visible = depth.reshape(-1) != 0
+    cov3d = compute_cov3d_forward(scale, rotate, visible)
+    conic, radius, tiles = ewa_project_forward(xyz, cov3d, intr, extr, uv, W, H, visible, ortho=ortho)
+    idx_sorted, tile_range = sort_gaussian(uv, depth, W, H, radius, tiles)
+    res = alpha_blending_forward(uv, conic, opacity, feature, idx_sorted, tile_range, bg, W, H, K=K)
+    saved.update(uv=uv, depth=depth, visible=visible, cov3d=cov3d, conic=conic, radius=radius, tiles=tiles,
+                 idx_sorted=idx_sorted, tile_range=tile_range, feature=feature, final_T=res[1], ncontrib=res[2])
+    return res, saved
+
+
+def render_backward(xyz, scale, rotate, opacity, intr, extr, W, H, bg, saved, dL_dout,
+                    ortho=False, shs=None, sh_degree=3):
+    """Backward of :func:`render_forward` -> dict of gradients (autograd order of SURVEY 3.3)."""
+    s = saved
+    duv, dcon, dop, df, dabs = alpha_blending_backward(s["uv"], s["conic"], opacity, s["feature"],
+                                                       s["idx_sorted"], s["tile_range"], bg, W, H,
+                                                       s["final_T"], s["ncontrib"], dL_dout)
+    dxyz_e, dcov, _, _ = ewa_project_backward(xyz, s["cov3d"], intr, extr, s["radius"], dcon, W, H, ortho=ortho,
+                                              need_intr=False, need_extr=False)
+    P = s["uv"].shape[0]
+    zero_d = np.zeros((P, 1), np.float32)
+    if ortho:
+        dxyz_p = project_point_ortho_backward(extr, W, H, s["depth"], duv, zero_d)
+    else:
+        dxyz_p, _, _ = project_point_backward(xyz, intr, extr, W, H, s["uv"], s["depth"], duv, zero_d,
+                                              need_intr=False, need_extr=False)
+    dscale, dquat = compute_cov3d_backward(scale, rotate, s["visible"], dcov)
+    out = dict(xyz=dxyz_e + dxyz_p, scale=dscale, rotate=dquat, opacity=dop, uv=duv, abs_uv=dabs,
+               conic=dcon, feature=df)
+    if shs is not None:
+        dshs, _ = compute_sh_backward(shs, sh_degree, s["dirs"], None, s["clamped"], df[:, :3])
+        out["shs"] = dshs
+        out["feature"] = df[:, 3:]
+    return out

@@ -1,0 +1,156 @@
+"""Generates tests/golden/*.npz from the importable pure-torch pieces of the reference.
+
+Run ONLY in the build container (needs /root/reference); the fixtures (inputs + expected outputs,
+data only) are committed, the reference's sources are neither copied nor shipped.
+
+What is importable:
+  * src/pointrix/renderer/dptr_ortho_enhanced.py : DPTROrthoEnhancedRender.project_point (ortho
+    projection + culling) and ewa_project_torch_impl (ortho EWA) -- loaded by file path with stub
+    modules for jaxtyping / dptr / pointrix.utils.{base,registry};
+  * src/pointrix/utils/sh_utils.py : eval_sh (SH basis, [...,3,16] layout, no +0.5 / clamp).
+Gradients of the two twins are produced with torch.autograd on them.
+
+    python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/src"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+
+from splatter_a_video_amd.synth import make_scene  # noqa: E402
+
+
+def _load_reference_twins():
+    class _Sub:
+        def __getitem__(self, item):
+            return self
+
+    jt = types.ModuleType("jaxtyping")
+    jt.Float = _Sub(); jt.Int = _Sub(); jt.Bool = _Sub()
+    sys.modules["jaxtyping"] = jt
+    for name in ["dptr", "dptr.gs", "pointrix", "pointrix.utils", "pointrix.utils.renderer"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["dptr"].gs = sys.modules["dptr.gs"]
+    base = types.ModuleType("pointrix.utils.base")
+
+    class BaseObject:
+        def __init__(self, *a, **k):
+            pass
+
+        def setup(self, *a, **k):
+            pass
+    base.BaseObject = BaseObject
+    sys.modules["pointrix.utils.base"] = base
+    reg = types.ModuleType("pointrix.utils.registry")
+
+    class Registry:
+        def __init__(self, *a, **k):
+            pass
+
+        def register(self, *a, **k):
+            return lambda cls: cls
+    reg.Registry = Registry
+    sys.modules["pointrix.utils.registry"] = reg
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    load(os.path.join(REF, "pointrix/utils/renderer/renderer_utils.py"), "pointrix.utils.renderer.renderer_utils")
+    pkg = types.ModuleType("refpkg"); pkg.__path__ = []
+    sys.modules["refpkg"] = pkg
+    sub = types.ModuleType("refpkg.dptr"); sub.RENDERER_REGISTRY = Registry()
+    sys.modules["refpkg.dptr"] = sub
+    ortho = load(os.path.join(REF, "pointrix/renderer/dptr_ortho_enhanced.py"), "refpkg.dptr_ortho_enhanced")
+    sh = load(os.path.join(REF, "pointrix/utils/sh_utils.py"), "ref_sh_utils")
+    return ortho, sh
+
+
+def _cov3d_torch(scale, quat):
+    """Sigma = R diag(s^2) R^T, formula of build_covariance_from_scaling_rotation
+    (reference: src/pointrix/utils/gaussian_points/gaussian_utils.py:36-61), in float32 torch."""
+    r, x, y, z = quat.unbind(-1)
+    R = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+    L = R * scale[:, None, :]
+    S = L @ L.transpose(1, 2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
+
+
+def make_case(ortho_mod, sh_mod, name, N, W, H, seed, extr=None):
+    sc = make_scene(N, W, H, F=50, seed=seed)
+    rng = np.random.default_rng(seed + 77)
+    xyz = sc.positions(3)
+    # push a few points over the culling limits so every mask branch is exercised
+    xyz[: N // 50, 2] = rng.uniform(-0.2, 0.012, size=N // 50).astype(np.float32)
+    xyz[N // 50: N // 25, 0] = rng.uniform(1.2, 1.5, size=N // 25 - N // 50).astype(np.float32)
+    E = np.eye(4, dtype=np.float32) if extr is None else extr.astype(np.float32)
+
+    t_xyz = torch.tensor(xyz, requires_grad=True)
+    t_E = torch.tensor(E)
+    uv, depth = ortho_mod.DPTROrthoEnhancedRender.project_point(None, t_xyz, t_E, W, H, nearest=0.01)
+    g_uv = torch.tensor(rng.normal(size=(N, 2)).astype(np.float32))
+    g_d = torch.tensor(rng.normal(size=(N, 1)).astype(np.float32))
+    (uv * g_uv).sum().backward(retain_graph=True)
+    dxyz_uv = t_xyz.grad.clone(); t_xyz.grad = None
+    (depth * g_d).sum().backward()
+    dxyz_d = t_xyz.grad.clone()
+
+    visible = (depth != 0).squeeze(-1)
+    cov3d = _cov3d_torch(torch.tensor(sc.scale), torch.tensor(sc.rotate)) * visible[:, None].float()
+    t_cov = cov3d.clone().requires_grad_(True)
+    conic, radius, tiles = ortho_mod.ewa_project_torch_impl(t_xyz.detach(), t_cov, t_E, uv.detach(), W, H, visible)
+    g_c = torch.tensor(rng.normal(size=(N, 3)).astype(np.float32))
+    (conic * g_c).sum().backward()
+    dcov = t_cov.grad.clone()
+
+    dirs = rng.normal(size=(N, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dirs[: N // 2] = np.array([0, 0, 1], np.float32)  # the video renderer's constant direction
+    sh_out = {}
+    for deg in range(4):
+        nb = (deg + 1) ** 2
+        sh_cm = torch.tensor(np.ascontiguousarray(sc.shs[:, :nb, :].transpose(0, 2, 1)))  # [N,3,nb]
+        sh_out[f"sh_deg{deg}"] = sh_mod.eval_sh(deg, sh_cm, torch.tensor(dirs)).numpy()
+
+    out = dict(
+        W=np.int32(W), H=np.int32(H), extr=E, xyz=xyz, scale=sc.scale, rotate=sc.rotate, shs=sc.shs, dirs=dirs,
+        uv=uv.detach().numpy(), depth=depth.detach().numpy(), g_uv=g_uv.numpy(), g_d=g_d.numpy(),
+        dxyz_uv=dxyz_uv.numpy(), dxyz_d=dxyz_d.numpy(),
+        cov3d=cov3d.numpy(), conic=conic.detach().numpy(), radius=radius.numpy().astype(np.int32),
+        tiles=tiles.numpy().astype(np.int32), g_conic=g_c.numpy(), dcov3d=dcov.numpy(), **sh_out)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "N", N, "visible", int(visible.sum()), "radius>0", int((radius > 0).sum()),
+          "M", int(tiles.sum()))
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    ortho_mod, sh_mod = _load_reference_twins()
+    make_case(ortho_mod, sh_mod, "ortho_64_32x32", 64, 32, 32, 11)
+    make_case(ortho_mod, sh_mod, "ortho_1k_64x48", 1000, 64, 48, 12)          # H not a multiple of 16
+    th = 0.3
+    E = np.eye(4, dtype=np.float32)
+    E[:3, :3] = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], np.float32) @ \
+        np.array([[1, 0, 0], [0, np.cos(0.2), -np.sin(0.2)], [0, np.sin(0.2), np.cos(0.2)]], np.float32)
+    E[:3, 3] = np.array([0.05, -0.1, 0.3], np.float32)
+    make_case(ortho_mod, sh_mod, "ortho_1k5_100x60_rot", 1500, 100, 60, 13, extr=E)  # rotated camera, ragged W and H
+
+
+if __name__ == "__main__":
+    main()
