@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""bench.py -- rendered frames/s, forward+backward, 300k dynamic Gaussians @ 854x480 (BASELINE.json
+configs[1]) through the dptr.gs operator surface on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" is one gradient step of the frame-sharded data-parallel renderer: every rank renders
+`--frames` frames of the clip forward+backward (SH colour -> ortho projection -> cov3d -> EWA ->
+tile sort -> alpha blending, and the whole backward chain), accumulates the Gaussian gradients
+in one flat bucket, then ONE all-reduce of that bucket (skipped at N=1).  Weak scaling: frames per
+rank fixed, so N ranks render N*frames frames per step (N=8, frames=25 -> the 200-frame
+configs[2]).  value = frames rendered by all ranks / wall time (max over ranks).
+
+Inputs are synthetic (SURVEY.md 8d generator) and resident in HBM before the timed region.
+The CPU oracle is only used for the `cpu_baseline` leg (rank 0, N=1, one bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import dptr.gs as gs  # noqa: E402
+import splatter_a_video_amd._lib as L  # noqa: E402
+from splatter_a_video_amd.synth import make_scene  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=25, help="frames per rank per gradient step")
+    ap.add_argument("--gaussians", type=int, default=300000)
+    ap.add_argument("--width", type=int, default=854)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--clip", type=int, default=50, help="frames in the clip (per 8 ranks: 200)")
+    ap.add_argument("--channels", type=int, default=0, help="extra feature channels (configs[4]: 32 -> no SH)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+class FrameRenderer:
+    """Frame-sharded DP unit: parameters replicated, gradients of all local frames accumulate into
+    one flat bucket (views), one all-reduce per step."""
+
+    def __init__(self, sc, device, C_extra=0):
+        self.sc = sc
+        self.dev = device
+        N = sc.N
+        self.W, self.H = sc.W, sc.H
+        shapes = [("xyz", (N, 3)), ("scale", (N, 3)), ("rotate", (N, 4)), ("opacity", (N, 1))]
+        self.use_sh = C_extra == 0
+        shapes.append(("shs", (N, 16, 3)) if self.use_sh else ("feature", (N, C_extra)))
+        total = sum(int(np.prod(s)) for _, s in shapes)
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.p = {}
+        src = dict(xyz=sc.xyz, scale=sc.scale, rotate=sc.rotate, opacity=sc.opacity, shs=sc.shs, feature=sc.feature)
+        o = 0
+        for name, shp in shapes:
+            n = int(np.prod(shp))
+            v = self.flat_param[o:o + n].view(shp)
+            v.copy_(torch.as_tensor(src[name], device=device))
+            v.requires_grad_(True)
+            v.grad = self.flat_grad[o:o + n].view(shp)
+            self.p[name] = v
+            o += n
+        self.extr = torch.tensor(sc.extr, device=device)
+        self.phase = torch.tensor(sc.phase, device=device)
+        self.dirs = torch.zeros(N, 3, device=device)
+        self.dirs[:, 2] = 1.0
+        self.C = 3 if self.use_sh else C_extra
+        g = torch.Generator(device="cpu").manual_seed(4321)
+        self.dL_dout = torch.randn(self.C, self.H, self.W, generator=g).to(device)
+        self.last = {}
+
+    def offsets(self, f):
+        d = 0.05 * torch.sin(2.0 * np.pi * (f / float(self.sc.F)) + self.phase)
+        off = torch.zeros(self.sc.N, 3, device=self.dev)
+        off[:, 0] = d
+        off[:, 1] = d
+        return off
+
+    def frame(self, off):
+        p = self.p
+        W, H = self.W, self.H
+        pos = p["xyz"] + off
+        feat = gs.compute_sh(p["shs"], 3, self.dirs) if self.use_sh else p["feature"]
+        uv, depth = gs.project_point_ortho(pos, self.extr, W, H, nearest=0.01)
+        visible = depth != 0
+        cov3d = gs.compute_cov3d(p["scale"], p["rotate"], visible)
+        conic, radius, tiles = gs.ewa_project_ortho(pos, cov3d, self.extr, uv, W, H, visible)
+        idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        img = gs.alpha_blending(uv, conic, p["opacity"], feat, idx, tr, self.sc.bg, W, H)
+        img.backward(self.dL_dout)
+        self.last = dict(M=idx.numel(), T=tr.shape[0])
+        return img
+
+    def step(self, offs, world):
+        self.flat_grad.zero_()
+        for off in offs:
+            self.frame(off)
+        if world > 1:
+            dist.all_reduce(self.flat_grad)
+
+
+def kernel_bytes(name, N, M, HW, C, T, use_sh):
+    """Algorithmic HBM bytes of one launch (SURVEY.md 8d bookkeeping, per kernel)."""
+    F_in = 192 if use_sh else 0
+    table = {
+        "sh_fwd": N * (F_in + 12 + 1 + 12 + 3),
+        "sh_bwd": N * (F_in + 12 + 1 + 3 + 12 + F_in + 12),
+        "project_point_fwd": N * (12 + 8 + 4),
+        "project_point_bwd": N * (4 + 8 + 4 + 12 + 12),
+        "cov3d_fwd": N * (12 + 16 + 1 + 24),
+        "cov3d_bwd": N * (12 + 16 + 1 + 24 + 12 + 16),
+        "ewa_fwd": N * (12 + 24 + 8 + 1 + 12 + 4 + 4),
+        "ewa_bwd": N * (12 + 24 + 4 + 12 + 24),
+        "bin_count": N * 12,
+        "bin_colscan": 0,
+        "bin_tilescan": T * 12,
+        "bin_scatter": N * 16 + M * 8,
+        "tile_sort": M * (8 + 4),
+        "blend_fwd": M * (28 + 4 * C) + HW * (4 * C + 8),
+        "blend_bwd": M * (28 + 4 * C) + M * (32 + 4 * C) + HW * (4 * C + 8),
+    }
+    return table.get(name, 0)
+
+
+def cpu_baseline(sc, C_extra):
+    """One frame forward+backward of the same workload with the C oracle on the host cores."""
+    import oracle
+    threads = os.cpu_count() or 1
+    if not oracle.has_openmp():
+        threads = 1
+    oracle.set_threads(threads)
+    xyz = sc.positions(0)
+    feat = sc.feature if C_extra else None
+    shs = None if C_extra else sc.shs
+    C = C_extra if C_extra else 3
+    g = np.random.default_rng(4321).normal(size=(C, sc.H, sc.W)).astype(np.float32)
+    t0 = time.perf_counter()
+    (out, fT, nc), saved = oracle.render_forward(xyz, sc.scale, sc.rotate, sc.opacity, feat, sc.intr, sc.extr, sc.W, sc.H,
+                                                 sc.bg, ortho=True, shs=shs)
+    oracle.render_backward(xyz, sc.scale, sc.rotate, sc.opacity, sc.intr, sc.extr, sc.W, sc.H, sc.bg, saved, g,
+                           ortho=True, shs=shs)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 frame fwd+bwd of the same workload ({sc.N} Gaussians, {sc.W}x{sc.H}, M={saved['idx_sorted'].size}), "
+                      f"C oracle with OpenMP over tiles, {dt:.2f} s wall"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    clip = max(a.clip, 25 * world)
+    sc = make_scene(a.gaussians, a.width, a.height, F=clip, C=a.channels, seed=1234)
+    R = FrameRenderer(sc, dev, a.channels)
+    # rank r renders frames {f : f mod world == r} of the step's frame batch
+    offs = [R.offsets(((i * world + rank) % clip)) for i in range(a.frames)]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        R.step(offs, world)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        R.step(offs, world)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    frames_total = a.frames * a.steps * world
+    fps = frames_total / dt
+    M, T = R.last["M"], R.last["T"]
+    HW = a.width * a.height
+
+    roofline = None
+    kernels = {}
+    fwd_ms = bwd_ms = None
+    if rank == 0 and not a.no_kernel_timing:
+        # same step again with per-kernel HIP events recorded on the launch stream
+        L.profile_reset()
+        L.profile_enable(True)
+        R.step(offs, 1)
+        torch.cuda.synchronize()
+        L.profile_enable(False)
+        names = ["sh_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
+                 "bin_scatter", "tile_sort", "blend_fwd", "blend_bwd", "ewa_bwd", "project_point_bwd", "cov3d_bwd", "sh_bwd"]
+        for n in names:
+            ms, cnt = L.profile_read(n)
+            if cnt:
+                avg = ms / cnt
+                b = kernel_bytes(n, a.gaussians, M, HW, R.C, T, R.use_sh)
+                kernels[n] = {"avg_us": round(avg * 1e3, 2), "launches": cnt, "alg_MB": round(b / 1e6, 2),
+                              "GBps": round(b / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
+            ach = kernels[dom]["GBps"]
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "avg_us": kernels[dom]["avg_us"], "alg_bytes_per_launch": int(kernel_bytes(dom, a.gaussians, M, HW, R.C, T, R.use_sh))}
+            fwd = [k for k in kernels if not k.endswith("_bwd")]
+            fwd_ms = sum(kernels[k]["avg_us"] for k in fwd) / 1e3
+            bwd_ms = sum(kernels[k]["avg_us"] for k in kernels if k.endswith("_bwd")) / 1e3
+        L.profile_reset()
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(sc, a.channels)
+
+    if rank == 0:
+        line = {
+            "metric": "rendered frames/sec fwd+bwd @480p, 300k Gaussians",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.gaussians} dynamic Gaussians, {a.frames} frames/rank/step of a {clip}-frame "
+                                   f"{a.width}x{a.height} clip, fwd+bwd, ortho camera, "
+                                   + ("SH deg 3 -> RGB" if R.use_sh else f"{a.channels} feature channels"),
+                       "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
+                       "tile_pairs_M": M, "channels": R.C, "parallelism": f"frame-sharded dp{world}",
+                       "grad_bucket_MB": round(R.flat_grad.numel() * 4 / 1e6, 1)},
+            "ms_per_frame": round(dt / (a.frames * a.steps) * 1e3, 4),
+            "gpu_kernel_ms_per_frame": {"forward": None if fwd_ms is None else round(fwd_ms, 4),
+                                        "backward": None if bwd_ms is None else round(bwd_ms, 4)},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

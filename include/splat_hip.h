@@ -1,0 +1,126 @@
+/*
+ * splat_hip.h -- C ABI of libsplat_hip.so, the MI355X (gfx950) native layer behind the
+ * `dptr.gs` operator surface.
+ *
+ * It replaces the reference's pybind module `dptr.gs._C`
+ * (reference: src/submodules/dptr/dptr/gs/src/ext.cpp:14-33, 18 functions on torch::Tensor).
+ * Differences by design:
+ *   - plain C: raw DEVICE pointers + int sizes + scalars + a hipStream_t; no torch / pybind types;
+ *   - the CALLER owns every buffer (zero-filled where marked "zero-init": culled points keep 0,
+ *     empty tiles keep (0,0), gradients accumulate), the library allocates nothing persistent;
+ *   - every launch goes to the caller's stream (the reference uses the legacy default stream);
+ *   - returns 0 or a negative SPLAT_E_* code; splat_last_error() gives the thread-local message.
+ *
+ * Layout conventions: row-major float32 / int32 / uint8(bool); xyz[P,3], uv[P,2], depth[P],
+ * conic[P,3], cov3d[P,6], scales[P,3], uquats[P,4] (r,x,y,z), shs flat with stride (deg+1)^2
+ * triplets per point, feature[P,C] (row-major; the reference transposes to [C,P] on the host),
+ * out[C,H,W], final_T[H,W], ncontrib[H,W], gs_idx[H,W,K], tile_range[T,2] with
+ * T = ceil(W/16)*ceil(H/16); intr = [fx,fy,cx,cy]; extr = first 12 floats of a row-major [R|T].
+ * `ortho` != 0 selects the orthographic twins of
+ * src/pointrix/renderer/dptr_ortho_enhanced.py:18-111,:145-202 instead of the perspective CUDA
+ * semantics.
+ */
+#ifndef SPLAT_HIP_H
+#define SPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *splat_stream_t; /* hipStream_t */
+
+#define SPLAT_OK 0
+#define SPLAT_E_ARG (-1)      /* bad argument (null pointer, negative size, unsupported value) */
+#define SPLAT_E_LAUNCH (-2)   /* HIP launch / runtime error */
+#define SPLAT_E_CAPACITY (-3) /* caller-provided capacity too small */
+
+const char *splat_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int splat_abi_version(void);
+
+/* ---- project_point : replaces projectPointsForward/Backward (src/project_point.cu:147-227) ---- */
+/* uv, depth zero-init. */
+int splat_project_point_forward(int P, const float *xyz, const float *intr, const float *extr, int W, int H,
+                                float nearest, float extent, int ortho, float *uv, float *depth,
+                                splat_stream_t stream);
+/* dL_dxyz zero-init; dL_dintr[4] / dL_dextr[12] zero-init or NULL (only when requires_grad). */
+int splat_project_point_backward(int P, const float *xyz, const float *intr, const float *extr, int W, int H,
+                                 int ortho, const float *depth, const float *dL_duv, const float *dL_ddepth,
+                                 float *dL_dxyz, float *dL_dintr, float *dL_dextr, splat_stream_t stream);
+
+/* ---- compute_cov3d : replaces computeCov3DForward/Backward (src/compute_cov3d.cu:149-199) ---- */
+int splat_compute_cov3d_forward(int P, const float *scales, const float *uquats, const uint8_t *visible,
+                                float *cov3d /*zero-init*/, splat_stream_t stream);
+int splat_compute_cov3d_backward(int P, const float *scales, const float *uquats, const uint8_t *visible,
+                                 const float *dL_dcov3d, float *dL_dscales /*zero-init*/,
+                                 float *dL_duquats /*zero-init*/, splat_stream_t stream);
+
+/* ---- ewa_project : replaces EWAProjectForward/Backward (src/ewa_project.cu:254-344) ---- */
+int splat_ewa_project_forward(int P, const float *xyz, const float *cov3d, const float *intr, const float *extr,
+                              const float *uv, int W, int H, const uint8_t *visible, int ortho,
+                              float *conic, int32_t *radius, int32_t *tiles /*all zero-init*/,
+                              splat_stream_t stream);
+int splat_ewa_project_backward(int P, const float *xyz, const float *cov3d, const float *intr, const float *extr,
+                               int W, int H, int ortho, const int32_t *radius, const float *dL_dconic,
+                               float *dL_dxyz, float *dL_dcov3d /*zero-init*/,
+                               float *dL_dintr /*[4] or NULL*/, float *dL_dextr /*[12] or NULL*/,
+                               splat_stream_t stream);
+
+/* ---- compute_sh / compute_sh_free : replaces computeSH(Free)Forward/Backward
+ *      (src/compute_sh.cu:235-295, src/compute_sh_free.cu) ---- */
+int splat_compute_sh_forward(int P, const float *shs, int degree, const float *dirs, const uint8_t *visible,
+                             int free_variant, float *colors /*zero-init*/,
+                             uint8_t *clamped /*[P,3], ones-init, NULL when free*/, splat_stream_t stream);
+int splat_compute_sh_backward(int P, const float *shs, int degree, const float *dirs, const uint8_t *visible,
+                              const uint8_t *clamped /*NULL when free*/, int free_variant,
+                              const float *dL_dcolors, float *dL_dshs /*zero-init*/, float *dL_ddirs /*zero-init*/,
+                              splat_stream_t stream);
+
+/* ---- sort_gaussian : replaces computeGaussianKey + torch.sort + gather + computeTileGaussianRange
+ *      (dptr/gs/sort_gaussian.py:42-52, src/sort_gaussian.cu:72-146) by a two-level sort:
+ *      counting scatter by tile, then a per-tile bitonic sort on (depth bits, gaussian id).
+ *      Result order == stable sort of the reference's 64-bit keys (ties -> ascending id).
+ *   step 1  splat_bin_count : tile_range[T,2] and *M_out (device int32) from uv / radius;
+ *   step 2  splat_bin_sort  : idx_sorted[0..M) (needs capacity >= M, else SPLAT_E_CAPACITY is
+ *           reported through the device flag *overflow_out (no host sync inside)).
+ *   scratch: splat_bin_scratch_bytes(P, W, H) bytes, shared by both steps (must stay untouched in
+ *   between); keys: capacity * 8 bytes. ---- */
+size_t splat_bin_scratch_bytes(int P, int W, int H);
+int splat_bin_count(int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
+                    int32_t *tile_range, int32_t *M_out, splat_stream_t stream);
+int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
+                   void *scratch, const int32_t *tile_range, int64_t capacity, uint64_t *keys,
+                   int32_t *idx_sorted, int32_t *overflow_out, splat_stream_t stream);
+
+/* ---- alpha blending : replaces alphaBlendingForward/Backward, ...Enhanced, ...WithBias
+ *      (src/alpha_blending.cu:251-582, src/alpha_blending_enhanced.cu:275-627,
+ *       src/alpha_blending_with_bias.cu:266-621).
+ *      opacity_bias NULL -> plain; gs_idx NULL / K<=0 -> not enhanced. Channels are processed in
+ *      chunks of <=32 exactly as the reference does (matters for dL_dabs_uv only). ---- */
+int splat_alpha_blending_forward(int P, int C, const float *uv, const float *conic, const float *opacity,
+                                 const float *feature, const float *opacity_bias, const int32_t *idx_sorted,
+                                 const int32_t *tile_range, float bg, int W, int H, int K, int enable_truncation,
+                                 float *out, float *final_T, int32_t *ncontrib,
+                                 int32_t *gs_idx /*[H,W,K] filled with -1 by caller, or NULL*/,
+                                 splat_stream_t stream);
+/* all gradient outputs zero-init; dL_dfeature is [P,C]; dL_dopacity_bias NULL unless bias given. */
+int splat_alpha_blending_backward(int P, int C, const float *uv, const float *conic, const float *opacity,
+                                  const float *feature, const float *opacity_bias, const int32_t *idx_sorted,
+                                  const int32_t *tile_range, float bg, int W, int H, const float *final_T,
+                                  const int32_t *ncontrib, const float *dL_dout, float *dL_duv, float *dL_dabs_uv,
+                                  float *dL_dconic, float *dL_dopacity, float *dL_dfeature,
+                                  float *dL_dopacity_bias, splat_stream_t stream);
+
+/* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */
+void splat_profile_enable(int on);
+void splat_profile_reset(void);
+/* sums elapsed ms / launches of every kernel whose name starts with `prefix` (blocks on the events). */
+int splat_profile_read(const char *prefix, double *total_ms, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLAT_HIP_H */

@@ -1,0 +1,104 @@
+"""ctypes binding of libsplat_hip.so (C ABI: include/splat_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a tensor is not a contiguous
+float32/int32 CUDA tensor the call raises.  (The CPU oracle lives in ``oracle/`` and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsplat_hip.so")
+_lib: Optional[ctypes.CDLL] = None
+
+ABI_VERSION = 1
+
+# every symbol include/splat_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "splat_last_error", "splat_abi_version",
+    "splat_project_point_forward", "splat_project_point_backward",
+    "splat_compute_cov3d_forward", "splat_compute_cov3d_backward",
+    "splat_ewa_project_forward", "splat_ewa_project_backward",
+    "splat_compute_sh_forward", "splat_compute_sh_backward",
+    "splat_bin_scratch_bytes", "splat_bin_count", "splat_bin_sort",
+    "splat_alpha_blending_forward", "splat_alpha_blending_backward",
+    "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
+]
+
+
+class SplatError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SplatError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C splatter_a_video_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.splat_last_error.restype = ctypes.c_char_p
+        L.splat_abi_version.restype = ctypes.c_int
+        L.splat_bin_scratch_bytes.restype = ctypes.c_size_t
+        L.splat_bin_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.splat_profile_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+        if L.splat_abi_version() != ABI_VERSION:
+            raise SplatError("libsplat_hip.so ABI version mismatch; rebuild it")
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise SplatError(f"libsplat_hip error {rc}: {lib().splat_last_error().decode()}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def cf(x: float) -> ctypes.c_float:
+    return ctypes.c_float(float(x))
+
+
+def ci(x: int) -> ctypes.c_int:
+    return ctypes.c_int(int(x))
+
+
+def need(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    """Device / dtype gate + contiguity (the reference calls .contiguous() on every input too)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA (ROCm) tensor")
+    if t.dtype != dtype:
+        if dtype == torch.uint8 and t.dtype == torch.bool:
+            t = t.contiguous().view(torch.uint8)
+        else:
+            raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def profile_enable(on: bool) -> None:
+    lib().splat_profile_enable(ctypes.c_int(1 if on else 0))
+
+
+def profile_reset() -> None:
+    lib().splat_profile_reset()
+
+
+def profile_read(prefix: str = ""):
+    ms = ctypes.c_double(0.0)
+    n = ctypes.c_int(0)
+    lib().splat_profile_read(prefix.encode(), ctypes.byref(ms), ctypes.byref(n))
+    return ms.value, n.value

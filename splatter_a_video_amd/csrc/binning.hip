@@ -1,0 +1,315 @@
+// Tile binning + per-tile depth sort (the reference's sort_gaussian op).
+//
+// The reference emits one 64-bit key (tile << 32 | depth bits) per (Gaussian, tile) pair and runs
+// a global 64-bit radix sort (torch.sort) over all M pairs (dptr/gs/sort_gaussian.py:42-52,
+// src/sort_gaussian.cu:16-70).  Here the tile id never enters a sort key:
+//
+//   K1 bin_count    each workgroup owns a contiguous chunk of Gaussians and histograms the tiles
+//                   they touch in LDS (ds_add, no global atomics), then stores its row of the
+//                   [NB, T] count matrix;
+//   K2a bin_colscan one wave per tile: exclusive scan of that tile's column over the NB chunks
+//                   (DPP prefix), column total -> tile_count[T];
+//   K2b bin_tilescan single workgroup: exclusive scan of tile_count -> tile_range[T,2], M;
+//   K3 bin_scatter  same chunking as K1; LDS counters start at the chunk's base, ds_add_rtn
+//                   hands out the slot; writes key = (depth bits << 32 | gaussian id);
+//   K4 tile_sort    one workgroup per tile: bitonic sort of the tile's keys in LDS (all
+//                   comparators ascending -> no power-of-two padding needed), writes ids.
+//
+// Since keys inside a tile are unique (id in the low word) the result is deterministic and equals
+// a STABLE sort of the reference keys (ties: ascending Gaussian id).  No host synchronisation.
+#include "common.h"
+
+#define BIN_BLOCK 256
+#define BIN_MAX_NB 128          // rows of the count matrix
+#define BIN_LDS_TILES 12288     // <= 48 KB of LDS counters; larger tile grids use global atomics
+#define SORT_BLOCK 256
+#define SORT_LDS_KEYS 4096      // 32 KB of LDS per sort workgroup
+
+struct BinPlan {
+    int T, gx, gy;
+    int NB;        // number of Gaussian chunks (= workgroups of K1/K3)
+    int chunk;     // Gaussians per chunk
+    bool lds;      // LDS histogram path
+    size_t off_matrix, off_tilecount, off_total;  // byte offsets inside scratch
+    size_t bytes;
+};
+
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+static BinPlan make_plan(int P, int W, int H) {
+    BinPlan p;
+    p.gx = (W + TILE - 1) / TILE;
+    p.gy = (H + TILE - 1) / TILE;
+    p.T = p.gx * p.gy;
+    p.lds = p.T <= BIN_LDS_TILES;
+    int nb = (P + 2047) / 2048;
+    if (nb < 1) nb = 1;
+    if (nb > BIN_MAX_NB) nb = BIN_MAX_NB;
+    if (!p.lds) nb = 1;  // global-atomic path keeps a single row
+    p.NB = nb;
+    p.chunk = (P + nb - 1) / nb;
+    if (p.chunk < 1) p.chunk = 1;
+    size_t o = 0;
+    p.off_matrix = o; o += (size_t)(p.NB < 2 ? 2 : p.NB) * p.T * sizeof(int);  // global path: [counts, fill]
+    o = (o + 255) & ~(size_t)255;
+    p.off_tilecount = o; o += (size_t)p.T * sizeof(int);
+    o = (o + 255) & ~(size_t)255;
+    p.off_total = o; o += 256;
+    p.bytes = o;
+    return p;
+}
+
+// ------------------------------------------------------------------ K1
+template <bool LDS>
+__global__ void __launch_bounds__(BIN_BLOCK)
+bin_count_kernel(int P, const float2 *__restrict__ uv, const int *__restrict__ radius, int gx, int gy, int T,
+                 int chunk, int *__restrict__ matrix) {
+    extern __shared__ __attribute__((aligned(16))) int cnt[];
+    const int wg = blockIdx.x;
+    if (LDS) {
+        for (int t = threadIdx.x; t < T; t += BIN_BLOCK) cnt[t] = 0;
+        __syncthreads();
+    }
+    const int beg = wg * chunk, end = imin_(P, beg + chunk);
+    for (int i = beg + threadIdx.x; i < end; i += BIN_BLOCK) {
+        const int r = radius[i];
+        if (r <= 0) continue;
+        const float2 q = uv[i];
+        int x0, y0, x1, y1;
+        tile_rect(q.x, q.y, r, gx, gy, x0, y0, x1, y1);
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) {
+                if (LDS) atomicAdd(&cnt[ty * gx + tx], 1);
+                else atomicAdd(&matrix[ty * gx + tx], 1);
+            }
+    }
+    if (LDS) {
+        __syncthreads();
+        int *row = matrix + (size_t)wg * T;
+        for (int t = threadIdx.x; t < T; t += BIN_BLOCK) row[t] = cnt[t];
+    }
+}
+
+// ------------------------------------------------------------------ K2a: one wave per tile column
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(v, o);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+bin_colscan_kernel(int T, int NB, int *__restrict__ matrix, int *__restrict__ tile_count) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    int carry = 0;
+    for (int base = 0; base < NB; base += 64) {
+        const int row = base + lane;
+        const int v = row < NB ? matrix[(size_t)row * T + t] : 0;
+        const int inc = wave_incl_scan_i(v, lane);
+        if (row < NB) matrix[(size_t)row * T + t] = carry + inc - v;  // exclusive
+        carry += __shfl(inc, 63);
+    }
+    if (lane == 0) tile_count[t] = carry;
+}
+
+// ------------------------------------------------------------------ K2b: scan over tiles (single workgroup)
+__global__ void __launch_bounds__(1024)
+bin_tilescan_kernel(int T, const int *__restrict__ tile_count, int *__restrict__ tile_range, int *__restrict__ M_out,
+                    int *__restrict__ total_scratch) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 1024) {
+        const int t = base + threadIdx.x;
+        const int v = t < T ? tile_count[t] : 0;
+        const int inc = wave_incl_scan_i(v, lane);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        const int carry = carry_s;
+        const int start = carry + woff + inc - v;
+        if (t < T) {
+            // reference: tiles without pairs keep (0,0) (src/sort_gaussian.cu:44-70, zero-init)
+            tile_range[2 * t] = v > 0 ? start : 0;
+            tile_range[2 * t + 1] = v > 0 ? start + v : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (M_out) *M_out = carry_s;
+        *total_scratch = carry_s;
+    }
+}
+
+// ------------------------------------------------------------------ K3
+template <bool LDS>
+__global__ void __launch_bounds__(BIN_BLOCK)
+bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict__ depth,
+                   const int *__restrict__ radius, int gx, int gy, int T, int chunk, int *__restrict__ matrix,
+                   const int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
+                   int *__restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) int cnt[];
+    const int wg = blockIdx.x;
+    if (LDS) {
+        const int *row = matrix + (size_t)wg * T;
+        for (int t = threadIdx.x; t < T; t += BIN_BLOCK) cnt[t] = tile_range[2 * t] + row[t];
+        __syncthreads();
+    }
+    const int beg = wg * chunk, end = imin_(P, beg + chunk);
+    for (int i = beg + threadIdx.x; i < end; i += BIN_BLOCK) {
+        const int r = radius[i];
+        if (r <= 0) continue;
+        const float2 q = uv[i];
+        int x0, y0, x1, y1;
+        tile_rect(q.x, q.y, r, gx, gy, x0, y0, x1, y1);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(depth[i]) << 32) | (unsigned)i;
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) {
+                const int t = ty * gx + tx;
+                int slot;
+                if (LDS) slot = atomicAdd(&cnt[t], 1);
+                else slot = tile_range[2 * t] + atomicAdd(&matrix[T + t], 1);  // second row = fill counters
+                if ((long long)slot < capacity) keys[slot] = key;
+                else *overflow = 1;
+            }
+    }
+}
+
+// ------------------------------------------------------------------ K4: per-tile bitonic sort
+// All comparators ascending ("flip" first step of every merge), so indices >= n behave as +inf
+// without being stored: works for any n.  MEM = LDS copy (n <= SORT_LDS_KEYS) or the global
+// buffer itself (rare oversized tiles; a workgroup's global stores are visible to itself after
+// __syncthreads()).
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_any_n(KeyPtr a, int n) {
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    const int half = np2 >> 1;
+    for (int k = 2; k <= np2; k <<= 1) {
+        const int hk = k >> 1;
+        for (int t = threadIdx.x; t < half; t += SORT_BLOCK) {  // flip step: i <-> mirror in block of k
+            const int blk = t / hk, off = t - blk * hk;
+            const int lo = blk * k + off, hi = blk * k + k - 1 - off;
+            if (hi < n) {
+                const unsigned long long x = a[lo], y = a[hi];
+                if (x > y) { a[lo] = y; a[hi] = x; }
+            }
+        }
+        __syncthreads();
+        for (int j = hk >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < half; t += SORT_BLOCK) {
+                const int blk = t / j, off = t - blk * j;
+                const int lo = blk * 2 * j + off, hi = lo + j;
+                if (hi < n) {
+                    const unsigned long long x = a[lo], y = a[hi];
+                    if (x > y) { a[lo] = y; a[hi] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK)
+tile_sort_kernel(const int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
+                 int *__restrict__ idx_sorted) {
+    __shared__ __attribute__((aligned(16))) unsigned long long sk[SORT_LDS_KEYS];
+    const int t = blockIdx.x;
+    const long long r0 = tile_range[2 * t];
+    long long r1 = tile_range[2 * t + 1];
+    if (r1 > capacity) r1 = capacity;  // overflow already flagged by K3
+    const int n = (int)(r1 - r0);
+    if (n <= 0) return;
+    unsigned long long *g = keys + r0;
+    if (n <= SORT_LDS_KEYS) {
+        for (int i = threadIdx.x; i < n; i += SORT_BLOCK) sk[i] = g[i];
+        __syncthreads();
+        if (n > 1) bitonic_any_n(sk, n);
+        for (int i = threadIdx.x; i < n; i += SORT_BLOCK) idx_sorted[r0 + i] = (int)(unsigned)(sk[i] & 0xffffffffull);
+    } else {
+        __syncthreads();
+        bitonic_any_n((volatile unsigned long long *)g, n);
+        for (int i = threadIdx.x; i < n; i += SORT_BLOCK) idx_sorted[r0 + i] = (int)(unsigned)(g[i] & 0xffffffffull);
+    }
+}
+
+// ================================================================== C ABI
+extern "C" size_t splat_bin_scratch_bytes(int P, int W, int H) {
+    if (P < 0 || W <= 0 || H <= 0) return 0;
+    return make_plan(P, W, H).bytes;
+}
+
+extern "C" int splat_bin_count(int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
+                               int32_t *tile_range, int32_t *M_out, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0, "bad sizes");
+    SPLAT_CHECK_ARG(scratch && tile_range, "null pointer");
+    SPLAT_CHECK_ARG(P == 0 || (uv && radius), "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const BinPlan p = make_plan(P, W, H);
+    char *base = (char *)scratch;
+    int *matrix = (int *)(base + p.off_matrix);
+    int *tile_count = (int *)(base + p.off_tilecount);
+    int *total = (int *)(base + p.off_total);
+    if (p.lds) {
+        SPLAT_LAUNCH("bin_count", bin_count_kernel<true>, dim3(p.NB), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
+                     P, (const float2 *)uv, radius, p.gx, p.gy, p.T, p.chunk, matrix);
+    } else {
+        // rows: [0] counts, [1] fill counters of K3
+        SPLAT_CHECK_HIP(hipMemsetAsync(matrix, 0, (size_t)p.T * sizeof(int), s));
+        const int nblk = imax(1, imin((P + BIN_BLOCK - 1) / BIN_BLOCK, 2048));
+        const int chunk = (P + nblk - 1) / nblk;
+        SPLAT_LAUNCH("bin_count", bin_count_kernel<false>, dim3(nblk), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
+                     radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix);
+    }
+    SPLAT_POST_LAUNCH();
+    if (p.lds) {
+        SPLAT_LAUNCH("bin_colscan", bin_colscan_kernel, dim3((p.T + 3) / 4), dim3(256), 0, s, p.T, p.NB, matrix, tile_count);
+        SPLAT_POST_LAUNCH();
+    } else {
+        SPLAT_CHECK_HIP(hipMemcpyAsync(tile_count, matrix, (size_t)p.T * sizeof(int), hipMemcpyDeviceToDevice, s));
+    }
+    SPLAT_LAUNCH("bin_tilescan", bin_tilescan_kernel, dim3(1), dim3(1024), 0, s, p.T, tile_count, tile_range, M_out, total);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
+                              void *scratch, const int32_t *tile_range, int64_t capacity, uint64_t *keys,
+                              int32_t *idx_sorted, int32_t *overflow_out, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0 && capacity >= 0, "bad sizes");
+    SPLAT_CHECK_ARG(scratch && tile_range && overflow_out, "null pointer");
+    if (P == 0 || capacity == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(uv && depth && radius && keys && idx_sorted, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const BinPlan p = make_plan(P, W, H);
+    char *base = (char *)scratch;
+    int *matrix = (int *)(base + p.off_matrix);
+    if (p.lds) {
+        SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<true>, dim3(p.NB), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
+                     P, (const float2 *)uv, depth, radius, p.gx, p.gy, p.T, p.chunk, matrix, tile_range,
+                     (long long)capacity, (unsigned long long *)keys, overflow_out);
+    } else {
+        // fill counters live in tile_count's neighbour: reuse matrix row "1" = matrix + T (allocated: NB=1 -> need 2 rows)
+        SPLAT_CHECK_HIP(hipMemsetAsync(matrix + p.T, 0, (size_t)p.T * sizeof(int), s));
+        const int nblk = imax(1, imin((P + BIN_BLOCK - 1) / BIN_BLOCK, 2048));
+        const int chunk = (P + nblk - 1) / nblk;
+        SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<false>, dim3(nblk), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
+                     depth, radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, tile_range, (long long)capacity,
+                     (unsigned long long *)keys, overflow_out);
+    }
+    SPLAT_POST_LAUNCH();
+    SPLAT_LAUNCH("tile_sort", tile_sort_kernel, dim3(p.T), dim3(SORT_BLOCK), 0, s, tile_range, (long long)capacity,
+                 (unsigned long long *)keys, idx_sorted);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}

@@ -1,0 +1,107 @@
+// Internal helpers shared by the HIP translation units of libsplat_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/splat_hip.h"
+
+#define TILE 16
+#define TILE_PIX 256
+#define WAVE 64
+
+// ---------------------------------------------------------------- errors
+void splat_set_error(const char *fmt, ...);
+
+#define SPLAT_CHECK_ARG(cond, msg)                     \
+    do {                                               \
+        if (!(cond)) {                                 \
+            splat_set_error("%s: %s", __func__, msg);  \
+            return SPLAT_E_ARG;                        \
+        }                                              \
+    } while (0)
+
+#define SPLAT_CHECK_HIP(expr)                                                          \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            splat_set_error("%s: %s -> %s", __func__, #expr, hipGetErrorString(e_));   \
+            return SPLAT_E_LAUNCH;                                                     \
+        }                                                                              \
+    } while (0)
+
+// ---------------------------------------------------------------- profiled launches
+// When splat_profile_enable(1) was called, every kernel launch is bracketed by two hipEvents
+// recorded on the launch stream; splat_profile_read() sums them per kernel-name prefix.
+bool splat_profile_on();
+void splat_profile_begin(const char *name, hipStream_t s);
+void splat_profile_end(hipStream_t s);
+
+struct ProfiledLaunch {
+    hipStream_t s;
+    bool on;
+    ProfiledLaunch(const char *name, hipStream_t st) : s(st), on(splat_profile_on()) {
+        if (on) splat_profile_begin(name, s);
+    }
+    ~ProfiledLaunch() {
+        if (on) splat_profile_end(s);
+    }
+};
+
+#define SPLAT_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                        \
+    do {                                                                                   \
+        ProfiledLaunch pl_(name, stream);                                                  \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);               \
+    } while (0)
+
+#define SPLAT_POST_LAUNCH() SPLAT_CHECK_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
+
+// Tile rectangle of a splat: float arithmetic, truncation toward zero, clamp to [0, grid]
+// (reference: include/utils.h:17-37).
+__device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, int &x0, int &y0, int &x1,
+                                          int &y1) {
+    const float fr = (float)r;
+    x0 = imin_(gx, imax_(0, (int)((px - fr) / (float)TILE)));
+    y0 = imin_(gy, imax_(0, (int)((py - fr) / (float)TILE)));
+    x1 = imin_(gx, imax_(0, (int)((((px + fr) + (float)TILE) - 1.0f) / (float)TILE)));
+    y1 = imin_(gy, imax_(0, (int)((((py + fr) + (float)TILE) - 1.0f) / (float)TILE)));
+}
+
+// ---- wave64 reductions with DPP (gfx9 row_shr / row_bcast); result valid in lane 63 ----
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, BOUND));
+}
+
+// Sum over the 64 lanes; the total lands in lane 63 (other lanes hold partials).
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v += dpp_f<0x111, 0xf, 0xf, true>(v);  // row_shr:1
+    v += dpp_f<0x112, 0xf, 0xf, true>(v);  // row_shr:2
+    v += dpp_f<0x114, 0xf, 0xf, true>(v);  // row_shr:4
+    v += dpp_f<0x118, 0xf, 0xf, true>(v);  // row_shr:8  -> lane 15 of every row = row total
+    v += dpp_f<0x142, 0xa, 0xf, true>(v);  // row_bcast:15 into rows 1,3
+    v += dpp_f<0x143, 0xc, 0xf, true>(v);  // row_bcast:31 into rows 2,3 -> lane 63 = total
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum_bcast(float v) {
+    v = wave_sum_to_lane63(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = imax_(v, __shfl_xor(v, o));
+    return v;
+}
+
+// hardware float atomic add, agent scope, no return (global_atomic_add_f32)
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}

@@ -1,0 +1,104 @@
+// Error reporting and the optional per-kernel hipEvent timing of libsplat_hip.so.
+#include <stdarg.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void splat_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *splat_last_error(void) { return g_err; }
+extern "C" int splat_abi_version(void) { return 1; }
+
+namespace {
+struct Pending {
+    std::string name;
+    hipEvent_t a, b;
+};
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Pending> g_pending;
+std::vector<hipEvent_t> g_pool;
+std::map<std::string, std::pair<double, int>> g_acc;
+thread_local Pending g_cur;
+
+hipEvent_t get_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void drain_locked() {
+    for (auto &p : g_pending) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(p.b);
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto &acc = g_acc[p.name];
+            acc.first += ms;
+            acc.second += 1;
+        }
+        g_pool.push_back(p.a);
+        g_pool.push_back(p.b);
+    }
+    g_pending.clear();
+}
+}  // namespace
+
+bool splat_profile_on() { return g_on; }
+
+void splat_profile_begin(const char *name, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_cur.name = name;
+    g_cur.a = get_event();
+    g_cur.b = get_event();
+    (void)hipEventRecord(g_cur.a, s);
+}
+
+void splat_profile_end(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipEventRecord(g_cur.b, s);
+    g_pending.push_back(g_cur);
+}
+
+extern "C" void splat_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+}
+
+extern "C" void splat_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain_locked();
+    g_acc.clear();
+}
+
+extern "C" int splat_profile_read(const char *prefix, double *total_ms, int *launches) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain_locked();
+    double t = 0.0;
+    int n = 0;
+    const size_t L = prefix ? strlen(prefix) : 0;
+    for (auto &kv : g_acc) {
+        if (L == 0 || kv.first.compare(0, L, prefix) == 0) {
+            t += kv.second.first;
+            n += kv.second.second;
+        }
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = n;
+    return SPLAT_OK;
+}

@@ -1,0 +1,168 @@
+"""Tile operators of the ``dptr.gs`` surface: sort_gaussian, alpha_blending,
+alpha_blending_enhanced, alpha_blending_with_bias and the rasterization() convenience chain.
+
+Signatures / defaults / autograd contract follow the reference
+(reference: src/submodules/dptr/dptr/gs/sort_gaussian.py:8-54, alpha_blending.py:7-147,
+alpha_blending_enhanced.py:7-160, alpha_blending_with_bias.py, __init__.py:28-100).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .. import _lib as L
+from .point_ops import compute_cov3d, ewa_project, project_point
+
+
+def _num_tiles(W: int, H: int) -> int:
+    return ((W + 15) // 16) * ((H + 15) // 16)
+
+
+# ------------------------------------------------------------------ sort_gaussian
+def sort_gaussian(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Tensor) -> Tuple[Tensor, Tensor]:
+    """(idx_sorted[M] int32, tile_range[T,2] int32): Gaussian ids ordered by (tile, depth) and each
+    tile's [start, end) slice.  Ties (same tile, bit-equal depth) are ordered by ascending id, i.e.
+    the result of a STABLE sort of the reference's 64-bit keys (the reference's torch.sort is
+    unstable).  ``tiles`` is accepted for signature parity; the per-tile counts are re-derived from
+    uv/radius on the device.  One host sync (to size idx_sorted; the reference needs two)."""
+    uv = L.need(uv, "uv")
+    depth = L.need(depth, "depth")
+    radius = L.need(radius, "radius", torch.int32)
+    if tiles is not None and tiles.shape[0] != uv.shape[0]:
+        raise ValueError("tiles must have P elements")
+    P = uv.shape[0]
+    if depth.numel() != P or radius.numel() != P:
+        raise ValueError("uv, depth, radius must agree on P")
+    dev = uv.device
+    T = _num_tiles(W, H)
+    tile_range = torch.empty(T, 2, dtype=torch.int32, device=dev)
+    if P == 0:
+        return torch.empty(0, dtype=torch.int32, device=dev), tile_range.zero_()
+    lib = L.lib()
+    scratch = torch.empty(lib.splat_bin_scratch_bytes(P, W, H), dtype=torch.uint8, device=dev)
+    m_dev = torch.empty(1, dtype=torch.int32, device=dev)
+    L.check(lib.splat_bin_count(L.ci(P), L.ptr(uv), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
+                                L.ptr(tile_range), L.ptr(m_dev), L.stream()))
+    M = int(m_dev.item())
+    idx_sorted = torch.empty(M, dtype=torch.int32, device=dev)
+    if M > 0:
+        keys = torch.empty(M, dtype=torch.int64, device=dev)
+        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(lib.splat_bin_sort(L.ci(P), L.ptr(uv), L.ptr(depth), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
+                                   L.ptr(tile_range), ctypes.c_int64(M), L.ptr(keys), L.ptr(idx_sorted),
+                                   L.ptr(overflow), L.stream()))
+    return idx_sorted, tile_range
+
+
+# ------------------------------------------------------------------ alpha blending (3 variants, one Function)
+class _AlphaBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, uv, conic, opacity, feature, bias, idx_sorted, tile_range, bg, W, H, ndc, abs_ndc, K, trunc):
+        uv = L.need(uv, "uv")
+        conic = L.need(conic, "conic")
+        opacity = L.need(opacity, "opacity")
+        feature = L.need(feature, "feature")
+        idx_sorted = L.need(idx_sorted, "idx_sorted", torch.int32)
+        tile_range = L.need(tile_range, "tile_range", torch.int32)
+        bias_c = None if bias is None else L.need(bias, "opacity_bias")
+        if feature.dim() != 2:
+            raise ValueError("feature must have shape [P, C]")
+        P, C = feature.shape
+        if C < 1:
+            raise ValueError("feature needs at least one channel")
+        if uv.shape[0] != P or conic.shape[0] != P or opacity.numel() != P:
+            raise ValueError("uv / conic / opacity / feature must agree on P")
+        if tile_range.numel() != 2 * _num_tiles(W, H):
+            raise ValueError("tile_range must have shape [ceil(W/16)*ceil(H/16), 2]")
+        dev = feature.device
+        out = torch.empty(C, H, W, dtype=torch.float32, device=dev)
+        final_T = torch.empty(H, W, dtype=torch.float32, device=dev)
+        ncontrib = torch.empty(H, W, dtype=torch.int32, device=dev)
+        gs_idx = torch.full((H, W, K), -1, dtype=torch.int32, device=dev) if K > 0 else None
+        L.check(L.lib().splat_alpha_blending_forward(
+            L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias_c),
+            L.ptr(idx_sorted), L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ci(K), L.ci(1 if trunc else 0),
+            L.ptr(out), L.ptr(final_T), L.ptr(ncontrib), L.ptr(gs_idx), L.stream()))
+        ctx.meta = (float(bg), int(W), int(H), bias is not None, ndc is not None, abs_ndc is not None)
+        saved = [uv, conic, opacity, feature, idx_sorted, tile_range, final_T, ncontrib]
+        if bias_c is not None:
+            saved.append(bias_c)
+        ctx.save_for_backward(*saved)
+        if K > 0:
+            ctx.mark_non_differentiable(ncontrib, gs_idx)
+            return out, ncontrib, gs_idx
+        return out
+
+    @staticmethod
+    def backward(ctx, dL_dout, *_unused):
+        bg, W, H, has_bias, has_ndc, has_abs = ctx.meta
+        saved = ctx.saved_tensors
+        uv, conic, opacity, feature, idx_sorted, tile_range, final_T, ncontrib = saved[:8]
+        bias = saved[8] if has_bias else None
+        P, C = feature.shape
+        g = L.need(dL_dout, "dL_dout")
+        dev = feature.device
+        duv = torch.zeros(P, 2, dtype=torch.float32, device=dev)
+        dabs = torch.zeros(P, 2, dtype=torch.float32, device=dev)
+        dconic = torch.zeros(P, 3, dtype=torch.float32, device=dev)
+        dop = torch.zeros(opacity.shape, dtype=torch.float32, device=dev)
+        dfeat = torch.zeros(P, C, dtype=torch.float32, device=dev)
+        dbias = torch.zeros(bias.shape, dtype=torch.float32, device=dev) if has_bias else None
+        L.check(L.lib().splat_alpha_blending_backward(
+            L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias), L.ptr(idx_sorted),
+            L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(g), L.ptr(duv),
+            L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(dbias), L.stream()))
+        # gradient taps used by densification (reference: alpha_blending.py:112-120)
+        dndc = dabs_ndc = None
+        if has_ndc or has_abs:
+            half = torch.tensor([0.5 * W, 0.5 * H], dtype=uv.dtype, device=dev)
+            if has_ndc:
+                dndc = duv * half[None, :]
+            if has_abs:
+                dabs_ndc = dabs * half[None, :]
+        return duv, dconic, dop, dfeat, dbias, None, None, None, None, None, dndc, dabs_ndc, None, None
+
+
+def alpha_blending(uv: Tensor, conic: Tensor, opacity: Tensor, feature: Tensor, idx_sorted: Tensor,
+                   title_bins: Tensor, bg: float, W: int, H: int, ndc: Optional[Tensor] = None,
+                   abs_ndc: Optional[Tensor] = None) -> Tensor:
+    """Front-to-back compositing of feature[P,C] -> [C,H,W]."""
+    return _AlphaBlend.apply(uv, conic, opacity, feature, None, idx_sorted, title_bins, bg, W, H, ndc, abs_ndc, 0,
+                             False)
+
+
+def alpha_blending_enhanced(uv: Tensor, conic: Tensor, opacity: Tensor, feature: Tensor, idx_sorted: Tensor,
+                            title_bins: Tensor, bg: float, W: int, H: int, ndc: Optional[Tensor] = None,
+                            abs_ndc: Optional[Tensor] = None, K: int = 10, enable_truncation: bool = False):
+    """alpha_blending that also returns ncontrib[H,W] and the first K contributing ids gs_idx[H,W,K]
+    (-1 padded); with enable_truncation a pixel stops after K contributors."""
+    K = int(K)
+    if K < 1:
+        raise ValueError("K must be >= 1")
+    return _AlphaBlend.apply(uv, conic, opacity, feature, None, idx_sorted, title_bins, bg, W, H, ndc, abs_ndc, K,
+                             bool(enable_truncation))
+
+
+def alpha_blending_with_bias(uv: Tensor, conic: Tensor, opacity: Tensor, feature: Tensor, opacity_bias: Tensor,
+                             idx_sorted: Tensor, title_bins: Tensor, bg: float, W: int, H: int,
+                             ndc: Optional[Tensor] = None, abs_ndc: Optional[Tensor] = None) -> Tensor:
+    """alpha = min(0.99, opacity * G + opacity_bias[P,1])."""
+    if opacity_bias is None:
+        raise ValueError("opacity_bias is required")
+    return _AlphaBlend.apply(uv, conic, opacity, feature, opacity_bias, idx_sorted, title_bins, bg, W, H, ndc,
+                             abs_ndc, 0, False)
+
+
+# ------------------------------------------------------------------ rasterization (5-op chain)
+def rasterization(xyz: Tensor, scale: Tensor, rotate: Tensor, opacity: Tensor, feature: Tensor, intr: Tensor,
+                  extr: Tensor, W: int, H: int, bg: float, ndc: Optional[Tensor] = None) -> Tensor:
+    """project_point -> compute_cov3d -> ewa_project -> sort_gaussian -> alpha_blending."""
+    uv, depth = project_point(xyz, intr, extr, W, H)
+    visible = depth != 0
+    cov3d = compute_cov3d(scale, rotate, visible)
+    conic, radius, tiles = ewa_project(xyz, cov3d, intr, extr, uv, W, H, visible)
+    idx_sorted, tile_range = sort_gaussian(uv, depth, W, H, radius, tiles)
+    return alpha_blending(uv, conic, opacity, feature, idx_sorted, tile_range, bg, W, H, ndc)
