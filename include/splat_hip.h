@@ -89,11 +89,16 @@ int splat_compute_sh_backward(int P, const float *shs, int degree, const float *
  *   scratch: splat_bin_scratch_bytes(P, W, H) bytes, shared by both steps (must stay untouched in
  *   between); keys: capacity * 8 bytes. ---- */
 size_t splat_bin_scratch_bytes(int P, int W, int H);
+/* gcount[P] (optional, may be NULL): number of tiles each Gaussian touches (0 when radius <= 0). */
 int splat_bin_count(int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
-                    int32_t *tile_range, int32_t *M_out, splat_stream_t stream);
+                    int32_t *tile_range, int32_t *M_out, int32_t *gcount, splat_stream_t stream);
+/* goff_incl[P] / inv_pos[M] (optional, both or neither): given the INCLUSIVE prefix sum of gcount, also
+ * emit the inverse pair map inv_pos[goff_excl[id] + k] = sorted position of Gaussian id's k-th tile
+ * (row-major inside its tile rectangle).  The atomic-free blend backward consumes it. */
 int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
                    void *scratch, const int32_t *tile_range, int64_t capacity, uint64_t *keys,
-                   int32_t *idx_sorted, int32_t *overflow_out, splat_stream_t stream);
+                   int32_t *idx_sorted, int32_t *overflow_out, const int32_t *goff_incl, int32_t *inv_pos,
+                   splat_stream_t stream);
 
 /* ---- alpha blending : replaces alphaBlendingForward/Backward, ...Enhanced, ...WithBias
  *      (src/alpha_blending.cu:251-582, src/alpha_blending_enhanced.cu:275-627,
@@ -106,13 +111,21 @@ int splat_alpha_blending_forward(int P, int C, const float *uv, const float *con
                                  float *out, float *final_T, int32_t *ncontrib,
                                  int32_t *gs_idx /*[H,W,K] filled with -1 by caller, or NULL*/,
                                  splat_stream_t stream);
-/* all gradient outputs zero-init; dL_dfeature is [P,C]; dL_dopacity_bias NULL unless bias given. */
+/* dL_dfeature is [P,C]; dL_dopacity_bias NULL unless bias given.
+ * Two modes:
+ *  - atomic mode (goff_incl / inv_pos / pair_scratch NULL): wave-reduced hardware float atomics;
+ *    all gradient outputs must be zero-init.
+ *  - pair mode (all three given; goff_incl / inv_pos from splat_bin_sort for THIS idx_sorted;
+ *    pair_scratch = M * splat_blend_pair_floats(C, bias != NULL) floats, uninitialised): no global
+ *    atomics, every gradient element is written (no zero-init needed). */
+size_t splat_blend_pair_floats(int C, int has_bias);
 int splat_alpha_blending_backward(int P, int C, const float *uv, const float *conic, const float *opacity,
                                   const float *feature, const float *opacity_bias, const int32_t *idx_sorted,
                                   const int32_t *tile_range, float bg, int W, int H, const float *final_T,
                                   const int32_t *ncontrib, const float *dL_dout, float *dL_duv, float *dL_dabs_uv,
                                   float *dL_dconic, float *dL_dopacity, float *dL_dfeature,
-                                  float *dL_dopacity_bias, splat_stream_t stream);
+                                  float *dL_dopacity_bias, const int32_t *goff_incl, const int32_t *inv_pos,
+                                  float *pair_scratch, splat_stream_t stream);
 
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */
 void splat_profile_enable(int on);

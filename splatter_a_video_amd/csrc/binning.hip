@@ -64,7 +64,7 @@ static BinPlan make_plan(int P, int W, int H) {
 template <bool LDS>
 __global__ void __launch_bounds__(BIN_BLOCK)
 bin_count_kernel(int P, const float2 *__restrict__ uv, const int *__restrict__ radius, int gx, int gy, int T,
-                 int chunk, int *__restrict__ matrix) {
+                 int chunk, int *__restrict__ matrix, int *__restrict__ gcount) {
     extern __shared__ __attribute__((aligned(16))) int cnt[];
     const int wg = blockIdx.x;
     if (LDS) {
@@ -74,10 +74,14 @@ bin_count_kernel(int P, const float2 *__restrict__ uv, const int *__restrict__ r
     const int beg = wg * chunk, end = imin_(P, beg + chunk);
     for (int i = beg + threadIdx.x; i < end; i += BIN_BLOCK) {
         const int r = radius[i];
-        if (r <= 0) continue;
+        if (r <= 0) {
+            if (gcount) gcount[i] = 0;
+            continue;
+        }
         const float2 q = uv[i];
         int x0, y0, x1, y1;
         tile_rect(q.x, q.y, r, gx, gy, x0, y0, x1, y1);
+        if (gcount) gcount[i] = (x1 - x0) * (y1 - y0);
         for (int ty = y0; ty < y1; ++ty)
             for (int tx = x0; tx < x1; ++tx) {
                 if (LDS) atomicAdd(&cnt[ty * gx + tx], 1);
@@ -222,7 +226,8 @@ __device__ __forceinline__ void bitonic_any_n(KeyPtr a, int n) {
 
 __global__ void __launch_bounds__(SORT_BLOCK)
 tile_sort_kernel(const int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
-                 int *__restrict__ idx_sorted) {
+                 int *__restrict__ idx_sorted, const float2 *__restrict__ uv, const int *__restrict__ radius, int gx,
+                 int gy, const int *__restrict__ goff_incl, int *__restrict__ inv_pos) {
     __shared__ __attribute__((aligned(16))) unsigned long long sk[SORT_LDS_KEYS];
     const int t = blockIdx.x;
     const long long r0 = tile_range[2 * t];
@@ -236,10 +241,26 @@ tile_sort_kernel(const int *__restrict__ tile_range, long long capacity, unsigne
         __syncthreads();
         if (n > 1) bitonic_any_n(sk, n);
         for (int i = threadIdx.x; i < n; i += SORT_BLOCK) idx_sorted[r0 + i] = (int)(unsigned)(sk[i] & 0xffffffffull);
+        __syncthreads();
     } else {
         __syncthreads();
         bitonic_any_n((volatile unsigned long long *)g, n);
         for (int i = threadIdx.x; i < n; i += SORT_BLOCK) idx_sorted[r0 + i] = (int)(unsigned)(g[i] & 0xffffffffull);
+        __syncthreads();
+    }
+    // inverse pair map: the k-th tile (row-major inside the splat's rectangle) of Gaussian id sits at sorted
+    // position s  ->  inv_pos[goff_excl[id] + k] = s   (used by the atomic-free blend backward)
+    if (inv_pos) {
+        const int tx = t % gx, ty = t / gx;
+        for (int i = threadIdx.x; i < n; i += SORT_BLOCK) {
+            const int id = idx_sorted[r0 + i];
+            const float2 q = uv[id];
+            int x0, y0, x1, y1;
+            tile_rect(q.x, q.y, radius[id], gx, gy, x0, y0, x1, y1);
+            const int k = (ty - y0) * (x1 - x0) + (tx - x0);
+            const int base = id > 0 ? goff_incl[id - 1] : 0;
+            inv_pos[base + k] = (int)(r0 + i);
+        }
     }
 }
 
@@ -250,7 +271,7 @@ extern "C" size_t splat_bin_scratch_bytes(int P, int W, int H) {
 }
 
 extern "C" int splat_bin_count(int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
-                               int32_t *tile_range, int32_t *M_out, splat_stream_t stream) {
+                               int32_t *tile_range, int32_t *M_out, int32_t *gcount, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0, "bad sizes");
     SPLAT_CHECK_ARG(scratch && tile_range, "null pointer");
     SPLAT_CHECK_ARG(P == 0 || (uv && radius), "null pointer");
@@ -262,14 +283,14 @@ extern "C" int splat_bin_count(int P, const float *uv, const int32_t *radius, in
     int *total = (int *)(base + p.off_total);
     if (p.lds) {
         SPLAT_LAUNCH("bin_count", bin_count_kernel<true>, dim3(p.NB), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
-                     P, (const float2 *)uv, radius, p.gx, p.gy, p.T, p.chunk, matrix);
+                     P, (const float2 *)uv, radius, p.gx, p.gy, p.T, p.chunk, matrix, gcount);
     } else {
         // rows: [0] counts, [1] fill counters of K3
         SPLAT_CHECK_HIP(hipMemsetAsync(matrix, 0, (size_t)p.T * sizeof(int), s));
         const int nblk = imax(1, imin((P + BIN_BLOCK - 1) / BIN_BLOCK, 2048));
         const int chunk = (P + nblk - 1) / nblk;
         SPLAT_LAUNCH("bin_count", bin_count_kernel<false>, dim3(nblk), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
-                     radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix);
+                     radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, gcount);
     }
     SPLAT_POST_LAUNCH();
     if (p.lds) {
@@ -285,7 +306,8 @@ extern "C" int splat_bin_count(int P, const float *uv, const int32_t *radius, in
 
 extern "C" int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
                               void *scratch, const int32_t *tile_range, int64_t capacity, uint64_t *keys,
-                              int32_t *idx_sorted, int32_t *overflow_out, splat_stream_t stream) {
+                              int32_t *idx_sorted, int32_t *overflow_out, const int32_t *goff_incl, int32_t *inv_pos,
+                              splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0 && capacity >= 0, "bad sizes");
     SPLAT_CHECK_ARG(scratch && tile_range && overflow_out, "null pointer");
     if (P == 0 || capacity == 0) return SPLAT_OK;
@@ -308,8 +330,9 @@ extern "C" int splat_bin_sort(int P, const float *uv, const float *depth, const 
                      (unsigned long long *)keys, overflow_out);
     }
     SPLAT_POST_LAUNCH();
+    SPLAT_CHECK_ARG((goff_incl == nullptr) == (inv_pos == nullptr), "goff_incl and inv_pos go together");
     SPLAT_LAUNCH("tile_sort", tile_sort_kernel, dim3(p.T), dim3(SORT_BLOCK), 0, s, tile_range, (long long)capacity,
-                 (unsigned long long *)keys, idx_sorted);
+                 (unsigned long long *)keys, idx_sorted, (const float2 *)uv, radius, p.gx, p.gy, goff_incl, inv_pos);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }

@@ -44,16 +44,21 @@ def sort_gaussian(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, til
     lib = L.lib()
     scratch = torch.empty(lib.splat_bin_scratch_bytes(P, W, H), dtype=torch.uint8, device=dev)
     m_dev = torch.empty(1, dtype=torch.int32, device=dev)
+    gcount = torch.empty(P, dtype=torch.int32, device=dev)
     L.check(lib.splat_bin_count(L.ci(P), L.ptr(uv), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
-                                L.ptr(tile_range), L.ptr(m_dev), L.stream()))
+                                L.ptr(tile_range), L.ptr(m_dev), L.ptr(gcount), L.stream()))
+    goff = torch.cumsum(gcount, 0, dtype=torch.int32)      # queued before the sync below
     M = int(m_dev.item())
     idx_sorted = torch.empty(M, dtype=torch.int32, device=dev)
     if M > 0:
         keys = torch.empty(M, dtype=torch.int64, device=dev)
+        inv_pos = torch.empty(M, dtype=torch.int32, device=dev)
         overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         L.check(lib.splat_bin_sort(L.ci(P), L.ptr(uv), L.ptr(depth), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
                                    L.ptr(tile_range), ctypes.c_int64(M), L.ptr(keys), L.ptr(idx_sorted),
-                                   L.ptr(overflow), L.stream()))
+                                   L.ptr(overflow), L.ptr(goff), L.ptr(inv_pos), L.stream()))
+        # hidden companion of idx_sorted: lets alpha_blending's backward run without global atomics
+        idx_sorted._splat_pairmap = (goff, inv_pos)
     return idx_sorted, tile_range
 
 
@@ -65,6 +70,7 @@ class _AlphaBlend(torch.autograd.Function):
         conic = L.need(conic, "conic")
         opacity = L.need(opacity, "opacity")
         feature = L.need(feature, "feature")
+        pairmap = getattr(idx_sorted, "_splat_pairmap", None)
         idx_sorted = L.need(idx_sorted, "idx_sorted", torch.int32)
         tile_range = L.need(tile_range, "tile_range", torch.int32)
         bias_c = None if bias is None else L.need(bias, "opacity_bias")
@@ -87,6 +93,9 @@ class _AlphaBlend(torch.autograd.Function):
             L.ptr(idx_sorted), L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ci(K), L.ci(1 if trunc else 0),
             L.ptr(out), L.ptr(final_T), L.ptr(ncontrib), L.ptr(gs_idx), L.stream()))
         ctx.meta = (float(bg), int(W), int(H), bias is not None, ndc is not None, abs_ndc is not None)
+        if pairmap is not None and (pairmap[0].numel() != P or pairmap[1].numel() != idx_sorted.numel()):
+            pairmap = None
+        ctx.pairmap = pairmap
         saved = [uv, conic, opacity, feature, idx_sorted, tile_range, final_T, ncontrib]
         if bias_c is not None:
             saved.append(bias_c)
@@ -105,16 +114,28 @@ class _AlphaBlend(torch.autograd.Function):
         P, C = feature.shape
         g = L.need(dL_dout, "dL_dout")
         dev = feature.device
-        duv = torch.zeros(P, 2, dtype=torch.float32, device=dev)
-        dabs = torch.zeros(P, 2, dtype=torch.float32, device=dev)
-        dconic = torch.zeros(P, 3, dtype=torch.float32, device=dev)
-        dop = torch.zeros(opacity.shape, dtype=torch.float32, device=dev)
-        dfeat = torch.zeros(P, C, dtype=torch.float32, device=dev)
-        dbias = torch.zeros(bias.shape, dtype=torch.float32, device=dev) if has_bias else None
+        pm = ctx.pairmap
+        M = idx_sorted.numel()
+        if pm is not None and M > 0:
+            # pair mode: every gradient element is written by the reduce kernel -> no zero fill
+            alloc = torch.empty
+            goff, inv_pos = pm
+            scratch = torch.empty(M * L.lib().splat_blend_pair_floats(C, 1 if has_bias else 0), dtype=torch.float32,
+                                  device=dev)
+        else:
+            alloc = torch.zeros
+            goff = inv_pos = scratch = None
+        duv = alloc(P, 2, dtype=torch.float32, device=dev)
+        dabs = alloc(P, 2, dtype=torch.float32, device=dev)
+        dconic = alloc(P, 3, dtype=torch.float32, device=dev)
+        dop = alloc(opacity.shape, dtype=torch.float32, device=dev)
+        dfeat = alloc(P, C, dtype=torch.float32, device=dev)
+        dbias = alloc(bias.shape, dtype=torch.float32, device=dev) if has_bias else None
         L.check(L.lib().splat_alpha_blending_backward(
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias), L.ptr(idx_sorted),
             L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(g), L.ptr(duv),
-            L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(dbias), L.stream()))
+            L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(dbias), L.ptr(goff), L.ptr(inv_pos),
+            L.ptr(scratch), L.stream()))
         # gradient taps used by densification (reference: alpha_blending.py:112-120)
         dndc = dabs_ndc = None
         if has_ndc or has_abs:

@@ -186,7 +186,10 @@ def test_sort_gaussian_ties_and_empty(gpu, oracle_mod):
 
 
 # ------------------------------------------------------------------ alpha blending
-def _blend_case(gpu, o, N, W, H, C, bg, variant, seed=0, K=4):
+def _blend_case(gpu, o, N, W, H, C, bg, variant, seed=0, K=4, mode="atomic"):
+    """mode "atomic": idx_sorted comes from the oracle (plain tensor) -> wave-reduced atomics backward;
+    mode "pair": idx_sorted comes from gs.sort_gaussian (bit-identical, carries the pair map) ->
+    atomic-free backward."""
     import dptr.gs as gs
     sc = make_scene(N, W, H, seed=seed + N + C)
     G = oracle_geometry(o, sc)
@@ -199,6 +202,9 @@ def _blend_case(gpu, o, N, W, H, C, bg, variant, seed=0, K=4):
     res_r = o.alpha_blending_forward(G["uv"], G["conic"], sc.opacity, feat, G["idx"], G["tr"], bg, W, H, opacity_bias=ob, **kw)
     t = {k: dev(v, gpu).requires_grad_(True) for k, v in dict(uv=G["uv"], conic=G["conic"], opacity=sc.opacity, feat=feat).items()}
     t_idx, t_tr = dev(G["idx"], gpu), dev(G["tr"], gpu)
+    if mode == "pair":
+        t_idx, t_tr = gs.sort_gaussian(dev(G["uv"], gpu), dev(G["depth"], gpu), W, H, dev(G["radius"], gpu), dev(G["tiles"], gpu))
+        assert (t_idx.cpu().numpy() == G["idx"]).all() and hasattr(t_idx, "_splat_pairmap")
     ndc = torch.zeros(N, 2, device=gpu, requires_grad=True)
     andc = torch.zeros(N, 2, device=gpu, requires_grad=True)
     t_ob = dev(ob, gpu).requires_grad_(True) if ob is not None else None
@@ -227,15 +233,38 @@ def _blend_case(gpu, o, N, W, H, C, bg, variant, seed=0, K=4):
         assert_grad(t_ob.grad, gr[5], "dL_dopacity_bias")
 
 
+@pytest.mark.parametrize("mode", ["atomic", "pair"])
 @pytest.mark.parametrize("C", [1, 3, 5, 19, 32, 40])
-def test_alpha_blending_channels(gpu, oracle_mod, C):
-    _blend_case(gpu, oracle_mod, 4000, 100, 60, C, 0.3, "plain")
+def test_alpha_blending_channels(gpu, oracle_mod, C, mode):
+    _blend_case(gpu, oracle_mod, 4000, 100, 60, C, 0.3, "plain", mode=mode)
 
 
+@pytest.mark.parametrize("mode", ["atomic", "pair"])
 @pytest.mark.parametrize("variant", ["plain", "enh", "trunc", "bias"])
 @pytest.mark.parametrize("N,W,H", [(1, 16, 16), (300, 33, 17), (10000, 256, 256)])
-def test_alpha_blending_variants(gpu, oracle_mod, variant, N, W, H):
-    _blend_case(gpu, oracle_mod, N, W, H, 3, 1.0 if variant == "plain" else 0.0, variant, seed=5)
+def test_alpha_blending_variants(gpu, oracle_mod, variant, N, W, H, mode):
+    _blend_case(gpu, oracle_mod, N, W, H, 3, 1.0 if variant == "plain" else 0.0, variant, seed=5, mode=mode)
+
+
+def test_alpha_blending_pair_mode_big_splats(gpu, oracle_mod):
+    """sigma = 12 px: long per-Gaussian pair lists and > 4096-entry tiles through the pair-mode backward."""
+    sc_kw = dict()
+    import dptr.gs as gs
+    o = oracle_mod
+    sc = make_scene(3000, 64, 64, seed=77)
+    sc.scale *= 6.0
+    G = oracle_geometry(o, sc)
+    feat = np.random.default_rng(5).uniform(size=(sc.N, 3)).astype(np.float32)
+    out_r, fT_r, nc_r = o.alpha_blending_forward(G["uv"], G["conic"], sc.opacity, feat, G["idx"], G["tr"], 0.0, 64, 64)
+    idx, tr = gs.sort_gaussian(dev(G["uv"], gpu), dev(G["depth"], gpu), 64, 64, dev(G["radius"], gpu), dev(G["tiles"], gpu))
+    t = {k: dev(v, gpu).requires_grad_(True) for k, v in dict(uv=G["uv"], conic=G["conic"], opacity=sc.opacity, feat=feat).items()}
+    out = gs.alpha_blending(t["uv"], t["conic"], t["opacity"], t["feat"], idx, tr, 0.0, 64, 64)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_r, rtol=IMG_RTOL, atol=IMG_ATOL)
+    g = np.random.default_rng(6).normal(size=out_r.shape).astype(np.float32)
+    out.backward(dev(g, gpu))
+    gr = o.alpha_blending_backward(G["uv"], G["conic"], sc.opacity, feat, G["idx"], G["tr"], 0.0, 64, 64, fT_r, nc_r, g)
+    assert_grad(t["uv"].grad, gr[0], "dL_duv"); assert_grad(t["conic"].grad, gr[1], "dL_dconic")
+    assert_grad(t["opacity"].grad, gr[2], "dL_dopacity"); assert_grad(t["feat"].grad, gr[3], "dL_dfeature")
 
 
 def test_alpha_blending_dense_saturating(gpu, oracle_mod):
