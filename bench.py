@@ -136,7 +136,10 @@ def kernel_bytes(name, N, M, HW, C, T, use_sh):
         "bin_scatter": N * 16 + M * 8,
         "tile_sort": M * (8 + 4),
         "blend_fwd": M * (28 + 4 * C) + HW * (4 * C + 8),
+        # gather again + one (8+C)-float record per pair (pair mode: plain store) + dL_dout/final_T/ncontrib
         "blend_bwd": M * (28 + 4 * C) + M * (32 + 4 * C) + HW * (4 * C + 8),
+        # reads the records through the inverse pair map, writes the per-Gaussian gradients
+        "pair_reduce": M * (4 + 32 + 4 * C) + N * (4 + 32 + 4 * C),
     }
     return table.get(name, 0)
 
@@ -218,7 +221,8 @@ def main():
         torch.cuda.synchronize()
         L.profile_enable(False)
         names = ["sh_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
-                 "bin_scatter", "tile_sort", "blend_fwd", "blend_bwd", "ewa_bwd", "project_point_bwd", "cov3d_bwd", "sh_bwd"]
+                 "bin_scatter", "tile_sort", "blend_fwd", "blend_bwd", "pair_reduce", "ewa_bwd", "project_point_bwd",
+                 "cov3d_bwd", "sh_bwd"]
         for n in names:
             ms, cnt = L.profile_read(n)
             if cnt:
@@ -232,9 +236,9 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                         "avg_us": kernels[dom]["avg_us"], "alg_bytes_per_launch": int(kernel_bytes(dom, a.gaussians, M, HW, R.C, T, R.use_sh))}
-            fwd = [k for k in kernels if not k.endswith("_bwd")]
-            fwd_ms = sum(kernels[k]["avg_us"] for k in fwd) / 1e3
-            bwd_ms = sum(kernels[k]["avg_us"] for k in kernels if k.endswith("_bwd")) / 1e3
+            is_bwd = lambda k: k.endswith("_bwd") or k == "pair_reduce"
+            fwd_ms = sum(kernels[k]["avg_us"] for k in kernels if not is_bwd(k)) / 1e3
+            bwd_ms = sum(kernels[k]["avg_us"] for k in kernels if is_bwd(k)) / 1e3
         L.profile_reset()
 
     cpu = None

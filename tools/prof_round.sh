@@ -7,6 +7,6 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --frames 5 --no-cpu-baseline > $OUT/bench_stdout.log 2>&1
+timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --frames 5 --no-cpu-baseline > $OUT/bench_stdout.log 2>&1
 cd $GRAFT_REPO_ROOT
 find $OUT -name '*kernel_stats*' | head
