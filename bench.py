@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 import dptr.gs as gs  # noqa: E402
 import splatter_a_video_amd._lib as L  # noqa: E402
+from splatter_a_video_amd.parallel import FlatGradBucket  # noqa: E402
 from splatter_a_video_amd.synth import make_scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
@@ -62,23 +63,15 @@ class FrameRenderer:
         self.dev = device
         N = sc.N
         self.W, self.H = sc.W, sc.H
-        shapes = [("xyz", (N, 3)), ("scale", (N, 3)), ("rotate", (N, 4)), ("opacity", (N, 1))]
         self.use_sh = C_extra == 0
-        shapes.append(("shs", (N, 16, 3)) if self.use_sh else ("feature", (N, C_extra)))
-        total = sum(int(np.prod(s)) for _, s in shapes)
-        self.flat_param = torch.empty(total, dtype=torch.float32, device=device)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
-        self.p = {}
-        src = dict(xyz=sc.xyz, scale=sc.scale, rotate=sc.rotate, opacity=sc.opacity, shs=sc.shs, feature=sc.feature)
-        o = 0
-        for name, shp in shapes:
-            n = int(np.prod(shp))
-            v = self.flat_param[o:o + n].view(shp)
-            v.copy_(torch.as_tensor(src[name], device=device))
-            v.requires_grad_(True)
-            v.grad = self.flat_grad[o:o + n].view(shp)
-            self.p[name] = v
-            o += n
+        src = dict(xyz=sc.xyz, scale=sc.scale, rotate=sc.rotate, opacity=sc.opacity)
+        if self.use_sh:
+            src["shs"] = sc.shs
+        else:
+            src["feature"] = sc.feature
+        self.bucket = FlatGradBucket({k: torch.as_tensor(v, device=device) for k, v in src.items()})
+        self.p = self.bucket.params
+        self.flat_grad = self.bucket.flat_grad
         self.extr = torch.tensor(sc.extr, device=device)
         self.phase = torch.tensor(sc.phase, device=device)
         self.dirs = torch.zeros(N, 3, device=device)
@@ -111,11 +104,11 @@ class FrameRenderer:
         return img
 
     def step(self, offs, world):
-        self.flat_grad.zero_()
+        self.bucket.zero_grad()
         for off in offs:
             self.frame(off)
         if world > 1:
-            dist.all_reduce(self.flat_grad)
+            self.bucket.all_reduce()
 
 
 def kernel_bytes(name, N, M, HW, C, T, use_sh):

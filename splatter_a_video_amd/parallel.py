@@ -1,0 +1,86 @@
+"""Frame-sharded data parallelism for the video rasterizer.
+
+All frames of a clip share one Gaussian parameter set, so the natural multi-GPU axis is the
+frame: every rank holds a replica, renders the frames ``f = rank (mod world)`` of the step's frame
+batch forward+backward, and the Gaussian gradients (accumulated locally over the rank's frames in
+ONE flat fp32 bucket) are summed with a single ``all_reduce`` per optimiser step -- RCCL over xGMI on
+MI355X (``backend="nccl"``), gloo in the CPU tests.  The reference initialises a process group and a
+DistributedSampler but never synchronises gradients (src/train.py:31,212); this is the missing
+piece, not a translation of anything.
+
+The module is backend-agnostic plumbing (no kernels): it only depends on torch / torch.distributed.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def frames_of_rank(frames: Sequence[int], rank: int, world: int) -> List[int]:
+    """Round-robin frame shard: rank r takes frames[r], frames[r+world], ..."""
+    return list(frames[rank::world])
+
+
+class FlatGradBucket:
+    """Parameters as views of one flat tensor, gradients as views of another.
+
+    ``bucket.params[name]`` are leaf tensors (``requires_grad=True``) whose ``.grad`` aliases a slice of
+    ``bucket.flat_grad``; autograd accumulates in place, so after the local frames' backward passes
+    ``all_reduce()`` moves exactly one contiguous buffer."""
+
+    def __init__(self, tensors: Dict[str, torch.Tensor]):
+        names = list(tensors)
+        dev = tensors[names[0]].device
+        total = sum(t.numel() for t in tensors.values())
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.params: Dict[str, torch.Tensor] = {}
+        self.slices: Dict[str, Tuple[int, int]] = {}
+        o = 0
+        for n in names:
+            t = tensors[n]
+            k = t.numel()
+            v = self.flat_param[o:o + k].view(t.shape)
+            with torch.no_grad():
+                v.copy_(t)
+            v.requires_grad_(True)
+            v.grad = self.flat_grad[o:o + k].view(t.shape)
+            self.params[n] = v
+            self.slices[n] = (o, o + k)
+            o += k
+
+    def zero_grad(self) -> None:
+        self.flat_grad.zero_()
+
+    def all_reduce(self, average: bool = False) -> None:
+        """One collective per step; a no-op for a single process."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            if average:
+                self.flat_grad.div_(dist.get_world_size())
+
+    def grad(self, name: str) -> torch.Tensor:
+        a, b = self.slices[name]
+        return self.flat_grad[a:b].view(self.params[name].shape)
+
+
+def reduce_visibility(visibility: torch.Tensor, radii: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Densification statistics the renderer ORs / maxes over its frames
+    (reference: dptr_ortho_enhanced.py:430-431) reduced over the ranks as well."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        v = visibility.to(torch.int32)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        r = radii.clone()
+        dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        return v.bool(), r
+    return visibility, radii
+
+
+def sharded_step(bucket: FlatGradBucket, frames: Iterable[int], render_and_backward) -> None:
+    """zero -> local frames forward+backward (grads accumulate in the bucket) -> one all-reduce."""
+    bucket.zero_grad()
+    for f in frames:
+        render_and_backward(f)
+    bucket.all_reduce()
