@@ -6,8 +6,10 @@
  * (reference: src/submodules/dptr/dptr/gs/src/ext.cpp:14-33, 18 functions on torch::Tensor).
  * Differences by design:
  *   - plain C: raw DEVICE pointers + int sizes + scalars + a hipStream_t; no torch / pybind types;
- *   - the CALLER owns every buffer (zero-filled where marked "zero-init": culled points keep 0,
- *     empty tiles keep (0,0), gradients accumulate), the library allocates nothing persistent;
+ *   - the CALLER owns every buffer, the library allocates nothing persistent.  Unless marked
+ *     "zero-init", the kernels write EVERY element of an output (zeros for culled points, -1 for
+ *     unused gs_idx slots, (0,0) for empty tiles), so outputs may be uninitialised memory;
+ *     "zero-init" buffers are accumulated into (camera gradients, atomic-mode blend gradients);
  *   - every launch goes to the caller's stream (the reference uses the legacy default stream);
  *   - returns 0 or a negative SPLAT_E_* code; splat_last_error() gives the thread-local message.
  *
@@ -42,41 +44,42 @@ const char *splat_last_error(void);
 int splat_abi_version(void);
 
 /* ---- project_point : replaces projectPointsForward/Backward (src/project_point.cu:147-227) ---- */
-/* uv, depth zero-init. */
+/* uv, depth: fully written. */
 int splat_project_point_forward(int P, const float *xyz, const float *intr, const float *extr, int W, int H,
                                 float nearest, float extent, int ortho, float *uv, float *depth,
                                 splat_stream_t stream);
-/* dL_dxyz zero-init; dL_dintr[4] / dL_dextr[12] zero-init or NULL (only when requires_grad). */
+/* dL_dxyz fully written; dL_dintr[4] / dL_dextr[12] zero-init or NULL (only when requires_grad). */
 int splat_project_point_backward(int P, const float *xyz, const float *intr, const float *extr, int W, int H,
                                  int ortho, const float *depth, const float *dL_duv, const float *dL_ddepth,
                                  float *dL_dxyz, float *dL_dintr, float *dL_dextr, splat_stream_t stream);
 
 /* ---- compute_cov3d : replaces computeCov3DForward/Backward (src/compute_cov3d.cu:149-199) ---- */
 int splat_compute_cov3d_forward(int P, const float *scales, const float *uquats, const uint8_t *visible,
-                                float *cov3d /*zero-init*/, splat_stream_t stream);
+                                float *cov3d, splat_stream_t stream);
 int splat_compute_cov3d_backward(int P, const float *scales, const float *uquats, const uint8_t *visible,
-                                 const float *dL_dcov3d, float *dL_dscales /*zero-init*/,
-                                 float *dL_duquats /*zero-init*/, splat_stream_t stream);
+                                 const float *dL_dcov3d, float *dL_dscales, float *dL_duquats,
+                                 splat_stream_t stream);
 
 /* ---- ewa_project : replaces EWAProjectForward/Backward (src/ewa_project.cu:254-344) ---- */
 int splat_ewa_project_forward(int P, const float *xyz, const float *cov3d, const float *intr, const float *extr,
                               const float *uv, int W, int H, const uint8_t *visible, int ortho,
-                              float *conic, int32_t *radius, int32_t *tiles /*all zero-init*/,
+                              float *conic, int32_t *radius, int32_t *tiles,
                               splat_stream_t stream);
 int splat_ewa_project_backward(int P, const float *xyz, const float *cov3d, const float *intr, const float *extr,
                                int W, int H, int ortho, const int32_t *radius, const float *dL_dconic,
-                               float *dL_dxyz, float *dL_dcov3d /*zero-init*/,
+                               float *dL_dxyz, float *dL_dcov3d,
                                float *dL_dintr /*[4] or NULL*/, float *dL_dextr /*[12] or NULL*/,
                                splat_stream_t stream);
 
 /* ---- compute_sh / compute_sh_free : replaces computeSH(Free)Forward/Backward
  *      (src/compute_sh.cu:235-295, src/compute_sh_free.cu) ---- */
 int splat_compute_sh_forward(int P, const float *shs, int degree, const float *dirs, const uint8_t *visible,
-                             int free_variant, float *colors /*zero-init*/,
-                             uint8_t *clamped /*[P,3], ones-init, NULL when free*/, splat_stream_t stream);
+                             int free_variant, float *colors,
+                             uint8_t *clamped /*[P,3], NULL when free*/, splat_stream_t stream);
 int splat_compute_sh_backward(int P, const float *shs, int degree, const float *dirs, const uint8_t *visible,
                               const uint8_t *clamped /*NULL when free*/, int free_variant,
-                              const float *dL_dcolors, float *dL_dshs /*zero-init*/, float *dL_ddirs /*zero-init*/,
+                              const float *dL_dcolors, float *dL_dshs /*rows of (deg+1)^2 triplets written*/,
+                              float *dL_ddirs,
                               splat_stream_t stream);
 
 /* ---- sort_gaussian : replaces computeGaussianKey + torch.sort + gather + computeTileGaussianRange
@@ -109,7 +112,7 @@ int splat_alpha_blending_forward(int P, int C, const float *uv, const float *con
                                  const float *feature, const float *opacity_bias, const int32_t *idx_sorted,
                                  const int32_t *tile_range, float bg, int W, int H, int K, int enable_truncation,
                                  float *out, float *final_T, int32_t *ncontrib,
-                                 int32_t *gs_idx /*[H,W,K] filled with -1 by caller, or NULL*/,
+                                 int32_t *gs_idx /*[H,W,K] (unused slots are set to -1), or NULL*/,
                                  splat_stream_t stream);
 /* dL_dfeature is [P,C]; dL_dopacity_bias NULL unless bias given.
  * Two modes:

@@ -125,7 +125,7 @@ struct TileLDS {
     float4 g0[SB + 4];  // u v a b   (+4: the unrolled pixel loop may read past the last survivor)
     float4 g1[SB + 4];  // c o bias id(bits)
     float f[(SB + 4) * CHP];
-    unsigned short list[4][SB + 4];
+    unsigned short list[4][SB + 8];
 };
 
 template <int CH, int SB>
@@ -175,7 +175,7 @@ __device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane, i
         if (keep) L.list[w][cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
         cnt += __popcll(m);
     }
-    if (lane < 4) L.list[w][cnt + lane] = (unsigned short)SB;  // pad: the unrolled loop reads slot SB (inert record)
+    if (lane < 8) L.list[w][cnt + lane] = (unsigned short)SB;  // pad: unrolled / prefetching loops read slot SB (inert record)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return cnt;
@@ -235,6 +235,14 @@ blend_fwd_kernel(const BlendArgs A) {
         if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;  // every pixel of the tile is saturated
         if (!alld) {
             const int cnt = build_list<CH, SB, BIAS>(L, w, lane, nb, bx0, bx1, by0, by1, [](int) { return true; });
+            int en[U];
+            float4 g0n[U], g1n[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {  // records of the first trip
+                en[u] = L.list[w][u];
+                g0n[u] = L.g0[en[u]];
+                g1n[u] = L.g1[en[u]];
+            }
             for (int j0 = 0; j0 < cnt; j0 += U) {
                 int e[U];
                 float4 g0[U], g1[U];
@@ -243,9 +251,13 @@ blend_fwd_kernel(const BlendArgs A) {
                 bool any_ok = false;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    e[u] = L.list[w][j0 + u];
-                    g0[u] = L.g0[e[u]];
-                    g1[u] = L.g1[e[u]];
+                    e[u] = en[u]; g0[u] = g0n[u]; g1[u] = g1n[u];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {  // prefetch the next trip (padded list -> inert slot past the end)
+                    en[u] = L.list[w][imin_(j0 + U + u, SB + 7)];
+                    g0n[u] = L.g0[en[u]];
+                    g1n[u] = L.g1[en[u]];
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -294,6 +306,8 @@ blend_fwd_kernel(const BlendArgs A) {
 #pragma unroll
         for (int k = 0; k < CH; ++k)
             if (k < cn) A.out[(size_t)(A.c0 + k) * HW + pix] = F[k] + T * A.bg;
+        if (ENH)
+            for (int l = layer; l < A.K; ++l) A.gs_idx[pix * A.K + l] = -1;  // unused slots (reference: -1 init)
     }
 }
 
@@ -367,7 +381,8 @@ __device__ __forceinline__ void replay_one(const float4 &g0, const float4 &g1, c
 template <int CH, bool BIAS>
 struct PairCfg {
     static constexpr int NG = BIAS ? 9 : 8;  // ux uy ax ay ca cb cc o [bias]
-    static constexpr int NC = NG + CH;       // floats per pair record
+    static constexpr int NC = NG + CH;       // used floats per pair record
+    static constexpr int NCP = (NC + 15) & ~15;  // record stride in pair_buf: whole 64-B sectors
     static constexpr int SB = 64;
 };
 
@@ -375,7 +390,7 @@ template <int CH, bool BIAS, bool EXACT>
 __global__ void __launch_bounds__(256)
 blend_bwd_pair_kernel(const BlendArgs A) {
     using Cfg = PairCfg<CH, BIAS>;
-    constexpr int SB = Cfg::SB, NC = Cfg::NC, NG = Cfg::NG;
+    constexpr int SB = Cfg::SB, NC = Cfg::NC, NG = Cfg::NG, NCP = Cfg::NCP;
     constexpr int U = CH <= 8 ? 2 : 1;
     __shared__ TileLDS<CH, SB> L;
     __shared__ float s_acc[4][SB * NC];          // private slab per wave: plain stores, no atomics
@@ -415,8 +430,8 @@ blend_bwd_pair_kernel(const BlendArgs A) {
     const int2 range = A.tile_range[tile];
     const int len = range.y - range.x;
     const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
-    float *pb = A.pair_buf + (size_t)range.x * NC;
-    for (int i = n * NC + tid; i < len * NC; i += 256) pb[i] = 0.f;  // entries nobody replays: zero record
+    float *pb = A.pair_buf + (size_t)range.x * NCP;
+    for (int i = n * NCP + tid; i < len * NCP; i += 256) pb[i] = 0.f;  // entries nobody replays: zero record
     if (n <= 0) return;
 
     // thread e < SB stages entry q = top - e
@@ -440,6 +455,14 @@ blend_bwd_pair_kernel(const BlendArgs A) {
                                                  [=](int e) { return top - e < wmax; });
         unsigned long long wrote = 0ull;
         float *slab = s_acc[w];
+        int en[U];
+        float4 g0n[U], g1n[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            en[u] = L.list[w][u];
+            g0n[u] = L.g0[en[u]];
+            g1n[u] = L.g1[en[u]];
+        }
         for (int j0 = 0; j0 < cnt; j0 += U) {
             int e[U];
             float4 g0[U], g1[U];
@@ -448,9 +471,13 @@ blend_bwd_pair_kernel(const BlendArgs A) {
             bool any_ok = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                e[u] = L.list[w][j0 + u];
-                g0[u] = L.g0[e[u]];
-                g1[u] = L.g1[e[u]];
+                e[u] = en[u]; g0[u] = g0n[u]; g1[u] = g1n[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {  // prefetch the next trip
+                en[u] = L.list[w][imin_(j0 + U + u, SB + 7)];
+                g0n[u] = L.g0[en[u]];
+                g1n[u] = L.g1[en[u]];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -493,16 +520,18 @@ blend_bwd_pair_kernel(const BlendArgs A) {
         // ---- combine the four slabs, one coalesced store: entry e <-> sorted position top - e
         {
             const int lo = top - nb + 1;
-            float *dst = pb + (size_t)lo * NC;
+            float *dst = pb + (size_t)lo * NCP;
             const unsigned long long m0 = s_mask[0], m1 = s_mask[1], m2 = s_mask[2], m3 = s_mask[3];
-            for (int i = tid; i < nb * NC; i += 256) {
-                const int ql = i / NC, c = i - ql * NC;
+            for (int i = tid; i < nb * NCP; i += 256) {
+                const int ql = i / NCP, c = i - ql * NCP;
                 const int e = nb - 1 - ql;
                 float v = 0.f;
-                if ((m0 >> e) & 1ull) v += s_acc[0][e * NC + c];
-                if ((m1 >> e) & 1ull) v += s_acc[1][e * NC + c];
-                if ((m2 >> e) & 1ull) v += s_acc[2][e * NC + c];
-                if ((m3 >> e) & 1ull) v += s_acc[3][e * NC + c];
+                if (c < NC) {
+                    if ((m0 >> e) & 1ull) v += s_acc[0][e * NC + c];
+                    if ((m1 >> e) & 1ull) v += s_acc[1][e * NC + c];
+                    if ((m2 >> e) & 1ull) v += s_acc[2][e * NC + c];
+                    if ((m3 >> e) & 1ull) v += s_acc[3][e * NC + c];
+                }
                 dst[i] = v;
             }
         }
@@ -511,6 +540,11 @@ blend_bwd_pair_kernel(const BlendArgs A) {
 }
 
 // sums each Gaussian's pair records (inverse pair map) into the final gradients -- plain stores.
+// Four records are fetched per trip so that the indirect loads overlap (most Gaussians touch <= 4 tiles).
+struct __attribute__((packed, aligned(4))) F4 {
+    float x, y, z, w;
+};
+
 template <bool BIAS>
 __global__ void __launch_bounds__(256)
 pair_reduce_kernel(const BlendArgs A, int NC) {
@@ -527,15 +561,24 @@ pair_reduce_kernel(const BlendArgs A, int NC) {
         float fs[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) fs[k] = 0.f;
-        for (int j = beg; j < end; ++j) {
-            const float *rec = A.pair_buf + (size_t)A.inv_pos[j] * NC;
-            if (k0 == 0) {
+        for (int j = beg; j < end; j += 4) {
+            int sp[4];
 #pragma unroll
-                for (int k = 0; k < NG; ++k) g[k] += rec[k];
+            for (int u = 0; u < 4; ++u) sp[u] = (j + u < end) ? A.inv_pos[j + u] : -1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (sp[u] < 0) continue;
+                const float *rec = A.pair_buf + (size_t)sp[u] * NC;
+                if (k0 == 0) {
+                    const float4 r0 = *reinterpret_cast<const float4 *>(rec), r1 = *reinterpret_cast<const float4 *>(rec + 4);
+                    g[0] += r0.x; g[1] += r0.y; g[2] += r0.z; g[3] += r0.w;
+                    g[4] += r1.x; g[5] += r1.y; g[6] += r1.z; g[7] += r1.w;
+                    if (BIAS) g[NG - 1] += rec[8];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k0 + k < A.cn) fs[k] += rec[NG + k0 + k];
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k0 + k < A.cn) fs[k] += rec[NG + k0 + k];
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -690,7 +733,7 @@ static int launch_bwd(const BlendArgs &A, int T, bool bias, bool pair, hipStream
 #undef BWD
     SPLAT_POST_LAUNCH();
     if (pair) {
-        const int NC = (bias ? 9 : 8) + CH;
+        const int NC = (((bias ? 9 : 8) + CH) + 15) & ~15;  // padded record stride (PairCfg::NCP)
         const dim3 rgrid((unsigned)((A.P + 255) / 256));
         if (bias) SPLAT_LAUNCH("pair_reduce", pair_reduce_kernel<true>, rgrid, dim3(256), 0, s, A, NC);
         else SPLAT_LAUNCH("pair_reduce", pair_reduce_kernel<false>, rgrid, dim3(256), 0, s, A, NC);
@@ -726,7 +769,7 @@ static int bwd_chunk(const BlendArgs &A, int T, bool bias, bool pair, hipStream_
 
 extern "C" size_t splat_blend_pair_floats(int C, int has_bias) {
     // floats per pair record for the widest channel chunk of a C-channel backward
-    return (size_t)((has_bias ? 9 : 8) + chunk_ch(C > 32 ? 32 : C));
+    return (size_t)((((has_bias ? 9 : 8) + chunk_ch(C > 32 ? 32 : C)) + 15) & ~15);
 }
 
 // ================================================================== C ABI

@@ -67,10 +67,9 @@ project_point_fwd_kernel(int P, const float *__restrict__ xyz, const float *__re
             cull = cull || (u < xlo) || (u > xhi) || (v < ylo) || (v > yhi);
         }
     }
-    if (cull) return;
-    uv[2 * i] = u;
-    uv[2 * i + 1] = v;
-    depth[i] = d;
+    uv[2 * i] = cull ? 0.f : u;
+    uv[2 * i + 1] = cull ? 0.f : v;
+    depth[i] = cull ? 0.f : d;
 }
 
 // reference: src/project_point.cu:59-145 ; ortho: autograd of the twin.
@@ -92,7 +91,7 @@ project_point_bwd_kernel(int P, const float *__restrict__ xyz, const float *__re
         if (ORTHO) {
             const float gx = gu * ((float)W / 2.f), gy = gv * ((float)H / 2.f);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) dL_dxyz[3 * i + j] += c.e[j] * gx + c.e[4 + j] * gy + c.e[8 + j] * gd;
+            for (int j = 0; j < 3; ++j) dL_dxyz[3 * i + j] = c.e[j] * gx + c.e[4 + j] * gy + c.e[8 + j] * gd;
         } else {
             const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
             float tx, ty, tz;
@@ -105,7 +104,7 @@ project_point_bwd_kernel(int P, const float *__restrict__ xyz, const float *__re
                 g += (c.fx * (c.e[j] * tz - tx * c.e[8 + j]) * n2) * gu;
                 g += (c.fy * (c.e[4 + j] * tz - ty * c.e[8 + j]) * n2) * gv;
                 g += c.e[8 + j] * gd;
-                dL_dxyz[3 * i + j] += g;
+                dL_dxyz[3 * i + j] = g;
             }
             if (CAMGRAD) {
                 cg[0] = tx * n1 * gu; cg[1] = ty * n1 * gv; cg[2] = gu; cg[3] = gv;
@@ -118,6 +117,9 @@ project_point_bwd_kernel(int P, const float *__restrict__ xyz, const float *__re
                 }
             }
         }
+    }
+    if (!live && i < P) {
+        dL_dxyz[3 * i] = 0.f; dL_dxyz[3 * i + 1] = 0.f; dL_dxyz[3 * i + 2] = 0.f;
     }
     if (CAMGRAD && !ORTHO) {  // whole wave participates: reduce, then one atomic per wave and component
         const int lane = threadIdx.x & 63;
@@ -145,7 +147,13 @@ __global__ void __launch_bounds__(PW_BLOCK)
 cov3d_fwd_kernel(int P, const float *__restrict__ scales, const float4 *__restrict__ uquats,
                  const uint8_t *__restrict__ visible, float *__restrict__ cov3d) {
     const int i = blockIdx.x * PW_BLOCK + threadIdx.x;
-    if (i >= P || !visible[i]) return;
+    if (i >= P) return;
+    float *o = cov3d + 6 * (size_t)i;
+    if (!visible[i]) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = 0.f;
+        return;
+    }
     const float4 q4 = uquats[i];
     const float q[4] = {q4.x, q4.y, q4.z, q4.w};
     const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
@@ -155,7 +163,6 @@ cov3d_fwd_kernel(int P, const float *__restrict__ scales, const float4 *__restri
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int j = 0; j < 3; ++j) M[k][j] = s[k] * R[j][k];
-    float *o = cov3d + 6 * (size_t)i;
     int n = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -169,7 +176,12 @@ cov3d_bwd_kernel(int P, const float *__restrict__ scales, const float4 *__restri
                  const uint8_t *__restrict__ visible, const float *__restrict__ dL_dcov3d,
                  float *__restrict__ dL_dscales, float4 *__restrict__ dL_duquats) {
     const int i = blockIdx.x * PW_BLOCK + threadIdx.x;
-    if (i >= P || !visible[i]) return;
+    if (i >= P) return;
+    if (!visible[i]) {
+        dL_dscales[3 * i] = 0.f; dL_dscales[3 * i + 1] = 0.f; dL_dscales[3 * i + 2] = 0.f;
+        dL_duquats[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const float4 q4 = uquats[i];
     const float q[4] = {q4.x, q4.y, q4.z, q4.w};
     const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
@@ -237,6 +249,7 @@ __device__ __forceinline__ void ewa_cov2d(const float a[3], const float b[3], co
 }
 
 // reference: src/ewa_project.cu:16-83 ; ortho: dptr_ortho_enhanced.py:18-111
+// Every element of conic / radius / tiles is written (zeros for culled / degenerate splats).
 template <bool ORTHO>
 __global__ void __launch_bounds__(PW_BLOCK)
 ewa_fwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ cov3d, const float *__restrict__ intr,
@@ -244,36 +257,45 @@ ewa_fwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ c
                const uint8_t *__restrict__ visible, float *__restrict__ conic, int *__restrict__ radius,
                int *__restrict__ tiles) {
     const int i = blockIdx.x * PW_BLOCK + threadIdx.x;
-    if (i >= P || !visible[i]) return;
-    Cam c;
-    load_cam(ORTHO ? nullptr : intr, extr, c);
-    const float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-    float c3[6];
+    if (i >= P) return;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    int orad = 0, otiles = 0;
+    if (visible[i]) {
+        Cam c;
+        load_cam(ORTHO ? nullptr : intr, extr, c);
+        const float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        float c3[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) c3[k] = cov3d[6 * (size_t)i + k];
-    float a[3], b[3], t[3], Jm[4], cov[3];
-    ewa_T<ORTHO>(c, p, W, H, a, b, t, Jm);
-    ewa_cov2d<ORTHO>(a, b, c3, cov);
-    const float det = cov[0] * cov[2] - cov[1] * cov[1];
-    if (det == 0.0f) return;
-    if (ORTHO && isnan(det)) return;
-    const float mid = 0.5f * (cov[0] + cov[2]);
-    const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
-    const float l1 = mid + sq, l2 = mid - sq;
-    const int r = (int)ceilf(3.f * sqrtf(fmaxf(l1, l2)));
-    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    const float2 q = uv[i];
-    int x0, y0, x1, y1;
-    tile_rect(q.x, q.y, r, gx, gy, x0, y0, x1, y1);
-    if ((x1 - x0) * (y1 - y0) == 0) return;
-    if (ORTHO) {
-        conic[3 * i] = cov[2] / det; conic[3 * i + 1] = -cov[1] / det; conic[3 * i + 2] = cov[0] / det;
-    } else {
-        const float di = 1.f / det;
-        conic[3 * i] = cov[2] * di; conic[3 * i + 1] = -cov[1] * di; conic[3 * i + 2] = cov[0] * di;
+        for (int k = 0; k < 6; ++k) c3[k] = cov3d[6 * (size_t)i + k];
+        float a[3], b[3], t[3], Jm[4], cov[3];
+        ewa_T<ORTHO>(c, p, W, H, a, b, t, Jm);
+        ewa_cov2d<ORTHO>(a, b, c3, cov);
+        const float det = cov[0] * cov[2] - cov[1] * cov[1];
+        const bool bad = (det == 0.0f) || (ORTHO && isnan(det));
+        if (!bad) {
+            const float mid = 0.5f * (cov[0] + cov[2]);
+            const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float l1 = mid + sq, l2 = mid - sq;
+            const int r = (int)ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+            const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+            const float2 q = uv[i];
+            int x0, y0, x1, y1;
+            tile_rect(q.x, q.y, r, gx, gy, x0, y0, x1, y1);
+            if ((x1 - x0) * (y1 - y0) != 0) {
+                if (ORTHO) {
+                    o0 = cov[2] / det; o1 = -cov[1] / det; o2 = cov[0] / det;
+                } else {
+                    const float di = 1.f / det;
+                    o0 = cov[2] * di; o1 = -cov[1] * di; o2 = cov[0] * di;
+                }
+                orad = r;
+                otiles = (y1 - y0) * (x1 - x0);
+            }
+        }
     }
-    radius[i] = r;
-    tiles[i] = (y1 - y0) * (x1 - x0);
+    conic[3 * i] = o0; conic[3 * i + 1] = o1; conic[3 * i + 2] = o2;
+    radius[i] = orad;
+    tiles[i] = otiles;
 }
 
 // reference: src/ewa_project.cu:85-252
@@ -288,6 +310,8 @@ ewa_bwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ c
 #pragma unroll
     for (int k = 0; k < 14; ++k) cg[k] = 0.f;
     bool live = (i < P) && (radius[i] > 0);
+    bool wrote = false;   // dL_dcov3d row written
+    bool wrote_xyz = false;
     if (live) {
         Cam c;
         load_cam(ORTHO ? nullptr : intr, extr, c);
@@ -306,12 +330,13 @@ ewa_bwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ c
             const float dcy = nom * (2 * cov[1] * cov[2] * gx_ - (det + 2 * cov[1] * cov[1]) * gy_ + 2 * cov[0] * cov[1] * gz_);
             const float dcz = nom * ((det - cov[0] * cov[2]) * gx_ + cov[0] * cov[1] * gy_ - cov[0] * cov[0] * gz_);
             float *o = dL_dcov3d + 6 * (size_t)i;
-            o[0] += a[0] * a[0] * dcx + a[0] * b[0] * dcy + b[0] * b[0] * dcz;
-            o[1] += 2 * a[0] * a[1] * dcx + (a[0] * b[1] + b[0] * a[1]) * dcy + 2 * b[0] * b[1] * dcz;
-            o[2] += 2 * a[0] * a[2] * dcx + (a[0] * b[2] + b[0] * a[2]) * dcy + 2 * b[0] * b[2] * dcz;
-            o[3] += a[1] * a[1] * dcx + a[1] * b[1] * dcy + b[1] * b[1] * dcz;
-            o[4] += 2 * a[1] * a[2] * dcx + (a[1] * b[2] + b[1] * a[2]) * dcy + 2 * b[1] * b[2] * dcz;
-            o[5] += a[2] * a[2] * dcx + a[2] * b[2] * dcy + b[2] * b[2] * dcz;
+            o[0] = a[0] * a[0] * dcx + a[0] * b[0] * dcy + b[0] * b[0] * dcz;
+            o[1] = 2 * a[0] * a[1] * dcx + (a[0] * b[1] + b[0] * a[1]) * dcy + 2 * b[0] * b[1] * dcz;
+            o[2] = 2 * a[0] * a[2] * dcx + (a[0] * b[2] + b[0] * a[2]) * dcy + 2 * b[0] * b[2] * dcz;
+            o[3] = a[1] * a[1] * dcx + a[1] * b[1] * dcy + b[1] * b[1] * dcz;
+            o[4] = 2 * a[1] * a[2] * dcx + (a[1] * b[2] + b[1] * a[2]) * dcy + 2 * b[1] * b[2] * dcz;
+            o[5] = a[2] * a[2] * dcx + a[2] * b[2] * dcy + b[2] * b[2] * dcz;
+            wrote = true;
             if (!ORTHO) {
                 const float S[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
                 float da[3], db[3];
@@ -334,6 +359,7 @@ ewa_bwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ c
                 dL_dxyz[3 * i + 0] = c.e[0] * dtx + c.e[4] * dty + c.e[8] * dtz;
                 dL_dxyz[3 * i + 1] = c.e[1] * dtx + c.e[5] * dty + c.e[9] * dtz;
                 dL_dxyz[3 * i + 2] = c.e[2] * dtx + c.e[6] * dty + c.e[10] * dtz;
+                wrote_xyz = true;
                 if (CAMGRAD) {
                     cg[0] = tz * dJ00 - t[0] * tz2 * dJ02;
                     cg[1] = tz * dJ11 - t[1] * tz2 * dJ12;
@@ -346,6 +372,16 @@ ewa_bwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ c
                     }
                 }
             }
+        }
+    }
+    if (i < P) {  // every element is written: zeros where nothing flows
+        if (!wrote) {
+            float *o = dL_dcov3d + 6 * (size_t)i;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = 0.f;
+        }
+        if (!wrote_xyz) {
+            dL_dxyz[3 * i] = 0.f; dL_dxyz[3 * i + 1] = 0.f; dL_dxyz[3 * i + 2] = 0.f;
         }
     }
     if (CAMGRAD && !ORTHO) {
@@ -391,7 +427,15 @@ sh_fwd_kernel(int P, const float *__restrict__ shs, const float *__restrict__ di
               const uint8_t *__restrict__ visible, float *__restrict__ colors, uint8_t *__restrict__ clamped) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const int i = blockIdx.x * PW_BLOCK + threadIdx.x;
-    if (i >= P || !visible[i]) return;
+    if (i >= P) return;
+    if (!visible[i]) {  // reference: colors zero-init, clamped ones-init
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            colors[3 * i + c] = 0.f;
+            if (!FREE) clamped[3 * i + c] = 1;
+        }
+        return;
+    }
     float B[16];
     sh_basis(DEG, dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], B);
     const float *sh = shs + (size_t)i * NB * 3;
@@ -422,7 +466,14 @@ sh_bwd_kernel(int P, const float *__restrict__ shs, const float *__restrict__ di
               const float *__restrict__ dL_dcolors, float *__restrict__ dL_dshs, float *__restrict__ dL_ddirs) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const int i = blockIdx.x * PW_BLOCK + threadIdx.x;
-    if (i >= P || !visible[i]) return;
+    if (i >= P) return;
+    if (!visible[i]) {
+        float *oz = dL_dshs + (size_t)i * NB * 3;
+#pragma unroll
+        for (int k = 0; k < NB * 3; ++k) oz[k] = 0.f;
+        dL_ddirs[3 * i] = 0.f; dL_ddirs[3 * i + 1] = 0.f; dL_ddirs[3 * i + 2] = 0.f;
+        return;
+    }
     const float x = dirs[3 * i], y = dirs[3 * i + 1], z = dirs[3 * i + 2];
     float B[16];
     sh_basis(DEG, x, y, z, B);

@@ -55,8 +55,8 @@ class _ProjectPoint(torch.autograd.Function):
         extr_c = _extr12(extr)
         intr_c = None if ortho else _intr4(intr)
         P = xyz.shape[0]
-        uv = torch.zeros(P, 2, dtype=torch.float32, device=xyz.device)
-        depth = torch.zeros(P, 1, dtype=torch.float32, device=xyz.device)
+        uv = torch.empty(P, 2, dtype=torch.float32, device=xyz.device)      # kernels write every element
+        depth = torch.empty(P, 1, dtype=torch.float32, device=xyz.device)   # (zeros for culled points)
         L.check(L.lib().splat_project_point_forward(
             L.ci(P), L.ptr(xyz), L.ptr(intr_c), L.ptr(extr_c), L.ci(W), L.ci(H), L.cf(nearest), L.cf(extent),
             L.ci(1 if ortho else 0), L.ptr(uv), L.ptr(depth), L.stream()))
@@ -73,7 +73,7 @@ class _ProjectPoint(torch.autograd.Function):
         P = xyz.shape[0]
         dL_duv = L.need(dL_duv, "dL_duv")
         dL_ddepth = L.need(dL_ddepth, "dL_ddepth")
-        dxyz = torch.zeros_like(xyz)
+        dxyz = torch.empty_like(xyz)
         g_intr, g_extr = ctx.cam_grad
         dintr = torch.zeros(4, dtype=torch.float32, device=xyz.device) if g_intr else None
         dextr = torch.zeros(12, dtype=torch.float32, device=xyz.device) if g_extr else None
@@ -108,7 +108,7 @@ class _ComputeCov3D(torch.autograd.Function):
         uquats = _points(uquats, "uquats", 4)
         P = scales.shape[0]
         vis = _visible(visible, P, scales.device)
-        cov3d = torch.zeros(P, 6, dtype=torch.float32, device=scales.device)
+        cov3d = torch.empty(P, 6, dtype=torch.float32, device=scales.device)
         L.check(L.lib().splat_compute_cov3d_forward(L.ci(P), L.ptr(scales), L.ptr(uquats), L.ptr(vis), L.ptr(cov3d),
                                                     L.stream()))
         ctx.save_for_backward(scales, uquats, vis)
@@ -119,8 +119,8 @@ class _ComputeCov3D(torch.autograd.Function):
         scales, uquats, vis = ctx.saved_tensors
         P = scales.shape[0]
         g = L.need(dL_dcov3d, "dL_dcov3d")
-        ds = torch.zeros_like(scales)
-        dq = torch.zeros_like(uquats)
+        ds = torch.empty_like(scales)
+        dq = torch.empty_like(uquats)
         L.check(L.lib().splat_compute_cov3d_backward(L.ci(P), L.ptr(scales), L.ptr(uquats), L.ptr(vis), L.ptr(g),
                                                      L.ptr(ds), L.ptr(dq), L.stream()))
         return ds, dq, None
@@ -142,9 +142,9 @@ class _EWAProject(torch.autograd.Function):
         intr_c = None if ortho else _intr4(intr)
         P = xyz.shape[0]
         vis = _visible(visible, P, xyz.device)
-        conic = torch.zeros(P, 3, dtype=torch.float32, device=xyz.device)
-        radius = torch.zeros(P, dtype=torch.int32, device=xyz.device)
-        tiles = torch.zeros(P, dtype=torch.int32, device=xyz.device)
+        conic = torch.empty(P, 3, dtype=torch.float32, device=xyz.device)
+        radius = torch.empty(P, dtype=torch.int32, device=xyz.device)
+        tiles = torch.empty(P, dtype=torch.int32, device=xyz.device)
         L.check(L.lib().splat_ewa_project_forward(
             L.ci(P), L.ptr(xyz), L.ptr(cov3d), L.ptr(intr_c), L.ptr(extr_c), L.ptr(uv), L.ci(W), L.ci(H), L.ptr(vis),
             L.ci(1 if ortho else 0), L.ptr(conic), L.ptr(radius), L.ptr(tiles), L.stream()))
@@ -161,8 +161,8 @@ class _EWAProject(torch.autograd.Function):
         xyz, cov3d, intr_c, extr_c, radius = ctx.saved_tensors
         P = xyz.shape[0]
         g = L.need(dL_dconic, "dL_dconic")
-        dxyz = torch.zeros_like(xyz)
-        dcov = torch.zeros_like(cov3d)
+        dxyz = torch.empty_like(xyz)
+        dcov = torch.empty_like(cov3d)
         g_intr, g_extr = ctx.cam_grad
         dintr = torch.zeros(4, dtype=torch.float32, device=xyz.device) if g_intr else None
         dextr = torch.zeros(12, dtype=torch.float32, device=xyz.device) if g_extr else None
@@ -204,8 +204,8 @@ class _ComputeSH(torch.autograd.Function):
             raise ValueError(f"shs holds {shs.shape[1]} coefficients per point, degree {degree} needs {(degree + 1) ** 2}")
         dirs = _points(view_dirs, "view_dirs", 3)
         vis = _visible(visible, P, shs.device)
-        colors = torch.zeros(P, 3, dtype=torch.float32, device=shs.device)
-        clamped = None if free else torch.ones(P, 3, dtype=torch.uint8, device=shs.device)
+        colors = torch.empty(P, 3, dtype=torch.float32, device=shs.device)
+        clamped = None if free else torch.empty(P, 3, dtype=torch.uint8, device=shs.device)
         L.check(L.lib().splat_compute_sh_forward(L.ci(P), L.ptr(shs), L.ci(degree), L.ptr(dirs), L.ptr(vis),
                                                  L.ci(1 if free else 0), L.ptr(colors), L.ptr(clamped), L.stream()))
         ctx.meta = (degree, bool(free))
@@ -223,8 +223,8 @@ class _ComputeSH(torch.autograd.Function):
         clamped = None if free else saved[3]
         P = shs.shape[0]
         g = L.need(dL_dcolor, "dL_dcolor")
-        dshs = torch.zeros_like(shs)
-        ddirs = torch.zeros_like(dirs)
+        dshs = torch.zeros_like(shs) if shs.shape[1] != (degree + 1) ** 2 else torch.empty_like(shs)
+        ddirs = torch.empty_like(dirs)
         L.check(L.lib().splat_compute_sh_backward(L.ci(P), L.ptr(shs), L.ci(degree), L.ptr(dirs), L.ptr(vis),
                                                   L.ptr(clamped), L.ci(1 if free else 0), L.ptr(g), L.ptr(dshs),
                                                   L.ptr(ddirs), L.stream()))

@@ -87,7 +87,7 @@ class _AlphaBlend(torch.autograd.Function):
         out = torch.empty(C, H, W, dtype=torch.float32, device=dev)
         final_T = torch.empty(H, W, dtype=torch.float32, device=dev)
         ncontrib = torch.empty(H, W, dtype=torch.int32, device=dev)
-        gs_idx = torch.full((H, W, K), -1, dtype=torch.int32, device=dev) if K > 0 else None
+        gs_idx = torch.empty(H, W, K, dtype=torch.int32, device=dev) if K > 0 else None  # kernel pads with -1
         L.check(L.lib().splat_alpha_blending_forward(
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias_c),
             L.ptr(idx_sorted), L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ci(K), L.ci(1 if trunc else 0),
