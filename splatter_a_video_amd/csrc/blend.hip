@@ -235,14 +235,6 @@ blend_fwd_kernel(const BlendArgs A) {
         if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;  // every pixel of the tile is saturated
         if (!alld) {
             const int cnt = build_list<CH, SB, BIAS>(L, w, lane, nb, bx0, bx1, by0, by1, [](int) { return true; });
-            int en[U];
-            float4 g0n[U], g1n[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {  // records of the first trip
-                en[u] = L.list[w][u];
-                g0n[u] = L.g0[en[u]];
-                g1n[u] = L.g1[en[u]];
-            }
             for (int j0 = 0; j0 < cnt; j0 += U) {
                 int e[U];
                 float4 g0[U], g1[U];
@@ -251,13 +243,9 @@ blend_fwd_kernel(const BlendArgs A) {
                 bool any_ok = false;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    e[u] = en[u]; g0[u] = g0n[u]; g1[u] = g1n[u];
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {  // prefetch the next trip (padded list -> inert slot past the end)
-                    en[u] = L.list[w][imin_(j0 + U + u, SB + 7)];
-                    g0n[u] = L.g0[en[u]];
-                    g1n[u] = L.g1[en[u]];
+                    e[u] = L.list[w][j0 + u];
+                    g0[u] = L.g0[e[u]];
+                    g1[u] = L.g1[e[u]];
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -455,14 +443,6 @@ blend_bwd_pair_kernel(const BlendArgs A) {
                                                  [=](int e) { return top - e < wmax; });
         unsigned long long wrote = 0ull;
         float *slab = s_acc[w];
-        int en[U];
-        float4 g0n[U], g1n[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            en[u] = L.list[w][u];
-            g0n[u] = L.g0[en[u]];
-            g1n[u] = L.g1[en[u]];
-        }
         for (int j0 = 0; j0 < cnt; j0 += U) {
             int e[U];
             float4 g0[U], g1[U];
@@ -471,13 +451,9 @@ blend_bwd_pair_kernel(const BlendArgs A) {
             bool any_ok = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                e[u] = en[u]; g0[u] = g0n[u]; g1[u] = g1n[u];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {  // prefetch the next trip
-                en[u] = L.list[w][imin_(j0 + U + u, SB + 7)];
-                g0n[u] = L.g0[en[u]];
-                g1n[u] = L.g1[en[u]];
+                e[u] = L.list[w][j0 + u];
+                g0[u] = L.g0[e[u]];
+                g1[u] = L.g1[e[u]];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
