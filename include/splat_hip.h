@@ -79,7 +79,7 @@ int splat_compute_sh_forward(int P, const float *shs, int degree, const float *d
 int splat_compute_sh_backward(int P, const float *shs, int degree, const float *dirs, const uint8_t *visible,
                               const uint8_t *clamped /*NULL when free*/, int free_variant,
                               const float *dL_dcolors, float *dL_dshs /*rows of (deg+1)^2 triplets written*/,
-                              float *dL_ddirs,
+                              float *dL_ddirs /*NULL: direction gradient not needed (skips reading shs)*/,
                               splat_stream_t stream);
 
 /* ---- sort_gaussian : replaces computeGaussianKey + torch.sort + gather + computeTileGaussianRange
@@ -95,13 +95,14 @@ size_t splat_bin_scratch_bytes(int P, int W, int H);
 /* gcount[P] (optional, may be NULL): number of tiles each Gaussian touches (0 when radius <= 0). */
 int splat_bin_count(int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
                     int32_t *tile_range, int32_t *M_out, int32_t *gcount, splat_stream_t stream);
-/* goff_incl[P] / inv_pos[M] (optional, both or neither): given the INCLUSIVE prefix sum of gcount, also
- * emit the inverse pair map inv_pos[goff_excl[id] + k] = sorted position of Gaussian id's k-th tile
- * (row-major inside its tile rectangle).  The atomic-free blend backward consumes it. */
+/* Pair map (optional; goff_incl, owner, slot_sorted all given or all NULL): with the INCLUSIVE
+ * prefix sum goff_incl[P] of gcount, every (Gaussian, tile) pair owns the slot goff_excl[id] + k (k-th tile,
+ * row-major inside the splat's tile rectangle); the sort then also emits slot_sorted[M] = slot of each
+ * sorted entry (owner[M] is workspace: Gaussian id of each slot).  The atomic-free blend backward consumes it. */
 int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
                    void *scratch, const int32_t *tile_range, int64_t capacity, uint64_t *keys,
-                   int32_t *idx_sorted, int32_t *overflow_out, const int32_t *goff_incl, int32_t *inv_pos,
-                   splat_stream_t stream);
+                   int32_t *idx_sorted, int32_t *overflow_out, const int32_t *goff_incl,
+                   int32_t *owner, int32_t *slot_sorted, splat_stream_t stream);
 
 /* ---- alpha blending : replaces alphaBlendingForward/Backward, ...Enhanced, ...WithBias
  *      (src/alpha_blending.cu:251-582, src/alpha_blending_enhanced.cu:275-627,
@@ -116,18 +117,18 @@ int splat_alpha_blending_forward(int P, int C, const float *uv, const float *con
                                  splat_stream_t stream);
 /* dL_dfeature is [P,C]; dL_dopacity_bias NULL unless bias given.
  * Two modes:
- *  - atomic mode (goff_incl / inv_pos / pair_scratch NULL): wave-reduced hardware float atomics;
+ *  - atomic mode (goff_incl / slot_sorted / pair_scratch NULL): wave-reduced hardware float atomics;
  *    all gradient outputs must be zero-init.
- *  - pair mode (all three given; goff_incl / inv_pos from splat_bin_sort for THIS idx_sorted;
- *    pair_scratch = M * splat_blend_pair_floats(C, bias != NULL) floats, uninitialised): no global
- *    atomics, every gradient element is written (no zero-init needed). */
+ *  - pair mode (all three given; goff_incl / slot_sorted from splat_bin_sort for THIS idx_sorted;
+ *    pair_scratch = M * splat_blend_pair_floats(C, bias != NULL) floats, 64-byte aligned,
+ *    uninitialised): no global atomics, every gradient element is written (no zero-init needed). */
 size_t splat_blend_pair_floats(int C, int has_bias);
 int splat_alpha_blending_backward(int P, int C, const float *uv, const float *conic, const float *opacity,
                                   const float *feature, const float *opacity_bias, const int32_t *idx_sorted,
                                   const int32_t *tile_range, float bg, int W, int H, const float *final_T,
                                   const int32_t *ncontrib, const float *dL_dout, float *dL_duv, float *dL_dabs_uv,
                                   float *dL_dconic, float *dL_dopacity, float *dL_dfeature,
-                                  float *dL_dopacity_bias, const int32_t *goff_incl, const int32_t *inv_pos,
+                                  float *dL_dopacity_bias, const int32_t *goff_incl, const int32_t *slot_sorted,
                                   float *pair_scratch, splat_stream_t stream);
 
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */

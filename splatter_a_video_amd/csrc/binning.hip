@@ -13,7 +13,8 @@
 //   K3 bin_scatter  same chunking as K1; LDS counters start at the chunk's base, ds_add_rtn
 //                   hands out the slot; writes key = (depth bits << 32 | gaussian id);
 //   K4 tile_sort    one workgroup per tile: bitonic sort of the tile's keys in LDS (all
-//                   comparators ascending -> no power-of-two padding needed), writes ids.
+//                   comparators ascending -> no power-of-two padding needed), writes ids (and,
+//                   in pair-map mode, the Gaussian-major pair slot of every sorted entry).
 //
 // Since keys inside a tile are unique (id in the low word) the result is deterministic and equals
 // a STABLE sort of the reference keys (ties: ascending Gaussian id).  No host synchronisation.
@@ -161,7 +162,10 @@ __global__ void __launch_bounds__(BIN_BLOCK)
 bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict__ depth,
                    const int *__restrict__ radius, int gx, int gy, int T, int chunk, int *__restrict__ matrix,
                    const int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
-                   int *__restrict__ overflow) {
+                   int *__restrict__ overflow, const int *__restrict__ goff_incl, int *__restrict__ owner) {
+    // With goff_incl (inclusive prefix of tiles per Gaussian) the low key word is the pair slot
+    // j = goff_excl[i] + k (k-th tile of the splat's rectangle) instead of the Gaussian id: slots grow with
+    // the id, so ties still order by ascending id, and the sorted keys directly give the pair map.
     extern __shared__ __attribute__((aligned(16))) int cnt[];
     const int wg = blockIdx.x;
     if (LDS) {
@@ -176,15 +180,21 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
         const float2 q = uv[i];
         int x0, y0, x1, y1;
         tile_rect(q.x, q.y, r, gx, gy, x0, y0, x1, y1);
-        const unsigned long long key = ((unsigned long long)__float_as_uint(depth[i]) << 32) | (unsigned)i;
+        const unsigned long long dkey = (unsigned long long)__float_as_uint(depth[i]) << 32;
+        int j = goff_incl ? (i > 0 ? goff_incl[i - 1] : 0) : 0;
         for (int ty = y0; ty < y1; ++ty)
             for (int tx = x0; tx < x1; ++tx) {
                 const int t = ty * gx + tx;
                 int slot;
                 if (LDS) slot = atomicAdd(&cnt[t], 1);
                 else slot = tile_range[2 * t] + atomicAdd(&matrix[T + t], 1);  // second row = fill counters
-                if ((long long)slot < capacity) keys[slot] = key;
-                else *overflow = 1;
+                if ((long long)slot < capacity) {
+                    keys[slot] = dkey | (unsigned)(goff_incl ? j : i);
+                    if (goff_incl && (long long)j < capacity) owner[j] = i;
+                } else {
+                    *overflow = 1;
+                }
+                ++j;
             }
     }
 }
@@ -226,8 +236,7 @@ __device__ __forceinline__ void bitonic_any_n(KeyPtr a, int n) {
 
 __global__ void __launch_bounds__(SORT_BLOCK)
 tile_sort_kernel(const int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
-                 int *__restrict__ idx_sorted, const float2 *__restrict__ uv, const int *__restrict__ radius, int gx,
-                 int gy, const int *__restrict__ goff_incl, int *__restrict__ inv_pos) {
+                 int *__restrict__ idx_sorted, const int *__restrict__ owner, int *__restrict__ slot_sorted) {
     __shared__ __attribute__((aligned(16))) unsigned long long sk[SORT_LDS_KEYS];
     const int t = blockIdx.x;
     const long long r0 = tile_range[2 * t];
@@ -236,30 +245,31 @@ tile_sort_kernel(const int *__restrict__ tile_range, long long capacity, unsigne
     const int n = (int)(r1 - r0);
     if (n <= 0) return;
     unsigned long long *g = keys + r0;
+    // low key word: Gaussian id, or (pair-map mode) the pair slot whose owner is the Gaussian id
     if (n <= SORT_LDS_KEYS) {
         for (int i = threadIdx.x; i < n; i += SORT_BLOCK) sk[i] = g[i];
         __syncthreads();
         if (n > 1) bitonic_any_n(sk, n);
-        for (int i = threadIdx.x; i < n; i += SORT_BLOCK) idx_sorted[r0 + i] = (int)(unsigned)(sk[i] & 0xffffffffull);
-        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += SORT_BLOCK) {
+            const int lo = (int)(unsigned)(sk[i] & 0xffffffffull);
+            if (slot_sorted) {
+                slot_sorted[r0 + i] = lo;
+                idx_sorted[r0 + i] = owner[lo];
+            } else {
+                idx_sorted[r0 + i] = lo;
+            }
+        }
     } else {
         __syncthreads();
         bitonic_any_n((volatile unsigned long long *)g, n);
-        for (int i = threadIdx.x; i < n; i += SORT_BLOCK) idx_sorted[r0 + i] = (int)(unsigned)(g[i] & 0xffffffffull);
-        __syncthreads();
-    }
-    // inverse pair map: the k-th tile (row-major inside the splat's rectangle) of Gaussian id sits at sorted
-    // position s  ->  inv_pos[goff_excl[id] + k] = s   (used by the atomic-free blend backward)
-    if (inv_pos) {
-        const int tx = t % gx, ty = t / gx;
         for (int i = threadIdx.x; i < n; i += SORT_BLOCK) {
-            const int id = idx_sorted[r0 + i];
-            const float2 q = uv[id];
-            int x0, y0, x1, y1;
-            tile_rect(q.x, q.y, radius[id], gx, gy, x0, y0, x1, y1);
-            const int k = (ty - y0) * (x1 - x0) + (tx - x0);
-            const int base = id > 0 ? goff_incl[id - 1] : 0;
-            inv_pos[base + k] = (int)(r0 + i);
+            const int lo = (int)(unsigned)(g[i] & 0xffffffffull);
+            if (slot_sorted) {
+                slot_sorted[r0 + i] = lo;
+                idx_sorted[r0 + i] = owner[lo];
+            } else {
+                idx_sorted[r0 + i] = lo;
+            }
         }
     }
 }
@@ -306,12 +316,16 @@ extern "C" int splat_bin_count(int P, const float *uv, const int32_t *radius, in
 
 extern "C" int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
                               void *scratch, const int32_t *tile_range, int64_t capacity, uint64_t *keys,
-                              int32_t *idx_sorted, int32_t *overflow_out, const int32_t *goff_incl, int32_t *inv_pos,
-                              splat_stream_t stream) {
+                              int32_t *idx_sorted, int32_t *overflow_out, const int32_t *goff_incl,
+                              int32_t *owner_scratch, int32_t *slot_sorted, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0 && capacity >= 0, "bad sizes");
     SPLAT_CHECK_ARG(scratch && tile_range && overflow_out, "null pointer");
     if (P == 0 || capacity == 0) return SPLAT_OK;
     SPLAT_CHECK_ARG(uv && depth && radius && keys && idx_sorted, "null pointer");
+    {
+        const int npm = (goff_incl != nullptr) + (owner_scratch != nullptr) + (slot_sorted != nullptr);
+        SPLAT_CHECK_ARG(npm == 0 || npm == 3, "goff_incl, owner_scratch and slot_sorted go together");
+    }
     hipStream_t s = (hipStream_t)stream;
     const BinPlan p = make_plan(P, W, H);
     char *base = (char *)scratch;
@@ -319,7 +333,7 @@ extern "C" int splat_bin_sort(int P, const float *uv, const float *depth, const 
     if (p.lds) {
         SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<true>, dim3(p.NB), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
                      P, (const float2 *)uv, depth, radius, p.gx, p.gy, p.T, p.chunk, matrix, tile_range,
-                     (long long)capacity, (unsigned long long *)keys, overflow_out);
+                     (long long)capacity, (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch);
     } else {
         // fill counters live in tile_count's neighbour: reuse matrix row "1" = matrix + T (allocated: NB=1 -> need 2 rows)
         SPLAT_CHECK_HIP(hipMemsetAsync(matrix + p.T, 0, (size_t)p.T * sizeof(int), s));
@@ -327,12 +341,11 @@ extern "C" int splat_bin_sort(int P, const float *uv, const float *depth, const 
         const int chunk = (P + nblk - 1) / nblk;
         SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<false>, dim3(nblk), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
                      depth, radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, tile_range, (long long)capacity,
-                     (unsigned long long *)keys, overflow_out);
+                     (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch);
     }
     SPLAT_POST_LAUNCH();
-    SPLAT_CHECK_ARG((goff_incl == nullptr) == (inv_pos == nullptr), "goff_incl and inv_pos go together");
     SPLAT_LAUNCH("tile_sort", tile_sort_kernel, dim3(p.T), dim3(SORT_BLOCK), 0, s, tile_range, (long long)capacity,
-                 (unsigned long long *)keys, idx_sorted, (const float2 *)uv, radius, p.gx, p.gy, goff_incl, inv_pos);
+                 (unsigned long long *)keys, idx_sorted, owner_scratch, slot_sorted);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }

@@ -20,9 +20,9 @@
 //   * backward ("pair" mode, used when idx_sorted comes from our sort_gaussian): per-lane partial
 //     gradients are wave-reduced with in-place DPP adds (row_shr x4, row_bcast x2), lane 63
 //     stores the (8+C)-float record into the wave's private LDS slab; after the super-batch the
-//     four slabs are summed and written with ONE coalesced store per super-batch into
-//     pair_buf[sorted position]; pair_reduce_kernel sums each Gaussian's records through the
-//     inverse pair map produced by the tile sort.  No global atomics at all.
+//     four slabs are summed and every record (padded to whole 64-B sectors) is stored at its
+//     Gaussian-major pair slot (slot_sorted[] comes out of the tile sort); pair_reduce_kernel then
+//     streams each Gaussian's contiguous records.  No global atomics at all.
 //   * backward ("atomic" mode, foreign idx_sorted): same replay per wave, one hardware float
 //     atomic per (wave, splat, component).
 #include <stdlib.h>
@@ -51,9 +51,9 @@ struct BlendArgs {
     const float *dL_dout;
     float *dL_duv, *dL_dabs_uv, *dL_dconic, *dL_dopacity, *dL_dfeature, *dL_dbias;
     // atomic-free backward: per-(tile,splat) partial sums + inverse pair map
-    float *pair_buf;        // [M, NC] partial gradients in sorted-pair order
-    const int *goff_incl;   // [P] inclusive prefix of tiles per Gaussian
-    const int *inv_pos;     // [M] pair slot -> sorted position
+    float *pair_buf;        // [M, NCP] partial gradients, one 64-B-aligned record per pair SLOT (Gaussian-major)
+    const int *goff_incl;   // [P] inclusive prefix of tiles per Gaussian (slot ranges)
+    const int *slot_sorted; // [M] sorted position -> pair slot
     int accumulate;         // reduce: add to the geometry gradients (channel chunks > 0)
 };
 
@@ -418,8 +418,11 @@ blend_bwd_pair_kernel(const BlendArgs A) {
     const int2 range = A.tile_range[tile];
     const int len = range.y - range.x;
     const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
-    float *pb = A.pair_buf + (size_t)range.x * NCP;
-    for (int i = n * NCP + tid; i < len * NCP; i += 256) pb[i] = 0.f;  // entries nobody replays: zero record
+    const int *slots = A.slot_sorted + range.x;
+    for (int i = n * NCP + tid; i < len * NCP; i += 256) {  // entries nobody replays: zero record
+        const int ql = i / NCP;
+        A.pair_buf[(size_t)slots[ql] * NCP + (i - ql * NCP)] = 0.f;
+    }
     if (n <= 0) return;
 
     // thread e < SB stages entry q = top - e
@@ -493,10 +496,10 @@ blend_bwd_pair_kernel(const BlendArgs A) {
         }
         if (lane == 0) s_mask[w] = wrote;
         __syncthreads();
-        // ---- combine the four slabs, one coalesced store: entry e <-> sorted position top - e
+        // ---- combine the four slabs; each record (NCP floats = whole 64-B sectors) goes to its pair slot,
+        //      16 consecutive lanes write one sector: entry e <-> sorted position top - e
         {
             const int lo = top - nb + 1;
-            float *dst = pb + (size_t)lo * NCP;
             const unsigned long long m0 = s_mask[0], m1 = s_mask[1], m2 = s_mask[2], m3 = s_mask[3];
             for (int i = tid; i < nb * NCP; i += 256) {
                 const int ql = i / NCP, c = i - ql * NCP;
@@ -508,70 +511,74 @@ blend_bwd_pair_kernel(const BlendArgs A) {
                     if ((m2 >> e) & 1ull) v += s_acc[2][e * NC + c];
                     if ((m3 >> e) & 1ull) v += s_acc[3][e * NC + c];
                 }
-                dst[i] = v;
+                A.pair_buf[(size_t)slots[lo + ql] * NCP + c] = v;
             }
         }
         __syncthreads();
     }
 }
 
-// sums each Gaussian's pair records (inverse pair map) into the final gradients -- plain stores.
-// Four records are fetched per trip so that the indirect loads overlap (most Gaussians touch <= 4 tiles).
-struct __attribute__((packed, aligned(4))) F4 {
-    float x, y, z, w;
-};
-
+// sums each Gaussian's pair records (contiguous slots [goff[i-1], goff[i])) into the final gradients.
+// Four lanes per Gaussian: lane `sub` owns floats [4*sub, 4*sub+4) of every 16-float sector, so a
+// quad reads one whole 64-B sector per record (coalesced), accumulates in registers with no
+// cross-lane traffic, and writes its own components with plain stores.
 template <bool BIAS>
-__global__ void __launch_bounds__(256)
-pair_reduce_kernel(const BlendArgs A, int NC) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= A.P) return;
+__device__ __forceinline__ void store_component(const BlendArgs &A, int i, int k, float v) {
     constexpr int NG = BIAS ? 9 : 8;
+    float *dst;
+    if (k < 2) dst = A.dL_duv + 2 * i + k;
+    else if (k < 4) dst = A.dL_dabs_uv + 2 * i + (k - 2);
+    else if (k < 7) dst = A.dL_dconic + 3 * i + (k - 4);
+    else if (k == 7) dst = A.dL_dopacity + i;
+    else if (BIAS && k == 8) dst = A.dL_dbias + i;
+    else {
+        if (k - NG >= A.cn) return;  // padding
+        A.dL_dfeature[(size_t)i * A.C + A.c0 + (k - NG)] = v;  // features of this chunk: always plain store
+        return;
+    }
+    *dst = A.accumulate ? *dst + v : v;
+}
+
+template <bool BIAS, int NCP>
+__global__ void __launch_bounds__(256)
+pair_reduce_kernel(const BlendArgs A) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 2, sub = t & 3;
+    if (i >= A.P) return;
     const int beg = i > 0 ? A.goff_incl[i - 1] : 0, end = A.goff_incl[i];
-    float g[NG];
+    constexpr int NS = NCP / 16;  // sectors per record
+    float4 a[NS];
 #pragma unroll
-    for (int k = 0; k < NG; ++k) g[k] = 0.f;
-    float *df = A.dL_dfeature + (size_t)i * A.C + A.c0;
-    // features: register groups of 8 to bound register use for wide chunks
-    for (int k0 = 0; k0 < A.cn; k0 += 8) {
-        float fs[8];
+    for (int c = 0; c < NS; ++c) a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *base = A.pair_buf + 4 * sub;
+    int j = beg;
+    for (; j + 1 < end; j += 2) {  // two records in flight
+        float4 v0[NS], v1[NS];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) fs[k] = 0.f;
-        for (int j = beg; j < end; j += 4) {
-            int sp[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) sp[u] = (j + u < end) ? A.inv_pos[j + u] : -1;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (sp[u] < 0) continue;
-                const float *rec = A.pair_buf + (size_t)sp[u] * NC;
-                if (k0 == 0) {
-                    const float4 r0 = *reinterpret_cast<const float4 *>(rec), r1 = *reinterpret_cast<const float4 *>(rec + 4);
-                    g[0] += r0.x; g[1] += r0.y; g[2] += r0.z; g[3] += r0.w;
-                    g[4] += r1.x; g[5] += r1.y; g[6] += r1.z; g[7] += r1.w;
-                    if (BIAS) g[NG - 1] += rec[8];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (k0 + k < A.cn) fs[k] += rec[NG + k0 + k];
-            }
+        for (int c = 0; c < NS; ++c) {
+            v0[c] = *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c);
+            v1[c] = *reinterpret_cast<const float4 *>(base + (size_t)(j + 1) * NCP + 16 * c);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k0 + k < A.cn) df[k0 + k] = fs[k];
+        for (int c = 0; c < NS; ++c) {
+            a[c].x += v0[c].x; a[c].y += v0[c].y; a[c].z += v0[c].z; a[c].w += v0[c].w;
+            a[c].x += v1[c].x; a[c].y += v1[c].y; a[c].z += v1[c].z; a[c].w += v1[c].w;
+        }
     }
-    if (A.accumulate) {
-        A.dL_duv[2 * i] += g[0]; A.dL_duv[2 * i + 1] += g[1];
-        A.dL_dabs_uv[2 * i] += g[2]; A.dL_dabs_uv[2 * i + 1] += g[3];
-        A.dL_dconic[3 * i] += g[4]; A.dL_dconic[3 * i + 1] += g[5]; A.dL_dconic[3 * i + 2] += g[6];
-        A.dL_dopacity[i] += g[7];
-        if (BIAS) A.dL_dbias[i] += g[NG - 1];
-    } else {
-        A.dL_duv[2 * i] = g[0]; A.dL_duv[2 * i + 1] = g[1];
-        A.dL_dabs_uv[2 * i] = g[2]; A.dL_dabs_uv[2 * i + 1] = g[3];
-        A.dL_dconic[3 * i] = g[4]; A.dL_dconic[3 * i + 1] = g[5]; A.dL_dconic[3 * i + 2] = g[6];
-        A.dL_dopacity[i] = g[7];
-        if (BIAS) A.dL_dbias[i] = g[NG - 1];
+    if (j < end) {
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c);
+            a[c].x += v.x; a[c].y += v.y; a[c].z += v.z; a[c].w += v.w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        const int k = 16 * c + 4 * sub;
+        store_component<BIAS>(A, i, k + 0, a[c].x);
+        store_component<BIAS>(A, i, k + 1, a[c].y);
+        store_component<BIAS>(A, i, k + 2, a[c].z);
+        store_component<BIAS>(A, i, k + 3, a[c].w);
     }
 }
 
@@ -709,10 +716,9 @@ static int launch_bwd(const BlendArgs &A, int T, bool bias, bool pair, hipStream
 #undef BWD
     SPLAT_POST_LAUNCH();
     if (pair) {
-        const int NC = (((bias ? 9 : 8) + CH) + 15) & ~15;  // padded record stride (PairCfg::NCP)
-        const dim3 rgrid((unsigned)((A.P + 255) / 256));
-        if (bias) SPLAT_LAUNCH("pair_reduce", pair_reduce_kernel<true>, rgrid, dim3(256), 0, s, A, NC);
-        else SPLAT_LAUNCH("pair_reduce", pair_reduce_kernel<false>, rgrid, dim3(256), 0, s, A, NC);
+        const dim3 rgrid((unsigned)(((size_t)A.P * 4 + 255) / 256));
+        if (bias) SPLAT_LAUNCH("pair_reduce", (pair_reduce_kernel<true, PairCfg<CH, true>::NCP>), rgrid, dim3(256), 0, s, A);
+        else SPLAT_LAUNCH("pair_reduce", (pair_reduce_kernel<false, PairCfg<CH, false>::NCP>), rgrid, dim3(256), 0, s, A);
         SPLAT_POST_LAUNCH();
     }
     return SPLAT_OK;
@@ -782,7 +788,7 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
                                              int H, const float *final_T, const int32_t *ncontrib,
                                              const float *dL_dout, float *dL_duv, float *dL_dabs_uv, float *dL_dconic,
                                              float *dL_dopacity, float *dL_dfeature, float *dL_dopacity_bias,
-                                             const int32_t *goff_incl, const int32_t *inv_pos, float *pair_scratch,
+                                             const int32_t *goff_incl, const int32_t *slot_sorted, float *pair_scratch,
                                              splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && C >= 1 && W > 0 && H > 0, "bad sizes");
     if (P == 0) return SPLAT_OK;
@@ -790,8 +796,8 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
                     "null pointer");
     SPLAT_CHECK_ARG(dL_duv && dL_dabs_uv && dL_dconic && dL_dopacity && dL_dfeature, "null gradient pointer");
     SPLAT_CHECK_ARG(!opacity_bias || dL_dopacity_bias, "bias given without dL_dopacity_bias");
-    const int npm = (goff_incl != nullptr) + (inv_pos != nullptr) + (pair_scratch != nullptr);
-    SPLAT_CHECK_ARG(npm == 0 || npm == 3, "goff_incl, inv_pos and pair_scratch go together");
+    const int npm = (goff_incl != nullptr) + (slot_sorted != nullptr) + (pair_scratch != nullptr);
+    SPLAT_CHECK_ARG(npm == 0 || npm == 3, "goff_incl, slot_sorted and pair_scratch go together");
     const bool pair_mode = npm == 3;
     BlendArgs A;
     memset(&A, 0, sizeof(A));
@@ -803,7 +809,7 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
     A.dL_dout = dL_dout;
     A.dL_duv = dL_duv; A.dL_dabs_uv = dL_dabs_uv; A.dL_dconic = dL_dconic; A.dL_dopacity = dL_dopacity;
     A.dL_dfeature = dL_dfeature; A.dL_dbias = dL_dopacity_bias;
-    A.goff_incl = goff_incl; A.inv_pos = inv_pos; A.pair_buf = pair_scratch;
+    A.goff_incl = goff_incl; A.slot_sorted = slot_sorted; A.pair_buf = pair_scratch;
     const int T = A.gx * ((H + TILE - 1) / TILE);
     for (int c0 = 0; c0 < C; c0 += 32) {  // reference chunking: src/alpha_blending.cu:440-577
         A.c0 = c0;

@@ -471,7 +471,9 @@ sh_bwd_kernel(int P, const float *__restrict__ shs, const float *__restrict__ di
         float *oz = dL_dshs + (size_t)i * NB * 3;
 #pragma unroll
         for (int k = 0; k < NB * 3; ++k) oz[k] = 0.f;
-        dL_ddirs[3 * i] = 0.f; dL_ddirs[3 * i + 1] = 0.f; dL_ddirs[3 * i + 2] = 0.f;
+        if (dL_ddirs) {
+            dL_ddirs[3 * i] = 0.f; dL_ddirs[3 * i + 1] = 0.f; dL_ddirs[3 * i + 2] = 0.f;
+        }
         return;
     }
     const float x = dirs[3 * i], y = dirs[3 * i + 1], z = dirs[3 * i + 2];
@@ -490,6 +492,7 @@ sh_bwd_kernel(int P, const float *__restrict__ shs, const float *__restrict__ di
         o[3 * k + 1] = B[k] * g[1];
         o[3 * k + 2] = B[k] * g[2];
     }
+    if (!dL_ddirs) return;  // direction gradient not requested: the coefficients are never read
     if (DEG == 0) {
         dL_ddirs[3 * i] = 0.f; dL_ddirs[3 * i + 1] = 0.f; dL_ddirs[3 * i + 2] = 0.f;
         return;
@@ -657,7 +660,7 @@ extern "C" int splat_compute_sh_backward(int P, const float *shs, int degree, co
                                          float *dL_dshs, float *dL_ddirs, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && degree >= 0 && degree <= 3, "degree must be 0..3");
     if (P == 0) return SPLAT_OK;
-    SPLAT_CHECK_ARG(shs && dirs && visible && dL_dcolors && dL_dshs && dL_ddirs && (free_variant || clamped), "null pointer");
+    SPLAT_CHECK_ARG(shs && dirs && visible && dL_dcolors && dL_dshs && (free_variant || clamped), "null pointer");
     return free_variant ? sh_bwd_dispatch<true>(P, shs, degree, dirs, visible, clamped, dL_dcolors, dL_dshs, dL_ddirs, (hipStream_t)stream)
                         : sh_bwd_dispatch<false>(P, shs, degree, dirs, visible, clamped, dL_dcolors, dL_dshs, dL_ddirs, (hipStream_t)stream);
 }

@@ -224,7 +224,7 @@ class _ComputeSH(torch.autograd.Function):
         P = shs.shape[0]
         g = L.need(dL_dcolor, "dL_dcolor")
         dshs = torch.zeros_like(shs) if shs.shape[1] != (degree + 1) ** 2 else torch.empty_like(shs)
-        ddirs = torch.empty_like(dirs)
+        ddirs = torch.empty_like(dirs) if ctx.needs_input_grad[2] else None
         L.check(L.lib().splat_compute_sh_backward(L.ci(P), L.ptr(shs), L.ci(degree), L.ptr(dirs), L.ptr(vis),
                                                   L.ptr(clamped), L.ci(1 if free else 0), L.ptr(g), L.ptr(dshs),
                                                   L.ptr(ddirs), L.stream()))

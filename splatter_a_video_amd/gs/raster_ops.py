@@ -52,13 +52,14 @@ def sort_gaussian(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, til
     idx_sorted = torch.empty(M, dtype=torch.int32, device=dev)
     if M > 0:
         keys = torch.empty(M, dtype=torch.int64, device=dev)
-        inv_pos = torch.empty(M, dtype=torch.int32, device=dev)
+        owner = torch.empty(M, dtype=torch.int32, device=dev)
+        slot_sorted = torch.empty(M, dtype=torch.int32, device=dev)
         overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         L.check(lib.splat_bin_sort(L.ci(P), L.ptr(uv), L.ptr(depth), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
                                    L.ptr(tile_range), ctypes.c_int64(M), L.ptr(keys), L.ptr(idx_sorted),
-                                   L.ptr(overflow), L.ptr(goff), L.ptr(inv_pos), L.stream()))
+                                   L.ptr(overflow), L.ptr(goff), L.ptr(owner), L.ptr(slot_sorted), L.stream()))
         # hidden companion of idx_sorted: lets alpha_blending's backward run without global atomics
-        idx_sorted._splat_pairmap = (goff, inv_pos)
+        idx_sorted._splat_pairmap = (goff, slot_sorted)
     return idx_sorted, tile_range
 
 
@@ -119,12 +120,12 @@ class _AlphaBlend(torch.autograd.Function):
         if pm is not None and M > 0:
             # pair mode: every gradient element is written by the reduce kernel -> no zero fill
             alloc = torch.empty
-            goff, inv_pos = pm
+            goff, slot_sorted = pm
             scratch = torch.empty(M * L.lib().splat_blend_pair_floats(C, 1 if has_bias else 0), dtype=torch.float32,
                                   device=dev)
         else:
             alloc = torch.zeros
-            goff = inv_pos = scratch = None
+            goff = slot_sorted = scratch = None
         duv = alloc(P, 2, dtype=torch.float32, device=dev)
         dabs = alloc(P, 2, dtype=torch.float32, device=dev)
         dconic = alloc(P, 3, dtype=torch.float32, device=dev)
@@ -134,7 +135,7 @@ class _AlphaBlend(torch.autograd.Function):
         L.check(L.lib().splat_alpha_blending_backward(
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias), L.ptr(idx_sorted),
             L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(g), L.ptr(duv),
-            L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(dbias), L.ptr(goff), L.ptr(inv_pos),
+            L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(dbias), L.ptr(goff), L.ptr(slot_sorted),
             L.ptr(scratch), L.stream()))
         # gradient taps used by densification (reference: alpha_blending.py:112-120)
         dndc = dabs_ndc = None
