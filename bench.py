@@ -128,6 +128,7 @@ def kernel_bytes(name, N, M, HW, C, T, use_sh):
         "bin_tilescan": T * 12,
         "bin_scatter": N * 16 + M * 8,
         "tile_sort": M * (8 + 4),
+        "blend_pack": N * (28 + 4 * C) + N * ((8 + C + 15) // 16 * 64),
         "blend_fwd": M * (28 + 4 * C) + HW * (4 * C + 8),
         # gather again + one (8+C)-float record per pair (pair mode: plain store) + dL_dout/final_T/ncontrib
         "blend_bwd": M * (28 + 4 * C) + M * (32 + 4 * C) + HW * (4 * C + 8),
@@ -214,7 +215,7 @@ def main():
         torch.cuda.synchronize()
         L.profile_enable(False)
         names = ["sh_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
-                 "bin_scatter", "tile_sort", "blend_fwd", "blend_bwd", "pair_reduce", "ewa_bwd", "project_point_bwd",
+                 "bin_scatter", "tile_sort", "blend_pack", "blend_fwd", "blend_bwd", "pair_reduce", "ewa_bwd", "project_point_bwd",
                  "cov3d_bwd", "sh_bwd"]
         for n in names:
             ms, cnt = L.profile_read(n)

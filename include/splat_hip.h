@@ -109,12 +109,16 @@ int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *ra
  *       src/alpha_blending_with_bias.cu:266-621).
  *      opacity_bias NULL -> plain; gs_idx NULL / K<=0 -> not enhanced. Channels are processed in
  *      chunks of <=32 exactly as the reference does (matters for dL_dabs_uv only). ---- */
+/* pack_scratch: P * splat_blend_pack_floats(C) floats, 64-byte aligned, uninitialised: the library first
+ * packs {uv, conic, opacity, bias, id, features of the chunk} into one record per Gaussian so that the
+ * tile kernels gather one contiguous record per list entry. */
+size_t splat_blend_pack_floats(int C);
 int splat_alpha_blending_forward(int P, int C, const float *uv, const float *conic, const float *opacity,
                                  const float *feature, const float *opacity_bias, const int32_t *idx_sorted,
                                  const int32_t *tile_range, float bg, int W, int H, int K, int enable_truncation,
                                  float *out, float *final_T, int32_t *ncontrib,
                                  int32_t *gs_idx /*[H,W,K] (unused slots are set to -1), or NULL*/,
-                                 splat_stream_t stream);
+                                 float *pack_scratch, splat_stream_t stream);
 /* dL_dfeature is [P,C]; dL_dopacity_bias NULL unless bias given.
  * Two modes:
  *  - atomic mode (goff_incl / slot_sorted / pair_scratch NULL): wave-reduced hardware float atomics;
@@ -129,7 +133,9 @@ int splat_alpha_blending_backward(int P, int C, const float *uv, const float *co
                                   const int32_t *ncontrib, const float *dL_dout, float *dL_duv, float *dL_dabs_uv,
                                   float *dL_dconic, float *dL_dopacity, float *dL_dfeature,
                                   float *dL_dopacity_bias, const int32_t *goff_incl, const int32_t *slot_sorted,
-                                  float *pair_scratch, splat_stream_t stream);
+                                  float *pair_scratch, float *pack_scratch,
+                                  int pack_is_valid /*pack_scratch still holds the forward's records (C <= 32)*/,
+                                  splat_stream_t stream);
 
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */
 void splat_profile_enable(int on);

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -26,7 +26,7 @@ SYMBOLS = [
     "splat_ewa_project_forward", "splat_ewa_project_backward",
     "splat_compute_sh_forward", "splat_compute_sh_backward",
     "splat_bin_scratch_bytes", "splat_bin_count", "splat_bin_sort",
-    "splat_alpha_blending_forward", "splat_alpha_blending_backward", "splat_blend_pair_floats",
+    "splat_alpha_blending_forward", "splat_alpha_blending_backward", "splat_blend_pair_floats", "splat_blend_pack_floats",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]
 
@@ -47,6 +47,8 @@ def lib() -> ctypes.CDLL:
         L.splat_abi_version.restype = ctypes.c_int
         L.splat_bin_scratch_bytes.restype = ctypes.c_size_t
         L.splat_bin_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.splat_blend_pack_floats.restype = ctypes.c_size_t
+        L.splat_blend_pack_floats.argtypes = [ctypes.c_int]
         L.splat_blend_pair_floats.restype = ctypes.c_size_t
         L.splat_blend_pair_floats.argtypes = [ctypes.c_int, ctypes.c_int]
         L.splat_profile_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]

@@ -55,48 +55,47 @@ struct BlendArgs {
     const int *goff_incl;   // [P] inclusive prefix of tiles per Gaussian (slot ranges)
     const int *slot_sorted; // [M] sorted position -> pair slot
     int accumulate;         // reduce: add to the geometry gradients (channel chunks > 0)
+    int pack_valid;         // backward: pack already holds this chunk's records (kept from the forward)
+    float *pack;            // [P, Rec<CH>::RS] packed records of the current channel chunk (scratch)
 };
 
 struct __attribute__((packed, aligned(4))) F3 {
     float x, y, z;
 };
 
+// ---- packed per-Gaussian record (built once per blend call by pack_kernel):
+//   [u v A B | C o bias id | f0 .. f(CH-1) | pad]  RS floats, RS a multiple of 16 (whole 64-B sectors).
+// The tile kernels gather ONE contiguous record per list entry (4 lanes x 16 B per sector) instead
+// of touching four separate arrays (uv, conic, opacity, feature) -- a 128-B line fetched per 4..12-B
+// access was 4-7x the algorithmic bytes (profiles/: TCC_EA0_RDREQ_128B).
 template <int CH>
-struct Splat {  // one gathered list entry, held by one thread
-    float u, v, a, b, c, o, bias;
-    int id;
-    float f[CH];
+struct Rec {
+    static constexpr int RS = (8 + CH + 15) & ~15;  // floats per record
+    static constexpr int RQ = RS / 4;               // float4 chunks per record
 };
 
-// EXACT: the chunk has exactly CH channels
 template <int CH, bool BIAS, bool EXACT>
-__device__ __forceinline__ void gather_splat(const BlendArgs &A, int id, bool valid, Splat<CH> &s) {
-    s.id = id; s.u = s.v = s.a = s.b = s.c = s.o = s.bias = 0.f;
+__global__ void __launch_bounds__(256)
+pack_kernel(const BlendArgs A) {
+    constexpr int RS = Rec<CH>::RS;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.P) return;
+    float r[RS];
 #pragma unroll
-    for (int k = 0; k < CH; ++k) s.f[k] = 0.f;
-    if (valid) {
-        const float2 q = A.uv[id];
-        s.u = q.x; s.v = q.y;
-        const F3 cn = *reinterpret_cast<const F3 *>(A.conic + 3 * (size_t)id);  // one dwordx3
-        s.a = cn.x; s.b = cn.y; s.c = cn.z;
-        s.o = A.opacity[id];
-        if (BIAS) s.bias = A.bias[id];
-        const float *f = A.feature + (size_t)id * A.C + A.c0;
-        if (EXACT && CH == 3) {
-            const F3 t = *reinterpret_cast<const F3 *>(f);
-            s.f[0] = t.x; s.f[1] = t.y; s.f[2] = t.z;
-        } else if (EXACT && (CH % 4) == 0 && (A.C & 3) == 0) {
+    for (int k = 0; k < RS; ++k) r[k] = 0.f;
+    const float2 q = A.uv[i];
+    r[0] = q.x; r[1] = q.y;
+    r[2] = A.conic[3 * i]; r[3] = A.conic[3 * i + 1]; r[4] = A.conic[3 * i + 2];
+    r[5] = A.opacity[i];
+    if (BIAS) r[6] = A.bias[i];
+    r[7] = __int_as_float(i);
+    const float *f = A.feature + (size_t)i * A.C + A.c0;
 #pragma unroll
-            for (int k = 0; k < CH; k += 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(f + k);
-                s.f[k] = t.x; s.f[k + 1] = t.y; s.f[k + 2] = t.z; s.f[k + 3] = t.w;
-            }
-        } else {
+    for (int k = 0; k < CH; ++k)
+        if (EXACT || k < A.cn) r[8 + k] = f[k];
+    float4 *dst = reinterpret_cast<float4 *>(A.pack + (size_t)i * RS);
 #pragma unroll
-            for (int k = 0; k < CH; ++k)
-                if (EXACT || k < A.cn) s.f[k] = f[k];
-        }
-    }
+    for (int k = 0; k < RS; k += 4) dst[k / 4] = make_float4(r[k], r[k + 1], r[k + 2], r[k + 3]);
 }
 
 // Can the splat reach alpha >= 1/255 anywhere in the pixel block [bx0,bx1]x[by0,by1]?
@@ -118,44 +117,68 @@ __device__ __forceinline__ bool splat_touches(float u, float v, float a, float b
     return (ddx <= hx) && (ddy <= hy);
 }
 
-// ---- staging area of one super-batch (shared by the four waves of a tile)
+// ---- staging area of one super-batch (shared by the four waves of a tile): SB packed records,
+// slot SB = inert (all-zero) record for the padded tail of the survivor lists
 template <int CH, int SB>
 struct TileLDS {
-    static constexpr int CHP = (CH + 3) & ~3;
-    float4 g0[SB + 4];  // u v a b   (+4: the unrolled pixel loop may read past the last survivor)
-    float4 g1[SB + 4];  // c o bias id(bits)
-    float f[(SB + 4) * CHP];
+    static constexpr int RQ = Rec<CH>::RQ;
+    float4 rec[(SB + 1) * RQ];
     unsigned short list[4][SB + 8];
+    __device__ __forceinline__ const float4 &g0(int e) const { return rec[e * RQ]; }      // u v A B
+    __device__ __forceinline__ const float4 &g1(int e) const { return rec[e * RQ + 1]; }  // C o bias id
 };
 
 template <int CH, int SB>
-__device__ __forceinline__ void park_splat(TileLDS<CH, SB> &L, int slot, const Splat<CH> &s) {
-    L.g0[slot] = make_float4(s.u, s.v, s.a, s.b);
-    L.g1[slot] = make_float4(s.c, s.o, s.bias, __int_as_float(s.id));
-    constexpr int CHP = TileLDS<CH, SB>::CHP;
-#pragma unroll
-    for (int k = 0; k < CHP; k += 4) {
-        float4 v;
-        v.x = k + 0 < CH ? s.f[k + 0] : 0.f;
-        v.y = k + 1 < CH ? s.f[k + 1] : 0.f;
-        v.z = k + 2 < CH ? s.f[k + 2] : 0.f;
-        v.w = k + 3 < CH ? s.f[k + 3] : 0.f;
-        *reinterpret_cast<float4 *>(&L.f[slot * CHP + k]) = v;
-    }
-}
-
-template <int CH, int SB>
 __device__ __forceinline__ void read_feat(const TileLDS<CH, SB> &L, int e, float f[CH]) {
-    constexpr int CHP = TileLDS<CH, SB>::CHP;
+    constexpr int RQ = Rec<CH>::RQ;
 #pragma unroll
-    for (int k = 0; k < CHP; k += 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(&L.f[e * CHP + k]);
+    for (int k = 0; k < CH; k += 4) {
+        const float4 v = L.rec[e * RQ + 2 + k / 4];
         if (k + 0 < CH) f[k + 0] = v.x;
         if (k + 1 < CH) f[k + 1] = v.y;
         if (k + 2 < CH) f[k + 2] = v.z;
         if (k + 3 < CH) f[k + 3] = v.w;
     }
 }
+
+// Software-pipelined gather of packed records: a super-batch is SB*RQ float4 chunks, chunk c belongs
+// to entry c / RQ; thread t moves chunks t, t+256, ...  Ids run two super-batches ahead, payload one.
+// `pos(e, b)` maps (entry, batch) to the list position or -1.
+template <int CH, int SB>
+struct Stager {
+    static constexpr int RQ = Rec<CH>::RQ;
+    static constexpr int NCHUNK = SB * RQ;
+    static constexpr int K = (NCHUNK + 255) / 256;
+    int id_next[K];
+    float4 v[K];
+
+    template <typename Pos>
+    __device__ __forceinline__ void load_ids(const BlendArgs &A, int tid, int base, Pos pos, int batch) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = tid + 256 * k;
+            const int q = (c < NCHUNK) ? pos(c / RQ, batch) : -1;
+            id_next[k] = q >= 0 ? A.idx_sorted[base + q] : -1;
+        }
+    }
+    __device__ __forceinline__ void load_payload(const BlendArgs &A, int tid) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = tid + 256 * k;
+            const int part = c % RQ;
+            v[k] = id_next[k] >= 0
+                       ? *reinterpret_cast<const float4 *>(A.pack + (size_t)id_next[k] * Rec<CH>::RS + 4 * part)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void park(TileLDS<CH, SB> &L, int tid) const {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = tid + 256 * k;
+            if (c < NCHUNK) L.rec[c] = v[k];
+        }
+    }
+};
 
 // per-wave cull of the staged super-batch -> private order-preserving survivor list; returns count.
 // pred(e) drops entries before the box test.
@@ -168,14 +191,14 @@ __device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane, i
         const int e = r * WAVE + lane;
         bool keep = (e < nb) && pred(e);
         if (keep && !BIAS) {
-            const float4 a0 = L.g0[e], a1 = L.g1[e];
+            const float4 a0 = L.g0(e), a1 = L.g1(e);
             keep = splat_touches(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, bx0, bx1, by0, by1);
         }
         const unsigned long long m = __ballot(keep);
         if (keep) L.list[w][cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
         cnt += __popcll(m);
     }
-    if (lane < 8) L.list[w][cnt + lane] = (unsigned short)SB;  // pad: unrolled / prefetching loops read slot SB (inert record)
+    if (lane < 8) L.list[w][cnt + lane] = (unsigned short)SB;  // pad: the unrolled loops read slot SB (inert record)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return cnt;
@@ -212,25 +235,21 @@ blend_fwd_kernel(const BlendArgs A) {
     const int2 range = A.tile_range[tile];
     const int n = range.y - range.x;
 
-    if (tid < 4) {  // slot SB = inert record for the padded tail of the survivor lists
-        L.g0[SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        L.g1[SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const bool stager = tid < SB;
-    int id1 = (stager && tid < n) ? A.idx_sorted[range.x + tid] : 0;
-    int id2 = (stager && SB + tid < n) ? A.idx_sorted[range.x + SB + tid] : 0;
-    Splat<CH> cur;
-    gather_splat<CH, BIAS, EXACT>(A, id1, stager && tid < n, cur);
+    if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
+    // list position of (entry e, super-batch b): forward walk
+    auto pos = [n](int e, int b) { const int q = b * SB + e; return q < n ? q : -1; };
+    Stager<CH, SB> st;
+    st.load_ids(A, tid, range.x, pos, 0);
+    st.load_payload(A, tid);
+    st.load_ids(A, tid, range.x, pos, 1);
 
-    for (int base = 0; base < n; base += SB) {
+    for (int base = 0, batch = 0; base < n; base += SB, ++batch) {
         const bool alld = __all(done);
         if (lane == 0) s_done[w] = alld;
         const int nb = imin_(SB, n - base);
-        if (stager) {
-            park_splat<CH, SB>(L, tid, cur);
-            gather_splat<CH, BIAS, EXACT>(A, id2, base + SB + tid < n, cur);  // prefetch next super-batch
-            id2 = (base + 2 * SB + tid < n) ? A.idx_sorted[range.x + base + 2 * SB + tid] : 0;
-        }
+        st.park(L, tid);
+        st.load_payload(A, tid);                       // payload of the next super-batch
+        st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
         if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;  // every pixel of the tile is saturated
         if (!alld) {
@@ -244,8 +263,8 @@ blend_fwd_kernel(const BlendArgs A) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     e[u] = L.list[w][j0 + u];
-                    g0[u] = L.g0[e[u]];
-                    g1[u] = L.g1[e[u]];
+                    g0[u] = L.g0(e[u]);
+                    g1[u] = L.g1(e[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -410,10 +429,7 @@ blend_bwd_pair_kernel(const BlendArgs A) {
     }
     const int wmax = wave_max_i(last);  // this wave never needs entries q >= wmax
     if (lane == 0) s_wmax[w] = wmax;
-    if (tid < 4) {
-        L.g0[SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        L.g1[SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
     __syncthreads();
     const int2 range = A.tile_range[tile];
     const int len = range.y - range.x;
@@ -425,21 +441,19 @@ blend_bwd_pair_kernel(const BlendArgs A) {
     }
     if (n <= 0) return;
 
-    // thread e < SB stages entry q = top - e
-    const bool stager = tid < SB;
-    int id1 = (stager && n - 1 - tid >= 0) ? A.idx_sorted[range.x + n - 1 - tid] : 0;
-    int id2 = (stager && n - 1 - SB - tid >= 0) ? A.idx_sorted[range.x + n - 1 - SB - tid] : 0;
-    Splat<CH> cur;
-    gather_splat<CH, BIAS, EXACT>(A, id1, stager && n - 1 - tid >= 0, cur);
+    // reverse walk: entry e of super-batch b sits at list position n-1 - b*SB - e
+    auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };  // negative = past the front
+    Stager<CH, SB> st;
+    st.load_ids(A, tid, range.x, pos, 0);
+    st.load_payload(A, tid);
+    st.load_ids(A, tid, range.x, pos, 1);
 
-    for (int top = n - 1; top >= 0; top -= SB) {
+    int batch = 0;
+    for (int top = n - 1; top >= 0; top -= SB, ++batch) {
         const int nb = imin_(SB, top + 1);
-        if (stager) {
-            park_splat<CH, SB>(L, tid, cur);
-            gather_splat<CH, BIAS, EXACT>(A, id2, top - SB - tid >= 0, cur);  // prefetch next super-batch
-            const int q2 = top - 2 * SB - tid;
-            id2 = (q2 >= 0) ? A.idx_sorted[range.x + q2] : 0;
-        }
+        st.park(L, tid);
+        st.load_payload(A, tid);                       // payload of the next super-batch
+        st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
 
         const int cnt = build_list<CH, SB, BIAS>(L, w, lane, nb, bx0, bx1, by0, by1,
@@ -455,8 +469,8 @@ blend_bwd_pair_kernel(const BlendArgs A) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 e[u] = L.list[w][j0 + u];
-                g0[u] = L.g0[e[u]];
-                g1[u] = L.g1[e[u]];
+                g0[u] = L.g0(e[u]);
+                g1[u] = L.g1(e[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -617,33 +631,28 @@ blend_bwd_atomic_kernel(const BlendArgs A) {
     }
     const int wmax = wave_max_i(last);
     if (lane == 0) s_wmax[w] = wmax;
-    if (tid < 4) {
-        L.g0[SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        L.g1[SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
     __syncthreads();
     const int2 range = A.tile_range[tile];
     const int n = imin_(range.y - range.x, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
     if (n <= 0) return;
-    const bool stager = tid < SB;
-    int id1 = (stager && n - 1 - tid >= 0) ? A.idx_sorted[range.x + n - 1 - tid] : 0;
-    int id2 = (stager && n - 1 - SB - tid >= 0) ? A.idx_sorted[range.x + n - 1 - SB - tid] : 0;
-    Splat<CH> cur;
-    gather_splat<CH, BIAS, EXACT>(A, id1, stager && n - 1 - tid >= 0, cur);
-    for (int top = n - 1; top >= 0; top -= SB) {
+    auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };
+    Stager<CH, SB> st;
+    st.load_ids(A, tid, range.x, pos, 0);
+    st.load_payload(A, tid);
+    st.load_ids(A, tid, range.x, pos, 1);
+    int batch = 0;
+    for (int top = n - 1; top >= 0; top -= SB, ++batch) {
         const int nb = imin_(SB, top + 1);
-        if (stager) {
-            park_splat<CH, SB>(L, tid, cur);
-            gather_splat<CH, BIAS, EXACT>(A, id2, top - SB - tid >= 0, cur);
-            const int q2 = top - 2 * SB - tid;
-            id2 = (q2 >= 0) ? A.idx_sorted[range.x + q2] : 0;
-        }
+        st.park(L, tid);
+        st.load_payload(A, tid);
+        st.load_ids(A, tid, range.x, pos, batch + 2);
         __syncthreads();
         const int cnt = build_list<CH, SB, BIAS>(L, w, lane, nb, bx0, bx1, by0, by1,
                                                  [=](int e) { return top - e < wmax; });
         for (int j = 0; j < cnt; ++j) {
             const int e = L.list[w][j];
-            const float4 g0 = L.g0[e], g1 = L.g1[e];
+            const float4 g0 = L.g0(e), g1 = L.g1(e);
             const float dx = g0.x - pxf, dy = g0.y - pyf;
             const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
             const float G = __expf(power);
@@ -685,9 +694,24 @@ blend_bwd_atomic_kernel(const BlendArgs A) {
 
 // ================================================================== launch tables
 template <int CH>
+static int launch_pack(const BlendArgs &A, bool bias, hipStream_t s) {
+    if (A.P == 0) return SPLAT_OK;
+    const dim3 grid((unsigned)((A.P + 255) / 256)), block(256);
+    const bool exact = A.cn == CH;
+    if (bias) { if (exact) SPLAT_LAUNCH("blend_pack", (pack_kernel<CH, true, true>), grid, block, 0, s, A); else SPLAT_LAUNCH("blend_pack", (pack_kernel<CH, true, false>), grid, block, 0, s, A); }
+    else { if (exact) SPLAT_LAUNCH("blend_pack", (pack_kernel<CH, false, true>), grid, block, 0, s, A); else SPLAT_LAUNCH("blend_pack", (pack_kernel<CH, false, false>), grid, block, 0, s, A); }
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+template <int CH>
 static int launch_fwd(const BlendArgs &A, int T, bool enh, bool bias, hipStream_t s) {
     const dim3 grid((unsigned)T), block(256);
     const bool exact = A.cn == CH;
+    {
+        const int rc = launch_pack<CH>(A, bias, s);
+        if (rc != SPLAT_OK) return rc;
+    }
 #define FWD(E, B, X) SPLAT_LAUNCH("blend_fwd", (blend_fwd_kernel<CH, E, B, X>), grid, block, 0, s, A)
     if (enh) {
         if (bias) { if (exact) FWD(true, true, true); else FWD(true, true, false); }
@@ -705,6 +729,10 @@ template <int CH>
 static int launch_bwd(const BlendArgs &A, int T, bool bias, bool pair, hipStream_t s) {
     const dim3 grid((unsigned)T), block(256);
     const bool exact = A.cn == CH;
+    if (!A.pack_valid) {
+        const int rc = launch_pack<CH>(A, bias, s);
+        if (rc != SPLAT_OK) return rc;
+    }
 #define BWD(K, B, X) SPLAT_LAUNCH("blend_bwd", (K<CH, B, X>), grid, block, 0, s, A)
     if (pair) {
         if (bias) { if (exact) BWD(blend_bwd_pair_kernel, true, true); else BWD(blend_bwd_pair_kernel, true, false); }
@@ -749,6 +777,11 @@ static int bwd_chunk(const BlendArgs &A, int T, bool bias, bool pair, hipStream_
     }
 }
 
+extern "C" size_t splat_blend_pack_floats(int C) {
+    // floats per packed Gaussian record for the widest channel chunk: [u v A B | C o bias id | features | pad]
+    return (size_t)((8 + chunk_ch(C > 32 ? 32 : C) + 15) & ~15);
+}
+
 extern "C" size_t splat_blend_pair_floats(int C, int has_bias) {
     // floats per pair record for the widest channel chunk of a C-channel backward
     return (size_t)((((has_bias ? 9 : 8) + chunk_ch(C > 32 ? 32 : C)) + 15) & ~15);
@@ -759,10 +792,11 @@ extern "C" int splat_alpha_blending_forward(int P, int C, const float *uv, const
                                             const float *feature, const float *opacity_bias,
                                             const int32_t *idx_sorted, const int32_t *tile_range, float bg, int W,
                                             int H, int K, int enable_truncation, float *out, float *final_T,
-                                            int32_t *ncontrib, int32_t *gs_idx, splat_stream_t stream) {
+                                            int32_t *ncontrib, int32_t *gs_idx, float *pack_scratch,
+                                            splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && C >= 1 && W > 0 && H > 0, "bad sizes");
     SPLAT_CHECK_ARG(tile_range && out && final_T && ncontrib, "null pointer");
-    SPLAT_CHECK_ARG(P == 0 || (uv && conic && opacity && feature), "null pointer");
+    SPLAT_CHECK_ARG(P == 0 || (uv && conic && opacity && feature && pack_scratch), "null pointer");
     const bool enh = (gs_idx != nullptr) && K > 0;
     BlendArgs A;
     memset(&A, 0, sizeof(A));
@@ -772,6 +806,7 @@ extern "C" int splat_alpha_blending_forward(int P, int C, const float *uv, const
     A.bg = bg; A.W = W; A.H = H; A.gx = (W + TILE - 1) / TILE;
     A.K = enh ? K : 0; A.trunc = enable_truncation ? 1 : 0;
     A.out = out; A.final_T = final_T; A.ncontrib = ncontrib; A.gs_idx = gs_idx;
+    A.pack = pack_scratch;
     const int T = A.gx * ((H + TILE - 1) / TILE);
     for (int c0 = 0; c0 < C; c0 += 32) {  // reference chunking: src/alpha_blending.cu:287-394
         A.c0 = c0;
@@ -789,10 +824,11 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
                                              const float *dL_dout, float *dL_duv, float *dL_dabs_uv, float *dL_dconic,
                                              float *dL_dopacity, float *dL_dfeature, float *dL_dopacity_bias,
                                              const int32_t *goff_incl, const int32_t *slot_sorted, float *pair_scratch,
-                                             splat_stream_t stream) {
+                                             float *pack_scratch, int pack_is_valid, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && C >= 1 && W > 0 && H > 0, "bad sizes");
     if (P == 0) return SPLAT_OK;
-    SPLAT_CHECK_ARG(uv && conic && opacity && feature && idx_sorted && tile_range && final_T && ncontrib && dL_dout,
+    SPLAT_CHECK_ARG(uv && conic && opacity && feature && idx_sorted && tile_range && final_T && ncontrib && dL_dout &&
+                        pack_scratch,
                     "null pointer");
     SPLAT_CHECK_ARG(dL_duv && dL_dabs_uv && dL_dconic && dL_dopacity && dL_dfeature, "null gradient pointer");
     SPLAT_CHECK_ARG(!opacity_bias || dL_dopacity_bias, "bias given without dL_dopacity_bias");
@@ -810,6 +846,8 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
     A.dL_duv = dL_duv; A.dL_dabs_uv = dL_dabs_uv; A.dL_dconic = dL_dconic; A.dL_dopacity = dL_dopacity;
     A.dL_dfeature = dL_dfeature; A.dL_dbias = dL_dopacity_bias;
     A.goff_incl = goff_incl; A.slot_sorted = slot_sorted; A.pair_buf = pair_scratch;
+    A.pack = pack_scratch;
+    A.pack_valid = (pack_is_valid && C <= 32) ? 1 : 0;  // one chunk only: later chunks overwrite the scratch
     const int T = A.gx * ((H + TILE - 1) / TILE);
     for (int c0 = 0; c0 < C; c0 += 32) {  // reference chunking: src/alpha_blending.cu:440-577
         A.c0 = c0;

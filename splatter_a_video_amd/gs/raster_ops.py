@@ -89,14 +89,16 @@ class _AlphaBlend(torch.autograd.Function):
         final_T = torch.empty(H, W, dtype=torch.float32, device=dev)
         ncontrib = torch.empty(H, W, dtype=torch.int32, device=dev)
         gs_idx = torch.empty(H, W, K, dtype=torch.int32, device=dev) if K > 0 else None  # kernel pads with -1
+        pack = torch.empty(max(P, 1) * L.lib().splat_blend_pack_floats(C), dtype=torch.float32, device=dev)
         L.check(L.lib().splat_alpha_blending_forward(
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias_c),
             L.ptr(idx_sorted), L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ci(K), L.ci(1 if trunc else 0),
-            L.ptr(out), L.ptr(final_T), L.ptr(ncontrib), L.ptr(gs_idx), L.stream()))
+            L.ptr(out), L.ptr(final_T), L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.stream()))
         ctx.meta = (float(bg), int(W), int(H), bias is not None, ndc is not None, abs_ndc is not None)
         if pairmap is not None and (pairmap[0].numel() != P or pairmap[1].numel() != idx_sorted.numel()):
             pairmap = None
         ctx.pairmap = pairmap
+        ctx.pack = pack          # packed records: reused by the backward when C <= 32 (one channel chunk)
         saved = [uv, conic, opacity, feature, idx_sorted, tile_range, final_T, ncontrib]
         if bias_c is not None:
             saved.append(bias_c)
@@ -132,11 +134,12 @@ class _AlphaBlend(torch.autograd.Function):
         dop = alloc(opacity.shape, dtype=torch.float32, device=dev)
         dfeat = alloc(P, C, dtype=torch.float32, device=dev)
         dbias = alloc(bias.shape, dtype=torch.float32, device=dev) if has_bias else None
+        pack = ctx.pack
         L.check(L.lib().splat_alpha_blending_backward(
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias), L.ptr(idx_sorted),
             L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(g), L.ptr(duv),
             L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(dbias), L.ptr(goff), L.ptr(slot_sorted),
-            L.ptr(scratch), L.stream()))
+            L.ptr(scratch), L.ptr(pack), L.ci(1), L.stream()))
         # gradient taps used by densification (reference: alpha_blending.py:112-120)
         dndc = dabs_ndc = None
         if has_ndc or has_abs:
