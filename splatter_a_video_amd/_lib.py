@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsplat_hip.so")
+# SPLAT_LIB_PATH: alternative build of the same ABI (kernel tuning A/B runs); default = in-tree library
+LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
 ABI_VERSION = 4

@@ -21,7 +21,7 @@
 #include "common.h"
 
 #define BIN_BLOCK 256
-#define BIN_MAX_NB 128          // rows of the count matrix
+#define BIN_MAX_NB 512          // rows of the count matrix (= workgroups of K1/K3)
 #define BIN_LDS_TILES 12288     // <= 48 KB of LDS counters; larger tile grids use global atomics
 #define SORT_BLOCK 256
 #define SORT_LDS_KEYS 4096      // 32 KB of LDS per sort workgroup
@@ -44,7 +44,7 @@ static BinPlan make_plan(int P, int W, int H) {
     p.gy = (H + TILE - 1) / TILE;
     p.T = p.gx * p.gy;
     p.lds = p.T <= BIN_LDS_TILES;
-    int nb = (P + 2047) / 2048;
+    int nb = (P + 511) / 512;
     if (nb < 1) nb = 1;
     if (nb > BIN_MAX_NB) nb = BIN_MAX_NB;
     if (!p.lds) nb = 1;  // global-atomic path keeps a single row

@@ -29,6 +29,20 @@
 
 #include "common.h"
 
+// tuning knobs (compile time; tools/build_variants.sh builds alternatives for A/B runs)
+#ifndef BLEND_FWD_U
+#define BLEND_FWD_U 4      // survivors evaluated per trip in the forward (narrow channel counts)
+#endif
+#ifndef BLEND_FWD_MINW
+#define BLEND_FWD_MINW 1   // __launch_bounds__ min waves per SIMD (register cap) for the forward
+#endif
+#ifndef BLEND_BWD_U
+#define BLEND_BWD_U 2
+#endif
+#ifndef BLEND_BWD_MINW
+#define BLEND_BWD_MINW 1
+#endif
+
 struct BlendArgs {
     int P, C;          // C = row stride of feature / dL_dfeature
     int c0, cn;        // channel chunk [c0, c0+cn)
@@ -211,10 +225,10 @@ struct FwdCfg {
 };
 
 template <int CH, bool ENH, bool BIAS, bool EXACT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_FWD_MINW : 1))
 blend_fwd_kernel(const BlendArgs A) {
     constexpr int SB = FwdCfg<CH>::SB;
-    constexpr int U = CH <= 8 ? 4 : 2;  // survivors evaluated per trip
+    constexpr int U = CH <= 8 ? BLEND_FWD_U : 2;  // survivors evaluated per trip
     __shared__ TileLDS<CH, SB> L;
     __shared__ int s_done[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -394,11 +408,11 @@ struct PairCfg {
 };
 
 template <int CH, bool BIAS, bool EXACT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_BWD_MINW : 1))
 blend_bwd_pair_kernel(const BlendArgs A) {
     using Cfg = PairCfg<CH, BIAS>;
     constexpr int SB = Cfg::SB, NC = Cfg::NC, NG = Cfg::NG, NCP = Cfg::NCP;
-    constexpr int U = CH <= 8 ? 2 : 1;
+    constexpr int U = CH <= 8 ? BLEND_BWD_U : 1;
     __shared__ TileLDS<CH, SB> L;
     __shared__ float s_acc[4][SB * NC];          // private slab per wave: plain stores, no atomics
     __shared__ unsigned long long s_mask[4];     // which entries of the super-batch the wave wrote
