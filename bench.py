@@ -123,7 +123,7 @@ class FrameRenderer:
         self.bucket.zero_grad()
         for off in offs:
             self.frame(off)
-        if world > 1:
+        if world > 1 or (dist.is_available() and dist.is_initialized()):
             self.bucket.all_reduce()
 
 
@@ -182,7 +182,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run (any N)
+    if launched:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -198,7 +199,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if launched:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -210,7 +211,7 @@ def main():
         R.step(offs, world)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if launched:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -275,7 +276,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line))
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

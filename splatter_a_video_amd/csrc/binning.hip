@@ -206,24 +206,25 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
 // __syncthreads()).
 template <typename KeyPtr>
 __device__ __forceinline__ void bitonic_any_n(KeyPtr a, int n) {
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    const int half = np2 >> 1;
-    for (int k = 2; k <= np2; k <<= 1) {
-        const int hk = k >> 1;
-        for (int t = threadIdx.x; t < half; t += SORT_BLOCK) {  // flip step: i <-> mirror in block of k
-            const int blk = t / hk, off = t - blk * hk;
-            const int lo = blk * k + off, hi = blk * k + k - 1 - off;
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;  // padded size 2^lg
+    const int half = (1 << lg) >> 1;
+    for (int lk = 1; lk <= lg; ++lk) {  // merge width k = 2^lk; all index math in shifts / masks
+        const int k = 1 << lk, hk = k >> 1;
+        for (int t = threadIdx.x; t < half; t += SORT_BLOCK) {  // flip step: i <-> mirror inside the block of k
+            const int blk = t >> (lk - 1), off = t & (hk - 1);
+            const int lo = (blk << lk) + off, hi = (blk << lk) + k - 1 - off;
             if (hi < n) {
                 const unsigned long long x = a[lo], y = a[hi];
                 if (x > y) { a[lo] = y; a[hi] = x; }
             }
         }
         __syncthreads();
-        for (int j = hk >> 1; j > 0; j >>= 1) {
+        for (int lj = lk - 2; lj >= 0; --lj) {  // stride j = 2^lj
+            const int j = 1 << lj;
             for (int t = threadIdx.x; t < half; t += SORT_BLOCK) {
-                const int blk = t / j, off = t - blk * j;
-                const int lo = blk * 2 * j + off, hi = lo + j;
+                const int blk = t >> lj, off = t & (j - 1);
+                const int lo = (blk << (lj + 1)) + off, hi = lo + j;
                 if (hi < n) {
                     const unsigned long long x = a[lo], y = a[hi];
                     if (x > y) { a[lo] = y; a[hi] = x; }

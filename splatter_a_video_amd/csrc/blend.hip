@@ -112,8 +112,11 @@ pack_kernel(const BlendArgs A) {
     for (int k = 0; k < RS; k += 4) dst[k / 4] = make_float4(r[k], r[k + 1], r[k + 2], r[k + 3]);
 }
 
-// Can the splat reach alpha >= 1/255 anywhere in the pixel block [bx0,bx1]x[by0,by1]?
-// Conservative: never false for a splat that contributes.
+// Can the splat reach alpha >= 1/255 at any pixel centre of the block [bx0,bx1]x[by0,by1]?
+// alpha >= 1/255 needs q(d) = d^T Q d <= tau = 2 ln(255 o).  Two conservative stages (never false for a
+// splat that contributes; every bound is inflated by the rounding error it can carry):
+//   1. axis-aligned box of the ellipse {q <= tau} against the block;
+//   2. exact: the minimum of the convex q over the block rectangle (centre inside, else on an edge).
 __device__ __forceinline__ bool splat_touches(float u, float v, float a, float b, float c, float o, float bx0,
                                               float bx1, float by0, float by1) {
     const float t = 255.f * o;
@@ -122,13 +125,35 @@ __device__ __forceinline__ bool splat_touches(float u, float v, float a, float b
     if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return true;
     const float relerr = 4e-7f * (a * c + b * b) / det;  // rounding bound of det (cancellation)
     if (!(relerr < 0.25f)) return true;
-    const float tau = fmaxf(2.f * __logf(t), 0.f) * (1.f + 2.f * relerr) * 1.002f + 2e-3f;
+    const float tau0 = fmaxf(2.f * __logf(t), 0.f);
+    const float tau = tau0 * (1.f + 2.f * relerr) * 1.002f + 2e-3f;
     const float inv = 1.f / det;
     const float hx = sqrtf(tau * c * inv) * 1.001f + 0.01f;
     const float hy = sqrtf(tau * a * inv) * 1.001f + 0.01f;
-    const float ddx = fmaxf(fmaxf(bx0 - u, u - bx1), 0.f);
-    const float ddy = fmaxf(fmaxf(by0 - v, v - by1), 0.f);
-    return (ddx <= hx) && (ddy <= hy);
+    const float dx0 = bx0 - u, dx1 = bx1 - u, dy0 = by0 - v, dy1 = by1 - v;  // block relative to the centre
+    const float ddx = fmaxf(fmaxf(dx0, -dx1), 0.f);
+    const float ddy = fmaxf(fmaxf(dy0, -dy1), 0.f);
+    if (!((ddx <= hx) && (ddy <= hy))) return false;
+    if (ddx == 0.f && ddy == 0.f) return true;  // centre inside the block
+    // minimum of q on the four edges (q is convex: clamp the unconstrained minimiser of each edge line)
+    const float ia = 1.f / a, ic = 1.f / c;
+    float qmin;
+    {
+        const float y0 = fminf(fmaxf(-b * dx0 * ic, dy0), dy1), y1 = fminf(fmaxf(-b * dx1 * ic, dy0), dy1);
+        const float q0 = a * dx0 * dx0 + 2.f * b * dx0 * y0 + c * y0 * y0;
+        const float q1 = a * dx1 * dx1 + 2.f * b * dx1 * y1 + c * y1 * y1;
+        qmin = fminf(q0, q1);
+    }
+    {
+        const float x0 = fminf(fmaxf(-b * dy0 * ia, dx0), dx1), x1 = fminf(fmaxf(-b * dy1 * ia, dx0), dx1);
+        const float q0 = a * x0 * x0 + 2.f * b * x0 * dy0 + c * dy0 * dy0;
+        const float q1 = a * x1 * x1 + 2.f * b * x1 * dy1 + c * dy1 * dy1;
+        qmin = fminf(qmin, fminf(q0, q1));
+    }
+    // q is evaluated with ~1e-6 relative error of its largest term; the terms are bounded by (a+c+2|b|) * r^2
+    const float r2 = fmaxf(dx0 * dx0, dx1 * dx1) + fmaxf(dy0 * dy0, dy1 * dy1);
+    const float qerr = 4e-6f * (a + c + 2.f * fabsf(b)) * r2;
+    return qmin <= tau * 1.002f + qerr + 2e-3f;
 }
 
 // ---- staging area of one super-batch (shared by the four waves of a tile): SB packed records,

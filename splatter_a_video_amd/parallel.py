@@ -56,8 +56,8 @@ class FlatGradBucket:
 
     def all_reduce(self, average: bool = False) -> None:
         """One collective per step; a no-op for a single process."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)  # world size 1: identity, still exercises RCCL
             if average:
                 self.flat_grad.div_(dist.get_world_size())
 
