@@ -76,3 +76,24 @@ def test_operator_surface_matches_reference_names():
     assert inspect.signature(gs.project_point).parameters["nearest"].default == 0.2
     assert inspect.signature(gs.project_point).parameters["extent"].default == 1.3
     assert inspect.signature(gs.alpha_blending_enhanced).parameters["K"].default == 10
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No CPU fallback: without the HIP library the binding raises instead of computing something else."""
+    import subprocess
+    import sys
+    code = ("import os; os.environ['SPLAT_LIB_PATH'] = r'%s/nope.so'\n"
+            "import splatter_a_video_amd._lib as L\n"
+            "try:\n    L.lib()\nexcept L.SplatError as e:\n    print('RAISED', 'no CPU fallback' in str(e).lower() or 'not found' in str(e))\n" % tmp_path)
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not reference the oracle (checker only)."""
+    import pathlib
+    for p in pathlib.Path(ROOT, "splatter_a_video_amd").rglob("*.py"):
+        src = p.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, p
+    for p in pathlib.Path(ROOT, "dptr").rglob("*.py"):
+        assert "oracle" not in p.read_text(), p

@@ -352,3 +352,89 @@ def test_full_size_properties(gpu):
     assert float((out2 - 1.0).abs().max()) < 1e-5
     assert float(out.max()) <= 1.0 + 1e-6 and int(nc.max()) > 0
     assert bool(((gi[..., 0] >= 0) == (nc > 0)).all())
+
+
+# ------------------------------------------------------------------ full-size, size-independent properties (no CPU oracle run)
+def _gpu_chain(gpu, sc, feat_np, bg=0.0, f=0):
+    import dptr.gs as gs
+    W, H = sc.W, sc.H
+    xyz = dev(sc.positions(f), gpu); extr = dev(sc.extr, gpu)
+    uv, depth = gs.project_point_ortho(xyz, extr, W, H, nearest=0.01)
+    vis = depth != 0
+    cov = gs.compute_cov3d(dev(sc.scale, gpu), dev(sc.rotate, gpu), vis)
+    conic, radius, tiles = gs.ewa_project_ortho(xyz, cov, extr, uv, W, H, vis)
+    idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+    return dict(uv=uv, conic=conic, idx=idx, tr=tr, opacity=dev(sc.opacity, gpu), radius=radius)
+
+
+@pytest.mark.parametrize("N,W,H,C", [(300000, 854, 480, 32), (1000000, 1280, 720, 3)])
+def test_full_size_linearity_and_weight_sum(gpu, N, W, H, C):
+    """BASELINE configs 5 (32 channels) and 4 (1M Gaussians, 720p):
+    (1) the forward is linear in the features (bg = 0);
+    (2) with dL_dout = 1 on one channel, sum_i dL_dfeature[i,c] == sum_pixels (1 - T_final): the backward
+        redistributes exactly the weights the forward applied;
+    (3) dL_dfeature does not depend on the feature values."""
+    import dptr.gs as gs
+    sc = make_scene(N, W, H, seed=4321)
+    G = _gpu_chain(gpu, sc, None)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    f1 = torch.rand(N, C, generator=g).to(gpu).requires_grad_(True)
+    f2 = torch.rand(N, C, generator=g).to(gpu).requires_grad_(True)
+    args = (G["uv"], G["conic"], G["opacity"])
+    o1 = gs.alpha_blending(*args, f1, G["idx"], G["tr"], 0.0, W, H)
+    o2 = gs.alpha_blending(*args, f2, G["idx"], G["tr"], 0.0, W, H)
+    o12 = gs.alpha_blending(*args, (f1 + 2.0 * f2).detach(), G["idx"], G["tr"], 0.0, W, H)
+    assert float((o12 - (o1 + 2.0 * o2)).detach().abs().max()) < 2e-4
+    ones = torch.ones(N, 1, device=gpu)
+    oT = gs.alpha_blending(*args, ones, G["idx"], G["tr"], 0.0, W, H)           # = 1 - T_final
+    gout = torch.zeros(C, H, W, device=gpu); gout[C // 2] = 1.0
+    o1.backward(gout)
+    o2.backward(gout)
+    total_w = float(oT.double().sum())
+    got = float(f1.grad[:, C // 2].double().sum())
+    assert abs(got - total_w) < 1e-4 * total_w
+    assert float((f1.grad - f2.grad).abs().max()) == 0.0 or float((f1.grad - f2.grad).abs().max()) < 1e-6
+    assert float(f1.grad[:, :C // 2].abs().max()) == 0.0                          # untouched channels stay 0
+
+
+def test_extreme_splats_and_thresholds(gpu, oracle_mod):
+    """Edge cases the reference's loop distinguishes: needle-like splats (conic condition number > 1e4),
+    a splat covering the whole image, opacities at / below the 1/255 threshold, alpha saturating at 0.99."""
+    import dptr.gs as gs
+    o = oracle_mod
+    W, H = 96, 64
+    sc = make_scene(600, W, H, seed=8)
+    sc.scale[:150] *= np.array([[40.0, 0.05, 1.0]], np.float32)       # needles
+    sc.scale[150:153] *= 60.0                                          # huge splats: every tile, long lists
+    sc.opacity[153:250] = np.float32(1.0 / 255.0)                      # exactly at the threshold
+    sc.opacity[250:300] = np.float32(0.0039)                           # just below
+    sc.opacity[300:350] = np.float32(1.0)                              # clamps to 0.99
+    G = oracle_geometry(o, sc)
+    feat = np.random.default_rng(3).uniform(size=(sc.N, 3)).astype(np.float32)
+    out_r, fT_r, nc_r = o.alpha_blending_forward(G["uv"], G["conic"], sc.opacity, feat, G["idx"], G["tr"], 0.5, W, H)
+    idx, tr = gs.sort_gaussian(dev(G["uv"], gpu), dev(G["depth"], gpu), W, H, dev(G["radius"], gpu), dev(G["tiles"], gpu))
+    assert (idx.cpu().numpy() == G["idx"]).all()
+    t = {k: dev(v, gpu).requires_grad_(True) for k, v in dict(uv=G["uv"], conic=G["conic"], opacity=sc.opacity, feat=feat).items()}
+    out = gs.alpha_blending(t["uv"], t["conic"], t["opacity"], t["feat"], idx, tr, 0.5, W, H)
+    bad = np.abs(out.detach().cpu().numpy() - out_r) > (IMG_ATOL + IMG_RTOL * np.abs(out_r))
+    assert bad.mean() < 1e-3, bad.mean()
+    g = np.random.default_rng(4).normal(size=out_r.shape).astype(np.float32)
+    out.backward(dev(g, gpu))
+    gr = o.alpha_blending_backward(G["uv"], G["conic"], sc.opacity, feat, G["idx"], G["tr"], 0.5, W, H, fT_r, nc_r, g)
+    assert_grad(t["uv"].grad, gr[0], "dL_duv", 5e-3); assert_grad(t["conic"].grad, gr[1], "dL_dconic", 5e-3)
+    assert_grad(t["opacity"].grad, gr[2], "dL_dopacity", 5e-3); assert_grad(t["feat"].grad, gr[3], "dL_dfeature", 5e-3)
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (16, 1), (17, 33)])
+def test_tiny_images(gpu, oracle_mod, W, H):
+    import dptr.gs as gs
+    o = oracle_mod
+    sc = make_scene(50, max(W, 8), max(H, 8), seed=2)
+    sc.W, sc.H = W, H
+    G = oracle_geometry(o, sc)
+    feat = np.random.default_rng(5).uniform(size=(sc.N, 2)).astype(np.float32)
+    out_r, fT_r, nc_r = o.alpha_blending_forward(G["uv"], G["conic"], sc.opacity, feat, G["idx"], G["tr"], 0.1, W, H)
+    idx, tr = gs.sort_gaussian(dev(G["uv"], gpu), dev(G["depth"], gpu), W, H, dev(G["radius"], gpu), dev(G["tiles"], gpu))
+    assert (idx.cpu().numpy() == G["idx"]).all() and (tr.cpu().numpy() == G["tr"]).all()
+    out = gs.alpha_blending(dev(G["uv"], gpu), dev(G["conic"], gpu), dev(sc.opacity, gpu), dev(feat, gpu), idx, tr, 0.1, W, H)
+    np.testing.assert_allclose(out.cpu().numpy(), out_r, rtol=IMG_RTOL, atol=IMG_ATOL)
