@@ -24,7 +24,7 @@
 #define BIN_MAX_NB 512          // rows of the count matrix (= workgroups of K1/K3)
 #define BIN_LDS_TILES 12288     // <= 48 KB of LDS counters; larger tile grids use global atomics
 #define SORT_BLOCK 256
-#define SORT_LDS_KEYS 4096      // 32 KB of LDS per sort workgroup
+#define SORT_LDS_KEYS 2048      // 16 KB of LDS per sort workgroup (larger tiles sort in their global segment)
 
 struct BinPlan {
     int T, gx, gy;
