@@ -114,7 +114,9 @@ class FrameRenderer:
         cov3d = gs.compute_cov3d(p["scale"], p["rotate"], visible)
         conic, radius, tiles = gs.ewa_project_ortho(pos, cov3d, self.extr, uv, W, H, visible)
         idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
-        img = gs.alpha_blending(uv, conic, p["opacity"], feat, idx, tr, self.sc.bg, W, H)
+        # densification tap, as the reference renderers create it (dptr.py:151-162)
+        ndc = torch.zeros_like(uv, requires_grad=True)
+        img = gs.alpha_blending(uv, conic, p["opacity"], feat, idx, tr, self.sc.bg, W, H, ndc)
         img.backward(self.dL_dout)
         self.last = dict(M=idx.numel(), T=tr.shape[0])
         return img

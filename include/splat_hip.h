@@ -119,7 +119,9 @@ int splat_alpha_blending_forward(int P, int C, const float *uv, const float *con
                                  float *out, float *final_T, int32_t *ncontrib,
                                  int32_t *gs_idx /*[H,W,K] (unused slots are set to -1), or NULL*/,
                                  float *pack_scratch, splat_stream_t stream);
-/* dL_dfeature is [P,C]; dL_dopacity_bias NULL unless bias given.
+/* dL_dfeature is [P,C]; dL_dopacity_bias NULL unless bias given; dL_dabs_uv may be NULL (the sums of
+ * |d uv| are only needed when the caller's abs_ndc tap is present -- skipping them saves two of the
+ * per-splat wave reductions).
  * Two modes:
  *  - atomic mode (goff_incl / slot_sorted / pair_scratch NULL): wave-reduced hardware float atomics;
  *    all gradient outputs must be zero-init.

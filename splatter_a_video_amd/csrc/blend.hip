@@ -377,25 +377,51 @@ __device__ __forceinline__ void wave_sum4_to_lane63(float &a, float &b, float &c
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
-template <int N>
-__device__ __forceinline__ void wave_sum_n_to_lane63(float (&v)[N]) {
-    constexpr int N4 = N & ~3;
-#pragma unroll
-    for (int k = 0; k < N4; k += 4) wave_sum4_to_lane63(v[k], v[k + 1], v[k + 2], v[k + 3]);
-    if constexpr ((N & 3) == 3) {
-        float z = 0.f;
-        wave_sum4_to_lane63(v[N4], v[N4 + 1], v[N4 + 2], z);
-    } else if constexpr ((N & 3) != 0) {
-#pragma unroll
-        for (int k = N4; k < N; ++k) v[k] = wave_sum_to_lane63(v[k]);
-    }
+#define DPP3(op)                                   \
+    "v_add_f32_dpp %0, %0, %0 " op "\n\t"          \
+    "v_add_f32_dpp %1, %1, %1 " op "\n\t"          \
+    "v_add_f32_dpp %2, %2, %2 " op "\n\t"
+
+// three interleaved chains: dependent DPP adds are still 2 issue slots apart
+__device__ __forceinline__ void wave_sum3_to_lane63(float &a, float &b, float &c) {
+    asm volatile("s_nop 1\n\t" DPP3("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                     DPP3("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                         DPP3("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                             DPP3("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                                 DPP3("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                                     DPP3("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(a), "+v"(b), "+v"(c));
 }
 
-// per-pixel replay of one survivor in the backward (shared by pair and atomic kernels)
-template <int CH, int NG, bool BIAS>
+// N values -> lane 63, in blocks of 4 and 3 (N = 4a + 3b whenever N >= 6; small N fall back to the builtin chain)
+template <int N>
+__device__ __forceinline__ void wave_sum_n_to_lane63(float (&v)[N]) {
+    constexpr int B3 = (N >= 6 || N == 3) ? ((4 - (N & 3)) & 3) : 0;  // number of 3-blocks: N - 3*B3 divisible by 4
+    constexpr int N3 = 3 * B3;
+    constexpr int N4 = (N - N3) & ~3;
+#pragma unroll
+    for (int k = 0; k < N4; k += 4) wave_sum4_to_lane63(v[k], v[k + 1], v[k + 2], v[k + 3]);
+#pragma unroll
+    for (int k = N4; k < N4 + N3; k += 3) wave_sum3_to_lane63(v[k], v[k + 1], v[k + 2]);
+#pragma unroll
+    for (int k = N4 + N3; k < N; ++k) v[k] = wave_sum_to_lane63(v[k]);
+}
+
+// per-pixel replay of one survivor in the backward (shared by pair and atomic kernels).
+// r[] = [ux uy ca cb cc o | ax ay (ABS) | bias (BIAS) | CH feature terms]  -- one array so that the wave
+// reduction can interleave all chains.
+template <bool ABS, bool BIAS>
+struct GradLayout {
+    static constexpr int NG = 6 + (ABS ? 2 : 0) + (BIAS ? 1 : 0);
+    static constexpr int I_ABS = 6;
+    static constexpr int I_BIAS = 6 + (ABS ? 2 : 0);
+};
+
+template <int CH, bool ABS, bool BIAS>
 __device__ __forceinline__ void replay_one(const float4 &g0, const float4 &g1, const float (&f)[CH], float dx, float dy,
                                            float G, float a, float Tf, float bgdot, const float (&gp)[CH], float &T,
-                                           float (&acc)[CH], bool &done, float (&s)[NG], float (&s_f)[CH]) {
+                                           float (&acc)[CH], bool &done, float (&r)[GradLayout<ABS, BIAS>::NG + CH]) {
+    using GL = GradLayout<ABS, BIAS>;
     const float r1a = __builtin_amdgcn_rcpf(1.f - a);
     T = T * r1a;
     const float wgt = a * T;
@@ -403,7 +429,7 @@ __device__ __forceinline__ void replay_one(const float4 &g0, const float4 &g1, c
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
         dLa += (f[k] - acc[k]) * gp[k];
-        s_f[k] = wgt * gp[k];
+        r[GL::NG + k] = wgt * gp[k];
         acc[k] = a * f[k] + (1.f - a) * acc[k];  // == the reference's deferred accum_rec update
     }
     dLa *= T;
@@ -411,32 +437,34 @@ __device__ __forceinline__ void replay_one(const float4 &g0, const float4 &g1, c
     const float dLG = g1.y * dLa;
     const float gx_ = -G * dx * g0.z - G * dy * g0.w;
     const float gy_ = -G * dy * g1.x - G * dx * g0.w;
-    s[0] = dLG * gx_; s[1] = dLG * gy_;
-    s[2] = fabsf(s[0]); s[3] = fabsf(s[1]);
-    s[4] = -0.5f * G * dx * dx * dLG;
-    s[5] = -G * dx * dy * dLG;
-    s[6] = -0.5f * G * dy * dy * dLG;
-    s[7] = G * dLa;
+    r[0] = dLG * gx_; r[1] = dLG * gy_;
+    r[2] = -0.5f * G * dx * dx * dLG;
+    r[3] = -G * dx * dy * dLG;
+    r[4] = -0.5f * G * dy * dy * dLG;
+    r[5] = G * dLa;
+    if (ABS) {
+        r[GL::I_ABS] = fabsf(r[0]); r[GL::I_ABS + 1] = fabsf(r[1]);
+    }
     if (BIAS) {
-        s[NG - 1] = dLa;
+        r[GL::I_BIAS] = dLa;
         done = T < 0.0001f;
     }
 }
 
 // ------------------------------------------------------------------ backward, atomic-free ("pair" mode)
-template <int CH, bool BIAS>
+template <int CH, bool ABS, bool BIAS>
 struct PairCfg {
-    static constexpr int NG = BIAS ? 9 : 8;  // ux uy ax ay ca cb cc o [bias]
+    static constexpr int NG = GradLayout<ABS, BIAS>::NG;  // ux uy ca cb cc o [ax ay] [bias]
     static constexpr int NC = NG + CH;       // used floats per pair record
     static constexpr int NCP = (NC + 15) & ~15;  // record stride in pair_buf: whole 64-B sectors
     static constexpr int SB = 64;
 };
 
-template <int CH, bool BIAS, bool EXACT>
+template <int CH, bool ABS, bool BIAS, bool EXACT>
 __global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_BWD_MINW : 1))
 blend_bwd_pair_kernel(const BlendArgs A) {
-    using Cfg = PairCfg<CH, BIAS>;
-    constexpr int SB = Cfg::SB, NC = Cfg::NC, NG = Cfg::NG, NCP = Cfg::NCP;
+    using Cfg = PairCfg<CH, ABS, BIAS>;
+    constexpr int SB = Cfg::SB, NC = Cfg::NC, NCP = Cfg::NCP;
     constexpr int U = CH <= 8 ? BLEND_BWD_U : 1;
     __shared__ TileLDS<CH, SB> L;
     __shared__ float s_acc[4][SB * NC];          // private slab per wave: plain stores, no atomics
@@ -529,20 +557,15 @@ blend_bwd_pair_kernel(const BlendArgs A) {
                 if (!__any(ok[u])) continue;
                 float f[CH];
                 read_feat<CH, SB>(L, e[u], f);
-                float s[NG], s_f[CH];
+                float r[NC];
 #pragma unroll
-                for (int k = 0; k < NG; ++k) s[k] = 0.f;
-#pragma unroll
-                for (int k = 0; k < CH; ++k) s_f[k] = 0.f;
-                if (ok[u]) replay_one<CH, NG, BIAS>(g0[u], g1[u], f, dx[u], dy[u], G[u], alpha[u], Tf, bgdot, gp, T, acc, done, s, s_f);
-                wave_sum_n_to_lane63<NG>(s);
-                wave_sum_n_to_lane63<CH>(s_f);
+                for (int k = 0; k < NC; ++k) r[k] = 0.f;
+                if (ok[u]) replay_one<CH, ABS, BIAS>(g0[u], g1[u], f, dx[u], dy[u], G[u], alpha[u], Tf, bgdot, gp, T, acc, done, r);
+                wave_sum_n_to_lane63<NC>(r);
                 if (lane == 63) {
                     float *a = slab + e[u] * NC;
 #pragma unroll
-                    for (int k = 0; k < NG; ++k) a[k] = s[k];
-#pragma unroll
-                    for (int k = 0; k < CH; ++k) a[NG + k] = s_f[k];
+                    for (int k = 0; k < NC; ++k) a[k] = r[k];
                 }
                 wrote |= 1ull << e[u];
             }
@@ -575,15 +598,16 @@ blend_bwd_pair_kernel(const BlendArgs A) {
 // Four lanes per Gaussian: lane `sub` owns floats [4*sub, 4*sub+4) of every 16-float sector, so a
 // quad reads one whole 64-B sector per record (coalesced), accumulates in registers with no
 // cross-lane traffic, and writes its own components with plain stores.
-template <bool BIAS>
+template <bool ABS, bool BIAS>
 __device__ __forceinline__ void store_component(const BlendArgs &A, int i, int k, float v) {
-    constexpr int NG = BIAS ? 9 : 8;
+    using GL = GradLayout<ABS, BIAS>;
+    constexpr int NG = GL::NG;
     float *dst;
     if (k < 2) dst = A.dL_duv + 2 * i + k;
-    else if (k < 4) dst = A.dL_dabs_uv + 2 * i + (k - 2);
-    else if (k < 7) dst = A.dL_dconic + 3 * i + (k - 4);
-    else if (k == 7) dst = A.dL_dopacity + i;
-    else if (BIAS && k == 8) dst = A.dL_dbias + i;
+    else if (k < 5) dst = A.dL_dconic + 3 * i + (k - 2);
+    else if (k == 5) dst = A.dL_dopacity + i;
+    else if (ABS && k < GL::I_ABS + 2) dst = A.dL_dabs_uv + 2 * i + (k - GL::I_ABS);
+    else if (BIAS && k == GL::I_BIAS) dst = A.dL_dbias + i;
     else {
         if (k - NG >= A.cn) return;  // padding
         A.dL_dfeature[(size_t)i * A.C + A.c0 + (k - NG)] = v;  // features of this chunk: always plain store
@@ -592,7 +616,7 @@ __device__ __forceinline__ void store_component(const BlendArgs &A, int i, int k
     *dst = A.accumulate ? *dst + v : v;
 }
 
-template <bool BIAS, int NCP>
+template <bool ABS, bool BIAS, int NCP>
 __global__ void __launch_bounds__(256)
 pair_reduce_kernel(const BlendArgs A) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -628,20 +652,21 @@ pair_reduce_kernel(const BlendArgs A) {
 #pragma unroll
     for (int c = 0; c < NS; ++c) {
         const int k = 16 * c + 4 * sub;
-        store_component<BIAS>(A, i, k + 0, a[c].x);
-        store_component<BIAS>(A, i, k + 1, a[c].y);
-        store_component<BIAS>(A, i, k + 2, a[c].z);
-        store_component<BIAS>(A, i, k + 3, a[c].w);
+        store_component<ABS, BIAS>(A, i, k + 0, a[c].x);
+        store_component<ABS, BIAS>(A, i, k + 1, a[c].y);
+        store_component<ABS, BIAS>(A, i, k + 2, a[c].z);
+        store_component<ABS, BIAS>(A, i, k + 3, a[c].w);
     }
 }
 
 // ------------------------------------------------------------------ backward, atomic mode (foreign idx_sorted)
 // Same tile structure; every wave reduces its partials and lane 63 issues one hardware float atomic
 // per (wave, splat, component).  Gradient outputs must be zero-initialised.
-template <int CH, bool BIAS, bool EXACT>
+template <int CH, bool ABS, bool BIAS, bool EXACT>
 __global__ void __launch_bounds__(256)
 blend_bwd_atomic_kernel(const BlendArgs A) {
-    constexpr int SB = 64, NG = BIAS ? 9 : 8;
+    using GL = GradLayout<ABS, BIAS>;
+    constexpr int SB = 64, NG = GL::NG, NC = NG + CH;
     __shared__ TileLDS<CH, SB> L;
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -702,29 +727,28 @@ blend_bwd_atomic_kernel(const BlendArgs A) {
             if (!__any(ok)) continue;
             float f[CH];
             read_feat<CH, SB>(L, e, f);
-            float s[NG], s_f[CH];
+            float r[NC];
 #pragma unroll
-            for (int k = 0; k < NG; ++k) s[k] = 0.f;
-#pragma unroll
-            for (int k = 0; k < CH; ++k) s_f[k] = 0.f;
-            if (ok) replay_one<CH, NG, BIAS>(g0, g1, f, dx, dy, G, alpha, Tf, bgdot, gp, T, acc, done, s, s_f);
-            wave_sum_n_to_lane63<NG>(s);
-            wave_sum_n_to_lane63<CH>(s_f);
+            for (int k = 0; k < NC; ++k) r[k] = 0.f;
+            if (ok) replay_one<CH, ABS, BIAS>(g0, g1, f, dx, dy, G, alpha, Tf, bgdot, gp, T, acc, done, r);
+            wave_sum_n_to_lane63<NC>(r);
             if (lane == 63) {
                 const int id = __float_as_int(g1.w);
-                atomic_add_f32(A.dL_duv + 2 * id, s[0]);
-                atomic_add_f32(A.dL_duv + 2 * id + 1, s[1]);
-                atomic_add_f32(A.dL_dabs_uv + 2 * id, s[2]);
-                atomic_add_f32(A.dL_dabs_uv + 2 * id + 1, s[3]);
-                atomic_add_f32(A.dL_dconic + 3 * id, s[4]);
-                atomic_add_f32(A.dL_dconic + 3 * id + 1, s[5]);
-                atomic_add_f32(A.dL_dconic + 3 * id + 2, s[6]);
-                atomic_add_f32(A.dL_dopacity + id, s[7]);
-                if (BIAS) atomic_add_f32(A.dL_dbias + id, s[NG - 1]);
+                atomic_add_f32(A.dL_duv + 2 * id, r[0]);
+                atomic_add_f32(A.dL_duv + 2 * id + 1, r[1]);
+                atomic_add_f32(A.dL_dconic + 3 * id, r[2]);
+                atomic_add_f32(A.dL_dconic + 3 * id + 1, r[3]);
+                atomic_add_f32(A.dL_dconic + 3 * id + 2, r[4]);
+                atomic_add_f32(A.dL_dopacity + id, r[5]);
+                if (ABS) {
+                    atomic_add_f32(A.dL_dabs_uv + 2 * id, r[GL::I_ABS]);
+                    atomic_add_f32(A.dL_dabs_uv + 2 * id + 1, r[GL::I_ABS + 1]);
+                }
+                if (BIAS) atomic_add_f32(A.dL_dbias + id, r[GL::I_BIAS]);
                 float *df = A.dL_dfeature + (size_t)id * A.C + A.c0;
 #pragma unroll
                 for (int k = 0; k < CH; ++k)
-                    if (k < cn) atomic_add_f32(df + k, s_f[k]);
+                    if (k < cn) atomic_add_f32(df + k, r[NG + k]);
             }
         }
         __syncthreads();
@@ -764,31 +788,35 @@ static int launch_fwd(const BlendArgs &A, int T, bool enh, bool bias, hipStream_
     return SPLAT_OK;
 }
 
-template <int CH>
-static int launch_bwd(const BlendArgs &A, int T, bool bias, bool pair, hipStream_t s) {
+template <int CH, bool ABS, bool BIAS>
+static int launch_bwd_ab(const BlendArgs &A, int T, bool pair, hipStream_t s) {
     const dim3 grid((unsigned)T), block(256);
     const bool exact = A.cn == CH;
+    if (pair) {
+        if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_pair_kernel<CH, ABS, BIAS, true>), grid, block, 0, s, A);
+        else SPLAT_LAUNCH("blend_bwd", (blend_bwd_pair_kernel<CH, ABS, BIAS, false>), grid, block, 0, s, A);
+    } else {
+        if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_atomic_kernel<CH, ABS, BIAS, true>), grid, block, 0, s, A);
+        else SPLAT_LAUNCH("blend_bwd", (blend_bwd_atomic_kernel<CH, ABS, BIAS, false>), grid, block, 0, s, A);
+    }
+    SPLAT_POST_LAUNCH();
+    if (pair) {
+        const dim3 rgrid((unsigned)(((size_t)A.P * 4 + 255) / 256));
+        SPLAT_LAUNCH("pair_reduce", (pair_reduce_kernel<ABS, BIAS, PairCfg<CH, ABS, BIAS>::NCP>), rgrid, dim3(256), 0, s, A);
+        SPLAT_POST_LAUNCH();
+    }
+    return SPLAT_OK;
+}
+
+template <int CH>
+static int launch_bwd(const BlendArgs &A, int T, bool bias, bool pair, hipStream_t s) {
     if (!A.pack_valid) {
         const int rc = launch_pack<CH>(A, bias, s);
         if (rc != SPLAT_OK) return rc;
     }
-#define BWD(K, B, X) SPLAT_LAUNCH("blend_bwd", (K<CH, B, X>), grid, block, 0, s, A)
-    if (pair) {
-        if (bias) { if (exact) BWD(blend_bwd_pair_kernel, true, true); else BWD(blend_bwd_pair_kernel, true, false); }
-        else { if (exact) BWD(blend_bwd_pair_kernel, false, true); else BWD(blend_bwd_pair_kernel, false, false); }
-    } else {
-        if (bias) { if (exact) BWD(blend_bwd_atomic_kernel, true, true); else BWD(blend_bwd_atomic_kernel, true, false); }
-        else { if (exact) BWD(blend_bwd_atomic_kernel, false, true); else BWD(blend_bwd_atomic_kernel, false, false); }
-    }
-#undef BWD
-    SPLAT_POST_LAUNCH();
-    if (pair) {
-        const dim3 rgrid((unsigned)(((size_t)A.P * 4 + 255) / 256));
-        if (bias) SPLAT_LAUNCH("pair_reduce", (pair_reduce_kernel<true, PairCfg<CH, true>::NCP>), rgrid, dim3(256), 0, s, A);
-        else SPLAT_LAUNCH("pair_reduce", (pair_reduce_kernel<false, PairCfg<CH, false>::NCP>), rgrid, dim3(256), 0, s, A);
-        SPLAT_POST_LAUNCH();
-    }
-    return SPLAT_OK;
+    const bool abs_ = A.dL_dabs_uv != nullptr;  // |d uv| sums are only produced when the caller asks for them
+    if (abs_) return bias ? launch_bwd_ab<CH, true, true>(A, T, pair, s) : launch_bwd_ab<CH, true, false>(A, T, pair, s);
+    return bias ? launch_bwd_ab<CH, false, true>(A, T, pair, s) : launch_bwd_ab<CH, false, false>(A, T, pair, s);
 }
 
 // channel-chunk width -> kernel instantiation
@@ -822,7 +850,7 @@ extern "C" size_t splat_blend_pack_floats(int C) {
 }
 
 extern "C" size_t splat_blend_pair_floats(int C, int has_bias) {
-    // floats per pair record for the widest channel chunk of a C-channel backward
+    // floats per pair record (upper bound over the abs / no-abs layouts) for the widest channel chunk
     return (size_t)((((has_bias ? 9 : 8) + chunk_ch(C > 32 ? 32 : C)) + 15) & ~15);
 }
 
@@ -869,7 +897,7 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
     SPLAT_CHECK_ARG(uv && conic && opacity && feature && idx_sorted && tile_range && final_T && ncontrib && dL_dout &&
                         pack_scratch,
                     "null pointer");
-    SPLAT_CHECK_ARG(dL_duv && dL_dabs_uv && dL_dconic && dL_dopacity && dL_dfeature, "null gradient pointer");
+    SPLAT_CHECK_ARG(dL_duv && dL_dconic && dL_dopacity && dL_dfeature, "null gradient pointer");
     SPLAT_CHECK_ARG(!opacity_bias || dL_dopacity_bias, "bias given without dL_dopacity_bias");
     const int npm = (goff_incl != nullptr) + (slot_sorted != nullptr) + (pair_scratch != nullptr);
     SPLAT_CHECK_ARG(npm == 0 || npm == 3, "goff_incl, slot_sorted and pair_scratch go together");

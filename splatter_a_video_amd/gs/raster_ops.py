@@ -21,6 +21,20 @@ def _num_tiles(W: int, H: int) -> int:
     return ((W + 15) // 16) * ((H + 15) // 16)
 
 
+_HALF_WH = {}
+
+
+def _half_wh(W: int, H: int, device) -> Tensor:
+    """[W/2, H/2] on the device, created once per (W, H, device): building it in every backward (as the
+    reference does, alpha_blending.py:113-115) is a blocking host-to-device copy on the critical path."""
+    key = (int(W), int(H), str(device))
+    t = _HALF_WH.get(key)
+    if t is None:
+        t = torch.tensor([0.5 * W, 0.5 * H], dtype=torch.float32, device=device)
+        _HALF_WH[key] = t
+    return t
+
+
 # ------------------------------------------------------------------ sort_gaussian
 def sort_gaussian(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Tensor) -> Tuple[Tensor, Tensor]:
     """(idx_sorted[M] int32, tile_range[T,2] int32): Gaussian ids ordered by (tile, depth) and each
@@ -129,7 +143,7 @@ class _AlphaBlend(torch.autograd.Function):
             alloc = torch.zeros
             goff = slot_sorted = scratch = None
         duv = alloc(P, 2, dtype=torch.float32, device=dev)
-        dabs = alloc(P, 2, dtype=torch.float32, device=dev)
+        dabs = alloc(P, 2, dtype=torch.float32, device=dev) if has_abs else None
         dconic = alloc(P, 3, dtype=torch.float32, device=dev)
         dop = alloc(opacity.shape, dtype=torch.float32, device=dev)
         dfeat = alloc(P, C, dtype=torch.float32, device=dev)
@@ -143,7 +157,7 @@ class _AlphaBlend(torch.autograd.Function):
         # gradient taps used by densification (reference: alpha_blending.py:112-120)
         dndc = dabs_ndc = None
         if has_ndc or has_abs:
-            half = torch.tensor([0.5 * W, 0.5 * H], dtype=uv.dtype, device=dev)
+            half = _half_wh(W, H, dev)
             if has_ndc:
                 dndc = duv * half[None, :]
             if has_abs:
