@@ -121,11 +121,13 @@ class FrameRenderer:
         self.last = dict(M=idx.numel(), T=tr.shape[0])
         return img
 
-    def step(self, offs, world):
+    def step(self, offs, collective=True):
+        """one gradient step: local frames forward+backward, then ONE all-reduce of the flat bucket
+        (skipped when no process group exists, and in rank 0's private kernel-timing pass)"""
         self.bucket.zero_grad()
         for off in offs:
             self.frame(off)
-        if world > 1 or (dist.is_available() and dist.is_initialized()):
+        if collective and dist.is_available() and dist.is_initialized():
             self.bucket.all_reduce()
 
 
@@ -187,8 +189,14 @@ def main():
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run (any N)
     if launched:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # SPLAT_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a 1-GPU box (ranks share cuda:0)
+        backend = os.environ.get("SPLAT_BENCH_BACKEND", "nccl")
+        local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -206,11 +214,11 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        R.step(offs, world)
+        R.step(offs)
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        R.step(offs, world)
+        R.step(offs)
     sync()
     dt = time.perf_counter() - t0
     if launched:
@@ -230,7 +238,7 @@ def main():
         # same step again with per-kernel HIP events recorded on the launch stream
         L.profile_reset()
         L.profile_enable(True)
-        R.step(offs, 1)
+        R.step(offs, collective=False)  # rank-0 only: must not enter a collective
         torch.cuda.synchronize()
         L.profile_enable(False)
         names = ["sh_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
@@ -279,6 +287,7 @@ def main():
         }
         print(json.dumps(line))
     if launched:
+        dist.barrier()  # rank 0 did extra (untimed) measurement work: leave together
         dist.destroy_process_group()
 
 
