@@ -339,3 +339,51 @@ def render_backward(xyz, scale, rotate, opacity, intr, extr, W, H, bg, saved, dL
         out["shs"] = dshs
         out["feature"] = df[:, 3:]
     return out
+
+
+# ------------------------------------------------------------------ dynamic Gaussians (row a15)
+def dynamic_time_scalars(time, num_frames, intervals, start_frame_id, time_len):
+    """Host-side scalars of get_position / get_rotation (reference:
+    src/dynamic_gaussian_with_base_point_cloud.py:184-198,236-250) in float32 arithmetic:
+    segment index, d = t - knot, polynomial basis t^k (k<4), Fourier basis cos/sin(t k pi) (k=1..4)."""
+    intervals = np.asarray(intervals, np.float32)
+    nt = float(time) / float(num_frames - 1)
+    seg = int(np.searchsorted(intervals, np.float32(nt - 1e-7), side="left")) - 1
+    seg = max(seg, 0)
+    d = np.float32(np.float32(nt) - intervals[seg])
+    rt = np.float32((float(time) - float(start_frame_id)) / float(time_len))
+    poly = np.power(rt, np.arange(4, dtype=np.float32)).astype(np.float32)
+    k = (np.arange(4, dtype=np.float32) + np.float32(1.0))
+    arg = (rt * k * np.float32(np.pi)).astype(np.float32)
+    fourier = np.concatenate([np.cos(arg), np.sin(arg)]).astype(np.float32)
+    return seg, float(d), poly, fourier
+
+
+def dynamic_eval_forward(position, cubic, rotation, rot_poly, rot_fourier, opacity, scaling, seg, d, poly, fourier):
+    position = _f(position, (-1, 3)); P = position.shape[0]
+    cubic = _f(cubic).reshape(P, 4, -1, 3); I = cubic.shape[2]
+    rotation = _f(rotation, (-1, 4)); rot_poly = _f(rot_poly).reshape(P, 4, 4); rot_fourier = _f(rot_fourier).reshape(P, 8, 4)
+    opacity = _f(opacity).reshape(-1); scaling = _f(scaling, (-1, 3)); poly = _f(poly); fourier = _f(fourier)
+    pos = np.zeros((P, 3), np.float32); rot = np.zeros((P, 4), np.float32)
+    opa = np.zeros((P, 1), np.float32); scl = np.zeros((P, 3), np.float32)
+    lib().oracle_dynamic_eval_forward(P, I, int(seg), ctypes.c_float(d), _p(position, _f32p), _p(cubic, _f32p),
+                                      _p(rotation, _f32p), _p(rot_poly, _f32p), _p(rot_fourier, _f32p), _p(poly, _f32p),
+                                      _p(fourier, _f32p), _p(opacity, _f32p), _p(scaling, _f32p), _p(pos, _f32p),
+                                      _p(rot, _f32p), _p(opa, _f32p), _p(scl, _f32p))
+    return pos, rot, opa, scl
+
+
+def dynamic_eval_backward(cubic_shape, rotation, rot_poly, rot_fourier, opacity, scaling, seg, d, poly, fourier,
+                          g_pos, g_rot, g_opa, g_scl):
+    P, _, I, _ = cubic_shape
+    rotation = _f(rotation, (-1, 4)); rot_poly = _f(rot_poly).reshape(P, 4, 4); rot_fourier = _f(rot_fourier).reshape(P, 8, 4)
+    opacity = _f(opacity).reshape(-1); scaling = _f(scaling, (-1, 3)); poly = _f(poly); fourier = _f(fourier)
+    g_pos = _f(g_pos, (-1, 3)); g_rot = _f(g_rot, (-1, 4)); g_opa = _f(g_opa).reshape(-1); g_scl = _f(g_scl, (-1, 3))
+    dpos = np.zeros((P, 3), np.float32); dcub = np.zeros((P, 4, I, 3), np.float32); drot = np.zeros((P, 4), np.float32)
+    dopa = np.zeros((P, 1), np.float32); dscl = np.zeros((P, 3), np.float32)
+    lib().oracle_dynamic_eval_backward(P, I, int(seg), ctypes.c_float(d), _p(rotation, _f32p), _p(rot_poly, _f32p),
+                                       _p(rot_fourier, _f32p), _p(poly, _f32p), _p(fourier, _f32p), _p(opacity, _f32p),
+                                       _p(scaling, _f32p), _p(g_pos, _f32p), _p(g_rot, _f32p), _p(g_opa, _f32p),
+                                       _p(g_scl, _f32p), _p(dpos, _f32p), _p(dcub, _f32p), _p(drot, _f32p),
+                                       _p(dopa, _f32p), _p(dscl, _f32p))
+    return dpos, dcub, drot, dopa, dscl

@@ -798,3 +798,79 @@ void oracle_alpha_blending_backward(int P, int C, const float *uv, const float *
     }
     free(a_uv); free(a_abs); free(a_con); free(a_op); free(a_bias); free(a_f);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Per-frame evaluation of the dynamic Gaussians ("next" row 8f-1).
+ * Reference: src/dynamic_gaussian_with_base_point_cloud.py
+ *   get_position :236-250  position + cubic-spline segment  c3 + c2 d + c1 d^2 + c0 d^3
+ *                          (coeff [N,4,I,3]; segment index and d = t - knot are host scalars)
+ *   get_rotation :184-198  normalize(rotation + sum_k poly_k * t^k + sum_m fourier_m * basis_m),
+ *                          the two time-dependent sums are .detach()'ed (no gradient to them)
+ *   get_opacity  :171-172  sigmoid ; get_scaling :175-177 exp
+ * Pinned by tests/golden/dynamic_*.npz (generated from the reference methods).
+ * ---------------------------------------------------------------------------------------- */
+void oracle_dynamic_eval_forward(int P, int I, int seg, float d, const float *position, const float *cubic,
+                                 const float *rotation, const float *rot_poly, const float *rot_fourier,
+                                 const float *poly_basis /*[4]*/, const float *fourier_basis /*[8]*/,
+                                 const float *opacity, const float *scaling,
+                                 float *pos_t, float *rot_t, float *opa_t, float *scl_t) {
+    const float d2 = d * d, d3 = d * d * d;
+    for (int i = 0; i < P; ++i) {
+        const float *c = cubic + (size_t)i * 4 * I * 3;
+        for (int a = 0; a < 3; ++a) {
+            const float c0 = c[(0 * I + seg) * 3 + a], c1 = c[(1 * I + seg) * 3 + a];
+            const float c2 = c[(2 * I + seg) * 3 + a], c3 = c[(3 * I + seg) * 3 + a];
+            float p = c3 + c2 * d;
+            p = p + c1 * d2;
+            p = p + c0 * d3;
+            pos_t[3 * i + a] = p + position[3 * i + a];
+        }
+        float q[4];
+        for (int a = 0; a < 4; ++a) {
+            float sp = 0.f, sf = 0.f;
+            for (int k = 0; k < 4; ++k) sp += rot_poly[(i * 4 + k) * 4 + a] * poly_basis[k];
+            for (int m = 0; m < 8; ++m) sf += rot_fourier[(i * 8 + m) * 4 + a] * fourier_basis[m];
+            q[a] = rotation[4 * i + a] + sp + sf;
+        }
+        float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        if (n < 1e-12f) n = 1e-12f;
+        for (int a = 0; a < 4; ++a) rot_t[4 * i + a] = q[a] / n;
+        opa_t[i] = 1.0f / (1.0f + expf(-opacity[i]));
+        for (int a = 0; a < 3; ++a) scl_t[3 * i + a] = expf(scaling[3 * i + a]);
+    }
+}
+
+/* gradients w.r.t. position, cubic (dense, zero outside the active segment), rotation, opacity, scaling */
+void oracle_dynamic_eval_backward(int P, int I, int seg, float d, const float *rotation, const float *rot_poly,
+                                  const float *rot_fourier, const float *poly_basis, const float *fourier_basis,
+                                  const float *opacity, const float *scaling,
+                                  const float *g_pos, const float *g_rot, const float *g_opa, const float *g_scl,
+                                  float *d_position, float *d_cubic, float *d_rotation, float *d_opacity,
+                                  float *d_scaling) {
+    const float pw[4] = {d * d * d, d * d, d, 1.0f}; /* derivative of the segment value w.r.t. c0..c3 */
+    memset(d_cubic, 0, sizeof(float) * (size_t)P * 4 * I * 3);
+    for (int i = 0; i < P; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            d_position[3 * i + a] = g_pos[3 * i + a];
+            for (int k = 0; k < 4; ++k) d_cubic[((size_t)i * 4 + k) * I * 3 + seg * 3 + a] = g_pos[3 * i + a] * pw[k];
+        }
+        float q[4];
+        for (int a = 0; a < 4; ++a) {
+            float sp = 0.f, sf = 0.f;
+            for (int k = 0; k < 4; ++k) sp += rot_poly[(i * 4 + k) * 4 + a] * poly_basis[k];
+            for (int m = 0; m < 8; ++m) sf += rot_fourier[(i * 8 + m) * 4 + a] * fourier_basis[m];
+            q[a] = rotation[4 * i + a] + sp + sf;
+        }
+        const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        if (n < 1e-12f) { /* F.normalize clamps the norm: plain scaling */
+            for (int a = 0; a < 4; ++a) d_rotation[4 * i + a] = g_rot[4 * i + a] / 1e-12f;
+        } else {
+            float dot = 0.f;
+            for (int a = 0; a < 4; ++a) dot += (q[a] / n) * g_rot[4 * i + a];
+            for (int a = 0; a < 4; ++a) d_rotation[4 * i + a] = (g_rot[4 * i + a] - (q[a] / n) * dot) / n;
+        }
+        const float s = 1.0f / (1.0f + expf(-opacity[i]));
+        d_opacity[i] = g_opa[i] * s * (1.0f - s);
+        for (int a = 0; a < 3; ++a) d_scaling[3 * i + a] = g_scl[3 * i + a] * expf(scaling[3 * i + a]);
+    }
+}

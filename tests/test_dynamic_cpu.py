@@ -1,0 +1,62 @@
+"""Row a15 (per-frame dynamic Gaussian evaluation): the C oracle pinned to vectors produced by the reference's own
+get_position / get_rotation / get_opacity / get_scaling (tests/golden/make_golden_dynamic.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+G = os.path.join(os.path.dirname(__file__), "golden", "dynamic_400x50.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(G))
+
+
+def _scalars(g, t):
+    return oracle.dynamic_time_scalars(int(t), int(g["T"]), g["intervals"], int(g["start_frame_id"]), int(g["time_len"]))
+
+
+def test_segment_lookup_matches_reference_knots(gold):
+    # frames that sit exactly on a knot belong to the segment that ENDS there (searchsorted(nt-1e-7) - 1), frame 0 to segment 0
+    T, I = int(gold["T"]), int(gold["I"])
+    knots = np.linspace(0, T - 1, I + 1).astype(np.int64)
+    for t in range(T):
+        seg, d, _, _ = _scalars(gold, t)
+        want = 0 if t == 0 else int(np.searchsorted(knots, t, side="left")) - 1
+        assert seg == want, (t, seg, want)
+        assert 0.0 <= d <= 1.0
+
+
+@pytest.mark.parametrize("t", [0, 1, 5, 24, 25, 44, 45, 49])
+def test_forward_matches_reference(gold, t):
+    g = gold
+    seg, d, poly, fourier = _scalars(g, t)
+    pos, rot, opa, scl = oracle.dynamic_eval_forward(g["position"], g["pos_cubic_node"], g["rotation"], g["rot_poly_feat"],
+                                                     g["rot_fourier_feat"], g["opacity"], g["scaling"], seg, d, poly, fourier)
+    pre = f"t{t}_"
+    np.testing.assert_allclose(pos, g[pre + "pos"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(rot, g[pre + "rot"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(opa, g[pre + "opa"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(scl, g[pre + "scl"], rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("t", [0, 1, 5, 24, 25, 44, 45, 49])
+def test_backward_matches_reference(gold, t):
+    g = gold
+    N, I = g["position"].shape[0], int(g["I"])
+    seg, d, poly, fourier = _scalars(g, t)
+    pre = f"t{t}_"
+    dpos, dcub, drot, dopa, dscl = oracle.dynamic_eval_backward(
+        (N, 4, I, 3), g["rotation"], g["rot_poly_feat"], g["rot_fourier_feat"], g["opacity"], g["scaling"], seg, d, poly,
+        fourier, g[pre + "g_pos"], g[pre + "g_rot"], g[pre + "g_opa"], g[pre + "g_scl"])
+    np.testing.assert_allclose(dpos, g[pre + "d_position"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dcub.reshape(N, -1), g[pre + "d_cubic"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(drot, g[pre + "d_rotation"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dopa, g[pre + "d_opacity"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(dscl, g[pre + "d_scaling"], rtol=2e-6, atol=1e-9)
+    # only the active segment of the spline table receives gradient
+    mask = np.ones(I, bool); mask[seg] = False
+    assert not dcub[:, :, mask, :].any()
