@@ -139,6 +139,32 @@ int splat_alpha_blending_backward(int P, int C, const float *uv, const float *co
                                   int pack_is_valid /*pack_scratch still holds the forward's records (C <= 32)*/,
                                   splat_stream_t stream);
 
+/* ---- per-frame evaluation of the dynamic Gaussians --------------------------------------
+ * Replaces the eager torch of src/dynamic_gaussian_with_base_point_cloud.py:
+ *   get_position :236-250  pos_t = position + c3 + c2 d + c1 d^2 + c0 d^3, c = cubic[N,4,I,3][:, :, seg]
+ *   get_rotation :184-198  rot_t = normalize(rotation + sum_k rot_poly[N,4,4][:,k] t^k + sum_m rot_fourier[N,8,4][:,m] f_m)
+ *                          (both sums are detached in the reference: rot_poly / rot_fourier receive no gradient)
+ *   get_opacity  :171-172  opa_t = sigmoid(opacity) ;  get_scaling :175-177  scl_t = exp(scaling)
+ * seg, d and the 12 basis values (t^0..t^3, cos(t k pi) k=1..4, sin(t k pi) k=1..4) are per-frame HOST scalars
+ * (basis_host is a HOST pointer, copied into the kernel arguments; no device read of it).  All other pointers are
+ * device pointers.  Any output (and, in the backward, any g_* / d_* pair) may be NULL to skip it.
+ * cubic_layout: SPLAT_CUBIC_GAUSSIAN_MAJOR reads the reference's table as is (4 strided 12-byte reads per Gaussian,
+ * one 128-byte line each); SPLAT_CUBIC_SEGMENT_MAJOR is the native layout (4x less HBM traffic for this row).
+ * backward: accumulate=0 stores, accumulate=1 adds into the d_* buffers (gradient-bucket use).  d_cubic [N,4,I,3]
+ * is touched ONLY in the active segment; with accumulate=0 the caller zero-fills it once if it needs the dense
+ * gradient the reference's autograd produces. */
+#define SPLAT_CUBIC_GAUSSIAN_MAJOR 0 /* cubic[N,4,I,3]: the reference's parameter layout (:73-75) */
+#define SPLAT_CUBIC_SEGMENT_MAJOR 1  /* cubic[I,N,4,3]: one contiguous 48-byte record per Gaussian and frame */
+int splat_dynamic_eval_forward(int P, int I, int seg, float d, const float *basis_host, const float *position,
+                               const float *cubic, int cubic_layout, const float *rotation, const float *rot_poly,
+                               const float *rot_fourier, const float *opacity, const float *scaling, float *pos_t,
+                               float *rot_t, float *opa_t, float *scl_t, splat_stream_t stream);
+int splat_dynamic_eval_backward(int P, int I, int seg, float d, const float *basis_host, const float *rotation,
+                                const float *rot_poly, const float *rot_fourier, const float *opacity,
+                                const float *scaling, const float *g_pos, const float *g_rot, const float *g_opa,
+                                const float *g_scl, int accumulate, int cubic_layout, float *d_position, float *d_cubic,
+                                float *d_rotation, float *d_opacity, float *d_scaling, splat_stream_t stream);
+
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */
 void splat_profile_enable(int on);
 void splat_profile_reset(void);

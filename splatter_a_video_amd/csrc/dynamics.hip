@@ -1,0 +1,217 @@
+// Per-frame evaluation of the dynamic Gaussians: canonical parameters + time -> the
+// per-frame position / rotation / opacity / scaling the rasterizer chain consumes, and the matching backward.
+// Replaces the eager torch of the reference's point-cloud class
+// (src/dynamic_gaussian_with_base_point_cloud.py:171-198 get_opacity/get_scaling/get_rotation, :236-250 get_position).
+//
+// One quad (4 adjacent lanes) per Gaussian: lane j<3 owns position/scaling component j, lane 3 owns the opacity,
+// lane a owns quaternion component a.  The [N,4,4] / [N,8,4] rotation tables are read as one float4 row per lane
+// (a wave reads 1 KiB contiguous per instruction) and transposed-reduced inside the quad with DPP quad_perm;
+// every output is written component-per-lane, i.e. contiguous across the wave.
+#include "common.h"
+
+namespace {
+
+struct DynBasis {
+    float poly[4];     // t^k, k = 0..3
+    float fourier[8];  // cos(t k pi) k=1..4, then sin(t k pi) k=1..4
+};
+
+// where coefficient k of Gaussian n for the active segment lives: cubic[seg_off + n*stride_n + k*stride_k + axis]
+struct CubicAddr {
+    size_t seg_off, stride_n, stride_k;
+};
+
+constexpr int DYN_BLOCK = 256;  // 64 Gaussians per workgroup
+
+__device__ __forceinline__ float quad_xor1(float v) { return dpp_f<0xB1, 0xf, 0xf, true>(v); }  // quad_perm:[1,0,3,2]
+__device__ __forceinline__ float quad_xor2(float v) { return dpp_f<0x4E, 0xf, 0xf, true>(v); }  // quad_perm:[2,3,0,1]
+__device__ __forceinline__ float quad_sum(float v) {
+    v += quad_xor1(v);
+    v += quad_xor2(v);
+    return v;
+}
+
+// lane j holds a float4 partial; returns in lane a the sum over the quad of component a
+__device__ __forceinline__ float quad_transpose_sum(float4 v, int j) {
+    const bool odd = j & 1, hi = j & 2;
+    // pairs (x,y) and (z,w): keep the component whose parity matches the lane, send the other to the xor-1 partner
+    const float keep_xy = odd ? v.y : v.x, send_xy = odd ? v.x : v.y;
+    const float keep_zw = odd ? v.w : v.z, send_zw = odd ? v.z : v.w;
+    const float xy = keep_xy + quad_xor1(send_xy);  // lanes 0,2: x over {j,j^1};  lanes 1,3: y
+    const float zw = keep_zw + quad_xor1(send_zw);  // lanes 0,2: z;               lanes 1,3: w
+    const float keep = hi ? zw : xy, send = hi ? xy : zw;
+    return keep + quad_xor2(send);
+}
+
+// un-normalised quaternion component of this lane: rotation + detached polynomial + Fourier sums (:184-198)
+__device__ __forceinline__ float quat_component(int n, int j, const DynBasis &b, const float *rotation,
+                                                const float4 *rot_poly, const float4 *rot_fourier) {
+    const float4 rp = rot_poly[(size_t)n * 4 + j];
+    const float4 f0 = rot_fourier[(size_t)n * 8 + j];
+    const float4 f1 = rot_fourier[(size_t)n * 8 + 4 + j];
+    const float wp = b.poly[j], w0 = b.fourier[j], w1 = b.fourier[4 + j];
+    float4 part;
+    part.x = rp.x * wp + f0.x * w0 + f1.x * w1;
+    part.y = rp.y * wp + f0.y * w0 + f1.y * w1;
+    part.z = rp.z * wp + f0.z * w0 + f1.z * w1;
+    part.w = rp.w * wp + f0.w * w0 + f1.w * w1;
+    return rotation[(size_t)n * 4 + j] + quad_transpose_sum(part, j);
+}
+
+__global__ __launch_bounds__(DYN_BLOCK) void dynamic_eval_fwd_kernel(
+    int P, CubicAddr ca, float d, DynBasis b, const float *__restrict__ position, const float *__restrict__ cubic,
+    const float *__restrict__ rotation, const float4 *__restrict__ rot_poly, const float4 *__restrict__ rot_fourier,
+    const float *__restrict__ opacity, const float *__restrict__ scaling, float *__restrict__ pos_t,
+    float *__restrict__ rot_t, float *__restrict__ opa_t, float *__restrict__ scl_t) {
+    const int t = blockIdx.x * DYN_BLOCK + threadIdx.x;
+    const int n = t >> 2, j = t & 3;
+    if (n >= P) return;  // whole quads leave together
+    if (pos_t && j < 3) {
+        // segment polynomial c3 + c2 d + c1 d^2 + c0 d^3 of the [N,4,I,3] table (:241-248)
+        const float *c = cubic + ca.seg_off + (size_t)n * ca.stride_n + j;
+        const size_t row = ca.stride_k;
+        const float c0 = c[0], c1 = c[row], c2 = c[2 * row], c3 = c[3 * row];
+        float p = c3 + c2 * d;
+        p = p + c1 * (d * d);
+        p = p + c0 * (d * d * d);
+        pos_t[(size_t)n * 3 + j] = p + position[(size_t)n * 3 + j];
+    }
+    if (rot_t) {
+        const float q = quat_component(n, j, b, rotation, rot_poly, rot_fourier);
+        const float nrm = fmaxf(sqrtf(quad_sum(q * q)), 1e-12f);  // F.normalize: x / max(|x|, eps)
+        rot_t[(size_t)n * 4 + j] = q / nrm;
+    }
+    if (scl_t && j < 3) scl_t[(size_t)n * 3 + j] = expf(scaling[(size_t)n * 3 + j]);
+    if (opa_t && j == 3) opa_t[n] = 1.0f / (1.0f + expf(-opacity[n]));
+}
+
+template <bool ACC>
+__device__ __forceinline__ void put(float *p, float v) {
+    if (ACC)
+        *p += v;
+    else
+        *p = v;
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(DYN_BLOCK) void dynamic_eval_bwd_kernel(
+    int P, CubicAddr ca, float d, DynBasis b, const float *__restrict__ rotation,
+    const float4 *__restrict__ rot_poly, const float4 *__restrict__ rot_fourier, const float *__restrict__ opacity,
+    const float *__restrict__ scaling, const float *__restrict__ g_pos, const float *__restrict__ g_rot,
+    const float *__restrict__ g_opa, const float *__restrict__ g_scl, float *__restrict__ d_position,
+    float *__restrict__ d_cubic, float *__restrict__ d_rotation, float *__restrict__ d_opacity,
+    float *__restrict__ d_scaling) {
+    const int t = blockIdx.x * DYN_BLOCK + threadIdx.x;
+    const int n = t >> 2, j = t & 3;
+    if (n >= P) return;
+    if (g_pos && j < 3) {
+        const float g = g_pos[(size_t)n * 3 + j];
+        if (d_position) put<ACC>(d_position + (size_t)n * 3 + j, g);
+        if (d_cubic) {  // only the active segment of the spline table is touched
+            float *c = d_cubic + ca.seg_off + (size_t)n * ca.stride_n + j;
+            const size_t row = ca.stride_k;
+            put<ACC>(c, g * (d * d * d));
+            put<ACC>(c + row, g * (d * d));
+            put<ACC>(c + 2 * row, g * d);
+            put<ACC>(c + 3 * row, g);
+        }
+    }
+    if (g_rot && d_rotation) {
+        const float q = quat_component(n, j, b, rotation, rot_poly, rot_fourier);
+        const float nrm = sqrtf(quad_sum(q * q));
+        const float g = g_rot[(size_t)n * 4 + j];
+        float dq;
+        if (nrm < 1e-12f) {
+            dq = g / 1e-12f;  // clamped norm: plain scaling
+        } else {
+            const float qh = q / nrm;
+            const float dot = quad_sum(qh * g);
+            dq = (g - qh * dot) / nrm;
+        }
+        put<ACC>(d_rotation + (size_t)n * 4 + j, dq);
+    }
+    if (g_scl && d_scaling && j < 3)
+        put<ACC>(d_scaling + (size_t)n * 3 + j, g_scl[(size_t)n * 3 + j] * expf(scaling[(size_t)n * 3 + j]));
+    if (g_opa && d_opacity && j == 3) {
+        const float s = 1.0f / (1.0f + expf(-opacity[n]));
+        put<ACC>(d_opacity + n, g_opa[n] * s * (1.0f - s));
+    }
+}
+
+inline dim3 dyn_grid(int P) { return dim3((unsigned)(((size_t)P * 4 + DYN_BLOCK - 1) / DYN_BLOCK)); }
+
+// SPLAT_CUBIC_GAUSSIAN_MAJOR: the reference's [N,4,I,3]; SPLAT_CUBIC_SEGMENT_MAJOR: [I,N,4,3], one contiguous
+// 48-byte record per Gaussian and frame
+inline CubicAddr cubic_addr(int layout, int P, int I, int seg) {
+    CubicAddr a;
+    if (layout == SPLAT_CUBIC_SEGMENT_MAJOR) {
+        a.seg_off = (size_t)seg * (size_t)P * 12;
+        a.stride_n = 12;
+        a.stride_k = 3;
+    } else {
+        a.seg_off = (size_t)seg * 3;
+        a.stride_n = (size_t)4 * I * 3;
+        a.stride_k = (size_t)I * 3;
+    }
+    return a;
+}
+
+inline DynBasis load_basis(const float *host12) {
+    DynBasis b;
+    memcpy(b.poly, host12, sizeof(float) * 4);
+    memcpy(b.fourier, host12 + 4, sizeof(float) * 8);
+    return b;
+}
+
+}  // namespace
+
+extern "C" int splat_dynamic_eval_forward(int P, int I, int seg, float d, const float *basis_host,
+                                          const float *position, const float *cubic, int cubic_layout, const float *rotation,
+                                          const float *rot_poly, const float *rot_fourier, const float *opacity,
+                                          const float *scaling, float *pos_t, float *rot_t, float *opa_t, float *scl_t,
+                                          void *stream) {
+    SPLAT_CHECK_ARG(P >= 0 && I >= 1, "P >= 0 and I >= 1 required");
+    SPLAT_CHECK_ARG(seg >= 0 && seg < I, "segment index out of range");
+    SPLAT_CHECK_ARG(basis_host != nullptr, "basis_host (12 host floats) is required");
+    SPLAT_CHECK_ARG(cubic_layout == SPLAT_CUBIC_GAUSSIAN_MAJOR || cubic_layout == SPLAT_CUBIC_SEGMENT_MAJOR,
+                    "unknown cubic_layout");
+    SPLAT_CHECK_ARG(!pos_t || (position && cubic), "pos_t needs position and cubic");
+    SPLAT_CHECK_ARG(!rot_t || (rotation && rot_poly && rot_fourier), "rot_t needs rotation, rot_poly, rot_fourier");
+    SPLAT_CHECK_ARG(!opa_t || opacity, "opa_t needs opacity");
+    SPLAT_CHECK_ARG(!scl_t || scaling, "scl_t needs scaling");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_LAUNCH("dynamic_eval_fwd", dynamic_eval_fwd_kernel, dyn_grid(P), dim3(DYN_BLOCK), 0, (hipStream_t)stream, P,
+                 cubic_addr(cubic_layout, P, I, seg), d, load_basis(basis_host), position, cubic, rotation, (const float4 *)rot_poly,
+                 (const float4 *)rot_fourier, opacity, scaling, pos_t, rot_t, opa_t, scl_t);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_dynamic_eval_backward(int P, int I, int seg, float d, const float *basis_host,
+                                           const float *rotation, const float *rot_poly, const float *rot_fourier,
+                                           const float *opacity, const float *scaling, const float *g_pos,
+                                           const float *g_rot, const float *g_opa, const float *g_scl, int accumulate,
+                                           int cubic_layout, float *d_position, float *d_cubic, float *d_rotation, float *d_opacity,
+                                           float *d_scaling, void *stream) {
+    SPLAT_CHECK_ARG(P >= 0 && I >= 1, "P >= 0 and I >= 1 required");
+    SPLAT_CHECK_ARG(seg >= 0 && seg < I, "segment index out of range");
+    SPLAT_CHECK_ARG(basis_host != nullptr, "basis_host (12 host floats) is required");
+    SPLAT_CHECK_ARG(cubic_layout == SPLAT_CUBIC_GAUSSIAN_MAJOR || cubic_layout == SPLAT_CUBIC_SEGMENT_MAJOR,
+                    "unknown cubic_layout");
+    SPLAT_CHECK_ARG(!(g_rot && d_rotation) || (rotation && rot_poly && rot_fourier),
+                    "rotation gradient needs rotation, rot_poly, rot_fourier");
+    SPLAT_CHECK_ARG(!(g_opa && d_opacity) || opacity, "opacity gradient needs opacity");
+    SPLAT_CHECK_ARG(!(g_scl && d_scaling) || scaling, "scaling gradient needs scaling");
+    if (P == 0) return SPLAT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (accumulate)
+        SPLAT_LAUNCH("dynamic_eval_bwd", dynamic_eval_bwd_kernel<true>, dyn_grid(P), dim3(DYN_BLOCK), 0, s, P,
+                     cubic_addr(cubic_layout, P, I, seg), d, load_basis(basis_host), rotation, (const float4 *)rot_poly, (const float4 *)rot_fourier, opacity,
+                     scaling, g_pos, g_rot, g_opa, g_scl, d_position, d_cubic, d_rotation, d_opacity, d_scaling);
+    else
+        SPLAT_LAUNCH("dynamic_eval_bwd", dynamic_eval_bwd_kernel<false>, dyn_grid(P), dim3(DYN_BLOCK), 0, s, P,
+                     cubic_addr(cubic_layout, P, I, seg), d, load_basis(basis_host), rotation, (const float4 *)rot_poly, (const float4 *)rot_fourier, opacity,
+                     scaling, g_pos, g_rot, g_opa, g_scl, d_position, d_cubic, d_rotation, d_opacity, d_scaling);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}

@@ -1,0 +1,253 @@
+"""Per-frame evaluation of the dynamic Gaussians on the native path.
+
+Mirrors what the reference's point-cloud class computes per rendered frame
+(reference: src/dynamic_gaussian_with_base_point_cloud.py:171-198 ``get_opacity`` / ``get_scaling`` /
+``get_rotation(time)``, :236-250 ``get_position(time)``; knot construction :64-66) -- one fused HIP launch
+for all four outputs instead of ~25 eager torch kernels, one fused launch for the backward.
+
+* ``FrameClock``      host-side per-frame scalars (segment index, offset inside the segment, time bases).
+* ``evaluate(...)``   functional form (autograd-aware), any subset of outputs.
+* ``DynamicGaussians`` parameter holder with the reference's attribute and getter names.
+
+There is no CPU fallback: the tensors must live on the GPU and libsplat_hip.so must be built.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+_F12 = ctypes.c_float * 12
+
+# layouts of the spline table (include/splat_hip.h)
+GAUSSIAN_MAJOR = 0      # [N, 4*I*3] == [N,4,I,3]: the reference's parameter (:73-75)
+SEGMENT_MAJOR = 1       # [I, N, 4, 3]: native layout, one contiguous 48-byte record per Gaussian and frame
+
+
+def to_segment_major(pos_cubic_node: Tensor, interval_num: int) -> Tensor:
+    """reference layout [N, 4*I*3] -> native [I, N, 4, 3] (checkpoint import)"""
+    N = pos_cubic_node.shape[0]
+    return pos_cubic_node.reshape(N, 4, interval_num, 3).permute(2, 0, 1, 3).contiguous()
+
+
+def to_gaussian_major(cubic_seg: Tensor) -> Tensor:
+    """native [I, N, 4, 3] -> reference layout [N, 4*I*3] (checkpoint export)"""
+    I, N = cubic_seg.shape[0], cubic_seg.shape[1]
+    return cubic_seg.permute(1, 2, 0, 3).reshape(N, 4 * I * 3).contiguous()
+
+
+class FrameClock:
+    """Time scalars of one clip.  ``intervals`` are the float32 spline knots in [0, 1]; when omitted they are
+    built like the reference does (:64-66): one segment per 5 frames, knots at truncated linspace frame indices."""
+
+    def __init__(self, num_frames: int, intervals: Optional[Sequence[float]] = None, start_frame_id: int = 0,
+                 time_len: Optional[int] = None):
+        if num_frames < 2:
+            raise ValueError("a clip needs at least 2 frames")
+        self.num_frames = int(num_frames)
+        if intervals is None:
+            n_seg = math.ceil(num_frames / 5)
+            idx = np.linspace(0, num_frames - 1, n_seg + 1, dtype=np.float32).astype(np.int64)
+            intervals = idx.astype(np.float32) / np.float32(num_frames - 1)
+        self.intervals = np.ascontiguousarray(np.asarray(intervals, dtype=np.float32))
+        if self.intervals.ndim != 1 or self.intervals.size < 2:
+            raise ValueError("intervals must hold at least two knots")
+        self.interval_num = int(self.intervals.size - 1)
+        self.start_frame_id = int(start_frame_id)
+        self.time_len = int(time_len if time_len is not None else num_frames - 1)
+        self._cache: Dict[float, Tuple[int, float, "ctypes.Array"]] = {}
+
+    def scalars(self, time) -> Tuple[int, float, "ctypes.Array"]:
+        """(segment, d, basis[12]) for frame ``time`` in the reference's float32 arithmetic: the segment is
+        searchsorted(knots, t - 1e-7) - 1 clamped at 0 (:243-245), d = t - knot[segment]; basis = t'^0..3,
+        cos(t' k pi), sin(t' k pi), k = 1..4 with t' = (time - start_frame_id) / time_len (:186-193)."""
+        if isinstance(time, Tensor):
+            time = time.item()
+        key = float(time)
+        hit = self._cache.get(key)
+        if hit is not None:
+            return hit
+        nt = key / float(self.num_frames - 1)
+        seg = int(np.searchsorted(self.intervals, np.float32(nt - 1e-7), side="left")) - 1
+        seg = min(max(seg, 0), self.interval_num - 1)
+        d = float(np.float32(nt) - self.intervals[seg])
+        rt = np.float32((key - float(self.start_frame_id)) / float(self.time_len))
+        k = np.arange(4, dtype=np.float32)
+        arg = (rt * (k + np.float32(1.0)) * np.float32(np.pi)).astype(np.float32)
+        basis = np.concatenate([np.power(rt, k), np.cos(arg), np.sin(arg)]).astype(np.float32)
+        out = (seg, d, _F12(*basis.tolist()))
+        self._cache[key] = out
+        return out
+
+
+def _opt(t: Optional[Tensor], name: str, rows: int, width: int) -> Optional[Tensor]:
+    if t is None:
+        return None
+    t = L.need(t, name)
+    if t.numel() != rows * width:
+        raise ValueError(f"{name} must hold {rows} x {width} floats, got shape {tuple(t.shape)}")
+    return t
+
+
+class _DynamicEval(torch.autograd.Function):
+    """inputs: position[N,3] cubic[N,4*I*3] rotation[N,4] rot_poly[N,4,4] rot_fourier[N,8,4] opacity[N,1] scaling[N,3]
+    outputs: pos_t[N,3] rot_t[N,4] opa_t[N,1] scl_t[N,3] (a zero-size tensor for a group whose inputs are None)."""
+
+    @staticmethod
+    def forward(ctx, position, cubic, rotation, rot_poly, rot_fourier, opacity, scaling, seg, d, basis, I, sink, layout):
+        ctx.set_materialize_grads(False)             # an unused output arrives as None, not as a zero tensor
+        ref = next(t for t in (position, rotation, opacity, scaling) if t is not None)
+        N, dev = ref.shape[0], ref.device
+        want_pos = position is not None and cubic is not None
+        want_rot = rotation is not None
+        position = _opt(position, "position", N, 3) if want_pos else None
+        cubic = _opt(cubic, "pos_cubic_node", N, 4 * I * 3) if want_pos else None
+        rotation = _opt(rotation, "rotation", N, 4)
+        rot_poly = _opt(rot_poly, "rot_poly_feat", N, 16) if want_rot else None
+        rot_fourier = _opt(rot_fourier, "rot_fourier_feat", N, 32) if want_rot else None
+        if want_rot and (rot_poly is None or rot_fourier is None):
+            raise ValueError("rotation needs rot_poly_feat [N,4,4] and rot_fourier_feat [N,8,4]")
+        opacity = _opt(opacity, "opacity", N, 1)
+        scaling = _opt(scaling, "scaling", N, 3)
+        new = lambda w, on: torch.empty((N, w) if on else (0,), dtype=torch.float32, device=dev)
+        pos_t, rot_t = new(3, want_pos), new(4, want_rot)
+        opa_t, scl_t = new(1, opacity is not None), new(3, scaling is not None)
+        on = lambda t, flag: L.ptr(t if flag else None)
+        L.check(L.lib().splat_dynamic_eval_forward(
+            L.ci(N), L.ci(I), L.ci(seg), L.cf(d), basis, L.ptr(position), L.ptr(cubic), L.ci(layout),
+            L.ptr(rotation), L.ptr(rot_poly), L.ptr(rot_fourier), L.ptr(opacity), L.ptr(scaling), on(pos_t, want_pos),
+            on(rot_t, want_rot), on(opa_t, opacity is not None), on(scl_t, scaling is not None), L.stream()))
+        ctx.meta = (N, int(I), int(seg), float(d), basis, want_pos, cubic.shape if want_pos else None, int(layout))
+        ctx.sink = sink
+        ctx.save_for_backward(rotation, rot_poly, rot_fourier, opacity, scaling)
+        ctx.mark_non_differentiable(*[t for t, f in ((pos_t, want_pos), (rot_t, want_rot), (opa_t, opacity is not None),
+                                                    (scl_t, scaling is not None)) if not f])
+        return pos_t, rot_t, opa_t, scl_t
+
+    @staticmethod
+    def backward(ctx, g_pos, g_rot, g_opa, g_scl):
+        N, I, seg, d, basis, want_pos, cubic_shape, layout = ctx.meta
+        rotation, rot_poly, rot_fourier, opacity, scaling = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        sink = ctx.sink or {}
+        dev = next(t for t in (g_pos, g_rot, g_opa, g_scl) if t is not None).device
+
+        def grad_of(idx, name, g, shape, zero=False):
+            """(buffer the kernel writes, tensor handed back to autograd)"""
+            if g is None or not need[idx]:
+                return None, None
+            if name in sink:                        # accumulate straight into the caller's gradient bucket
+                return sink[name], None
+            buf = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=dev)
+            return buf, buf
+
+        g_pos = L.need(g_pos, "g_pos") if (g_pos is not None and want_pos and (need[0] or need[1])) else None
+        g_rot = L.need(g_rot, "g_rot") if (g_rot is not None and rotation is not None and need[2]) else None
+        g_opa = L.need(g_opa, "g_opa") if (g_opa is not None and opacity is not None and need[5]) else None
+        g_scl = L.need(g_scl, "g_scl") if (g_scl is not None and scaling is not None and need[6]) else None
+        b_pos, r_pos = grad_of(0, "position", g_pos, (N, 3))
+        b_cub, r_cub = grad_of(1, "pos_cubic_node", g_pos, cubic_shape, zero=True)   # dense like the reference's autograd
+        b_rot, r_rot = grad_of(2, "rotation", g_rot, (N, 4))
+        b_opa, r_opa = grad_of(5, "opacity", g_opa, (N, 1))
+        b_scl, r_scl = grad_of(6, "scaling", g_scl, (N, 3))
+        acc = 1 if sink else 0
+        if sink and any(r is not None for r in (r_pos, r_cub, r_rot, r_opa, r_scl)):
+            raise ValueError("grad_sink must cover every parameter that requires grad: "
+                             "position, pos_cubic_node, rotation, opacity, scaling")
+        L.check(L.lib().splat_dynamic_eval_backward(
+            L.ci(N), L.ci(I), L.ci(seg), L.cf(d), basis, L.ptr(rotation), L.ptr(rot_poly), L.ptr(rot_fourier),
+            L.ptr(opacity), L.ptr(scaling), L.ptr(g_pos), L.ptr(g_rot), L.ptr(g_opa), L.ptr(g_scl), L.ci(acc),
+            L.ci(layout), L.ptr(b_pos), L.ptr(b_cub), L.ptr(b_rot), L.ptr(b_opa), L.ptr(b_scl), L.stream()))
+        # rot_poly / rot_fourier: the reference detaches both sums (:195-197) -> no gradient
+        return r_pos, r_cub, r_rot, None, None, r_opa, r_scl, None, None, None, None, None, None
+
+
+def evaluate(clock: FrameClock, time, *, position: Optional[Tensor] = None, pos_cubic_node: Optional[Tensor] = None,
+             rotation: Optional[Tensor] = None, rot_poly_feat: Optional[Tensor] = None,
+             rot_fourier_feat: Optional[Tensor] = None, opacity: Optional[Tensor] = None,
+             scaling: Optional[Tensor] = None, grad_sink: Optional[Dict[str, Tensor]] = None,
+             cubic_layout: int = GAUSSIAN_MAJOR):
+    """One fused launch: returns (pos_t, rot_t, opa_t, scl_t); an entry is None when its inputs were not given.
+
+    ``grad_sink`` (optional) maps parameter names to float32 buffers of the parameter's shape: the backward then
+    ADDS the gradients into those buffers (e.g. views of a ``FlatGradBucket``) and autograd sees no gradient for
+    them -- no dense zero-filled spline gradient, no AccumulateGrad kernels.
+    ``cubic_layout``: GAUSSIAN_MAJOR (reference, [N,4*I*3]) or SEGMENT_MAJOR (native, [I,N,4,3]) for
+    ``pos_cubic_node`` and its gradient.
+    """
+    if cubic_layout not in (GAUSSIAN_MAJOR, SEGMENT_MAJOR):
+        raise ValueError("cubic_layout must be GAUSSIAN_MAJOR or SEGMENT_MAJOR")
+    seg, d, basis = clock.scalars(time)
+    if grad_sink:
+        for k, v in grad_sink.items():
+            L.need(v, f"grad_sink[{k}]")
+            if not v.is_contiguous():
+                raise ValueError(f"grad_sink[{k}] must be contiguous")
+    pos_t, rot_t, opa_t, scl_t = _DynamicEval.apply(position, pos_cubic_node, rotation, rot_poly_feat, rot_fourier_feat,
+                                                    opacity, scaling, seg, d, basis, clock.interval_num, grad_sink,
+                                                    cubic_layout)
+    pick = lambda t: t if t.numel() or (t.dim() == 2) else None
+    return pick(pos_t), pick(rot_t), pick(opa_t), pick(scl_t)
+
+
+class DynamicGaussians(torch.nn.Module):
+    """Parameter holder with the reference's attribute / getter names (position, pos_cubic_node, rotation,
+    rot_poly_feat, rot_fourier_feat, opacity, scaling; get_position(time), get_rotation(time), get_opacity,
+    get_scaling) plus ``frame(time)``, the fused form the MI355X renderer uses."""
+
+    def __init__(self, clock: FrameClock, position: Tensor, pos_cubic_node: Tensor, rotation: Tensor, opacity: Tensor,
+                 scaling: Tensor, rot_poly_feat: Optional[Tensor] = None, rot_fourier_feat: Optional[Tensor] = None,
+                 cubic_layout: int = GAUSSIAN_MAJOR):
+        """``pos_cubic_node`` is given in the reference layout [N, 4*I*3]; with ``cubic_layout=SEGMENT_MAJOR`` it is
+        STORED (and optimised) as [I,N,4,3] and ``reference_pos_cubic_node()`` converts back for checkpoints."""
+        super().__init__()
+        N = position.shape[0]
+        self.clock = clock
+        self.cubic_layout = int(cubic_layout)
+        P = torch.nn.Parameter
+        self.position = P(position.contiguous(), requires_grad=False)            # :90 position is not optimised
+        if pos_cubic_node.numel() != N * 4 * clock.interval_num * 3:
+            raise ValueError("pos_cubic_node must be [N, 4 * interval_num * 3]")
+        pos_cubic_node = pos_cubic_node.reshape(N, -1)
+        if self.cubic_layout == SEGMENT_MAJOR:
+            pos_cubic_node = to_segment_major(pos_cubic_node, clock.interval_num)
+        self.pos_cubic_node = P(pos_cubic_node.contiguous())
+        self.rotation = P(rotation.contiguous())
+        self.opacity = P(opacity.reshape(N, 1).contiguous())
+        self.scaling = P(scaling.contiguous())
+        z = lambda k: torch.zeros(N, k, 4, dtype=torch.float32, device=position.device)
+        self.rot_poly_feat = P(rot_poly_feat.contiguous() if rot_poly_feat is not None else z(4))
+        self.rot_fourier_feat = P(rot_fourier_feat.contiguous() if rot_fourier_feat is not None else z(8))
+
+    def reference_pos_cubic_node(self) -> Tensor:
+        """the spline table in the reference's [N, 4*I*3] layout (checkpoint export)"""
+        t = self.pos_cubic_node.detach()
+        return to_gaussian_major(t) if self.cubic_layout == SEGMENT_MAJOR else t
+
+    def frame(self, time, grad_sink: Optional[Dict[str, Tensor]] = None):
+        return evaluate(self.clock, time, position=self.position, pos_cubic_node=self.pos_cubic_node,
+                        rotation=self.rotation, rot_poly_feat=self.rot_poly_feat,
+                        rot_fourier_feat=self.rot_fourier_feat, opacity=self.opacity, scaling=self.scaling,
+                        grad_sink=grad_sink, cubic_layout=self.cubic_layout)
+
+    def get_position(self, time, detach_pos: bool = False) -> Tensor:
+        return evaluate(self.clock, time, position=self.position, pos_cubic_node=self.pos_cubic_node,
+                        cubic_layout=self.cubic_layout)[0]
+
+    def get_rotation(self, time) -> Tensor:
+        return evaluate(self.clock, time, rotation=self.rotation, rot_poly_feat=self.rot_poly_feat,
+                        rot_fourier_feat=self.rot_fourier_feat)[1]
+
+    @property
+    def get_opacity(self) -> Tensor:
+        return evaluate(self.clock, 0, opacity=self.opacity)[2]
+
+    @property
+    def get_scaling(self) -> Tensor:
+        return evaluate(self.clock, 0, scaling=self.scaling)[3]

@@ -60,3 +60,33 @@ def test_backward_matches_reference(gold, t):
     # only the active segment of the spline table receives gradient
     mask = np.ones(I, bool); mask[seg] = False
     assert not dcub[:, :, mask, :].any()
+
+
+def test_frame_clock_matches_oracle_scalars(gold):
+    """host logic of the product path (splatter_a_video_amd.dynamics.FrameClock) against the oracle's restatement"""
+    from splatter_a_video_amd.dynamics import FrameClock
+    T = int(gold["T"])
+    clock = FrameClock(T)                                   # builds the knots the way the reference does
+    np.testing.assert_array_equal(clock.intervals, gold["intervals"])
+    assert clock.interval_num == int(gold["I"])
+    for t in range(T):
+        seg, d, basis = clock.scalars(t)
+        oseg, od, opoly, ofour = _scalars(gold, t)
+        assert seg == oseg
+        assert np.float32(d) == np.float32(od)
+        np.testing.assert_array_equal(np.array(list(basis), np.float32), np.concatenate([opoly, ofour]))
+    for T2 in (2, 7, 11, 250):
+        c = FrameClock(T2)
+        assert c.intervals[0] == 0.0 and c.intervals[-1] == 1.0 and np.all(np.diff(c.intervals) > 0)
+        for t in range(T2):
+            seg, d, _ = c.scalars(t)
+            assert 0 <= seg < c.interval_num and d >= 0.0
+
+
+def test_dynamic_eval_fails_loudly_without_gpu():
+    import torch
+    from splatter_a_video_amd.dynamics import FrameClock, evaluate
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises((ValueError, RuntimeError)):
+        evaluate(FrameClock(10), 3, opacity=torch.zeros(4, 1))

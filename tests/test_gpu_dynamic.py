@@ -1,0 +1,164 @@
+"""Row a15 on the GPU: the HIP dynamic-evaluation path (C ABI through splatter_a_video_amd.dynamics) against
+(1) vectors produced by the reference's own methods, (2) the C oracle at a larger random size,
+(3) the accumulate-into-bucket mode, (4) the reference-named getters."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from splatter_a_video_amd.dynamics import DynamicGaussians, FrameClock, evaluate
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden", "dynamic_400x50.npz")
+NAMES = ("position", "pos_cubic_node", "rotation", "rot_poly_feat", "rot_fourier_feat", "opacity", "scaling")
+
+
+def _dev(a, grad=False):
+    return torch.tensor(np.asarray(a, np.float32), device="cuda", requires_grad=grad)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(G))
+
+
+@pytest.mark.parametrize("t", [0, 1, 5, 24, 25, 44, 45, 49])
+def test_hip_matches_reference_vectors(gold, t):
+    g = gold
+    clock = FrameClock(int(g["T"]), g["intervals"], int(g["start_frame_id"]), int(g["time_len"]))
+    p = {k: _dev(g[k], grad=True) for k in NAMES}
+    pos, rot, opa, scl = evaluate(clock, t, **p)
+    pre = f"t{t}_"
+    tol = dict(rtol=3e-6, atol=3e-6)       # float32 path; FMA contraction and sum order differ from eager torch
+    np.testing.assert_allclose(pos.detach().cpu().numpy(), g[pre + "pos"], **tol)
+    np.testing.assert_allclose(rot.detach().cpu().numpy(), g[pre + "rot"], **tol)
+    np.testing.assert_allclose(opa.detach().cpu().numpy(), g[pre + "opa"], rtol=3e-6, atol=1e-7)
+    np.testing.assert_allclose(scl.detach().cpu().numpy(), g[pre + "scl"], rtol=3e-6, atol=1e-9)
+    loss = (pos * _dev(g[pre + "g_pos"])).sum() + (rot * _dev(g[pre + "g_rot"])).sum() \
+        + (opa * _dev(g[pre + "g_opa"])).sum() + (scl * _dev(g[pre + "g_scl"])).sum()
+    loss.backward()
+    np.testing.assert_allclose(p["position"].grad.cpu().numpy(), g[pre + "d_position"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(p["pos_cubic_node"].grad.cpu().numpy(), g[pre + "d_cubic"], rtol=3e-6, atol=1e-7)
+    np.testing.assert_allclose(p["rotation"].grad.cpu().numpy(), g[pre + "d_rotation"], rtol=3e-5, atol=3e-6)
+    np.testing.assert_allclose(p["opacity"].grad.cpu().numpy(), g[pre + "d_opacity"], rtol=3e-5, atol=1e-7)
+    np.testing.assert_allclose(p["scaling"].grad.cpu().numpy(), g[pre + "d_scaling"], rtol=3e-6, atol=1e-9)
+    assert p["rot_poly_feat"].grad is None and p["rot_fourier_feat"].grad is None     # detached in the reference
+
+
+def _random_params(N, I, seed):
+    rng = np.random.default_rng(seed)
+    f = lambda *s, scale=1.0: rng.normal(0, scale, size=s).astype(np.float32)
+    return dict(position=f(N, 3), pos_cubic_node=f(N, 4 * I * 3, scale=0.1), rotation=f(N, 4),
+                rot_poly_feat=f(N, 4, 4, scale=0.05), rot_fourier_feat=f(N, 8, 4, scale=0.05),
+                opacity=f(N, 1, scale=1.5), scaling=f(N, 3, scale=0.5) - 4.0), rng
+
+
+@pytest.mark.parametrize("N,T", [(1, 6), (3, 11), (257, 23), (100_003, 250)])
+def test_hip_matches_oracle(N, T):
+    clock = FrameClock(T)
+    I = clock.interval_num
+    host, rng = _random_params(N, I, seed=N)
+    for t in sorted({0, 1, T // 2, T - 1}):
+        seg, d, basis = clock.scalars(t)
+        b = np.array(list(basis), np.float32)
+        o_pos, o_rot, o_opa, o_scl = oracle.dynamic_eval_forward(
+            host["position"], host["pos_cubic_node"], host["rotation"], host["rot_poly_feat"], host["rot_fourier_feat"],
+            host["opacity"], host["scaling"], seg, d, b[:4], b[4:])
+        p = {k: _dev(v, grad=True) for k, v in host.items()}
+        pos, rot, opa, scl = evaluate(clock, t, **p)
+        np.testing.assert_allclose(pos.detach().cpu().numpy(), o_pos, rtol=3e-6, atol=3e-6)
+        np.testing.assert_allclose(rot.detach().cpu().numpy(), o_rot, rtol=3e-6, atol=3e-6)
+        np.testing.assert_allclose(opa.detach().cpu().numpy(), o_opa, rtol=3e-6, atol=1e-7)
+        np.testing.assert_allclose(scl.detach().cpu().numpy(), o_scl, rtol=3e-6, atol=1e-9)
+        g = dict(pos=rng.normal(size=(N, 3)), rot=rng.normal(size=(N, 4)), opa=rng.normal(size=(N, 1)),
+                 scl=rng.normal(size=(N, 3)))
+        g = {k: v.astype(np.float32) for k, v in g.items()}
+        torch.autograd.backward([pos, rot, opa, scl], [_dev(g["pos"]), _dev(g["rot"]), _dev(g["opa"]), _dev(g["scl"])])
+        o = oracle.dynamic_eval_backward((N, 4, I, 3), host["rotation"], host["rot_poly_feat"], host["rot_fourier_feat"],
+                                         host["opacity"], host["scaling"], seg, d, b[:4], b[4:], g["pos"], g["rot"],
+                                         g["opa"], g["scl"])
+        np.testing.assert_allclose(p["position"].grad.cpu().numpy(), o[0], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(p["pos_cubic_node"].grad.cpu().numpy().reshape(N, 4, I, 3), o[1], rtol=3e-6, atol=1e-7)
+        np.testing.assert_allclose(p["rotation"].grad.cpu().numpy(), o[2], rtol=5e-5, atol=5e-6)
+        np.testing.assert_allclose(p["opacity"].grad.cpu().numpy(), o[3], rtol=3e-5, atol=1e-7)
+        np.testing.assert_allclose(p["scaling"].grad.cpu().numpy(), o[4], rtol=3e-6, atol=1e-9)
+
+
+def test_grad_sink_accumulates_over_frames():
+    """backward adds straight into caller-owned gradient buffers; three frames == the sum of three dense autograd runs"""
+    N, T = 5000, 40
+    clock = FrameClock(T)
+    host, rng = _random_params(N, clock.interval_num, seed=11)
+    frames = [3, 17, 18]
+    gs = [{k: _dev(rng.normal(size=s)) for k, s in (("pos", (N, 3)), ("rot", (N, 4)), ("opa", (N, 1)), ("scl", (N, 3)))}
+          for _ in frames]
+    # dense autograd
+    p = {k: _dev(v, grad=True) for k, v in host.items()}
+    for t, g in zip(frames, gs):
+        out = evaluate(clock, t, **p)
+        torch.autograd.backward(list(out), [g["pos"], g["rot"], g["opa"], g["scl"]])
+    # sink mode
+    q = {k: _dev(v, grad=True) for k, v in host.items()}
+    sink = {k: torch.zeros_like(q[k]) for k in ("position", "pos_cubic_node", "rotation", "opacity", "scaling")}
+    for t, g in zip(frames, gs):
+        out = evaluate(clock, t, grad_sink=sink, **q)
+        torch.autograd.backward(list(out), [g["pos"], g["rot"], g["opa"], g["scl"]])
+    for k in sink:
+        assert q[k].grad is None
+        np.testing.assert_allclose(sink[k].cpu().numpy(), p[k].grad.cpu().numpy(), rtol=2e-6, atol=1e-6)
+
+
+def test_reference_named_getters_and_frozen_position():
+    N, T = 777, 30
+    clock = FrameClock(T)
+    host, _ = _random_params(N, clock.interval_num, seed=5)
+    m = DynamicGaussians(clock, **{k: _dev(v) for k, v in host.items()})
+    pos, rot, opa, scl = m.frame(12)
+    assert torch.equal(m.get_position(12), pos) and torch.equal(m.get_rotation(12), rot)
+    assert torch.equal(m.get_opacity, opa) and torch.equal(m.get_scaling, scl)
+    assert torch.allclose(rot.norm(dim=1), torch.ones(N, device="cuda"), atol=1e-6)
+    (pos.sum() + rot[:, 0].sum() + opa.sum() + scl.sum()).backward()
+    assert m.position.grad is None                       # position is not optimised in the reference (:90)
+    assert m.pos_cubic_node.grad is not None and m.rotation.grad is not None
+    seg = clock.scalars(12)[0]
+    dense = m.pos_cubic_node.grad.reshape(N, 4, clock.interval_num, 3)
+    other = [i for i in range(clock.interval_num) if i != seg]
+    assert not dense[:, :, other].any() and dense[:, :, seg].abs().sum() > 0
+
+
+def test_degenerate_quaternion_and_empty():
+    clock = FrameClock(10)
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    rot = evaluate(clock, 4, rotation=z(8, 4), rot_poly_feat=z(8, 4, 4), rot_fourier_feat=z(8, 8, 4))[1]
+    assert torch.equal(rot, z(8, 4))                      # F.normalize of a zero vector is zero
+    out = evaluate(clock, 4, opacity=z(0, 1), scaling=z(0, 3))
+    assert out[2].shape == (0, 1) and out[3].shape == (0, 3)
+
+
+def test_segment_major_layout_is_a_pure_permutation():
+    """native [I,N,4,3] spline table: same values, same gradients (permuted), checkpoint export round-trips"""
+    from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, to_gaussian_major, to_segment_major
+    N, T = 4099, 60
+    clock = FrameClock(T)
+    I = clock.interval_num
+    host, rng = _random_params(N, I, seed=3)
+    g_pos = _dev(rng.normal(size=(N, 3)))
+    for t in (0, 7, 30, 59):
+        a = {k: _dev(v, grad=True) for k, v in host.items()}
+        pos_a = evaluate(clock, t, position=a["position"], pos_cubic_node=a["pos_cubic_node"])[0]
+        pos_a.backward(g_pos)
+        seg_tab = to_segment_major(_dev(host["pos_cubic_node"]), I).requires_grad_()
+        assert seg_tab.shape == (I, N, 4, 3)
+        pos_b = evaluate(clock, t, position=_dev(host["position"]), pos_cubic_node=seg_tab, cubic_layout=SEGMENT_MAJOR)[0]
+        pos_b.backward(g_pos)
+        assert torch.equal(pos_a, pos_b)
+        assert torch.equal(to_gaussian_major(seg_tab.grad), a["pos_cubic_node"].grad)
+    assert torch.equal(to_gaussian_major(to_segment_major(_dev(host["pos_cubic_node"]), I)), _dev(host["pos_cubic_node"]))
+    m = DynamicGaussians(clock, **{k: _dev(v) for k, v in host.items()}, cubic_layout=SEGMENT_MAJOR)
+    assert m.pos_cubic_node.shape == (I, N, 4, 3)
+    assert torch.equal(m.reference_pos_cubic_node(), _dev(host["pos_cubic_node"]))
+    ref = DynamicGaussians(clock, **{k: _dev(v) for k, v in host.items()})
+    for x, y in zip(m.frame(33), ref.frame(33)):
+        assert torch.equal(x, y)

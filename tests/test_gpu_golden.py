@@ -10,7 +10,7 @@ import torch
 from test_gpu_parity import dev
 
 pytestmark = pytest.mark.gpu
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ortho_*.npz")))
 
 
 def rel(a, b):

@@ -14,7 +14,7 @@ import torch
 import torch_twin as tw
 from splatter_a_video_amd.synth import make_scene
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ortho_*.npz")))
 
 
 def rel(a, b):
