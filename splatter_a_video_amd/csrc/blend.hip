@@ -42,6 +42,12 @@
 #ifndef BLEND_BWD_MINW
 #define BLEND_BWD_MINW 1
 #endif
+#ifndef BLEND_MFMA_SB
+#define BLEND_MFMA_SB 128  // super-batch of the MFMA backward (narrow channel counts)
+#endif
+#ifndef BLEND_MFMA_MINW
+#define BLEND_MFMA_MINW 1
+#endif
 
 struct BlendArgs {
     int P, C;          // C = row stride of feature / dL_dfeature
@@ -162,7 +168,7 @@ template <int CH, int SB>
 struct TileLDS {
     static constexpr int RQ = Rec<CH>::RQ;
     float4 rec[(SB + 1) * RQ];
-    unsigned short list[4][SB + 8];
+    unsigned short list[4][SB + 16];
     __device__ __forceinline__ const float4 &g0(int e) const { return rec[e * RQ]; }      // u v A B
     __device__ __forceinline__ const float4 &g1(int e) const { return rec[e * RQ + 1]; }  // C o bias id
 };
@@ -223,7 +229,7 @@ struct Stager {
 // pred(e) drops entries before the box test.
 template <int CH, int SB, bool BIAS, typename Pred>
 __device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane, int nb, float bx0, float bx1,
-                                          float by0, float by1, Pred pred) {
+                                          float by0, float by1, Pred pred, unsigned long long *masks = nullptr) {
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < SB / WAVE; ++r) {
@@ -236,8 +242,9 @@ __device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane, i
         const unsigned long long m = __ballot(keep);
         if (keep) L.list[w][cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
         cnt += __popcll(m);
+        if (masks && lane == 0) masks[r] = m;  // which entries of the super-batch this wave will write
     }
-    if (lane < 8) L.list[w][cnt + lane] = (unsigned short)SB;  // pad: the unrolled loops read slot SB (inert record)
+    if (lane < 16) L.list[w][cnt + lane] = (unsigned short)SB;  // pad: the unrolled loops read slot SB (inert record)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return cnt;
@@ -659,6 +666,288 @@ pair_reduce_kernel(const BlendArgs A) {
     }
 }
 
+// ------------------------------------------------------------------ backward, pair mode, MFMA reductions
+// The per-splat sums over pixels are matrix products with K = pixels:
+//     [moments | dL_dout]^T (M x pixels)  *  [per-(pixel,splat) scalar] (pixels x splats)
+// so they run on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32, K = 4 pixels per instruction) instead of
+// 9..40 DPP wave reductions per (wave, splat).  Lane roles inside a wave: n = lane & 15 is one of 16 survivors
+// (a "chunk", back to front), kk = lane >> 4 one of the 4 pixels of the current step; 16 steps cover the wave's
+// 8x8 pixel block.  With lanes = splats the per-pixel recurrences of the reference's backward loop
+// (src/alpha_blending.cu:152-249) become prefix scans over the 16-lane DPP row:
+//     T_n   = T_state * prod_{q<=n} 1/(1-a_q)                (transmittance in front of splat n)
+//     R_n   = R_state + sum_{q<n} a_q T_q (f_q . g)           (colour behind splat n, already dotted with dL_dout)
+//     dL/da = T_n (f_n . g) - (R_n + T_final bg.g) / (1-a_n)
+// and the geometry gradients follow from six pixel moments of dL/dpower (1, x, y, xx, xy, yy in block-local
+// pixel coordinates): power is a quadratic in (u - x, v - y), so d/du, d/dv, d/dconic are linear in them.
+// The records written to the slabs / pair_buf are the same as blend_bwd_pair_kernel's (pair_reduce is shared).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CH, bool ABS>
+struct MfmaCfg {
+    static constexpr int NG = GradLayout<ABS, false>::NG;
+    static constexpr int NC = NG + CH;
+    static constexpr int NCP = (NC + 15) & ~15;
+    static constexpr int SB = CH <= 8 ? BLEND_MFMA_SB : 64;
+    static constexpr int PW = (CH + 4 + 3) & ~3;  // floats per pixel record: g[CH], T_final*bg.g, ncontrib, T_final, 0
+    static constexpr int NA = (CH + 15) / 16;     // feature accumulators (16 channels each)
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_keep(float old, float v) {  // lanes without a source keep `old`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// inclusive prefix product / sum over the 16-lane row (lane 0 first)
+__device__ __forceinline__ float row_scan_mul(float v) {
+    v *= dpp_keep<0x111>(1.f, v);
+    v *= dpp_keep<0x112>(1.f, v);
+    v *= dpp_keep<0x114>(1.f, v);
+    v *= dpp_keep<0x118>(1.f, v);
+    return v;
+}
+__device__ __forceinline__ float row_scan_add(float v) {
+    v += dpp_keep<0x111>(0.f, v);
+    v += dpp_keep<0x112>(0.f, v);
+    v += dpp_keep<0x114>(0.f, v);
+    v += dpp_keep<0x118>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float row_shr1(float v) { return dpp_keep<0x111>(0.f, v); }  // exclusive from inclusive
+__device__ __forceinline__ float row_last(float v) {                                     // lane 15 of the row -> whole row
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x15F, 0xf, 0xf, true));
+}
+
+// four interleaved inclusive row scans (lane 0 first): dependent DPP instructions are 4 issue slots apart; lanes
+// without a source (bound_ctrl off) keep their own value, which is what an inclusive scan needs
+#define SCAN4(op, sh)                                                        \
+    op " %0, %0, %0 row_shr:" sh " row_mask:0xf bank_mask:0xf\n\t"        \
+    op " %1, %1, %1 row_shr:" sh " row_mask:0xf bank_mask:0xf\n\t"        \
+    op " %2, %2, %2 row_shr:" sh " row_mask:0xf bank_mask:0xf\n\t"        \
+    op " %3, %3, %3 row_shr:" sh " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void row_scan_mul4(float &a, float &b, float &c, float &d) {
+    asm volatile("s_nop 1\n\t" SCAN4("v_mul_f32_dpp", "1") SCAN4("v_mul_f32_dpp", "2") SCAN4("v_mul_f32_dpp", "4")
+                     SCAN4("v_mul_f32_dpp", "8")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void row_scan_add4(float &a, float &b, float &c, float &d) {
+    asm volatile("s_nop 1\n\t" SCAN4("v_add_f32_dpp", "1") SCAN4("v_add_f32_dpp", "2") SCAN4("v_add_f32_dpp", "4")
+                     SCAN4("v_add_f32_dpp", "8")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+template <int CH, bool ABS, bool EXACT>
+__global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_MFMA_MINW : 1))
+blend_bwd_mfma_kernel(const BlendArgs A) {
+    using Cfg = MfmaCfg<CH, ABS>;
+    constexpr int SB = Cfg::SB, NG = Cfg::NG, NC = Cfg::NC, NCP = Cfg::NCP, PW = Cfg::PW, NA = Cfg::NA;
+    constexpr int I_ABS = GradLayout<ABS, false>::I_ABS;
+    __shared__ TileLDS<CH, SB> L;
+    __shared__ float s_acc[4][SB * NC];                // private slab per wave
+    __shared__ unsigned long long s_mask[4][SB / 64];  // entries of the super-batch each wave wrote
+    __shared__ __attribute__((aligned(16))) float s_pix[4][64 * PW];
+    __shared__ float s_mom[16 * 64];  // MFMA "A" operand of the moment product: [step][lane]
+    __shared__ int s_wmax[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x;
+    const int tx = tile % A.gx, ty = tile / A.gx;
+    const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
+    const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+    const int cn = EXACT ? CH : A.cn;
+    int wmax;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // rows 0-3: 1 x y xx | rows 4-7: 1 x y xy | rows 8-11: 1 y yy 0 | rows 12-15: 0  (x, y block-local pixel coordinates)
+        const int s_ = 4 * w + r, m = lane & 15, k_ = lane >> 4;
+        const float x = (float)(4 * (s_ & 1) + k_), y = (float)(s_ >> 1);
+        const int grp = m >> 2, i = m & 3;
+        float v = 0.f;
+        if (grp == 0) v = i == 0 ? 1.f : i == 1 ? x : i == 2 ? y : x * x;
+        if (grp == 1) v = i == 0 ? 1.f : i == 1 ? x : i == 2 ? y : x * y;
+        if (grp == 2) v = i == 0 ? 1.f : i == 1 ? y : i == 2 ? y * y : 0.f;
+        s_mom[64 * s_ + lane] = v;
+    }
+    {   // stage the per-pixel constants: lane q <-> pixel (q & 7, q >> 3) of the wave's block
+        const int px = bx + (lane & 7), py = by + (lane >> 3);
+        const size_t HW = (size_t)A.H * A.W;
+        const bool inside = (px < A.W) && (py < A.H);
+        const size_t pix = (size_t)A.W * (size_t)py + px;
+        const float Tf = inside ? A.final_T[pix] : 0.f;
+        const int last = inside ? A.ncontrib[pix] : 0;
+        float *r = s_pix[w] + lane * PW;
+        float bgdot = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const float g = (inside && k < cn) ? A.dL_dout[(size_t)(A.c0 + k) * HW + pix] : 0.f;
+            r[k] = g;
+            bgdot += A.bg * g;
+        }
+        r[CH] = Tf * bgdot;
+        r[CH + 1] = __int_as_float(last);
+        r[CH + 2] = Tf;
+        r[CH + 3] = 0.f;          // what lanes without a channel feed to the feature MFMA
+        wmax = wave_max_i(last);  // this wave never needs entries q >= wmax
+        if (lane == 0) s_wmax[w] = wmax;
+    }
+    if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
+    __syncthreads();
+    const int2 range = A.tile_range[tile];
+    const int len = range.y - range.x;
+    const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
+    const int *slots = A.slot_sorted + range.x;
+    for (int i = n * NCP + tid; i < len * NCP; i += 256) {  // entries nobody replays: zero record
+        const int ql = i / NCP;
+        A.pair_buf[(size_t)slots[ql] * NCP + (i - ql * NCP)] = 0.f;
+    }
+    if (n <= 0) return;
+
+    // ---- lane roles: row m = n = lane & 15, pixel kk = lane >> 4 of step s (pixel q = 4 s + kk of the block)
+    const int nl = lane & 15, kk = lane >> 4;
+    const float *pixrow = s_pix[w] + kk * PW;  // pixel (s, kk) sits at pixrow + 4 * s * PW
+    const float *momrow = s_mom + lane;        // moment operand of step s at momrow[64 * s]
+    float Tst[16], Rst[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        Tst[s] = pixrow[4 * s * PW + CH + 2];
+        Rst[s] = 0.f;
+    }
+    const float a_one = nl == 0 ? 1.f : 0.f;
+    int gch[NA];  // slot of the pixel record this lane feeds to the feature MFMA q: dL_dout of channel 16 q + n, or the zero slot
+#pragma unroll
+    for (int q = 0; q < NA; ++q) gch[q] = 16 * q + nl < CH ? 16 * q + nl : CH + 3;
+
+    // reverse walk: entry e of super-batch b sits at list position n-1 - b*SB - e
+    auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };  // negative = past the front
+    Stager<CH, SB> st;
+    st.load_ids(A, tid, range.x, pos, 0);
+    st.load_payload(A, tid);
+    st.load_ids(A, tid, range.x, pos, 1);
+
+    int batch = 0;
+    for (int top = n - 1; top >= 0; top -= SB, ++batch) {
+        const int nb = imin_(SB, top + 1);
+        st.park(L, tid);
+        st.load_payload(A, tid);                       // payload of the next super-batch
+        st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
+        __syncthreads();
+
+        const int cnt = build_list<CH, SB, false>(L, w, lane, nb, bx0, bx1, by0, by1,
+                                                  [=](int e) { return top - e < wmax; }, s_mask[w]);
+        float *slab = s_acc[w];
+        for (int j0 = 0; j0 < cnt; j0 += 16) {
+            const int e = L.list[w][j0 + nl];  // ascending e = back to front; slot SB (inert) past the end
+            const float4 g0 = L.g0(e), g1 = L.g1(e);
+            float f[CH];
+            read_feat<CH, SB>(L, e, f);
+            const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
+            const float ul = g0.x - bx0, vl = g0.y - by0;  // centre in block-local pixel coordinates
+            const float ur = ul - (float)kk;
+            const int qn = top - e;  // list position of this survivor (negative for the inert slot: harmless, alpha = 0)
+            f32x4 d_mom = {0.f, 0.f, 0.f, 0.f}, d_ax = {0.f, 0.f, 0.f, 0.f}, d_ay = {0.f, 0.f, 0.f, 0.f};
+            f32x4 d_f[NA];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" ::: "memory");  // keep the per-pixel LDS reads inside the chunk (registers, not hoisted copies)
+#pragma unroll
+            for (int s0 = 0; s0 < 16; s0 += 4) {  // four independent steps per group: the DPP scans interleave
+                float cg[4], araw[4], a[4], r1a[4], rp[4], dxs[4], dys[4], Tb[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = s0 + u;
+                    const float *pr = pixrow + 4 * s * PW;
+                    cg[u] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) cg[u] += f[k] * pr[k];
+                    Tb[u] = pr[CH];
+                    const int last = __float_as_int(pr[CH + 1]);
+                    const float dx = ur - (float)(4 * (s & 1)), dy = vl - (float)(s >> 1);
+                    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+                    const float G = __expf(power);
+                    araw[u] = o * G;
+                    const float alpha = fminf(0.99f, araw[u]);
+                    ok[u] = (qn < last) && !(power > 0.f) && !(alpha < (1.0f / 255.0f));
+                    a[u] = ok[u] ? alpha : 0.f;
+                    r1a[u] = __builtin_amdgcn_rcpf(1.f - a[u]);
+                    rp[u] = r1a[u];
+                    dxs[u] = dx; dys[u] = dy;
+                }
+                row_scan_mul4(rp[0], rp[1], rp[2], rp[3]);
+                float T[4], wgt[4], rs[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    T[u] = Tst[s0 + u] * rp[u];  // transmittance in front of this splat
+                    wgt[u] = a[u] * T[u];
+                    rs[u] = cg[u] * wgt[u];
+                }
+                row_scan_add4(rs[0], rs[1], rs[2], rs[3]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = s0 + u;
+                    const float R = Rst[s] + row_shr1(rs[u]);  // colour behind this splat (dotted with dL_dout)
+                    const float dLa = T[u] * cg[u] - (R + Tb[u]) * r1a[u];
+                    const float dLp = ok[u] ? araw[u] * dLa : 0.f;  // dL/dpower
+                    d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[64 * s], dLp, d_mom, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NA; ++q)
+                        d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(pixrow[4 * s * PW + gch[q]], wgt[u], d_f[q], 0, 0, 0);
+                    if (ABS) {
+                        d_ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cA * dxs[u] + cB * dys[u])), d_ax, 0, 0, 0);
+                        d_ay = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cB * dxs[u] + cC * dys[u])), d_ay, 0, 0, 0);
+                    }
+                    Tst[s] = row_last(T[u]);
+                    Rst[s] = Rst[s] + row_last(rs[u]);
+                }
+            }
+            // ---- chunk epilogue: lane (n, kk) holds rows 4kk..4kk+3 of every accumulator for survivor n
+            if (j0 + nl < cnt) {
+                float *rec = slab + e * NC;
+                const float D0 = d_mom[0];
+                if (kk == 0) {
+                    const float Dx = d_mom[1], Dy = d_mom[2], Dxx = d_mom[3];
+                    rec[0] = cA * Dx + cB * Dy - (cA * ul + cB * vl) * D0;
+                    rec[1] = cB * Dx + cC * Dy - (cB * ul + cC * vl) * D0;
+                    rec[2] = -0.5f * (ul * ul * D0 - 2.f * ul * Dx + Dxx);
+                    rec[5] = o > 0.f ? D0 / o : 0.f;
+                    if (ABS) {
+                        rec[I_ABS] = d_ax[0];
+                        rec[I_ABS + 1] = d_ay[0];
+                    }
+                } else if (kk == 1) {
+                    const float Dx = d_mom[1], Dy = d_mom[2], Dxy = d_mom[3];
+                    rec[3] = -(ul * vl * D0 - ul * Dy - vl * Dx + Dxy);
+                } else if (kk == 2) {
+                    const float Dy = d_mom[1], Dyy = d_mom[2];
+                    rec[4] = -0.5f * (vl * vl * D0 - 2.f * vl * Dy + Dyy);
+                }
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = 16 * q + 4 * kk + i;
+                        if (c < CH) rec[NG + c] = d_f[q][i];
+                    }
+            }
+        }
+        __syncthreads();
+        // ---- combine the four slabs; each record (NCP floats = whole 64-B sectors) goes to its pair slot
+        {
+            const int lo = top - nb + 1;
+            for (int i = tid; i < nb * NCP; i += 256) {
+                const int ql = i / NCP, c = i - ql * NCP;
+                const int e = nb - 1 - ql;
+                float v = 0.f;
+                if (c < NC) {
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww)
+                        if ((s_mask[ww][e >> 6] >> (e & 63)) & 1ull) v += s_acc[ww][e * NC + c];
+                }
+                A.pair_buf[(size_t)slots[lo + ql] * NCP + c] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ backward, atomic mode (foreign idx_sorted)
 // Same tile structure; every wave reduces its partials and lane 63 issues one hardware float atomic
 // per (wave, splat, component).  Gradient outputs must be zero-initialised.
@@ -788,11 +1077,23 @@ static int launch_fwd(const BlendArgs &A, int T, bool enh, bool bias, hipStream_
     return SPLAT_OK;
 }
 
+// SPLAT_BWD_KERNEL=dpp selects the DPP-reduction pair kernel (A/B measurements); default: MFMA reductions
+static bool bwd_use_mfma() {
+    static const int v = [] {
+        const char *e = getenv("SPLAT_BWD_KERNEL");
+        return (e && strcmp(e, "dpp") == 0) ? 0 : 1;
+    }();
+    return v != 0;
+}
+
 template <int CH, bool ABS, bool BIAS>
 static int launch_bwd_ab(const BlendArgs &A, int T, bool pair, hipStream_t s) {
     const dim3 grid((unsigned)T), block(256);
     const bool exact = A.cn == CH;
-    if (pair) {
+    if (pair && !BIAS && bwd_use_mfma()) {
+        if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_mfma_kernel<CH, ABS, true>), grid, block, 0, s, A);
+        else SPLAT_LAUNCH("blend_bwd", (blend_bwd_mfma_kernel<CH, ABS, false>), grid, block, 0, s, A);
+    } else if (pair) {
         if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_pair_kernel<CH, ABS, BIAS, true>), grid, block, 0, s, A);
         else SPLAT_LAUNCH("blend_bwd", (blend_bwd_pair_kernel<CH, ABS, BIAS, false>), grid, block, 0, s, A);
     } else {
