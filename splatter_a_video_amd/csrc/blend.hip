@@ -229,7 +229,7 @@ struct Stager {
 // pred(e) drops entries before the box test.
 template <int CH, int SB, bool BIAS, typename Pred>
 __device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane, int nb, float bx0, float bx1,
-                                          float by0, float by1, Pred pred, unsigned long long *masks = nullptr) {
+                                          float by0, float by1, Pred pred, unsigned char *flags = nullptr) {
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < SB / WAVE; ++r) {
@@ -242,7 +242,7 @@ __device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane, i
         const unsigned long long m = __ballot(keep);
         if (keep) L.list[w][cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
         cnt += __popcll(m);
-        if (masks && lane == 0) masks[r] = m;  // which entries of the super-batch this wave will write
+        if (flags) flags[4 * e] = keep ? 1 : 0;  // which entries of the super-batch this wave will write (byte per wave)
     }
     if (lane < 16) L.list[w][cnt + lane] = (unsigned short)SB;  // pad: the unrolled loops read slot SB (inert record)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -666,19 +666,23 @@ pair_reduce_kernel(const BlendArgs A) {
     }
 }
 
-// ------------------------------------------------------------------ backward, pair mode, MFMA reductions
-// The per-splat sums over pixels are matrix products with K = pixels:
-//     [moments | dL_dout]^T (M x pixels)  *  [per-(pixel,splat) scalar] (pixels x splats)
-// so they run on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32, K = 4 pixels per instruction) instead of
-// 9..40 DPP wave reductions per (wave, splat).  Lane roles inside a wave: n = lane & 15 is one of 16 survivors
-// (a "chunk", back to front), kk = lane >> 4 one of the 4 pixels of the current step; 16 steps cover the wave's
-// 8x8 pixel block.  With lanes = splats the per-pixel recurrences of the reference's backward loop
+// ------------------------------------------------------------------ backward, pair mode, matrix-core version
+// Everything that is a product over (pixels x splats) runs on the matrix cores (v_mfma_f32_16x16x4_f32: exact
+// f32 FMA chains, 16x16 outputs, K = 4 per instruction):
+//   power[p,n]  = phi(p) . q(n)          K = 6 monomials (1 x y xx xy yy) of the block-centred pixel coordinates
+//   cg[p,n]     = dL_dout[p,:] . f[n,:]  K = channels
+//   moments[n]  = sum_p phi(p) dL/dpower[p,n]      K = pixels  -> d uv, d conic, d opacity (power is quadratic in
+//   dfeat[n,c]  = sum_p dL_dout[p,c] w[p,n]        K = pixels     (u - x, v - y), so its gradients are linear in
+//                                                                 the six moments)
+// instead of 9..40 DPP wave reductions per (wave, splat).  Lane roles inside a wave: n = lane & 15 is one of 16
+// survivors (a "chunk", deepest first), kk = lane >> 4.  The wave's 8x8 pixel block is walked as four 2x8
+// strips G; in strip G lane (n, kk) owns pixels m = 4 kk + i (i = 0..3, row-major in the strip), which is exactly
+// the C/D layout of the 16x16 MFMA (row 4 kk + i, column n) -- the power and cg products land in the lane that
+// consumes them.  With lanes = splats the per-pixel recurrences of the reference's backward loop
 // (src/alpha_blending.cu:152-249) become prefix scans over the 16-lane DPP row:
 //     T_n   = T_state * prod_{q<=n} 1/(1-a_q)                (transmittance in front of splat n)
-//     R_n   = R_state + sum_{q<n} a_q T_q (f_q . g)           (colour behind splat n, already dotted with dL_dout)
-//     dL/da = T_n (f_n . g) - (R_n + T_final bg.g) / (1-a_n)
-// and the geometry gradients follow from six pixel moments of dL/dpower (1, x, y, xx, xy, yy in block-local
-// pixel coordinates): power is a quadratic in (u - x, v - y), so d/du, d/dv, d/dconic are linear in them.
+//     R_n   = R_state + sum_{q<n} a_q T_q cg_q                (colour behind splat n, already dotted with dL_dout)
+//     dL/da = T_n cg_n - (R_n + T_final bg.g) / (1-a_n)
 // The records written to the slabs / pair_buf are the same as blend_bwd_pair_kernel's (pair_reduce is shared).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -689,37 +693,13 @@ struct MfmaCfg {
     static constexpr int NCP = (NC + 15) & ~15;
     static constexpr int SB = CH <= 8 ? BLEND_MFMA_SB : 64;
     static constexpr int PW = (CH + 4 + 3) & ~3;  // floats per pixel record: g[CH], T_final*bg.g, ncontrib, T_final, 0
-    static constexpr int NA = (CH + 15) / 16;     // feature accumulators (16 channels each)
+    static constexpr int NA = (CH + 15) / 16;     // feature-gradient accumulators (16 channels each)
+    static constexpr int NK = (CH + 3) / 4;       // K-slabs of the cg product (4 channels each)
 };
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_keep(float old, float v) {  // lanes without a source keep `old`
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
-                                                                 __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-// inclusive prefix product / sum over the 16-lane row (lane 0 first)
-__device__ __forceinline__ float row_scan_mul(float v) {
-    v *= dpp_keep<0x111>(1.f, v);
-    v *= dpp_keep<0x112>(1.f, v);
-    v *= dpp_keep<0x114>(1.f, v);
-    v *= dpp_keep<0x118>(1.f, v);
-    return v;
-}
-__device__ __forceinline__ float row_scan_add(float v) {
-    v += dpp_keep<0x111>(0.f, v);
-    v += dpp_keep<0x112>(0.f, v);
-    v += dpp_keep<0x114>(0.f, v);
-    v += dpp_keep<0x118>(0.f, v);
-    return v;
-}
-__device__ __forceinline__ float row_shr1(float v) { return dpp_keep<0x111>(0.f, v); }  // exclusive from inclusive
-__device__ __forceinline__ float row_last(float v) {                                     // lane 15 of the row -> whole row
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x15F, 0xf, 0xf, true));
-}
 
 // four interleaved inclusive row scans (lane 0 first): dependent DPP instructions are 4 issue slots apart; lanes
 // without a source (bound_ctrl off) keep their own value, which is what an inclusive scan needs
-#define SCAN4(op, sh)                                                        \
+#define SCAN4(op, sh)                                                     \
     op " %0, %0, %0 row_shr:" sh " row_mask:0xf bank_mask:0xf\n\t"        \
     op " %1, %1, %1 row_shr:" sh " row_mask:0xf bank_mask:0xf\n\t"        \
     op " %2, %2, %2 row_shr:" sh " row_mask:0xf bank_mask:0xf\n\t"        \
@@ -734,18 +714,43 @@ __device__ __forceinline__ void row_scan_add4(float &a, float &b, float &c, floa
                      SCAN4("v_add_f32_dpp", "8")
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+// after the scans, for four steps at once:  R = R_state + (scan shifted by one lane),  R_state += row total,
+// T_state = T of the row's last lane
+__device__ __forceinline__ void row_state_update4(float (&R)[4], float (&Rst)[4], const float (&rs)[4], float (&Tst)[4],
+                                                  const float (&T)[4]) {
+    // operands: %0-3 R (out), %4-7 R_state (in/out), %8-11 T_state (out), %12-15 rs, %16-19 T
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %12, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %13, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %14, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %15, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %12, %4 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %13, %5 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %14, %6 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %15, %7 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %8, %16 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %9, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %10, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %11, %19 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]), "+v"(Rst[0]), "+v"(Rst[1]), "+v"(Rst[2]), "+v"(Rst[3]),
+          "=&v"(Tst[0]), "=&v"(Tst[1]), "=&v"(Tst[2]), "=&v"(Tst[3])
+        : "v"(rs[0]), "v"(rs[1]), "v"(rs[2]), "v"(rs[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]));
+}
 
 template <int CH, bool ABS, bool EXACT>
 __global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_MFMA_MINW : 1))
 blend_bwd_mfma_kernel(const BlendArgs A) {
     using Cfg = MfmaCfg<CH, ABS>;
-    constexpr int SB = Cfg::SB, NG = Cfg::NG, NC = Cfg::NC, NCP = Cfg::NCP, PW = Cfg::PW, NA = Cfg::NA;
+    constexpr int SB = Cfg::SB, NG = Cfg::NG, NC = Cfg::NC, NCP = Cfg::NCP, PW = Cfg::PW, NA = Cfg::NA, NK = Cfg::NK;
     constexpr int I_ABS = GradLayout<ABS, false>::I_ABS;
+    constexpr float L2E = 1.4426950408889634f;
     __shared__ TileLDS<CH, SB> L;
-    __shared__ float s_acc[4][SB * NC];                // private slab per wave
-    __shared__ unsigned long long s_mask[4][SB / 64];  // entries of the super-batch each wave wrote
+    __shared__ float s_acc[4][SB * NC];      // private slab per wave
+    __shared__ unsigned int s_wr[SB];        // byte w of entry e: wave w wrote its slab record
     __shared__ __attribute__((aligned(16))) float s_pix[4][64 * PW];
-    __shared__ float s_mom[16 * 64];  // MFMA "A" operand of the moment product: [step][lane]
+    __shared__ float s_mom[16 * 64];         // A operand of the moment product: [step 4 G + i][lane]
+    __shared__ float s_phi[8 * 64];          // A operand of the power product:  [2 G + j][lane]
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
@@ -753,20 +758,33 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
     const int cn = EXACT ? CH : A.cn;
+    const int nl = lane & 15, kk = lane >> 4;
     int wmax;
+    // ---- operand tables (block-centred pixel coordinates x, y in [-3.5, 3.5]; pixel q = 8 row + column)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        // rows 0-3: 1 x y xx | rows 4-7: 1 x y xy | rows 8-11: 1 y yy 0 | rows 12-15: 0  (x, y block-local pixel coordinates)
-        const int s_ = 4 * w + r, m = lane & 15, k_ = lane >> 4;
-        const float x = (float)(4 * (s_ & 1) + k_), y = (float)(s_ >> 1);
-        const int grp = m >> 2, i = m & 3;
+        const int st = 4 * w + r, Gs = st >> 2, is = st & 3;  // step = (strip, sub-step)
+        const int q = 16 * Gs + 4 * kk + is;                 // the pixel lane-group kk handles in this step
+        const float x = (float)(q & 7) - 3.5f, y = (float)(q >> 3) - 3.5f;
+        // rows 0-3: 1 x y xx | rows 4-7: 1 x y xy | rows 8-11: 1 y yy 0 | rows 12-15: 0
+        const int grp = nl >> 2, i = nl & 3;
         float v = 0.f;
         if (grp == 0) v = i == 0 ? 1.f : i == 1 ? x : i == 2 ? y : x * x;
         if (grp == 1) v = i == 0 ? 1.f : i == 1 ? x : i == 2 ? y : x * y;
         if (grp == 2) v = i == 0 ? 1.f : i == 1 ? y : i == 2 ? y * y : 0.f;
-        s_mom[64 * s_ + lane] = v;
+        s_mom[64 * st + lane] = v;
     }
-    {   // stage the per-pixel constants: lane q <-> pixel (q & 7, q >> 3) of the wave's block
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int t = 2 * w + r, Gs = t >> 1, j = t & 1;  // A[m = pixel nl of strip Gs][k = kk]
+        const int q = 16 * Gs + nl;
+        const float x = (float)(q & 7) - 3.5f, y = (float)(q >> 3) - 3.5f;
+        float v;
+        if (j == 0) v = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
+        else v = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
+        s_phi[64 * t + lane] = v;
+    }
+    {   // per-pixel constants: lane q <-> pixel (q & 7, q >> 3) of the wave's block
         const int px = bx + (lane & 7), py = by + (lane >> 3);
         const size_t HW = (size_t)A.H * A.W;
         const bool inside = (px < A.W) && (py < A.H);
@@ -784,7 +802,8 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
         r[CH] = Tf * bgdot;
         r[CH + 1] = __int_as_float(last);
         r[CH + 2] = Tf;
-        r[CH + 3] = 0.f;          // what lanes without a channel feed to the feature MFMA
+#pragma unroll
+        for (int k = CH + 3; k < PW; ++k) r[k] = 0.f;  // slot CH+3: what lanes without a channel feed to the MFMAs
         wmax = wave_max_i(last);  // this wave never needs entries q >= wmax
         if (lane == 0) s_wmax[w] = wmax;
     }
@@ -800,20 +819,24 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
     }
     if (n <= 0) return;
 
-    // ---- lane roles: row m = n = lane & 15, pixel kk = lane >> 4 of step s (pixel q = 4 s + kk of the block)
-    const int nl = lane & 15, kk = lane >> 4;
-    const float *pixrow = s_pix[w] + kk * PW;  // pixel (s, kk) sits at pixrow + 4 * s * PW
-    const float *momrow = s_mom + lane;        // moment operand of step s at momrow[64 * s]
+    // ---- per-lane addressing: pixel (G, kk, i) is q = 16 G + 4 kk + i
+    const float *pixrow = s_pix[w] + 4 * kk * PW;  // own pixel of step (G, i): pixrow + (16 G + i) * PW
+    const float *pixcol = s_pix[w] + nl * PW;      // pixel nl of strip G (cg product, A operand): pixcol + 16 G * PW
+    const float *momrow = s_mom + lane;            // + 64 * (4 G + i)
+    const float *phirow = s_phi + lane;            // + 64 * (2 G + j)
+    int gch[NA], kch[NK];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) gch[q] = 16 * q + nl < CH ? 16 * q + nl : CH + 3;  // channel row of the feature product
+#pragma unroll
+    for (int j = 0; j < NK; ++j) kch[j] = 4 * j + kk < CH ? 4 * j + kk : CH + 3;    // K index of the cg product
     float Tst[16], Rst[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        Tst[s] = pixrow[4 * s * PW + CH + 2];
+        Tst[s] = pixrow[(16 * (s >> 2) + (s & 3)) * PW + CH + 2];
         Rst[s] = 0.f;
     }
     const float a_one = nl == 0 ? 1.f : 0.f;
-    int gch[NA];  // slot of the pixel record this lane feeds to the feature MFMA q: dL_dout of channel 16 q + n, or the zero slot
-#pragma unroll
-    for (int q = 0; q < NA; ++q) gch[q] = 16 * q + nl < CH ? 16 * q + nl : CH + 3;
+    const float xk = (float)(4 * (kk & 1)) - 3.5f, yk = (float)(kk >> 1) - 3.5f;  // own pixel: x = xk + i, y = yk + 2 G
 
     // reverse walk: entry e of super-batch b sits at list position n-1 - b*SB - e
     auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };  // negative = past the front
@@ -831,71 +854,84 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
         __syncthreads();
 
         const int cnt = build_list<CH, SB, false>(L, w, lane, nb, bx0, bx1, by0, by1,
-                                                  [=](int e) { return top - e < wmax; }, s_mask[w]);
+                                                  [=](int e) { return top - e < wmax; },
+                                                  reinterpret_cast<unsigned char *>(s_wr) + w);
         float *slab = s_acc[w];
         for (int j0 = 0; j0 < cnt; j0 += 16) {
             const int e = L.list[w][j0 + nl];  // ascending e = back to front; slot SB (inert) past the end
             const float4 g0 = L.g0(e), g1 = L.g1(e);
-            float f[CH];
-            read_feat<CH, SB>(L, e, f);
             const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
-            const float ul = g0.x - bx0, vl = g0.y - by0;  // centre in block-local pixel coordinates
-            const float ur = ul - (float)kk;
+            const float uc = g0.x - bx0 - 3.5f, vc = g0.y - by0 - 3.5f;  // centre in block-centred pixel coordinates
             const int qn = top - e;  // list position of this survivor (negative for the inert slot: harmless, alpha = 0)
+            // B operands: this lane's K-slice of the splat's power coefficients (x log2 e) and features
+            float bq1, bq2, bf[NK];
+            {
+                const float q0 = L2E * (-0.5f * (cA * uc * uc + cC * vc * vc) - cB * uc * vc);
+                const float qx = L2E * (cA * uc + cB * vc), qy = L2E * (cB * uc + cC * vc);
+                const float qxx = -0.5f * L2E * cA, qxy = -L2E * cB, qyy = -0.5f * L2E * cC;
+                bq1 = kk == 0 ? q0 : kk == 1 ? qx : kk == 2 ? qy : qxx;
+                bq2 = kk == 0 ? qxy : kk == 1 ? qyy : 0.f;
+                const float *fr = reinterpret_cast<const float *>(&L.rec[e * Rec<CH>::RQ + 2]);
+#pragma unroll
+                for (int j = 0; j < NK; ++j) bf[j] = fr[4 * j + kk];  // padded with zeros past CH (pack_kernel)
+            }
             f32x4 d_mom = {0.f, 0.f, 0.f, 0.f}, d_ax = {0.f, 0.f, 0.f, 0.f}, d_ay = {0.f, 0.f, 0.f, 0.f};
             f32x4 d_f[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
             asm volatile("" ::: "memory");  // keep the per-pixel LDS reads inside the chunk (registers, not hoisted copies)
 #pragma unroll
-            for (int s0 = 0; s0 < 16; s0 += 4) {  // four independent steps per group: the DPP scans interleave
-                float cg[4], araw[4], a[4], r1a[4], rp[4], dxs[4], dys[4], Tb[4];
+            for (int G = 0; G < 4; ++G) {  // strip G: four independent sub-steps, their DPP scans interleave
+                f32x4 pw = {0.f, 0.f, 0.f, 0.f}, cgv = {0.f, 0.f, 0.f, 0.f};
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phirow[64 * (2 * G)], bq1, pw, 0, 0, 0);
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phirow[64 * (2 * G + 1)], bq2, pw, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NK; ++j)
+                    cgv = __builtin_amdgcn_mfma_f32_16x16x4f32(pixcol[16 * G * PW + kch[j]], bf[j], cgv, 0, 0, 0);
+                float cg[4], araw[4], a[4], r1a[4], rp[4], Tb[4];
                 bool ok[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int s = s0 + u;
-                    const float *pr = pixrow + 4 * s * PW;
-                    cg[u] = 0.f;
-#pragma unroll
-                    for (int k = 0; k < CH; ++k) cg[u] += f[k] * pr[k];
-                    Tb[u] = pr[CH];
+                for (int i = 0; i < 4; ++i) {
+                    const float *pr = pixrow + (16 * G + i) * PW;
+                    cg[i] = cgv[i];
+                    Tb[i] = pr[CH];
                     const int last = __float_as_int(pr[CH + 1]);
-                    const float dx = ur - (float)(4 * (s & 1)), dy = vl - (float)(s >> 1);
-                    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-                    const float G = __expf(power);
-                    araw[u] = o * G;
-                    const float alpha = fminf(0.99f, araw[u]);
-                    ok[u] = (qn < last) && !(power > 0.f) && !(alpha < (1.0f / 255.0f));
-                    a[u] = ok[u] ? alpha : 0.f;
-                    r1a[u] = __builtin_amdgcn_rcpf(1.f - a[u]);
-                    rp[u] = r1a[u];
-                    dxs[u] = dx; dys[u] = dy;
+                    const float Gs = __builtin_amdgcn_exp2f(pw[i]);
+                    araw[i] = o * Gs;
+                    const float alpha = fminf(0.99f, araw[i]);
+                    ok[i] = (qn < last) && !(pw[i] > 0.f) && !(alpha < (1.0f / 255.0f));
+                    a[i] = ok[i] ? alpha : 0.f;
+                    r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
+                    rp[i] = r1a[i];
                 }
                 row_scan_mul4(rp[0], rp[1], rp[2], rp[3]);
-                float T[4], wgt[4], rs[4];
+                float T[4], wgt[4], rs[4], R[4], Ts4[4], Rs4[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    T[u] = Tst[s0 + u] * rp[u];  // transmittance in front of this splat
-                    wgt[u] = a[u] * T[u];
-                    rs[u] = cg[u] * wgt[u];
+                for (int i = 0; i < 4; ++i) {
+                    Ts4[i] = Tst[4 * G + i];
+                    Rs4[i] = Rst[4 * G + i];
+                    T[i] = Ts4[i] * rp[i];  // transmittance in front of this splat
+                    wgt[i] = a[i] * T[i];
+                    rs[i] = cg[i] * wgt[i];
                 }
                 row_scan_add4(rs[0], rs[1], rs[2], rs[3]);
+                row_state_update4(R, Rs4, rs, Ts4, T);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int s = s0 + u;
-                    const float R = Rst[s] + row_shr1(rs[u]);  // colour behind this splat (dotted with dL_dout)
-                    const float dLa = T[u] * cg[u] - (R + Tb[u]) * r1a[u];
-                    const float dLp = ok[u] ? araw[u] * dLa : 0.f;  // dL/dpower
+                for (int i = 0; i < 4; ++i) {
+                    const int s = 4 * G + i;
+                    Tst[s] = Ts4[i];
+                    Rst[s] = Rs4[i];
+                    const float dLa = T[i] * cg[i] - (R[i] + Tb[i]) * r1a[i];
+                    const float dLp = ok[i] ? araw[i] * dLa : 0.f;  // dL/dpower
                     d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[64 * s], dLp, d_mom, 0, 0, 0);
 #pragma unroll
                     for (int q = 0; q < NA; ++q)
-                        d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(pixrow[4 * s * PW + gch[q]], wgt[u], d_f[q], 0, 0, 0);
+                        d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(pixrow[(16 * G + i) * PW + gch[q]], wgt[i], d_f[q], 0, 0, 0);
                     if (ABS) {
-                        d_ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cA * dxs[u] + cB * dys[u])), d_ax, 0, 0, 0);
-                        d_ay = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cB * dxs[u] + cC * dys[u])), d_ay, 0, 0, 0);
+                        const float dx = uc - (xk + (float)i), dy = vc - (yk + (float)(2 * G));
+                        d_ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cA * dx + cB * dy)), d_ax, 0, 0, 0);
+                        d_ay = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cB * dx + cC * dy)), d_ay, 0, 0, 0);
                     }
-                    Tst[s] = row_last(T[u]);
-                    Rst[s] = Rst[s] + row_last(rs[u]);
                 }
             }
             // ---- chunk epilogue: lane (n, kk) holds rows 4kk..4kk+3 of every accumulator for survivor n
@@ -904,9 +940,9 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
                 const float D0 = d_mom[0];
                 if (kk == 0) {
                     const float Dx = d_mom[1], Dy = d_mom[2], Dxx = d_mom[3];
-                    rec[0] = cA * Dx + cB * Dy - (cA * ul + cB * vl) * D0;
-                    rec[1] = cB * Dx + cC * Dy - (cB * ul + cC * vl) * D0;
-                    rec[2] = -0.5f * (ul * ul * D0 - 2.f * ul * Dx + Dxx);
+                    rec[0] = cA * Dx + cB * Dy - (cA * uc + cB * vc) * D0;
+                    rec[1] = cB * Dx + cC * Dy - (cB * uc + cC * vc) * D0;
+                    rec[2] = -0.5f * (uc * uc * D0 - 2.f * uc * Dx + Dxx);
                     rec[5] = o > 0.f ? D0 / o : 0.f;
                     if (ABS) {
                         rec[I_ABS] = d_ax[0];
@@ -914,10 +950,10 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
                     }
                 } else if (kk == 1) {
                     const float Dx = d_mom[1], Dy = d_mom[2], Dxy = d_mom[3];
-                    rec[3] = -(ul * vl * D0 - ul * Dy - vl * Dx + Dxy);
+                    rec[3] = -(uc * vc * D0 - uc * Dy - vc * Dx + Dxy);
                 } else if (kk == 2) {
                     const float Dy = d_mom[1], Dyy = d_mom[2];
-                    rec[4] = -0.5f * (vl * vl * D0 - 2.f * vl * Dy + Dyy);
+                    rec[4] = -0.5f * (vc * vc * D0 - 2.f * vc * Dy + Dyy);
                 }
 #pragma unroll
                 for (int q = 0; q < NA; ++q)
@@ -937,9 +973,12 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
                 const int e = nb - 1 - ql;
                 float v = 0.f;
                 if (c < NC) {
+                    const unsigned int fl = s_wr[e];
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww)
-                        if ((s_mask[ww][e >> 6] >> (e & 63)) & 1ull) v += s_acc[ww][e * NC + c];
+                    for (int ww = 0; ww < 4; ++ww) {
+                        const float x = s_acc[ww][e * NC + c];
+                        v += ((fl >> (8 * ww)) & 1u) ? x : 0.f;
+                    }
                 }
                 A.pair_buf[(size_t)slots[lo + ql] * NCP + c] = v;
             }
