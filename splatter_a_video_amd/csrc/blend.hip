@@ -692,7 +692,9 @@ struct MfmaCfg {
     static constexpr int NC = NG + CH;
     static constexpr int NCP = (NC + 15) & ~15;
     static constexpr int SB = CH <= 8 ? BLEND_MFMA_SB : 64;
-    static constexpr int PW = (CH + 4 + 3) & ~3;  // floats per pixel record: g[CH], T_final*bg.g, ncontrib, T_final, 0
+    static constexpr int PZ = CH;                 // a zero slot (lanes without a channel feed it to the MFMAs)
+    static constexpr int PS = (CH + 1 + 3) & ~3;  // state block [T_final*bg.g, ncontrib, T_state, R_state] (16-B aligned)
+    static constexpr int PW = PS + 4;             // floats per pixel record: g[CH], 0.., state block
     static constexpr int NA = (CH + 15) / 16;     // feature-gradient accumulators (16 channels each)
     static constexpr int NK = (CH + 3) / 4;       // K-slabs of the cg product (4 channels each)
 };
@@ -714,28 +716,16 @@ __device__ __forceinline__ void row_scan_add4(float &a, float &b, float &c, floa
                      SCAN4("v_add_f32_dpp", "8")
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
-// after the scans, for four steps at once:  R = R_state + (scan shifted by one lane),  R_state += row total,
-// T_state = T of the row's last lane
-__device__ __forceinline__ void row_state_update4(float (&R)[4], float (&Rst)[4], const float (&rs)[4], float (&Tst)[4],
-                                                  const float (&T)[4]) {
-    // operands: %0-3 R (out), %4-7 R_state (in/out), %8-11 T_state (out), %12-15 rs, %16-19 T
+// R[i] = base[i] + (rs[i] of the previous lane of the row; 0 for lane 0): exclusive scan from the inclusive one
+__device__ __forceinline__ void row_shr1_add4(float (&R)[4], const float (&rs)[4], const float (&base)[4]) {
     asm volatile(
         "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %12, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %13, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %14, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %15, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %4, %12, %4 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %5, %13, %5 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %6, %14, %6 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %7, %15, %7 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %8, %16 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %9, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %10, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %11, %19 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]), "+v"(Rst[0]), "+v"(Rst[1]), "+v"(Rst[2]), "+v"(Rst[3]),
-          "=&v"(Tst[0]), "=&v"(Tst[1]), "=&v"(Tst[2]), "=&v"(Tst[3])
-        : "v"(rs[0]), "v"(rs[1]), "v"(rs[2]), "v"(rs[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]));
+        "v_add_f32_dpp %0, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %5, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %6, %10 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %7, %11 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3])
+        : "v"(rs[0]), "v"(rs[1]), "v"(rs[2]), "v"(rs[3]), "v"(base[0]), "v"(base[1]), "v"(base[2]), "v"(base[3]));
 }
 
 template <int CH, bool ABS, bool EXACT>
@@ -743,6 +733,7 @@ __global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_MFMA_MINW : 1))
 blend_bwd_mfma_kernel(const BlendArgs A) {
     using Cfg = MfmaCfg<CH, ABS>;
     constexpr int SB = Cfg::SB, NG = Cfg::NG, NC = Cfg::NC, NCP = Cfg::NCP, PW = Cfg::PW, NA = Cfg::NA, NK = Cfg::NK;
+    constexpr int PZ = Cfg::PZ, PS = Cfg::PS;
     constexpr int I_ABS = GradLayout<ABS, false>::I_ABS;
     constexpr float L2E = 1.4426950408889634f;
     __shared__ TileLDS<CH, SB> L;
@@ -750,7 +741,6 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
     __shared__ unsigned int s_wr[SB];        // byte w of entry e: wave w wrote its slab record
     __shared__ __attribute__((aligned(16))) float s_pix[4][64 * PW];
     __shared__ float s_mom[16 * 64];         // A operand of the moment product: [step 4 G + i][lane]
-    __shared__ float s_phi[8 * 64];          // A operand of the power product:  [2 G + j][lane]
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
@@ -774,15 +764,14 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
         if (grp == 2) v = i == 0 ? 1.f : i == 1 ? y : i == 2 ? y * y : 0.f;
         s_mom[64 * st + lane] = v;
     }
+    // A operand of the power product, A[m = pixel nl of strip G][k = kk]: monomials 1 x y xx | xy yy 0 0
+    float phi1[4], phi2[4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int t = 2 * w + r, Gs = t >> 1, j = t & 1;  // A[m = pixel nl of strip Gs][k = kk]
+    for (int Gs = 0; Gs < 4; ++Gs) {
         const int q = 16 * Gs + nl;
         const float x = (float)(q & 7) - 3.5f, y = (float)(q >> 3) - 3.5f;
-        float v;
-        if (j == 0) v = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
-        else v = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
-        s_phi[64 * t + lane] = v;
+        phi1[Gs] = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
+        phi2[Gs] = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
     }
     {   // per-pixel constants: lane q <-> pixel (q & 7, q >> 3) of the wave's block
         const int px = bx + (lane & 7), py = by + (lane >> 3);
@@ -799,11 +788,12 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
             r[k] = g;
             bgdot += A.bg * g;
         }
-        r[CH] = Tf * bgdot;
-        r[CH + 1] = __int_as_float(last);
-        r[CH + 2] = Tf;
 #pragma unroll
-        for (int k = CH + 3; k < PW; ++k) r[k] = 0.f;  // slot CH+3: what lanes without a channel feed to the MFMAs
+        for (int k = CH; k < PS; ++k) r[k] = 0.f;  // slot PZ: what lanes without a channel feed to the MFMAs
+        r[PS] = Tf * bgdot;
+        r[PS + 1] = __int_as_float(last);
+        r[PS + 2] = Tf;   // T_state: transmittance behind the splats replayed so far
+        r[PS + 3] = 0.f;  // R_state: colour behind them (dotted with dL_dout)
         wmax = wave_max_i(last);  // this wave never needs entries q >= wmax
         if (lane == 0) s_wmax[w] = wmax;
     }
@@ -820,21 +810,14 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
     if (n <= 0) return;
 
     // ---- per-lane addressing: pixel (G, kk, i) is q = 16 G + 4 kk + i
-    const float *pixrow = s_pix[w] + 4 * kk * PW;  // own pixel of step (G, i): pixrow + (16 G + i) * PW
+    float *pixrow = s_pix[w] + 4 * kk * PW;        // own pixel of step (G, i): pixrow + (16 G + i) * PW
     const float *pixcol = s_pix[w] + nl * PW;      // pixel nl of strip G (cg product, A operand): pixcol + 16 G * PW
     const float *momrow = s_mom + lane;            // + 64 * (4 G + i)
-    const float *phirow = s_phi + lane;            // + 64 * (2 G + j)
     int gch[NA], kch[NK];
 #pragma unroll
-    for (int q = 0; q < NA; ++q) gch[q] = 16 * q + nl < CH ? 16 * q + nl : CH + 3;  // channel row of the feature product
+    for (int q = 0; q < NA; ++q) gch[q] = 16 * q + nl < CH ? 16 * q + nl : PZ;  // channel row of the feature product
 #pragma unroll
-    for (int j = 0; j < NK; ++j) kch[j] = 4 * j + kk < CH ? 4 * j + kk : CH + 3;    // K index of the cg product
-    float Tst[16], Rst[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        Tst[s] = pixrow[(16 * (s >> 2) + (s & 3)) * PW + CH + 2];
-        Rst[s] = 0.f;
-    }
+    for (int j = 0; j < NK; ++j) kch[j] = 4 * j + kk < CH ? 4 * j + kk : PZ;    // K index of the cg product
     const float a_one = nl == 0 ? 1.f : 0.f;
     const float xk = (float)(4 * (kk & 1)) - 3.5f, yk = (float)(kk >> 1) - 3.5f;  // own pixel: x = xk + i, y = yk + 2 G
 
@@ -883,19 +866,21 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
 #pragma unroll
             for (int G = 0; G < 4; ++G) {  // strip G: four independent sub-steps, their DPP scans interleave
                 f32x4 pw = {0.f, 0.f, 0.f, 0.f}, cgv = {0.f, 0.f, 0.f, 0.f};
-                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phirow[64 * (2 * G)], bq1, pw, 0, 0, 0);
-                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phirow[64 * (2 * G + 1)], bq2, pw, 0, 0, 0);
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bq1, pw, 0, 0, 0);
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi2[G], bq2, pw, 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < NK; ++j)
                     cgv = __builtin_amdgcn_mfma_f32_16x16x4f32(pixcol[16 * G * PW + kch[j]], bf[j], cgv, 0, 0, 0);
-                float cg[4], araw[4], a[4], r1a[4], rp[4], Tb[4];
+                float cg[4], araw[4], a[4], r1a[4], rp[4], Tb[4], Ts4[4], Rs4[4];
                 bool ok[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float *pr = pixrow + (16 * G + i) * PW;
+                    const float4 stv = *reinterpret_cast<const float4 *>(pixrow + (16 * G + i) * PW + PS);
                     cg[i] = cgv[i];
-                    Tb[i] = pr[CH];
-                    const int last = __float_as_int(pr[CH + 1]);
+                    Tb[i] = stv.x;
+                    const int last = __float_as_int(stv.y);
+                    Ts4[i] = stv.z;
+                    Rs4[i] = stv.w;
                     const float Gs = __builtin_amdgcn_exp2f(pw[i]);
                     araw[i] = o * Gs;
                     const float alpha = fminf(0.99f, araw[i]);
@@ -905,22 +890,23 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
                     rp[i] = r1a[i];
                 }
                 row_scan_mul4(rp[0], rp[1], rp[2], rp[3]);
-                float T[4], wgt[4], rs[4], R[4], Ts4[4], Rs4[4];
+                float T[4], wgt[4], rs[4], R[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    Ts4[i] = Tst[4 * G + i];
-                    Rs4[i] = Rst[4 * G + i];
                     T[i] = Ts4[i] * rp[i];  // transmittance in front of this splat
                     wgt[i] = a[i] * T[i];
                     rs[i] = cg[i] * wgt[i];
                 }
                 row_scan_add4(rs[0], rs[1], rs[2], rs[3]);
-                row_state_update4(R, Rs4, rs, Ts4, T);
+                row_shr1_add4(R, rs, Rs4);  // R = R_state + colour of the deeper splats of this chunk
+                if (nl == 15) {             // the row's last lane holds the new state of its pixel
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<float2 *>(pixrow + (16 * G + i) * PW + PS + 2) = make_float2(T[i], Rs4[i] + rs[i]);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int s = 4 * G + i;
-                    Tst[s] = Ts4[i];
-                    Rst[s] = Rs4[i];
                     const float dLa = T[i] * cg[i] - (R[i] + Tb[i]) * r1a[i];
                     const float dLp = ok[i] ? araw[i] * dLa : 0.f;  // dL/dpower
                     d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[64 * s], dLp, d_mom, 0, 0, 0);

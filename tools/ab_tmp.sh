@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-export PYTHONPATH=$GRAFT_REPO_ROOT
-B="python $GRAFT_REPO_ROOT/tools/blend_bench.py --reps 2"
-bash tools/pmc_run.sh i1 "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA" $B < /dev/null > /dev/null
-bash tools/pmc_run.sh i2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES" $B < /dev/null > /dev/null
-bash tools/pmc_run.sh i3 "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_WAVES_EQ_64 SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES GRBM_GUI_ACTIVE" $B < /dev/null > /dev/null
+export PYTHONPATH=.
+run() { timeout 100 python tools/blend_bench.py "$@" < /dev/null 2>&1 | grep "^\[" ; }
+echo base; run
+timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_renderer_flow.py tests/test_gpu_golden.py -x -q < /dev/null 2>&1 | tail -15
