@@ -48,6 +48,13 @@
 #ifndef BLEND_MFMA_MINW
 #define BLEND_MFMA_MINW 1
 #endif
+#ifndef BLEND_FWDM_MINW
+#define BLEND_FWDM_MINW 1
+#endif
+// power is a negative-semidefinite form: it can only exceed 0 by rounding.  The matrix-core kernels evaluate it as
+// an expanded polynomial (absolute error up to ~5e-6 in log2 units), so their "power > 0" guard of the reference
+// (src/alpha_blending.cu:93) sits just above that noise; it still rejects genuinely indefinite conics.
+#define BLEND_PW_MAX 1.5e-4f
 
 struct BlendArgs {
     int P, C;          // C = row stride of feature / dL_dfeature
@@ -884,7 +891,7 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
                     const float Gs = __builtin_amdgcn_exp2f(pw[i]);
                     araw[i] = o * Gs;
                     const float alpha = fminf(0.99f, araw[i]);
-                    ok[i] = (qn < last) && !(pw[i] > 0.f) && !(alpha < (1.0f / 255.0f));
+                    ok[i] = (qn < last) && !(pw[i] > BLEND_PW_MAX) && !(alpha < (1.0f / 255.0f));
                     a[i] = ok[i] ? alpha : 0.f;
                     r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
                     rp[i] = r1a[i];
@@ -970,6 +977,200 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
             }
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ forward, matrix-core version (plain blending)
+// Same idea as the matrix-core backward, transposed: lane (p = lane & 15, g = lane >> 4) owns pixel p of the
+// current 2x8 strip and, per 16-survivor chunk (front to back), the four consecutive splats 4g..4g+3:
+//   power[n,p]  = q(n) . phi(p)             MFMA, K = 6 monomials -> D rows = splats, columns = pixels
+//   T chain     = in-register products over the lane's 4 splats + a two-step exchange across the 4 lane groups
+//   out[c,p]   += f[n,c] w[n,p]             MFMA, K = splats; the accumulators stay in registers for the whole tile
+// Early termination (reference: src/alpha_blending.cu:79-113): a pixel stops at the first valid splat that would
+// push T below 1e-4.  T is non-increasing, so with Ti = T after splat i (all valid splats multiplied in) the applied
+// splats are exactly {valid, Ti >= 1e-4}; the pixel state keeps T of the last applied splat, negated once stopped.
+// value of lane ^ 16 / lane ^ 32 without an LDS round trip (gfx950 v_permlane{16,32}_swap: exchange the odd 16-lane
+// rows of the first operand with the even rows of the second / rows 2,3 with rows 0,1)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float xchg16(float v, bool odd_row) {
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r[0] rows: x0 x0 x2 x2, r[1]: x1 x1 x3 x3
+    return __builtin_bit_cast(float, odd_row ? r[0] : r[1]);
+}
+__device__ __forceinline__ float xchg32(float v, bool upper_half) {
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r[0] rows: x0 x1 x0 x1, r[1]: x2 x3 x2 x3
+    return __builtin_bit_cast(float, upper_half ? r[0] : r[1]);
+}
+
+template <int CH>
+struct FwdMfmaCfg {
+    static constexpr int SB = CH <= 8 ? 256 : 128;
+    static constexpr int NA = (CH + 15) / 16;  // output accumulators per strip (16 channels each)
+};
+
+template <int CH, bool EXACT>
+__global__ void __launch_bounds__(256, BLEND_FWDM_MINW)
+blend_fwd_mfma_kernel(const BlendArgs A) {
+    using Cfg = FwdMfmaCfg<CH>;
+    constexpr int SB = Cfg::SB, NA = Cfg::NA, RQ = Rec<CH>::RQ;
+    constexpr float L2E = 1.4426950408889634f;
+    constexpr float T_BIG = 4.f;
+    __shared__ TileLDS<CH, SB> L;
+    __shared__ int s_done[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x;
+    const int tx = tile % A.gx, ty = tile / A.gx;
+    const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
+    const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+    const int cn = EXACT ? CH : A.cn;
+    const int pl = lane & 15, g = lane >> 4;
+
+    // B operand of the power product, B[k = g][n = pixel pl of strip G]: monomials 1 x y xx | xy yy 0 0 of the
+    // block-centred pixel coordinates (identical values and K order as the backward: bitwise the same powers)
+    float phi1[4], phi2[4];
+    float Tst[4];   // per strip: T of the lane's pixel after the last applied splat; negative once the pixel stopped
+    int lastL[4];   // per strip: last applied list position + 1 among THIS lane's splats (reduced over g at the end)
+    f32x4 acc[4][NA];
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+        const int q = 16 * G + pl;
+        const float x = (float)(q & 7) - 3.5f, y = (float)(q >> 3) - 3.5f;
+        phi1[G] = g == 0 ? 1.f : g == 1 ? x : g == 2 ? y : x * x;
+        phi2[G] = g == 0 ? x * y : g == 1 ? y * y : 0.f;
+        const bool inside = (bx + (q & 7) < A.W) && (by + (q >> 3) < A.H);
+        Tst[G] = inside ? 1.f : -1.f;
+        lastL[G] = 0;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) acc[G][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int2 range = A.tile_range[tile];
+    const int n = range.y - range.x;
+
+    if (tid < RQ) L.rec[SB * RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
+    auto pos = [n](int e, int b) { const int q = b * SB + e; return q < n ? q : -1; };  // forward walk
+    Stager<CH, SB> st;
+    st.load_ids(A, tid, range.x, pos, 0);
+    st.load_payload(A, tid);
+    st.load_ids(A, tid, range.x, pos, 1);
+
+    for (int base = 0, batch = 0; base < n; base += SB, ++batch) {
+        const bool alld = !__any((Tst[0] > 0.f) || (Tst[1] > 0.f) || (Tst[2] > 0.f) || (Tst[3] > 0.f));
+        if (lane == 0) s_done[w] = alld;
+        const int nb = imin_(SB, n - base);
+        st.park(L, tid);
+        st.load_payload(A, tid);                       // payload of the next super-batch
+        st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
+        __syncthreads();
+        if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;  // every pixel of the tile is saturated
+        if (!alld) {
+            const int cnt = build_list<CH, SB, false>(L, w, lane, nb, bx0, bx1, by0, by1, [](int) { return true; });
+            for (int j0 = 0; j0 < cnt; j0 += 16) {
+                // ---- coefficient role: lane (s = pl, k = g) supplies coefficient k of survivor j0 + pl (x log2 e)
+                float aq1, aq2;
+                {
+                    const int ec = L.list[w][j0 + pl];
+                    const float4 g0 = L.g0(ec), g1 = L.g1(ec);
+                    const float cA = g0.z, cB = g0.w, cC = g1.x;
+                    const float uc = g0.x - bx0 - 3.5f, vc = g0.y - by0 - 3.5f;
+                    const float q0 = L2E * (-0.5f * (cA * uc * uc + cC * vc * vc) - cB * uc * vc);
+                    const float qx = L2E * (cA * uc + cB * vc), qy = L2E * (cB * uc + cC * vc);
+                    const float qxx = -0.5f * L2E * cA, qxy = -L2E * cB, qyy = -0.5f * L2E * cC;
+                    aq1 = g == 0 ? q0 : g == 1 ? qx : g == 2 ? qy : qxx;
+                    aq2 = g == 0 ? qxy : g == 1 ? qyy : 0.f;
+                }
+                // ---- pixel role: the lane's four splats 4g..4g+3 of the chunk
+                float op[4], fa[NA][4];
+                int qpos[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = L.list[w][j0 + 4 * g + i];  // slot SB (inert: opacity 0) past the end of the list
+                    op[i] = L.g1(e).y;
+                    qpos[i] = base + e + 1;
+                    const float *fr = reinterpret_cast<const float *>(&L.rec[e * RQ + 2]);
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        const int c = 16 * a + pl;  // channel row this lane feeds to the output product
+                        const float v = fr[c < CH ? c : 0];
+                        fa[a][i] = c < CH ? v : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    f32x4 pw = {0.f, 0.f, 0.f, 0.f};
+                    pw = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1, phi1[G], pw, 0, 0, 0);
+                    pw = __builtin_amdgcn_mfma_f32_16x16x4f32(aq2, phi2[G], pw, 0, 0, 0);
+                    const bool active = Tst[G] > 0.f;
+                    float a[4], om[4];
+                    bool valid[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float alpha = fminf(0.99f, op[i] * __builtin_amdgcn_exp2f(pw[i]));
+                        valid[i] = active && !(pw[i] > BLEND_PW_MAX) && !(alpha < (1.0f / 255.0f));
+                        a[i] = valid[i] ? alpha : 0.f;
+                        om[i] = 1.f - a[i];
+                    }
+                    const float c1 = om[0], c2 = c1 * om[1], c3 = c2 * om[2], c4 = c3 * om[3];
+                    // products of the other lane groups: xor-16 / xor-32 butterfly gives total and exclusive prefix
+                    const float t1 = xchg16(c4, g & 1);
+                    const float t2 = xchg32(c4 * t1, g & 2);
+                    const float excl = ((g & 1) ? t1 : 1.f) * ((g & 2) ? t2 : 1.f);
+                    const float Tb0 = fabsf(Tst[G]) * excl;  // T in front of the lane's first splat
+                    const float Tb[4] = {Tb0, Tb0 * c1, Tb0 * c2, Tb0 * c3};
+                    const float Ti[4] = {Tb[1], Tb[2], Tb[3], Tb0 * c4};
+                    float tmin = T_BIG;
+                    int lst = 0;
+                    bool stop = false;
+                    float wv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool app = valid[i] && (Ti[i] >= 0.0001f);
+                        stop = stop || (valid[i] && !app);
+                        wv[i] = app ? a[i] * Tb[i] : 0.f;
+                        tmin = app ? Ti[i] : tmin;  // Ti is non-increasing: the last applied one is the smallest
+                        lst = app ? qpos[i] : lst;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < NA; ++q)
+                            acc[G][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q][i], wv[i], acc[G][q], 0, 0, 0);
+                    lastL[G] = imax_(lastL[G], lst);
+                    // pixel state: smallest applied Ti over the four lane groups; stopped if any group saw a stop
+                    float kmin = fminf(tmin, xchg16(tmin, g & 1));
+                    kmin = fminf(kmin, xchg32(kmin, g & 2));
+                    const unsigned long long sb = __ballot(stop);
+                    const bool stopped = ((sb >> pl) & 0x0001000100010001ull) != 0ull;
+                    const float Tn = fminf(fabsf(Tst[G]), kmin);
+                    Tst[G] = (active && !stopped) ? Tn : -Tn;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- write back: lane (p, g) holds channels 4g..4g+3 of pixel p of every strip
+    const size_t HW = (size_t)A.H * A.W;
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+        const int q = 16 * G + pl;
+        const int px = bx + (q & 7), py = by + (q >> 3);
+        int last = imax_(lastL[G], __float_as_int(xchg16(__int_as_float(lastL[G]), g & 1)));
+        last = imax_(last, __float_as_int(xchg32(__int_as_float(last), g & 2)));
+        if (px < A.W && py < A.H) {
+            const size_t pix = (size_t)A.W * (size_t)py + px;
+            const float T = fabsf(Tst[G]);
+            if (g == 0) {
+                A.final_T[pix] = T;
+                A.ncontrib[pix] = last;
+            }
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 16 * a + 4 * g + i;
+                    if (c < cn) A.out[(size_t)(A.c0 + c) * HW + pix] = acc[G][a][i] + T * A.bg;
+                }
+        }
     }
 }
 
@@ -1081,6 +1282,15 @@ static int launch_pack(const BlendArgs &A, bool bias, hipStream_t s) {
     return SPLAT_OK;
 }
 
+// SPLAT_FWD_KERNEL=valu selects the per-pixel-lane forward kernel (A/B measurements); default: matrix cores
+static bool fwd_use_mfma() {
+    static const int v = [] {
+        const char *e = getenv("SPLAT_FWD_KERNEL");
+        return (e && strcmp(e, "valu") == 0) ? 0 : 1;
+    }();
+    return v != 0;
+}
+
 template <int CH>
 static int launch_fwd(const BlendArgs &A, int T, bool enh, bool bias, hipStream_t s) {
     const dim3 grid((unsigned)T), block(256);
@@ -1090,7 +1300,10 @@ static int launch_fwd(const BlendArgs &A, int T, bool enh, bool bias, hipStream_
         if (rc != SPLAT_OK) return rc;
     }
 #define FWD(E, B, X) SPLAT_LAUNCH("blend_fwd", (blend_fwd_kernel<CH, E, B, X>), grid, block, 0, s, A)
-    if (enh) {
+    if (!enh && !bias && fwd_use_mfma()) {
+        if (exact) SPLAT_LAUNCH("blend_fwd", (blend_fwd_mfma_kernel<CH, true>), grid, block, 0, s, A);
+        else SPLAT_LAUNCH("blend_fwd", (blend_fwd_mfma_kernel<CH, false>), grid, block, 0, s, A);
+    } else if (enh) {
         if (bias) { if (exact) FWD(true, true, true); else FWD(true, true, false); }
         else { if (exact) FWD(true, false, true); else FWD(true, false, false); }
     } else {
