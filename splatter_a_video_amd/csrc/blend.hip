@@ -48,9 +48,6 @@
 #ifndef BLEND_MFMA_MINW
 #define BLEND_MFMA_MINW 1
 #endif
-#ifndef BLEND_FWDM_MINW
-#define BLEND_FWDM_MINW 1
-#endif
 // power is a negative-semidefinite form: it can only exceed 0 by rounding.  The matrix-core kernels evaluate it as
 // an expanded polynomial (absolute error up to ~5e-6 in log2 units), so their "power > 0" guard of the reference
 // (src/alpha_blending.cu:93) sits just above that noise; it still rejects genuinely indefinite conics.
@@ -99,7 +96,73 @@ template <int CH>
 struct Rec {
     static constexpr int RS = (8 + CH + 15) & ~15;  // floats per record
     static constexpr int RQ = RS / 4;               // float4 chunks per record
+    // culling parameters [hx hy tauq 1/A 1/C] of the splat (cull_params) live in the last 5 pad floats when the
+    // record has that much padding; otherwise the tile kernels derive them from the conic
+    static constexpr int CULL = (RS - 8 - CH >= 5) ? RS - 5 : -1;
 };
+
+// Can the splat reach alpha >= 1/255 at any pixel centre of the block [bx0,bx1]x[by0,by1]?
+// alpha >= 1/255 needs q(d) = d^T Q d <= tau = 2 ln(255 o).  Two conservative stages (never false for a
+// splat that contributes; every bound is inflated by the rounding error it can carry):
+//   1. axis-aligned box of the ellipse {q <= tau} against the block;
+//   2. exact: the minimum of the convex q over the block rectangle (centre inside, else on an edge).
+// The block-independent part (cull_params: log, two sqrt, three rcp) is evaluated once per Gaussian and frame.
+struct CullP {
+    float hx, hy;   // half extents of the ellipse's bounding box (hx < 0: the splat never contributes)
+    float tauq;     // inflated tau for the exact test (+inf: keep whenever the box test passes)
+    float ia, ic;   // 1/A, 1/C
+};
+
+__device__ __forceinline__ CullP cull_params(float a, float b, float c, float o) {
+    CullP p;
+    const float INF = __builtin_inff();
+    p.hx = INF; p.hy = INF; p.tauq = INF; p.ia = 0.f; p.ic = 0.f;  // degenerate conic: always keep
+    const float t = 255.f * o;
+    if (t < 0.999f) {  // alpha <= o < 1/255 everywhere
+        p.hx = -1.f;
+        return p;
+    }
+    const float det = a * c - b * b;
+    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return p;
+    const float relerr = 4e-7f * (a * c + b * b) / det;  // rounding bound of det (cancellation)
+    if (!(relerr < 0.25f)) return p;
+    const float tau0 = fmaxf(2.f * __logf(t), 0.f);
+    const float tau = tau0 * (1.f + 2.f * relerr) * 1.002f + 2e-3f;
+    const float inv = 1.f / det;
+    p.hx = sqrtf(tau * c * inv) * 1.001f + 0.01f;
+    p.hy = sqrtf(tau * a * inv) * 1.001f + 0.01f;
+    p.tauq = tau * 1.002f + 2e-3f;
+    p.ia = 1.f / a;
+    p.ic = 1.f / c;
+    return p;
+}
+
+__device__ __forceinline__ bool cull_test(float u, float v, float a, float b, float c, const CullP &p, float bx0,
+                                          float bx1, float by0, float by1) {
+    const float dx0 = bx0 - u, dx1 = bx1 - u, dy0 = by0 - v, dy1 = by1 - v;  // block relative to the centre
+    const float ddx = fmaxf(fmaxf(dx0, -dx1), 0.f);
+    const float ddy = fmaxf(fmaxf(dy0, -dy1), 0.f);
+    if (!((ddx <= p.hx) && (ddy <= p.hy))) return false;
+    if (ddx == 0.f && ddy == 0.f) return true;  // centre inside the block
+    // minimum of q on the four edges (q is convex: clamp the unconstrained minimiser of each edge line)
+    float qmin;
+    {
+        const float y0 = fminf(fmaxf(-b * dx0 * p.ic, dy0), dy1), y1 = fminf(fmaxf(-b * dx1 * p.ic, dy0), dy1);
+        const float q0 = a * dx0 * dx0 + 2.f * b * dx0 * y0 + c * y0 * y0;
+        const float q1 = a * dx1 * dx1 + 2.f * b * dx1 * y1 + c * y1 * y1;
+        qmin = fminf(q0, q1);
+    }
+    {
+        const float x0 = fminf(fmaxf(-b * dy0 * p.ia, dx0), dx1), x1 = fminf(fmaxf(-b * dy1 * p.ia, dx0), dx1);
+        const float q0 = a * x0 * x0 + 2.f * b * x0 * dy0 + c * dy0 * dy0;
+        const float q1 = a * x1 * x1 + 2.f * b * x1 * dy1 + c * dy1 * dy1;
+        qmin = fminf(qmin, fminf(q0, q1));
+    }
+    // q is evaluated with ~1e-6 relative error of its largest term; the terms are bounded by (a+c+2|b|) * r^2
+    const float r2 = fmaxf(dx0 * dx0, dx1 * dx1) + fmaxf(dy0 * dy0, dy1 * dy1);
+    const float qerr = 4e-6f * (a + c + 2.f * fabsf(b)) * r2;
+    return qmin <= p.tauq + qerr;
+}
 
 template <int CH, bool BIAS, bool EXACT>
 __global__ void __launch_bounds__(256)
@@ -120,53 +183,14 @@ pack_kernel(const BlendArgs A) {
 #pragma unroll
     for (int k = 0; k < CH; ++k)
         if (EXACT || k < A.cn) r[8 + k] = f[k];
+    if (Rec<CH>::CULL >= 0) {
+        constexpr int CO = Rec<CH>::CULL >= 0 ? Rec<CH>::CULL : 0;
+        const CullP cp = cull_params(r[2], r[3], r[4], r[5]);
+        r[CO] = cp.hx; r[CO + 1] = cp.hy; r[CO + 2] = cp.tauq; r[CO + 3] = cp.ia; r[CO + 4] = cp.ic;
+    }
     float4 *dst = reinterpret_cast<float4 *>(A.pack + (size_t)i * RS);
 #pragma unroll
     for (int k = 0; k < RS; k += 4) dst[k / 4] = make_float4(r[k], r[k + 1], r[k + 2], r[k + 3]);
-}
-
-// Can the splat reach alpha >= 1/255 at any pixel centre of the block [bx0,bx1]x[by0,by1]?
-// alpha >= 1/255 needs q(d) = d^T Q d <= tau = 2 ln(255 o).  Two conservative stages (never false for a
-// splat that contributes; every bound is inflated by the rounding error it can carry):
-//   1. axis-aligned box of the ellipse {q <= tau} against the block;
-//   2. exact: the minimum of the convex q over the block rectangle (centre inside, else on an edge).
-__device__ __forceinline__ bool splat_touches(float u, float v, float a, float b, float c, float o, float bx0,
-                                              float bx1, float by0, float by1) {
-    const float t = 255.f * o;
-    if (t < 0.999f) return false;  // alpha <= o < 1/255 everywhere
-    const float det = a * c - b * b;
-    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return true;
-    const float relerr = 4e-7f * (a * c + b * b) / det;  // rounding bound of det (cancellation)
-    if (!(relerr < 0.25f)) return true;
-    const float tau0 = fmaxf(2.f * __logf(t), 0.f);
-    const float tau = tau0 * (1.f + 2.f * relerr) * 1.002f + 2e-3f;
-    const float inv = 1.f / det;
-    const float hx = sqrtf(tau * c * inv) * 1.001f + 0.01f;
-    const float hy = sqrtf(tau * a * inv) * 1.001f + 0.01f;
-    const float dx0 = bx0 - u, dx1 = bx1 - u, dy0 = by0 - v, dy1 = by1 - v;  // block relative to the centre
-    const float ddx = fmaxf(fmaxf(dx0, -dx1), 0.f);
-    const float ddy = fmaxf(fmaxf(dy0, -dy1), 0.f);
-    if (!((ddx <= hx) && (ddy <= hy))) return false;
-    if (ddx == 0.f && ddy == 0.f) return true;  // centre inside the block
-    // minimum of q on the four edges (q is convex: clamp the unconstrained minimiser of each edge line)
-    const float ia = 1.f / a, ic = 1.f / c;
-    float qmin;
-    {
-        const float y0 = fminf(fmaxf(-b * dx0 * ic, dy0), dy1), y1 = fminf(fmaxf(-b * dx1 * ic, dy0), dy1);
-        const float q0 = a * dx0 * dx0 + 2.f * b * dx0 * y0 + c * y0 * y0;
-        const float q1 = a * dx1 * dx1 + 2.f * b * dx1 * y1 + c * y1 * y1;
-        qmin = fminf(q0, q1);
-    }
-    {
-        const float x0 = fminf(fmaxf(-b * dy0 * ia, dx0), dx1), x1 = fminf(fmaxf(-b * dy1 * ia, dx0), dx1);
-        const float q0 = a * x0 * x0 + 2.f * b * x0 * dy0 + c * dy0 * dy0;
-        const float q1 = a * x1 * x1 + 2.f * b * x1 * dy1 + c * dy1 * dy1;
-        qmin = fminf(qmin, fminf(q0, q1));
-    }
-    // q is evaluated with ~1e-6 relative error of its largest term; the terms are bounded by (a+c+2|b|) * r^2
-    const float r2 = fmaxf(dx0 * dx0, dx1 * dx1) + fmaxf(dy0 * dy0, dy1 * dy1);
-    const float qerr = 4e-6f * (a + c + 2.f * fabsf(b)) * r2;
-    return qmin <= tau * 1.002f + qerr + 2e-3f;
 }
 
 // ---- staging area of one super-batch (shared by the four waves of a tile): SB packed records,
@@ -175,6 +199,7 @@ template <int CH, int SB>
 struct TileLDS {
     static constexpr int RQ = Rec<CH>::RQ;
     float4 rec[(SB + 1) * RQ];
+    unsigned int keep[SB];  // byte w of entry e: wave w's 8x8 block can be reached by the splat (and passes its predicate)
     unsigned short list[4][SB + 16];
     __device__ __forceinline__ const float4 &g0(int e) const { return rec[e * RQ]; }      // u v A B
     __device__ __forceinline__ const float4 &g1(int e) const { return rec[e * RQ + 1]; }  // C o bias id
@@ -232,24 +257,56 @@ struct Stager {
     }
 };
 
-// per-wave cull of the staged super-batch -> private order-preserving survivor list; returns count.
-// pred(e) drops entries before the box test.
+// Cooperative cull of the staged super-batch: thread e tests entry e once against the four 8x8 blocks of the tile
+// (wave w owns block (w & 1, w >> 1)) and records one flag byte per wave.  pred(e, w) drops entries a wave does not
+// need before the geometric test.  Callers put a __syncthreads() between tile_cull and build_list.
 template <int CH, int SB, bool BIAS, typename Pred>
-__device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane, int nb, float bx0, float bx1,
-                                          float by0, float by1, Pred pred, unsigned char *flags = nullptr) {
+__device__ __forceinline__ void tile_cull(TileLDS<CH, SB> &L, int tid, int nb, float tx0, float ty0, Pred pred) {
+    constexpr int TPE = 256 / SB;  // threads per entry (1, 2 or 4): each tests 4 / TPE of the blocks
+    constexpr int BPT = 4 / TPE;
+    static_assert(SB == 64 || SB == 128 || SB == 256, "super-batch sizes the 256-thread cull supports");
+    const int e = tid & (SB - 1), part = tid / SB;
+    unsigned char *flags = reinterpret_cast<unsigned char *>(L.keep) + 4 * e + BPT * part;
+    bool k[BPT];
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) k[j] = false;
+    if (e < nb) {
+        if (BIAS) {  // the opacity bias lifts alpha everywhere: no geometric cull
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) k[j] = pred(e, BPT * part + j);
+        } else {
+            const float4 a0 = L.g0(e), a1 = L.g1(e);
+            CullP cp;
+            if (Rec<CH>::CULL >= 0) {
+                constexpr int CO = Rec<CH>::CULL >= 0 ? Rec<CH>::CULL : 0;
+                const float *r = reinterpret_cast<const float *>(&L.rec[e * Rec<CH>::RQ]);
+                cp.hx = r[CO]; cp.hy = r[CO + 1]; cp.tauq = r[CO + 2]; cp.ia = r[CO + 3]; cp.ic = r[CO + 4];
+            } else {
+                cp = cull_params(a0.z, a0.w, a1.x, a1.y);
+            }
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) {
+                const int ww = BPT * part + j;
+                const float x0 = tx0 + (float)(8 * (ww & 1)), y0 = ty0 + (float)(8 * (ww >> 1));
+                k[j] = pred(e, ww) && cull_test(a0.x, a0.y, a0.z, a0.w, a1.x, cp, x0, x0 + 7.f, y0, y0 + 7.f);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) flags[j] = k[j] ? 1 : 0;
+}
+
+// wave w's order-preserving survivor list from the flag bytes; returns the count.
+template <int CH, int SB>
+__device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane) {
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < SB / WAVE; ++r) {
         const int e = r * WAVE + lane;
-        bool keep = (e < nb) && pred(e);
-        if (keep && !BIAS) {
-            const float4 a0 = L.g0(e), a1 = L.g1(e);
-            keep = splat_touches(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, bx0, bx1, by0, by1);
-        }
+        const bool keep = (L.keep[e] >> (8 * w)) & 1u;
         const unsigned long long m = __ballot(keep);
         if (keep) L.list[w][cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
         cnt += __popcll(m);
-        if (flags) flags[4 * e] = keep ? 1 : 0;  // which entries of the super-batch this wave will write (byte per wave)
     }
     if (lane < 16) L.list[w][cnt + lane] = (unsigned short)SB;  // pad: the unrolled loops read slot SB (inert record)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -276,7 +333,6 @@ blend_fwd_kernel(const BlendArgs A) {
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const int px = bx + (lane & 7), py = by + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
-    const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
     const int cn = EXACT ? CH : A.cn;
 
     const bool inside = (px < A.W) && (py < A.H);
@@ -305,8 +361,10 @@ blend_fwd_kernel(const BlendArgs A) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
         if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;  // every pixel of the tile is saturated
+        tile_cull<CH, SB, BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE), [&](int, int ww) { return !s_done[ww]; });
+        __syncthreads();
         if (!alld) {
-            const int cnt = build_list<CH, SB, BIAS>(L, w, lane, nb, bx0, bx1, by0, by1, [](int) { return true; });
+            const int cnt = build_list<CH, SB>(L, w, lane);
             for (int j0 = 0; j0 < cnt; j0 += U) {
                 int e[U];
                 float4 g0[U], g1[U];
@@ -456,10 +514,10 @@ __device__ __forceinline__ void replay_one(const float4 &g0, const float4 &g1, c
     r[3] = -G * dx * dy * dLG;
     r[4] = -0.5f * G * dy * dy * dLG;
     r[5] = G * dLa;
-    if (ABS) {
+    if constexpr (ABS) {
         r[GL::I_ABS] = fabsf(r[0]); r[GL::I_ABS + 1] = fabsf(r[1]);
     }
-    if (BIAS) {
+    if constexpr (BIAS) {
         r[GL::I_BIAS] = dLa;
         done = T < 0.0001f;
     }
@@ -490,7 +548,6 @@ blend_bwd_pair_kernel(const BlendArgs A) {
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const int px = bx + (lane & 7), py = by + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
-    const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
     const size_t HW = (size_t)A.H * A.W;
     const int cn = EXACT ? CH : A.cn;
 
@@ -537,8 +594,10 @@ blend_bwd_pair_kernel(const BlendArgs A) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
 
-        const int cnt = build_list<CH, SB, BIAS>(L, w, lane, nb, bx0, bx1, by0, by1,
-                                                 [=](int e) { return top - e < wmax; });
+        tile_cull<CH, SB, BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+                                [&](int e, int ww) { return top - e < s_wmax[ww]; });
+        __syncthreads();
+        const int cnt = build_list<CH, SB>(L, w, lane);
         unsigned long long wrote = 0ull;
         float *slab = s_acc[w];
         for (int j0 = 0; j0 < cnt; j0 += U) {
@@ -745,7 +804,6 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
     constexpr float L2E = 1.4426950408889634f;
     __shared__ TileLDS<CH, SB> L;
     __shared__ float s_acc[4][SB * NC];      // private slab per wave
-    __shared__ unsigned int s_wr[SB];        // byte w of entry e: wave w wrote its slab record
     __shared__ __attribute__((aligned(16))) float s_pix[4][64 * PW];
     __shared__ float s_mom[16 * 64];         // A operand of the moment product: [step 4 G + i][lane]
     __shared__ int s_wmax[4];
@@ -753,7 +811,7 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
     const int tile = blockIdx.x;
     const int tx = tile % A.gx, ty = tile / A.gx;
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
-    const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+    const float bx0 = (float)bx, by0 = (float)by;
     const int cn = EXACT ? CH : A.cn;
     const int nl = lane & 15, kk = lane >> 4;
     int wmax;
@@ -843,9 +901,10 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
 
-        const int cnt = build_list<CH, SB, false>(L, w, lane, nb, bx0, bx1, by0, by1,
-                                                  [=](int e) { return top - e < wmax; },
-                                                  reinterpret_cast<unsigned char *>(s_wr) + w);
+        tile_cull<CH, SB, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+                                 [&](int e, int ww) { return top - e < s_wmax[ww]; });
+        __syncthreads();
+        const int cnt = build_list<CH, SB>(L, w, lane);  // every survivor gets a slab record: keep flags = written flags
         float *slab = s_acc[w];
         for (int j0 = 0; j0 < cnt; j0 += 16) {
             const int e = L.list[w][j0 + nl];  // ascending e = back to front; slot SB (inert) past the end
@@ -966,7 +1025,7 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
                 const int e = nb - 1 - ql;
                 float v = 0.f;
                 if (c < NC) {
-                    const unsigned int fl = s_wr[e];
+                    const unsigned int fl = L.keep[e];
 #pragma unroll
                     for (int ww = 0; ww < 4; ++ww) {
                         const float x = s_acc[ww][e * NC + c];
@@ -977,200 +1036,6 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
             }
         }
         __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------ forward, matrix-core version (plain blending)
-// Same idea as the matrix-core backward, transposed: lane (p = lane & 15, g = lane >> 4) owns pixel p of the
-// current 2x8 strip and, per 16-survivor chunk (front to back), the four consecutive splats 4g..4g+3:
-//   power[n,p]  = q(n) . phi(p)             MFMA, K = 6 monomials -> D rows = splats, columns = pixels
-//   T chain     = in-register products over the lane's 4 splats + a two-step exchange across the 4 lane groups
-//   out[c,p]   += f[n,c] w[n,p]             MFMA, K = splats; the accumulators stay in registers for the whole tile
-// Early termination (reference: src/alpha_blending.cu:79-113): a pixel stops at the first valid splat that would
-// push T below 1e-4.  T is non-increasing, so with Ti = T after splat i (all valid splats multiplied in) the applied
-// splats are exactly {valid, Ti >= 1e-4}; the pixel state keeps T of the last applied splat, negated once stopped.
-// value of lane ^ 16 / lane ^ 32 without an LDS round trip (gfx950 v_permlane{16,32}_swap: exchange the odd 16-lane
-// rows of the first operand with the even rows of the second / rows 2,3 with rows 0,1)
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float xchg16(float v, bool odd_row) {
-    const unsigned x = __builtin_bit_cast(unsigned, v);
-    const u32x2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r[0] rows: x0 x0 x2 x2, r[1]: x1 x1 x3 x3
-    return __builtin_bit_cast(float, odd_row ? r[0] : r[1]);
-}
-__device__ __forceinline__ float xchg32(float v, bool upper_half) {
-    const unsigned x = __builtin_bit_cast(unsigned, v);
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r[0] rows: x0 x1 x0 x1, r[1]: x2 x3 x2 x3
-    return __builtin_bit_cast(float, upper_half ? r[0] : r[1]);
-}
-
-template <int CH>
-struct FwdMfmaCfg {
-    static constexpr int SB = CH <= 8 ? 256 : 128;
-    static constexpr int NA = (CH + 15) / 16;  // output accumulators per strip (16 channels each)
-};
-
-template <int CH, bool EXACT>
-__global__ void __launch_bounds__(256, BLEND_FWDM_MINW)
-blend_fwd_mfma_kernel(const BlendArgs A) {
-    using Cfg = FwdMfmaCfg<CH>;
-    constexpr int SB = Cfg::SB, NA = Cfg::NA, RQ = Rec<CH>::RQ;
-    constexpr float L2E = 1.4426950408889634f;
-    constexpr float T_BIG = 4.f;
-    __shared__ TileLDS<CH, SB> L;
-    __shared__ int s_done[4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tile = blockIdx.x;
-    const int tx = tile % A.gx, ty = tile / A.gx;
-    const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
-    const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
-    const int cn = EXACT ? CH : A.cn;
-    const int pl = lane & 15, g = lane >> 4;
-
-    // B operand of the power product, B[k = g][n = pixel pl of strip G]: monomials 1 x y xx | xy yy 0 0 of the
-    // block-centred pixel coordinates (identical values and K order as the backward: bitwise the same powers)
-    float phi1[4], phi2[4];
-    float Tst[4];   // per strip: T of the lane's pixel after the last applied splat; negative once the pixel stopped
-    int lastL[4];   // per strip: last applied list position + 1 among THIS lane's splats (reduced over g at the end)
-    f32x4 acc[4][NA];
-#pragma unroll
-    for (int G = 0; G < 4; ++G) {
-        const int q = 16 * G + pl;
-        const float x = (float)(q & 7) - 3.5f, y = (float)(q >> 3) - 3.5f;
-        phi1[G] = g == 0 ? 1.f : g == 1 ? x : g == 2 ? y : x * x;
-        phi2[G] = g == 0 ? x * y : g == 1 ? y * y : 0.f;
-        const bool inside = (bx + (q & 7) < A.W) && (by + (q >> 3) < A.H);
-        Tst[G] = inside ? 1.f : -1.f;
-        lastL[G] = 0;
-#pragma unroll
-        for (int a = 0; a < NA; ++a) acc[G][a] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const int2 range = A.tile_range[tile];
-    const int n = range.y - range.x;
-
-    if (tid < RQ) L.rec[SB * RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
-    auto pos = [n](int e, int b) { const int q = b * SB + e; return q < n ? q : -1; };  // forward walk
-    Stager<CH, SB> st;
-    st.load_ids(A, tid, range.x, pos, 0);
-    st.load_payload(A, tid);
-    st.load_ids(A, tid, range.x, pos, 1);
-
-    for (int base = 0, batch = 0; base < n; base += SB, ++batch) {
-        const bool alld = !__any((Tst[0] > 0.f) || (Tst[1] > 0.f) || (Tst[2] > 0.f) || (Tst[3] > 0.f));
-        if (lane == 0) s_done[w] = alld;
-        const int nb = imin_(SB, n - base);
-        st.park(L, tid);
-        st.load_payload(A, tid);                       // payload of the next super-batch
-        st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
-        __syncthreads();
-        if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;  // every pixel of the tile is saturated
-        if (!alld) {
-            const int cnt = build_list<CH, SB, false>(L, w, lane, nb, bx0, bx1, by0, by1, [](int) { return true; });
-            for (int j0 = 0; j0 < cnt; j0 += 16) {
-                // ---- coefficient role: lane (s = pl, k = g) supplies coefficient k of survivor j0 + pl (x log2 e)
-                float aq1, aq2;
-                {
-                    const int ec = L.list[w][j0 + pl];
-                    const float4 g0 = L.g0(ec), g1 = L.g1(ec);
-                    const float cA = g0.z, cB = g0.w, cC = g1.x;
-                    const float uc = g0.x - bx0 - 3.5f, vc = g0.y - by0 - 3.5f;
-                    const float q0 = L2E * (-0.5f * (cA * uc * uc + cC * vc * vc) - cB * uc * vc);
-                    const float qx = L2E * (cA * uc + cB * vc), qy = L2E * (cB * uc + cC * vc);
-                    const float qxx = -0.5f * L2E * cA, qxy = -L2E * cB, qyy = -0.5f * L2E * cC;
-                    aq1 = g == 0 ? q0 : g == 1 ? qx : g == 2 ? qy : qxx;
-                    aq2 = g == 0 ? qxy : g == 1 ? qyy : 0.f;
-                }
-                // ---- pixel role: the lane's four splats 4g..4g+3 of the chunk
-                float op[4], fa[NA][4];
-                int qpos[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = L.list[w][j0 + 4 * g + i];  // slot SB (inert: opacity 0) past the end of the list
-                    op[i] = L.g1(e).y;
-                    qpos[i] = base + e + 1;
-                    const float *fr = reinterpret_cast<const float *>(&L.rec[e * RQ + 2]);
-#pragma unroll
-                    for (int a = 0; a < NA; ++a) {
-                        const int c = 16 * a + pl;  // channel row this lane feeds to the output product
-                        const float v = fr[c < CH ? c : 0];
-                        fa[a][i] = c < CH ? v : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int G = 0; G < 4; ++G) {
-                    f32x4 pw = {0.f, 0.f, 0.f, 0.f};
-                    pw = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1, phi1[G], pw, 0, 0, 0);
-                    pw = __builtin_amdgcn_mfma_f32_16x16x4f32(aq2, phi2[G], pw, 0, 0, 0);
-                    const bool active = Tst[G] > 0.f;
-                    float a[4], om[4];
-                    bool valid[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float alpha = fminf(0.99f, op[i] * __builtin_amdgcn_exp2f(pw[i]));
-                        valid[i] = active && !(pw[i] > BLEND_PW_MAX) && !(alpha < (1.0f / 255.0f));
-                        a[i] = valid[i] ? alpha : 0.f;
-                        om[i] = 1.f - a[i];
-                    }
-                    const float c1 = om[0], c2 = c1 * om[1], c3 = c2 * om[2], c4 = c3 * om[3];
-                    // products of the other lane groups: xor-16 / xor-32 butterfly gives total and exclusive prefix
-                    const float t1 = xchg16(c4, g & 1);
-                    const float t2 = xchg32(c4 * t1, g & 2);
-                    const float excl = ((g & 1) ? t1 : 1.f) * ((g & 2) ? t2 : 1.f);
-                    const float Tb0 = fabsf(Tst[G]) * excl;  // T in front of the lane's first splat
-                    const float Tb[4] = {Tb0, Tb0 * c1, Tb0 * c2, Tb0 * c3};
-                    const float Ti[4] = {Tb[1], Tb[2], Tb[3], Tb0 * c4};
-                    float tmin = T_BIG;
-                    int lst = 0;
-                    bool stop = false;
-                    float wv[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const bool app = valid[i] && (Ti[i] >= 0.0001f);
-                        stop = stop || (valid[i] && !app);
-                        wv[i] = app ? a[i] * Tb[i] : 0.f;
-                        tmin = app ? Ti[i] : tmin;  // Ti is non-increasing: the last applied one is the smallest
-                        lst = app ? qpos[i] : lst;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int q = 0; q < NA; ++q)
-                            acc[G][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q][i], wv[i], acc[G][q], 0, 0, 0);
-                    lastL[G] = imax_(lastL[G], lst);
-                    // pixel state: smallest applied Ti over the four lane groups; stopped if any group saw a stop
-                    float kmin = fminf(tmin, xchg16(tmin, g & 1));
-                    kmin = fminf(kmin, xchg32(kmin, g & 2));
-                    const unsigned long long sb = __ballot(stop);
-                    const bool stopped = ((sb >> pl) & 0x0001000100010001ull) != 0ull;
-                    const float Tn = fminf(fabsf(Tst[G]), kmin);
-                    Tst[G] = (active && !stopped) ? Tn : -Tn;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- write back: lane (p, g) holds channels 4g..4g+3 of pixel p of every strip
-    const size_t HW = (size_t)A.H * A.W;
-#pragma unroll
-    for (int G = 0; G < 4; ++G) {
-        const int q = 16 * G + pl;
-        const int px = bx + (q & 7), py = by + (q >> 3);
-        int last = imax_(lastL[G], __float_as_int(xchg16(__int_as_float(lastL[G]), g & 1)));
-        last = imax_(last, __float_as_int(xchg32(__int_as_float(last), g & 2)));
-        if (px < A.W && py < A.H) {
-            const size_t pix = (size_t)A.W * (size_t)py + px;
-            const float T = fabsf(Tst[G]);
-            if (g == 0) {
-                A.final_T[pix] = T;
-                A.ncontrib[pix] = last;
-            }
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = 16 * a + 4 * g + i;
-                    if (c < cn) A.out[(size_t)(A.c0 + c) * HW + pix] = acc[G][a][i] + T * A.bg;
-                }
-        }
     }
 }
 
@@ -1190,7 +1055,6 @@ blend_bwd_atomic_kernel(const BlendArgs A) {
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const int px = bx + (lane & 7), py = by + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
-    const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
     const size_t HW = (size_t)A.H * A.W;
     const int cn = EXACT ? CH : A.cn;
 
@@ -1227,8 +1091,10 @@ blend_bwd_atomic_kernel(const BlendArgs A) {
         st.load_payload(A, tid);
         st.load_ids(A, tid, range.x, pos, batch + 2);
         __syncthreads();
-        const int cnt = build_list<CH, SB, BIAS>(L, w, lane, nb, bx0, bx1, by0, by1,
-                                                 [=](int e) { return top - e < wmax; });
+        tile_cull<CH, SB, BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+                                [&](int e, int ww) { return top - e < s_wmax[ww]; });
+        __syncthreads();
+        const int cnt = build_list<CH, SB>(L, w, lane);
         for (int j = 0; j < cnt; ++j) {
             const int e = L.list[w][j];
             const float4 g0 = L.g0(e), g1 = L.g1(e);
@@ -1282,15 +1148,6 @@ static int launch_pack(const BlendArgs &A, bool bias, hipStream_t s) {
     return SPLAT_OK;
 }
 
-// SPLAT_FWD_KERNEL=valu selects the per-pixel-lane forward kernel (A/B measurements); default: matrix cores
-static bool fwd_use_mfma() {
-    static const int v = [] {
-        const char *e = getenv("SPLAT_FWD_KERNEL");
-        return (e && strcmp(e, "valu") == 0) ? 0 : 1;
-    }();
-    return v != 0;
-}
-
 template <int CH>
 static int launch_fwd(const BlendArgs &A, int T, bool enh, bool bias, hipStream_t s) {
     const dim3 grid((unsigned)T), block(256);
@@ -1300,10 +1157,7 @@ static int launch_fwd(const BlendArgs &A, int T, bool enh, bool bias, hipStream_
         if (rc != SPLAT_OK) return rc;
     }
 #define FWD(E, B, X) SPLAT_LAUNCH("blend_fwd", (blend_fwd_kernel<CH, E, B, X>), grid, block, 0, s, A)
-    if (!enh && !bias && fwd_use_mfma()) {
-        if (exact) SPLAT_LAUNCH("blend_fwd", (blend_fwd_mfma_kernel<CH, true>), grid, block, 0, s, A);
-        else SPLAT_LAUNCH("blend_fwd", (blend_fwd_mfma_kernel<CH, false>), grid, block, 0, s, A);
-    } else if (enh) {
+    if (enh) {
         if (bias) { if (exact) FWD(true, true, true); else FWD(true, true, false); }
         else { if (exact) FWD(true, false, true); else FWD(true, false, false); }
     } else {
