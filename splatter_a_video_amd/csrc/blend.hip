@@ -868,10 +868,11 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
     const int len = range.y - range.x;
     const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
     const int *slots = A.slot_sorted + range.x;
-    for (int i = n * NCP + tid; i < len * NCP; i += 256) {  // entries nobody replays: zero record
-        const int ql = i / NCP;
-        A.pair_buf[(size_t)slots[ql] * NCP + (i - ql * NCP)] = 0.f;
-    }
+    constexpr int EPI = 256 / NC;                   // pair records the 256 threads write per pass, NC floats each
+    const int ce = tid / NC, cc = tid - ce * NC;    // this thread's (entry within the pass, component)
+    if (ce < EPI)
+        for (int ql = n + ce; ql < len; ql += EPI)  // entries nobody replays: zero record
+            A.pair_buf[(size_t)slots[ql] * NCP + cc] = 0.f;
     if (n <= 0) return;
 
     // ---- per-lane addressing: pixel (G, kk, i) is q = 16 G + 4 kk + i
@@ -1017,22 +1018,20 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
             }
         }
         __syncthreads();
-        // ---- combine the four slabs; each record (NCP floats = whole 64-B sectors) goes to its pair slot
-        {
+        // ---- combine the four slabs: thread (ce, cc) sums component cc of every EPI-th entry and stores it at the
+        //      entry's pair slot (the NCP - NC pad floats of a record are never written; pair_reduce ignores them)
+        if (ce < EPI) {
             const int lo = top - nb + 1;
-            for (int i = tid; i < nb * NCP; i += 256) {
-                const int ql = i / NCP, c = i - ql * NCP;
+            for (int ql = ce; ql < nb; ql += EPI) {
                 const int e = nb - 1 - ql;
+                const unsigned int fl = L.keep[e];
                 float v = 0.f;
-                if (c < NC) {
-                    const unsigned int fl = L.keep[e];
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) {
-                        const float x = s_acc[ww][e * NC + c];
-                        v += ((fl >> (8 * ww)) & 1u) ? x : 0.f;
-                    }
+                for (int ww = 0; ww < 4; ++ww) {
+                    const float x = s_acc[ww][e * NC + cc];
+                    v += ((fl >> (8 * ww)) & 1u) ? x : 0.f;
                 }
-                A.pair_buf[(size_t)slots[lo + ql] * NCP + c] = v;
+                A.pair_buf[(size_t)slots[lo + ql] * NCP + cc] = v;
             }
         }
         __syncthreads();
