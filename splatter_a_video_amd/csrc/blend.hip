@@ -782,6 +782,18 @@ __device__ __forceinline__ void row_scan_add4(float &a, float &b, float &c, floa
                      SCAN4("v_add_f32_dpp", "8")
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+// two floats to LDS from the last lane of every 16-lane row (EXEC is all ones in the callers: full waves, uniform flow)
+__device__ __forceinline__ void lds_store2_lane15(float *p, float a, float b) {
+    const unsigned addr = (unsigned)(size_t)p;  // LDS byte address = low 32 bits of the generic shared pointer
+    asm volatile(
+        "s_mov_b64 exec, %3\n\t"
+        "ds_write2_b32 %0, %1, %2 offset1:1\n\t"
+        "s_mov_b64 exec, -1"
+        :
+        : "v"(addr), "v"(a), "v"(b), "s"(0x8000800080008000ull)
+        : "memory");
+}
+
 // R[i] = base[i] + (rs[i] of the previous lane of the row; 0 for lane 0): exclusive scan from the inclusive one
 __device__ __forceinline__ void row_shr1_add4(float (&R)[4], const float (&rs)[4], const float (&base)[4]) {
     asm volatile(
@@ -966,11 +978,11 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
                 }
                 row_scan_add4(rs[0], rs[1], rs[2], rs[3]);
                 row_shr1_add4(R, rs, Rs4);  // R = R_state + colour of the deeper splats of this chunk
-                if (nl == 15) {             // the row's last lane holds the new state of its pixel
+                // the row's last lane holds the new state of its pixel: store from lanes 15/31/47/63 only, without a
+                // branch (the chunk stays one basic block, so the four strips' instruction streams interleave)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        *reinterpret_cast<float2 *>(pixrow + (16 * G + i) * PW + PS + 2) = make_float2(T[i], Rs4[i] + rs[i]);
-                }
+                for (int i = 0; i < 4; ++i)
+                    lds_store2_lane15(pixrow + (16 * G + i) * PW + PS + 2, T[i], Rs4[i] + rs[i]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int s = 4 * G + i;

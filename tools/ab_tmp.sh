@@ -2,5 +2,4 @@ cd $GRAFT_REPO_ROOT
 export PYTHONPATH=.
 run() { timeout 100 python tools/blend_bench.py "$@" < /dev/null 2>&1 | grep "^\[" ; }
 echo base; run
-echo dpp; SPLAT_BWD_KERNEL=dpp run
 timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_renderer_flow.py tests/test_gpu_golden.py -x -q < /dev/null 2>&1 | tail -25
