@@ -165,6 +165,24 @@ int splat_dynamic_eval_backward(int P, int I, int seg, float d, const float *bas
                                 const float *g_scl, int accumulate, int cubic_layout, float *d_position, float *d_cubic,
                                 float *d_rotation, float *d_opacity, float *d_scaling, splat_stream_t stream);
 
+/* ---- fused per-frame preprocess of the orthographic renderer (rows a2 + a5 + a3 in one pass) -------------------
+ * Replaces, per rendered frame, the eager-torch orthographic projection and EWA of the reference renderer plus its
+ * compute_cov3d call (src/pointrix/renderer/dptr_ortho_enhanced.py:145-202 project_point, :282-310 call sites,
+ * :18-111 ewa_project_torch_impl): pos = xyz (+ offset, may be NULL) -> uv, depth ; visible = depth != 0 ;
+ * cov3d(scales, uquats) ; conic, radius, tiles.  Same results as splat_project_point_forward(ortho) +
+ * splat_compute_cov3d_forward + splat_ewa_project_forward(ortho) on the same inputs; visible and cov3d are not
+ * materialised.  backward: dL_dxyz from dL_duv / dL_ddepth (NULL = 0), dL_dscales / dL_duquats from dL_dconic;
+ * any output may be NULL; accumulate=1 adds into the outputs (gradient-bucket use), 0 stores (every element). */
+int splat_preprocess_ortho_forward(int P, const float *xyz, const float *offset, const float *scales,
+                                   const float *uquats, const float *extr, int W, int H, float nearest, float extent,
+                                   float *uv, float *depth, float *conic, int32_t *radius, int32_t *tiles,
+                                   splat_stream_t stream);
+int splat_preprocess_ortho_backward(int P, const float *xyz, const float *offset, const float *scales,
+                                    const float *uquats, const float *extr, int W, int H, const float *depth,
+                                    const int32_t *radius, const float *dL_duv, const float *dL_ddepth,
+                                    const float *dL_dconic, int accumulate, float *dL_dxyz, float *dL_dscales,
+                                    float *dL_duquats, splat_stream_t stream);
+
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */
 void splat_profile_enable(int on);
 void splat_profile_reset(void);

@@ -3,32 +3,10 @@
 // blocks; HBM-bound (24..250 B per point).  Semantics follow the reference kernels cited in
 // include/splat_hip.h; the arithmetic mirrors oracle/splat_oracle.c.
 #include "common.h"
+#include "pointwise_dev.h"
 
 #define PW_BLOCK 256
 static inline dim3 pw_grid(int P) { return dim3((unsigned)((P + PW_BLOCK - 1) / PW_BLOCK)); }
-
-struct Cam {
-    float e[12];  // extr rows
-    float fx, fy, cx, cy;
-};
-
-
-// camera constants are read once per thread from global (L2/K$ resident, 16 floats)
-__device__ __forceinline__ void load_cam(const float *intr, const float *extr, Cam &c) {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) c.e[k] = extr[k];
-    if (intr) {
-        c.fx = intr[0]; c.fy = intr[1]; c.cx = intr[2]; c.cy = intr[3];
-    } else {
-        c.fx = c.fy = c.cx = c.cy = 0.f;
-    }
-}
-
-__device__ __forceinline__ void cam_xform(const Cam &c, float x, float y, float z, float &tx, float &ty, float &tz) {
-    tx = c.e[0] * x + c.e[1] * y + c.e[2] * z + c.e[3];
-    ty = c.e[4] * x + c.e[5] * y + c.e[6] * z + c.e[7];
-    tz = c.e[8] * x + c.e[9] * y + c.e[10] * z + c.e[11];
-}
 
 // ------------------------------------------------------------------ project_point
 // reference: src/project_point.cu:13-57 ; ortho: dptr_ortho_enhanced.py:177-202
@@ -47,14 +25,7 @@ project_point_fwd_kernel(int P, const float *__restrict__ xyz, const float *__re
     float u, v, d;
     bool cull = false;
     if (ORTHO) {
-        u = ((tx + 1.f) * (float)W) / 2.f - 0.5f;
-        v = ((ty + 1.f) * (float)H) / 2.f - 0.5f;
-        d = tz;
-        if (isnan(d)) d = 0.f;
-        else if (isinf(d)) d = d > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
-        const float xlo = (float)((1.0 - (double)extent) * W * 0.5), xhi = (float)((1.0 + (double)extent) * W * 0.5);
-        const float ylo = (float)((1.0 - (double)extent) * H * 0.5), yhi = (float)((1.0 + (double)extent) * H * 0.5);
-        cull = (d <= nearest) || (u < xlo) || (u > xhi) || (v < ylo) || (v > yhi);
+        cull = project_ortho_pt(c, x, y, z, W, H, nearest, extent, u, v, d);
     } else {
         const float inv = (float)(1.0 / ((double)tz + 1e-7));
         u = (float)((double)(c.fx * tx * inv + c.cx) - 0.5);
@@ -89,9 +60,10 @@ project_point_bwd_kernel(int P, const float *__restrict__ xyz, const float *__re
         load_cam(ORTHO ? nullptr : intr, extr, c);
         const float gu = dL_duv[2 * i], gv = dL_duv[2 * i + 1], gd = dL_ddepth[i];
         if (ORTHO) {
-            const float gx = gu * ((float)W / 2.f), gy = gv * ((float)H / 2.f);
+            float g[3];
+            project_ortho_grad_pt(c, W, H, gu, gv, gd, g);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) dL_dxyz[3 * i + j] = c.e[j] * gx + c.e[4 + j] * gy + c.e[8 + j] * gd;
+            for (int j = 0; j < 3; ++j) dL_dxyz[3 * i + j] = g[j];
         } else {
             const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
             float tx, ty, tz;
@@ -135,13 +107,6 @@ project_point_bwd_kernel(int P, const float *__restrict__ xyz, const float *__re
 }
 
 // ------------------------------------------------------------------ compute_cov3d
-__device__ __forceinline__ void quat_R(const float *q, float R[3][3]) {
-    const float r = q[0], x = q[1], y = q[2], z = q[3];
-    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
-    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
-    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
-}
-
 // reference: src/compute_cov3d.cu:14-58,119-129
 __global__ void __launch_bounds__(PW_BLOCK)
 cov3d_fwd_kernel(int P, const float *__restrict__ scales, const float4 *__restrict__ uquats,
@@ -157,17 +122,10 @@ cov3d_fwd_kernel(int P, const float *__restrict__ scales, const float4 *__restri
     const float4 q4 = uquats[i];
     const float q[4] = {q4.x, q4.y, q4.z, q4.w};
     const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
-    float R[3][3], M[3][3];
-    quat_R(q, R);
+    float c6[6];
+    cov3d_pt(s, q, c6);
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) M[k][j] = s[k] * R[j][k];
-    int n = 0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = a; b < 3; ++b) o[n++] = M[0][a] * M[0][b] + M[1][a] * M[1][b] + M[2][a] * M[2][b];
+    for (int k = 0; k < 6; ++k) o[k] = c6[k];
 }
 
 // reference: src/compute_cov3d.cu:60-117,131-147
@@ -185,69 +143,16 @@ cov3d_bwd_kernel(int P, const float *__restrict__ scales, const float4 *__restri
     const float4 q4 = uquats[i];
     const float q[4] = {q4.x, q4.y, q4.z, q4.w};
     const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
-    const float *g = dL_dcov3d + 6 * (size_t)i;
-    float R[3][3], M[3][3];
-    quat_R(q, R);
+    float g[6], ds[3], dq[4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 6; ++k) g[k] = dL_dcov3d[6 * (size_t)i + k];
+    cov3d_grad_pt(s, q, g, ds, dq);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) M[k][j] = s[k] * R[j][k];
-    const float G[3][3] = {{g[0], 0.5f * g[1], 0.5f * g[2]}, {0.5f * g[1], g[3], 0.5f * g[4]}, {0.5f * g[2], 0.5f * g[4], g[5]}};
-    float dM[3][3], D[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) dM[a][b] = 2.0f * (M[a][0] * G[0][b] + M[a][1] * G[1][b] + M[a][2] * G[2][b]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) dL_dscales[3 * i + k] = R[0][k] * dM[k][0] + R[1][k] * dM[k][1] + R[2][k] * dM[k][2];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) D[a][b] = s[a] * dM[a][b];
-    const float r = q[0], x = q[1], y = q[2], z = q[3];
-    float4 o;
-    o.x = 2 * z * (D[0][1] - D[1][0]) + 2 * y * (D[2][0] - D[0][2]) + 2 * x * (D[1][2] - D[2][1]);
-    o.y = 2 * y * (D[1][0] + D[0][1]) + 2 * z * (D[2][0] + D[0][2]) + 2 * r * (D[1][2] - D[2][1]) - 4 * x * (D[2][2] + D[1][1]);
-    o.z = 2 * x * (D[1][0] + D[0][1]) + 2 * r * (D[2][0] - D[0][2]) + 2 * z * (D[1][2] + D[2][1]) - 4 * y * (D[2][2] + D[0][0]);
-    o.w = 2 * r * (D[0][1] - D[1][0]) + 2 * x * (D[2][0] + D[0][2]) + 2 * y * (D[1][2] + D[2][1]) - 4 * z * (D[1][1] + D[0][0]);
-    dL_duquats[i] = o;
+    for (int k = 0; k < 3; ++k) dL_dscales[3 * i + k] = ds[k];
+    dL_duquats[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
 }
 
 // ------------------------------------------------------------------ ewa_project
-template <bool ORTHO>
-__device__ __forceinline__ void ewa_T(const Cam &c, const float p[3], int W, int H, float a[3], float b[3],
-                                      float t[3], float Jm[4]) {
-    cam_xform(c, p[0], p[1], p[2], t[0], t[1], t[2]);
-    float J00, J11, J02, J12;
-    if (ORTHO) {
-        J00 = (float)W / 2.f; J11 = (float)H / 2.f; J02 = 0.f; J12 = 0.f;
-    } else {
-        J00 = c.fx / t[2]; J11 = c.fy / t[2];
-        J02 = -(c.fx * t[0]) / (t[2] * t[2]);
-        J12 = -(c.fy * t[1]) / (t[2] * t[2]);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        a[k] = J00 * c.e[k] + 0.0f * c.e[4 + k] + J02 * c.e[8 + k];
-        b[k] = 0.0f * c.e[k] + J11 * c.e[4 + k] + J12 * c.e[8 + k];
-    }
-    Jm[0] = J00; Jm[1] = J11; Jm[2] = J02; Jm[3] = J12;
-}
-
-template <bool ORTHO>
-__device__ __forceinline__ void ewa_cov2d(const float a[3], const float b[3], const float c3[6], float cov[3]) {
-    const float S[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
-    float Xa[3], Xb[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        Xa[c] = a[0] * S[0][c] + a[1] * S[1][c] + a[2] * S[2][c];
-        Xb[c] = b[0] * S[0][c] + b[1] * S[1][c] + b[2] * S[2][c];
-    }
-    cov[0] = (Xa[0] * a[0] + Xa[1] * a[1] + Xa[2] * a[2]) + 0.3f;
-    cov[1] = ORTHO ? (Xa[0] * b[0] + Xa[1] * b[1] + Xa[2] * b[2]) : (Xb[0] * a[0] + Xb[1] * a[1] + Xb[2] * a[2]);
-    cov[2] = (Xb[0] * b[0] + Xb[1] * b[1] + Xb[2] * b[2]) + 0.3f;
-}
-
 // reference: src/ewa_project.cu:16-83 ; ortho: dptr_ortho_enhanced.py:18-111
 // Every element of conic / radius / tiles is written (zeros for culled / degenerate splats).
 template <bool ORTHO>
@@ -270,28 +175,7 @@ ewa_fwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ c
         float a[3], b[3], t[3], Jm[4], cov[3];
         ewa_T<ORTHO>(c, p, W, H, a, b, t, Jm);
         ewa_cov2d<ORTHO>(a, b, c3, cov);
-        const float det = cov[0] * cov[2] - cov[1] * cov[1];
-        const bool bad = (det == 0.0f) || (ORTHO && isnan(det));
-        if (!bad) {
-            const float mid = 0.5f * (cov[0] + cov[2]);
-            const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
-            const float l1 = mid + sq, l2 = mid - sq;
-            const int r = (int)ceilf(3.f * sqrtf(fmaxf(l1, l2)));
-            const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-            const float2 q = uv[i];
-            int x0, y0, x1, y1;
-            tile_rect(q.x, q.y, r, gx, gy, x0, y0, x1, y1);
-            if ((x1 - x0) * (y1 - y0) != 0) {
-                if (ORTHO) {
-                    o0 = cov[2] / det; o1 = -cov[1] / det; o2 = cov[0] / det;
-                } else {
-                    const float di = 1.f / det;
-                    o0 = cov[2] * di; o1 = -cov[1] * di; o2 = cov[0] * di;
-                }
-                orad = r;
-                otiles = (y1 - y0) * (x1 - x0);
-            }
-        }
+        ewa_finish_pt<ORTHO>(cov, uv[i], W, H, o0, o1, o2, orad, otiles);
     }
     conic[3 * i] = o0; conic[3 * i + 1] = o1; conic[3 * i + 2] = o2;
     radius[i] = orad;
@@ -324,18 +208,12 @@ ewa_bwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ c
         ewa_cov2d<ORTHO>(a, b, c3, cov);
         const float det = cov[0] * cov[2] - cov[1] * cov[1];
         if (det != 0.0f) {
-            const float nom = 1.0f / (det * det);
-            const float gx_ = dL_dconic[3 * i], gy_ = dL_dconic[3 * i + 1], gz_ = dL_dconic[3 * i + 2];
-            const float dcx = nom * (-cov[2] * cov[2] * gx_ + cov[1] * cov[2] * gy_ + (det - cov[0] * cov[2]) * gz_);
-            const float dcy = nom * (2 * cov[1] * cov[2] * gx_ - (det + 2 * cov[1] * cov[1]) * gy_ + 2 * cov[0] * cov[1] * gz_);
-            const float dcz = nom * ((det - cov[0] * cov[2]) * gx_ + cov[0] * cov[1] * gy_ - cov[0] * cov[0] * gz_);
+            const float g3[3] = {dL_dconic[3 * i], dL_dconic[3 * i + 1], dL_dconic[3 * i + 2]};
+            float dcx, dcy, dcz, o6[6];
+            ewa_grad_cov_pt(a, b, cov, det, g3, dcx, dcy, dcz, o6);
             float *o = dL_dcov3d + 6 * (size_t)i;
-            o[0] = a[0] * a[0] * dcx + a[0] * b[0] * dcy + b[0] * b[0] * dcz;
-            o[1] = 2 * a[0] * a[1] * dcx + (a[0] * b[1] + b[0] * a[1]) * dcy + 2 * b[0] * b[1] * dcz;
-            o[2] = 2 * a[0] * a[2] * dcx + (a[0] * b[2] + b[0] * a[2]) * dcy + 2 * b[0] * b[2] * dcz;
-            o[3] = a[1] * a[1] * dcx + a[1] * b[1] * dcy + b[1] * b[1] * dcz;
-            o[4] = 2 * a[1] * a[2] * dcx + (a[1] * b[2] + b[1] * a[2]) * dcy + 2 * b[1] * b[2] * dcz;
-            o[5] = a[2] * a[2] * dcx + a[2] * b[2] * dcy + b[2] * b[2] * dcz;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = o6[k];
             wrote = true;
             if (!ORTHO) {
                 const float S[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};

@@ -3,6 +3,7 @@
 through the top-level ``dptr`` shim package of this repository."""
 from .point_ops import (compute_cov3d, compute_sh, compute_sh_free, ewa_project, ewa_project_ortho, project_point,
                         project_point_ortho)
+from .fused_ops import preprocess_ortho
 from .raster_ops import (alpha_blending, alpha_blending_enhanced, alpha_blending_with_bias, rasterization,
                          sort_gaussian)
 
@@ -20,4 +21,6 @@ __all__ = [
     # extensions (orthographic camera ops the reference renderer does in eager torch)
     "project_point_ortho",
     "ewa_project_ortho",
+    # fused per-frame operators of the MI355X renderer
+    "preprocess_ortho",
 ]
