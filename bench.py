@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--clip", type=int, default=50, help="frames in the clip (per 8 ranks: 200)")
     ap.add_argument("--channels", type=int, default=0, help="extra feature channels (configs[4]: 32 -> no SH)")
+    ap.add_argument("--ops", action="store_true", help="per-operator chain through autograd instead of the fused frame operators")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -74,8 +75,11 @@ class FrameRenderer:
     """Frame-sharded DP unit: parameters replicated, gradients of all local frames accumulate into
     one flat bucket (views), one all-reduce per step."""
 
-    def __init__(self, sc, device, C_extra=0):
+    def __init__(self, sc, device, C_extra=0, fused=True):
         self.sc = sc
+        self.fused = fused
+        self.capacity = None      # pair capacity of the sync-free sort (learned on the first frame)
+        self.sort_status = []
         self.dev = device
         N = sc.N
         self.W, self.H = sc.W, sc.H
@@ -105,20 +109,36 @@ class FrameRenderer:
         return off
 
     def frame(self, off):
+        """one frame, forward + backward.  ``fused`` path: fused per-frame operators whose backward adds the parameter
+        gradients straight into the flat bucket, sort without a host sync; ``ops`` path: the reference's operator
+        sequence (dptr_ortho_enhanced.py:282-349) through autograd.  Same images, same gradients."""
         p = self.p
         W, H = self.W, self.H
-        pos = p["xyz"] + off
-        feat = gs.compute_sh(p["shs"], 3, self.dirs) if self.use_sh else p["feature"]
-        uv, depth = gs.project_point_ortho(pos, self.extr, W, H, nearest=0.01)
-        visible = depth != 0
-        cov3d = gs.compute_cov3d(p["scale"], p["rotate"], visible)
-        conic, radius, tiles = gs.ewa_project_ortho(pos, cov3d, self.extr, uv, W, H, visible)
-        idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        if self.fused:
+            g = {k: self.bucket.grad(k) for k in self.p}
+            feat = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"]) if self.use_sh else p["feature"]
+            uv, depth, conic, radius, tiles = gs.preprocess_ortho(
+                p["xyz"], p["scale"], p["rotate"], self.extr, W, H, nearest=0.01, offset=off,
+                grad_sink={"xyz": g["xyz"], "scales": g["scale"], "uquats": g["rotate"]})
+            if self.capacity is None:   # first frame: learn the pair count with the synchronising sort
+                idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+                self.capacity = int(idx.numel() * 1.25) + 1024
+            else:
+                idx, tr, st = gs.sort_gaussian_capped(uv, depth, W, H, radius, self.capacity)
+                self.sort_status.append(st)
+        else:
+            pos = p["xyz"] + off
+            feat = gs.compute_sh(p["shs"], 3, self.dirs) if self.use_sh else p["feature"]
+            uv, depth = gs.project_point_ortho(pos, self.extr, W, H, nearest=0.01)
+            visible = depth != 0
+            cov3d = gs.compute_cov3d(p["scale"], p["rotate"], visible)
+            conic, radius, tiles = gs.ewa_project_ortho(pos, cov3d, self.extr, uv, W, H, visible)
+            idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
         # densification tap, as the reference renderers create it (dptr.py:151-162)
         ndc = torch.zeros_like(uv, requires_grad=True)
         img = gs.alpha_blending(uv, conic, p["opacity"], feat, idx, tr, self.sc.bg, W, H, ndc)
         img.backward(self.dL_dout)
-        self.last = dict(M=idx.numel(), T=tr.shape[0])
+        self.last = dict(M=idx.numel() if not self.fused else self.last.get("M", idx.numel()), T=tr.shape[0])
         return img
 
     def step(self, offs, collective=True):
@@ -130,15 +150,28 @@ class FrameRenderer:
         if collective and dist.is_available() and dist.is_initialized():
             self.bucket.all_reduce()
 
+    def check_sorts(self):
+        """after the timed region: every capacity-bounded sort of the run fitted (host sync)"""
+        m = 0
+        for st in self.sort_status:
+            m = max(m, st.check())
+        self.sort_status.clear()
+        if m:
+            self.last["M"] = m
+
 
 def kernel_bytes(name, N, M, HW, C, T, use_sh):
     """Algorithmic HBM bytes of one launch (SURVEY.md 8d bookkeeping, per kernel)."""
     F_in = 192 if use_sh else 0
     table = {
         "sh_fwd": N * (F_in + 12 + 1 + 12 + 3),
-        "sh_bwd": N * (F_in + 12 + 1 + 3 + 12 + F_in + 12),
+        "sh_bwd": N * (F_in + 12 + 1 + 3 + 12 + F_in + 12),   # (+F_in read when it accumulates into the bucket)
         "project_point_fwd": N * (12 + 8 + 4),
         "project_point_bwd": N * (4 + 8 + 4 + 12 + 12),
+        # fused: xyz + offset + scale + quat in; uv, depth, conic, radius, tiles out
+        "preprocess_fwd": N * (12 + 12 + 12 + 16 + 8 + 4 + 12 + 4 + 4),
+        # fused backward: inputs again + depth, radius + dL_duv, dL_ddepth, dL_dconic; read-modify-write of 3 gradients
+        "preprocess_bwd": N * (12 + 12 + 12 + 16 + 4 + 4 + 8 + 4 + 12 + 2 * (12 + 12 + 16)),
         "cov3d_fwd": N * (12 + 16 + 1 + 24),
         "cov3d_bwd": N * (12 + 16 + 1 + 24 + 12 + 16),
         "ewa_fwd": N * (12 + 24 + 8 + 1 + 12 + 4 + 4),
@@ -203,7 +236,7 @@ def main():
 
     clip = max(a.clip, 25 * world)
     sc = make_scene(a.gaussians, a.width, a.height, F=clip, C=a.channels, seed=1234)
-    R = FrameRenderer(sc, dev, a.channels)
+    R = FrameRenderer(sc, dev, a.channels, fused=not a.ops)
     # rank r renders frames {f : f mod world == r} of the step's frame batch
     offs = [R.offsets(((i * world + rank) % clip)) for i in range(a.frames)]
 
@@ -221,6 +254,7 @@ def main():
         R.step(offs)
     sync()
     dt = time.perf_counter() - t0
+    R.check_sorts()   # the sync-free sorts of the timed steps all fitted their capacity (raises otherwise)
     if launched:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -241,8 +275,8 @@ def main():
         R.step(offs, collective=False)  # rank-0 only: must not enter a collective
         torch.cuda.synchronize()
         L.profile_enable(False)
-        names = ["sh_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
-                 "bin_scatter", "tile_sort", "blend_pack", "blend_fwd", "blend_bwd", "pair_reduce", "ewa_bwd", "project_point_bwd",
+        names = ["sh_fwd", "preprocess_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
+                 "bin_scatter", "tile_sort", "blend_pack", "blend_fwd", "blend_bwd", "pair_reduce", "preprocess_bwd", "ewa_bwd", "project_point_bwd",
                  "cov3d_bwd", "sh_bwd"]
         for n in names:
             ms, cnt = L.profile_read(n)
@@ -279,6 +313,7 @@ def main():
                                    + ("SH deg 3 -> RGB" if R.use_sh else f"{a.channels} feature channels"),
                        "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
                        "tile_pairs_M": M, "channels": R.C, "parallelism": f"frame-sharded dp{world}",
+                       "path": "fused frame operators + gradient sinks" if R.fused else "per-operator autograd chain",
                        "grad_bucket_MB": round(R.flat_grad.numel() * 4 / 1e6, 1)},
             "ms_per_frame": round(dt / (a.frames * a.steps) * 1e3, 4),
             "gpu_kernel_ms_per_frame": {"forward": None if fwd_ms is None else round(fwd_ms, 4),

@@ -78,7 +78,9 @@ int splat_compute_sh_forward(int P, const float *shs, int degree, const float *d
                              uint8_t *clamped /*[P,3], NULL when free*/, splat_stream_t stream);
 int splat_compute_sh_backward(int P, const float *shs, int degree, const float *dirs, const uint8_t *visible,
                               const uint8_t *clamped /*NULL when free*/, int free_variant,
-                              const float *dL_dcolors, float *dL_dshs /*rows of (deg+1)^2 triplets written*/,
+                              const float *dL_dcolors,
+                              int accumulate /*1: add into dL_dshs (gradient-bucket use), 0: store*/,
+                              float *dL_dshs /*rows of (deg+1)^2 triplets written*/,
                               float *dL_ddirs /*NULL: direction gradient not needed (skips reading shs)*/,
                               splat_stream_t stream);
 

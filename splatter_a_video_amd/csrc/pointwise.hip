@@ -337,7 +337,7 @@ sh_fwd_kernel(int P, const float *__restrict__ shs, const float *__restrict__ di
 }
 
 // reference: src/compute_sh.cu:82-195
-template <int DEG, bool FREE>
+template <int DEG, bool FREE, bool ACC>
 __global__ void __launch_bounds__(PW_BLOCK)
 sh_bwd_kernel(int P, const float *__restrict__ shs, const float *__restrict__ dirs,
               const uint8_t *__restrict__ visible, const uint8_t *__restrict__ clamped,
@@ -346,9 +346,11 @@ sh_bwd_kernel(int P, const float *__restrict__ shs, const float *__restrict__ di
     const int i = blockIdx.x * PW_BLOCK + threadIdx.x;
     if (i >= P) return;
     if (!visible[i]) {
-        float *oz = dL_dshs + (size_t)i * NB * 3;
+        if (!ACC) {
+            float *oz = dL_dshs + (size_t)i * NB * 3;
 #pragma unroll
-        for (int k = 0; k < NB * 3; ++k) oz[k] = 0.f;
+            for (int k = 0; k < NB * 3; ++k) oz[k] = 0.f;
+        }
         if (dL_ddirs) {
             dL_ddirs[3 * i] = 0.f; dL_ddirs[3 * i + 1] = 0.f; dL_ddirs[3 * i + 2] = 0.f;
         }
@@ -366,9 +368,15 @@ sh_bwd_kernel(int P, const float *__restrict__ shs, const float *__restrict__ di
     float *o = dL_dshs + (size_t)i * NB * 3;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        o[3 * k + 0] = B[k] * g[0];
-        o[3 * k + 1] = B[k] * g[1];
-        o[3 * k + 2] = B[k] * g[2];
+        if (ACC) {  // gradient-bucket use: add to what the earlier frames of the step left there
+            o[3 * k + 0] += B[k] * g[0];
+            o[3 * k + 1] += B[k] * g[1];
+            o[3 * k + 2] += B[k] * g[2];
+        } else {
+            o[3 * k + 0] = B[k] * g[0];
+            o[3 * k + 1] = B[k] * g[1];
+            o[3 * k + 2] = B[k] * g[2];
+        }
     }
     if (!dL_ddirs) return;  // direction gradient not requested: the coefficients are never read
     if (DEG == 0) {
@@ -511,14 +519,14 @@ static int sh_fwd_dispatch(int P, const float *shs, int degree, const float *dir
     return SPLAT_OK;
 }
 
-template <bool FREE>
+template <bool FREE, bool ACC>
 static int sh_bwd_dispatch(int P, const float *shs, int degree, const float *dirs, const uint8_t *visible,
                            const uint8_t *clamped, const float *g, float *dshs, float *ddirs, hipStream_t s) {
     switch (degree) {
-        case 0: SPLAT_LAUNCH("sh_bwd", (sh_bwd_kernel<0, FREE>), pw_grid(P), dim3(PW_BLOCK), 0, s, P, shs, dirs, visible, clamped, g, dshs, ddirs); break;
-        case 1: SPLAT_LAUNCH("sh_bwd", (sh_bwd_kernel<1, FREE>), pw_grid(P), dim3(PW_BLOCK), 0, s, P, shs, dirs, visible, clamped, g, dshs, ddirs); break;
-        case 2: SPLAT_LAUNCH("sh_bwd", (sh_bwd_kernel<2, FREE>), pw_grid(P), dim3(PW_BLOCK), 0, s, P, shs, dirs, visible, clamped, g, dshs, ddirs); break;
-        default: SPLAT_LAUNCH("sh_bwd", (sh_bwd_kernel<3, FREE>), pw_grid(P), dim3(PW_BLOCK), 0, s, P, shs, dirs, visible, clamped, g, dshs, ddirs); break;
+        case 0: SPLAT_LAUNCH("sh_bwd", (sh_bwd_kernel<0, FREE, ACC>), pw_grid(P), dim3(PW_BLOCK), 0, s, P, shs, dirs, visible, clamped, g, dshs, ddirs); break;
+        case 1: SPLAT_LAUNCH("sh_bwd", (sh_bwd_kernel<1, FREE, ACC>), pw_grid(P), dim3(PW_BLOCK), 0, s, P, shs, dirs, visible, clamped, g, dshs, ddirs); break;
+        case 2: SPLAT_LAUNCH("sh_bwd", (sh_bwd_kernel<2, FREE, ACC>), pw_grid(P), dim3(PW_BLOCK), 0, s, P, shs, dirs, visible, clamped, g, dshs, ddirs); break;
+        default: SPLAT_LAUNCH("sh_bwd", (sh_bwd_kernel<3, FREE, ACC>), pw_grid(P), dim3(PW_BLOCK), 0, s, P, shs, dirs, visible, clamped, g, dshs, ddirs); break;
     }
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
@@ -535,10 +543,14 @@ extern "C" int splat_compute_sh_forward(int P, const float *shs, int degree, con
 
 extern "C" int splat_compute_sh_backward(int P, const float *shs, int degree, const float *dirs, const uint8_t *visible,
                                          const uint8_t *clamped, int free_variant, const float *dL_dcolors,
-                                         float *dL_dshs, float *dL_ddirs, splat_stream_t stream) {
+                                         int accumulate, float *dL_dshs, float *dL_ddirs, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && degree >= 0 && degree <= 3, "degree must be 0..3");
     if (P == 0) return SPLAT_OK;
     SPLAT_CHECK_ARG(shs && dirs && visible && dL_dcolors && dL_dshs && (free_variant || clamped), "null pointer");
-    return free_variant ? sh_bwd_dispatch<true>(P, shs, degree, dirs, visible, clamped, dL_dcolors, dL_dshs, dL_ddirs, (hipStream_t)stream)
-                        : sh_bwd_dispatch<false>(P, shs, degree, dirs, visible, clamped, dL_dcolors, dL_dshs, dL_ddirs, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    if (accumulate)
+        return free_variant ? sh_bwd_dispatch<true, true>(P, shs, degree, dirs, visible, clamped, dL_dcolors, dL_dshs, dL_ddirs, s)
+                            : sh_bwd_dispatch<false, true>(P, shs, degree, dirs, visible, clamped, dL_dcolors, dL_dshs, dL_ddirs, s);
+    return free_variant ? sh_bwd_dispatch<true, false>(P, shs, degree, dirs, visible, clamped, dL_dcolors, dL_dshs, dL_ddirs, s)
+                        : sh_bwd_dispatch<false, false>(P, shs, degree, dirs, visible, clamped, dL_dcolors, dL_dshs, dL_ddirs, s);
 }

@@ -3,9 +3,9 @@
 through the top-level ``dptr`` shim package of this repository."""
 from .point_ops import (compute_cov3d, compute_sh, compute_sh_free, ewa_project, ewa_project_ortho, project_point,
                         project_point_ortho)
-from .fused_ops import preprocess_ortho
-from .raster_ops import (alpha_blending, alpha_blending_enhanced, alpha_blending_with_bias, rasterization,
-                         sort_gaussian)
+from .fused_ops import compute_sh_into, preprocess_ortho
+from .raster_ops import (SortStatus, alpha_blending, alpha_blending_enhanced, alpha_blending_with_bias, rasterization,
+                         sort_gaussian, sort_gaussian_capped)
 
 __all__ = [
     "project_point",
@@ -23,4 +23,7 @@ __all__ = [
     "ewa_project_ortho",
     # fused per-frame operators of the MI355X renderer
     "preprocess_ortho",
+    "compute_sh_into",
+    "sort_gaussian_capped",
+    "SortStatus",
 ]

@@ -17,7 +17,7 @@ import torch
 from torch import Tensor
 
 from .. import _lib as L
-from .point_ops import _extr12, _points
+from .point_ops import _ComputeSH, _extr12, _points
 
 
 def check_sink(sink: Optional[Dict[str, Tensor]], shapes: Dict[str, Tensor]) -> Optional[Dict[str, Tensor]]:
@@ -109,3 +109,12 @@ def preprocess_ortho(xyz: Tensor, scales: Tensor, uquats: Tensor, extr: Tensor, 
     for "xyz", "scales", "uquats"."""
     sink = check_sink(grad_sink, {"xyz": xyz, "scales": scales, "uquats": uquats})
     return _PreprocessOrtho.apply(xyz, scales, uquats, extr, W, H, nearest, extent, offset, sink)
+
+
+def compute_sh_into(shs: Tensor, degree: int, view_dirs: Tensor, visible: Optional[Tensor], shs_grad: Tensor) -> Tensor:
+    """``compute_sh`` whose backward ADDS dL/dshs into ``shs_grad`` (same shape as ``shs``, e.g. a FlatGradBucket view)
+    instead of returning it: no 58 MB temporary and no accumulate pass per frame at 300k Gaussians."""
+    if shs.shape[1] != (int(degree) + 1) ** 2:
+        raise ValueError("compute_sh_into needs shs with exactly (degree + 1)^2 coefficients per point")
+    check_sink({"shs": shs_grad}, {"shs": shs})
+    return _ComputeSH.apply(shs, degree, view_dirs, visible, False, shs_grad)

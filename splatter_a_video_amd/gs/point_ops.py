@@ -192,7 +192,7 @@ def ewa_project_ortho(xyz: Tensor, cov3d: Tensor, extr: Tensor, uv: Tensor, W: i
 # ------------------------------------------------------------------ compute_sh / compute_sh_free
 class _ComputeSH(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, shs, degree, view_dirs, visible, free):
+    def forward(ctx, shs, degree, view_dirs, visible, free, sink=None):
         shs = L.need(shs, "shs")
         degree = int(degree)
         if degree < 0 or degree > 3:
@@ -209,6 +209,7 @@ class _ComputeSH(torch.autograd.Function):
         L.check(L.lib().splat_compute_sh_forward(L.ci(P), L.ptr(shs), L.ci(degree), L.ptr(dirs), L.ptr(vis),
                                                  L.ci(1 if free else 0), L.ptr(colors), L.ptr(clamped), L.stream()))
         ctx.meta = (degree, bool(free))
+        ctx.sink = sink
         if free:
             ctx.save_for_backward(shs, dirs, vis)
         else:
@@ -223,12 +224,17 @@ class _ComputeSH(torch.autograd.Function):
         clamped = None if free else saved[3]
         P = shs.shape[0]
         g = L.need(dL_dcolor, "dL_dcolor")
-        dshs = torch.zeros_like(shs) if shs.shape[1] != (degree + 1) ** 2 else torch.empty_like(shs)
+        sink = ctx.sink            # caller-owned gradient buffer: the kernel adds into it, autograd sees no gradient
+        if sink is not None:
+            dshs = sink
+        else:
+            dshs = torch.zeros_like(shs) if shs.shape[1] != (degree + 1) ** 2 else torch.empty_like(shs)
         ddirs = torch.empty_like(dirs) if ctx.needs_input_grad[2] else None
         L.check(L.lib().splat_compute_sh_backward(L.ci(P), L.ptr(shs), L.ci(degree), L.ptr(dirs), L.ptr(vis),
-                                                  L.ptr(clamped), L.ci(1 if free else 0), L.ptr(g), L.ptr(dshs),
-                                                  L.ptr(ddirs), L.stream()))
-        return dshs, None, ddirs, None, None
+                                                  L.ptr(clamped), L.ci(1 if free else 0), L.ptr(g),
+                                                  L.ci(1 if sink is not None else 0), L.ptr(dshs), L.ptr(ddirs),
+                                                  L.stream()))
+        return (None if sink is not None else dshs), None, ddirs, None, None, None
 
 
 def compute_sh(shs: Tensor, degree: int, view_dirs: Tensor, visible: Optional[Tensor] = None) -> Tensor:

@@ -36,12 +36,22 @@ def _half_wh(W: int, H: int, device) -> Tensor:
 
 
 # ------------------------------------------------------------------ sort_gaussian
-def sort_gaussian(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Tensor) -> Tuple[Tensor, Tensor]:
-    """(idx_sorted[M] int32, tile_range[T,2] int32): Gaussian ids ordered by (tile, depth) and each
-    tile's [start, end) slice.  Ties (same tile, bit-equal depth) are ordered by ascending id, i.e.
-    the result of a STABLE sort of the reference's 64-bit keys (the reference's torch.sort is
-    unstable).  ``tiles`` is accepted for signature parity; the per-tile counts are re-derived from
-    uv/radius on the device.  One host sync (to size idx_sorted; the reference needs two)."""
+class SortStatus:
+    """Device-side outcome of a capacity-bounded sort: ``pairs`` (int32[1], the true number of tile-Gaussian
+    pairs M) and ``overflow`` (int32[1], 1 when M exceeded the capacity and pairs were dropped)."""
+
+    def __init__(self, pairs: Tensor, overflow: Tensor, capacity: int):
+        self.pairs, self.overflow, self.capacity = pairs, overflow, int(capacity)
+
+    def check(self) -> int:
+        """host sync; raises when the capacity was too small, else returns M"""
+        m = int(self.pairs.item())
+        if m > self.capacity or int(self.overflow.item()):
+            raise L.SplatError(f"sort_gaussian_capped: {m} tile-Gaussian pairs exceed the capacity {self.capacity}")
+        return m
+
+
+def _sort(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Optional[Tensor], capacity: Optional[int]):
     uv = L.need(uv, "uv")
     depth = L.need(depth, "depth")
     radius = L.need(radius, "radius", torch.int32)
@@ -54,7 +64,8 @@ def sort_gaussian(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, til
     T = _num_tiles(W, H)
     tile_range = torch.empty(T, 2, dtype=torch.int32, device=dev)
     if P == 0:
-        return torch.empty(0, dtype=torch.int32, device=dev), tile_range.zero_()
+        z = torch.zeros(1, dtype=torch.int32, device=dev)
+        return torch.empty(0, dtype=torch.int32, device=dev), tile_range.zero_(), SortStatus(z, z.clone(), 0)
     lib = L.lib()
     scratch = torch.empty(lib.splat_bin_scratch_bytes(P, W, H), dtype=torch.uint8, device=dev)
     m_dev = torch.empty(1, dtype=torch.int32, device=dev)
@@ -62,19 +73,39 @@ def sort_gaussian(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, til
     L.check(lib.splat_bin_count(L.ci(P), L.ptr(uv), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
                                 L.ptr(tile_range), L.ptr(m_dev), L.ptr(gcount), L.stream()))
     goff = torch.cumsum(gcount, 0, dtype=torch.int32)      # queued before the sync below
-    M = int(m_dev.item())
+    M = int(m_dev.item()) if capacity is None else int(capacity)   # the only host sync (none with a capacity)
     idx_sorted = torch.empty(M, dtype=torch.int32, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
     if M > 0:
         keys = torch.empty(M, dtype=torch.int64, device=dev)
         owner = torch.empty(M, dtype=torch.int32, device=dev)
         slot_sorted = torch.empty(M, dtype=torch.int32, device=dev)
-        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         L.check(lib.splat_bin_sort(L.ci(P), L.ptr(uv), L.ptr(depth), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
                                    L.ptr(tile_range), ctypes.c_int64(M), L.ptr(keys), L.ptr(idx_sorted),
                                    L.ptr(overflow), L.ptr(goff), L.ptr(owner), L.ptr(slot_sorted), L.stream()))
         # hidden companion of idx_sorted: lets alpha_blending's backward run without global atomics
         idx_sorted._splat_pairmap = (goff, slot_sorted)
+    return idx_sorted, tile_range, SortStatus(m_dev, overflow, M)
+
+
+def sort_gaussian(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Tensor) -> Tuple[Tensor, Tensor]:
+    """(idx_sorted[M] int32, tile_range[T,2] int32): Gaussian ids ordered by (tile, depth) and each
+    tile's [start, end) slice.  Ties (same tile, bit-equal depth) are ordered by ascending id, i.e.
+    the result of a STABLE sort of the reference's 64-bit keys (the reference's torch.sort is
+    unstable).  ``tiles`` is accepted for signature parity; the per-tile counts are re-derived from
+    uv/radius on the device.  One host sync (to size idx_sorted; the reference needs two)."""
+    idx_sorted, tile_range, _ = _sort(uv, depth, W, H, radius, tiles, None)
     return idx_sorted, tile_range
+
+
+def sort_gaussian_capped(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor,
+                         capacity: int) -> Tuple[Tensor, Tensor, SortStatus]:
+    """``sort_gaussian`` without the host synchronisation: ``idx_sorted`` is allocated with ``capacity`` entries (only
+    the first M are meaningful, tile_range never points past them) and the caller checks ``status`` whenever it next
+    synchronises anyway (e.g. once per gradient step).  On overflow the surplus pairs are dropped and flagged."""
+    if capacity < 0:
+        raise ValueError("capacity must be >= 0")
+    return _sort(uv, depth, W, H, radius, None, capacity)
 
 
 # ------------------------------------------------------------------ alpha blending (3 variants, one Function)

@@ -96,3 +96,51 @@ def test_preprocess_ortho_grad_sink_accumulates():
         assert snk[key].grad is None
         b = ref[key].grad.cpu().numpy()
         np.testing.assert_allclose(sink[name].cpu().numpy(), b, rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(b).max())))
+
+
+def test_compute_sh_into_accumulates():
+    N = 30_000
+    rng = np.random.default_rng(2)
+    shs = rng.normal(size=(N, 16, 3)).astype(np.float32) * 0.3
+    dirs = rng.normal(size=(N, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    vis = rng.random(N) > 0.1
+    gcol = [rng.normal(size=(N, 3)).astype(np.float32) for _ in range(3)]
+    a = _t(shs, True)
+    b = _t(shs, True)
+    sink = torch.zeros(N, 16, 3, device="cuda")
+    for g in gcol:
+        gs.compute_sh(a, 3, _t(dirs), _t(vis)).backward(_t(g))
+        rgb = gs.compute_sh_into(b, 3, _t(dirs), _t(vis), sink)
+        rgb.backward(_t(g))
+    assert b.grad is None
+    ref = a.grad.cpu().numpy()
+    np.testing.assert_allclose(sink.cpu().numpy(), ref, rtol=1e-5, atol=1e-6 * float(np.abs(ref).max()))
+
+
+def test_sort_gaussian_capped_matches_sort_gaussian():
+    N, W, H = 40_000, 320, 208
+    sc = make_scene(N, W, H, C=3, seed=6)
+    uv, depth, conic, radius, tiles = gs.preprocess_ortho(_t(sc.positions(1)), _t(sc.scale), _t(sc.rotate), _t(sc.extr), W, H,
+                                                          nearest=0.01)
+    idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+    M = idx.numel()
+    idx2, tr2, st = gs.sort_gaussian_capped(uv, depth, W, H, radius, capacity=M + 1000)
+    assert st.check() == M and idx2.numel() == M + 1000
+    assert torch.equal(tr, tr2) and torch.equal(idx, idx2[:M])
+    # the capped result drives the blend exactly like the exact one (pair-mode backward included)
+    feat = _t(sc.feature, True); op = _t(sc.opacity, True)
+    g = torch.randn(3, H, W, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    outs = []
+    for i_, t_ in ((idx, tr), (idx2, tr2)):
+        feat.grad = None; op.grad = None
+        uvg = uv.detach().requires_grad_(); cg = conic.detach().requires_grad_()
+        img = gs.alpha_blending(uvg, cg, op, feat, i_, t_, 0.0, W, H)
+        img.backward(g)
+        outs.append([img.detach(), uvg.grad, cg.grad, op.grad.clone(), feat.grad.clone()])
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    # too small: flagged, and check() raises
+    _, _, st3 = gs.sort_gaussian_capped(uv, depth, W, H, radius, capacity=M // 2)
+    with pytest.raises(Exception):
+        st3.check()
