@@ -337,83 +337,98 @@ sh_fwd_kernel(int P, const float *__restrict__ shs, const float *__restrict__ di
 }
 
 // reference: src/compute_sh.cu:82-195
+// dL/dshs[i][k][c] = B_k(dir_i) * g_i[c] is a rank-1 block of (DEG+1)^2 x 3 floats per Gaussian.  Phase 1 (thread per
+// Gaussian) puts the basis values and the masked colour gradient into LDS, phase 2 streams the workgroup's
+// contiguous output range with consecutive lanes on consecutive addresses (float4 when the row length allows),
+// storing or -- gradient-bucket use -- adding.
 template <int DEG, bool FREE, bool ACC>
 __global__ void __launch_bounds__(PW_BLOCK)
 sh_bwd_kernel(int P, const float *__restrict__ shs, const float *__restrict__ dirs,
               const uint8_t *__restrict__ visible, const uint8_t *__restrict__ clamped,
               const float *__restrict__ dL_dcolors, float *__restrict__ dL_dshs, float *__restrict__ dL_ddirs) {
-    constexpr int NB = (DEG + 1) * (DEG + 1);
-    const int i = blockIdx.x * PW_BLOCK + threadIdx.x;
-    if (i >= P) return;
-    if (!visible[i]) {
-        if (!ACC) {
-            float *oz = dL_dshs + (size_t)i * NB * 3;
+    constexpr int NB = (DEG + 1) * (DEG + 1), NB3 = NB * 3;
+    __shared__ float sB[PW_BLOCK][NB + 1];
+    __shared__ float sg[PW_BLOCK][3];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * PW_BLOCK;
+    const int i = i0 + tid;
+    const int nG = imin_(PW_BLOCK, P - i0);
+    if (i < P) {
+        float B[16], g[3] = {0.f, 0.f, 0.f};
+        const bool vis = visible[i] != 0;
+        const float x = dirs[3 * i], y = dirs[3 * i + 1], z = dirs[3 * i + 2];
+        sh_basis(DEG, x, y, z, B);
+        if (vis) {
 #pragma unroll
-            for (int k = 0; k < NB * 3; ++k) oz[k] = 0.f;
+            for (int c = 0; c < 3; ++c) {
+                g[c] = dL_dcolors[3 * i + c];
+                if (!FREE && clamped[3 * i + c]) g[c] = 0.f;
+            }
         }
-        if (dL_ddirs) {
-            dL_ddirs[3 * i] = 0.f; dL_ddirs[3 * i + 1] = 0.f; dL_ddirs[3 * i + 2] = 0.f;
-        }
-        return;
-    }
-    const float x = dirs[3 * i], y = dirs[3 * i + 1], z = dirs[3 * i + 2];
-    float B[16];
-    sh_basis(DEG, x, y, z, B);
-    float g[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        g[c] = dL_dcolors[3 * i + c];
-        if (!FREE && clamped[3 * i + c]) g[c] = 0.f;
-    }
-    float *o = dL_dshs + (size_t)i * NB * 3;
+        for (int k = 0; k < NB; ++k) sB[tid][k] = B[k];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        if (ACC) {  // gradient-bucket use: add to what the earlier frames of the step left there
-            o[3 * k + 0] += B[k] * g[0];
-            o[3 * k + 1] += B[k] * g[1];
-            o[3 * k + 2] += B[k] * g[2];
-        } else {
-            o[3 * k + 0] = B[k] * g[0];
-            o[3 * k + 1] = B[k] * g[1];
-            o[3 * k + 2] = B[k] * g[2];
-        }
-    }
-    if (!dL_ddirs) return;  // direction gradient not requested: the coefficients are never read
-    if (DEG == 0) {
-        dL_ddirs[3 * i] = 0.f; dL_ddirs[3 * i + 1] = 0.f; dL_ddirs[3 * i + 2] = 0.f;
-        return;
-    }
-    const float C1 = 0.4886025119029199f;
-    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
-                         0.5462742152960396f};
-    const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
-                         -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
-    const float *sh = shs + (size_t)i * NB * 3;
-    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-    float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+        for (int c = 0; c < 3; ++c) sg[tid][c] = g[c];   // zero for invisible points: their rows become zero / unchanged
+        if (dL_ddirs) {  // direction gradient (reads the coefficients; skipped when not requested)
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            if (vis && DEG > 0) {
+                const float C1 = 0.4886025119029199f;
+                const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                     0.5462742152960396f};
+                const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                     -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+                const float *sh = shs + (size_t)i * NB * 3;
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
 #define SHC(k) sh[3 * (k) + c]
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float dx = -C1 * SHC(3), dy = -C1 * SHC(1), dz = C1 * SHC(2);
-        if (DEG > 1) {
-            dx += C2[0] * y * SHC(4) + C2[2] * 2.f * -x * SHC(6) + C2[3] * z * SHC(7) + C2[4] * 2.f * x * SHC(8);
-            dy += C2[0] * x * SHC(4) + C2[1] * z * SHC(5) + C2[2] * 2.f * -y * SHC(6) + C2[4] * 2.f * -y * SHC(8);
-            dz += C2[1] * y * SHC(5) + C2[2] * 2.f * 2.f * z * SHC(6) + C2[3] * x * SHC(7);
-        }
-        if (DEG > 2) {
-            dx += (C3[0] * SHC(9) * 3.f * 2.f * xy + C3[1] * SHC(10) * yz + C3[2] * SHC(11) * -2.f * xy +
-                   C3[3] * SHC(12) * -3.f * 2.f * xz + C3[4] * SHC(13) * (-3.f * xx + 4.f * zz - yy) +
-                   C3[5] * SHC(14) * 2.f * xz + C3[6] * SHC(15) * 3.f * (xx - yy));
-            dy += (C3[0] * SHC(9) * 3.f * (xx - yy) + C3[1] * SHC(10) * xz + C3[2] * SHC(11) * (-3.f * yy + 4.f * zz - xx) +
-                   C3[3] * SHC(12) * -3.f * 2.f * yz + C3[4] * SHC(13) * -2.f * xy + C3[5] * SHC(14) * -2.f * yz +
-                   C3[6] * SHC(15) * -3.f * 2.f * xy);
-            dz += (C3[1] * SHC(10) * xy + C3[2] * SHC(11) * 4.f * 2.f * yz + C3[3] * SHC(12) * 3.f * (2.f * zz - xx - yy) +
-                   C3[4] * SHC(13) * 4.f * 2.f * xz + C3[5] * SHC(14) * (xx - yy));
-        }
-        ddx += dx * g[c]; ddy += dy * g[c]; ddz += dz * g[c];
-    }
+                for (int c = 0; c < 3; ++c) {
+                    float dx = -C1 * SHC(3), dy = -C1 * SHC(1), dz = C1 * SHC(2);
+                    if (DEG > 1) {
+                        dx += C2[0] * y * SHC(4) + C2[2] * 2.f * -x * SHC(6) + C2[3] * z * SHC(7) + C2[4] * 2.f * x * SHC(8);
+                        dy += C2[0] * x * SHC(4) + C2[1] * z * SHC(5) + C2[2] * 2.f * -y * SHC(6) + C2[4] * 2.f * -y * SHC(8);
+                        dz += C2[1] * y * SHC(5) + C2[2] * 2.f * 2.f * z * SHC(6) + C2[3] * x * SHC(7);
+                    }
+                    if (DEG > 2) {
+                        dx += (C3[0] * SHC(9) * 3.f * 2.f * xy + C3[1] * SHC(10) * yz + C3[2] * SHC(11) * -2.f * xy +
+                               C3[3] * SHC(12) * -3.f * 2.f * xz + C3[4] * SHC(13) * (-3.f * xx + 4.f * zz - yy) +
+                               C3[5] * SHC(14) * 2.f * xz + C3[6] * SHC(15) * 3.f * (xx - yy));
+                        dy += (C3[0] * SHC(9) * 3.f * (xx - yy) + C3[1] * SHC(10) * xz + C3[2] * SHC(11) * (-3.f * yy + 4.f * zz - xx) +
+                               C3[3] * SHC(12) * -3.f * 2.f * yz + C3[4] * SHC(13) * -2.f * xy + C3[5] * SHC(14) * -2.f * yz +
+                               C3[6] * SHC(15) * -3.f * 2.f * xy);
+                        dz += (C3[1] * SHC(10) * xy + C3[2] * SHC(11) * 4.f * 2.f * yz + C3[3] * SHC(12) * 3.f * (2.f * zz - xx - yy) +
+                               C3[4] * SHC(13) * 4.f * 2.f * xz + C3[5] * SHC(14) * (xx - yy));
+                    }
+                    ddx += dx * g[c]; ddy += dy * g[c]; ddz += dz * g[c];
+                }
 #undef SHC
-    dL_ddirs[3 * i] = ddx; dL_ddirs[3 * i + 1] = ddy; dL_ddirs[3 * i + 2] = ddz;
+            }
+            dL_ddirs[3 * i] = ddx; dL_ddirs[3 * i + 1] = ddy; dL_ddirs[3 * i + 2] = ddz;
+        }
+    }
+    __syncthreads();
+    float *out = dL_dshs + (size_t)i0 * NB3;
+    if (NB3 % 4 == 0) {
+        constexpr int Q = NB3 / 4;  // float4 chunks per Gaussian
+        float4 *out4 = reinterpret_cast<float4 *>(out);
+        for (int e = tid; e < nG * Q; e += PW_BLOCK) {
+            const int gi = e / Q, j = e - gi * Q;
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int idx = 4 * j + t, k = idx / 3, c = idx - 3 * k;
+                v[t] = sB[gi][k] * sg[gi][c];
+            }
+            float4 o = ACC ? out4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+            out4[e] = o;
+        }
+    } else {
+        for (int e = tid; e < nG * NB3; e += PW_BLOCK) {
+            const int gi = e / NB3, r = e - gi * NB3, k = r / 3, c = r - 3 * k;
+            const float v = sB[gi][k] * sg[gi][c];
+            out[e] = ACC ? out[e] + v : v;
+        }
+    }
 }
 
 // ================================================================== C ABI
