@@ -1,0 +1,36 @@
+"""Per-kernel HBM/fabric traffic per launch from two rocprofv3 --pmc passes (GPU box):
+   read : TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum  -> 32 n32 + 64 n64 + 128 n128
+          (n64 = RDREQ - n32 - n128 when the 64B counter is unavailable)
+   write: WRITE_SIZE (KiB)
+usage: python tools/pmc_traffic.py <read_pass_dir> <write_pass_dir> <out.json> "<source note>"
+"""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def load(d):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+            if not m:
+                continue
+            a = acc[m.group(1)][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    return {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in acc.items()}
+
+
+rd, wr = load(sys.argv[1]), load(sys.argv[2])
+out = {"source": sys.argv[4], "kernels": {}}
+for k in sorted(set(rd) | set(wr)):
+    c = rd.get(k, {})
+    n32, n64, n128 = c.get("TCC_EA0_RDREQ_32B_sum", 0.0), c.get("TCC_EA0_RDREQ_64B_sum", 0.0), c.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+    rb = 32 * n32 + 64 * n64 + 128 * n128
+    wb = wr.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
+    out["kernels"][k] = {"read_bytes": int(rb), "write_bytes": int(wb), "total_MB": round((rb + wb) / 1e6, 1)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))

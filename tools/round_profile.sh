@@ -1,0 +1,18 @@
+#!/bin/bash
+# GPU box: everything the round's measurement record needs, in one gpurun call.
+#   tools/round_profile.sh <tag>
+cd $GRAFT_REPO_ROOT
+TAG=${1:-r01f}
+export PYTHONPATH=$GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q < /dev/null > gpurun_out/pytest_gpu_$TAG.log 2>&1; tail -3 gpurun_out/pytest_gpu_$TAG.log
+timeout 300 python bench.py < /dev/null 2> /dev/null | tail -1 > gpurun_out/bench_$TAG.json; cut -c1-400 gpurun_out/bench_$TAG.json
+timeout 300 python bench.py --ops --no-cpu-baseline < /dev/null 2> /dev/null | tail -1 > gpurun_out/bench_${TAG}_ops.json; cut -c1-200 gpurun_out/bench_${TAG}_ops.json
+timeout 300 python bench.py --gaussians 1000000 --width 1280 --height 720 --no-cpu-baseline < /dev/null 2> /dev/null | tail -1 > gpurun_out/bench_${TAG}_c4.json; cut -c1-200 gpurun_out/bench_${TAG}_c4.json
+timeout 300 python bench.py --channels 32 --no-cpu-baseline < /dev/null 2> /dev/null | tail -1 > gpurun_out/bench_${TAG}_c5.json; cut -c1-200 gpurun_out/bench_${TAG}_c5.json
+bash tools/prof_round.sh $TAG < /dev/null
+B="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --frames 3 --no-cpu-baseline --no-kernel-timing"
+bash tools/pmc_run.sh ${TAG}_rd "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum" $B < /dev/null > /dev/null
+bash tools/pmc_run.sh ${TAG}_wr "WRITE_SIZE" $B < /dev/null > /dev/null
+python tools/pmc_traffic.py gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr gpurun_out/pmc_traffic_$TAG.json "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum (bytes = 32*n32+64*n64+128*n128) and WRITE_SIZE (KiB), separate passes, bench.py --frames 3 at configs[1], per launch" > /dev/null
+ls gpurun_out | grep $TAG
