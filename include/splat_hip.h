@@ -185,6 +185,28 @@ int splat_preprocess_ortho_backward(int P, const float *xyz, const float *offset
                                     const float *dL_dconic, int accumulate, float *dL_dxyz, float *dL_dscales,
                                     float *dL_duquats, splat_stream_t stream);
 
+/* ---- dynamic Gaussians -> screen space in one pass (row a15 fused into the preprocess) --------
+ * splat_dynamic_eval_forward + splat_preprocess_ortho_forward on the same inputs (time scalars as for
+ * splat_dynamic_eval_*; scaling / opacity are the raw parameters: exp / sigmoid are applied inside); the per-frame
+ * position, rotation and scale stay in registers.  Outputs: uv[P,2], depth[P,1], conic[P,3], radius[P], tiles[P] and
+ * opa_t[P,1] = sigmoid(opacity) for the blend.  backward: gradients w.r.t. the parameters from dL_duv, dL_ddepth,
+ * dL_dconic, dL_dopa (each may be NULL = 0); d_* may be NULL; accumulate=1 adds (d_cubic: active segment only, in the
+ * given cubic_layout). */
+int splat_frame_preprocess_forward(int P, int I, int seg, float d, const float *basis_host, const float *position,
+                                   const float *cubic, int cubic_layout, const float *rotation, const float *rot_poly,
+                                   const float *rot_fourier, const float *opacity, const float *scaling,
+                                   const float *extr, int W, int H, float nearest, float extent, float *uv,
+                                   float *depth, float *conic, int32_t *radius, int32_t *tiles, float *opa_t,
+                                   splat_stream_t stream);
+int splat_frame_preprocess_backward(int P, int I, int seg, float d, const float *basis_host, const float *position,
+                                    const float *cubic, int cubic_layout, const float *rotation,
+                                    const float *rot_poly, const float *rot_fourier, const float *opacity,
+                                    const float *scaling, const float *extr, int W, int H, const float *depth,
+                                    const int32_t *radius, const float *dL_duv, const float *dL_ddepth,
+                                    const float *dL_dconic, const float *dL_dopa, int accumulate, float *d_position,
+                                    float *d_cubic, float *d_rotation, float *d_opacity, float *d_scaling,
+                                    splat_stream_t stream);
+
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */
 void splat_profile_enable(int on);
 void splat_profile_reset(void);

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -30,6 +30,7 @@ SYMBOLS = [
     "splat_alpha_blending_forward", "splat_alpha_blending_backward", "splat_blend_pair_floats", "splat_blend_pack_floats",
     "splat_dynamic_eval_forward", "splat_dynamic_eval_backward",
     "splat_preprocess_ortho_forward", "splat_preprocess_ortho_backward",
+    "splat_frame_preprocess_forward", "splat_frame_preprocess_backward",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]
 

@@ -6,6 +6,7 @@
 // i.e. the same functions the separate operators run.
 #include "common.h"
 #include "pointwise_dev.h"
+#include "dynamics_dev.h"
 
 namespace {
 
@@ -105,6 +106,152 @@ preprocess_ortho_bwd_kernel(int P, const float *__restrict__ xyz, const float *_
     }
 }
 
+
+// ------------------------------------------------------------------ dynamic Gaussians -> screen space in one pass
+// the per-frame evaluation of the dynamic Gaussians (row a15) fused into the preprocess.  One
+// quad of lanes per Gaussian as in dynamics.hip (coalesced float4 table rows, component-per-lane stores); after the
+// quad has assembled position / unit quaternion / scale, all four lanes run the projection + cov3d + EWA of the
+// Gaussian redundantly (a few hundred flops against ~330 bytes of HBM traffic) and each stores its own components.
+struct DynFrame {
+    float pos[3], q[4], scl[3];  // per-frame position, normalised rotation, activated scale
+    float qraw[4], nrm;          // un-normalised rotation and its norm (backward)
+};
+
+__device__ __forceinline__ DynFrame dyn_frame(int n, int j, const CubicAddr &ca, float d, const DynBasis &b,
+                                              const float *position, const float *cubic, const float *rotation,
+                                              const float4 *rot_poly, const float4 *rot_fourier, const float *scaling) {
+    float pj = 0.f, sj = 0.f;
+    if (j < 3) {
+        const float *c = cubic + ca.seg_off + (size_t)n * ca.stride_n + j;
+        const size_t row = ca.stride_k;
+        const float c0 = c[0], c1 = c[row], c2 = c[2 * row], c3 = c[3 * row];
+        float p = c3 + c2 * d;
+        p = p + c1 * (d * d);
+        p = p + c0 * (d * d * d);
+        pj = p + position[(size_t)n * 3 + j];
+        sj = expf(scaling[(size_t)n * 3 + j]);
+    }
+    const float qj = quat_component(n, j, b, rotation, rot_poly, rot_fourier);
+    const float nr = sqrtf(quad_sum(qj * qj));
+    const float qn = qj / fmaxf(nr, 1e-12f);  // F.normalize: x / max(|x|, eps)
+    DynFrame f;
+    f.pos[0] = quad_bcast<0>(pj); f.pos[1] = quad_bcast<1>(pj); f.pos[2] = quad_bcast<2>(pj);
+    f.scl[0] = quad_bcast<0>(sj); f.scl[1] = quad_bcast<1>(sj); f.scl[2] = quad_bcast<2>(sj);
+    f.q[0] = quad_bcast<0>(qn); f.q[1] = quad_bcast<1>(qn); f.q[2] = quad_bcast<2>(qn); f.q[3] = quad_bcast<3>(qn);
+    f.qraw[0] = quad_bcast<0>(qj); f.qraw[1] = quad_bcast<1>(qj); f.qraw[2] = quad_bcast<2>(qj); f.qraw[3] = quad_bcast<3>(qj);
+    f.nrm = nr;
+    return f;
+}
+
+__global__ void __launch_bounds__(DYN_BLOCK)
+frame_preprocess_fwd_kernel(int P, CubicAddr ca, float d, DynBasis b, const float *__restrict__ position,
+                            const float *__restrict__ cubic, const float *__restrict__ rotation,
+                            const float4 *__restrict__ rot_poly, const float4 *__restrict__ rot_fourier,
+                            const float *__restrict__ opacity, const float *__restrict__ scaling,
+                            const float *__restrict__ extr, int W, int H, float nearest, float extent,
+                            float *__restrict__ uv, float *__restrict__ depth, float *__restrict__ conic,
+                            int *__restrict__ radius, int *__restrict__ tiles, float *__restrict__ opa_t) {
+    const int t = blockIdx.x * DYN_BLOCK + threadIdx.x;
+    const int n = t >> 2, j = t & 3;
+    if (n >= P) return;  // whole quads leave together
+    const DynFrame f = dyn_frame(n, j, ca, d, b, position, cubic, rotation, rot_poly, rot_fourier, scaling);
+    Cam c;
+    load_cam(nullptr, extr, c);
+    float u, v, dep;
+    const bool cull = project_ortho_pt(c, f.pos[0], f.pos[1], f.pos[2], W, H, nearest, extent, u, v, dep);
+    u = cull ? 0.f : u; v = cull ? 0.f : v; dep = cull ? 0.f : dep;
+    float o[3] = {0.f, 0.f, 0.f};
+    int orad = 0, otiles = 0;
+    if (dep != 0.f) {
+        float c3[6], a[3], bb[3], tt[3], Jm[4], cov[3];
+        cov3d_pt(f.scl, f.q, c3);
+        ewa_T<true>(c, f.pos, W, H, a, bb, tt, Jm);
+        ewa_cov2d<true>(a, bb, c3, cov);
+        ewa_finish_pt<true>(cov, make_float2(u, v), W, H, o[0], o[1], o[2], orad, otiles);
+    }
+    if (j < 2) uv[(size_t)n * 2 + j] = j == 0 ? u : v;
+    if (j < 3) conic[(size_t)n * 3 + j] = j == 0 ? o[0] : j == 1 ? o[1] : o[2];
+    if (j == 2) depth[n] = dep;
+    if (j == 3) {
+        radius[n] = orad;
+        tiles[n] = otiles;
+        opa_t[n] = 1.0f / (1.0f + expf(-opacity[n]));
+    }
+}
+
+template <bool ACC>
+__global__ void __launch_bounds__(DYN_BLOCK)
+frame_preprocess_bwd_kernel(int P, CubicAddr ca, float d, DynBasis b, const float *__restrict__ position,
+                            const float *__restrict__ cubic, const float *__restrict__ rotation,
+                            const float4 *__restrict__ rot_poly, const float4 *__restrict__ rot_fourier,
+                            const float *__restrict__ opacity, const float *__restrict__ scaling,
+                            const float *__restrict__ extr, int W, int H, const float *__restrict__ depth,
+                            const int *__restrict__ radius, const float *__restrict__ dL_duv,
+                            const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dconic,
+                            const float *__restrict__ dL_dopa, float *__restrict__ d_position,
+                            float *__restrict__ d_cubic, float *__restrict__ d_rotation, float *__restrict__ d_opacity,
+                            float *__restrict__ d_scaling) {
+    const int t = blockIdx.x * DYN_BLOCK + threadIdx.x;
+    const int n = t >> 2, j = t & 3;
+    if (n >= P) return;
+    const DynFrame f = dyn_frame(n, j, ca, d, b, position, cubic, rotation, rot_poly, rot_fourier, scaling);
+    float gp[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (depth[n] != 0.f) {
+        Cam c;
+        load_cam(nullptr, extr, c);
+        if (dL_duv) project_ortho_grad_pt(c, W, H, dL_duv[2 * n], dL_duv[2 * n + 1], dL_ddepth ? dL_ddepth[n] : 0.f, gp);
+        if (radius[n] > 0 && dL_dconic) {
+            float c3[6], a[3], bb[3], tt[3], Jm[4], cov[3];
+            cov3d_pt(f.scl, f.q, c3);
+            ewa_T<true>(c, f.pos, W, H, a, bb, tt, Jm);
+            ewa_cov2d<true>(a, bb, c3, cov);
+            const float det = cov[0] * cov[2] - cov[1] * cov[1];
+            if (det != 0.0f) {
+                const float g3[3] = {dL_dconic[3 * n], dL_dconic[3 * n + 1], dL_dconic[3 * n + 2]};
+                float dcx, dcy, dcz, g6[6];
+                ewa_grad_cov_pt(a, bb, cov, det, g3, dcx, dcy, dcz, g6);
+                cov3d_grad_pt(f.scl, f.q, g6, ds, dq);
+            }
+        }
+    }
+    // chain through the activations: scale = exp(scaling), rotation = normalize(raw)  (poly / Fourier sums detached)
+    if (j < 3) {
+        const float g = j == 0 ? gp[0] : j == 1 ? gp[1] : gp[2];
+        if (d_position) put<ACC>(d_position + (size_t)n * 3 + j, g);
+        if (d_cubic) {  // only the active segment of the spline table is touched
+            float *c = d_cubic + ca.seg_off + (size_t)n * ca.stride_n + j;
+            const size_t row = ca.stride_k;
+            put<ACC>(c, g * (d * d * d));
+            put<ACC>(c + row, g * (d * d));
+            put<ACC>(c + 2 * row, g * d);
+            put<ACC>(c + 3 * row, g);
+        }
+        if (d_scaling) {
+            const float dsj = j == 0 ? ds[0] : j == 1 ? ds[1] : ds[2];
+            const float sj = j == 0 ? f.scl[0] : j == 1 ? f.scl[1] : f.scl[2];
+            put<ACC>(d_scaling + (size_t)n * 3 + j, dsj * sj);
+        }
+    }
+    if (d_rotation) {
+        const float gq = j == 0 ? dq[0] : j == 1 ? dq[1] : j == 2 ? dq[2] : dq[3];
+        float r;
+        if (f.nrm < 1e-12f) {
+            r = gq / 1e-12f;
+        } else {
+            const float dot = f.q[0] * dq[0] + f.q[1] * dq[1] + f.q[2] * dq[2] + f.q[3] * dq[3];
+            const float qh = j == 0 ? f.q[0] : j == 1 ? f.q[1] : j == 2 ? f.q[2] : f.q[3];
+            r = (gq - qh * dot) / f.nrm;
+        }
+        put<ACC>(d_rotation + (size_t)n * 4 + j, r);
+    }
+    if (d_opacity && j == 3) {
+        const float s = 1.0f / (1.0f + expf(-opacity[n]));
+        put<ACC>(d_opacity + n, (dL_dopa ? dL_dopa[n] : 0.f) * s * (1.0f - s));
+    }
+}
+
+inline dim3 dyn_grid(int P) { return dim3((unsigned)(((size_t)P * 4 + DYN_BLOCK - 1) / DYN_BLOCK)); }
+
 }  // namespace
 
 extern "C" int splat_preprocess_ortho_forward(int P, const float *xyz, const float *offset, const float *scales,
@@ -140,6 +287,64 @@ extern "C" int splat_preprocess_ortho_backward(int P, const float *xyz, const fl
         SPLAT_LAUNCH("preprocess_bwd", preprocess_ortho_bwd_kernel<false>, pp_grid(P), dim3(PP_BLOCK), 0, s, P, xyz, offset,
                      scales, (const float4 *)uquats, extr, W, H, depth, radius, dL_duv, dL_ddepth, dL_dconic, dL_dxyz,
                      dL_dscales, dL_duquats);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_frame_preprocess_forward(int P, int I, int seg, float d, const float *basis_host,
+                                              const float *position, const float *cubic, int cubic_layout,
+                                              const float *rotation, const float *rot_poly, const float *rot_fourier,
+                                              const float *opacity, const float *scaling, const float *extr, int W,
+                                              int H, float nearest, float extent, float *uv, float *depth,
+                                              float *conic, int32_t *radius, int32_t *tiles, float *opa_t,
+                                              void *stream) {
+    SPLAT_CHECK_ARG(P >= 0 && I >= 1 && W > 0 && H > 0, "bad sizes");
+    SPLAT_CHECK_ARG(seg >= 0 && seg < I, "segment index out of range");
+    SPLAT_CHECK_ARG(basis_host != nullptr, "basis_host (12 host floats) is required");
+    SPLAT_CHECK_ARG(cubic_layout == SPLAT_CUBIC_GAUSSIAN_MAJOR || cubic_layout == SPLAT_CUBIC_SEGMENT_MAJOR,
+                    "unknown cubic_layout");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(position && cubic && rotation && rot_poly && rot_fourier && opacity && scaling && extr,
+                    "null input pointer");
+    SPLAT_CHECK_ARG(uv && depth && conic && radius && tiles && opa_t, "null output pointer");
+    SPLAT_LAUNCH("frame_preprocess_fwd", frame_preprocess_fwd_kernel, dyn_grid(P), dim3(DYN_BLOCK), 0, (hipStream_t)stream,
+                 P, cubic_addr(cubic_layout, P, I, seg), d, load_basis(basis_host), position, cubic, rotation,
+                 (const float4 *)rot_poly, (const float4 *)rot_fourier, opacity, scaling, extr, W, H, nearest, extent, uv,
+                 depth, conic, radius, tiles, opa_t);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_frame_preprocess_backward(int P, int I, int seg, float d, const float *basis_host,
+                                               const float *position, const float *cubic, int cubic_layout,
+                                               const float *rotation, const float *rot_poly, const float *rot_fourier,
+                                               const float *opacity, const float *scaling, const float *extr, int W,
+                                               int H, const float *depth, const int32_t *radius, const float *dL_duv,
+                                               const float *dL_ddepth, const float *dL_dconic, const float *dL_dopa,
+                                               int accumulate, float *d_position, float *d_cubic, float *d_rotation,
+                                               float *d_opacity, float *d_scaling, void *stream) {
+    SPLAT_CHECK_ARG(P >= 0 && I >= 1 && W > 0 && H > 0, "bad sizes");
+    SPLAT_CHECK_ARG(seg >= 0 && seg < I, "segment index out of range");
+    SPLAT_CHECK_ARG(basis_host != nullptr, "basis_host (12 host floats) is required");
+    SPLAT_CHECK_ARG(cubic_layout == SPLAT_CUBIC_GAUSSIAN_MAJOR || cubic_layout == SPLAT_CUBIC_SEGMENT_MAJOR,
+                    "unknown cubic_layout");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(position && cubic && rotation && rot_poly && rot_fourier && opacity && scaling && extr && depth &&
+                        radius,
+                    "null input pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const CubicAddr ca = cubic_addr(cubic_layout, P, I, seg);
+    const DynBasis b = load_basis(basis_host);
+    if (accumulate)
+        SPLAT_LAUNCH("frame_preprocess_bwd", frame_preprocess_bwd_kernel<true>, dyn_grid(P), dim3(DYN_BLOCK), 0, s, P, ca, d,
+                     b, position, cubic, rotation, (const float4 *)rot_poly, (const float4 *)rot_fourier, opacity, scaling,
+                     extr, W, H, depth, radius, dL_duv, dL_ddepth, dL_dconic, dL_dopa, d_position, d_cubic, d_rotation,
+                     d_opacity, d_scaling);
+    else
+        SPLAT_LAUNCH("frame_preprocess_bwd", frame_preprocess_bwd_kernel<false>, dyn_grid(P), dim3(DYN_BLOCK), 0, s, P, ca,
+                     d, b, position, cubic, rotation, (const float4 *)rot_poly, (const float4 *)rot_fourier, opacity,
+                     scaling, extr, W, H, depth, radius, dL_duv, dL_ddepth, dL_dconic, dL_dopa, d_position, d_cubic,
+                     d_rotation, d_opacity, d_scaling);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }

@@ -196,6 +196,105 @@ def evaluate(clock: FrameClock, time, *, position: Optional[Tensor] = None, pos_
     return pick(pos_t), pick(rot_t), pick(opa_t), pick(scl_t)
 
 
+class _FramePreprocess(torch.autograd.Function):
+    """dynamic parameters + time -> (uv, depth, conic, radius, tiles, opacity) of the orthographic camera, one launch
+    each way (splat_frame_preprocess_*)."""
+
+    @staticmethod
+    def forward(ctx, position, cubic, rotation, rot_poly, rot_fourier, opacity, scaling, extr, seg, d, basis, I, W, H,
+                nearest, extent, sink, layout):
+        N = position.shape[0]
+        position = _opt(position, "position", N, 3)
+        cubic = _opt(cubic, "pos_cubic_node", N, 4 * I * 3)
+        rotation = _opt(rotation, "rotation", N, 4)
+        rot_poly = _opt(rot_poly, "rot_poly_feat", N, 16)
+        rot_fourier = _opt(rot_fourier, "rot_fourier_feat", N, 32)
+        opacity = _opt(opacity, "opacity", N, 1)
+        scaling = _opt(scaling, "scaling", N, 3)
+        extr_c = L.need(extr, "extr")
+        if extr_c.numel() < 12:
+            raise ValueError("extr must hold at least 3x4 floats (row-major [R|T])")
+        dev = position.device
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        uv, depth, conic, opa_t = f32(N, 2), f32(N, 1), f32(N, 3), f32(N, 1)
+        radius = torch.empty(N, dtype=torch.int32, device=dev)
+        tiles = torch.empty(N, dtype=torch.int32, device=dev)
+        L.check(L.lib().splat_frame_preprocess_forward(
+            L.ci(N), L.ci(I), L.ci(seg), L.cf(d), basis, L.ptr(position), L.ptr(cubic), L.ci(layout), L.ptr(rotation),
+            L.ptr(rot_poly), L.ptr(rot_fourier), L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c), L.ci(W), L.ci(H),
+            L.cf(nearest), L.cf(extent), L.ptr(uv), L.ptr(depth), L.ptr(conic), L.ptr(radius), L.ptr(tiles),
+            L.ptr(opa_t), L.stream()))
+        ctx.meta = (N, int(I), int(seg), float(d), basis, int(W), int(H), int(layout), cubic.shape)
+        ctx.sink = sink
+        ctx.save_for_backward(position, cubic, rotation, rot_poly, rot_fourier, opacity, scaling, extr_c, depth, radius)
+        ctx.mark_non_differentiable(radius, tiles)
+        ctx.set_materialize_grads(False)
+        return uv, depth, conic, radius, tiles, opa_t
+
+    @staticmethod
+    def backward(ctx, g_uv, g_depth, g_conic, _r, _t, g_opa):
+        N, I, seg, d, basis, W, H, layout, cubic_shape = ctx.meta
+        position, cubic, rotation, rot_poly, rot_fourier, opacity, scaling, extr_c, depth, radius = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        sink = ctx.sink or {}
+        dev = position.device
+        g_uv = L.need(g_uv, "dL_duv") if g_uv is not None else None
+        g_depth = L.need(g_depth, "dL_ddepth") if g_depth is not None else None
+        g_conic = L.need(g_conic, "dL_dconic") if g_conic is not None else None
+        g_opa = L.need(g_opa, "dL_dopacity") if g_opa is not None else None
+        if g_uv is None and g_depth is not None:
+            g_uv = torch.zeros(N, 2, dtype=torch.float32, device=dev)
+
+        def out(idx, name, shape, zero=False):
+            if not need[idx]:
+                return None, None
+            if name in sink:
+                return sink[name], None
+            buf = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=dev)
+            return buf, buf
+
+        b_pos, r_pos = out(0, "position", (N, 3))
+        b_cub, r_cub = out(1, "pos_cubic_node", cubic_shape, zero=True)   # dense like the reference's autograd
+        b_rot, r_rot = out(2, "rotation", (N, 4))
+        b_opa, r_opa = out(5, "opacity", (N, 1))
+        b_scl, r_scl = out(6, "scaling", (N, 3))
+        rets = (r_pos, r_cub, r_rot, r_opa, r_scl)
+        bufs = (b_pos, b_cub, b_rot, b_opa, b_scl)
+        sinked = any(b is not None and r is None for b, r in zip(bufs, rets))
+        if sinked and any(r is not None for r in rets):
+            raise ValueError("grad_sink must cover every parameter that requires grad: "
+                             "position, pos_cubic_node, rotation, opacity, scaling")
+        if any(b is not None for b in bufs):
+            L.check(L.lib().splat_frame_preprocess_backward(
+                L.ci(N), L.ci(I), L.ci(seg), L.cf(d), basis, L.ptr(position), L.ptr(cubic), L.ci(layout),
+                L.ptr(rotation), L.ptr(rot_poly), L.ptr(rot_fourier), L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c),
+                L.ci(W), L.ci(H), L.ptr(depth), L.ptr(radius), L.ptr(g_uv), L.ptr(g_depth), L.ptr(g_conic), L.ptr(g_opa),
+                L.ci(1 if sinked else 0), L.ptr(b_pos), L.ptr(b_cub), L.ptr(b_rot), L.ptr(b_opa), L.ptr(b_scl),
+                L.stream()))
+        # rot_poly / rot_fourier: detached in the reference (:195-197) -> no gradient
+        return (r_pos, r_cub, r_rot, None, None, r_opa, r_scl) + (None,) * 11
+
+
+def frame_preprocess(clock: FrameClock, time, extr: Tensor, W: int, H: int, *, position: Tensor, pos_cubic_node: Tensor,
+                     rotation: Tensor, rot_poly_feat: Tensor, rot_fourier_feat: Tensor, opacity: Tensor,
+                     scaling: Tensor, nearest: float = 0.2, extent: float = 1.3,
+                     grad_sink: Optional[Dict[str, Tensor]] = None, cubic_layout: int = GAUSSIAN_MAJOR):
+    """Per-frame evaluation of the dynamic Gaussians fused with the orthographic preprocess:
+    returns (uv[N,2], depth[N,1], conic[N,3], radius[N] i32, tiles[N] i32, opacity[N,1] = sigmoid) -- what
+    ``evaluate`` followed by ``gs.preprocess_ortho`` returns, without the per-frame position / rotation / scale tensors.
+    ``grad_sink`` as in ``evaluate``."""
+    if cubic_layout not in (GAUSSIAN_MAJOR, SEGMENT_MAJOR):
+        raise ValueError("cubic_layout must be GAUSSIAN_MAJOR or SEGMENT_MAJOR")
+    seg, d, basis = clock.scalars(time)
+    if grad_sink:
+        for k, v in grad_sink.items():
+            L.need(v, f"grad_sink[{k}]")
+            if not v.is_contiguous():
+                raise ValueError(f"grad_sink[{k}] must be contiguous")
+    return _FramePreprocess.apply(position, pos_cubic_node, rotation, rot_poly_feat, rot_fourier_feat, opacity, scaling,
+                                  extr, seg, d, basis, clock.interval_num, W, H, nearest, extent, grad_sink, cubic_layout)
+
+
 class DynamicGaussians(torch.nn.Module):
     """Parameter holder with the reference's attribute / getter names (position, pos_cubic_node, rotation,
     rot_poly_feat, rot_fourier_feat, opacity, scaling; get_position(time), get_rotation(time), get_opacity,
@@ -235,6 +334,14 @@ class DynamicGaussians(torch.nn.Module):
                         rotation=self.rotation, rot_poly_feat=self.rot_poly_feat,
                         rot_fourier_feat=self.rot_fourier_feat, opacity=self.opacity, scaling=self.scaling,
                         grad_sink=grad_sink, cubic_layout=self.cubic_layout)
+
+    def preprocess(self, time, extr: Tensor, W: int, H: int, nearest: float = 0.2, extent: float = 1.3,
+                   grad_sink: Optional[Dict[str, Tensor]] = None):
+        """``frame(time)`` + orthographic projection / cov3d / EWA in one launch"""
+        return frame_preprocess(self.clock, time, extr, W, H, position=self.position, pos_cubic_node=self.pos_cubic_node,
+                                rotation=self.rotation, rot_poly_feat=self.rot_poly_feat,
+                                rot_fourier_feat=self.rot_fourier_feat, opacity=self.opacity, scaling=self.scaling,
+                                nearest=nearest, extent=extent, grad_sink=grad_sink, cubic_layout=self.cubic_layout)
 
     def get_position(self, time, detach_pos: bool = False) -> Tensor:
         return evaluate(self.clock, time, position=self.position, pos_cubic_node=self.pos_cubic_node,

@@ -162,3 +162,87 @@ def test_segment_major_layout_is_a_pure_permutation():
     ref = DynamicGaussians(clock, **{k: _dev(v) for k, v in host.items()})
     for x, y in zip(m.frame(33), ref.frame(33)):
         assert torch.equal(x, y)
+
+
+def _model(N, T, seed, W, H):
+    """dynamic Gaussians that land inside a W x H ortho view: positions in [-1,1]^2 x [2,4], pixel-sized splats"""
+    clock = FrameClock(T)
+    host, rng = _random_params(N, clock.interval_num, seed=seed)
+    host["position"] = np.concatenate([rng.uniform(-1.1, 1.1, size=(N, 2)), rng.uniform(2.0, 4.0, size=(N, 1))], 1).astype(np.float32)
+    host["pos_cubic_node"] = (host["pos_cubic_node"] * 0.2).astype(np.float32)
+    host["scaling"] = np.log(rng.uniform(0.004, 0.02, size=(N, 3))).astype(np.float32)
+    extr = np.eye(4, dtype=np.float32)[:3]
+    return clock, host, extr, rng
+
+
+@pytest.mark.parametrize("N,T,W,H", [(1, 6, 32, 32), (4001, 30, 160, 96), (60_000, 250, 854, 480)])
+def test_frame_preprocess_equals_evaluate_then_preprocess(N, T, W, H):
+    import dptr.gs as gs
+    from splatter_a_video_amd.dynamics import frame_preprocess
+    clock, host, extr, rng = _model(N, T, 7 + N, W, H)
+    g = [_dev(rng.normal(size=s)) for s in ((N, 2), (N, 1), (N, 3), (N, 1))]
+    for t in sorted({0, T // 3, T - 1}):
+        a = {k: _dev(v, grad=True) for k, v in host.items()}
+        pos, rot, opa, scl = evaluate(clock, t, **a)
+        uv, depth, conic, radius, tiles = gs.preprocess_ortho(pos, scl, rot, _dev(extr), W, H, nearest=0.01)
+        torch.autograd.backward([uv, depth, conic, opa], g)
+        b = {k: _dev(v, grad=True) for k, v in host.items()}
+        uv2, depth2, conic2, radius2, tiles2, opa2 = frame_preprocess(clock, t, _dev(extr), W, H, nearest=0.01, **b)
+        torch.autograd.backward([uv2, depth2, conic2, opa2], g)
+        assert N == 1 or (radius > 0).sum() > N // 4                    # the scene is actually on screen
+        assert torch.equal(radius, radius2) and torch.equal(tiles, tiles2)
+        np.testing.assert_allclose(uv2.detach().cpu().numpy(), uv.detach().cpu().numpy(), rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(depth2.detach().cpu().numpy(), depth.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+        c0 = conic.detach().cpu().numpy()
+        np.testing.assert_allclose(conic2.detach().cpu().numpy(), c0, rtol=5e-5, atol=2e-6 * max(1.0, float(np.abs(c0).max())))
+        np.testing.assert_allclose(opa2.detach().cpu().numpy(), opa.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+        for k in ("position", "pos_cubic_node", "rotation", "opacity", "scaling"):
+            x, y = b[k].grad.cpu().numpy(), a[k].grad.cpu().numpy()
+            np.testing.assert_allclose(x, y, rtol=3e-4, atol=2e-6 * max(1.0, float(np.abs(y).max())), err_msg=k)
+        assert b["rot_poly_feat"].grad is None and b["rot_fourier_feat"].grad is None
+
+
+def test_frame_preprocess_matches_oracle_chain():
+    from splatter_a_video_amd.dynamics import frame_preprocess
+    N, T, W, H = 3000, 40, 128, 96
+    clock, host, extr, rng = _model(N, T, 21, W, H)
+    t = 17
+    seg, d, basis = clock.scalars(t)
+    bb = np.array(list(basis), np.float32)
+    o_pos, o_rot, o_opa, o_scl = oracle.dynamic_eval_forward(host["position"], host["pos_cubic_node"], host["rotation"],
+                                                             host["rot_poly_feat"], host["rot_fourier_feat"], host["opacity"],
+                                                             host["scaling"], seg, d, bb[:4], bb[4:])
+    o_uv, o_d = oracle.project_point_ortho_forward(o_pos, extr, W, H, 0.01, 1.3)
+    vis = (o_d != 0).reshape(-1)
+    o_cov = oracle.compute_cov3d_forward(o_scl, o_rot, vis)
+    o_conic, o_r, o_t = oracle.ewa_project_forward(o_pos, o_cov, None, extr, o_uv, W, H, vis, ortho=True)
+    uv, depth, conic, radius, tiles, opa = frame_preprocess(clock, t, _dev(extr), W, H, nearest=0.01,
+                                                           **{k: _dev(v) for k, v in host.items()})
+    np.testing.assert_allclose(uv.cpu().numpy(), o_uv, rtol=1e-5, atol=2e-4)
+    np.testing.assert_allclose(depth.cpu().numpy(), o_d.reshape(-1, 1), rtol=1e-5, atol=1e-5)
+    same = radius.cpu().numpy() == o_r
+    assert same.mean() > 0.999                                        # ceil(3 sqrt(lambda)) may flip on a rounding tie
+    np.testing.assert_allclose(conic.cpu().numpy()[same], o_conic[same], rtol=2e-4, atol=2e-5 * float(np.abs(o_conic).max()))
+    np.testing.assert_allclose(opa.cpu().numpy(), o_opa, rtol=3e-6, atol=1e-7)
+
+
+def test_frame_preprocess_grad_sink_and_segment_major():
+    from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, to_gaussian_major
+    N, T, W, H = 9000, 60, 256, 144
+    clock, host, extr, rng = _model(N, T, 33, W, H)
+    ref = DynamicGaussians(clock, **{k: _dev(v) for k, v in host.items()})
+    seg = DynamicGaussians(clock, **{k: _dev(v) for k, v in host.items()}, cubic_layout=SEGMENT_MAJOR)
+    sink = {k: torch.zeros_like(getattr(seg, k)) for k in ("pos_cubic_node", "rotation", "opacity", "scaling")}
+    for t in (5, 31, 32):
+        g = [_dev(rng.normal(size=s)) for s in ((N, 2), (N, 1), (N, 3), (N, 1))]
+        r = ref.preprocess(t, _dev(extr), W, H, nearest=0.01)
+        torch.autograd.backward([r[0], r[1], r[2], r[5]], g)
+        r = seg.preprocess(t, _dev(extr), W, H, nearest=0.01, grad_sink=sink)
+        torch.autograd.backward([r[0], r[1], r[2], r[5]], g)
+    assert seg.pos_cubic_node.grad is None and seg.rotation.grad is None
+    for k in ("rotation", "opacity", "scaling"):
+        y = getattr(ref, k).grad.cpu().numpy()
+        np.testing.assert_allclose(sink[k].cpu().numpy(), y, rtol=1e-5, atol=2e-6 * max(1.0, float(np.abs(y).max())), err_msg=k)
+    y = ref.pos_cubic_node.grad.cpu().numpy()
+    np.testing.assert_allclose(to_gaussian_major(sink["pos_cubic_node"]).cpu().numpy(), y, rtol=1e-5,
+                               atol=2e-6 * max(1.0, float(np.abs(y).max())))
