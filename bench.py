@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--clip", type=int, default=50, help="frames in the clip (per 8 ranks: 200)")
     ap.add_argument("--channels", type=int, default=0, help="extra feature channels (configs[4]: 32 -> no SH)")
     ap.add_argument("--ops", action="store_true", help="per-operator chain through autograd instead of the fused frame operators")
+    ap.add_argument("--dynamic", action="store_true",
+                    help="parameterise the scene as the reference's dynamic Gaussians and run their per-frame evaluation "
+                         "inside the fused preprocess (row a15 on the path; implies the fused operators)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -75,9 +78,10 @@ class FrameRenderer:
     """Frame-sharded DP unit: parameters replicated, gradients of all local frames accumulate into
     one flat bucket (views), one all-reduce per step."""
 
-    def __init__(self, sc, device, C_extra=0, fused=True):
+    def __init__(self, sc, device, C_extra=0, fused=True, dynamic=False):
         self.sc = sc
-        self.fused = fused
+        self.fused = fused or dynamic
+        self.dynamic = dynamic
         self.capacity = None      # pair capacity of the sync-free sort (learned on the first frame)
         self.sort_status = []
         self.dev = device
@@ -85,6 +89,21 @@ class FrameRenderer:
         self.W, self.H = sc.W, sc.H
         self.use_sh = C_extra == 0
         src = dict(xyz=sc.xyz, scale=sc.scale, rotate=sc.rotate, opacity=sc.opacity)
+        if dynamic:
+            # the same Gaussians parameterised as the reference's dynamic model (row a15): canonical position + cubic
+            # spline per 5-frame segment (native segment-major table), raw rotation + frozen polynomial / Fourier
+            # tables, logit opacity, log scale
+            from splatter_a_video_amd.dynamics import FrameClock, to_segment_major
+            self.clock = FrameClock(sc.F)
+            I = self.clock.interval_num
+            rng = np.random.default_rng(99)
+            cub = (0.002 * rng.normal(size=(N, 4 * I * 3))).astype(np.float32)
+            op = np.clip(sc.opacity, 1e-4, 1 - 1e-4)
+            src = dict(pos_cubic_node=to_segment_major(torch.as_tensor(cub), I).numpy(), rotation=sc.rotate,
+                       opacity=np.log(op / (1 - op)).astype(np.float32), scaling=np.log(sc.scale).astype(np.float32))
+            self.position = torch.as_tensor(sc.xyz, device=device)
+            self.rot_poly = torch.as_tensor((0.01 * rng.normal(size=(N, 4, 4))).astype(np.float32), device=device)
+            self.rot_fourier = torch.as_tensor((0.01 * rng.normal(size=(N, 8, 4))).astype(np.float32), device=device)
         if self.use_sh:
             src["shs"] = sc.shs
         else:
@@ -114,7 +133,23 @@ class FrameRenderer:
         sequence (dptr_ortho_enhanced.py:282-349) through autograd.  Same images, same gradients."""
         p = self.p
         W, H = self.W, self.H
-        if self.fused:
+        opacity = p["opacity"]
+        if self.dynamic:
+            from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, frame_preprocess
+            g = {k: self.bucket.grad(k) for k in self.p}
+            feat = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"]) if self.use_sh else p["feature"]
+            uv, depth, conic, radius, tiles, opacity = frame_preprocess(
+                self.clock, off, self.extr, W, H, position=self.position, pos_cubic_node=p["pos_cubic_node"],
+                rotation=p["rotation"], rot_poly_feat=self.rot_poly, rot_fourier_feat=self.rot_fourier,
+                opacity=p["opacity"], scaling=p["scaling"], nearest=0.01, cubic_layout=SEGMENT_MAJOR,
+                grad_sink={k: g[k] for k in ("pos_cubic_node", "rotation", "opacity", "scaling")})
+            if self.capacity is None:
+                idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+                self.capacity = int(idx.numel() * 1.25) + 1024
+            else:
+                idx, tr, st = gs.sort_gaussian_capped(uv, depth, W, H, radius, self.capacity)
+                self.sort_status.append(st)
+        elif self.fused:
             g = {k: self.bucket.grad(k) for k in self.p}
             feat = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"]) if self.use_sh else p["feature"]
             uv, depth, conic, radius, tiles = gs.preprocess_ortho(
@@ -136,7 +171,7 @@ class FrameRenderer:
             idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
         # densification tap, as the reference renderers create it (dptr.py:151-162)
         ndc = torch.zeros_like(uv, requires_grad=True)
-        img = gs.alpha_blending(uv, conic, p["opacity"], feat, idx, tr, self.sc.bg, W, H, ndc)
+        img = gs.alpha_blending(uv, conic, opacity, feat, idx, tr, self.sc.bg, W, H, ndc)
         img.backward(self.dL_dout)
         self.last = dict(M=idx.numel() if not self.fused else self.last.get("M", idx.numel()), T=tr.shape[0])
         return img
@@ -172,6 +207,9 @@ def kernel_bytes(name, N, M, HW, C, T, use_sh):
         "preprocess_fwd": N * (12 + 12 + 12 + 16 + 8 + 4 + 12 + 4 + 4),
         # fused backward: inputs again + depth, radius + dL_duv, dL_ddepth, dL_dconic; read-modify-write of 3 gradients
         "preprocess_bwd": N * (12 + 12 + 12 + 16 + 4 + 4 + 8 + 4 + 12 + 2 * (12 + 12 + 16)),
+        # dynamic parameters (position, 48-B spline segment, rotation + 192 B of tables, opacity, scaling) -> screen space
+        "frame_preprocess_fwd": N * (12 + 48 + 16 + 192 + 4 + 12 + 8 + 4 + 12 + 4 + 4 + 4),
+        "frame_preprocess_bwd": N * (12 + 48 + 16 + 192 + 4 + 12 + 4 + 4 + 8 + 4 + 12 + 4 + 2 * (48 + 16 + 4 + 12)),
         "cov3d_fwd": N * (12 + 16 + 1 + 24),
         "cov3d_bwd": N * (12 + 16 + 1 + 24 + 12 + 16),
         "ewa_fwd": N * (12 + 24 + 8 + 1 + 12 + 4 + 4),
@@ -236,9 +274,12 @@ def main():
 
     clip = max(a.clip, 25 * world)
     sc = make_scene(a.gaussians, a.width, a.height, F=clip, C=a.channels, seed=1234)
-    R = FrameRenderer(sc, dev, a.channels, fused=not a.ops)
+    R = FrameRenderer(sc, dev, a.channels, fused=not a.ops, dynamic=a.dynamic)
     # rank r renders frames {f : f mod world == r} of the step's frame batch
-    offs = [R.offsets(((i * world + rank) % clip)) for i in range(a.frames)]
+    if a.dynamic:
+        offs = [((i * world + rank) % clip) for i in range(a.frames)]      # frame times of the dynamic model
+    else:
+        offs = [R.offsets(((i * world + rank) % clip)) for i in range(a.frames)]
 
     def sync():
         torch.cuda.synchronize()
@@ -275,7 +316,7 @@ def main():
         R.step(offs, collective=False)  # rank-0 only: must not enter a collective
         torch.cuda.synchronize()
         L.profile_enable(False)
-        names = ["sh_fwd", "preprocess_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
+        names = ["sh_fwd", "frame_preprocess_fwd", "frame_preprocess_bwd", "preprocess_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
                  "bin_scatter", "tile_sort", "blend_pack", "blend_fwd", "blend_bwd", "pair_reduce", "preprocess_bwd", "ewa_bwd", "project_point_bwd",
                  "cov3d_bwd", "sh_bwd"]
         for n in names:
@@ -313,7 +354,8 @@ def main():
                                    + ("SH deg 3 -> RGB" if R.use_sh else f"{a.channels} feature channels"),
                        "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
                        "tile_pairs_M": M, "channels": R.C, "parallelism": f"frame-sharded dp{world}",
-                       "path": "fused frame operators + gradient sinks" if R.fused else "per-operator autograd chain",
+                       "path": ("dynamic-Gaussian evaluation fused into the preprocess + gradient sinks" if R.dynamic else
+                                "fused frame operators + gradient sinks" if R.fused else "per-operator autograd chain"),
                        "grad_bucket_MB": round(R.flat_grad.numel() * 4 / 1e6, 1)},
             "ms_per_frame": round(dt / (a.frames * a.steps) * 1e3, 4),
             "gpu_kernel_ms_per_frame": {"forward": None if fwd_ms is None else round(fwd_ms, 4),
