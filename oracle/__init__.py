@@ -387,3 +387,52 @@ def dynamic_eval_backward(cubic_shape, rotation, rot_poly, rot_fourier, opacity,
                                        _p(g_scl, _f32p), _p(dpos, _f32p), _p(dcub, _f32p), _p(drot, _f32p),
                                        _p(dopa, _f32p), _p(dscl, _f32p))
     return dpos, dcub, drot, dopa, dscl
+
+
+# ------------------------------------------------------------------ densification statistics
+_u8p = ctypes.POINTER(ctypes.c_ubyte)
+_i32p = ctypes.POINTER(ctypes.c_int)
+
+
+def densify_accumulate(radius, tap, sx, sy, viewspace_grad, visible, radii):
+    """in place on viewspace_grad [P,2] f32, visible [P] u8, radii [P] i32"""
+    radius = np.ascontiguousarray(radius, np.int32); tap = _f(tap, (-1, 2))
+    assert viewspace_grad.dtype == np.float32 and visible.dtype == np.uint8 and radii.dtype == np.int32
+    lib().oracle_densify_accumulate(radius.size, _p(radius, _i32p), _p(tap, _f32p), ctypes.c_float(sx), ctypes.c_float(sy),
+                                    _p(viewspace_grad, _f32p), _p(visible, _u8p), _p(radii, _i32p))
+
+
+def densify_update(visible, viewspace_grad, radii, max_radii2D, pos_gradient_accum, denom):
+    """in place on max_radii2D, pos_gradient_accum, denom (float32 [P])"""
+    visible = np.ascontiguousarray(visible, np.uint8); viewspace_grad = _f(viewspace_grad, (-1, 2))
+    radii = np.ascontiguousarray(radii, np.int32)
+    for a in (max_radii2D, pos_gradient_accum, denom):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    lib().oracle_densify_update(visible.size, _p(visible, _u8p), _p(viewspace_grad, _f32p), _p(radii, _i32p),
+                                _p(max_radii2D, _f32p), _p(pos_gradient_accum, _f32p), _p(denom, _f32p))
+
+
+def densify_masks(pos_gradient_accum, denom, max_radii2D, scaling_raw, opacity_raw, grad_threshold, percent_dense,
+                  cameras_extent, min_opacity, size_threshold=20.0):
+    acc = _f(pos_gradient_accum).reshape(-1); den = _f(denom).reshape(-1); mr = _f(max_radii2D).reshape(-1)
+    sc = _f(scaling_raw, (-1, 3)); op = _f(opacity_raw).reshape(-1)
+    P = acc.size
+    clone = np.zeros(P, np.uint8); split = np.zeros(P, np.uint8); prune = np.zeros(P, np.uint8)
+    lib().oracle_densify_masks(P, _p(acc, _f32p), _p(den, _f32p), _p(mr, _f32p), _p(sc, _f32p), _p(op, _f32p),
+                               ctypes.c_float(grad_threshold), ctypes.c_float(percent_dense), ctypes.c_float(cameras_extent),
+                               ctypes.c_float(min_opacity), ctypes.c_float(size_threshold), _p(clone, _u8p),
+                               _p(split, _u8p), _p(prune, _u8p))
+    return clone.astype(bool), split.astype(bool), prune.astype(bool)
+
+
+def compact_rows(mask, src):
+    """src[mask] for a 32-bit array of shape [P, ...]"""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    src = np.ascontiguousarray(src)
+    assert src.dtype.itemsize == 4 and src.shape[0] == mask.size
+    rw = int(np.prod(src.shape[1:])) if src.ndim > 1 else 1
+    dst = np.empty_like(src)
+    f = lib().oracle_compact_rows
+    f.restype = ctypes.c_int
+    n = f(mask.size, _p(mask, _u8p), rw, ctypes.c_void_p(src.ctypes.data), ctypes.c_void_p(dst.ctypes.data))
+    return dst[:n]

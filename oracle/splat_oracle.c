@@ -874,3 +874,68 @@ void oracle_dynamic_eval_backward(int P, int I, int seg, float d, const float *r
         for (int a = 0; a < 3; ++a) d_scaling[3 * i + a] = g_scl[3 * i + a] * expf(scaling[3 * i + a]);
     }
 }
+
+/* ----------------------------------------------------------------------------------------
+ * Densification statistics (test infrastructure like the rest of this file).
+ *   batch reduction of the renderer      src/pointrix/renderer/dptr_ortho_enhanced.py:425-431
+ *   accumulate_viewspace_grad            src/pointrix/optimizer/atlas_gs_optimizer.py:414-433
+ *   update_structure (statistics part)   atlas_gs_optimizer.py:110-121
+ *   generate_clone_mask / split_mask     atlas_gs_optimizer.py:199-251
+ *   prune filter                         atlas_gs_optimizer.py:363-375
+ * Pinned by tests/golden/densify_5000.npz (generated from those methods).
+ * ---------------------------------------------------------------------------------------- */
+/* one frame of the batch: viewspace_grad += tap * (sx, sy); visible |= radius > 0; radii = max(radii, radius) */
+void oracle_densify_accumulate(int P, const int *radius, const float *tap, float sx, float sy, float *viewspace_grad,
+                               unsigned char *visible, int *radii) {
+    for (int i = 0; i < P; ++i) {
+        viewspace_grad[2 * i] += tap[2 * i] * sx;
+        viewspace_grad[2 * i + 1] += tap[2 * i + 1] * sy;
+        if (radius[i] > 0) visible[i] = 1;
+        if (radius[i] > radii[i]) radii[i] = radius[i];
+    }
+}
+
+/* once per step, for the Gaussians visible in the batch */
+void oracle_densify_update(int P, const unsigned char *visible, const float *viewspace_grad, const int *radii,
+                           float *max_radii2D, float *pos_gradient_accum, float *denom) {
+    for (int i = 0; i < P; ++i) {
+        if (!visible[i]) continue;
+        const float r = (float)radii[i];
+        if (r > max_radii2D[i]) max_radii2D[i] = r;
+        const float gx = viewspace_grad[2 * i], gy = viewspace_grad[2 * i + 1];
+        pos_gradient_accum[i] += sqrtf(gx * gx + gy * gy);
+        denom[i] += 1.0f;
+    }
+}
+
+/* clone / split / prune decisions from the accumulated statistics; scaling and opacity are the RAW parameters
+ * (exp / sigmoid applied here, as get_scaling / get_opacity do) */
+void oracle_densify_masks(int P, const float *pos_gradient_accum, const float *denom, const float *max_radii2D,
+                          const float *scaling_raw, const float *opacity_raw, float grad_threshold, float percent_dense,
+                          float cameras_extent, float min_opacity, float size_threshold, unsigned char *clone,
+                          unsigned char *split, unsigned char *prune) {
+    for (int i = 0; i < P; ++i) {
+        float g = pos_gradient_accum[i] / denom[i];
+        if (isnan(g)) g = 0.0f;
+        float smax = expf(scaling_raw[3 * i]);
+        const float s1 = expf(scaling_raw[3 * i + 1]), s2 = expf(scaling_raw[3 * i + 2]);
+        if (s1 > smax) smax = s1;
+        if (s2 > smax) smax = s2;
+        const float dense = percent_dense * cameras_extent;
+        clone[i] = (fabsf(g) >= grad_threshold) && (smax <= dense);
+        split[i] = (g >= grad_threshold) && (smax > dense);
+        const float op = 1.0f / (1.0f + expf(-opacity_raw[i]));
+        prune[i] = (op < min_opacity) || (size_threshold > 0.0f && (max_radii2D[i] > size_threshold || smax > 0.1f * cameras_extent));
+    }
+}
+
+/* stream compaction of rows of `row_words` 32-bit words: dst = src[mask]; returns the number of rows kept */
+int oracle_compact_rows(int P, const unsigned char *mask, int row_words, const unsigned int *src, unsigned int *dst) {
+    int n = 0;
+    for (int i = 0; i < P; ++i) {
+        if (!mask[i]) continue;
+        memcpy(dst + (size_t)n * row_words, src + (size_t)i * row_words, sizeof(unsigned int) * (size_t)row_words);
+        ++n;
+    }
+    return n;
+}
