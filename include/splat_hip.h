@@ -207,6 +207,33 @@ int splat_frame_preprocess_backward(int P, int I, int seg, float d, const float 
                                     float *d_cubic, float *d_rotation, float *d_opacity, float *d_scaling,
                                     splat_stream_t stream);
 
+/* ---- densification statistics and structure updates -----------------------------------------
+ * accumulate: one frame of a batch -- viewspace_grad[P,2] += tap[P,2] * (sx, sy) (tap = the frame's ndc / abs_ndc
+ *   gradient, or dL_duv with sx = W/2, sy = H/2; tap and viewspace_grad may both be NULL), visible[P] |= radius > 0,
+ *   radii[P] = max(radii, radius)            (dptr_ortho_enhanced.py:425-431, atlas_gs_optimizer.py:414-433)
+ * update: once per step, for visible Gaussians -- max_radii2D = max(., radii), pos_gradient_accum += |viewspace_grad|,
+ *   denom += 1                                (atlas_gs_optimizer.py:110-121)
+ * masks: clone = |g| >= thr & smax <= percent_dense*extent ; split = g >= thr & smax > percent_dense*extent ;
+ *   prune = sigmoid(opacity) < min_opacity | max_radii2D > size_threshold | smax > 0.1*extent (size tests skipped when
+ *   size_threshold <= 0), g = accum / denom with NaN -> 0, smax = max exp(scaling_raw)   (:199-251, :363-375);
+ *   any of the three outputs may be NULL.
+ * compact: index[i] = number of kept rows before i (one prefix sum of the byte mask, count = rows kept), then
+ *   splat_compact_rows moves row i (row_words 32-bit words) of any per-Gaussian tensor to row index[i] of dst when
+ *   mask[i] != 0 (points.py:282-312 prune_optimizer: parameters, Adam moments, statistics). */
+int splat_densify_accumulate(int P, const int32_t *radius, const float *tap, float sx, float sy, float *viewspace_grad,
+                             uint8_t *visible, int32_t *radii, splat_stream_t stream);
+int splat_densify_update(int P, const uint8_t *visible, const float *viewspace_grad, const int32_t *radii,
+                         float *max_radii2D, float *pos_gradient_accum, float *denom, splat_stream_t stream);
+int splat_densify_masks(int P, const float *pos_gradient_accum, const float *denom, const float *max_radii2D,
+                        const float *scaling_raw, const float *opacity_raw, float grad_threshold, float percent_dense,
+                        float cameras_extent, float min_opacity, float size_threshold, uint8_t *clone, uint8_t *split,
+                        uint8_t *prune, splat_stream_t stream);
+size_t splat_compact_scratch_bytes(int P);
+int splat_compact_scan(int P, const uint8_t *mask, int32_t *index, int32_t *count, void *scratch,
+                       splat_stream_t stream);
+int splat_compact_rows(int P, const uint8_t *mask, const int32_t *index, int row_words, const void *src, void *dst,
+                       splat_stream_t stream);
+
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */
 void splat_profile_enable(int on);
 void splat_profile_reset(void);

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -31,6 +31,8 @@ SYMBOLS = [
     "splat_dynamic_eval_forward", "splat_dynamic_eval_backward",
     "splat_preprocess_ortho_forward", "splat_preprocess_ortho_backward",
     "splat_frame_preprocess_forward", "splat_frame_preprocess_backward",
+    "splat_densify_accumulate", "splat_densify_update", "splat_densify_masks",
+    "splat_compact_scratch_bytes", "splat_compact_scan", "splat_compact_rows",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]
 
@@ -51,6 +53,8 @@ def lib() -> ctypes.CDLL:
         L.splat_abi_version.restype = ctypes.c_int
         L.splat_bin_scratch_bytes.restype = ctypes.c_size_t
         L.splat_bin_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.splat_compact_scratch_bytes.restype = ctypes.c_size_t
+        L.splat_compact_scratch_bytes.argtypes = [ctypes.c_int]
         L.splat_blend_pack_floats.restype = ctypes.c_size_t
         L.splat_blend_pack_floats.argtypes = [ctypes.c_int]
         L.splat_blend_pair_floats.restype = ctypes.c_size_t

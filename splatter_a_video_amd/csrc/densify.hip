@@ -1,0 +1,215 @@
+// Densification statistics and structure updates on the device.
+//   densify_accumulate  one frame of a batch: the gradient tap (ndc / abs_ndc .grad, reference
+//                       src/pointrix/renderer/dptr_ortho_enhanced.py:331-349,379) summed into viewspace_grad, visibility
+//                       OR-ed, radii max-ed (render_batch, :425-431; accumulate_viewspace_grad,
+//                       src/pointrix/optimizer/atlas_gs_optimizer.py:414-433) -- one pass instead of 3 F eager kernels
+//   densify_update      once per step (update_structure, atlas_gs_optimizer.py:110-121)
+//   densify_masks       clone / split / prune decisions (:199-251, :363-375)
+//   compact_scan/rows   stream compaction of every per-Gaussian tensor (parameters, Adam moments, statistics) with ONE
+//                       prefix sum of the keep mask (prune_optimizer, src/pointrix/point_cloud/points.py:282-312 does a
+//                       boolean-index pass with its own nonzero() per tensor)
+// All HBM streaming, 5..30 bytes per Gaussian.
+#include "common.h"
+
+namespace {
+
+constexpr int DB = 256;
+inline dim3 dgrid(size_t n) { return dim3((unsigned)((n + DB - 1) / DB)); }
+
+__global__ void __launch_bounds__(DB)
+densify_accumulate_kernel(int P, const int *__restrict__ radius, const float2 *__restrict__ tap, float sx, float sy,
+                          float2 *__restrict__ viewspace_grad, unsigned char *__restrict__ visible,
+                          int *__restrict__ radii) {
+    const int i = blockIdx.x * DB + threadIdx.x;
+    if (i >= P) return;
+    if (tap && viewspace_grad) {
+        const float2 t = tap[i];
+        float2 g = viewspace_grad[i];
+        // rounded product first (the tap itself is a rounded float32 in the reference): no FMA contraction here
+        float px = t.x * sx, py = t.y * sy;
+        asm volatile("" : "+v"(px), "+v"(py));
+        g.x += px;
+        g.y += py;
+        viewspace_grad[i] = g;
+    }
+    const int r = radius[i];
+    if (r > 0) visible[i] = 1;
+    if (r > radii[i]) radii[i] = r;
+}
+
+__global__ void __launch_bounds__(DB)
+densify_update_kernel(int P, const unsigned char *__restrict__ visible, const float2 *__restrict__ viewspace_grad,
+                      const int *__restrict__ radii, float *__restrict__ max_radii2D,
+                      float *__restrict__ pos_gradient_accum, float *__restrict__ denom) {
+    const int i = blockIdx.x * DB + threadIdx.x;
+    if (i >= P || !visible[i]) return;
+    max_radii2D[i] = fmaxf(max_radii2D[i], (float)radii[i]);
+    const float2 g = viewspace_grad[i];
+    pos_gradient_accum[i] += sqrtf(g.x * g.x + g.y * g.y);
+    denom[i] += 1.0f;
+}
+
+__global__ void __launch_bounds__(DB)
+densify_masks_kernel(int P, const float *__restrict__ accum, const float *__restrict__ denom,
+                     const float *__restrict__ max_radii2D, const float *__restrict__ scaling_raw,
+                     const float *__restrict__ opacity_raw, float grad_threshold, float dense, float big_ws,
+                     float min_opacity, float size_threshold, unsigned char *__restrict__ clone,
+                     unsigned char *__restrict__ split, unsigned char *__restrict__ prune) {
+    const int i = blockIdx.x * DB + threadIdx.x;
+    if (i >= P) return;
+    float g = accum[i] / denom[i];
+    if (isnan(g)) g = 0.f;  // never visible: 0 / 0
+    const float smax = fmaxf(fmaxf(expf(scaling_raw[3 * i]), expf(scaling_raw[3 * i + 1])), expf(scaling_raw[3 * i + 2]));
+    if (clone) clone[i] = (fabsf(g) >= grad_threshold) && (smax <= dense);
+    if (split) split[i] = (g >= grad_threshold) && (smax > dense);
+    if (prune) {
+        const float op = 1.0f / (1.0f + expf(-opacity_raw[i]));
+        prune[i] = (op < min_opacity) || (size_threshold > 0.f && (max_radii2D[i] > size_threshold || smax > big_ws));
+    }
+}
+
+// ---- prefix sum of a byte mask: per-block counts, single-workgroup scan of the counts, block-local positions
+__global__ void __launch_bounds__(DB)
+compact_count_kernel(int P, const unsigned char *__restrict__ mask, int *__restrict__ block_sum) {
+    __shared__ int ws[DB / WAVE];
+    const int i = blockIdx.x * DB + threadIdx.x;
+    const bool k = i < P && mask[i] != 0;
+    const unsigned long long m = __ballot(k);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ void __launch_bounds__(1024)
+compact_blockscan_kernel(int nb, int *__restrict__ block_sum, int *__restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int t = base + threadIdx.x;
+        const int v = t < nb ? block_sum[t] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_up(inc, o);
+            if (lane >= o) inc += n;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        const int carry = carry_s;
+        if (t < nb) block_sum[t] = carry + woff + inc - v;  // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = carry_s;
+}
+
+__global__ void __launch_bounds__(DB)
+compact_index_kernel(int P, const unsigned char *__restrict__ mask, const int *__restrict__ block_off,
+                     int *__restrict__ index) {
+    __shared__ int ws[DB / WAVE];
+    const int i = blockIdx.x * DB + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool k = i < P && mask[i] != 0;
+    const unsigned long long m = __ballot(k);
+    if (lane == 0) ws[w] = __popcll(m);
+    __syncthreads();
+    int off = block_off[blockIdx.x];
+    for (int q = 0; q < w; ++q) off += ws[q];
+    if (i < P) index[i] = off + __popcll(m & ((1ull << lane) - 1ull));  // destination row if kept
+}
+
+// row i (row_words 32-bit words) -> row index[i] of dst when mask[i]; consecutive lanes move consecutive words
+__global__ void __launch_bounds__(DB)
+compact_rows_kernel(size_t total_words, int row_words, const unsigned char *__restrict__ mask,
+                    const int *__restrict__ index, const unsigned int *__restrict__ src, unsigned int *__restrict__ dst) {
+    const size_t e = (size_t)blockIdx.x * DB + threadIdx.x;
+    if (e >= total_words) return;
+    const size_t i = e / (size_t)row_words;
+    if (!mask[i]) return;
+    const size_t w = e - i * (size_t)row_words;
+    dst[(size_t)index[i] * row_words + w] = src[e];
+}
+
+}  // namespace
+
+extern "C" int splat_densify_accumulate(int P, const int32_t *radius, const float *tap, float sx, float sy,
+                                        float *viewspace_grad, uint8_t *visible, int32_t *radii, void *stream) {
+    SPLAT_CHECK_ARG(P >= 0, "bad size");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(radius && visible && radii, "null pointer");
+    SPLAT_CHECK_ARG((tap == nullptr) == (viewspace_grad == nullptr), "tap and viewspace_grad go together");
+    SPLAT_LAUNCH("densify_accumulate", densify_accumulate_kernel, dgrid(P), dim3(DB), 0, (hipStream_t)stream, P, radius,
+                 (const float2 *)tap, sx, sy, (float2 *)viewspace_grad, visible, radii);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_densify_update(int P, const uint8_t *visible, const float *viewspace_grad, const int32_t *radii,
+                                    float *max_radii2D, float *pos_gradient_accum, float *denom, void *stream) {
+    SPLAT_CHECK_ARG(P >= 0, "bad size");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(visible && viewspace_grad && radii && max_radii2D && pos_gradient_accum && denom, "null pointer");
+    SPLAT_LAUNCH("densify_update", densify_update_kernel, dgrid(P), dim3(DB), 0, (hipStream_t)stream, P, visible,
+                 (const float2 *)viewspace_grad, radii, max_radii2D, pos_gradient_accum, denom);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_densify_masks(int P, const float *pos_gradient_accum, const float *denom,
+                                   const float *max_radii2D, const float *scaling_raw, const float *opacity_raw,
+                                   float grad_threshold, float percent_dense, float cameras_extent, float min_opacity,
+                                   float size_threshold, uint8_t *clone, uint8_t *split, uint8_t *prune, void *stream) {
+    SPLAT_CHECK_ARG(P >= 0, "bad size");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(pos_gradient_accum && denom && scaling_raw, "null pointer");
+    SPLAT_CHECK_ARG(!prune || (opacity_raw && max_radii2D), "prune needs opacity_raw and max_radii2D");
+    SPLAT_LAUNCH("densify_masks", densify_masks_kernel, dgrid(P), dim3(DB), 0, (hipStream_t)stream, P, pos_gradient_accum,
+                 denom, max_radii2D, scaling_raw, opacity_raw, grad_threshold, percent_dense * cameras_extent,
+                 0.1f * cameras_extent, min_opacity, size_threshold, clone, split, prune);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" size_t splat_compact_scratch_bytes(int P) {
+    if (P < 0) return 0;
+    return ((size_t)((P + DB - 1) / DB) + 64) * sizeof(int);
+}
+
+extern "C" int splat_compact_scan(int P, const uint8_t *mask, int32_t *index, int32_t *count, void *scratch,
+                                  void *stream) {
+    SPLAT_CHECK_ARG(P >= 0, "bad size");
+    SPLAT_CHECK_ARG(count != nullptr, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) {
+        SPLAT_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
+        return SPLAT_OK;
+    }
+    SPLAT_CHECK_ARG(mask && index && scratch, "null pointer");
+    const int nb = (P + DB - 1) / DB;
+    int *block_sum = (int *)scratch;
+    SPLAT_LAUNCH("compact_count", compact_count_kernel, dim3(nb), dim3(DB), 0, s, P, mask, block_sum);
+    SPLAT_POST_LAUNCH();
+    SPLAT_LAUNCH("compact_blockscan", compact_blockscan_kernel, dim3(1), dim3(1024), 0, s, nb, block_sum, count);
+    SPLAT_POST_LAUNCH();
+    SPLAT_LAUNCH("compact_index", compact_index_kernel, dim3(nb), dim3(DB), 0, s, P, mask, block_sum, index);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_compact_rows(int P, const uint8_t *mask, const int32_t *index, int row_words, const void *src,
+                                  void *dst, void *stream) {
+    SPLAT_CHECK_ARG(P >= 0 && row_words >= 1, "bad sizes");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(mask && index && src && dst, "null pointer");
+    const size_t total = (size_t)P * (size_t)row_words;
+    SPLAT_LAUNCH("compact_rows", compact_rows_kernel, dgrid(total), dim3(DB), 0, (hipStream_t)stream, total, row_words, mask,
+                 index, (const unsigned int *)src, (unsigned int *)dst);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
