@@ -234,6 +234,27 @@ int splat_compact_scan(int P, const uint8_t *mask, int32_t *index, int32_t *coun
 int splat_compact_rows(int P, const uint8_t *mask, const int32_t *index, int row_words, const void *src, void *dst,
                        splat_stream_t stream);
 
+/* ---- exact K nearest neighbours on a uniform grid ---------------------------------------------
+ * Replaces pytorch3d.ops.knn_points(points[None], points[None], K=K+1) of src/geometry_utils.py:17-19 (un-vendored CUDA
+ * dependency): squared Euclidean distances of the K nearest points per query, ascending, with indices (ties: smaller
+ * index first; fewer than K points: 0 / -1 padding).
+ *   budget = splat_knn_grid_cells(M)                 cell budget of the grid (the device picks an isotropic cell width
+ *                                                    and per-axis counts that fit it: no host round trip)
+ *   splat_knn_build   -> plan (opaque, splat_knn_plan_bytes() bytes), cell_of[M], cell_count[budget + 1] (caller zero-fills)
+ *   caller: cell_start = exclusive prefix sum of cell_count (budget + 1 entries, last = M) with any device scan
+ *   splat_knn_scatter -> sorted[M,4] = (x, y, z, bits of the original index), cell by cell (fill: zeroed [budget] scratch)
+ *   splat_knn_search  -> dists[N,K], idx[N,K]; query_order (nullable) = order in which the queries are walked
+ *                        (pass a spatially coherent permutation; results land at the original query index); K <= 16 */
+int splat_knn_grid_cells(int M);
+size_t splat_knn_plan_bytes(void);
+int splat_knn_build(int M, const float *points, int budget, void *plan, int32_t *cell_of, int32_t *cell_count,
+                    splat_stream_t stream);
+int splat_knn_scatter(int M, const float *points, const int32_t *cell_of, const int32_t *cell_start, int32_t *fill,
+                      float *sorted, splat_stream_t stream);
+int splat_knn_search(int N, const float *query, const int32_t *query_order, int M, const float *sorted,
+                     const int32_t *cell_start, const void *plan, int K, float *dists, int32_t *idx,
+                     splat_stream_t stream);
+
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */
 void splat_profile_enable(int on);
 void splat_profile_reset(void);

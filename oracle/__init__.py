@@ -436,3 +436,12 @@ def compact_rows(mask, src):
     f.restype = ctypes.c_int
     n = f(mask.size, _p(mask, _u8p), rw, ctypes.c_void_p(src.ctypes.data), ctypes.c_void_p(dst.ctypes.data))
     return dst[:n]
+
+
+# ------------------------------------------------------------------ K nearest neighbours
+def knn_points(query, points, K):
+    """(dists [N,K] squared L2 ascending, idx [N,K] int32) by brute force"""
+    q = _f(query, (-1, 3)); p = _f(points, (-1, 3))
+    d = np.zeros((q.shape[0], K), np.float32); i = np.zeros((q.shape[0], K), np.int32)
+    lib().oracle_knn_points(q.shape[0], _p(q, _f32p), p.shape[0], _p(p, _f32p), int(K), _p(d, _f32p), _p(i, _i32p))
+    return d, i

@@ -939,3 +939,38 @@ int oracle_compact_rows(int P, const unsigned char *mask, int row_words, const u
     }
     return n;
 }
+
+/* ----------------------------------------------------------------------------------------
+ * K nearest neighbours.  The reference calls pytorch3d.ops.knn_points(points[None],
+ * points[None], K=K+1) (src/geometry_utils.py:17-19; pytorch3d is an un-vendored dependency, absent from the
+ * reference tree: parity unpinned, anchored on the call site and on knn_points' published contract: squared
+ * Euclidean distances, the K smallest per query in ascending order, with their indices).  Brute force, exact;
+ * ties between equal distances are broken by the smaller index.
+ * ---------------------------------------------------------------------------------------- */
+void oracle_knn_points(int N, const float *query, int M, const float *points, int K, float *dists, int *idx) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        float *bd = dists + (size_t)i * K;
+        int *bi = idx + (size_t)i * K;
+        int n = 0;
+        const float qx = query[3 * i], qy = query[3 * i + 1], qz = query[3 * i + 2];
+        for (int j = 0; j < M; ++j) {
+            const float dx = qx - points[3 * j], dy = qy - points[3 * j + 1], dz = qz - points[3 * j + 2];
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (n == K && !(d < bd[K - 1])) continue;
+            int p = n < K ? n : K - 1;
+            while (p > 0 && d < bd[p - 1]) {
+                bd[p] = bd[p - 1];
+                bi[p] = bi[p - 1];
+                --p;
+            }
+            bd[p] = d;
+            bi[p] = j;
+            if (n < K) ++n;
+        }
+        for (int p = n; p < K; ++p) {
+            bd[p] = 0.0f;  /* fewer than K points: knn_points pads with 0 / -1 */
+            bi[p] = -1;
+        }
+    }
+}

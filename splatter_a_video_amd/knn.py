@@ -1,0 +1,71 @@
+"""Exact K nearest neighbours on the GPU.
+
+``knn_points`` mirrors the part of ``pytorch3d.ops.knn_points`` the reference uses
+(reference: src/geometry_utils.py:17-19 -- ``knn_points(points[None], points[None], None, None, K=K+1)``; pytorch3d is an
+un-vendored CUDA dependency without a ROCm build): batched point sets ``[B, N, 3]``, result fields ``dists`` (squared
+Euclidean, ascending), ``idx`` (int64) and ``knn`` (None unless ``return_nn``).  Uniform-grid search, exact; ties between
+equal distances resolve to the smaller index.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import namedtuple
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+KNN = namedtuple("KNN", "dists idx knn")
+
+
+def _knn_single(query: Tensor, points: Tensor, K: int):
+    lib = L.lib()
+    dev = points.device
+    N, M = query.shape[0], points.shape[0]
+    dists = torch.empty(N, K, dtype=torch.float32, device=dev)
+    idx = torch.empty(N, K, dtype=torch.int32, device=dev)
+    if N == 0:
+        return dists, idx.long()
+    budget = int(lib.splat_knn_grid_cells(L.ci(M)))
+    plan = torch.empty(int(lib.splat_knn_plan_bytes()), dtype=torch.uint8, device=dev)
+    cell_of = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    count = torch.zeros(budget + 1, dtype=torch.int32, device=dev)
+    L.check(lib.splat_knn_build(L.ci(M), L.ptr(points), L.ci(budget), L.ptr(plan), L.ptr(cell_of), L.ptr(count), L.stream()))
+    cell_start = (torch.cumsum(count, 0, dtype=torch.int32) - count).contiguous()      # exclusive; entry [budget] = M
+    fill = torch.zeros(budget, dtype=torch.int32, device=dev)
+    sorted_pts = torch.empty(max(M, 1), 4, dtype=torch.float32, device=dev)
+    L.check(lib.splat_knn_scatter(L.ci(M), L.ptr(points), L.ptr(cell_of), L.ptr(cell_start), L.ptr(fill), L.ptr(sorted_pts),
+                                  L.stream()))
+    # walk the queries cell by cell (cache locality) when they are the point set itself
+    order = None
+    if query.data_ptr() == points.data_ptr() and N == M:
+        order = sorted_pts[:, 3].contiguous().view(torch.int32)
+    L.check(lib.splat_knn_search(L.ci(N), L.ptr(query), L.ptr(order), L.ci(M), L.ptr(sorted_pts), L.ptr(cell_start),
+                                 L.ptr(plan), L.ci(K), L.ptr(dists), L.ptr(idx), L.stream()))
+    return dists, idx.long()
+
+
+def knn_points(p1: Tensor, p2: Tensor, lengths1: Optional[Tensor] = None, lengths2: Optional[Tensor] = None, K: int = 1,
+               version: int = -1, return_nn: bool = False, return_sorted: bool = True) -> KNN:
+    """K nearest neighbours in ``p2`` of every point of ``p1`` ([B,N,3], [B,M,3]); ``lengths*`` must be None (the
+    reference passes None); results are always sorted."""
+    if lengths1 is not None or lengths2 is not None:
+        raise NotImplementedError("ragged batches (lengths1 / lengths2) are not supported")
+    if p1.dim() != 3 or p2.dim() != 3 or p1.shape[2] != 3 or p2.shape[2] != 3 or p1.shape[0] != p2.shape[0]:
+        raise ValueError("p1 and p2 must be [B, N, 3] and [B, M, 3]")
+    if not 1 <= K <= 16:
+        raise ValueError("K must be in 1..16")
+    same = p1.data_ptr() == p2.data_ptr() and p1.shape == p2.shape
+    p1c = L.need(p1.detach(), "p1")
+    p2c = p1c if same else L.need(p2.detach(), "p2")
+    d, i = [], []
+    for b in range(p1c.shape[0]):
+        db, ib = _knn_single(p1c[b], p2c[b], K)
+        d.append(db); i.append(ib)
+    dists, idx = torch.stack(d), torch.stack(i)
+    nn = None
+    if return_nn:
+        nn = torch.stack([p2c[b][idx[b].clamp(min=0)] for b in range(p1c.shape[0])])
+    return KNN(dists=dists, idx=idx, knn=nn)
