@@ -69,3 +69,15 @@ def knn_points(p1: Tensor, p2: Tensor, lengths1: Optional[Tensor] = None, length
     if return_nn:
         nn = torch.stack([p2c[b][idx[b].clamp(min=0)] for b in range(p1c.shape[0])])
     return KNN(dists=dists, idx=idx, knn=nn)
+
+
+def distCUDA2(points: Tensor) -> Tensor:
+    """Mean squared distance of every point to its three nearest neighbours, the quantity ``simple_knn._C.distCUDA2``
+    returns (reference use: src/pointrix/utils/gaussian_points/gaussian_utils.py:5,68-73, initial Gaussian scales;
+    simple_knn is an un-vendored CUDA dependency: parity unpinned, semantics from its published kernel
+    ``simple_knn.cu`` -- exact 3-NN excluding the point itself, mean of the squared distances)."""
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise ValueError("points must be [N, 3]")
+    p = L.need(points.detach(), "points")
+    d = knn_points(p[None], p[None], None, None, K=4).dists[0]      # column 0 is the point itself
+    return d[:, 1:].mean(dim=1)

@@ -75,3 +75,13 @@ def test_reference_call_pattern_and_scale():
     od, oi = oracle.knn_points(sc.positions(0)[sub.cpu().numpy()], sc.positions(0), 6)
     np.testing.assert_allclose(res.dists[0][sub].cpu().numpy(), od, rtol=2e-6, atol=1e-12)
     assert (res.idx[0][sub].cpu().numpy() == oi).mean() > 0.999
+
+
+def test_distCUDA2_is_mean_of_three_nearest():
+    from splatter_a_video_amd.knn import distCUDA2
+    rng = np.random.default_rng(8)
+    pts = rng.normal(size=(15_000, 3)).astype(np.float32)
+    got = distCUDA2(torch.tensor(pts, device="cuda")).cpu().numpy()
+    od, _ = oracle.knn_points(pts, pts, 4)
+    np.testing.assert_allclose(got, od[:, 1:].mean(axis=1), rtol=3e-6, atol=1e-12)
+    assert (got > 0).all()
