@@ -235,6 +235,136 @@ __device__ __forceinline__ void bitonic_any_n(KeyPtr a, int n) {
     }
 }
 
+// ---- register-blocked bitonic sort: R keys per thread (element i = t R + r), 256 threads -> up to 256 R keys.
+// Compare-exchange partners inside a thread are registers, partners up to 63 lanes away are fetched with VALU-only
+// cross-lane moves (DPP quad_perm / row shifts / row_ror, gfx950 v_permlane{16,32}_swap), only the two largest
+// strides (other waves) go through LDS: 3 of the 55 (R = 4) / 66 (R = 8) stages.  Missing elements are +inf.
+typedef unsigned long long u64;
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+template <int D>
+__device__ __forceinline__ unsigned lane_xor_u(unsigned v, int lane) {
+    if (D == 1) return dpp_u<0xB1>(v);   // quad_perm:[1,0,3,2]
+    if (D == 2) return dpp_u<0x4E>(v);   // quad_perm:[2,3,0,1]
+    if (D == 4) {                        // inside a row of 16: lanes with bit 2 clear read lane+4, the others lane-4
+        const unsigned up = dpp_u<0x104>(v), dn = dpp_u<0x114>(v);  // row_shl:4 / row_shr:4
+        return (lane & 4) ? dn : up;
+    }
+    if (D == 8) return dpp_u<0x128>(v);  // row_ror:8
+    if (D == 16) {
+        const u32x2_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // r[0] rows: x0 x0 x2 x2, r[1]: x1 x1 x3 x3
+        return (lane & 16) ? r[0] : r[1];
+    }
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false);      // r[0] rows: x0 x1 x0 x1, r[1]: x2 x3 x2 x3
+    return (lane & 32) ? r[0] : r[1];
+}
+
+template <int D>
+__device__ __forceinline__ u64 lane_xor_key(u64 k, int lane) {
+    const unsigned lo = lane_xor_u<D>((unsigned)k, lane), hi = lane_xor_u<D>((unsigned)(k >> 32), lane);
+    return ((u64)hi << 32) | lo;
+}
+
+// one cross-thread stage at thread distance D (element stride D R): the lower thread keeps the minimum when ascending
+template <int R, int D>
+__device__ __forceinline__ void xthread_stage(u64 (&k)[R], int t, bool up, u64 *xbuf) {
+    const bool take_min = ((t & D) == 0) == up;
+    if (D < 64) {
+        const int lane = t & 63;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const u64 p = lane_xor_key<D>(k[r], lane);
+            const bool less = p < k[r];
+            k[r] = (less == take_min) ? p : k[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) xbuf[r * SORT_BLOCK + t] = k[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const u64 p = xbuf[r * SORT_BLOCK + (t ^ D)];
+            const bool less = p < k[r];
+            k[r] = (less == take_min) ? p : k[r];
+        }
+        __syncthreads();
+    }
+}
+
+template <int R, int K, int J>
+__device__ __forceinline__ void bitonic_stage(u64 (&k)[R], int t, u64 *xbuf) {
+    // merge width K, stride J (elements); direction of element i: ascending iff (i & K) == 0
+    if (J < R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if ((r & J) == 0) {
+                const bool up = (K < R) ? ((r & K) == 0) : (((t * R) & K) == 0);
+                const u64 a = k[r], b = k[r | J];
+                const bool sw = (a > b) == up;
+                k[r] = sw ? b : a;
+                k[r | J] = sw ? a : b;
+            }
+        }
+    } else {
+        const bool up = ((t * R) & K) == 0;
+        xthread_stage<R, J / R>(k, t, up, xbuf);
+    }
+}
+
+template <int R, int K, int J>
+struct BitonicJ {
+    static __device__ __forceinline__ void run(u64 (&k)[R], int t, u64 *xbuf) {
+        bitonic_stage<R, K, J>(k, t, xbuf);
+        BitonicJ<R, K, J / 2>::run(k, t, xbuf);
+    }
+};
+template <int R, int K>
+struct BitonicJ<R, K, 0> {
+    static __device__ __forceinline__ void run(u64 (&)[R], int, u64 *) {}
+};
+template <int R, int K, int NP>
+struct BitonicK {
+    static __device__ __forceinline__ void run(u64 (&k)[R], int t, u64 *xbuf) {
+        BitonicJ<R, K, K / 2>::run(k, t, xbuf);
+        BitonicK<R, K * 2, NP>::run(k, t, xbuf);
+    }
+};
+template <int R, int NP>
+struct BitonicK<R, NP * 2, NP> {
+    static __device__ __forceinline__ void run(u64 (&)[R], int, u64 *) {}
+};
+
+template <int R>
+__device__ __forceinline__ void tile_sort_regs(const u64 *g, int n, long long r0, int *idx_sorted, const int *owner,
+                                               int *slot_sorted, u64 *xbuf) {
+    const int t = threadIdx.x;
+    u64 k[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = t * R + r;
+        k[r] = i < n ? g[i] : ~0ull;
+    }
+    BitonicK<R, 2, R * SORT_BLOCK>::run(k, t, xbuf);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = t * R + r;
+        if (i < n) {
+            const int lo = (int)(unsigned)(k[r] & 0xffffffffull);
+            if (slot_sorted) {
+                slot_sorted[r0 + i] = lo;
+                idx_sorted[r0 + i] = owner[lo];
+            } else {
+                idx_sorted[r0 + i] = lo;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(SORT_BLOCK)
 tile_sort_kernel(const int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
                  int *__restrict__ idx_sorted, const int *__restrict__ owner, int *__restrict__ slot_sorted) {
@@ -247,19 +377,10 @@ tile_sort_kernel(const int *__restrict__ tile_range, long long capacity, unsigne
     if (n <= 0) return;
     unsigned long long *g = keys + r0;
     // low key word: Gaussian id, or (pair-map mode) the pair slot whose owner is the Gaussian id
-    if (n <= SORT_LDS_KEYS) {
-        for (int i = threadIdx.x; i < n; i += SORT_BLOCK) sk[i] = g[i];
-        __syncthreads();
-        if (n > 1) bitonic_any_n(sk, n);
-        for (int i = threadIdx.x; i < n; i += SORT_BLOCK) {
-            const int lo = (int)(unsigned)(sk[i] & 0xffffffffull);
-            if (slot_sorted) {
-                slot_sorted[r0 + i] = lo;
-                idx_sorted[r0 + i] = owner[lo];
-            } else {
-                idx_sorted[r0 + i] = lo;
-            }
-        }
+    if (n <= 4 * SORT_BLOCK) {
+        tile_sort_regs<4>(g, n, r0, idx_sorted, owner, slot_sorted, sk);
+    } else if (n <= 8 * SORT_BLOCK) {
+        tile_sort_regs<8>(g, n, r0, idx_sorted, owner, slot_sorted, sk);
     } else {
         __syncthreads();
         bitonic_any_n((volatile unsigned long long *)g, n);
