@@ -368,35 +368,34 @@ blend_fwd_kernel(const BlendArgs A) {
             for (int j0 = 0; j0 < cnt; j0 += U) {
                 int e[U];
                 float4 g0[U], g1[U];
-                float alpha[U];
-                bool ok[U];
-                bool any_ok = false;
+                float alpha[U];  // 0 where the splat does not touch the pixel: no per-splat predicate registers
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    e[u] = L.list[w][j0 + u];
+                    e[u] = L.list[w][j0 + u];  // slot SB (inert record: opacity 0 -> alpha 0) past the end of the list
                     g0[u] = L.g0(e[u]);
                     g1[u] = L.g1(e[u]);
                 }
+                float amax = 0.f;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const float dx = g0[u].x - pxf, dy = g0[u].y - pyf;
                     const float power = -0.5f * (g0[u].z * dx * dx + g1[u].x * dy * dy) - g0[u].w * dx * dy;
                     float araw = g1[u].y * __expf(power);
                     if (BIAS) araw = araw + g1[u].z;
-                    alpha[u] = fminf(0.99f, araw);
-                    ok[u] = (j0 + u < cnt) && !done && !(power > 0.f) && !(alpha[u] < (1.0f / 255.0f));
-                    any_ok = any_ok || ok[u];
+                    const float a = fminf(0.99f, araw);
+                    alpha[u] = (!(power > 0.f) && !(a < (1.0f / 255.0f))) ? a : 0.f;
+                    amax = fmaxf(amax, alpha[u]);
                 }
-                if (!__any(any_ok)) continue;
+                if (!__any(!done && amax > 0.f)) continue;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    ok[u] = ok[u] && !done;  // an earlier survivor of this trip may have saturated the pixel
-                    if (!__any(ok[u])) continue;
+                    const bool ok = !done && alpha[u] > 0.f;  // an earlier survivor of this trip may have saturated the pixel
+                    if (!__any(ok)) continue;
                     float f[CH];
                     read_feat<CH, SB>(L, e[u], f);
                     const float nT = T * (1.f - alpha[u]);
-                    const bool sat = ok[u] && (nT < 0.0001f);
-                    const bool app = ok[u] && !sat;
+                    const bool sat = ok && (nT < 0.0001f);
+                    const bool app = ok && !sat;
                     done = done || sat;
                     const float wgt = app ? alpha[u] * T : 0.f;
 #pragma unroll
