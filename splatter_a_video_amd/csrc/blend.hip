@@ -83,6 +83,26 @@ struct BlendArgs {
     float *pack;            // [P, Rec<CH>::RS] packed records of the current channel chunk (scratch)
 };
 
+// Workgroups are handed to the 8 XCDs round-robin by linear block id, and every XCD has its own L2.  Neighbouring
+// tiles gather largely the same packed records (a splat touches ~4 tiles), so runs of BLEND_XCD_RUN consecutive tiles
+// of the row-major order go to the same XCD (its consecutive blocks, i.e. roughly concurrently resident), and the runs
+// are dealt round-robin so that every XCD sees the whole image (a contiguous band per XCD halves the HBM reads as
+// well but leaves the XCDs that own the image borders idle early).  Block b = XCD b & 7, its (b >> 3)-th block.
+#ifndef BLEND_XCD_RUN
+#define BLEND_XCD_RUN 16
+#endif
+__device__ __forceinline__ int xcd_tile(int b, int T) {
+#if BLEND_XCD_RUN > 1
+    constexpr int S = BLEND_XCD_RUN;
+    const int full = (T / (8 * S)) * (8 * S);  // tiles covered by complete rounds of 8 runs; the tail maps linearly
+    if (b >= full) return b;
+    const int x = b & 7, q = b >> 3;
+    return ((q / S) * 8 + x) * S + (q % S);
+#else
+    return b;
+#endif
+}
+
 struct __attribute__((packed, aligned(4))) F3 {
     float x, y, z;
 };
@@ -328,7 +348,7 @@ blend_fwd_kernel(const BlendArgs A) {
     __shared__ TileLDS<CH, SB> L;
     __shared__ int s_done[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tile = blockIdx.x;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = tile % A.gx, ty = tile / A.gx;
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const int px = bx + (lane & 7), py = by + (lane >> 3);
@@ -542,7 +562,7 @@ blend_bwd_pair_kernel(const BlendArgs A) {
     __shared__ unsigned long long s_mask[4];     // which entries of the super-batch the wave wrote
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tile = blockIdx.x;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = tile % A.gx, ty = tile / A.gx;
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const int px = bx + (lane & 7), py = by + (lane >> 3);
@@ -819,7 +839,7 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
     __shared__ float s_mom[16 * 64];         // A operand of the moment product: [step 4 G + i][lane]
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tile = blockIdx.x;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = tile % A.gx, ty = tile / A.gx;
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const float bx0 = (float)bx, by0 = (float)by;
@@ -1060,7 +1080,7 @@ blend_bwd_atomic_kernel(const BlendArgs A) {
     __shared__ TileLDS<CH, SB> L;
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tile = blockIdx.x;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = tile % A.gx, ty = tile / A.gx;
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const int px = bx + (lane & 7), py = by + (lane >> 3);
