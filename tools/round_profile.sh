@@ -10,6 +10,8 @@ timeout 300 python bench.py < /dev/null 2> /dev/null | tail -1 > gpurun_out/benc
 timeout 300 python bench.py --ops --no-cpu-baseline < /dev/null 2> /dev/null | tail -1 > gpurun_out/bench_${TAG}_ops.json; cut -c1-200 gpurun_out/bench_${TAG}_ops.json
 timeout 300 python bench.py --gaussians 1000000 --width 1280 --height 720 --no-cpu-baseline < /dev/null 2> /dev/null | tail -1 > gpurun_out/bench_${TAG}_c4.json; cut -c1-200 gpurun_out/bench_${TAG}_c4.json
 timeout 300 python bench.py --channels 32 --no-cpu-baseline < /dev/null 2> /dev/null | tail -1 > gpurun_out/bench_${TAG}_c5.json; cut -c1-200 gpurun_out/bench_${TAG}_c5.json
+timeout 300 python bench.py --dynamic --no-cpu-baseline < /dev/null 2> /dev/null | tail -1 > gpurun_out/bench_${TAG}_dynamic.json; cut -c1-200 gpurun_out/bench_${TAG}_dynamic.json
+PYTHONPATH=. timeout 200 python tools/flow_bench.py < /dev/null 2> /dev/null | grep us > gpurun_out/flow_${TAG}.txt; cat gpurun_out/flow_${TAG}.txt
 bash tools/prof_round.sh $TAG < /dev/null
 B="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --frames 3 --no-cpu-baseline --no-kernel-timing"
 bash tools/pmc_run.sh ${TAG}_rd "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum" $B < /dev/null > /dev/null
