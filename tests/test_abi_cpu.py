@@ -97,3 +97,39 @@ def test_product_never_imports_oracle():
         assert "import oracle" not in src and "from oracle" not in src, p
     for p in pathlib.Path(ROOT, "dptr").rglob("*.py"):
         assert "oracle" not in p.read_text(), p
+
+
+def test_extension_modules_refuse_cpu(built_lib):
+    """the modules beyond the dptr.gs surface have no CPU fallback either"""
+    import torch
+    import dptr.gs as gs
+    from splatter_a_video_amd.densify import DensifyState, compact
+    from splatter_a_video_amd.dynamics import FrameClock, frame_preprocess
+    from splatter_a_video_amd.knn import distCUDA2, knn_points
+    with pytest.raises(ValueError):
+        DensifyState(10, "cpu")
+    with pytest.raises(ValueError):
+        compact(torch.ones(4, dtype=torch.bool), {"x": torch.zeros(4, 3)})
+    with pytest.raises(ValueError):
+        knn_points(torch.zeros(1, 8, 3), torch.zeros(1, 8, 3), None, None, K=3)
+    with pytest.raises(ValueError):
+        distCUDA2(torch.zeros(8, 3))
+    with pytest.raises(ValueError):
+        gs.preprocess_ortho(torch.zeros(4, 3), torch.ones(4, 3), torch.ones(4, 4), torch.eye(4), 32, 32)
+    z = lambda *s: torch.zeros(*s)
+    with pytest.raises(ValueError):
+        frame_preprocess(FrameClock(10), 3, torch.eye(4), 32, 32, position=z(4, 3), pos_cubic_node=z(4, 24), rotation=z(4, 4),
+                         rot_poly_feat=z(4, 4, 4), rot_fourier_feat=z(4, 8, 4), opacity=z(4, 1), scaling=z(4, 3))
+
+
+def test_new_entry_points_validate_arguments(built_lib):
+    lib = built_lib.lib()
+    f = ctypes.c_float
+    assert lib.splat_knn_search(ctypes.c_int(4), None, None, 4, None, None, None, ctypes.c_int(99), None, None, None) == -1
+    assert b"K must be" in lib.splat_last_error()
+    assert lib.splat_compact_rows(ctypes.c_int(4), None, None, ctypes.c_int(0), None, None, None) == -1
+    assert lib.splat_dynamic_eval_forward(ctypes.c_int(4), ctypes.c_int(2), ctypes.c_int(5), f(0.0), None, None, None, 0, None,
+                                          None, None, None, None, None, None, None, None, None) == -1
+    assert b"segment index" in lib.splat_last_error()
+    assert lib.splat_knn_grid_cells(ctypes.c_int(300000)) == 150000
+    assert lib.splat_compact_scratch_bytes(ctypes.c_int(1000)) >= 16
