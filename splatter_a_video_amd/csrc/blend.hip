@@ -187,30 +187,48 @@ __device__ __forceinline__ bool cull_test(float u, float v, float a, float b, fl
 template <int CH, bool BIAS, bool EXACT>
 __global__ void __launch_bounds__(256)
 pack_kernel(const BlendArgs A) {
-    constexpr int RS = Rec<CH>::RS;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= A.P) return;
+    constexpr int RS = Rec<CH>::RS, RQ = Rec<CH>::RQ;
+    constexpr int LS = RS + 4;  // LDS row stride in floats: 16-B aligned, conflict-free for the float4 row writes
+    __shared__ __attribute__((aligned(16))) float s_rec[(RS <= 32 ? 256 : 1) * LS];
+    const int i0 = blockIdx.x * 256;
+    const int i = i0 + threadIdx.x;
     float r[RS];
 #pragma unroll
     for (int k = 0; k < RS; ++k) r[k] = 0.f;
-    const float2 q = A.uv[i];
-    r[0] = q.x; r[1] = q.y;
-    r[2] = A.conic[3 * i]; r[3] = A.conic[3 * i + 1]; r[4] = A.conic[3 * i + 2];
-    r[5] = A.opacity[i];
-    if (BIAS) r[6] = A.bias[i];
-    r[7] = __int_as_float(i);
-    const float *f = A.feature + (size_t)i * A.C + A.c0;
+    if (i < A.P) {
+        const float2 q = A.uv[i];
+        r[0] = q.x; r[1] = q.y;
+        r[2] = A.conic[3 * i]; r[3] = A.conic[3 * i + 1]; r[4] = A.conic[3 * i + 2];
+        r[5] = A.opacity[i];
+        if (BIAS) r[6] = A.bias[i];
+        r[7] = __int_as_float(i);
+        const float *f = A.feature + (size_t)i * A.C + A.c0;
 #pragma unroll
-    for (int k = 0; k < CH; ++k)
-        if (EXACT || k < A.cn) r[8 + k] = f[k];
-    if (Rec<CH>::CULL >= 0) {
-        constexpr int CO = Rec<CH>::CULL >= 0 ? Rec<CH>::CULL : 0;
-        const CullP cp = cull_params(r[2], r[3], r[4], r[5]);
-        r[CO] = cp.hx; r[CO + 1] = cp.hy; r[CO + 2] = cp.tauq; r[CO + 3] = cp.ia; r[CO + 4] = cp.ic;
+        for (int k = 0; k < CH; ++k)
+            if (EXACT || k < A.cn) r[8 + k] = f[k];
+        if (Rec<CH>::CULL >= 0) {
+            constexpr int CO = Rec<CH>::CULL >= 0 ? Rec<CH>::CULL : 0;
+            const CullP cp = cull_params(r[2], r[3], r[4], r[5]);
+            r[CO] = cp.hx; r[CO + 1] = cp.hy; r[CO + 2] = cp.tauq; r[CO + 3] = cp.ia; r[CO + 4] = cp.ic;
+        }
     }
-    float4 *dst = reinterpret_cast<float4 *>(A.pack + (size_t)i * RS);
+    if (RS <= 32) {
+        // rows through LDS so that consecutive lanes store consecutive 16-byte chunks of the record array
+        float4 *row = reinterpret_cast<float4 *>(s_rec + threadIdx.x * LS);
 #pragma unroll
-    for (int k = 0; k < RS; k += 4) dst[k / 4] = make_float4(r[k], r[k + 1], r[k + 2], r[k + 3]);
+        for (int k = 0; k < RS; k += 4) row[k / 4] = make_float4(r[k], r[k + 1], r[k + 2], r[k + 3]);
+        __syncthreads();
+        const int nrec = imin_(256, A.P - i0);
+        float4 *dst = reinterpret_cast<float4 *>(A.pack + (size_t)i0 * RS);
+        for (int c = threadIdx.x; c < nrec * RQ; c += 256) {
+            const int g = c / RQ, part = c - g * RQ;
+            dst[c] = *reinterpret_cast<const float4 *>(s_rec + g * LS + 4 * part);
+        }
+    } else if (i < A.P) {
+        float4 *dst = reinterpret_cast<float4 *>(A.pack + (size_t)i * RS);
+#pragma unroll
+        for (int k = 0; k < RS; k += 4) dst[k / 4] = make_float4(r[k], r[k + 1], r[k + 2], r[k + 3]);
+    }
 }
 
 // ---- staging area of one super-batch (shared by the four waves of a tile): SB packed records,
