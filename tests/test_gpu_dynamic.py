@@ -246,3 +246,63 @@ def test_frame_preprocess_grad_sink_and_segment_major():
     y = ref.pos_cubic_node.grad.cpu().numpy()
     np.testing.assert_allclose(to_gaussian_major(sink["pos_cubic_node"]).cpu().numpy(), y, rtol=1e-5,
                                atol=2e-6 * max(1.0, float(np.abs(y).max())))
+
+
+def test_dynamic_pipeline_end_to_end_against_oracle():
+    """The whole per-frame path with row a15 on it -- dynamic parameters -> fused preprocess -> SH -> sync-free sort ->
+    blend -> backward into gradient sinks -- against the oracle chain (dynamic_eval -> render_forward / render_backward ->
+    dynamic_eval_backward), two frames accumulated."""
+    import dptr.gs as gs
+    from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, frame_preprocess, to_gaussian_major, to_segment_major
+    N, T, W, H = 6000, 30, 160, 112
+    clock, host, extr, rng = _model(N, T, 91, W, H)
+    host["scaling"] = np.log(rng.uniform(0.01, 0.035, size=(N, 3))).astype(np.float32)   # a few pixels wide
+    shs = (rng.normal(size=(N, 16, 3)) * 0.3).astype(np.float32)
+    I = clock.interval_num
+    p = {k: _dev(v) for k, v in host.items()}
+    p["pos_cubic_node"] = to_segment_major(p["pos_cubic_node"], I)
+    shs_d = _dev(shs, grad=True)
+    for k in ("pos_cubic_node", "rotation", "opacity", "scaling"):
+        p[k].requires_grad_()
+    sink = {k: torch.zeros_like(p[k]) for k in ("pos_cubic_node", "rotation", "opacity", "scaling")}
+    shs_sink = torch.zeros_like(shs_d)
+    dirs = torch.zeros(N, 3, device="cuda"); dirs[:, 2] = 1.0
+    want = {k: np.zeros(host[k].shape, np.float64) for k in ("pos_cubic_node", "rotation", "opacity", "scaling")}
+    want_shs = np.zeros(shs.shape, np.float64)
+    for t in (4, 19):
+        g = rng.normal(size=(3, H, W)).astype(np.float32)
+        # ---- GPU
+        feat = gs.compute_sh_into(shs_d, 3, dirs, None, shs_sink)
+        uv, depth, conic, radius, tiles, opa = frame_preprocess(clock, t, _dev(extr), W, H, nearest=0.01, grad_sink=sink,
+                                                               cubic_layout=SEGMENT_MAJOR, **p)
+        idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        idx2, tr2, st = gs.sort_gaussian_capped(uv, depth, W, H, radius, idx.numel() + 64)
+        img = gs.alpha_blending(uv, conic, opa, feat, idx2, tr2, 0.0, W, H, None)
+        img.backward(_dev(g))
+        assert st.check() == idx.numel()
+        # ---- oracle
+        seg, d, basis = clock.scalars(t)
+        b = np.array(list(basis), np.float32)
+        o_pos, o_rot, o_opa, o_scl = oracle.dynamic_eval_forward(host["position"], host["pos_cubic_node"], host["rotation"],
+                                                                 host["rot_poly_feat"], host["rot_fourier_feat"],
+                                                                 host["opacity"], host["scaling"], seg, d, b[:4], b[4:])
+        (out, fT, nc), saved = oracle.render_forward(o_pos, o_scl, o_rot, o_opa, None, None, extr, W, H, 0.0, ortho=True,
+                                                     shs=shs)
+        bad = np.abs(img.detach().cpu().numpy() - out) > (1e-5 + 1e-4 * np.abs(out))
+        assert bad.mean() < 2e-3
+        gr = oracle.render_backward(o_pos, o_scl, o_rot, o_opa, None, extr, W, H, 0.0, saved, g, ortho=True, shs=shs)
+        dpos, dcub, drot, dopa, dscl = oracle.dynamic_eval_backward(
+            (N, 4, I, 3), host["rotation"], host["rot_poly_feat"], host["rot_fourier_feat"], host["opacity"], host["scaling"],
+            seg, d, b[:4], b[4:], gr["xyz"], gr["rotate"], gr["opacity"], gr["scale"])
+        want["pos_cubic_node"] += dcub.reshape(N, -1); want["rotation"] += drot; want["opacity"] += dopa; want["scaling"] += dscl
+        want_shs += gr["shs"]
+    got = {k: sink[k] for k in sink}
+    got["pos_cubic_node"] = to_gaussian_major(sink["pos_cubic_node"])
+    for k in want:
+        a, bb = got[k].cpu().numpy().reshape(-1), want[k].reshape(-1)
+        assert np.abs(bb).max() > 0
+        err = np.abs(a - bb).max() / np.abs(bb).max()
+        assert err < 5e-3, (k, err)                         # same bar as the static chain test (gradients: rel-to-max)
+    err = np.abs(shs_sink.cpu().numpy() - want_shs).max() / np.abs(want_shs).max()
+    assert err < 5e-3, err
+    assert all(p[k].grad is None for k in sink) and shs_d.grad is None
