@@ -1,0 +1,84 @@
+"""Native renderer (row a1 counterpart) against the explicit operator chain of the reference's render_iter -- which
+tests/test_gpu_renderer_flow.py pins to the oracle -- and its batch reduction / densification hand-off."""
+import numpy as np
+import pytest
+import torch
+
+import dptr.gs as gs
+from splatter_a_video_amd.densify import DensifyState
+from splatter_a_video_amd.renderer import OrthoEnhancedRenderer
+from splatter_a_video_amd.synth import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, grad=False):
+    return torch.tensor(np.asarray(a), device="cuda", requires_grad=grad)
+
+
+def test_render_iter_equals_operator_chain():
+    N, W, H, K = 8000, 192, 128, 20
+    sc = make_scene(N, W, H, seed=5)
+    rng = np.random.default_rng(1)
+    attrs = rng.uniform(-1, 1, size=(N, 19)).astype(np.float32)
+    g1, g2, g3 = (rng.normal(size=s).astype(np.float32) for s in ((3, H, W), (1, H, W), (19, H, W)))
+    results = []
+    for native in (False, True):
+        p = {k: _t(v, True) for k, v in dict(position=sc.positions(2), opacity=sc.opacity, scaling=sc.scale, rotation=sc.rotate,
+                                             shs=sc.shs, attrs=attrs).items()}
+        extr = _t(sc.extr)
+        if native:
+            r = OrthoEnhancedRenderer(densify_abs_grad_enable=True).render_iter(
+                H, W, extr, p["position"], p["opacity"], p["scaling"], p["rotation"], p["shs"], num_idx=K,
+                render_attributes={"mask_attribute": p["attrs"][:, :1], "dino_attribute": p["attrs"][:, 1:]})
+            f = r["rendered_features_split"]
+            img, dimg = f["rgb"], f["depth"]
+            aimg = torch.cat([f["mask_attribute"], f["dino_attribute"]], 0)
+            tap, radius, gidx = r["viewspace_points"], r["radii"], r["gs_idx"]
+        else:
+            dirs = torch.zeros(N, 3, device="cuda"); dirs[:, 2] = 1.0
+            rgb = gs.compute_sh(p["shs"], 3, dirs)
+            uv, depth = gs.project_point_ortho(p["position"], extr, W, H, nearest=0.01)
+            vis = depth != 0
+            cov = gs.compute_cov3d(p["scaling"], p["rotation"], vis)
+            conic, radius, tiles = gs.ewa_project_ortho(p["position"], cov, extr, uv, W, H, vis)
+            idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+            ndc = torch.zeros_like(uv, requires_grad=True); tap = torch.zeros_like(uv, requires_grad=True)
+            img, _, gidx = gs.alpha_blending_enhanced(uv, conic, p["opacity"], rgb, idx, tr, 0.0, W, H, ndc, tap, K=K)
+            dimg = gs.alpha_blending(uv, conic, p["opacity"], depth, idx, tr, 1.0, W, H, ndc.detach())
+            aimg = gs.alpha_blending(uv, conic, p["opacity"].detach(), p["attrs"], idx, tr, 0.0, W, H, ndc.detach())
+        ((img * _t(g1)).sum() + (dimg * _t(g2)).sum() + (aimg * _t(g3)).sum()).backward()
+        results.append(dict(img=img.detach(), dimg=dimg.detach(), aimg=aimg.detach(), tap=tap.grad.clone(), radius=radius, gidx=gidx,
+                            grads={k: v.grad.clone() for k, v in p.items()}))
+    a, b = results
+    assert torch.equal(a["radius"], b["radius"]) and torch.equal(a["gidx"], b["gidx"])
+    for k in ("img", "dimg", "aimg"):
+        assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-6), k
+    assert torch.allclose(a["tap"], b["tap"], rtol=1e-4, atol=1e-6 * float(a["tap"].abs().max()))
+    for k in a["grads"]:
+        x, y = b["grads"][k], a["grads"][k]
+        assert torch.allclose(x, y, rtol=2e-4, atol=2e-6 * float(y.abs().max())), k
+
+
+def test_render_batch_reduction_and_densify_handoff():
+    N, W, H = 3000, 96, 64
+    sc = make_scene(N, W, H, seed=8)
+    R = OrthoEnhancedRenderer()
+    shared = dict(opacity=_t(sc.opacity, True), scaling=_t(sc.scale, True), rotation=_t(sc.rotate, True), shs=_t(sc.shs, True),
+                  height=H, width=W, extrinsic_matrix=_t(sc.extr))
+    frames = [dict(position=_t(sc.positions(f), True)) for f in (0, 3, 6)]
+    out = R.render_batch(shared, frames)
+    assert out["rgb"].shape == (3, 3, H, W) and out["depth"].shape == (3, 1, H, W) and len(out["viewspace_points"]) == 3
+    out["rgb"].sum().backward()
+    singles = [R.render_iter(**{**f, **shared}) for f in frames]
+    vis = torch.stack([s["visibility_filter"] for s in singles]).any(0)
+    rad = torch.stack([s["radii"] for s in singles]).max(0).values
+    assert torch.equal(out["visibility"], vis) and torch.equal(out["radii"], rad)
+    st = DensifyState(N, "cuda")
+    R.accumulate_densify(st, out)
+    vg = sum(v.grad for v in out["viewspace_points"])
+    assert torch.allclose(st.viewspace_grad, vg, rtol=1e-6, atol=1e-9)
+    assert torch.equal(st.visibility.bool(), vis) and torch.equal(st.radii, rad.to(torch.int32))
+    want = torch.where(vis, vg.norm(dim=1), torch.zeros_like(vg[:, 0]))
+    assert torch.allclose(st.pos_gradient_accum[:, 0], want, rtol=2e-6, atol=1e-12)
+    assert torch.equal(st.denom[:, 0], vis.float()) and torch.equal(st.max_radii2D, torch.where(vis, rad.float(), torch.zeros_like(rad.float())))
