@@ -298,20 +298,22 @@ struct Stager {
 // Cooperative cull of the staged super-batch: thread e tests entry e once against the four 8x8 blocks of the tile
 // (wave w owns block (w & 1, w >> 1)) and records one flag byte per wave.  pred(e, w) drops entries a wave does not
 // need before the geometric test.  Callers put a __syncthreads() between tile_cull and build_list.
-template <int CH, int SB, bool BIAS, typename Pred>
+// SUB: the flag byte of a kept block carries one bit per 4x4 quarter (bit sx + 2 sy) from a bounding-box test of the
+// quarter's pixel centres, for kernels that keep a survivor list per quarter; otherwise the byte is 0 / 1.
+template <int CH, int SB, bool BIAS, bool SUB, typename Pred>
 __device__ __forceinline__ void tile_cull(TileLDS<CH, SB> &L, int tid, int nb, float tx0, float ty0, Pred pred) {
     constexpr int TPE = 256 / SB;  // threads per entry (1, 2 or 4): each tests 4 / TPE of the blocks
     constexpr int BPT = 4 / TPE;
     static_assert(SB == 64 || SB == 128 || SB == 256, "super-batch sizes the 256-thread cull supports");
     const int e = tid & (SB - 1), part = tid / SB;
     unsigned char *flags = reinterpret_cast<unsigned char *>(L.keep) + 4 * e + BPT * part;
-    bool k[BPT];
+    unsigned k[BPT];
 #pragma unroll
-    for (int j = 0; j < BPT; ++j) k[j] = false;
+    for (int j = 0; j < BPT; ++j) k[j] = 0u;
     if (e < nb) {
         if (BIAS) {  // the opacity bias lifts alpha everywhere: no geometric cull
 #pragma unroll
-            for (int j = 0; j < BPT; ++j) k[j] = pred(e, BPT * part + j);
+            for (int j = 0; j < BPT; ++j) k[j] = pred(e, BPT * part + j) ? (SUB ? 15u : 1u) : 0u;
         } else {
             const float4 a0 = L.g0(e), a1 = L.g1(e);
             CullP cp;
@@ -326,12 +328,25 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB> &L, int tid, int nb, f
             for (int j = 0; j < BPT; ++j) {
                 const int ww = BPT * part + j;
                 const float x0 = tx0 + (float)(8 * (ww & 1)), y0 = ty0 + (float)(8 * (ww >> 1));
-                k[j] = pred(e, ww) && cull_test(a0.x, a0.y, a0.z, a0.w, a1.x, cp, x0, x0 + 7.f, y0, y0 + 7.f);
+                const bool kb = pred(e, ww) && cull_test(a0.x, a0.y, a0.z, a0.w, a1.x, cp, x0, x0 + 7.f, y0, y0 + 7.f);
+                if (SUB) {
+                    unsigned m = 0u;
+                    if (kb) {
+                        // distance from the centre to the pixel-centre range of each half along x and y (0 inside)
+                        const float ax0 = fmaxf(fmaxf(x0 - a0.x, a0.x - (x0 + 3.f)), 0.f), ax1 = fmaxf(fmaxf(x0 + 4.f - a0.x, a0.x - (x0 + 7.f)), 0.f);
+                        const float ay0 = fmaxf(fmaxf(y0 - a0.y, a0.y - (y0 + 3.f)), 0.f), ay1 = fmaxf(fmaxf(y0 + 4.f - a0.y, a0.y - (y0 + 7.f)), 0.f);
+                        const bool bx0_ = ax0 <= cp.hx, bx1_ = ax1 <= cp.hx, by0_ = ay0 <= cp.hy, by1_ = ay1 <= cp.hy;
+                        m = (bx0_ && by0_ ? 1u : 0u) | (bx1_ && by0_ ? 2u : 0u) | (bx0_ && by1_ ? 4u : 0u) | (bx1_ && by1_ ? 8u : 0u);
+                    }
+                    k[j] = m;
+                } else {
+                    k[j] = kb ? 1u : 0u;
+                }
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < BPT; ++j) flags[j] = k[j] ? 1 : 0;
+    for (int j = 0; j < BPT; ++j) flags[j] = (unsigned char)k[j];
 }
 
 // wave w's order-preserving survivor list from the flag bytes; returns the count.
@@ -341,7 +356,7 @@ __device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane) {
 #pragma unroll
     for (int r = 0; r < SB / WAVE; ++r) {
         const int e = r * WAVE + lane;
-        const bool keep = (L.keep[e] >> (8 * w)) & 1u;
+        const bool keep = ((L.keep[e] >> (8 * w)) & 0xffu) != 0u;
         const unsigned long long m = __ballot(keep);
         if (keep) L.list[w][cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
         cnt += __popcll(m);
@@ -364,6 +379,7 @@ blend_fwd_kernel(const BlendArgs A) {
     constexpr int SB = FwdCfg<CH>::SB;
     constexpr int U = CH <= 8 ? BLEND_FWD_U : 2;  // survivors evaluated per trip
     __shared__ TileLDS<CH, SB> L;
+    __shared__ unsigned short s_qlist[4][4][SB];  // [wave][quarter] survivor lists
     __shared__ int s_done[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -399,17 +415,40 @@ blend_fwd_kernel(const BlendArgs A) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
         if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;  // every pixel of the tile is saturated
-        tile_cull<CH, SB, BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE), [&](int, int ww) { return !s_done[ww]; });
+        tile_cull<CH, SB, BIAS, true>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE), [&](int, int ww) { return !s_done[ww]; });
         __syncthreads();
         if (!alld) {
-            const int cnt = build_list<CH, SB>(L, w, lane);
+            // one order-preserving survivor list per 4x4 quarter of the wave's block: the 16 lanes of a quarter walk
+            // their own list (a splat is evaluated only on the quarters its bounding box reaches), the wave loops to
+            // the longest of the four
+            int cq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cq[q] = 0;
+#pragma unroll
+            for (int r = 0; r < SB / WAVE; ++r) {
+                const int e = r * WAVE + lane;
+                const unsigned bits = (L.keep[e] >> (8 * w)) & 0xffu;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool keep = (bits >> q) & 1u;
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) s_qlist[w][q][cq[q] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
+                    cq[q] += __popcll(m);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int cnt = imax_(imax_(cq[0], cq[1]), imax_(cq[2], cq[3]));
+            const int myq = ((lane >> 2) & 1) + 2 * ((lane >> 5) & 1);  // quarter of this lane's pixel
+            const int mycnt = myq == 0 ? cq[0] : myq == 1 ? cq[1] : myq == 2 ? cq[2] : cq[3];
+            const unsigned short *mylist = s_qlist[w][myq];
             for (int j0 = 0; j0 < cnt; j0 += U) {
                 int e[U];
                 float4 g0[U], g1[U];
                 float alpha[U];  // 0 where the splat does not touch the pixel: no per-splat predicate registers
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    e[u] = L.list[w][j0 + u];  // slot SB (inert record: opacity 0 -> alpha 0) past the end of the list
+                    e[u] = (j0 + u < mycnt) ? (int)mylist[j0 + u] : SB;  // slot SB: inert record (opacity 0 -> alpha 0)
                     g0[u] = L.g0(e[u]);
                     g1[u] = L.g1(e[u]);
                 }
@@ -631,7 +670,7 @@ blend_bwd_pair_kernel(const BlendArgs A) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
 
-        tile_cull<CH, SB, BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+        tile_cull<CH, SB, BIAS, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
                                 [&](int e, int ww) { return top - e < s_wmax[ww]; });
         __syncthreads();
         const int cnt = build_list<CH, SB>(L, w, lane);
@@ -951,7 +990,7 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
 
-        tile_cull<CH, SB, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+        tile_cull<CH, SB, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
                                  [&](int e, int ww) { return top - e < s_wmax[ww]; });
         __syncthreads();
         const int cnt = build_list<CH, SB>(L, w, lane);  // every survivor gets a slab record: keep flags = written flags
@@ -1078,7 +1117,7 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
 #pragma unroll
                 for (int ww = 0; ww < 4; ++ww) {
                     const float x = s_acc[ww][e * NC + cc];
-                    v += ((fl >> (8 * ww)) & 1u) ? x : 0.f;
+                    v += ((fl >> (8 * ww)) & 0xffu) ? x : 0.f;
                 }
                 A.pair_buf[(size_t)slots[lo + ql] * NCP + cc] = v;
             }
@@ -1139,7 +1178,7 @@ blend_bwd_atomic_kernel(const BlendArgs A) {
         st.load_payload(A, tid);
         st.load_ids(A, tid, range.x, pos, batch + 2);
         __syncthreads();
-        tile_cull<CH, SB, BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+        tile_cull<CH, SB, BIAS, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
                                 [&](int e, int ww) { return top - e < s_wmax[ww]; });
         __syncthreads();
         const int cnt = build_list<CH, SB>(L, w, lane);
