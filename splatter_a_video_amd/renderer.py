@@ -27,13 +27,13 @@ class OrthoEnhancedRenderer:
 
     def render_iter(self, height: int, width: int, extrinsic_matrix: Tensor, position: Tensor, opacity: Tensor,
                     scaling: Tensor, rotation: Tensor, shs: Tensor, bg_color: Optional[float] = None, num_idx: int = 10,
-                    render_attributes: Optional[Dict[str, Tensor]] = None, **_unused) -> dict:
+                    render_attributes: Optional[Dict[str, Tensor]] = None, rgb: Optional[Tensor] = None, **_unused) -> dict:
         """One frame.  ``render_attributes`` maps names to per-Gaussian tensors [N, c] (the reference passes them as
-        keyword arguments listed in ``render_attributes_list``)."""
+        keyword arguments listed in ``render_attributes_list``).  ``rgb``: colours already evaluated from ``shs``
+        (``render_batch`` evaluates them once per batch: the view direction is the same constant for every frame)."""
         W, H = int(width), int(height)
-        direction = torch.zeros_like(position)
-        direction[:, 2] = 1.0                                            # :270-272 constant view direction
-        rgb = gs.compute_sh(shs, 3, direction)
+        if rgb is None:
+            rgb = self.colors(shs)
         uv, depth, conic, radius, tiles = gs.preprocess_ortho(position, scaling, rotation, extrinsic_matrix, W, H,
                                                               nearest=0.01)     # :282-321 in one launch
         idx_sorted, tile_range = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
@@ -59,13 +59,26 @@ class OrthoEnhancedRenderer:
                 "radii": radius,
                 "gs_idx": gs_idx}
 
+    @staticmethod
+    def colors(shs: Tensor) -> Tensor:
+        """SH -> RGB for the constant view direction (0, 0, 1) of the orthographic renderer (:270-272)"""
+        direction = torch.zeros(shs.shape[0], 3, dtype=torch.float32, device=shs.device)
+        direction[:, 2] = 1.0
+        return gs.compute_sh(shs, 3, direction)
+
     def render_batch(self, render_dict: dict, batch: Sequence[dict]) -> dict:
-        """``render_iter`` over the frames of a batch; features stacked, visibility OR-ed, radii max-ed (:385-433)"""
+        """``render_iter`` over the frames of a batch; features stacked, visibility OR-ed, radii max-ed (:385-433).
+        When the SH coefficients are shared by the whole batch (``shs`` in ``render_dict``) the colours are evaluated
+        once: they do not depend on the frame, and autograd sums the frames' colour gradients before the one SH
+        backward -- the same images and gradients with 1/F of the SH work."""
         feats: Dict[str, List[Tensor]] = {}
         viewspace_points, vis, radii, gs_idx = [], [], [], []
+        shared_rgb = self.colors(render_dict["shs"]) if "shs" in render_dict else None
         for b_i in batch:
             args = dict(b_i)
             args.update(render_dict)
+            if shared_rgb is not None:
+                args["rgb"] = shared_rgb
             r = self.render_iter(**args)
             for k, v in r["rendered_features_split"].items():
                 feats.setdefault(k, []).append(v)

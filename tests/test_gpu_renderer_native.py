@@ -82,3 +82,24 @@ def test_render_batch_reduction_and_densify_handoff():
     want = torch.where(vis, vg.norm(dim=1), torch.zeros_like(vg[:, 0]))
     assert torch.allclose(st.pos_gradient_accum[:, 0], want, rtol=2e-6, atol=1e-12)
     assert torch.equal(st.denom[:, 0], vis.float()) and torch.equal(st.max_radii2D, torch.where(vis, rad.float(), torch.zeros_like(rad.float())))
+
+
+def test_render_batch_shared_colours_give_the_same_gradients():
+    N, W, H = 2500, 96, 64
+    sc = make_scene(N, W, H, seed=12)
+    R = OrthoEnhancedRenderer()
+    rng = np.random.default_rng(0)
+    g = _t(rng.normal(size=(3, 3, H, W)).astype(np.float32))
+    grads = []
+    for shared in (True, False):
+        shs = _t(sc.shs, True)
+        common = dict(opacity=_t(sc.opacity), scaling=_t(sc.scale), rotation=_t(sc.rotate), height=H, width=W, extrinsic_matrix=_t(sc.extr))
+        frames = [dict(position=_t(sc.positions(f))) for f in (0, 2, 5)]
+        if shared:
+            out = R.render_batch({**common, "shs": shs}, frames)
+        else:
+            out = R.render_batch(common, [{**f, "shs": shs} for f in frames])
+        (out["rgb"] * g).sum().backward()
+        grads.append((out["rgb"].detach(), shs.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0])
+    assert torch.allclose(grads[0][1], grads[1][1], rtol=1e-5, atol=1e-6 * float(grads[1][1].abs().max()))
