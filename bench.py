@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--dynamic", action="store_true",
                     help="parameterise the scene as the reference's dynamic Gaussians and run their per-frame evaluation "
                          "inside the fused preprocess (row a15 on the path; implies the fused operators)")
+    ap.add_argument("--sync-allreduce", action="store_true",
+                    help="single gradient buffer, all-reduce between two steps (default with >1 rank: double-buffered, overlapped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -78,7 +80,7 @@ class FrameRenderer:
     """Frame-sharded DP unit: parameters replicated, gradients of all local frames accumulate into
     one flat bucket (views), one all-reduce per step."""
 
-    def __init__(self, sc, device, C_extra=0, fused=True, dynamic=False):
+    def __init__(self, sc, device, C_extra=0, fused=True, dynamic=False, overlap_allreduce=True):
         self.sc = sc
         self.fused = fused or dynamic
         self.dynamic = dynamic
@@ -108,7 +110,11 @@ class FrameRenderer:
             src["shs"] = sc.shs
         else:
             src["feature"] = sc.feature
-        self.bucket = FlatGradBucket({k: torch.as_tensor(v, device=device) for k, v in src.items()})
+        # two gradient buffers when ranks have to talk: the all-reduce of step s runs on RCCL's stream while step s+1
+        # accumulates into the other buffer
+        self.overlap = bool(overlap_allreduce) and dist.is_available() and dist.is_initialized()
+        self.bucket = FlatGradBucket({k: torch.as_tensor(v, device=device) for k, v in src.items()},
+                                     buffers=2 if self.overlap else 1)
         self.p = self.bucket.params
         self.flat_grad = self.bucket.flat_grad
         self.extr = torch.tensor(sc.extr, device=device)
@@ -179,11 +185,16 @@ class FrameRenderer:
     def step(self, offs, collective=True):
         """one gradient step: local frames forward+backward, then ONE all-reduce of the flat bucket
         (skipped when no process group exists, and in rank 0's private kernel-timing pass)"""
+        self.bucket.swap()        # double-buffered: waits for the collective that last used the buffer we switch to
         self.bucket.zero_grad()
         for off in offs:
             self.frame(off)
         if collective and dist.is_available() and dist.is_initialized():
-            self.bucket.all_reduce()
+            self.bucket.all_reduce(async_op=self.overlap)
+
+    def finish(self):
+        """all outstanding gradient collectives have completed (end of the timed region / of training)"""
+        self.bucket.wait()
 
     def check_sorts(self):
         """after the timed region: every capacity-bounded sort of the run fitted (host sync)"""
@@ -274,7 +285,7 @@ def main():
 
     clip = max(a.clip, 25 * world)
     sc = make_scene(a.gaussians, a.width, a.height, F=clip, C=a.channels, seed=1234)
-    R = FrameRenderer(sc, dev, a.channels, fused=not a.ops, dynamic=a.dynamic)
+    R = FrameRenderer(sc, dev, a.channels, fused=not a.ops, dynamic=a.dynamic, overlap_allreduce=not a.sync_allreduce)
     # rank r renders frames {f : f mod world == r} of the step's frame batch
     if a.dynamic:
         offs = [((i * world + rank) % clip) for i in range(a.frames)]      # frame times of the dynamic model
@@ -289,10 +300,12 @@ def main():
 
     for _ in range(a.warmup):
         R.step(offs)
+    R.finish()
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         R.step(offs)
+    R.finish()                # the last step's all-reduce is inside the timed region
     sync()
     dt = time.perf_counter() - t0
     R.check_sorts()   # the sync-free sorts of the timed steps all fitted their capacity (raises otherwise)
@@ -353,7 +366,7 @@ def main():
                                    f"{a.width}x{a.height} clip, fwd+bwd, ortho camera, "
                                    + ("SH deg 3 -> RGB" if R.use_sh else f"{a.channels} feature channels"),
                        "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
-                       "tile_pairs_M": M, "channels": R.C, "parallelism": f"frame-sharded dp{world}",
+                       "tile_pairs_M": M, "channels": R.C, "parallelism": f"frame-sharded dp{world}" + (", all-reduce overlapped with the next step" if R.overlap and world > 1 else ""),
                        "path": ("dynamic-Gaussian evaluation fused into the preprocess + gradient sinks" if R.dynamic else
                                 "fused frame operators + gradient sinks" if R.fused else "per-operator autograd chain"),
                        "grad_bucket_MB": round(R.flat_grad.numel() * 4 / 1e6, 1)},

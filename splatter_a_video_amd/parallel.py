@@ -27,15 +27,24 @@ class FlatGradBucket:
     """Parameters as views of one flat tensor, gradients as views of another.
 
     ``bucket.params[name]`` are leaf tensors (``requires_grad=True``) whose ``.grad`` aliases a slice of
-    ``bucket.flat_grad``; autograd accumulates in place, so after the local frames' backward passes
-    ``all_reduce()`` moves exactly one contiguous buffer."""
+    ``bucket.flat_grad``; autograd (or a kernel with a gradient sink) accumulates in place, so after the local frames'
+    backward passes ``all_reduce()`` moves exactly one contiguous buffer.
 
-    def __init__(self, tensors: Dict[str, torch.Tensor]):
+    ``buffers=2`` double-buffers the gradients: ``swap()`` at the start of a step points every ``.grad`` (and
+    ``grad(name)``) at the other buffer, ``all_reduce(async_op=True)`` at its end leaves the collective running on
+    RCCL's stream while the next step's frames fill the other buffer -- the reduction is off the critical path instead
+    of between two steps (``swap()`` waits for the collective that last used the buffer it switches to)."""
+
+    def __init__(self, tensors: Dict[str, torch.Tensor], buffers: int = 1):
+        if buffers < 1:
+            raise ValueError("buffers must be >= 1")
         names = list(tensors)
         dev = tensors[names[0]].device
         total = sum(t.numel() for t in tensors.values())
         self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grads = [torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(buffers)]
+        self.pending = [None] * buffers            # outstanding collective per buffer
+        self.active = 0
         self.params: Dict[str, torch.Tensor] = {}
         self.slices: Dict[str, Tuple[int, int]] = {}
         o = 0
@@ -46,24 +55,56 @@ class FlatGradBucket:
             with torch.no_grad():
                 v.copy_(t)
             v.requires_grad_(True)
-            v.grad = self.flat_grad[o:o + k].view(t.shape)
             self.params[n] = v
             self.slices[n] = (o, o + k)
             o += k
+        self._point_grads()
+
+    @property
+    def flat_grad(self) -> torch.Tensor:
+        return self.flat_grads[self.active]
+
+    def _point_grads(self) -> None:
+        for n, v in self.params.items():
+            v.grad = self.grad(n)
+
+    def swap(self) -> None:
+        """make the next buffer the active one (no-op with a single buffer), after its last collective has finished"""
+        if len(self.flat_grads) == 1:
+            self.wait(0)
+            return
+        self.active = (self.active + 1) % len(self.flat_grads)
+        self.wait(self.active)
+        self._point_grads()
 
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
 
-    def all_reduce(self, average: bool = False) -> None:
-        """One collective per step; a no-op for a single process."""
+    def all_reduce(self, average: bool = False, async_op: bool = False) -> None:
+        """One collective per step over the active buffer; a no-op for a single process.  ``async_op``: return at once,
+        ``wait()`` / ``swap()`` synchronise later."""
         if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)  # world size 1: identity, still exercises RCCL
-            if average:
-                self.flat_grad.div_(dist.get_world_size())
+            flat = self.flat_grad
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)  # world size 1: identity, still exercises RCCL
+            if async_op:
+                self.pending[self.active] = (work, average)
+            elif average:
+                flat.div_(dist.get_world_size())
 
-    def grad(self, name: str) -> torch.Tensor:
+    def wait(self, buffer: int = None) -> None:
+        """finish the outstanding collective of ``buffer`` (default: all buffers)"""
+        for b in (range(len(self.flat_grads)) if buffer is None else (buffer,)):
+            if self.pending[b] is not None:
+                work, average = self.pending[b]
+                work.wait()
+                if average:
+                    self.flat_grads[b].div_(dist.get_world_size())
+                self.pending[b] = None
+
+    def grad(self, name: str, buffer: int = None) -> torch.Tensor:
         a, b = self.slices[name]
-        return self.flat_grad[a:b].view(self.params[name].shape)
+        flat = self.flat_grads[self.active if buffer is None else buffer]
+        return flat[a:b].view(self.params[name].shape)
 
 
 def reduce_visibility(visibility: torch.Tensor, radii: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

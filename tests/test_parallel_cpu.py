@@ -89,3 +89,49 @@ def test_two_rank_allreduce_matches_single_process(tmp_path):
     flat_ref = torch.cat([ref[n].grad.reshape(-1) for n in ref])
     torch.testing.assert_close(got["flat"], flat_ref, rtol=1e-5, atol=1e-5)
     assert bool(got["vis"].all()) and bool((got["rad"] == 2).all())
+
+
+def _worker_double(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = FlatGradBucket(_params(), buffers=2)
+        results = []
+        for step in range(4):                       # the collective of step s runs while step s+1 fills the other buffer
+            b.swap()
+            b.zero_grad()
+            for f in frames_of_rank(list(range(10 * step, 10 * step + 6)), rank, world):
+                _toy_render(b.params, f).backward()
+            b.all_reduce(async_op=True)
+            results.append(b.active)
+        b.wait()
+        if rank == 0:
+            torch.save({"g2": b.flat_grads[results[2]].clone(), "g3": b.flat_grads[results[3]].clone(), "order": results}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_double_buffered_async_allreduce(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_double, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["order"] == [1, 0, 1, 0]
+    for step, key in ((2, "g2"), (3, "g3")):
+        ref = FlatGradBucket(_params())
+        for f in range(10 * step, 10 * step + 6):
+            _toy_render(ref.params, f).backward()
+        assert torch.allclose(got[key], ref.flat_grad, rtol=1e-5, atol=1e-6)
+
+
+def test_single_buffer_swap_is_a_noop():
+    b = FlatGradBucket(_params())
+    g = b.params["xyz"].grad
+    b.swap()
+    assert b.active == 0 and b.params["xyz"].grad.data_ptr() == g.data_ptr()
+    b2 = FlatGradBucket(_params(), buffers=2)
+    p0 = b2.params["shs"].grad.data_ptr()
+    b2.swap()
+    assert b2.active == 1 and b2.params["shs"].grad.data_ptr() != p0 and b2.grad("shs").data_ptr() == b2.params["shs"].grad.data_ptr()
+    _toy_render(b2.params, 1).backward()
+    assert b2.flat_grads[1].abs().sum() > 0 and b2.flat_grads[0].abs().sum() == 0
