@@ -22,6 +22,9 @@
 
 #define BIN_BLOCK 256
 #define BIN_MAX_NB 512          // rows of the count matrix (= workgroups of K1/K3)
+#ifndef BIN_CHUNK
+#define BIN_CHUNK 512           // Gaussians per row (chunk) before BIN_MAX_NB caps the row count
+#endif
 #define BIN_LDS_TILES 12288     // <= 48 KB of LDS counters; larger tile grids use global atomics
 #define SORT_BLOCK 256
 #define SORT_LDS_KEYS 2048      // 16 KB of LDS per sort workgroup (larger tiles sort in their global segment)
@@ -44,7 +47,7 @@ static BinPlan make_plan(int P, int W, int H) {
     p.gy = (H + TILE - 1) / TILE;
     p.T = p.gx * p.gy;
     p.lds = p.T <= BIN_LDS_TILES;
-    int nb = (P + 511) / 512;
+    int nb = (P + BIN_CHUNK - 1) / BIN_CHUNK;
     if (nb < 1) nb = 1;
     if (nb > BIN_MAX_NB) nb = BIN_MAX_NB;
     if (!p.lds) nb = 1;  // global-atomic path keeps a single row

@@ -186,7 +186,7 @@ def test_sort_gaussian_ties_and_empty(gpu, oracle_mod):
 
 
 # ------------------------------------------------------------------ alpha blending
-def _blend_case(gpu, o, N, W, H, C, bg, variant, seed=0, K=4, mode="atomic"):
+def _blend_case(gpu, o, N, W, H, C, bg, variant, seed=0, K=4, mode="atomic", strict=True):
     """mode "atomic": idx_sorted comes from the oracle (plain tensor) -> wave-reduced atomics backward;
     mode "pair": idx_sorted comes from gs.sort_gaussian (bit-identical, carries the pair map) ->
     atomic-free backward."""
@@ -217,7 +217,11 @@ def _blend_case(gpu, o, N, W, H, C, bg, variant, seed=0, K=4, mode="atomic"):
     else:
         out = gs.alpha_blending(t["uv"], t["conic"], t["opacity"], t["feat"], t_idx, t_tr, bg, W, H, ndc, andc)
     assert out.shape == (C, H, W)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), res_r[0], rtol=IMG_RTOL, atol=IMG_ATOL)
+    if strict:
+        np.testing.assert_allclose(out.detach().cpu().numpy(), res_r[0], rtol=IMG_RTOL, atol=IMG_ATOL)
+    else:   # a pixel may sit on a discrete decision (alpha = 1/255, T = 1e-4) that expf rounding flips
+        bad = np.abs(out.detach().cpu().numpy() - res_r[0]) > (IMG_ATOL + IMG_RTOL * np.abs(res_r[0]))
+        assert bad.mean() < 1e-3, bad.mean()
     g = rng.normal(size=(C, H, W)).astype(np.float32)
     (out * dev(g, gpu)).sum().backward()
     gr = o.alpha_blending_backward(G["uv"], G["conic"], sc.opacity, feat, G["idx"], G["tr"], bg, W, H, res_r[1], res_r[2], g,
@@ -438,3 +442,16 @@ def test_tiny_images(gpu, oracle_mod, W, H):
     assert (idx.cpu().numpy() == G["idx"]).all() and (tr.cpu().numpy() == G["tr"]).all()
     out = gs.alpha_blending(dev(G["uv"], gpu), dev(G["conic"], gpu), dev(sc.opacity, gpu), dev(feat, gpu), idx, tr, 0.1, W, H)
     np.testing.assert_allclose(out.cpu().numpy(), out_r, rtol=IMG_RTOL, atol=IMG_ATOL)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_alpha_blending_random_configurations(gpu, oracle_mod, seed):
+    """seeded sweep over image shapes (not multiples of the tile), Gaussian counts, channel counts that land in every
+    kernel instantiation, background values and variants -- pair mode (matrix-core backward where it applies)"""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(17, 230)), int(rng.integers(17, 150))
+    N = int(rng.integers(50, 6000))
+    C = int(rng.choice([1, 2, 3, 4, 7, 8, 9, 16, 19, 20, 21, 33]))
+    variant = str(rng.choice(["plain", "plain", "enh", "trunc", "bias"]))
+    bg = float(rng.choice([0.0, 1.0, 0.37]))
+    _blend_case(gpu, oracle_mod, N, W, H, C, bg, variant, seed=seed, K=int(rng.integers(1, 12)), mode="pair", strict=False)
