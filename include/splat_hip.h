@@ -117,8 +117,11 @@ int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *ra
 size_t splat_blend_pack_floats(int C);
 int splat_alpha_blending_forward(int P, int C, const float *uv, const float *conic, const float *opacity,
                                  const float *feature, const float *opacity_bias, const int32_t *idx_sorted,
-                                 const int32_t *tile_range, float bg, int W, int H, int K, int enable_truncation,
-                                 float *out, float *final_T, int32_t *ncontrib,
+                                 const int32_t *tile_range, float bg,
+                                 const float *bg_channels /*NULL, or a background per channel [C] overriding bg: several
+                                    feature sets of one geometry composited in ONE pass (depth with bg 1 next to rgb)*/,
+                                 int W, int H, int K, int enable_truncation, float *out, float *final_T,
+                                 int32_t *ncontrib,
                                  int32_t *gs_idx /*[H,W,K] (unused slots are set to -1), or NULL*/,
                                  float *pack_scratch, splat_stream_t stream);
 /* dL_dfeature is [P,C]; dL_dopacity_bias NULL unless bias given; dL_dabs_uv may be NULL (the sums of

@@ -64,6 +64,7 @@ struct BlendArgs {
     const int *idx_sorted;
     const int2 *tile_range;
     float bg;
+    const float *bgc;  // optional per-channel background [C] (forward); NULL: bg for every channel
     int W, H, gx;
     int K, trunc;
     // forward outputs
@@ -499,7 +500,7 @@ blend_fwd_kernel(const BlendArgs A) {
         A.ncontrib[pix] = last;
 #pragma unroll
         for (int k = 0; k < CH; ++k)
-            if (k < cn) A.out[(size_t)(A.c0 + k) * HW + pix] = F[k] + T * A.bg;
+            if (k < cn) A.out[(size_t)(A.c0 + k) * HW + pix] = F[k] + T * (A.bgc ? A.bgc[A.c0 + k] : A.bg);
         if (ENH)
             for (int l = layer; l < A.K; ++l) A.gs_idx[pix * A.K + l] = -1;  // unused slots (reference: -1 init)
     }
@@ -1337,10 +1338,10 @@ extern "C" size_t splat_blend_pair_floats(int C, int has_bias) {
 // ================================================================== C ABI
 extern "C" int splat_alpha_blending_forward(int P, int C, const float *uv, const float *conic, const float *opacity,
                                             const float *feature, const float *opacity_bias,
-                                            const int32_t *idx_sorted, const int32_t *tile_range, float bg, int W,
-                                            int H, int K, int enable_truncation, float *out, float *final_T,
-                                            int32_t *ncontrib, int32_t *gs_idx, float *pack_scratch,
-                                            splat_stream_t stream) {
+                                            const int32_t *idx_sorted, const int32_t *tile_range, float bg,
+                                            const float *bg_channels, int W, int H, int K, int enable_truncation,
+                                            float *out, float *final_T, int32_t *ncontrib, int32_t *gs_idx,
+                                            float *pack_scratch, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && C >= 1 && W > 0 && H > 0, "bad sizes");
     SPLAT_CHECK_ARG(tile_range && out && final_T && ncontrib, "null pointer");
     SPLAT_CHECK_ARG(P == 0 || (uv && conic && opacity && feature && pack_scratch), "null pointer");
@@ -1350,7 +1351,7 @@ extern "C" int splat_alpha_blending_forward(int P, int C, const float *uv, const
     A.P = P; A.C = C;
     A.uv = (const float2 *)uv; A.conic = conic; A.opacity = opacity; A.feature = feature; A.bias = opacity_bias;
     A.idx_sorted = idx_sorted; A.tile_range = (const int2 *)tile_range;
-    A.bg = bg; A.W = W; A.H = H; A.gx = (W + TILE - 1) / TILE;
+    A.bg = bg; A.bgc = bg_channels; A.W = W; A.H = H; A.gx = (W + TILE - 1) / TILE;
     A.K = enh ? K : 0; A.trunc = enable_truncation ? 1 : 0;
     A.out = out; A.final_T = final_T; A.ncontrib = ncontrib; A.gs_idx = gs_idx;
     A.pack = pack_scratch;

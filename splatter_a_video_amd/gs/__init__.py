@@ -4,7 +4,7 @@ through the top-level ``dptr`` shim package of this repository."""
 from .point_ops import (compute_cov3d, compute_sh, compute_sh_free, ewa_project, ewa_project_ortho, project_point,
                         project_point_ortho)
 from .fused_ops import compute_sh_into, preprocess_ortho
-from .raster_ops import (SortStatus, alpha_blending, alpha_blending_enhanced, alpha_blending_with_bias, rasterization,
+from .raster_ops import (SortStatus, alpha_blending, alpha_blending_shared, alpha_blending_enhanced, alpha_blending_with_bias, rasterization,
                          sort_gaussian, sort_gaussian_capped)
 
 __all__ = [
@@ -24,6 +24,7 @@ __all__ = [
     # fused per-frame operators of the MI355X renderer
     "preprocess_ortho",
     "compute_sh_into",
+    "alpha_blending_shared",
     "sort_gaussian_capped",
     "SortStatus",
 ]

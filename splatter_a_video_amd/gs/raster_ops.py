@@ -137,8 +137,8 @@ class _AlphaBlend(torch.autograd.Function):
         pack = torch.empty(max(P, 1) * L.lib().splat_blend_pack_floats(C), dtype=torch.float32, device=dev)
         L.check(L.lib().splat_alpha_blending_forward(
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias_c),
-            L.ptr(idx_sorted), L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ci(K), L.ci(1 if trunc else 0),
-            L.ptr(out), L.ptr(final_T), L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.stream()))
+            L.ptr(idx_sorted), L.ptr(tile_range), L.cf(bg), L.ptr(None), L.ci(W), L.ci(H), L.ci(K),
+            L.ci(1 if trunc else 0), L.ptr(out), L.ptr(final_T), L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.stream()))
         ctx.meta = (float(bg), int(W), int(H), bias is not None, ndc is not None, abs_ndc is not None)
         if pairmap is not None and (pairmap[0].numel() != P or pairmap[1].numel() != idx_sorted.numel()):
             pairmap = None
@@ -224,6 +224,130 @@ def alpha_blending_with_bias(uv: Tensor, conic: Tensor, opacity: Tensor, feature
         raise ValueError("opacity_bias is required")
     return _AlphaBlend.apply(uv, conic, opacity, feature, opacity_bias, idx_sorted, title_bins, bg, W, H, ndc,
                              abs_ndc, 0, False)
+
+
+# ------------------------------------------------------------------ several feature sets, one forward pass
+class _BlendShared(torch.autograd.Function):
+    """inputs: uv, conic, opacity, idx_sorted, tile_range, W, H, K, ndc, abs_ndc, bgs, detach_opacity, taps, *features"""
+
+    @staticmethod
+    def forward(ctx, uv, conic, opacity, idx_sorted, tile_range, W, H, K, ndc, abs_ndc, bgs, detach_opacity, taps, *features):
+        uv = L.need(uv, "uv")
+        conic = L.need(conic, "conic")
+        opacity = L.need(opacity, "opacity")
+        pairmap = getattr(idx_sorted, "_splat_pairmap", None)
+        idx_sorted = L.need(idx_sorted, "idx_sorted", torch.int32)
+        tile_range = L.need(tile_range, "tile_range", torch.int32)
+        feats = [L.need(f, f"features[{i}]") for i, f in enumerate(features)]
+        P = uv.shape[0]
+        if any(f.dim() != 2 or f.shape[0] != P for f in feats):
+            raise ValueError("every feature set must be [P, C_i]")
+        widths = [int(f.shape[1]) for f in feats]
+        C = sum(widths)
+        dev = uv.device
+        allf = torch.cat(feats, dim=1) if len(feats) > 1 else feats[0]
+        bgc = torch.cat([torch.full((w,), float(b), dtype=torch.float32, device=dev) for w, b in zip(widths, bgs)])
+        out = torch.empty(C, H, W, dtype=torch.float32, device=dev)
+        final_T = torch.empty(H, W, dtype=torch.float32, device=dev)
+        ncontrib = torch.empty(H, W, dtype=torch.int32, device=dev)
+        gs_idx = torch.empty(H, W, K, dtype=torch.int32, device=dev) if K > 0 else None
+        pack = torch.empty(max(P, 1) * L.lib().splat_blend_pack_floats(C), dtype=torch.float32, device=dev)
+        L.check(L.lib().splat_alpha_blending_forward(
+            L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(allf), L.ptr(None), L.ptr(idx_sorted),
+            L.ptr(tile_range), L.cf(0.0), L.ptr(bgc), L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(final_T),
+            L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.stream()))
+        if pairmap is not None and (pairmap[0].numel() != P or pairmap[1].numel() != idx_sorted.numel()):
+            pairmap = None
+        ctx.pairmap = pairmap
+        ctx.meta = (int(W), int(H), tuple(float(b) for b in bgs), tuple(bool(d) for d in detach_opacity),
+                    tuple(bool(t) for t in taps), ndc is not None, abs_ndc is not None, widths)
+        ctx.save_for_backward(uv, conic, opacity, idx_sorted, tile_range, final_T, ncontrib, *feats)
+        ctx.set_materialize_grads(False)
+        imgs = tuple(out[o:o + w] for o, w in zip(_offsets(widths), widths))
+        extra = (ncontrib,) + ((gs_idx,) if gs_idx is not None else ())
+        ctx.mark_non_differentiable(*extra)
+        return imgs + extra
+
+    @staticmethod
+    def backward(ctx, *grads):
+        W, H, bgs, detach, taps, has_ndc, has_abs, widths = ctx.meta
+        uv, conic, opacity, idx_sorted, tile_range, final_T, ncontrib = ctx.saved_tensors[:7]
+        feats = ctx.saved_tensors[7:]
+        P, dev = uv.shape[0], uv.device
+        pm = ctx.pairmap
+        M = idx_sorted.numel()
+        lib = L.lib()
+        duv_t = dconic_t = dop_t = dndc = dabs_t = None
+        dfeats = [None] * len(feats)
+        for s, (f, g) in enumerate(zip(feats, grads[:len(feats)])):
+            if g is None:
+                continue
+            C = f.shape[1]
+            g = L.need(g, "dL_dout")
+            want_abs = has_abs and taps[s]
+            if pm is not None and M > 0:
+                alloc = torch.empty
+                goff, slot_sorted = pm
+                scratch = torch.empty(M * lib.splat_blend_pair_floats(C, 0), dtype=torch.float32, device=dev)
+            else:
+                alloc = torch.zeros
+                goff = slot_sorted = scratch = None
+            duv = alloc(P, 2, dtype=torch.float32, device=dev)
+            dabs = alloc(P, 2, dtype=torch.float32, device=dev) if want_abs else None
+            dconic = alloc(P, 3, dtype=torch.float32, device=dev)
+            dop = alloc(opacity.shape, dtype=torch.float32, device=dev)
+            dfeat = alloc(P, C, dtype=torch.float32, device=dev)
+            pack = torch.empty(max(P, 1) * lib.splat_blend_pack_floats(C), dtype=torch.float32, device=dev)
+            L.check(lib.splat_alpha_blending_backward(
+                L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(f), L.ptr(None), L.ptr(idx_sorted),
+                L.ptr(tile_range), L.cf(bgs[s]), L.ci(W), L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(g), L.ptr(duv),
+                L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(None), L.ptr(goff), L.ptr(slot_sorted),
+                L.ptr(scratch), L.ptr(pack), L.ci(0), L.stream()))
+            dfeats[s] = dfeat
+            duv_t = duv if duv_t is None else duv_t + duv
+            dconic_t = dconic if dconic_t is None else dconic_t + dconic
+            if not detach[s]:
+                dop_t = dop if dop_t is None else dop_t + dop
+            if taps[s]:
+                half = _half_wh(W, H, dev)
+                if has_ndc:
+                    t = duv * half[None, :]
+                    dndc = t if dndc is None else dndc + t
+                if want_abs:
+                    t = dabs * half[None, :]
+                    dabs_t = t if dabs_t is None else dabs_t + t
+        return (duv_t, dconic_t, dop_t, None, None, None, None, None, dndc, dabs_t, None, None, None) + tuple(dfeats)
+
+
+def _offsets(widths):
+    o, out = 0, []
+    for w in widths:
+        out.append(o)
+        o += w
+    return out
+
+
+def alpha_blending_shared(uv: Tensor, conic: Tensor, opacity: Tensor, features, idx_sorted: Tensor, title_bins: Tensor,
+                          bgs, W: int, H: int, ndc: Optional[Tensor] = None, abs_ndc: Optional[Tensor] = None, K: int = 0,
+                          detach_opacity=None, taps=None):
+    """Several feature sets of ONE geometry composited in a single forward pass (extension).
+
+    Equivalent to ``alpha_blending(uv, conic, opacity[.detach()], features[i], idx_sorted, title_bins, bgs[i], W, H,
+    ndc or ndc.detach())`` for every i (``detach_opacity[i]``: that set does not feed the opacity gradient;
+    ``taps[i]``: that set feeds the ``ndc`` / ``abs_ndc`` gradient taps), but the transmittance chain, the culling and
+    the record gathers are paid once: this is how the reference's renderer uses its three blends
+    (dptr_ortho_enhanced.py:331-375).  Backward: one native backward per set.  Returns
+    ``(images..., ncontrib)`` plus ``gs_idx[H,W,K]`` when ``K > 0`` (``alpha_blending_enhanced``'s extra outputs)."""
+    features = list(features)
+    n = len(features)
+    if n < 1 or len(bgs) != n:
+        raise ValueError("need one background value per feature set")
+    detach_opacity = [False] * n if detach_opacity is None else list(detach_opacity)
+    taps = [i == 0 for i in range(n)] if taps is None else list(taps)
+    if len(detach_opacity) != n or len(taps) != n:
+        raise ValueError("detach_opacity / taps need one entry per feature set")
+    return _BlendShared.apply(uv, conic, opacity, idx_sorted, title_bins, int(W), int(H), int(K), ndc, abs_ndc, tuple(bgs),
+                              tuple(detach_opacity), tuple(taps), *features)
 
 
 # ------------------------------------------------------------------ rasterization (5-op chain)

@@ -40,19 +40,22 @@ class OrthoEnhancedRenderer:
         ndc = torch.zeros_like(uv, requires_grad=True)
         abs_ndc = torch.zeros_like(uv, requires_grad=True)
         bg = self.bg_color if bg_color is None else bg_color
-        rendered, ncontrib, gs_idx = gs.alpha_blending_enhanced(uv, conic, opacity, rgb, idx_sorted, tile_range, bg, W, H,
-                                                                ndc, abs_ndc, K=num_idx)
-        out = {"rgb": rendered}
-        out["depth"] = gs.alpha_blending(uv, conic, opacity, depth, idx_sorted, tile_range, 1.0, W, H, ndc.detach())
-        if render_attributes:
-            names = list(render_attributes)
-            feats = torch.cat([render_attributes[k] for k in names], dim=-1)
-            extra = gs.alpha_blending(uv, conic, opacity.detach(), feats, idx_sorted, tile_range, 0.0, W, H, ndc.detach())
-            start = 0
-            for k in names:
-                c = render_attributes[k].shape[-1]
-                out[k] = extra[start:start + c]
-                start += c
+        # the three blends of the reference (rgb enhanced with the taps; depth, bg = 1, ndc.detach(); attributes,
+        # bg = 0, opacity.detach(), ndc.detach()) share one geometry: ONE forward pass, one native backward per set
+        sets, bgs, detach, taps = [rgb, depth], [bg, 1.0], [False, False], [True, False]
+        names = list(render_attributes) if render_attributes else []
+        if names:
+            sets.append(torch.cat([render_attributes[k] for k in names], dim=-1))
+            bgs.append(0.0); detach.append(True); taps.append(False)
+        res = gs.alpha_blending_shared(uv, conic, opacity, sets, idx_sorted, tile_range, bgs, W, H, ndc, abs_ndc, K=num_idx,
+                                       detach_opacity=detach, taps=taps)
+        gs_idx = res[-1]
+        out = {"rgb": res[0], "depth": res[1]}
+        start = 0
+        for k in names:
+            c = render_attributes[k].shape[-1]
+            out[k] = res[2][start:start + c]
+            start += c
         return {"rendered_features_split": out,
                 "viewspace_points": abs_ndc if self.densify_abs_grad_enable else ndc,
                 "visibility_filter": radius > 0,

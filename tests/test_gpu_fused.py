@@ -144,3 +144,37 @@ def test_sort_gaussian_capped_matches_sort_gaussian():
     _, _, st3 = gs.sort_gaussian_capped(uv, depth, W, H, radius, capacity=M // 2)
     with pytest.raises(Exception):
         st3.check()
+
+
+def test_alpha_blending_shared_equals_separate_blends():
+    """three feature sets in one forward pass == the reference renderer's three calls: images bit-identical, gradients
+    and taps equal (same native backward per set, different summation order of the totals)"""
+    N, W, H, K = 12_000, 208, 144, 12
+    sc = make_scene(N, W, H, C=3, seed=21)
+    rng = np.random.default_rng(3)
+    attrs = rng.uniform(-1, 1, size=(N, 19)).astype(np.float32)
+    uv0, depth0, conic0, radius, tiles = gs.preprocess_ortho(_t(sc.positions(1)), _t(sc.scale), _t(sc.rotate), _t(sc.extr), W, H,
+                                                             nearest=0.01)
+    idx, tr = gs.sort_gaussian(uv0, depth0, W, H, radius, tiles)
+    g = [_t(rng.normal(size=(c, H, W)).astype(np.float32)) for c in (3, 1, 19)]
+    res = []
+    for shared in (False, True):
+        uv = uv0.detach().requires_grad_(); conic = conic0.detach().requires_grad_(); dep = depth0.detach().requires_grad_()
+        op = _t(sc.opacity, True); rgb = _t(sc.feature, True); at = _t(attrs, True)
+        ndc = torch.zeros_like(uv, requires_grad=True); andc = torch.zeros_like(uv, requires_grad=True)
+        if shared:
+            i1, i2, i3, nc, gi = gs.alpha_blending_shared(uv, conic, op, [rgb, dep, at], idx, tr, [0.25, 1.0, 0.0], W, H, ndc, andc,
+                                                          K=K, detach_opacity=[False, False, True], taps=[True, False, False])
+        else:
+            i1, nc, gi = gs.alpha_blending_enhanced(uv, conic, op, rgb, idx, tr, 0.25, W, H, ndc, andc, K=K)
+            i2 = gs.alpha_blending(uv, conic, op, dep, idx, tr, 1.0, W, H, ndc.detach())
+            i3 = gs.alpha_blending(uv, conic, op.detach(), at, idx, tr, 0.0, W, H, ndc.detach())
+        ((i1 * g[0]).sum() + (i2 * g[1]).sum() + (i3 * g[2]).sum()).backward()
+        res.append(dict(imgs=[i1.detach(), i2.detach(), i3.detach()], nc=nc, gi=gi,
+                        grads=[uv.grad, conic.grad, op.grad, rgb.grad, dep.grad, at.grad, ndc.grad, andc.grad]))
+    a, b = res
+    for x, y in zip(a["imgs"], b["imgs"]):
+        assert torch.equal(x, y)
+    assert torch.equal(a["nc"], b["nc"]) and torch.equal(a["gi"], b["gi"])
+    for x, y in zip(a["grads"], b["grads"]):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-6 * float(x.abs().max()))

@@ -46,3 +46,18 @@ timeit("rgb plain 3ch fwd+bwd (ndc)", rgb_plain)
 timeit("rgb enhanced K=20 fwd+bwd (ndc+abs_ndc)", rgb_enh)
 timeit("depth 1ch fwd+bwd", dep)
 timeit("attrs 19ch fwd+bwd", att)
+
+
+def flow_separate():
+    ndc = torch.zeros_like(uv, requires_grad=True); andc = torch.zeros_like(uv, requires_grad=True)
+    i1, nc, gi = gs.alpha_blending_enhanced(uvg, cg, op, rgb, idx, tr, 0.0, W, H, ndc, andc, K=20)
+    i2 = gs.alpha_blending(uvg, cg, op, dg, idx, tr, 1.0, W, H, ndc.detach())
+    i3 = gs.alpha_blending(uvg, cg, op.detach(), attrs, idx, tr, 0.0, W, H, ndc.detach())
+    torch.autograd.backward([i1, i2, i3], [g3, g1, g19])
+def flow_shared():
+    ndc = torch.zeros_like(uv, requires_grad=True); andc = torch.zeros_like(uv, requires_grad=True)
+    i1, i2, i3, nc, gi = gs.alpha_blending_shared(uvg, cg, op, [rgb, dg, attrs], idx, tr, [0.0, 1.0, 0.0], W, H, ndc, andc, K=20,
+                                                  detach_opacity=[False, False, True], taps=[True, False, False])
+    torch.autograd.backward([i1, i2, i3], [g3, g1, g19])
+timeit("three blends of render_iter, separate calls", flow_separate)
+timeit("three blends of render_iter, one shared forward", flow_shared)
