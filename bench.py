@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak (guides/MI355X_MICROARCH.md); ~6300 GB
 # HBM/fabric bytes per launch from PMC counters, measured offline with tools/pmc_run.sh (separate --pmc
 # passes, read requests sized by TCC_EA0_RDREQ_{32B,64B,128B}, WRITE_SIZE in KiB) at configs[1];
 # only reported when the bench runs that configuration.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")
 PMC_KERNEL_NAMES = {"blend_bwd": "blend_bwd_mfma_kernel", "blend_fwd": "blend_fwd_kernel", "tile_sort": "tile_sort_kernel",
                     "pair_reduce": "pair_reduce_kernel", "sh_fwd": "sh_fwd_kernel", "sh_bwd": "sh_bwd_kernel"}
 
@@ -345,7 +345,7 @@ def main():
             default_cfg = (a.gaussians, a.width, a.height, a.channels) == (300000, 854, 480, 0)
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, default_cfg),
-                        "traffic_source": "profiles/r01g_pmc_traffic.json (rocprofv3 --pmc, offline)" if default_cfg else None,
+                        "traffic_source": "profiles/r01h_pmc_traffic.json (rocprofv3 --pmc, offline)" if default_cfg else None,
                         "avg_us": kernels[dom]["avg_us"], "alg_bytes_per_launch": int(kernel_bytes(dom, a.gaussians, M, HW, R.C, T, R.use_sh))}
             is_bwd = lambda k: k.endswith("_bwd") or k == "pair_reduce"
             fwd_ms = sum(kernels[k]["avg_us"] for k in kernels if not is_bwd(k)) / 1e3
