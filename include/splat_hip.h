@@ -97,13 +97,15 @@ size_t splat_bin_scratch_bytes(int P, int W, int H);
 /* gcount[P] (optional, may be NULL): number of tiles each Gaussian touches (0 when radius <= 0). */
 int splat_bin_count(int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
                     int32_t *tile_range, int32_t *M_out, int32_t *gcount, splat_stream_t stream);
-/* Pair map (optional; goff_incl, owner, slot_sorted all given or all NULL): with the INCLUSIVE
- * prefix sum goff_incl[P] of gcount, every (Gaussian, tile) pair owns the slot goff_excl[id] + k (k-th tile,
- * row-major inside the splat's tile rectangle); the sort then also emits slot_sorted[M] = slot of each
- * sorted entry (owner[M] is workspace: Gaussian id of each slot).  The atomic-free blend backward consumes it. */
+/* Pair map (optional; goff_incl, owner, slot_sorted all given or all NULL): the sort WRITES goff_incl[P], the
+ * INCLUSIVE prefix sum of the tiles each Gaussian touches (the scan is fused into the count / scatter kernels: chunk
+ * totals in splat_bin_count, chunk offsets + a workgroup scan in the scatter).  Every (Gaussian, tile) pair owns the
+ * slot goff_excl[id] + k (k-th tile, row-major inside the splat's tile rectangle); the sort also emits
+ * slot_sorted[M] = slot of each sorted entry (owner[M] is workspace: Gaussian id of each slot).  The atomic-free
+ * blend backward consumes goff_incl and slot_sorted. */
 int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
                    void *scratch, const int32_t *tile_range, int64_t capacity, uint64_t *keys,
-                   int32_t *idx_sorted, int32_t *overflow_out, const int32_t *goff_incl,
+                   int32_t *idx_sorted, int32_t *overflow_out, int32_t *goff_incl /*out*/,
                    int32_t *owner, int32_t *slot_sorted, splat_stream_t stream);
 
 /* ---- alpha blending : replaces alphaBlendingForward/Backward, ...Enhanced, ...WithBias
@@ -139,7 +141,10 @@ int splat_alpha_blending_backward(int P, int C, const float *uv, const float *co
                                   const int32_t *tile_range, float bg, int W, int H, const float *final_T,
                                   const int32_t *ncontrib, const float *dL_dout, float *dL_duv, float *dL_dabs_uv,
                                   float *dL_dconic, float *dL_dopacity, float *dL_dfeature,
-                                  float *dL_dopacity_bias, const int32_t *goff_incl, const int32_t *slot_sorted,
+                                  float *dL_dopacity_bias,
+                                  float *dL_dndc /*NULL, or (pair mode) the tap dL_duv * [W/2, H/2] written alongside*/,
+                                  float *dL_dabs_ndc /*NULL, or (pair mode, with dL_dabs_uv) its abs twin*/,
+                                  const int32_t *goff_incl, const int32_t *slot_sorted,
                                   float *pair_scratch, float *pack_scratch,
                                   int pack_is_valid /*pack_scratch still holds the forward's records (C <= 32)*/,
                                   splat_stream_t stream);

@@ -26,6 +26,7 @@
 #define BIN_CHUNK 512           // Gaussians per row (chunk) before BIN_MAX_NB caps the row count
 #endif
 #define BIN_LDS_TILES 12288     // <= 48 KB of LDS counters; larger tile grids use global atomics
+#define BIN_GLOBAL_BLOCKS 2048   // grid of K1/K3 on the global-atomic path
 #define SORT_BLOCK 256
 #define SORT_LDS_KEYS 2048      // 16 KB of LDS per sort workgroup (larger tiles sort in their global segment)
 
@@ -34,7 +35,8 @@ struct BinPlan {
     int NB;        // number of Gaussian chunks (= workgroups of K1/K3)
     int chunk;     // Gaussians per chunk
     bool lds;      // LDS histogram path
-    size_t off_matrix, off_tilecount, off_total;  // byte offsets inside scratch
+    int nchunk;    // workgroups of K1/K3 on the path in use (NB, or the global-atomic path's own grid)
+    size_t off_matrix, off_tilecount, off_total, off_chunksum;  // byte offsets inside scratch
     size_t bytes;
 };
 
@@ -60,6 +62,9 @@ static BinPlan make_plan(int P, int W, int H) {
     p.off_tilecount = o; o += (size_t)p.T * sizeof(int);
     o = (o + 255) & ~(size_t)255;
     p.off_total = o; o += 256;
+    p.nchunk = p.lds ? p.NB : imax(1, imin((P + BIN_BLOCK - 1) / BIN_BLOCK, BIN_GLOBAL_BLOCKS));
+    p.off_chunksum = o; o += (size_t)(p.nchunk + 1) * sizeof(int);  // pairs per chunk -> exclusive chunk offsets
+    o = (o + 255) & ~(size_t)255;
     p.bytes = o;
     return p;
 }
@@ -68,9 +73,11 @@ static BinPlan make_plan(int P, int W, int H) {
 template <bool LDS>
 __global__ void __launch_bounds__(BIN_BLOCK)
 bin_count_kernel(int P, const float2 *__restrict__ uv, const int *__restrict__ radius, int gx, int gy, int T,
-                 int chunk, int *__restrict__ matrix, int *__restrict__ gcount) {
+                 int chunk, int *__restrict__ matrix, int *__restrict__ gcount, int *__restrict__ chunk_sum) {
     extern __shared__ __attribute__((aligned(16))) int cnt[];
+    __shared__ int wave_pairs[BIN_BLOCK / 64];
     const int wg = blockIdx.x;
+    int pairs = 0;  // this thread's share of the chunk's pair count
     if (LDS) {
         for (int t = threadIdx.x; t < T; t += BIN_BLOCK) cnt[t] = 0;
         __syncthreads();
@@ -86,14 +93,24 @@ bin_count_kernel(int P, const float2 *__restrict__ uv, const int *__restrict__ r
         int x0, y0, x1, y1;
         tile_rect(q.x, q.y, r, gx, gy, x0, y0, x1, y1);
         if (gcount) gcount[i] = (x1 - x0) * (y1 - y0);
+        pairs += (x1 - x0) * (y1 - y0);
         for (int ty = y0; ty < y1; ++ty)
             for (int tx = x0; tx < x1; ++tx) {
                 if (LDS) atomicAdd(&cnt[ty * gx + tx], 1);
                 else atomicAdd(&matrix[ty * gx + tx], 1);
             }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pairs += __shfl_xor(pairs, o);
+    if ((threadIdx.x & 63) == 0) wave_pairs[threadIdx.x >> 6] = pairs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < BIN_BLOCK / 64; ++k) s += wave_pairs[k];
+        chunk_sum[wg] = s;
+    }
     if (LDS) {
-        __syncthreads();
         int *row = matrix + (size_t)wg * T;
         for (int t = threadIdx.x; t < T; t += BIN_BLOCK) row[t] = cnt[t];
     }
@@ -128,7 +145,7 @@ bin_colscan_kernel(int T, int NB, int *__restrict__ matrix, int *__restrict__ ti
 // ------------------------------------------------------------------ K2b: scan over tiles (single workgroup)
 __global__ void __launch_bounds__(1024)
 bin_tilescan_kernel(int T, const int *__restrict__ tile_count, int *__restrict__ tile_range, int *__restrict__ M_out,
-                    int *__restrict__ total_scratch) {
+                    int *__restrict__ total_scratch, int nchunk, int *__restrict__ chunk_sum) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -156,6 +173,23 @@ bin_tilescan_kernel(int T, const int *__restrict__ tile_count, int *__restrict__
     if (threadIdx.x == 0) {
         if (M_out) *M_out = carry_s;
         *total_scratch = carry_s;
+        carry_s = 0;
+    }
+    __syncthreads();
+    // pairs per Gaussian chunk -> exclusive chunk offsets (K3 turns them into the Gaussian-major pair slots)
+    for (int base = 0; base < nchunk; base += 1024) {
+        const int c = base + threadIdx.x;
+        const int v = c < nchunk ? chunk_sum[c] : 0;
+        const int inc = wave_incl_scan_i(v, lane);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        const int carry = carry_s;
+        if (c < nchunk) chunk_sum[c] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
     }
 }
 
@@ -165,26 +199,51 @@ __global__ void __launch_bounds__(BIN_BLOCK)
 bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict__ depth,
                    const int *__restrict__ radius, int gx, int gy, int T, int chunk, int *__restrict__ matrix,
                    const int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
-                   int *__restrict__ overflow, const int *__restrict__ goff_incl, int *__restrict__ owner) {
-    // With goff_incl (inclusive prefix of tiles per Gaussian) the low key word is the pair slot
-    // j = goff_excl[i] + k (k-th tile of the splat's rectangle) instead of the Gaussian id: slots grow with
+                   int *__restrict__ overflow, int *__restrict__ goff_incl, int *__restrict__ owner,
+                   const int *__restrict__ chunk_off) {
+    // Pair-map mode (goff_incl != null): the kernel also produces goff_incl, the inclusive prefix of tiles per
+    // Gaussian (chunk offset from K2b + a workgroup scan of the rectangle areas), and the low key word is the pair
+    // slot j = goff_excl[i] + k (k-th tile of the splat's rectangle) instead of the Gaussian id: slots grow with
     // the id, so ties still order by ascending id, and the sorted keys directly give the pair map.
     extern __shared__ __attribute__((aligned(16))) int cnt[];
+    __shared__ int wave_pairs[BIN_BLOCK / 64];
     const int wg = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int running = goff_incl ? chunk_off[wg] : 0;
     if (LDS) {
         const int *row = matrix + (size_t)wg * T;
         for (int t = threadIdx.x; t < T; t += BIN_BLOCK) cnt[t] = tile_range[2 * t] + row[t];
         __syncthreads();
     }
     const int beg = wg * chunk, end = imin_(P, beg + chunk);
-    for (int i = beg + threadIdx.x; i < end; i += BIN_BLOCK) {
-        const int r = radius[i];
+    for (int base = beg; base < end; base += BIN_BLOCK) {  // uniform trip count: the scan below needs every thread
+        const int i = base + threadIdx.x;
+        const int r = i < end ? radius[i] : 0;
+        int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        if (r > 0) {
+            const float2 q = uv[i];
+            tile_rect(q.x, q.y, r, gx, gy, x0, y0, x1, y1);
+        }
+        int j = 0;
+        if (goff_incl) {
+            const int area = (x1 - x0) * (y1 - y0);
+            const int inc = wave_incl_scan_i(area, lane);
+            if (lane == 63) wave_pairs[w] = inc;
+            __syncthreads();
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int k = 0; k < BIN_BLOCK / 64; ++k) {
+                const int v = wave_pairs[k];
+                woff += k < w ? v : 0;
+                tot += v;
+            }
+            __syncthreads();
+            if (i < end) goff_incl[i] = running + woff + inc;
+            j = running + woff + inc - area;
+            running += tot;
+        }
         if (r <= 0) continue;
-        const float2 q = uv[i];
-        int x0, y0, x1, y1;
-        tile_rect(q.x, q.y, r, gx, gy, x0, y0, x1, y1);
         const unsigned long long dkey = (unsigned long long)__float_as_uint(depth[i]) << 32;
-        int j = goff_incl ? (i > 0 ? goff_incl[i - 1] : 0) : 0;
         for (int ty = y0; ty < y1; ++ty)
             for (int tx = x0; tx < x1; ++tx) {
                 const int t = ty * gx + tx;
@@ -343,8 +402,8 @@ struct BitonicK<R, NP * 2, NP> {
 };
 
 template <int R>
-__device__ __forceinline__ void tile_sort_regs(const u64 *g, int n, long long r0, int *idx_sorted, const int *owner,
-                                               int *slot_sorted, u64 *xbuf) {
+__device__ __forceinline__ void tile_sort_regs(const u64 *g, int n, long long r0, long long capacity, int *idx_sorted,
+                                               const int *owner, int *slot_sorted, u64 *xbuf) {
     const int t = threadIdx.x;
     u64 k[R];
 #pragma unroll
@@ -360,7 +419,7 @@ __device__ __forceinline__ void tile_sort_regs(const u64 *g, int n, long long r0
             const int lo = (int)(unsigned)(k[r] & 0xffffffffull);
             if (slot_sorted) {
                 slot_sorted[r0 + i] = lo;
-                idx_sorted[r0 + i] = owner[lo];
+                idx_sorted[r0 + i] = (long long)lo < capacity ? owner[lo] : 0;  // slots past the capacity: overflowed sort, owner unrecorded
             } else {
                 idx_sorted[r0 + i] = lo;
             }
@@ -381,9 +440,9 @@ tile_sort_kernel(const int *__restrict__ tile_range, long long capacity, unsigne
     unsigned long long *g = keys + r0;
     // low key word: Gaussian id, or (pair-map mode) the pair slot whose owner is the Gaussian id
     if (n <= 4 * SORT_BLOCK) {
-        tile_sort_regs<4>(g, n, r0, idx_sorted, owner, slot_sorted, sk);
+        tile_sort_regs<4>(g, n, r0, capacity, idx_sorted, owner, slot_sorted, sk);
     } else if (n <= 8 * SORT_BLOCK) {
-        tile_sort_regs<8>(g, n, r0, idx_sorted, owner, slot_sorted, sk);
+        tile_sort_regs<8>(g, n, r0, capacity, idx_sorted, owner, slot_sorted, sk);
     } else {
         __syncthreads();
         bitonic_any_n((volatile unsigned long long *)g, n);
@@ -391,7 +450,7 @@ tile_sort_kernel(const int *__restrict__ tile_range, long long capacity, unsigne
             const int lo = (int)(unsigned)(g[i] & 0xffffffffull);
             if (slot_sorted) {
                 slot_sorted[r0 + i] = lo;
-                idx_sorted[r0 + i] = owner[lo];
+                idx_sorted[r0 + i] = (long long)lo < capacity ? owner[lo] : 0;  // slots past the capacity: overflowed sort, owner unrecorded
             } else {
                 idx_sorted[r0 + i] = lo;
             }
@@ -416,16 +475,17 @@ extern "C" int splat_bin_count(int P, const float *uv, const int32_t *radius, in
     int *matrix = (int *)(base + p.off_matrix);
     int *tile_count = (int *)(base + p.off_tilecount);
     int *total = (int *)(base + p.off_total);
+    int *chunk_sum = (int *)(base + p.off_chunksum);
     if (p.lds) {
         SPLAT_LAUNCH("bin_count", bin_count_kernel<true>, dim3(p.NB), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
-                     P, (const float2 *)uv, radius, p.gx, p.gy, p.T, p.chunk, matrix, gcount);
+                     P, (const float2 *)uv, radius, p.gx, p.gy, p.T, p.chunk, matrix, gcount, chunk_sum);
     } else {
         // rows: [0] counts, [1] fill counters of K3
         SPLAT_CHECK_HIP(hipMemsetAsync(matrix, 0, (size_t)p.T * sizeof(int), s));
-        const int nblk = imax(1, imin((P + BIN_BLOCK - 1) / BIN_BLOCK, 2048));
+        const int nblk = p.nchunk;
         const int chunk = (P + nblk - 1) / nblk;
         SPLAT_LAUNCH("bin_count", bin_count_kernel<false>, dim3(nblk), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
-                     radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, gcount);
+                     radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, gcount, chunk_sum);
     }
     SPLAT_POST_LAUNCH();
     if (p.lds) {
@@ -434,14 +494,15 @@ extern "C" int splat_bin_count(int P, const float *uv, const int32_t *radius, in
     } else {
         SPLAT_CHECK_HIP(hipMemcpyAsync(tile_count, matrix, (size_t)p.T * sizeof(int), hipMemcpyDeviceToDevice, s));
     }
-    SPLAT_LAUNCH("bin_tilescan", bin_tilescan_kernel, dim3(1), dim3(1024), 0, s, p.T, tile_count, tile_range, M_out, total);
+    SPLAT_LAUNCH("bin_tilescan", bin_tilescan_kernel, dim3(1), dim3(1024), 0, s, p.T, tile_count, tile_range, M_out, total,
+                 p.nchunk, chunk_sum);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }
 
 extern "C" int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
                               void *scratch, const int32_t *tile_range, int64_t capacity, uint64_t *keys,
-                              int32_t *idx_sorted, int32_t *overflow_out, const int32_t *goff_incl,
+                              int32_t *idx_sorted, int32_t *overflow_out, int32_t *goff_incl,
                               int32_t *owner_scratch, int32_t *slot_sorted, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0 && capacity >= 0, "bad sizes");
     SPLAT_CHECK_ARG(scratch && tile_range && overflow_out, "null pointer");
@@ -455,18 +516,19 @@ extern "C" int splat_bin_sort(int P, const float *uv, const float *depth, const 
     const BinPlan p = make_plan(P, W, H);
     char *base = (char *)scratch;
     int *matrix = (int *)(base + p.off_matrix);
+    const int *chunk_off = (const int *)(base + p.off_chunksum);
     if (p.lds) {
         SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<true>, dim3(p.NB), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
                      P, (const float2 *)uv, depth, radius, p.gx, p.gy, p.T, p.chunk, matrix, tile_range,
-                     (long long)capacity, (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch);
+                     (long long)capacity, (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off);
     } else {
         // fill counters live in tile_count's neighbour: reuse matrix row "1" = matrix + T (allocated: NB=1 -> need 2 rows)
         SPLAT_CHECK_HIP(hipMemsetAsync(matrix + p.T, 0, (size_t)p.T * sizeof(int), s));
-        const int nblk = imax(1, imin((P + BIN_BLOCK - 1) / BIN_BLOCK, 2048));
+        const int nblk = p.nchunk;
         const int chunk = (P + nblk - 1) / nblk;
         SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<false>, dim3(nblk), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
                      depth, radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, tile_range, (long long)capacity,
-                     (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch);
+                     (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off);
     }
     SPLAT_POST_LAUNCH();
     SPLAT_LAUNCH("tile_sort", tile_sort_kernel, dim3(p.T), dim3(SORT_BLOCK), 0, s, tile_range, (long long)capacity,

@@ -75,6 +75,7 @@ struct BlendArgs {
     // backward inputs / outputs
     const float *dL_dout;
     float *dL_duv, *dL_dabs_uv, *dL_dconic, *dL_dopacity, *dL_dfeature, *dL_dbias;
+    float *dL_dndc, *dL_dabs_ndc;  // optional densification taps (pair mode): dL_duv / dL_dabs_uv scaled by (W/2, H/2)
     // atomic-free backward: per-(tile,splat) partial sums + inverse pair map
     float *pair_buf;        // [M, NCP] partial gradients, one 64-B-aligned record per pair SLOT (Gaussian-major)
     const int *goff_incl;   // [P] inclusive prefix of tiles per Gaussian (slot ranges)
@@ -753,10 +754,23 @@ __device__ __forceinline__ void store_component(const BlendArgs &A, int i, int k
     using GL = GradLayout<ABS, BIAS>;
     constexpr int NG = GL::NG;
     float *dst;
-    if (k < 2) dst = A.dL_duv + 2 * i + k;
-    else if (k < 5) dst = A.dL_dconic + 3 * i + (k - 2);
+    if (k < 2) {
+        dst = A.dL_duv + 2 * i + k;
+        if (A.dL_dndc) {  // the tap the reference fills with dL_duv * [W/2, H/2] (alpha_blending.py:140-147)
+            float *t = A.dL_dndc + 2 * i + k;
+            const float tv = v * (k == 0 ? 0.5f * (float)A.W : 0.5f * (float)A.H);
+            *t = A.accumulate ? *t + tv : tv;
+        }
+    } else if (k < 5) dst = A.dL_dconic + 3 * i + (k - 2);
     else if (k == 5) dst = A.dL_dopacity + i;
-    else if (ABS && k < GL::I_ABS + 2) dst = A.dL_dabs_uv + 2 * i + (k - GL::I_ABS);
+    else if (ABS && k < GL::I_ABS + 2) {
+        dst = A.dL_dabs_uv + 2 * i + (k - GL::I_ABS);
+        if (A.dL_dabs_ndc) {
+            float *t = A.dL_dabs_ndc + 2 * i + (k - GL::I_ABS);
+            const float tv = v * (k == GL::I_ABS ? 0.5f * (float)A.W : 0.5f * (float)A.H);
+            *t = A.accumulate ? *t + tv : tv;
+        }
+    }
     else if (BIAS && k == GL::I_BIAS) dst = A.dL_dbias + i;
     else {
         if (k - NG >= A.cn) return;  // padding
@@ -1371,8 +1385,9 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
                                              int H, const float *final_T, const int32_t *ncontrib,
                                              const float *dL_dout, float *dL_duv, float *dL_dabs_uv, float *dL_dconic,
                                              float *dL_dopacity, float *dL_dfeature, float *dL_dopacity_bias,
-                                             const int32_t *goff_incl, const int32_t *slot_sorted, float *pair_scratch,
-                                             float *pack_scratch, int pack_is_valid, splat_stream_t stream) {
+                                             float *dL_dndc, float *dL_dabs_ndc, const int32_t *goff_incl,
+                                             const int32_t *slot_sorted, float *pair_scratch, float *pack_scratch,
+                                             int pack_is_valid, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && C >= 1 && W > 0 && H > 0, "bad sizes");
     if (P == 0) return SPLAT_OK;
     SPLAT_CHECK_ARG(uv && conic && opacity && feature && idx_sorted && tile_range && final_T && ncontrib && dL_dout &&
@@ -1383,6 +1398,8 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
     const int npm = (goff_incl != nullptr) + (slot_sorted != nullptr) + (pair_scratch != nullptr);
     SPLAT_CHECK_ARG(npm == 0 || npm == 3, "goff_incl, slot_sorted and pair_scratch go together");
     const bool pair_mode = npm == 3;
+    SPLAT_CHECK_ARG(pair_mode || (!dL_dndc && !dL_dabs_ndc), "the tap outputs need the pair-mode backward");
+    SPLAT_CHECK_ARG(!dL_dabs_ndc || dL_dabs_uv, "dL_dabs_ndc needs dL_dabs_uv");
     BlendArgs A;
     memset(&A, 0, sizeof(A));
     A.P = P; A.C = C;
@@ -1393,6 +1410,7 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
     A.dL_dout = dL_dout;
     A.dL_duv = dL_duv; A.dL_dabs_uv = dL_dabs_uv; A.dL_dconic = dL_dconic; A.dL_dopacity = dL_dopacity;
     A.dL_dfeature = dL_dfeature; A.dL_dbias = dL_dopacity_bias;
+    A.dL_dndc = dL_dndc; A.dL_dabs_ndc = dL_dabs_ndc;
     A.goff_incl = goff_incl; A.slot_sorted = slot_sorted; A.pair_buf = pair_scratch;
     A.pack = pack_scratch;
     A.pack_valid = (pack_is_valid && C <= 32) ? 1 : 0;  // one chunk only: later chunks overwrite the scratch

@@ -38,9 +38,19 @@ def _points(t: Tensor, name: str, width: int) -> Tensor:
     return t
 
 
+_ALL_VISIBLE = {}
+
+
 def _visible(visible: Optional[Tensor], P: int, device) -> Tensor:
-    if visible is None:
-        return torch.ones(P, dtype=torch.uint8, device=device)
+    if visible is None:   # read-only all-ones mask, created once per (P, device) instead of one fill kernel per call
+        key = (int(P), str(device))
+        v = _ALL_VISIBLE.get(key)
+        if v is None:
+            if len(_ALL_VISIBLE) > 8:
+                _ALL_VISIBLE.clear()
+            v = torch.ones(P, dtype=torch.uint8, device=device)
+            _ALL_VISIBLE[key] = v
+        return v
     v = L.need(visible, "visible", torch.uint8)
     if v.numel() != P:
         raise ValueError("visible must have P elements")

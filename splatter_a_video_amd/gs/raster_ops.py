@@ -36,17 +36,32 @@ def _half_wh(W: int, H: int, device) -> Tensor:
 
 
 # ------------------------------------------------------------------ sort_gaussian
+_OVERFLOW_SINK = {}
+
+
+def _overflow_sink(device) -> Tensor:
+    t = _OVERFLOW_SINK.get(str(device))
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _OVERFLOW_SINK[str(device)] = t
+    return t
+
+
 class SortStatus:
     """Device-side outcome of a capacity-bounded sort: ``pairs`` (int32[1], the true number of tile-Gaussian
-    pairs M) and ``overflow`` (int32[1], 1 when M exceeded the capacity and pairs were dropped)."""
+    pairs M) and ``capacity``; ``overflow`` (bool[1], M exceeded the capacity and pairs were dropped) derives from them."""
 
-    def __init__(self, pairs: Tensor, overflow: Tensor, capacity: int):
-        self.pairs, self.overflow, self.capacity = pairs, overflow, int(capacity)
+    def __init__(self, pairs: Tensor, capacity: int):
+        self.pairs, self.capacity = pairs, int(capacity)
+
+    @property
+    def overflow(self) -> Tensor:
+        return self.pairs > self.capacity
 
     def check(self) -> int:
         """host sync; raises when the capacity was too small, else returns M"""
         m = int(self.pairs.item())
-        if m > self.capacity or int(self.overflow.item()):
+        if m > self.capacity:
             raise L.SplatError(f"sort_gaussian_capped: {m} tile-Gaussian pairs exceed the capacity {self.capacity}")
         return m
 
@@ -65,27 +80,26 @@ def _sort(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Opti
     tile_range = torch.empty(T, 2, dtype=torch.int32, device=dev)
     if P == 0:
         z = torch.zeros(1, dtype=torch.int32, device=dev)
-        return torch.empty(0, dtype=torch.int32, device=dev), tile_range.zero_(), SortStatus(z, z.clone(), 0)
+        return torch.empty(0, dtype=torch.int32, device=dev), tile_range.zero_(), SortStatus(z, 0)
     lib = L.lib()
     scratch = torch.empty(lib.splat_bin_scratch_bytes(P, W, H), dtype=torch.uint8, device=dev)
     m_dev = torch.empty(1, dtype=torch.int32, device=dev)
-    gcount = torch.empty(P, dtype=torch.int32, device=dev)
     L.check(lib.splat_bin_count(L.ci(P), L.ptr(uv), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
-                                L.ptr(tile_range), L.ptr(m_dev), L.ptr(gcount), L.stream()))
-    goff = torch.cumsum(gcount, 0, dtype=torch.int32)      # queued before the sync below
+                                L.ptr(tile_range), L.ptr(m_dev), L.ptr(None), L.stream()))
     M = int(m_dev.item()) if capacity is None else int(capacity)   # the only host sync (none with a capacity)
     idx_sorted = torch.empty(M, dtype=torch.int32, device=dev)
-    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    overflow = _overflow_sink(dev)   # the kernels only ever store 1 here; pairs > capacity carries the same fact
     if M > 0:
         keys = torch.empty(M, dtype=torch.int64, device=dev)
         owner = torch.empty(M, dtype=torch.int32, device=dev)
         slot_sorted = torch.empty(M, dtype=torch.int32, device=dev)
+        goff = torch.empty(P, dtype=torch.int32, device=dev)   # inclusive tiles-per-Gaussian prefix, written by the sort
         L.check(lib.splat_bin_sort(L.ci(P), L.ptr(uv), L.ptr(depth), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
                                    L.ptr(tile_range), ctypes.c_int64(M), L.ptr(keys), L.ptr(idx_sorted),
                                    L.ptr(overflow), L.ptr(goff), L.ptr(owner), L.ptr(slot_sorted), L.stream()))
         # hidden companion of idx_sorted: lets alpha_blending's backward run without global atomics
         idx_sorted._splat_pairmap = (goff, slot_sorted)
-    return idx_sorted, tile_range, SortStatus(m_dev, overflow, M)
+    return idx_sorted, tile_range, SortStatus(m_dev, M)
 
 
 def sort_gaussian(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Tensor) -> Tuple[Tensor, Tensor]:
@@ -180,14 +194,17 @@ class _AlphaBlend(torch.autograd.Function):
         dfeat = alloc(P, C, dtype=torch.float32, device=dev)
         dbias = alloc(bias.shape, dtype=torch.float32, device=dev) if has_bias else None
         pack = ctx.pack
+        # gradient taps used by densification (reference: alpha_blending.py:112-120): the pair-mode reduce kernel writes
+        # them next to dL_duv; the atomic-mode fallback scales afterwards
+        in_kernel = scratch is not None
+        dndc = alloc(P, 2, dtype=torch.float32, device=dev) if (has_ndc and in_kernel) else None
+        dabs_ndc = alloc(P, 2, dtype=torch.float32, device=dev) if (has_abs and in_kernel) else None
         L.check(L.lib().splat_alpha_blending_backward(
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias), L.ptr(idx_sorted),
             L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(g), L.ptr(duv),
-            L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(dbias), L.ptr(goff), L.ptr(slot_sorted),
-            L.ptr(scratch), L.ptr(pack), L.ci(1), L.stream()))
-        # gradient taps used by densification (reference: alpha_blending.py:112-120)
-        dndc = dabs_ndc = None
-        if has_ndc or has_abs:
+            L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(dbias), L.ptr(dndc), L.ptr(dabs_ndc), L.ptr(goff),
+            L.ptr(slot_sorted), L.ptr(scratch), L.ptr(pack), L.ci(1), L.stream()))
+        if (has_ndc or has_abs) and not in_kernel:
             half = _half_wh(W, H, dev)
             if has_ndc:
                 dndc = duv * half[None, :]
@@ -301,8 +318,8 @@ class _BlendShared(torch.autograd.Function):
             L.check(lib.splat_alpha_blending_backward(
                 L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(f), L.ptr(None), L.ptr(idx_sorted),
                 L.ptr(tile_range), L.cf(bgs[s]), L.ci(W), L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(g), L.ptr(duv),
-                L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(None), L.ptr(goff), L.ptr(slot_sorted),
-                L.ptr(scratch), L.ptr(pack), L.ci(0), L.stream()))
+                L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(goff),
+                L.ptr(slot_sorted), L.ptr(scratch), L.ptr(pack), L.ci(0), L.stream()))
             dfeats[s] = dfeat
             duv_t = duv if duv_t is None else duv_t + duv
             dconic_t = dconic if dconic_t is None else dconic_t + dconic
