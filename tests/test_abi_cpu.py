@@ -133,3 +133,29 @@ def test_new_entry_points_validate_arguments(built_lib):
     assert b"segment index" in lib.splat_last_error()
     assert lib.splat_knn_grid_cells(ctypes.c_int(300000)) == 150000
     assert lib.splat_compact_scratch_bytes(ctypes.c_int(1000)) >= 16
+
+
+def test_diff_gaussian_rasterization_shim_surface():
+    """the names and fields the reference's alternate renderer uses (base_splatting.py:17,123-139) resolve, argument
+    errors come before any device work, and CPU tensors are refused (no CPU fallback)"""
+    import torch
+
+    import diff_gaussian_rasterization as dgr
+    from splatter_a_video_amd import diff_rasterizer
+
+    assert dgr.GaussianRasterizer is diff_rasterizer.GaussianRasterizer
+    assert dgr.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered", "debug")
+    eye = torch.eye(4)
+    s = dgr.GaussianRasterizationSettings(image_height=32, image_width=32, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(3),
+                                          scale_modifier=1.0, viewmatrix=eye, projmatrix=eye, sh_degree=0,
+                                          campos=torch.zeros(3), prefiltered=False, debug=False)
+    rast = dgr.GaussianRasterizer(raster_settings=s)
+    xyz, op = torch.rand(8, 3), torch.rand(8, 1)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        rast(xyz, None, op, scales=torch.rand(8, 3), rotations=torch.rand(8, 4))
+    with pytest.raises(Exception, match="3D covariance"):
+        rast(xyz, None, op, colors_precomp=torch.rand(8, 3))
+    with pytest.raises((ValueError, RuntimeError)):
+        rast(xyz, None, op, colors_precomp=torch.rand(8, 3), scales=torch.rand(8, 3), rotations=torch.rand(8, 4))
