@@ -7,8 +7,8 @@
 //   K1 bin_count    each workgroup owns a contiguous chunk of Gaussians and histograms the tiles
 //                   they touch in LDS (ds_add, no global atomics), then stores its row of the
 //                   [NB, T] count matrix;
-//   K2a bin_colscan one wave per tile: exclusive scan of that tile's column over the NB chunks
-//                   (DPP prefix), column total -> tile_count[T];
+//   K2a bin_colscan exclusive scan of every tile's column over the NB chunks (32 columns x 32 row groups per
+//                   workgroup, rows held in registers), column total -> tile_count[T];
 //   K2b bin_tilescan single workgroup: exclusive scan of tile_count -> tile_range[T,2], M;
 //   K3 bin_scatter  same chunking as K1; LDS counters start at the chunk's base, ds_add_rtn
 //                   hands out the slot; writes key = (depth bits << 32 | gaussian id);
@@ -126,20 +126,42 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
     return v;
 }
 
-__global__ void __launch_bounds__(256)
+// 32 tile columns x 32 row groups per workgroup: every thread loads its (at most 16) rows of one column in one
+// batch -- a wave reads two 128-byte row segments per instruction --, scans them in registers, and the group totals
+// are exchanged through LDS.  The matrix is read once and written once.
+#define COLSCAN_COLS 32
+#define COLSCAN_GROUPS 32
+#define COLSCAN_ROWS (BIN_MAX_NB / COLSCAN_GROUPS)
+__global__ void __launch_bounds__(COLSCAN_COLS * COLSCAN_GROUPS)
 bin_colscan_kernel(int T, int NB, int *__restrict__ matrix, int *__restrict__ tile_count) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= T) return;
-    int carry = 0;
-    for (int base = 0; base < NB; base += 64) {
-        const int row = base + lane;
-        const int v = row < NB ? matrix[(size_t)row * T + t] : 0;
-        const int inc = wave_incl_scan_i(v, lane);
-        if (row < NB) matrix[(size_t)row * T + t] = carry + inc - v;  // exclusive
-        carry += __shfl(inc, 63);
+    __shared__ int gsum[COLSCAN_GROUPS][COLSCAN_COLS + 1];
+    const int c = threadIdx.x & (COLSCAN_COLS - 1), g = threadIdx.x / COLSCAN_COLS;
+    const int t = blockIdx.x * COLSCAN_COLS + c;
+    const int rpg = (NB + COLSCAN_GROUPS - 1) / COLSCAN_GROUPS;  // rows per group, <= COLSCAN_ROWS
+    const int r0 = g * rpg;
+    int v[COLSCAN_ROWS];
+#pragma unroll
+    for (int k = 0; k < COLSCAN_ROWS; ++k) {
+        const int r = r0 + k;
+        v[k] = (k < rpg && r < NB && t < T) ? matrix[(size_t)r * T + t] : 0;
     }
-    if (lane == 0) tile_count[t] = carry;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < COLSCAN_ROWS; ++k) {  // exclusive inside the group
+        const int x = v[k];
+        v[k] = s;
+        s += x;
+    }
+    gsum[g][c] = s;
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < g; ++k) off += gsum[k][c];
+#pragma unroll
+    for (int k = 0; k < COLSCAN_ROWS; ++k) {
+        const int r = r0 + k;
+        if (k < rpg && r < NB && t < T) matrix[(size_t)r * T + t] = off + v[k];
+    }
+    if (g == COLSCAN_GROUPS - 1 && t < T) tile_count[t] = off + s;
 }
 
 // ------------------------------------------------------------------ K2b: scan over tiles (single workgroup)
@@ -489,7 +511,8 @@ extern "C" int splat_bin_count(int P, const float *uv, const int32_t *radius, in
     }
     SPLAT_POST_LAUNCH();
     if (p.lds) {
-        SPLAT_LAUNCH("bin_colscan", bin_colscan_kernel, dim3((p.T + 3) / 4), dim3(256), 0, s, p.T, p.NB, matrix, tile_count);
+        SPLAT_LAUNCH("bin_colscan", bin_colscan_kernel, dim3((p.T + COLSCAN_COLS - 1) / COLSCAN_COLS),
+                     dim3(COLSCAN_COLS * COLSCAN_GROUPS), 0, s, p.T, p.NB, matrix, tile_count);
         SPLAT_POST_LAUNCH();
     } else {
         SPLAT_CHECK_HIP(hipMemcpyAsync(tile_count, matrix, (size_t)p.T * sizeof(int), hipMemcpyDeviceToDevice, s));

@@ -458,11 +458,12 @@ blend_fwd_kernel(const BlendArgs A) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const float dx = g0[u].x - pxf, dy = g0[u].y - pyf;
-                    const float power = -0.5f * (g0[u].z * dx * dx + g1[u].x * dy * dy) - g0[u].w * dx * dy;
-                    float araw = g1[u].y * __expf(power);
+                    // q = -power = dx (a dx/2 + b dy) + (c dy/2) dy : five dependent ops instead of nine
+                    const float q = dx * (g0[u].z * (0.5f * dx) + g0[u].w * dy) + (g1[u].x * (0.5f * dy)) * dy;
+                    float araw = g1[u].y * __expf(-q);
                     if (BIAS) araw = araw + g1[u].z;
                     const float a = fminf(0.99f, araw);
-                    alpha[u] = (!(power > 0.f) && !(a < (1.0f / 255.0f))) ? a : 0.f;
+                    alpha[u] = (!(q < 0.f) && !(a < (1.0f / 255.0f))) ? a : 0.f;
                     amax = fmaxf(amax, alpha[u]);
                 }
                 if (!__any(!done && amax > 0.f)) continue;
