@@ -33,8 +33,12 @@
 #ifndef BLEND_FWD_U
 #define BLEND_FWD_U 4      // survivors evaluated per trip in the forward (narrow channel counts)
 #endif
+#ifndef BLEND_FWD_SB
+#define BLEND_FWD_SB 128   // forward super-batch (narrow channel counts): 14 KB of LDS per workgroup
+#endif
 #ifndef BLEND_FWD_MINW
-#define BLEND_FWD_MINW 1   // __launch_bounds__ min waves per SIMD (register cap) for the forward
+#define BLEND_FWD_MINW 7   // __launch_bounds__ min waves per SIMD for the forward: 72 VGPRs, 7 workgroups per CU --
+                           // all 1620 tiles of a 480p frame are resident at once (no half-empty second round)
 #endif
 #ifndef BLEND_BWD_U
 #define BLEND_BWD_U 2
@@ -372,7 +376,7 @@ __device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane) {
 // ------------------------------------------------------------------ forward
 template <int CH>
 struct FwdCfg {
-    static constexpr int SB = CH <= 8 ? 256 : 128;
+    static constexpr int SB = CH <= 8 ? BLEND_FWD_SB : 128;
 };
 
 template <int CH, bool ENH, bool BIAS, bool EXACT>
@@ -380,8 +384,10 @@ __global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_FWD_MINW : 1))
 blend_fwd_kernel(const BlendArgs A) {
     constexpr int SB = FwdCfg<CH>::SB;
     constexpr int U = CH <= 8 ? BLEND_FWD_U : 2;  // survivors evaluated per trip
+    constexpr int RB = Rec<CH>::RS * 4;           // bytes per record
+    static_assert((SB + 1) * RB <= 65536 && SB % U == 0, "record offsets must fit the 16-bit list entries");
     __shared__ TileLDS<CH, SB> L;
-    __shared__ unsigned short s_qlist[4][4][SB];  // [wave][quarter] survivor lists
+    __shared__ __attribute__((aligned(8))) unsigned short s_qlist[4][4][SB];  // [wave][quarter] survivor lists (record byte offsets)
     __shared__ int s_done[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -422,7 +428,9 @@ blend_fwd_kernel(const BlendArgs A) {
         if (!alld) {
             // one order-preserving survivor list per 4x4 quarter of the wave's block: the 16 lanes of a quarter walk
             // their own list (a splat is evaluated only on the quarters its bounding box reaches), the wave loops to
-            // the longest of the four
+            // the longest of the four.  List entries are the byte offsets of the records inside L.rec; every list is
+            // padded with the inert record up to the common trip count, so a trip is one 8-byte list read + U record
+            // reads, with no bounds test.
             int cq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) cq[q] = 0;
@@ -434,25 +442,39 @@ blend_fwd_kernel(const BlendArgs A) {
                 for (int q = 0; q < 4; ++q) {
                     const bool keep = (bits >> q) & 1u;
                     const unsigned long long m = __ballot(keep);
-                    if (keep) s_qlist[w][q][cq[q] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
+                    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (keep) s_qlist[w][q][cq[q] + before] = (unsigned short)(e * RB);
                     cq[q] += __popcll(m);
                 }
             }
+            const int cnt = imax_(imax_(cq[0], cq[1]), imax_(cq[2], cq[3]));
+            const int cntU = (cnt + U - 1) / U * U;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll 1
+                for (int i = cq[q] + lane; i < cntU; i += WAVE) s_qlist[w][q][i] = (unsigned short)(SB * RB);  // opacity 0 -> alpha 0
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int cnt = imax_(imax_(cq[0], cq[1]), imax_(cq[2], cq[3]));
             const int myq = ((lane >> 2) & 1) + 2 * ((lane >> 5) & 1);  // quarter of this lane's pixel
-            const int mycnt = myq == 0 ? cq[0] : myq == 1 ? cq[1] : myq == 2 ? cq[2] : cq[3];
             const unsigned short *mylist = s_qlist[w][myq];
-            for (int j0 = 0; j0 < cnt; j0 += U) {
-                int e[U];
+            const char *recb = reinterpret_cast<const char *>(L.rec);
+            int lastoff = -1;  // record offset of the last splat applied in this super-batch
+            for (int j0 = 0; j0 < cntU; j0 += U) {
+                unsigned off[U];
+                if (U == 4) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(mylist + j0);
+                    off[0] = v.x & 0xffffu; off[1] = v.x >> 16; off[2 % U] = v.y & 0xffffu; off[3 % U] = v.y >> 16;
+                } else {
+                    static_assert(U == 2 || U == 4, "a trip reads its list entries as one 4- or 8-byte word");
+                    const unsigned v = *reinterpret_cast<const unsigned *>(mylist + j0);
+                    off[0] = v & 0xffffu; off[1] = v >> 16;
+                }
                 float4 g0[U], g1[U];
                 float alpha[U];  // 0 where the splat does not touch the pixel: no per-splat predicate registers
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    e[u] = (j0 + u < mycnt) ? (int)mylist[j0 + u] : SB;  // slot SB: inert record (opacity 0 -> alpha 0)
-                    g0[u] = L.g0(e[u]);
-                    g1[u] = L.g1(e[u]);
+                    g0[u] = *reinterpret_cast<const float4 *>(recb + off[u]);
+                    g1[u] = *reinterpret_cast<const float4 *>(recb + off[u] + 16);
                 }
                 float amax = 0.f;
 #pragma unroll
@@ -466,22 +488,30 @@ blend_fwd_kernel(const BlendArgs A) {
                     alpha[u] = (!(q < 0.f) && !(a < (1.0f / 255.0f))) ? a : 0.f;
                     amax = fmaxf(amax, alpha[u]);
                 }
-                if (!__any(!done && amax > 0.f)) continue;
+                if (__ballot(!done && amax > 0.f) == 0ull) continue;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const bool ok = !done && alpha[u] > 0.f;  // an earlier survivor of this trip may have saturated the pixel
-                    if (!__any(ok)) continue;
+                    if (__ballot(ok) == 0ull) continue;
                     float f[CH];
-                    read_feat<CH, SB>(L, e[u], f);
+                    const float4 *fq = reinterpret_cast<const float4 *>(recb + off[u] + 32);  // 16-byte chunks of the record
+#pragma unroll
+                    for (int k = 0; k < CH; k += 4) {
+                        const float4 v = fq[k / 4];
+                        if (k + 0 < CH) f[k + 0] = v.x;
+                        if (k + 1 < CH) f[k + 1] = v.y;
+                        if (k + 2 < CH) f[k + 2] = v.z;
+                        if (k + 3 < CH) f[k + 3] = v.w;
+                    }
                     const float nT = T * (1.f - alpha[u]);
                     const bool sat = ok && (nT < 0.0001f);
                     const bool app = ok && !sat;
                     done = done || sat;
-                    const float wgt = app ? alpha[u] * T : 0.f;
+                    const float wgt = (app ? alpha[u] : 0.f) * T;
 #pragma unroll
                     for (int k = 0; k < CH; ++k) F[k] += f[k] * wgt;
                     T = app ? nT : T;
-                    last = app ? base + e[u] + 1 : last;
+                    lastoff = app ? (int)off[u] : lastoff;
                     if (ENH) {
                         if (app && (A.trunc || layer < A.K)) {
                             const size_t pix = (size_t)A.W * (size_t)py + px;
@@ -492,6 +522,7 @@ blend_fwd_kernel(const BlendArgs A) {
                     }
                 }
             }
+            last = lastoff >= 0 ? base + lastoff / RB + 1 : last;
         }
         __syncthreads();
     }

@@ -10,6 +10,7 @@ import torch
 
 import dptr.gs as gs
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from splatter_a_video_amd.diff_rasterizer import _camera as adapter_camera
 from splatter_a_video_amd.synth import make_scene
 
 pytestmark = pytest.mark.gpu
@@ -63,6 +64,12 @@ def test_adapter_equals_operator_chain_sh():
     sc = make_scene(6000, 192, 128, seed=3, ortho=False)
     cam, intr, extr = _camera(sc)
     g = _t(np.random.default_rng(0).normal(size=(3, sc.H, sc.W)))
+    # the camera the adapter derives from the transposed matrices is the one they were built from; the chain below
+    # then uses the adapter's float32 values (a last-bit difference in fx moves alpha >= 1/255 decisions of single pixels)
+    settings = _settings(sc, cam, torch.full((3,), 0.25, device="cuda"))
+    intr_a, extr_a = adapter_camera(settings, torch.device("cuda"))
+    assert torch.allclose(intr_a, intr, rtol=2e-6) and torch.allclose(extr_a, extr[:3], atol=1e-6)
+    intr, extr = intr_a, extr_a
     # chain
     p = _leaves(sc)
     img_c, radius_c, ndc, _ = _chain(sc, p, intr, extr, cam["campos"], 0.25)
@@ -70,7 +77,7 @@ def test_adapter_equals_operator_chain_sh():
     # adapter
     q = _leaves(sc)
     means2D = torch.zeros(sc.N, 3, device="cuda", requires_grad=True)
-    rast = GaussianRasterizer(raster_settings=_settings(sc, cam, torch.full((3,), 0.25, device="cuda")))
+    rast = GaussianRasterizer(raster_settings=settings)
     img_a, radii = rast(means3D=q["xyz"], means2D=means2D, shs=q["shs"], colors_precomp=None, opacities=q["opacity"],
                         scales=q["scale"], rotations=q["rotate"], cov3D_precomp=None)
     (img_a * g).sum().backward()
