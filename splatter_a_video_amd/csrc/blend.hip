@@ -364,7 +364,8 @@ __device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane) {
         const int e = r * WAVE + lane;
         const bool keep = ((L.keep[e] >> (8 * w)) & 0xffu) != 0u;
         const unsigned long long m = __ballot(keep);
-        if (keep) L.list[w][cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (keep) L.list[w][cnt + before] = (unsigned short)e;
         cnt += __popcll(m);
     }
     if (lane < 16) L.list[w][cnt + lane] = (unsigned short)SB;  // pad: the unrolled loops read slot SB (inert record)
@@ -461,13 +462,12 @@ blend_fwd_kernel(const BlendArgs A) {
             int lastoff = -1;  // record offset of the last splat applied in this super-batch
             for (int j0 = 0; j0 < cntU; j0 += U) {
                 unsigned off[U];
-                if (U == 4) {
-                    const uint2 v = *reinterpret_cast<const uint2 *>(mylist + j0);
-                    off[0] = v.x & 0xffffu; off[1] = v.x >> 16; off[2 % U] = v.y & 0xffffu; off[3 % U] = v.y >> 16;
-                } else {
-                    static_assert(U == 2 || U == 4, "a trip reads its list entries as one 4- or 8-byte word");
-                    const unsigned v = *reinterpret_cast<const unsigned *>(mylist + j0);
-                    off[0] = v & 0xffffu; off[1] = v >> 16;
+                static_assert(U == 2 || U == 4, "a trip reads its list entries as one 4- or 8-byte word");
+#pragma unroll
+                for (int h = 0; h < U / 2; ++h) {
+                    const unsigned v = reinterpret_cast<const unsigned *>(mylist + j0)[h];  // adjacent words: one ds_read_b64 for U = 4
+                    off[2 * h] = v & 0xffffu;
+                    off[2 * h + 1] = v >> 16;
                 }
                 float4 g0[U], g1[U];
                 float alpha[U];  // 0 where the splat does not touch the pixel: no per-splat predicate registers

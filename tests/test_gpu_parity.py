@@ -163,6 +163,15 @@ def test_sort_gaussian_bit_exact(gpu, oracle_mod, N, W, H, sigma):
     assert (idx.cpu().numpy() == G["idx"]).all()
     if sigma != 2.0:
         assert (G["tr"][:, 1] - G["tr"][:, 0]).max() > 2048
+    # the pair map the sort produces alongside (prefix fused into the binning kernels): goff = inclusive cumsum of
+    # the tiles each Gaussian touches (reference: sort_gaussian.py:42), slot_sorted = a permutation of the pair slots
+    # whose owner is the Gaussian sorted to that position
+    goff, slot_sorted = idx._splat_pairmap
+    want = np.cumsum(G["tiles"].astype(np.int64))
+    assert (goff.cpu().numpy() == want).all()
+    slots = slot_sorted.cpu().numpy()
+    assert (np.sort(slots) == np.arange(slots.size)).all()
+    assert (np.searchsorted(want, slots, side="right") == G["idx"]).all()
 
 
 def test_sort_gaussian_ties_and_empty(gpu, oracle_mod):

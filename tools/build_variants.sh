@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../splatter_a_video_amd/csrc"
 mkdir -p ../../variants build
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function -fno-slp-vectorize"
 for spec in "$@"; do
   name="${spec%%:*}"; defs="${spec#*:}"
   /opt/rocm/bin/hipcc $FLAGS $defs -c blend.hip -o build/blend_$name.o &
