@@ -39,7 +39,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak (guides/MI355X_MICROARCH.md); ~6300 GB
 # HBM/fabric bytes per launch from PMC counters, measured offline with tools/pmc_run.sh (separate --pmc
 # passes, read requests sized by TCC_EA0_RDREQ_{32B,64B,128B}, WRITE_SIZE in KiB) at configs[1];
 # only reported when the bench runs that configuration.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")
+PMC_TAG = "r01i"
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_traffic.json")
+# instruction-issue counters of the two compositing kernels (tools/pmc_blend_counters.py): what actually bounds them
+PMC_COUNTER_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_blend_counters.json")
 PMC_KERNEL_NAMES = {"blend_bwd": "blend_bwd_mfma_kernel", "blend_fwd": "blend_fwd_kernel", "tile_sort": "tile_sort_kernel",
                     "pair_reduce": "pair_reduce_kernel", "sh_fwd": "sh_fwd_kernel", "sh_bwd": "sh_bwd_kernel"}
 
@@ -50,6 +53,17 @@ def pmc_traffic(kernel, is_default_config):
     try:
         k = json.load(open(PMC_TRAFFIC_FILE))["kernels"].get(PMC_KERNEL_NAMES.get(kernel, ""), None)
         return None if k is None else k["read_bytes"] + k["write_bytes"]
+    except Exception:
+        return None
+
+
+def pmc_issue(kernel, is_default_config):
+    """VALU / MFMA issue utilisation and wave-slot residency of a compositing kernel (offline PMC passes), or None"""
+    if not is_default_config or not os.path.exists(PMC_COUNTER_FILE):
+        return None
+    try:
+        k = json.load(open(PMC_COUNTER_FILE))["kernels"].get(kernel, None)
+        return None if k is None else dict(k["derived"], source=f"profiles/{PMC_TAG}_pmc_blend_counters.json (rocprofv3 --pmc, offline)")
     except Exception:
         return None
 
@@ -345,7 +359,9 @@ def main():
             default_cfg = (a.gaussians, a.width, a.height, a.channels) == (300000, 854, 480, 0)
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, default_cfg),
-                        "traffic_source": "profiles/r01h_pmc_traffic.json (rocprofv3 --pmc, offline)" if default_cfg else None,
+                        "traffic_source": f"profiles/{PMC_TAG}_pmc_traffic.json (rocprofv3 --pmc, offline)" if default_cfg else None,
+                        # the compositing kernels are bound by instruction issue, not by HBM: secondary ceiling
+                        "issue": pmc_issue(dom, default_cfg),
                         "avg_us": kernels[dom]["avg_us"], "alg_bytes_per_launch": int(kernel_bytes(dom, a.gaussians, M, HW, R.C, T, R.use_sh))}
             is_bwd = lambda k: k.endswith("_bwd") or k == "pair_reduce"
             fwd_ms = sum(kernels[k]["avg_us"] for k in kernels if not is_bwd(k)) / 1e3

@@ -1,0 +1,40 @@
+"""rocprofv3 --pmc counter_collection CSVs (several passes) of tools/blend_bench.py -> one JSON with per-launch counters of
+the two compositing kernels and the utilisation figures derived from them.
+   python tools/pmc_blend_counters.py <out.json> <pass dir> [<pass dir> ...]"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+out, dirs = sys.argv[1], sys.argv[2:]
+KERNELS = {"blend_fwd_kernel": "blend_fwd", "blend_bwd_mfma_kernel": "blend_bwd"}
+acc = defaultdict(lambda: [0.0, 0])
+for d in dirs:
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            for k in KERNELS:
+                if k in r["Kernel_Name"]:
+                    a = acc[(k, r["Counter_Name"])]
+                    a[0] += float(r["Counter_Value"]); a[1] += 1
+res = {"source": "rocprofv3 --pmc, three passes of tools/blend_bench.py --reps 2 (300k Gaussians, 854x480, 3 channels), per launch, "
+                 "summed over the 8 XCDs; SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES in quad-cycles (guides/MI355X_MICROARCH.md)",
+       "kernels": {}}
+SIMDS, WAVE_SLOTS, XCDS = 1024, 256 * 16, 8
+for k in KERNELS:
+    c = {n: round(v / cnt, 1) for (kk, n), (v, cnt) in sorted(acc.items()) if kk == k}
+    if not c:
+        continue
+    cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / XCDS          # kernel duration in shader clocks
+    d = {}
+    if cyc:
+        if "SQ_ACTIVE_INST_VALU" in c:
+            d["valu_busy_frac"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (SIMDS * cyc), 3)   # SIMD-cycles issuing VALU / all SIMD-cycles
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+            d["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * cyc), 3)
+        if "SQ_WAVE_CYCLES" in c:
+            d["wave_slot_residency"] = round(4.0 * c["SQ_WAVE_CYCLES"] / (WAVE_SLOTS * cyc), 3)  # resident waves / (16 per CU)
+        d["duration_cycles"] = round(cyc, 1)
+    res["kernels"][KERNELS[k]] = {"counters": c, "derived": d}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps({k: v["derived"] for k, v in res["kernels"].items()}))
