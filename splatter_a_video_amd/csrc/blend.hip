@@ -170,20 +170,16 @@ __device__ __forceinline__ bool cull_test(float u, float v, float a, float b, fl
     const float ddy = fmaxf(fmaxf(dy0, -dy1), 0.f);
     if (!((ddx <= p.hx) && (ddy <= p.hy))) return false;
     if (ddx == 0.f && ddy == 0.f) return true;  // centre inside the block
-    // minimum of q on the four edges (q is convex: clamp the unconstrained minimiser of each edge line)
-    float qmin;
-    {
-        const float y0 = fminf(fmaxf(-b * dx0 * p.ic, dy0), dy1), y1 = fminf(fmaxf(-b * dx1 * p.ic, dy0), dy1);
-        const float q0 = a * dx0 * dx0 + 2.f * b * dx0 * y0 + c * y0 * y0;
-        const float q1 = a * dx1 * dx1 + 2.f * b * dx1 * y1 + c * y1 * y1;
-        qmin = fminf(q0, q1);
-    }
-    {
-        const float x0 = fminf(fmaxf(-b * dy0 * p.ia, dx0), dx1), x1 = fminf(fmaxf(-b * dy1 * p.ia, dx0), dx1);
-        const float q0 = a * x0 * x0 + 2.f * b * x0 * dy0 + c * dy0 * dy0;
-        const float q1 = a * x1 * x1 + 2.f * b * x1 * dy1 + c * dy1 * dy1;
-        qmin = fminf(qmin, fminf(q0, q1));
-    }
+    // q is convex with its minimum at the centre, and the centre lies outside the block: the block minimum sits on an
+    // edge that FACES the centre (the segment from the centre to any point of the block enters it through such an
+    // edge, at a point where q is smaller) -- one vertical and/or one horizontal edge; on each, clamp the
+    // unconstrained minimiser of the edge line
+    const float INF = __builtin_inff();
+    const float xe = dx0 > 0.f ? dx0 : dx1, ye = dy0 > 0.f ? dy0 : dy1;  // the facing edges (meaningful where dd* > 0)
+    const float ys = fminf(fmaxf(-b * xe * p.ic, dy0), dy1), xs = fminf(fmaxf(-b * ye * p.ia, dx0), dx1);
+    const float qx = a * xe * xe + 2.f * b * xe * ys + c * ys * ys;
+    const float qy = a * xs * xs + 2.f * b * xs * ye + c * ye * ye;
+    const float qmin = fminf(ddx > 0.f ? qx : INF, ddy > 0.f ? qy : INF);
     // q is evaluated with ~1e-6 relative error of its largest term; the terms are bounded by (a+c+2|b|) * r^2
     const float r2 = fmaxf(dx0 * dx0, dx1 * dx1) + fmaxf(dy0 * dy0, dy1 * dy1);
     const float qerr = 4e-6f * (a + c + 2.f * fabsf(b)) * r2;
