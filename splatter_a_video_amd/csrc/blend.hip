@@ -20,7 +20,7 @@
 //   * backward ("pair" mode, used when idx_sorted comes from our sort_gaussian): per-lane partial
 //     gradients are wave-reduced with in-place DPP adds (row_shr x4, row_bcast x2), lane 63
 //     stores the (8+C)-float record into the wave's private LDS slab; after the super-batch the
-//     four slabs are summed and every record (padded to whole 64-B sectors) is stored at its
+//     four slabs are summed and every record (padded to whole 16-byte chunks) is stored at its
 //     Gaussian-major pair slot (slot_sorted[] comes out of the tile sort); pair_reduce_kernel then
 //     streams each Gaussian's contiguous records.  No global atomics at all.
 //   * backward ("atomic" mode, foreign idx_sorted): same replay per wave, one hardware float
@@ -81,7 +81,7 @@ struct BlendArgs {
     float *dL_duv, *dL_dabs_uv, *dL_dconic, *dL_dopacity, *dL_dfeature, *dL_dbias;
     float *dL_dndc, *dL_dabs_ndc;  // optional densification taps (pair mode): dL_duv / dL_dabs_uv scaled by (W/2, H/2)
     // atomic-free backward: per-(tile,splat) partial sums + inverse pair map
-    float *pair_buf;        // [M, NCP] partial gradients, one 64-B-aligned record per pair SLOT (Gaussian-major)
+    float *pair_buf;        // [M, NCP] partial gradients, one 16-B-aligned record per pair SLOT (Gaussian-major)
     const int *goff_incl;   // [P] inclusive prefix of tiles per Gaussian (slot ranges)
     const int *slot_sorted; // [M] sorted position -> pair slot
     int accumulate;         // reduce: add to the geometry gradients (channel chunks > 0)
@@ -630,11 +630,14 @@ __device__ __forceinline__ void replay_one(const float4 &g0, const float4 &g1, c
 }
 
 // ------------------------------------------------------------------ backward, atomic-free ("pair" mode)
+// stride of a pair record in floats: the used floats rounded up to whole 16-byte chunks (a Gaussian's records are
+// contiguous, pair_reduce streams them with float4 loads; padding every record to a 64-byte sector cost 30 % more traffic)
+#define PAIR_STRIDE(nc) (((nc) + 3) & ~3)
 template <int CH, bool ABS, bool BIAS>
 struct PairCfg {
     static constexpr int NG = GradLayout<ABS, BIAS>::NG;  // ux uy ca cb cc o [ax ay] [bias]
     static constexpr int NC = NG + CH;       // used floats per pair record
-    static constexpr int NCP = (NC + 15) & ~15;  // record stride in pair_buf: whole 64-B sectors
+    static constexpr int NCP = PAIR_STRIDE(NC);  // record stride in pair_buf
     static constexpr int SB = 64;
 };
 
@@ -751,8 +754,8 @@ blend_bwd_pair_kernel(const BlendArgs A) {
         }
         if (lane == 0) s_mask[w] = wrote;
         __syncthreads();
-        // ---- combine the four slabs; each record (NCP floats = whole 64-B sectors) goes to its pair slot,
-        //      16 consecutive lanes write one sector: entry e <-> sorted position top - e
+        // ---- combine the four slabs; each record (NCP floats) goes to its pair slot, consecutive lanes write
+        //      consecutive floats of it: entry e <-> sorted position top - e
         {
             const int lo = top - nb + 1;
             const unsigned long long m0 = s_mask[0], m1 = s_mask[1], m2 = s_mask[2], m3 = s_mask[3];
@@ -774,9 +777,9 @@ blend_bwd_pair_kernel(const BlendArgs A) {
 }
 
 // sums each Gaussian's pair records (contiguous slots [goff[i-1], goff[i])) into the final gradients.
-// Four lanes per Gaussian: lane `sub` owns floats [4*sub, 4*sub+4) of every 16-float sector, so a
-// quad reads one whole 64-B sector per record (coalesced), accumulates in registers with no
-// cross-lane traffic, and writes its own components with plain stores.
+// Four lanes per Gaussian: lane `sub` owns the 16-byte chunks sub, sub + 4, ... of every record, so a quad reads up to
+// 64 contiguous bytes per step (coalesced), accumulates in registers with no cross-lane traffic, and writes its own
+// components with plain stores.
 template <bool ABS, bool BIAS>
 __device__ __forceinline__ void store_component(const BlendArgs &A, int i, int k, float v) {
     using GL = GradLayout<ABS, BIAS>;
@@ -815,7 +818,8 @@ pair_reduce_kernel(const BlendArgs A) {
     const int i = t >> 2, sub = t & 3;
     if (i >= A.P) return;
     const int beg = i > 0 ? A.goff_incl[i - 1] : 0, end = A.goff_incl[i];
-    constexpr int NS = NCP / 16;  // sectors per record
+    constexpr int NQ = NCP / 4;         // 16-byte chunks per record; lane `sub` owns chunks sub, sub + 4, ...
+    constexpr int NS = (NQ + 3) / 4;
     float4 a[NS];
 #pragma unroll
     for (int c = 0; c < NS; ++c) a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -825,8 +829,9 @@ pair_reduce_kernel(const BlendArgs A) {
         float4 v0[NS], v1[NS];
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
-            v0[c] = *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c);
-            v1[c] = *reinterpret_cast<const float4 *>(base + (size_t)(j + 1) * NCP + 16 * c);
+            const bool mine = 4 * c + sub < NQ;
+            v0[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v1[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)(j + 1) * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
@@ -837,17 +842,21 @@ pair_reduce_kernel(const BlendArgs A) {
     if (j < end) {
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
-            const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c);
-            a[c].x += v.x; a[c].y += v.y; a[c].z += v.z; a[c].w += v.w;
+            if (4 * c + sub < NQ) {
+                const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c);
+                a[c].x += v.x; a[c].y += v.y; a[c].z += v.z; a[c].w += v.w;
+            }
         }
     }
 #pragma unroll
     for (int c = 0; c < NS; ++c) {
-        const int k = 16 * c + 4 * sub;
-        store_component<ABS, BIAS>(A, i, k + 0, a[c].x);
-        store_component<ABS, BIAS>(A, i, k + 1, a[c].y);
-        store_component<ABS, BIAS>(A, i, k + 2, a[c].z);
-        store_component<ABS, BIAS>(A, i, k + 3, a[c].w);
+        if (4 * c + sub < NQ) {
+            const int k = 16 * c + 4 * sub;
+            store_component<ABS, BIAS>(A, i, k + 0, a[c].x);
+            store_component<ABS, BIAS>(A, i, k + 1, a[c].y);
+            store_component<ABS, BIAS>(A, i, k + 2, a[c].z);
+            store_component<ABS, BIAS>(A, i, k + 3, a[c].w);
+        }
     }
 }
 
@@ -875,7 +884,7 @@ template <int CH, bool ABS>
 struct MfmaCfg {
     static constexpr int NG = GradLayout<ABS, false>::NG;
     static constexpr int NC = NG + CH;
-    static constexpr int NCP = (NC + 15) & ~15;
+    static constexpr int NCP = PAIR_STRIDE(NC);
     static constexpr int SB = CH <= 8 ? BLEND_MFMA_SB : 64;
     static constexpr int PZ = CH;                 // a zero slot (lanes without a channel feed it to the MFMAs)
     static constexpr int PS = (CH + 1 + 3) & ~3;  // state block [T_final*bg.g, ncontrib, T_state, R_state] (16-B aligned)
@@ -1374,7 +1383,7 @@ extern "C" size_t splat_blend_pack_floats(int C) {
 
 extern "C" size_t splat_blend_pair_floats(int C, int has_bias) {
     // floats per pair record (upper bound over the abs / no-abs layouts) for the widest channel chunk
-    return (size_t)((((has_bias ? 9 : 8) + chunk_ch(C > 32 ? 32 : C)) + 15) & ~15);
+    return (size_t)PAIR_STRIDE((has_bias ? 9 : 8) + chunk_ch(C > 32 ? 32 : C));
 }
 
 // ================================================================== C ABI
