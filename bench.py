@@ -312,6 +312,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # setup, not workload: one frame of a 512-Gaussian 64x64 scene through the same operators loads the library's code
+    # objects and initialises the allocator, so that `--warmup 0` does not time HIP module loading
+    tiny = make_scene(512, 64, 64, F=clip, C=a.channels, seed=1)
+    Rt = FrameRenderer(tiny, dev, a.channels, fused=not a.ops, dynamic=a.dynamic, overlap_allreduce=False)
+    Rt.step([0 if a.dynamic else Rt.offsets(0)], collective=False)
+    torch.cuda.synchronize()
+    del Rt, tiny
+
     for _ in range(a.warmup):
         R.step(offs)
     R.finish()
