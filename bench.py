@@ -319,6 +319,11 @@ def main():
     Rt.step([0 if a.dynamic else Rt.offsets(0)], collective=False)
     torch.cuda.synchronize()
     del Rt, tiny
+    if launched:   # communicator / channel set-up is setup as well (first collective of the process group)
+        prime = torch.zeros(1 << 20, device=dev)
+        dist.all_reduce(prime)
+        torch.cuda.synchronize()
+        del prime
 
     for _ in range(a.warmup):
         R.step(offs)
