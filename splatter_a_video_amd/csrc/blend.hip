@@ -95,7 +95,7 @@ struct BlendArgs {
 // are dealt round-robin so that every XCD sees the whole image (a contiguous band per XCD halves the HBM reads as
 // well but leaves the XCDs that own the image borders idle early).  Block b = XCD b & 7, its (b >> 3)-th block.
 #ifndef BLEND_XCD_RUN
-#define BLEND_XCD_RUN 16
+#define BLEND_XCD_RUN 64   // a run is about one tile row of a 480p frame plus the start of the next (54 tiles per row)
 #endif
 __device__ __forceinline__ int xcd_tile(int b, int T) {
 #if BLEND_XCD_RUN > 1
