@@ -129,8 +129,10 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
 // 32 tile columns x 32 row groups per workgroup: every thread loads its (at most 16) rows of one column in one
 // batch -- a wave reads two 128-byte row segments per instruction --, scans them in registers, and the group totals
 // are exchanged through LDS.  The matrix is read once and written once.
+#ifndef COLSCAN_COLS
 #define COLSCAN_COLS 32
-#define COLSCAN_GROUPS 32
+#endif
+#define COLSCAN_GROUPS (1024 / COLSCAN_COLS)
 #define COLSCAN_ROWS (BIN_MAX_NB / COLSCAN_GROUPS)
 __global__ void __launch_bounds__(COLSCAN_COLS * COLSCAN_GROUPS)
 bin_colscan_kernel(int T, int NB, int *__restrict__ matrix, int *__restrict__ tile_count) {
