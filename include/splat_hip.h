@@ -104,7 +104,7 @@ int splat_bin_count(int P, const float *uv, const int32_t *radius, int W, int H,
  * slot_sorted[M] = slot of each sorted entry (owner[M] is workspace: Gaussian id of each slot).  The atomic-free
  * blend backward consumes goff_incl and slot_sorted. */
 int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
-                   void *scratch, const int32_t *tile_range, int64_t capacity, uint64_t *keys,
+                   void *scratch, int32_t *tile_range /*in; clamped to the capacity on overflow*/, int64_t capacity, uint64_t *keys,
                    int32_t *idx_sorted, int32_t *overflow_out, int32_t *goff_incl /*out*/,
                    int32_t *owner, int32_t *slot_sorted, splat_stream_t stream);
 
@@ -147,6 +147,9 @@ int splat_alpha_blending_backward(int P, int C, const float *uv, const float *co
                                   const int32_t *goff_incl, const int32_t *slot_sorted,
                                   float *pair_scratch, float *pack_scratch,
                                   int pack_is_valid /*pack_scratch still holds the forward's records (C <= 32)*/,
+                                  float *dbg_T_front /*NULL, or [H,W]: the transmittance the replay reaches in front of
+                                    each pixel's first splat -- 1 up to rounding iff the backward reproduced every
+                                    inclusion decision of the forward (a flipped decision is off by >= 1/255)*/,
                                   splat_stream_t stream);
 
 /* ---- per-frame evaluation of the dynamic Gaussians --------------------------------------
@@ -262,6 +265,18 @@ int splat_knn_scatter(int M, const float *points, const int32_t *cell_of, const 
 int splat_knn_search(int N, const float *query, const int32_t *query_order, int M, const float *sorted,
                      const int32_t *cell_start, const void *plan, int K, float *dists, int32_t *idx,
                      splat_stream_t stream);
+
+/* ---- optimiser step of the frame-sharded data-parallel renderer: replaces the per-group
+ *      torch.optim.Adam.step() the reference reaches through src/pointrix/optimizer/optimizer.py:70-83 (Adam built in
+ *      atlas_gs_optimizer / configs with eps = 1e-15, one learning rate per parameter group), as one launch over the
+ *      flat buffer the gradient all-reduce just summed.  No weight decay, no amsgrad.
+ *      seg_end_host[nseg] (host, ascending, last == n) and seg_lr_host[nseg] (host): learning rate of each contiguous
+ *      segment (parameter group); grad_scale multiplies the gradient first (1 / world size for a mean); step >= 1 is
+ *      the 1-based step count t of the bias corrections.  All device buffers 16-byte aligned. ---- */
+#define SPLAT_ADAM_MAX_SEGMENTS 16
+int splat_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int nseg,
+                    const int64_t *seg_end_host, const float *seg_lr_host, float beta1, float beta2, float eps,
+                    int step, float grad_scale, splat_stream_t stream);
 
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */
 void splat_profile_enable(int on);

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -34,6 +34,7 @@ SYMBOLS = [
     "splat_densify_accumulate", "splat_densify_update", "splat_densify_masks",
     "splat_compact_scratch_bytes", "splat_compact_scan", "splat_compact_rows",
     "splat_knn_grid_cells", "splat_knn_plan_bytes", "splat_knn_build", "splat_knn_scatter", "splat_knn_search",
+    "splat_adam_step",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]
 

@@ -262,7 +262,8 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
                 tot += v;
             }
             __syncthreads();
-            if (i < end) goff_incl[i] = running + woff + inc;
+            // clamped to the capacity: after an overflowing (flagged) sort every consumer still stays inside its buffers
+            if (i < end) goff_incl[i] = (int)(((long long)(running + woff + inc) < capacity) ? (long long)(running + woff + inc) : capacity);
             j = running + woff + inc - area;
             running += tot;
         }
@@ -442,8 +443,8 @@ __device__ __forceinline__ void tile_sort_regs(const u64 *g, int n, long long r0
         if (i < n) {
             const int lo = (int)(unsigned)(k[r] & 0xffffffffull);
             if (slot_sorted) {
-                slot_sorted[r0 + i] = lo;
-                idx_sorted[r0 + i] = (long long)lo < capacity ? owner[lo] : 0;  // slots past the capacity: overflowed sort, owner unrecorded
+                slot_sorted[r0 + i] = (long long)lo < capacity ? lo : (int)(capacity - 1);
+                idx_sorted[r0 + i] = (long long)lo < capacity ? owner[lo] : 0;
             } else {
                 idx_sorted[r0 + i] = lo;
             }
@@ -452,13 +453,20 @@ __device__ __forceinline__ void tile_sort_regs(const u64 *g, int n, long long r0
 }
 
 __global__ void __launch_bounds__(SORT_BLOCK)
-tile_sort_kernel(const int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
+tile_sort_kernel(int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
                  int *__restrict__ idx_sorted, const int *__restrict__ owner, int *__restrict__ slot_sorted) {
     __shared__ __attribute__((aligned(16))) unsigned long long sk[SORT_LDS_KEYS];
     const int t = blockIdx.x;
-    const long long r0 = tile_range[2 * t];
+    long long r0 = tile_range[2 * t];
     long long r1 = tile_range[2 * t + 1];
-    if (r1 > capacity) r1 = capacity;  // overflow already flagged by K3
+    if (r1 > capacity) {  // overflow (already flagged by K3): the range the blend kernels will read never leaves the buffers
+        r1 = capacity;
+        if (r0 > capacity) r0 = capacity;
+        if (threadIdx.x == 0) {
+            tile_range[2 * t] = (int)r0;
+            tile_range[2 * t + 1] = (int)r1;
+        }
+    }
     const int n = (int)(r1 - r0);
     if (n <= 0) return;
     unsigned long long *g = keys + r0;
@@ -473,8 +481,8 @@ tile_sort_kernel(const int *__restrict__ tile_range, long long capacity, unsigne
         for (int i = threadIdx.x; i < n; i += SORT_BLOCK) {
             const int lo = (int)(unsigned)(g[i] & 0xffffffffull);
             if (slot_sorted) {
-                slot_sorted[r0 + i] = lo;
-                idx_sorted[r0 + i] = (long long)lo < capacity ? owner[lo] : 0;  // slots past the capacity: overflowed sort, owner unrecorded
+                slot_sorted[r0 + i] = (long long)lo < capacity ? lo : (int)(capacity - 1);
+                idx_sorted[r0 + i] = (long long)lo < capacity ? owner[lo] : 0;
             } else {
                 idx_sorted[r0 + i] = lo;
             }
@@ -526,7 +534,7 @@ extern "C" int splat_bin_count(int P, const float *uv, const int32_t *radius, in
 }
 
 extern "C" int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
-                              void *scratch, const int32_t *tile_range, int64_t capacity, uint64_t *keys,
+                              void *scratch, int32_t *tile_range, int64_t capacity, uint64_t *keys,
                               int32_t *idx_sorted, int32_t *overflow_out, int32_t *goff_incl,
                               int32_t *owner_scratch, int32_t *slot_sorted, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0 && capacity >= 0, "bad sizes");

@@ -87,7 +87,88 @@ struct BlendArgs {
     int accumulate;         // reduce: add to the geometry gradients (channel chunks > 0)
     int pack_valid;         // backward: pack already holds this chunk's records (kept from the forward)
     float *pack;            // [P, Rec<CH>::RS] packed records of the current channel chunk (scratch)
+    float *dbg_T_front;     // optional [H,W] (backward): the transmittance the replay arrives at in front of the first splat
+                            // (1 up to rounding iff every inclusion decision of the forward was reproduced)
+    // frame batch: F frames of one Gaussian set in a single launch (workgroup -> (frame, tile)); every per-frame array
+    // is the frame-0 pointer plus frame * stride.  F = 1: the single-frame operators.
+    int F, T;               // frames, tiles per frame
+    long long cap;          // pair capacity per frame: stride of idx_sorted / slot_sorted / pair_buf records
+    long long pack_fs;      // floats between two frames' packed records
+    long long opacity_fs, feature_fs, bias_fs;  // element strides of the per-Gaussian inputs (0: shared by all frames)
 };
+
+// per-frame view of the argument block (all uniform: scalar address arithmetic)
+__device__ __forceinline__ BlendArgs frame_args(const BlendArgs &B, int f) {
+    BlendArgs A = B;
+    if (B.F > 1) {
+        const size_t HW = (size_t)B.H * B.W, fz = (size_t)f;
+        A.uv = B.uv + fz * B.P;
+        A.conic = B.conic + fz * 3 * B.P;
+        A.opacity = B.opacity + fz * B.opacity_fs;
+        A.feature = B.feature + fz * B.feature_fs;
+        if (B.bias) A.bias = B.bias + fz * B.bias_fs;
+        A.idx_sorted = B.idx_sorted + fz * B.cap;
+        A.tile_range = B.tile_range + fz * B.T;
+        A.pack = B.pack + fz * B.pack_fs;
+        if (B.out) A.out = B.out + fz * B.C * HW;
+        if (B.final_T) A.final_T = B.final_T + fz * HW;
+        if (B.ncontrib) A.ncontrib = B.ncontrib + fz * HW;
+        if (B.gs_idx) A.gs_idx = B.gs_idx + fz * HW * B.K;
+        if (B.dL_dout) A.dL_dout = B.dL_dout + fz * B.C * HW;
+        if (B.slot_sorted) A.slot_sorted = B.slot_sorted + fz * B.cap;
+        if (B.goff_incl) A.goff_incl = B.goff_incl + fz * B.P;
+        if (B.dbg_T_front) A.dbg_T_front = B.dbg_T_front + fz * HW;
+    }
+    return A;
+}
+
+// ---- the splat's exponent: ONE arithmetic for the forward and every backward kernel, so that a pixel's backward
+// reproduces its forward's alpha bit for bit (the reference's two kernels share their expression as well,
+// src/alpha_blending.cu:78-87 vs :196-203; a decision alpha >= 1/255 that flips between the two passes would corrupt
+// the T /= (1 - alpha) replay of that pixel).
+//   power(x, y) * log2(e) = q0 + qx x + qy y + qxx x^2 + qxy x y + qyy y^2      x, y: pixel relative to the tile centre
+// evaluated as the fused-multiply-add chain q0 -> +x qx -> +y qy -> +xx qxx -> +xy qxy -> +yy qyy.  The matrix-core
+// backward gets exactly this chain from two v_mfma_f32_16x16x4_f32 (an f32 MFMA is the ascending fma chain over k
+// starting from C: profiles/r02_mfma_fma_chain_probe.json, 2^20 of 2^20 random products bit-equal); the lane = pixel
+// kernels run it on the VALU.  The coefficients come from power_coeffs() everywhere (explicit fma, no contraction).
+// power is a negative-semidefinite form that only exceeds 0 by rounding; the expanded polynomial carries an absolute
+// error of ~1e-5 (log2 units), so the reference's "power > 0" guard (src/alpha_blending.cu:93) sits just above that
+// noise (BLEND_PW_MAX) -- at exactly 0 it would drop pixels that sit on a splat's centre.
+#define BLEND_L2E 1.4426950408889634f
+struct PowerCoef {
+    float q0, qx, qy, qxx, qxy, qyy;
+};
+__device__ __forceinline__ PowerCoef power_coeffs(float u, float v, float cA, float cB, float cC, float cx, float cy) {
+#pragma clang fp contract(off)
+    const float uc = u - cx, vc = v - cy;  // splat centre relative to the tile centre
+    const float tx = __builtin_fmaf(cA, uc, cB * vc);
+    const float ty = __builtin_fmaf(cB, uc, cC * vc);
+    PowerCoef k;
+    k.q0 = (-0.5f * BLEND_L2E) * __builtin_fmaf(uc, tx, vc * ty);
+    k.qx = BLEND_L2E * tx;
+    k.qy = BLEND_L2E * ty;
+    k.qxx = (-0.5f * BLEND_L2E) * cA;
+    k.qxy = (-BLEND_L2E) * cB;
+    k.qyy = (-0.5f * BLEND_L2E) * cC;
+    return k;
+}
+// lane = pixel evaluation; c0 = [q0 qx qy qxx], c1 = [qxy qyy . .]; x, y, xx = x^2, xy, yy = y^2 exact in f32
+__device__ __forceinline__ float power_poly(const float4 &c0, const float4 &c1, float x, float y, float xx, float xy,
+                                            float yy) {
+    float pw = __builtin_fmaf(x, c0.y, c0.x);
+    pw = __builtin_fmaf(y, c0.z, pw);
+    pw = __builtin_fmaf(xx, c0.w, pw);
+    pw = __builtin_fmaf(xy, c1.x, pw);
+    return __builtin_fmaf(yy, c1.y, pw);
+}
+// opacity-bias variant (no cull, no matrix-core kernel): the reference's factored expression, shared by its forward
+// and backward kernels; returns -power
+__device__ __forceinline__ float neg_power_factored(float dx, float dy, float cA, float cB, float cC) {
+#pragma clang fp contract(off)
+    const float h = __builtin_fmaf(cA, 0.5f * dx, cB * dy);
+    return __builtin_fmaf(dx, h, (cC * (0.5f * dy)) * dy);
+}
+__device__ __forceinline__ float exp_neg(float q) { return __builtin_amdgcn_exp2f(-BLEND_L2E * q); }
 
 // Workgroups are handed to the 8 XCDs round-robin by linear block id, and every XCD has its own L2.  Neighbouring
 // tiles gather largely the same packed records (a splat touches ~4 tiles), so runs of BLEND_XCD_RUN consecutive tiles
@@ -188,7 +269,8 @@ __device__ __forceinline__ bool cull_test(float u, float v, float a, float b, fl
 
 template <int CH, bool BIAS, bool EXACT>
 __global__ void __launch_bounds__(256)
-pack_kernel(const BlendArgs A) {
+pack_kernel(const BlendArgs B) {
+    const BlendArgs A = frame_args(B, blockIdx.y);
     constexpr int RS = Rec<CH>::RS, RQ = Rec<CH>::RQ;
     constexpr int LS = RS + 4;  // LDS row stride in floats: 16-B aligned, conflict-free for the float4 row writes
     __shared__ __attribute__((aligned(16))) float s_rec[(RS <= 32 ? 256 : 1) * LS];
@@ -235,18 +317,21 @@ pack_kernel(const BlendArgs A) {
 
 // ---- staging area of one super-batch (shared by the four waves of a tile): SB packed records,
 // slot SB = inert (all-zero) record for the padded tail of the survivor lists
-template <int CH, int SB>
+// COEF: the staging threads also leave the exponent's polynomial [q0 qx qy qxx | qxy qyy o id] of every entry (tile-centred,
+// power_coeffs) for the lane = pixel kernels; slot SB is the inert entry (opacity 0).
+template <int CH, int SB, bool COEF = false>
 struct TileLDS {
     static constexpr int RQ = Rec<CH>::RQ;
     float4 rec[(SB + 1) * RQ];
+    float4 coef[COEF ? 2 * (SB + 1) : 1];
     unsigned int keep[SB];  // byte w of entry e: wave w's 8x8 block can be reached by the splat (and passes its predicate)
     unsigned short list[4][SB + 16];
     __device__ __forceinline__ const float4 &g0(int e) const { return rec[e * RQ]; }      // u v A B
     __device__ __forceinline__ const float4 &g1(int e) const { return rec[e * RQ + 1]; }  // C o bias id
 };
 
-template <int CH, int SB>
-__device__ __forceinline__ void read_feat(const TileLDS<CH, SB> &L, int e, float f[CH]) {
+template <int CH, int SB, bool COEF>
+__device__ __forceinline__ void read_feat(const TileLDS<CH, SB, COEF> &L, int e, float f[CH]) {
     constexpr int RQ = Rec<CH>::RQ;
 #pragma unroll
     for (int k = 0; k < CH; k += 4) {
@@ -288,7 +373,8 @@ struct Stager {
                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    __device__ __forceinline__ void park(TileLDS<CH, SB> &L, int tid) const {
+    template <bool COEF>
+    __device__ __forceinline__ void park(TileLDS<CH, SB, COEF> &L, int tid) const {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = tid + 256 * k;
@@ -302,8 +388,8 @@ struct Stager {
 // need before the geometric test.  Callers put a __syncthreads() between tile_cull and build_list.
 // SUB: the flag byte of a kept block carries one bit per 4x4 quarter (bit sx + 2 sy) from a bounding-box test of the
 // quarter's pixel centres, for kernels that keep a survivor list per quarter; otherwise the byte is 0 / 1.
-template <int CH, int SB, bool BIAS, bool SUB, typename Pred>
-__device__ __forceinline__ void tile_cull(TileLDS<CH, SB> &L, int tid, int nb, float tx0, float ty0, Pred pred) {
+template <int CH, int SB, bool BIAS, bool SUB, bool COEF, typename Pred>
+__device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF> &L, int tid, int nb, float tx0, float ty0, Pred pred) {
     constexpr int TPE = 256 / SB;  // threads per entry (1, 2 or 4): each tests 4 / TPE of the blocks
     constexpr int BPT = 4 / TPE;
     static_assert(SB == 64 || SB == 128 || SB == 256, "super-batch sizes the 256-thread cull supports");
@@ -318,6 +404,11 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB> &L, int tid, int nb, f
             for (int j = 0; j < BPT; ++j) k[j] = pred(e, BPT * part + j) ? (SUB ? 15u : 1u) : 0u;
         } else {
             const float4 a0 = L.g0(e), a1 = L.g1(e);
+            if (COEF && part == 0) {
+                const PowerCoef k = power_coeffs(a0.x, a0.y, a0.z, a0.w, a1.x, tx0 + 7.5f, ty0 + 7.5f);
+                L.coef[2 * e] = make_float4(k.q0, k.qx, k.qy, k.qxx);
+                L.coef[2 * e + 1] = make_float4(k.qxy, k.qyy, a1.y, a1.w);
+            }
             CullP cp;
             if (Rec<CH>::CULL >= 0) {
                 constexpr int CO = Rec<CH>::CULL >= 0 ? Rec<CH>::CULL : 0;
@@ -352,8 +443,8 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB> &L, int tid, int nb, f
 }
 
 // wave w's order-preserving survivor list from the flag bytes; returns the count.
-template <int CH, int SB>
-__device__ __forceinline__ int build_list(TileLDS<CH, SB> &L, int w, int lane) {
+template <int CH, int SB, bool COEF>
+__device__ __forceinline__ int build_list(TileLDS<CH, SB, COEF> &L, int w, int lane) {
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < SB / WAVE; ++r) {
@@ -378,20 +469,26 @@ struct FwdCfg {
 
 template <int CH, bool ENH, bool BIAS, bool EXACT>
 __global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_FWD_MINW : 1))
-blend_fwd_kernel(const BlendArgs A) {
+blend_fwd_kernel(const BlendArgs B) {
     constexpr int SB = FwdCfg<CH>::SB;
     constexpr int U = CH <= 8 ? BLEND_FWD_U : 2;  // survivors evaluated per trip
     constexpr int RB = Rec<CH>::RS * 4;           // bytes per record
-    static_assert((SB + 1) * RB <= 65536 && SB % U == 0, "record offsets must fit the 16-bit list entries");
-    __shared__ TileLDS<CH, SB> L;
-    __shared__ __attribute__((aligned(8))) unsigned short s_qlist[4][4][SB];  // [wave][quarter] survivor lists (record byte offsets)
+    constexpr int RM = RB / 32;                   // record offset = RM * coefficient-block offset
+    static_assert((SB + 1) * 32 <= 65536 && SB % U == 0 && RB % 32 == 0, "offsets must fit the 16-bit list entries");
+    __shared__ TileLDS<CH, SB, !BIAS> L;
+    __shared__ __attribute__((aligned(8))) unsigned short s_qlist[4][4][SB];  // [wave][quarter] survivor lists (32 e: coefficient-block byte offsets)
     __shared__ int s_done[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int gtile = xcd_tile(blockIdx.x, gridDim.x);
+    const int frame = gtile / B.T, tile = gtile - frame * B.T;
+    const BlendArgs A = frame_args(B, frame);
     const int tx = tile % A.gx, ty = tile / A.gx;
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const int px = bx + (lane & 7), py = by + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
+    // pixel relative to the tile centre and its monomials (exact in f32)
+    const float x = (float)((w & 1) * 8 + (lane & 7)) - 7.5f, y = (float)((w >> 1) * 8 + (lane >> 3)) - 7.5f;
+    const float xx = x * x, xy = x * y, yy = y * y;
     const int cn = EXACT ? CH : A.cn;
 
     const bool inside = (px < A.W) && (py < A.H);
@@ -404,6 +501,7 @@ blend_fwd_kernel(const BlendArgs A) {
     const int n = range.y - range.x;
 
     if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
+    if (!BIAS && tid < 2) L.coef[2 * SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     // list position of (entry e, super-batch b): forward walk
     auto pos = [n](int e, int b) { const int q = b * SB + e; return q < n ? q : -1; };
     Stager<CH, SB> st;
@@ -420,14 +518,14 @@ blend_fwd_kernel(const BlendArgs A) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
         if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;  // every pixel of the tile is saturated
-        tile_cull<CH, SB, BIAS, true>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE), [&](int, int ww) { return !s_done[ww]; });
+        tile_cull<CH, SB, BIAS, true, !BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE), [&](int, int ww) { return !s_done[ww]; });
         __syncthreads();
         if (!alld) {
             // one order-preserving survivor list per 4x4 quarter of the wave's block: the 16 lanes of a quarter walk
             // their own list (a splat is evaluated only on the quarters its bounding box reaches), the wave loops to
-            // the longest of the four.  List entries are the byte offsets of the records inside L.rec; every list is
-            // padded with the inert record up to the common trip count, so a trip is one 8-byte list read + U record
-            // reads, with no bounds test.
+            // the longest of the four.  List entries are byte offsets of the entries' coefficient blocks (32 e); every
+            // list is padded with the inert entry up to the common trip count, so a trip is one 8-byte list read + U
+            // block reads, with no bounds test.
             int cq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) cq[q] = 0;
@@ -440,7 +538,7 @@ blend_fwd_kernel(const BlendArgs A) {
                     const bool keep = (bits >> q) & 1u;
                     const unsigned long long m = __ballot(keep);
                     const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (keep) s_qlist[w][q][cq[q] + before] = (unsigned short)(e * RB);
+                    if (keep) s_qlist[w][q][cq[q] + before] = (unsigned short)(e * 32);
                     cq[q] += __popcll(m);
                 }
             }
@@ -449,13 +547,14 @@ blend_fwd_kernel(const BlendArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll 1
-                for (int i = cq[q] + lane; i < cntU; i += WAVE) s_qlist[w][q][i] = (unsigned short)(SB * RB);  // opacity 0 -> alpha 0
+                for (int i = cq[q] + lane; i < cntU; i += WAVE) s_qlist[w][q][i] = (unsigned short)(SB * 32);  // opacity 0 -> alpha 0
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int myq = ((lane >> 2) & 1) + 2 * ((lane >> 5) & 1);  // quarter of this lane's pixel
             const unsigned short *mylist = s_qlist[w][myq];
             const char *recb = reinterpret_cast<const char *>(L.rec);
-            int lastoff = -1;  // record offset of the last splat applied in this super-batch
+            const char *cfb = reinterpret_cast<const char *>(L.coef);
+            int lastoff = -1;  // block offset of the last splat applied in this super-batch
             for (int j0 = 0; j0 < cntU; j0 += U) {
                 unsigned off[U];
                 static_assert(U == 2 || U == 4, "a trip reads its list entries as one 4- or 8-byte word");
@@ -469,19 +568,22 @@ blend_fwd_kernel(const BlendArgs A) {
                 float alpha[U];  // 0 where the splat does not touch the pixel: no per-splat predicate registers
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    g0[u] = *reinterpret_cast<const float4 *>(recb + off[u]);
-                    g1[u] = *reinterpret_cast<const float4 *>(recb + off[u] + 16);
+                    const char *src = BIAS ? recb + off[u] * RM : cfb + off[u];
+                    g0[u] = *reinterpret_cast<const float4 *>(src);
+                    g1[u] = *reinterpret_cast<const float4 *>(src + 16);
                 }
                 float amax = 0.f;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const float dx = g0[u].x - pxf, dy = g0[u].y - pyf;
-                    // q = -power = dx (a dx/2 + b dy) + (c dy/2) dy : five dependent ops instead of nine
-                    const float q = dx * (g0[u].z * (0.5f * dx) + g0[u].w * dy) + (g1[u].x * (0.5f * dy)) * dy;
-                    float araw = g1[u].y * __expf(-q);
-                    if (BIAS) araw = araw + g1[u].z;
-                    const float a = fminf(0.99f, araw);
-                    alpha[u] = (!(q < 0.f) && !(a < (1.0f / 255.0f))) ? a : 0.f;
+                    if (BIAS) {
+                        const float q = neg_power_factored(g0[u].x - pxf, g0[u].y - pyf, g0[u].z, g0[u].w, g1[u].x);
+                        const float a = fminf(0.99f, __builtin_fmaf(g1[u].y, exp_neg(q), g1[u].z));
+                        alpha[u] = (!(q < 0.f) && !(a < (1.0f / 255.0f))) ? a : 0.f;
+                    } else {
+                        const float pw = power_poly(g0[u], g1[u], x, y, xx, xy, yy);
+                        const float a = fminf(0.99f, g1[u].z * __builtin_amdgcn_exp2f(pw));
+                        alpha[u] = (!(pw > BLEND_PW_MAX) && !(a < (1.0f / 255.0f))) ? a : 0.f;
+                    }
                     amax = fmaxf(amax, alpha[u]);
                 }
                 if (__ballot(!done && amax > 0.f) == 0ull) continue;
@@ -490,7 +592,7 @@ blend_fwd_kernel(const BlendArgs A) {
                     const bool ok = !done && alpha[u] > 0.f;  // an earlier survivor of this trip may have saturated the pixel
                     if (__ballot(ok) == 0ull) continue;
                     float f[CH];
-                    const float4 *fq = reinterpret_cast<const float4 *>(recb + off[u] + 32);  // 16-byte chunks of the record
+                    const float4 *fq = reinterpret_cast<const float4 *>(recb + off[u] * RM + 32);  // 16-byte chunks of the record
 #pragma unroll
                     for (int k = 0; k < CH; k += 4) {
                         const float4 v = fq[k / 4];
@@ -518,7 +620,7 @@ blend_fwd_kernel(const BlendArgs A) {
                     }
                 }
             }
-            last = lastoff >= 0 ? base + lastoff / RB + 1 : last;
+            last = lastoff >= 0 ? base + lastoff / 32 + 1 : last;
         }
         __syncthreads();
     }
@@ -643,20 +745,25 @@ struct PairCfg {
 
 template <int CH, bool ABS, bool BIAS, bool EXACT>
 __global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_BWD_MINW : 1))
-blend_bwd_pair_kernel(const BlendArgs A) {
+blend_bwd_pair_kernel(const BlendArgs B) {
     using Cfg = PairCfg<CH, ABS, BIAS>;
     constexpr int SB = Cfg::SB, NC = Cfg::NC, NCP = Cfg::NCP;
     constexpr int U = CH <= 8 ? BLEND_BWD_U : 1;
-    __shared__ TileLDS<CH, SB> L;
+    __shared__ TileLDS<CH, SB, !BIAS> L;
     __shared__ float s_acc[4][SB * NC];          // private slab per wave: plain stores, no atomics
     __shared__ unsigned long long s_mask[4];     // which entries of the super-batch the wave wrote
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int gtile = xcd_tile(blockIdx.x, gridDim.x);
+    const int frame = gtile / B.T, tile = gtile - frame * B.T;
+    const BlendArgs A = frame_args(B, frame);
+    float *const pair_buf = B.pair_buf + (size_t)frame * (size_t)B.cap * NCP;
     const int tx = tile % A.gx, ty = tile / A.gx;
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const int px = bx + (lane & 7), py = by + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
+    const float x = (float)((w & 1) * 8 + (lane & 7)) - 7.5f, y = (float)((w >> 1) * 8 + (lane >> 3)) - 7.5f;
+    const float xx = x * x, xy = x * y, yy = y * y;
     const size_t HW = (size_t)A.H * A.W;
     const int cn = EXACT ? CH : A.cn;
 
@@ -677,6 +784,7 @@ blend_bwd_pair_kernel(const BlendArgs A) {
     const int wmax = wave_max_i(last);  // this wave never needs entries q >= wmax
     if (lane == 0) s_wmax[w] = wmax;
     if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
+    if (!BIAS && tid < 2) L.coef[2 * SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     const int2 range = A.tile_range[tile];
     const int len = range.y - range.x;
@@ -684,9 +792,12 @@ blend_bwd_pair_kernel(const BlendArgs A) {
     const int *slots = A.slot_sorted + range.x;
     for (int i = n * NCP + tid; i < len * NCP; i += 256) {  // entries nobody replays: zero record
         const int ql = i / NCP;
-        A.pair_buf[(size_t)slots[ql] * NCP + (i - ql * NCP)] = 0.f;
+        pair_buf[(size_t)slots[ql] * NCP + (i - ql * NCP)] = 0.f;
     }
-    if (n <= 0) return;
+    if (n <= 0) {
+        if (A.dbg_T_front && inside) A.dbg_T_front[pix] = T;
+        return;
+    }
 
     // reverse walk: entry e of super-batch b sits at list position n-1 - b*SB - e
     auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };  // negative = past the front
@@ -703,10 +814,10 @@ blend_bwd_pair_kernel(const BlendArgs A) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
 
-        tile_cull<CH, SB, BIAS, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+        tile_cull<CH, SB, BIAS, false, !BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
                                 [&](int e, int ww) { return top - e < s_wmax[ww]; });
         __syncthreads();
-        const int cnt = build_list<CH, SB>(L, w, lane);
+        const int cnt = build_list(L, w, lane);
         unsigned long long wrote = 0ull;
         float *slab = s_acc[w];
         for (int j0 = 0; j0 < cnt; j0 += U) {
@@ -724,12 +835,21 @@ blend_bwd_pair_kernel(const BlendArgs A) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 dx[u] = g0[u].x - pxf; dy[u] = g0[u].y - pyf;
-                const float power = -0.5f * (g0[u].z * dx[u] * dx[u] + g1[u].x * dy[u] * dy[u]) - g0[u].w * dx[u] * dy[u];
-                G[u] = __expf(power);
-                float araw = g1[u].y * G[u];
-                if (BIAS) araw = araw + g1[u].z;
+                bool pw_ok;
+                float araw;
+                if (BIAS) {  // the forward's expressions (blend_fwd_kernel), bit for bit
+                    const float q = neg_power_factored(dx[u], dy[u], g0[u].z, g0[u].w, g1[u].x);
+                    G[u] = exp_neg(q);
+                    araw = __builtin_fmaf(g1[u].y, G[u], g1[u].z);
+                    pw_ok = !(q < 0.f);
+                } else {
+                    const float pw = power_poly(L.coef[2 * e[u]], L.coef[2 * e[u] + 1], x, y, xx, xy, yy);
+                    G[u] = __builtin_amdgcn_exp2f(pw);
+                    araw = g1[u].y * G[u];
+                    pw_ok = !(pw > BLEND_PW_MAX);
+                }
                 alpha[u] = fminf(0.99f, araw);
-                ok[u] = (j0 + u < cnt) && !done && (top - e[u] < last) && !(power > 0.f) && !(alpha[u] < (1.0f / 255.0f));
+                ok[u] = (j0 + u < cnt) && !done && (top - e[u] < last) && pw_ok && !(alpha[u] < (1.0f / 255.0f));
                 any_ok = any_ok || ok[u];
             }
             if (!__any(any_ok)) continue;
@@ -738,7 +858,7 @@ blend_bwd_pair_kernel(const BlendArgs A) {
                 if (BIAS) ok[u] = ok[u] && !done;
                 if (!__any(ok[u])) continue;
                 float f[CH];
-                read_feat<CH, SB>(L, e[u], f);
+                read_feat(L, e[u], f);
                 float r[NC];
 #pragma unroll
                 for (int k = 0; k < NC; ++k) r[k] = 0.f;
@@ -769,11 +889,12 @@ blend_bwd_pair_kernel(const BlendArgs A) {
                     if ((m2 >> e) & 1ull) v += s_acc[2][e * NC + c];
                     if ((m3 >> e) & 1ull) v += s_acc[3][e * NC + c];
                 }
-                A.pair_buf[(size_t)slots[lo + ql] * NCP + c] = v;
+                pair_buf[(size_t)slots[lo + ql] * NCP + c] = v;
             }
         }
         __syncthreads();
     }
+    if (A.dbg_T_front && inside) A.dbg_T_front[pix] = T;
 }
 
 // sums each Gaussian's pair records (contiguous slots [goff[i-1], goff[i])) into the final gradients.
@@ -936,22 +1057,26 @@ __device__ __forceinline__ void row_shr1_add4(float (&R)[4], const float (&rs)[4
 
 template <int CH, bool ABS, bool EXACT>
 __global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_MFMA_MINW : 1))
-blend_bwd_mfma_kernel(const BlendArgs A) {
+blend_bwd_mfma_kernel(const BlendArgs B) {
     using Cfg = MfmaCfg<CH, ABS>;
     constexpr int SB = Cfg::SB, NG = Cfg::NG, NC = Cfg::NC, NCP = Cfg::NCP, PW = Cfg::PW, NA = Cfg::NA, NK = Cfg::NK;
     constexpr int PZ = Cfg::PZ, PS = Cfg::PS;
     constexpr int I_ABS = GradLayout<ABS, false>::I_ABS;
-    constexpr float L2E = 1.4426950408889634f;
     __shared__ TileLDS<CH, SB> L;
     __shared__ float s_acc[4][SB * NC];      // private slab per wave
     __shared__ __attribute__((aligned(16))) float s_pix[4][64 * PW];
     __shared__ float s_mom[16 * 64];         // A operand of the moment product: [step 4 G + i][lane]
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int gtile = xcd_tile(blockIdx.x, gridDim.x);
+    const int frame = gtile / B.T, tile = gtile - frame * B.T;
+    const BlendArgs A = frame_args(B, frame);
+    float *const pair_buf = B.pair_buf + (size_t)frame * (size_t)B.cap * NCP;
     const int tx = tile % A.gx, ty = tile / A.gx;
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const float bx0 = (float)bx, by0 = (float)by;
+    const float tcx = (float)(tx * TILE) + 7.5f, tcy = (float)(ty * TILE) + 7.5f;  // tile centre: origin of the power polynomial
+    const float ox = (float)((w & 1) * 8) - 7.5f, oy = (float)((w >> 1) * 8) - 7.5f;  // block origin relative to it
     const int cn = EXACT ? CH : A.cn;
     const int nl = lane & 15, kk = lane >> 4;
     int wmax;
@@ -969,12 +1094,14 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
         if (grp == 2) v = i == 0 ? 1.f : i == 1 ? y : i == 2 ? y * y : 0.f;
         s_mom[64 * st + lane] = v;
     }
-    // A operand of the power product, A[m = pixel nl of strip G][k = kk]: monomials 1 x y xx | xy yy 0 0
+    // A operand of the power product, A[m = pixel nl of strip G][k = kk]: monomials 1 x y xx | xy yy 0 0 of the pixel's
+    // position relative to the TILE centre -- with the coefficients of power_coeffs() the two MFMAs below are the fma
+    // chain power_poly() runs in the forward kernel, bit for bit
     float phi1[4], phi2[4];
 #pragma unroll
     for (int Gs = 0; Gs < 4; ++Gs) {
         const int q = 16 * Gs + nl;
-        const float x = (float)(q & 7) - 3.5f, y = (float)(q >> 3) - 3.5f;
+        const float x = (float)(q & 7) + ox, y = (float)(q >> 3) + oy;
         phi1[Gs] = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
         phi2[Gs] = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
     }
@@ -1012,8 +1139,14 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
     const int ce = tid / NC, cc = tid - ce * NC;    // this thread's (entry within the pass, component)
     if (ce < EPI)
         for (int ql = n + ce; ql < len; ql += EPI)  // entries nobody replays: zero record
-            A.pair_buf[(size_t)slots[ql] * NCP + cc] = 0.f;
-    if (n <= 0) return;
+            pair_buf[(size_t)slots[ql] * NCP + cc] = 0.f;
+    if (n <= 0) {
+        if (A.dbg_T_front) {
+            const int px = bx + (lane & 7), py = by + (lane >> 3);
+            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_pix[w][lane * PW + PS + 2];
+        }
+        return;
+    }
 
     // ---- per-lane addressing: pixel (G, kk, i) is q = 16 G + 4 kk + i
     float *pixrow = s_pix[w] + 4 * kk * PW;        // own pixel of step (G, i): pixrow + (16 G + i) * PW
@@ -1042,10 +1175,10 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
 
-        tile_cull<CH, SB, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+        tile_cull<CH, SB, false, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
                                  [&](int e, int ww) { return top - e < s_wmax[ww]; });
         __syncthreads();
-        const int cnt = build_list<CH, SB>(L, w, lane);  // every survivor gets a slab record: keep flags = written flags
+        const int cnt = build_list(L, w, lane);  // every survivor gets a slab record: keep flags = written flags
         float *slab = s_acc[w];
         for (int j0 = 0; j0 < cnt; j0 += 16) {
             const int e = L.list[w][j0 + nl];  // ascending e = back to front; slot SB (inert) past the end
@@ -1056,11 +1189,9 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
             // B operands: this lane's K-slice of the splat's power coefficients (x log2 e) and features
             float bq1, bq2, bf[NK];
             {
-                const float q0 = L2E * (-0.5f * (cA * uc * uc + cC * vc * vc) - cB * uc * vc);
-                const float qx = L2E * (cA * uc + cB * vc), qy = L2E * (cB * uc + cC * vc);
-                const float qxx = -0.5f * L2E * cA, qxy = -L2E * cB, qyy = -0.5f * L2E * cC;
-                bq1 = kk == 0 ? q0 : kk == 1 ? qx : kk == 2 ? qy : qxx;
-                bq2 = kk == 0 ? qxy : kk == 1 ? qyy : 0.f;
+                const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, tcx, tcy);
+                bq1 = kk == 0 ? pc.q0 : kk == 1 ? pc.qx : kk == 2 ? pc.qy : pc.qxx;
+                bq2 = kk == 0 ? pc.qxy : kk == 1 ? pc.qyy : 0.f;
                 const float *fr = reinterpret_cast<const float *>(&L.rec[e * Rec<CH>::RQ + 2]);
 #pragma unroll
                 for (int j = 0; j < NK; ++j) bf[j] = fr[4 * j + kk];  // padded with zeros past CH (pack_kernel)
@@ -1171,10 +1302,14 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
                     const float x = s_acc[ww][e * NC + cc];
                     v += ((fl >> (8 * ww)) & 0xffu) ? x : 0.f;
                 }
-                A.pair_buf[(size_t)slots[lo + ql] * NCP + cc] = v;
+                pair_buf[(size_t)slots[lo + ql] * NCP + cc] = v;
             }
         }
         __syncthreads();
+    }
+    if (A.dbg_T_front) {  // per-pixel transmittance after the last (front-most) replayed splat: lane q <-> pixel q of the block
+        const int px = bx + (lane & 7), py = by + (lane >> 3);
+        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_pix[w][lane * PW + PS + 2];
     }
 }
 
@@ -1183,17 +1318,21 @@ blend_bwd_mfma_kernel(const BlendArgs A) {
 // per (wave, splat, component).  Gradient outputs must be zero-initialised.
 template <int CH, bool ABS, bool BIAS, bool EXACT>
 __global__ void __launch_bounds__(256)
-blend_bwd_atomic_kernel(const BlendArgs A) {
+blend_bwd_atomic_kernel(const BlendArgs B) {
     using GL = GradLayout<ABS, BIAS>;
     constexpr int SB = 64, NG = GL::NG, NC = NG + CH;
-    __shared__ TileLDS<CH, SB> L;
+    __shared__ TileLDS<CH, SB, !BIAS> L;
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int gtile = xcd_tile(blockIdx.x, gridDim.x);
+    const int frame = gtile / B.T, tile = gtile - frame * B.T;
+    const BlendArgs A = frame_args(B, frame);
     const int tx = tile % A.gx, ty = tile / A.gx;
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
     const int px = bx + (lane & 7), py = by + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
+    const float x = (float)((w & 1) * 8 + (lane & 7)) - 7.5f, y = (float)((w >> 1) * 8 + (lane >> 3)) - 7.5f;
+    const float xx = x * x, xy = x * y, yy = y * y;
     const size_t HW = (size_t)A.H * A.W;
     const int cn = EXACT ? CH : A.cn;
 
@@ -1214,10 +1353,14 @@ blend_bwd_atomic_kernel(const BlendArgs A) {
     const int wmax = wave_max_i(last);
     if (lane == 0) s_wmax[w] = wmax;
     if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
+    if (!BIAS && tid < 2) L.coef[2 * SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     const int2 range = A.tile_range[tile];
     const int n = imin_(range.y - range.x, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
-    if (n <= 0) return;
+    if (n <= 0) {
+        if (A.dbg_T_front && inside) A.dbg_T_front[pix] = T;
+        return;
+    }
     auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };
     Stager<CH, SB> st;
     st.load_ids(A, tid, range.x, pos, 0);
@@ -1230,23 +1373,32 @@ blend_bwd_atomic_kernel(const BlendArgs A) {
         st.load_payload(A, tid);
         st.load_ids(A, tid, range.x, pos, batch + 2);
         __syncthreads();
-        tile_cull<CH, SB, BIAS, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+        tile_cull<CH, SB, BIAS, false, !BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
                                 [&](int e, int ww) { return top - e < s_wmax[ww]; });
         __syncthreads();
-        const int cnt = build_list<CH, SB>(L, w, lane);
+        const int cnt = build_list(L, w, lane);
         for (int j = 0; j < cnt; ++j) {
             const int e = L.list[w][j];
             const float4 g0 = L.g0(e), g1 = L.g1(e);
             const float dx = g0.x - pxf, dy = g0.y - pyf;
-            const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
-            const float G = __expf(power);
-            float araw = g1.y * G;
-            if (BIAS) araw = araw + g1.z;
+            bool pw_ok;
+            float G, araw;
+            if (BIAS) {  // the forward's expressions (blend_fwd_kernel), bit for bit
+                const float q = neg_power_factored(dx, dy, g0.z, g0.w, g1.x);
+                G = exp_neg(q);
+                araw = __builtin_fmaf(g1.y, G, g1.z);
+                pw_ok = !(q < 0.f);
+            } else {
+                const float pw = power_poly(L.coef[2 * e], L.coef[2 * e + 1], x, y, xx, xy, yy);
+                G = __builtin_amdgcn_exp2f(pw);
+                araw = g1.y * G;
+                pw_ok = !(pw > BLEND_PW_MAX);
+            }
             const float alpha = fminf(0.99f, araw);
-            const bool ok = !done && (top - e < last) && !(power > 0.f) && !(alpha < (1.0f / 255.0f));
+            const bool ok = !done && (top - e < last) && pw_ok && !(alpha < (1.0f / 255.0f));
             if (!__any(ok)) continue;
             float f[CH];
-            read_feat<CH, SB>(L, e, f);
+            read_feat(L, e, f);
             float r[NC];
 #pragma unroll
             for (int k = 0; k < NC; ++k) r[k] = 0.f;
@@ -1273,13 +1425,14 @@ blend_bwd_atomic_kernel(const BlendArgs A) {
         }
         __syncthreads();
     }
+    if (A.dbg_T_front && inside) A.dbg_T_front[pix] = T;
 }
 
 // ================================================================== launch tables
 template <int CH>
 static int launch_pack(const BlendArgs &A, bool bias, hipStream_t s) {
     if (A.P == 0) return SPLAT_OK;
-    const dim3 grid((unsigned)((A.P + 255) / 256)), block(256);
+    const dim3 grid((unsigned)((A.P + 255) / 256), (unsigned)A.F), block(256);
     const bool exact = A.cn == CH;
     if (bias) { if (exact) SPLAT_LAUNCH("blend_pack", (pack_kernel<CH, true, true>), grid, block, 0, s, A); else SPLAT_LAUNCH("blend_pack", (pack_kernel<CH, true, false>), grid, block, 0, s, A); }
     else { if (exact) SPLAT_LAUNCH("blend_pack", (pack_kernel<CH, false, true>), grid, block, 0, s, A); else SPLAT_LAUNCH("blend_pack", (pack_kernel<CH, false, false>), grid, block, 0, s, A); }
@@ -1289,7 +1442,7 @@ static int launch_pack(const BlendArgs &A, bool bias, hipStream_t s) {
 
 template <int CH>
 static int launch_fwd(const BlendArgs &A, int T, bool enh, bool bias, hipStream_t s) {
-    const dim3 grid((unsigned)T), block(256);
+    const dim3 grid((unsigned)(T * A.F)), block(256);
     const bool exact = A.cn == CH;
     {
         const int rc = launch_pack<CH>(A, bias, s);
@@ -1319,7 +1472,7 @@ static bool bwd_use_mfma() {
 
 template <int CH, bool ABS, bool BIAS>
 static int launch_bwd_ab(const BlendArgs &A, int T, bool pair, hipStream_t s) {
-    const dim3 grid((unsigned)T), block(256);
+    const dim3 grid((unsigned)(T * A.F)), block(256);
     const bool exact = A.cn == CH;
     if (pair && !BIAS && bwd_use_mfma()) {
         if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_mfma_kernel<CH, ABS, true>), grid, block, 0, s, A);
@@ -1332,7 +1485,7 @@ static int launch_bwd_ab(const BlendArgs &A, int T, bool pair, hipStream_t s) {
         else SPLAT_LAUNCH("blend_bwd", (blend_bwd_atomic_kernel<CH, ABS, BIAS, false>), grid, block, 0, s, A);
     }
     SPLAT_POST_LAUNCH();
-    if (pair) {
+    if (pair && A.F == 1) {  // frame batches reduce their records in the Gaussian-side backward (frames.hip)
         const dim3 rgrid((unsigned)(((size_t)A.P * 4 + 255) / 256));
         SPLAT_LAUNCH("pair_reduce", (pair_reduce_kernel<ABS, BIAS, PairCfg<CH, ABS, BIAS>::NCP>), rgrid, dim3(256), 0, s, A);
         SPLAT_POST_LAUNCH();
@@ -1407,6 +1560,7 @@ extern "C" int splat_alpha_blending_forward(int P, int C, const float *uv, const
     A.out = out; A.final_T = final_T; A.ncontrib = ncontrib; A.gs_idx = gs_idx;
     A.pack = pack_scratch;
     const int T = A.gx * ((H + TILE - 1) / TILE);
+    A.F = 1; A.T = T;
     for (int c0 = 0; c0 < C; c0 += 32) {  // reference chunking: src/alpha_blending.cu:287-394
         A.c0 = c0;
         A.cn = C - c0 > 32 ? 32 : C - c0;
@@ -1424,11 +1578,11 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
                                              float *dL_dopacity, float *dL_dfeature, float *dL_dopacity_bias,
                                              float *dL_dndc, float *dL_dabs_ndc, const int32_t *goff_incl,
                                              const int32_t *slot_sorted, float *pair_scratch, float *pack_scratch,
-                                             int pack_is_valid, splat_stream_t stream) {
+                                             int pack_is_valid, float *dbg_T_front, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && C >= 1 && W > 0 && H > 0, "bad sizes");
     if (P == 0) return SPLAT_OK;
-    SPLAT_CHECK_ARG(uv && conic && opacity && feature && idx_sorted && tile_range && final_T && ncontrib && dL_dout &&
-                        pack_scratch,
+    // idx_sorted may be NULL when no Gaussian touches any tile (M = 0: every tile range is empty, nothing dereferences it)
+    SPLAT_CHECK_ARG(uv && conic && opacity && feature && tile_range && final_T && ncontrib && dL_dout && pack_scratch,
                     "null pointer");
     SPLAT_CHECK_ARG(dL_duv && dL_dconic && dL_dopacity && dL_dfeature, "null gradient pointer");
     SPLAT_CHECK_ARG(!opacity_bias || dL_dopacity_bias, "bias given without dL_dopacity_bias");
@@ -1450,8 +1604,10 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
     A.dL_dndc = dL_dndc; A.dL_dabs_ndc = dL_dabs_ndc;
     A.goff_incl = goff_incl; A.slot_sorted = slot_sorted; A.pair_buf = pair_scratch;
     A.pack = pack_scratch;
+    A.dbg_T_front = dbg_T_front;
     A.pack_valid = (pack_is_valid && C <= 32) ? 1 : 0;  // one chunk only: later chunks overwrite the scratch
     const int T = A.gx * ((H + TILE - 1) / TILE);
+    A.F = 1; A.T = T;
     for (int c0 = 0; c0 < C; c0 += 32) {  // reference chunking: src/alpha_blending.cu:440-577
         A.c0 = c0;
         A.cn = C - c0 > 32 ? 32 : C - c0;

@@ -1,0 +1,85 @@
+// Adam step over the flat parameter buffer of the frame-sharded data-parallel renderer ("one all-reduce of
+// the flat bucket per optimiser step, then identical Adam on every rank").  The reference steps torch.optim.Adam
+// parameter group by parameter group (src/pointrix/optimizer/optimizer.py, atlas_gs_optimizer.py: Adam with eps = 1e-15,
+// per-group learning rates); this is the same update rule (no weight decay, no amsgrad) as ONE streaming launch over the
+// contiguous buffer the collective just reduced, with the per-group learning rates looked up by segment:
+//     m <- b1 m + (1 - b1) g        v <- b2 v + (1 - b2) g^2
+//     p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// HBM-bound: 4 reads + 3 writes of 4 bytes per element, float4 lanes.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+constexpr int ADAM_MAX_SEG = SPLAT_ADAM_MAX_SEGMENTS;
+struct AdamSegs {
+    int n;
+    long long end[ADAM_MAX_SEG];  // exclusive end of segment k (elements); segment k uses step size ss[k]
+    float ss[ADAM_MAX_SEG];       // lr_k / (1 - b1^t)
+};
+
+__device__ __forceinline__ float seg_step(const AdamSegs &S, long long i) {
+    float s = S.ss[0];
+#pragma unroll
+    for (int k = 1; k < ADAM_MAX_SEG; ++k)
+        if (k < S.n && i >= S.end[k - 1]) s = S.ss[k];
+    return s;
+}
+
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float ss, float b1, float b2, float rbc2,
+                                      float eps) {
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p -= ss * m / (sqrtf(v) * rbc2 + eps);
+}
+
+__global__ void __launch_bounds__(256)
+adam_kernel(long long n, float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+            AdamSegs S, float b1, float b2, float rbc2, float eps, float gscale) {
+    const long long n4 = n >> 2;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        float4 P = reinterpret_cast<float4 *>(p)[q], M = reinterpret_cast<float4 *>(m)[q], V = reinterpret_cast<float4 *>(v)[q];
+        const float4 G = reinterpret_cast<const float4 *>(g)[q];
+        const long long i = q << 2;
+        adam1(P.x, G.x * gscale, M.x, V.x, seg_step(S, i), b1, b2, rbc2, eps);
+        adam1(P.y, G.y * gscale, M.y, V.y, seg_step(S, i + 1), b1, b2, rbc2, eps);
+        adam1(P.z, G.z * gscale, M.z, V.z, seg_step(S, i + 2), b1, b2, rbc2, eps);
+        adam1(P.w, G.w * gscale, M.w, V.w, seg_step(S, i + 3), b1, b2, rbc2, eps);
+        reinterpret_cast<float4 *>(p)[q] = P;
+        reinterpret_cast<float4 *>(m)[q] = M;
+        reinterpret_cast<float4 *>(v)[q] = V;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {  // tail
+        const long long i = (n4 << 2) + threadIdx.x;
+        adam1(p[i], g[i] * gscale, m[i], v[i], seg_step(S, i), b1, b2, rbc2, eps);
+    }
+}
+}  // namespace
+
+extern "C" int splat_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int nseg,
+                               const int64_t *seg_end_host, const float *seg_lr_host, float beta1, float beta2, float eps,
+                               int step, float grad_scale, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(n >= 0 && step >= 1, "bad sizes");
+    SPLAT_CHECK_ARG(nseg >= 1 && nseg <= ADAM_MAX_SEG && seg_end_host && seg_lr_host, "1..SPLAT_ADAM_MAX_SEGMENTS segments");
+    SPLAT_CHECK_ARG(seg_end_host[nseg - 1] == n, "the last segment must end at n");
+    if (n == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(param && grad && exp_avg && exp_avg_sq, "null pointer");
+    SPLAT_CHECK_ARG(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
+                    "buffers must be 16-byte aligned");
+    AdamSegs S;
+    S.n = nseg;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    for (int k = 0; k < ADAM_MAX_SEG; ++k) {
+        S.end[k] = k < nseg ? seg_end_host[k] : n;
+        S.ss[k] = k < nseg ? (float)((double)seg_lr_host[k] / bc1) : 0.f;
+        SPLAT_CHECK_ARG(k == 0 || k >= nseg || seg_end_host[k] >= seg_end_host[k - 1], "segments must be ascending");
+    }
+    const long long n4 = n >> 2;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    SPLAT_LAUNCH("adam_step", adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, param,
+                 grad, exp_avg, exp_avg_sq, S, beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}

@@ -8,6 +8,8 @@ alpha_blending_enhanced.py:7-160, alpha_blending_with_bias.py, __init__.py:28-10
 from __future__ import annotations
 
 import ctypes
+import warnings
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -35,6 +37,57 @@ def _half_wh(W: int, H: int, device) -> Tensor:
     return t
 
 
+# ------------------------------------------------------------------ pair map: the sort's companion for the atomic-free backward
+class PairMap:
+    """What ``sort_gaussian`` knows beyond the reference's two outputs: ``goff`` (inclusive prefix of tiles per Gaussian)
+    and ``slot_sorted`` (Gaussian-major pair slot of every sorted entry).  ``alpha_blending*``'s backward uses it to run
+    without global atomics.  The map is bound to the exact ``idx_sorted`` / ``tile_range`` tensors it was made with
+    (storage address, size and autograd version counter): ``match`` raises when either was modified in place since."""
+
+    def __init__(self, goff: Tensor, slot_sorted: Tensor, idx_sorted: Tensor, tile_range: Tensor):
+        self.goff, self.slot_sorted = goff, slot_sorted
+        self.P, self.M = int(goff.numel()), int(idx_sorted.numel())
+        self._idx = (idx_sorted.data_ptr(), idx_sorted._version)
+        self._tr = (tile_range.data_ptr(), tile_range.numel(), tile_range._version)
+
+    def match(self, idx_sorted: Tensor, tile_range: Tensor, P: int) -> None:
+        if idx_sorted.data_ptr() != self._idx[0] or idx_sorted.numel() != self.M:
+            raise L.SplatError("pair map belongs to a different idx_sorted tensor")
+        if idx_sorted._version != self._idx[1]:
+            raise L.SplatError("idx_sorted was modified in place after sort_gaussian: its pair map is stale")
+        if (tile_range.data_ptr(), tile_range.numel()) != self._tr[:2]:
+            raise L.SplatError("alpha blending got idx_sorted and tile_range of two different sort_gaussian calls")
+        if tile_range._version != self._tr[2]:
+            raise L.SplatError("tile_range was modified in place after sort_gaussian: the pair map is stale")
+        if P != self.P:
+            raise L.SplatError(f"the sort covered {self.P} Gaussians, the blend is called with {P}")
+
+
+_PAIRMAPS = {}     # idx_sorted storage address -> PairMap (entry dropped when the tensor dies)
+_warned_foreign = False
+
+
+def _register_pairmap(idx_sorted: Tensor, pm: PairMap) -> None:
+    key = idx_sorted.data_ptr()
+    _PAIRMAPS[key] = pm
+    weakref.finalize(idx_sorted, lambda k=key, m=pm: _PAIRMAPS.pop(k, None) if _PAIRMAPS.get(k) is m else None)
+
+
+def _find_pairmap(idx_sorted: Tensor, tile_range: Tensor, P: int, given: Optional[PairMap] = None) -> Optional[PairMap]:
+    """the pair map of this ``idx_sorted`` (validated), or None for an index list this package did not produce (a
+    foreign or copied tensor: the backward then takes the wave-reduced atomic kernel; warned about once)"""
+    global _warned_foreign
+    pm = given if given is not None else _PAIRMAPS.get(idx_sorted.data_ptr())
+    if pm is None:
+        if idx_sorted.numel() > 0 and not _warned_foreign:
+            _warned_foreign = True
+            warnings.warn("alpha_blending: idx_sorted does not come from this package's sort_gaussian (or is a copy of its "
+                          "result): the backward falls back to the atomic kernel", RuntimeWarning, stacklevel=3)
+        return None
+    pm.match(idx_sorted, tile_range, P)
+    return pm
+
+
 # ------------------------------------------------------------------ sort_gaussian
 _OVERFLOW_SINK = {}
 
@@ -51,8 +104,8 @@ class SortStatus:
     """Device-side outcome of a capacity-bounded sort: ``pairs`` (int32[1], the true number of tile-Gaussian
     pairs M) and ``capacity``; ``overflow`` (bool[1], M exceeded the capacity and pairs were dropped) derives from them."""
 
-    def __init__(self, pairs: Tensor, capacity: int):
-        self.pairs, self.capacity = pairs, int(capacity)
+    def __init__(self, pairs: Tensor, capacity: int, pairmap: Optional[PairMap] = None):
+        self.pairs, self.capacity, self.pairmap = pairs, int(capacity), pairmap
 
     @property
     def overflow(self) -> Tensor:
@@ -89,6 +142,7 @@ def _sort(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Opti
     M = int(m_dev.item()) if capacity is None else int(capacity)   # the only host sync (none with a capacity)
     idx_sorted = torch.empty(M, dtype=torch.int32, device=dev)
     overflow = _overflow_sink(dev)   # the kernels only ever store 1 here; pairs > capacity carries the same fact
+    pm = None
     if M > 0:
         keys = torch.empty(M, dtype=torch.int64, device=dev)
         owner = torch.empty(M, dtype=torch.int32, device=dev)
@@ -97,9 +151,11 @@ def _sort(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Opti
         L.check(lib.splat_bin_sort(L.ci(P), L.ptr(uv), L.ptr(depth), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
                                    L.ptr(tile_range), ctypes.c_int64(M), L.ptr(keys), L.ptr(idx_sorted),
                                    L.ptr(overflow), L.ptr(goff), L.ptr(owner), L.ptr(slot_sorted), L.stream()))
-        # hidden companion of idx_sorted: lets alpha_blending's backward run without global atomics
-        idx_sorted._splat_pairmap = (goff, slot_sorted)
-    return idx_sorted, tile_range, SortStatus(m_dev, M)
+        # companion of idx_sorted (the reference's signature has no room for it): lets alpha_blending's backward run
+        # without global atomics; found again through the tensor's storage address and validated there
+        pm = PairMap(goff, slot_sorted, idx_sorted, tile_range)
+        _register_pairmap(idx_sorted, pm)
+    return idx_sorted, tile_range, SortStatus(m_dev, M, pm)
 
 
 def sort_gaussian(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Tensor) -> Tuple[Tensor, Tensor]:
@@ -116,10 +172,44 @@ def sort_gaussian_capped(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tens
                          capacity: int) -> Tuple[Tensor, Tensor, SortStatus]:
     """``sort_gaussian`` without the host synchronisation: ``idx_sorted`` is allocated with ``capacity`` entries (only
     the first M are meaningful, tile_range never points past them) and the caller checks ``status`` whenever it next
-    synchronises anyway (e.g. once per gradient step).  On overflow the surplus pairs are dropped and flagged."""
+    synchronises anyway (e.g. once per gradient step).  On overflow the surplus pairs are dropped and flagged
+    (``status.check()`` raises); every range, slot and prefix the sort leaves behind is clamped to the capacity, so
+    blending such a result is memory-safe (and meaningless)."""
     if capacity < 0:
         raise ValueError("capacity must be >= 0")
     return _sort(uv, depth, W, H, radius, None, capacity)
+
+
+# ------------------------------------------------------------------ debug: does the backward replay the forward's decisions?
+_T_FRONT_CAPTURE = None
+
+
+class capture_T_front:
+    """``with capture_T_front() as cap: loss.backward()`` -- every blend backward inside stores, per pixel, the
+    transmittance its back-to-front replay (``T /= 1 - alpha``, src/alpha_blending.cu:196-214) arrives at in front of
+    the first splat into ``cap.maps`` ([H,W] tensors).  It equals 1 up to rounding iff the backward made exactly the
+    forward's inclusion decisions for that pixel; one flipped decision moves it by a factor >= 1/(1 - 1/255)."""
+
+    def __init__(self):
+        self.maps = []
+
+    def __enter__(self):
+        global _T_FRONT_CAPTURE
+        _T_FRONT_CAPTURE = self
+        return self
+
+    def __exit__(self, *exc):
+        global _T_FRONT_CAPTURE
+        _T_FRONT_CAPTURE = None
+        return False
+
+
+def _debug_T_front(H: int, W: int, device) -> Optional[Tensor]:
+    if _T_FRONT_CAPTURE is None:
+        return None
+    t = torch.full((H, W), float("nan"), dtype=torch.float32, device=device)
+    _T_FRONT_CAPTURE.maps.append(t)
+    return t
 
 
 # ------------------------------------------------------------------ alpha blending (3 variants, one Function)
@@ -130,7 +220,6 @@ class _AlphaBlend(torch.autograd.Function):
         conic = L.need(conic, "conic")
         opacity = L.need(opacity, "opacity")
         feature = L.need(feature, "feature")
-        pairmap = getattr(idx_sorted, "_splat_pairmap", None)
         idx_sorted = L.need(idx_sorted, "idx_sorted", torch.int32)
         tile_range = L.need(tile_range, "tile_range", torch.int32)
         bias_c = None if bias is None else L.need(bias, "opacity_bias")
@@ -154,9 +243,7 @@ class _AlphaBlend(torch.autograd.Function):
             L.ptr(idx_sorted), L.ptr(tile_range), L.cf(bg), L.ptr(None), L.ci(W), L.ci(H), L.ci(K),
             L.ci(1 if trunc else 0), L.ptr(out), L.ptr(final_T), L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.stream()))
         ctx.meta = (float(bg), int(W), int(H), bias is not None, ndc is not None, abs_ndc is not None)
-        if pairmap is not None and (pairmap[0].numel() != P or pairmap[1].numel() != idx_sorted.numel()):
-            pairmap = None
-        ctx.pairmap = pairmap
+        ctx.pairmap = _find_pairmap(idx_sorted, tile_range, P)
         ctx.pack = pack          # packed records: reused by the backward when C <= 32 (one channel chunk)
         saved = [uv, conic, opacity, feature, idx_sorted, tile_range, final_T, ncontrib]
         if bias_c is not None:
@@ -178,10 +265,15 @@ class _AlphaBlend(torch.autograd.Function):
         dev = feature.device
         pm = ctx.pairmap
         M = idx_sorted.numel()
-        if pm is not None and M > 0:
+        if M == 0:   # no Gaussian touches any tile: zero gradients (the reference's atomics add nothing)
+            z = torch.zeros
+            return (z(P, 2, device=dev), z(P, 3, device=dev), z(opacity.shape, device=dev), z(P, C, device=dev),
+                    z(bias.shape, device=dev) if has_bias else None, None, None, None, None, None,
+                    z(P, 2, device=dev) if has_ndc else None, z(P, 2, device=dev) if has_abs else None, None, None)
+        if pm is not None:
             # pair mode: every gradient element is written by the reduce kernel -> no zero fill
             alloc = torch.empty
-            goff, slot_sorted = pm
+            goff, slot_sorted = pm.goff, pm.slot_sorted
             scratch = torch.empty(M * L.lib().splat_blend_pair_floats(C, 1 if has_bias else 0), dtype=torch.float32,
                                   device=dev)
         else:
@@ -203,7 +295,7 @@ class _AlphaBlend(torch.autograd.Function):
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias), L.ptr(idx_sorted),
             L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(g), L.ptr(duv),
             L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(dbias), L.ptr(dndc), L.ptr(dabs_ndc), L.ptr(goff),
-            L.ptr(slot_sorted), L.ptr(scratch), L.ptr(pack), L.ci(1), L.stream()))
+            L.ptr(slot_sorted), L.ptr(scratch), L.ptr(pack), L.ci(1), L.ptr(_debug_T_front(H, W, dev)), L.stream()))
         if (has_ndc or has_abs) and not in_kernel:
             half = _half_wh(W, H, dev)
             if has_ndc:
@@ -252,7 +344,6 @@ class _BlendShared(torch.autograd.Function):
         uv = L.need(uv, "uv")
         conic = L.need(conic, "conic")
         opacity = L.need(opacity, "opacity")
-        pairmap = getattr(idx_sorted, "_splat_pairmap", None)
         idx_sorted = L.need(idx_sorted, "idx_sorted", torch.int32)
         tile_range = L.need(tile_range, "tile_range", torch.int32)
         feats = [L.need(f, f"features[{i}]") for i, f in enumerate(features)]
@@ -273,9 +364,7 @@ class _BlendShared(torch.autograd.Function):
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(allf), L.ptr(None), L.ptr(idx_sorted),
             L.ptr(tile_range), L.cf(0.0), L.ptr(bgc), L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(final_T),
             L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.stream()))
-        if pairmap is not None and (pairmap[0].numel() != P or pairmap[1].numel() != idx_sorted.numel()):
-            pairmap = None
-        ctx.pairmap = pairmap
+        ctx.pairmap = _find_pairmap(idx_sorted, tile_range, P)
         ctx.meta = (int(W), int(H), tuple(float(b) for b in bgs), tuple(bool(d) for d in detach_opacity),
                     tuple(bool(t) for t in taps), ndc is not None, abs_ndc is not None, widths)
         ctx.save_for_backward(uv, conic, opacity, idx_sorted, tile_range, final_T, ncontrib, *feats)
@@ -302,9 +391,12 @@ class _BlendShared(torch.autograd.Function):
             C = f.shape[1]
             g = L.need(g, "dL_dout")
             want_abs = has_abs and taps[s]
-            if pm is not None and M > 0:
+            if M == 0:
+                dfeats[s] = torch.zeros(P, C, dtype=torch.float32, device=dev)
+                continue
+            if pm is not None:
                 alloc = torch.empty
-                goff, slot_sorted = pm
+                goff, slot_sorted = pm.goff, pm.slot_sorted
                 scratch = torch.empty(M * lib.splat_blend_pair_floats(C, 0), dtype=torch.float32, device=dev)
             else:
                 alloc = torch.zeros
@@ -319,7 +411,7 @@ class _BlendShared(torch.autograd.Function):
                 L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(f), L.ptr(None), L.ptr(idx_sorted),
                 L.ptr(tile_range), L.cf(bgs[s]), L.ci(W), L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(g), L.ptr(duv),
                 L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(goff),
-                L.ptr(slot_sorted), L.ptr(scratch), L.ptr(pack), L.ci(0), L.stream()))
+                L.ptr(slot_sorted), L.ptr(scratch), L.ptr(pack), L.ci(0), L.ptr(_debug_T_front(H, W, dev)), L.stream()))
             dfeats[s] = dfeat
             duv_t = duv if duv_t is None else duv_t + duv
             dconic_t = dconic if dconic_t is None else dconic_t + dconic
@@ -333,6 +425,12 @@ class _BlendShared(torch.autograd.Function):
                 if want_abs:
                     t = dabs * half[None, :]
                     dabs_t = t if dabs_t is None else dabs_t + t
+        if M == 0:
+            z = torch.zeros
+            duv_t, dconic_t = z(P, 2, device=dev), z(P, 3, device=dev)
+            dop_t = z(opacity.shape, device=dev)
+            dndc = z(P, 2, device=dev) if has_ndc else None
+            dabs_t = z(P, 2, device=dev) if has_abs else None
         return (duv_t, dconic_t, dop_t, None, None, None, None, None, dndc, dabs_t, None, None, None) + tuple(dfeats)
 
 

@@ -1,0 +1,57 @@
+"""Adam on the flat parameter buffer of the frame-sharded data-parallel renderer.
+
+After the gradient all-reduce every rank holds the same flat gradient; ``FlatAdam.step`` applies the update rule of
+``torch.optim.Adam`` (what the reference's optimizer wrapper steps, src/pointrix/optimizer/optimizer.py:70-83, built with
+eps = 1e-15 and one learning rate per parameter group) to the whole ``FlatGradBucket`` in ONE native launch
+(``splat_adam_step``), with the groups' learning rates looked up by segment.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Union
+
+import torch
+
+from . import _lib as L
+from .parallel import FlatGradBucket
+
+MAX_SEGMENTS = 16
+
+
+class FlatAdam:
+    def __init__(self, bucket: FlatGradBucket, lr: Union[float, Dict[str, float]], betas=(0.9, 0.999), eps: float = 1e-15):
+        if not bucket.flat_param.is_cuda:
+            raise ValueError("FlatAdam steps GPU buffers (there is no CPU path)")
+        self.bucket = bucket
+        names = list(bucket.slices)
+        lrs = [float(lr[n]) if isinstance(lr, dict) else float(lr) for n in names]
+        # merge neighbouring groups with equal learning rates (the kernel looks a segment up per element)
+        ends, seg_lr = [], []
+        for n, r in zip(names, lrs):
+            e = bucket.slices[n][1]
+            if seg_lr and seg_lr[-1] == r:
+                ends[-1] = e
+            else:
+                ends.append(e); seg_lr.append(r)
+        if len(ends) > MAX_SEGMENTS:
+            raise ValueError(f"at most {MAX_SEGMENTS} learning-rate segments")
+        self.nseg = len(ends)
+        self.seg_end = (ctypes.c_int64 * self.nseg)(*ends)
+        self.seg_lr = (ctypes.c_float * self.nseg)(*seg_lr)
+        self.beta1, self.beta2, self.eps = float(betas[0]), float(betas[1]), float(eps)
+        self.exp_avg = torch.zeros_like(bucket.flat_param)
+        self.exp_avg_sq = torch.zeros_like(bucket.flat_param)
+        self.t = 0
+
+    def step(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0) -> None:
+        """one Adam step with the bucket's active gradient buffer (or ``grad``), scaled by ``grad_scale`` first"""
+        g = self.bucket.flat_grad if grad is None else grad
+        p = self.bucket.flat_param
+        if g.numel() != p.numel() or not g.is_cuda or g.dtype != torch.float32:
+            raise ValueError("grad must be a float32 GPU tensor with one entry per parameter")
+        self.t += 1
+        with torch.no_grad():
+            L.check(L.lib().splat_adam_step(
+                ctypes.c_int64(p.numel()), L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                L.ci(self.nseg), self.seg_end, self.seg_lr, L.cf(self.beta1), L.cf(self.beta2), L.cf(self.eps),
+                L.ci(self.t), L.cf(grad_scale), L.stream()))

@@ -119,9 +119,30 @@ def reduce_visibility(visibility: torch.Tensor, radii: torch.Tensor) -> Tuple[to
     return visibility, radii
 
 
-def sharded_step(bucket: FlatGradBucket, frames: Iterable[int], render_and_backward) -> None:
-    """zero -> local frames forward+backward (grads accumulate in the bucket) -> one all-reduce."""
+def reduce_densify_batch(viewspace_grad: torch.Tensor, visibility: torch.Tensor, radii: torch.Tensor) -> None:
+    """The batch statistics densification consumes, reduced over the ranks IN PLACE so that every rank takes the same
+    clone / split / prune decisions: the reference's single process sums the gradient taps of all frames of a batch, ORs
+    their visibility and maxes their radii (dptr_ortho_enhanced.py:425-431, frag_model.py:326-343); with the batch's
+    frames spread over the ranks that is SUM / MAX / MAX across the process group.  Call it once per step, after the
+    local frames' backward passes and before ``DensifyState.update()``.  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    dist.all_reduce(viewspace_grad, op=dist.ReduceOp.SUM)
+    v = visibility.to(torch.int32)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    visibility.copy_(v.to(visibility.dtype))
+    dist.all_reduce(radii, op=dist.ReduceOp.MAX)
+
+
+def sharded_step(bucket: FlatGradBucket, frames: Iterable[int], render_and_backward, optimizer=None,
+                 average: bool = False) -> None:
+    """One SYNCHRONOUS data-parallel gradient step: zero -> local frames forward+backward (gradients accumulate in the
+    bucket) -> one all-reduce -> the optimiser step every rank applies identically -> (caller) next step's forward.
+    ``optimizer`` is anything with ``step(grad_scale=...)`` over the bucket (``optim.FlatAdam`` on the GPU)."""
     bucket.zero_grad()
     for f in frames:
         render_and_backward(f)
     bucket.all_reduce()
+    if optimizer is not None:
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        optimizer.step(grad_scale=(1.0 / world) if average else 1.0)

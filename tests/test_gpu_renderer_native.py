@@ -53,7 +53,9 @@ def test_render_iter_equals_operator_chain():
     a, b = results
     assert torch.equal(a["radius"], b["radius"]) and torch.equal(a["gidx"], b["gidx"])
     for k in ("img", "dimg", "aimg"):
-        assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-6), k
+        # the fused preprocess rounds the conic differently (FMA contraction, <= 2e-5 relative); the exponent's polynomial
+        # then rounds its (large, cancelling) terms differently too: ~1e-5 absolute noise in the exponent
+        assert torch.allclose(a[k], b[k], rtol=1e-4, atol=1e-5), k
     assert torch.allclose(a["tap"], b["tap"], rtol=1e-4, atol=1e-6 * float(a["tap"].abs().max()))
     for k in a["grads"]:
         x, y = b["grads"][k], a["grads"][k]

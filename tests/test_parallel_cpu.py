@@ -5,12 +5,14 @@ collective logic does not depend on the kernels (those are covered by the -m gpu
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from splatter_a_video_amd.parallel import FlatGradBucket, frames_of_rank, reduce_visibility, sharded_step
+from splatter_a_video_amd.parallel import (FlatGradBucket, frames_of_rank, reduce_densify_batch, reduce_visibility,
+                                            sharded_step)
 
 
 def _free_port():
@@ -135,3 +137,104 @@ def test_single_buffer_swap_is_a_noop():
     assert b2.active == 1 and b2.params["shs"].grad.data_ptr() != p0 and b2.grad("shs").data_ptr() == b2.params["shs"].grad.data_ptr()
     _toy_render(b2.params, 1).backward()
     assert b2.flat_grads[1].abs().sum() > 0 and b2.flat_grads[0].abs().sum() == 0
+
+
+# ------------------------------------------------------------------ synchronous step: all-reduce -> optimiser -> next forward
+class _TorchFlatAdam:
+    """torch restatement of optim.FlatAdam's rule (the product's Adam is a HIP kernel, tests/test_gpu_optim.py checks it
+    against torch.optim.Adam); here only the ORDER of a synchronous data-parallel step is under test"""
+
+    def __init__(self, bucket, lr):
+        self.b, self.lr, self.t = bucket, lr, 0
+        self.m = torch.zeros_like(bucket.flat_param); self.v = torch.zeros_like(bucket.flat_param)
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        g = self.b.flat_grad * grad_scale
+        self.m.mul_(0.9).add_(g, alpha=0.1)
+        self.v.mul_(0.999).addcmul_(g, g, value=0.001)
+        with torch.no_grad():
+            self.b.flat_param -= (self.lr / (1 - 0.9 ** self.t)) * self.m / (self.v.sqrt() / (1 - 0.999 ** self.t) ** 0.5 + 1e-15)
+
+
+def _worker_sync(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = FlatGradBucket(_params())
+        opt = _TorchFlatAdam(b, 1e-2)
+        for step in range(3):      # every step's forward sees the parameters the previous step's optimiser produced
+            frames = frames_of_rank(list(range(6 * step, 6 * step + 6)), rank, world)
+            sharded_step(b, frames, lambda f: _toy_render(b.params, f).backward(), optimizer=opt)
+        torch.save({"param": b.flat_param.detach().clone()}, out + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_synchronous_steps_match_single_process(tmp_path):
+    out = str(tmp_path / "p")
+    mp.spawn(_worker_sync, args=(2, _free_port(), out), nprocs=2, join=True)
+    p0, p1 = torch.load(out + ".0")["param"], torch.load(out + ".1")["param"]
+    assert torch.equal(p0, p1)                       # replicas stay bit-identical
+    ref = FlatGradBucket(_params())
+    opt = _TorchFlatAdam(ref, 1e-2)
+    for step in range(3):
+        sharded_step(ref, list(range(6 * step, 6 * step + 6)), lambda f: _toy_render(ref.params, f).backward(), optimizer=opt)
+    torch.testing.assert_close(p0, ref.flat_param.detach(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ densification decisions are rank-deterministic
+def _densify_inputs(N=400, F=6, seed=3):
+    rng = np.random.default_rng(seed)
+    radius = (rng.integers(0, 30, size=(F, N)) * (rng.random((F, N)) < 0.6)).astype(np.int32)
+    taps = (rng.normal(size=(F, N, 2)) * 2e-4 * (radius > 0)[..., None]).astype(np.float32)
+    scaling_raw = np.log(rng.uniform(0.002, 0.05, size=(N, 3))).astype(np.float32)
+    opacity_raw = rng.normal(0, 2, size=(N, 1)).astype(np.float32)
+    return radius, taps, scaling_raw, opacity_raw
+
+
+def _masks_after(frames, radius, taps, scaling_raw, opacity_raw, reduce):
+    import oracle
+    N = radius.shape[1]
+    vg = np.zeros((N, 2), np.float32); vis = np.zeros(N, np.uint8); radii = np.zeros(N, np.int32)
+    for f in frames:
+        oracle.densify_accumulate(radius[f], taps[f], 1.0, 1.0, vg, vis, radii)
+    if reduce:
+        tv, tvis, tr = torch.from_numpy(vg), torch.from_numpy(vis), torch.from_numpy(radii)
+        reduce_densify_batch(tv, tvis, tr)         # in place, shares memory with the numpy arrays
+    max_r = np.zeros(N, np.float32); accum = np.zeros(N, np.float32); denom = np.zeros(N, np.float32)
+    oracle.densify_update(vis, vg, radii, max_r, accum, denom)
+    return oracle.densify_masks(accum, denom, max_r, scaling_raw, opacity_raw, 2e-4, 0.03, 1.0, 0.05, 20.0)
+
+
+def _worker_densify(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        radius, taps, sr, orr = _densify_inputs()
+        frames = frames_of_rank(list(range(radius.shape[0])), rank, world)
+        masks = _masks_after(frames, radius, taps, sr, orr, reduce=True)
+        np.savez(out + f".{rank}.npz", clone=masks[0], split=masks[1], prune=masks[2])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_ranks_take_identical_densification_decisions(tmp_path):
+    """every rank sees only its frames' gradient taps / radii; after reduce_densify_batch the clone / split / prune masks
+    are identical on both ranks and equal to a single process that rendered the whole batch"""
+    out = str(tmp_path / "m")
+    mp.spawn(_worker_densify, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    radius, taps, sr, orr = _densify_inputs()
+    ref = _masks_after(range(radius.shape[0]), radius, taps, sr, orr, reduce=False)
+    unreduced = _masks_after(frames_of_rank(list(range(radius.shape[0])), 0, 2), radius, taps, sr, orr, reduce=False)
+    for k, r in zip(("clone", "split", "prune"), ref):
+        np.testing.assert_array_equal(a[k], b[k])
+        # float sums over 3 + 3 frames vs 6 frames in a row may differ in the last bit: a threshold comparison can flip
+        assert (a[k] != r).sum() <= 1
+    assert ref[0].sum() > 5 and ref[1].sum() > 0
+    assert any((u != r).sum() > 5 for u, r in zip(unreduced, ref))     # without the reduction the ranks would diverge
