@@ -1,25 +1,33 @@
 #!/usr/bin/env python
 """bench.py -- rendered frames/s, forward+backward, 300k dynamic Gaussians @ 854x480 (BASELINE.json
-configs[1]) through the dptr.gs operator surface on MI355X.
+configs[1]) through the MI355X-native rasterizer behind the dptr.gs operator surface.
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
 
-A "step" is one gradient step of the frame-sharded data-parallel renderer: every rank renders
-`--frames` frames of the clip forward+backward (SH colour -> ortho projection -> cov3d -> EWA ->
-tile sort -> alpha blending, and the whole backward chain), accumulates the Gaussian gradients
-in one flat bucket, then ONE all-reduce of that bucket (skipped at N=1).  Weak scaling: frames per
-rank fixed, so N ranks render N*frames frames per step (N=8, frames=25 -> the 200-frame
+A "step" is one SYNCHRONOUS gradient step of the frame-sharded data-parallel renderer: every rank renders
+`--frames` frames of the clip forward+backward (SH colour -> ortho projection -> cov3d -> EWA -> tile sort
+-> alpha blending, and the whole backward chain), the Gaussian gradients accumulate in one flat bucket,
+ONE all-reduce of that bucket (RCCL; skipped at N=1), then one Adam step on the flat parameter buffer
+(every rank applies the same update) -- only then does the next step's forward start.  Weak scaling:
+frames per rank fixed, so N ranks render N*frames frames per step (N=8, frames=25 -> the 200-frame
 configs[2]).  value = frames rendered by all ranks / wall time (max over ranks).
 
+Paths (same images and gradients, tests/test_gpu_frames.py, test_gpu_fused.py):
+  default      frame batch: every kernel takes the frame as a grid dimension (splatter_a_video_amd.frames),
+               the Gaussian-side backward and the SH kernels run once per step
+  --per-frame  the fused per-frame operators of round 1 (13 launches per frame)
+  --ops        the reference's operator sequence through autograd (dptr_ortho_enhanced.py:282-349)
+
 Inputs are synthetic (SURVEY.md 8d generator) and resident in HBM before the timed region.
-The CPU oracle is only used for the `cpu_baseline` leg (rank 0, N=1, one bounded sample).
+The oracle (oracle/) is only used for the `cpu_baseline` leg (rank 0, N=1, bounded samples).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,37 +40,48 @@ sys.path.insert(0, ROOT)
 
 import dptr.gs as gs  # noqa: E402
 import splatter_a_video_amd._lib as L  # noqa: E402
+from splatter_a_video_amd.frames import FrameBatch  # noqa: E402
+from splatter_a_video_amd.optim import FlatAdam  # noqa: E402
 from splatter_a_video_amd.parallel import FlatGradBucket  # noqa: E402
 from splatter_a_video_amd.synth import make_scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
-# HBM/fabric bytes per launch from PMC counters, measured offline with tools/pmc_run.sh (separate --pmc
-# passes, read requests sized by TCC_EA0_RDREQ_{32B,64B,128B}, WRITE_SIZE in KiB) at configs[1];
-# only reported when the bench runs that configuration.
-PMC_TAG = "r01i"
+# HBM/fabric bytes per launch from PMC counters and the compositing kernels' issue counters, measured offline on the
+# same command line (tools/round_profile.sh: separate rocprofv3 --pmc passes; read requests sized by
+# TCC_EA0_RDREQ_{32B,64B,128B}, WRITE_SIZE in KiB); stamped with the profile they come from and only reported when the
+# bench runs the configuration they were taken at.
+PMC_TAG = os.environ.get("SPLAT_PMC_TAG", "r02")
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_traffic.json")
-# instruction-issue counters of the two compositing kernels (tools/pmc_blend_counters.py): what actually bounds them
 PMC_COUNTER_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_blend_counters.json")
 PMC_KERNEL_NAMES = {"blend_bwd": "blend_bwd_mfma_kernel", "blend_fwd": "blend_fwd_kernel", "tile_sort": "tile_sort_kernel",
-                    "pair_reduce": "pair_reduce_kernel", "sh_fwd": "sh_fwd_kernel", "sh_bwd": "sh_bwd_kernel"}
+                    "gauss_bwd": "frames_gauss_bwd_static_kernel", "pair_reduce": "pair_reduce_kernel",
+                    "sh_fwd": "sh_fwd_kernel", "sh_bwd": "sh_bwd_kernel", "bin_scatter": "bin_scatter_kernel"}
 
 
-def pmc_traffic(kernel, is_default_config):
-    if not is_default_config or not os.path.exists(PMC_TRAFFIC_FILE):
-        return None
+def pmc_traffic(kernel, tag_cfg):
+    """(bytes per launch, source note) of a kernel from the offline PMC record, if it was taken at this configuration"""
+    if not os.path.exists(PMC_TRAFFIC_FILE):
+        return None, None
     try:
-        k = json.load(open(PMC_TRAFFIC_FILE))["kernels"].get(PMC_KERNEL_NAMES.get(kernel, ""), None)
-        return None if k is None else k["read_bytes"] + k["write_bytes"]
+        rec = json.load(open(PMC_TRAFFIC_FILE))
+        if rec.get("config") != tag_cfg:
+            return None, None
+        k = rec["kernels"].get(PMC_KERNEL_NAMES.get(kernel, ""), None)
+        if k is None:
+            return None, None
+        return k["read_bytes"] + k["write_bytes"], f"profiles/{PMC_TAG}_pmc_traffic.json ({rec.get('source', 'rocprofv3 --pmc, offline')})"
     except Exception:
-        return None
+        return None, None
 
 
-def pmc_issue(kernel, is_default_config):
-    """VALU / MFMA issue utilisation and wave-slot residency of a compositing kernel (offline PMC passes), or None"""
-    if not is_default_config or not os.path.exists(PMC_COUNTER_FILE):
+def pmc_issue(kernel, tag_cfg):
+    if not os.path.exists(PMC_COUNTER_FILE):
         return None
     try:
-        k = json.load(open(PMC_COUNTER_FILE))["kernels"].get(kernel, None)
+        rec = json.load(open(PMC_COUNTER_FILE))
+        if rec.get("config") not in (None, tag_cfg):
+            return None
+        k = rec["kernels"].get(kernel, None)
         return None if k is None else dict(k["derived"], source=f"profiles/{PMC_TAG}_pmc_blend_counters.json (rocprofv3 --pmc, offline)")
     except Exception:
         return None
@@ -71,20 +90,23 @@ def pmc_issue(kernel, is_default_config):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=25, help="frames per rank per gradient step")
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--width", type=int, default=854)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--clip", type=int, default=50, help="frames in the clip (per 8 ranks: 200)")
     ap.add_argument("--channels", type=int, default=0, help="extra feature channels (configs[4]: 32 -> no SH)")
-    ap.add_argument("--ops", action="store_true", help="per-operator chain through autograd instead of the fused frame operators")
+    ap.add_argument("--per-frame", action="store_true", help="fused per-frame operators (round-1 path) instead of the frame batch")
+    ap.add_argument("--ops", action="store_true", help="per-operator chain through autograd")
     ap.add_argument("--dynamic", action="store_true",
                     help="parameterise the scene as the reference's dynamic Gaussians and run their per-frame evaluation "
-                         "inside the fused preprocess (row a15 on the path; implies the fused operators)")
-    ap.add_argument("--sync-allreduce", action="store_true",
-                    help="single gradient buffer, all-reduce between two steps (default with >1 rank: double-buffered, overlapped)")
+                         "inside the fused preprocess (row a15 on the path; per-frame operators)")
+    ap.add_argument("--stale-overlap", action="store_true",
+                    help="stale-1 mode: double-buffered gradient bucket, the all-reduce of step s overlaps step s+1's frames "
+                         "and no optimiser runs (NOT synchronous data parallelism; for comparison only)")
+    ap.add_argument("--no-optimizer", action="store_true", help="skip the Adam step (forward+backward+all-reduce only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -92,15 +114,16 @@ def parse():
 
 class FrameRenderer:
     """Frame-sharded DP unit: parameters replicated, gradients of all local frames accumulate into
-    one flat bucket (views), one all-reduce per step."""
+    one flat bucket (views), one all-reduce + one Adam step per gradient step."""
 
-    def __init__(self, sc, device, C_extra=0, fused=True, dynamic=False, overlap_allreduce=True):
+    def __init__(self, sc, device, frames, C_extra=0, mode="batch", dynamic=False, stale_overlap=False, optimizer=True):
         self.sc = sc
-        self.fused = fused or dynamic
+        self.mode = "frame" if dynamic else mode
         self.dynamic = dynamic
         self.capacity = None      # pair capacity of the sync-free sort (learned on the first frame)
         self.sort_status = []
         self.dev = device
+        self.F = len(frames)
         N = sc.N
         self.W, self.H = sc.W, sc.H
         self.use_sh = C_extra == 0
@@ -124,13 +147,16 @@ class FrameRenderer:
             src["shs"] = sc.shs
         else:
             src["feature"] = sc.feature
-        # two gradient buffers when ranks have to talk: the all-reduce of step s runs on RCCL's stream while step s+1
-        # accumulates into the other buffer
-        self.overlap = bool(overlap_allreduce) and dist.is_available() and dist.is_initialized()
+        # stale-1 mode only: two gradient buffers, the all-reduce of step s runs on RCCL's stream while step s+1 fills the other
+        self.overlap = bool(stale_overlap) and dist.is_available() and dist.is_initialized()
         self.bucket = FlatGradBucket({k: torch.as_tensor(v, device=device) for k, v in src.items()},
                                      buffers=2 if self.overlap else 1)
         self.p = self.bucket.params
         self.flat_grad = self.bucket.flat_grad
+        # Adam on the flat buffer (the reference's optimiser, eps 1e-15).  The learning rate is kept small so that the
+        # synthetic scene's statistics (pairs per frame, list lengths) stay put over the run's steps: the cost of the
+        # update does not depend on it.
+        self.opt = FlatAdam(self.bucket, 1e-6, eps=1e-15) if (optimizer and not self.overlap) else None
         self.extr = torch.tensor(sc.extr, device=device)
         self.phase = torch.tensor(sc.phase, device=device)
         self.dirs = torch.zeros(N, 3, device=device)
@@ -138,6 +164,17 @@ class FrameRenderer:
         self.C = 3 if self.use_sh else C_extra
         g = torch.Generator(device="cpu").manual_seed(4321)
         self.dL_dout = torch.randn(self.C, self.H, self.W, generator=g).to(device)
+        self.frames = list(frames)
+        if dynamic:
+            self.offs = self.frames
+        else:
+            self.offs = [self.offsets(f) for f in self.frames]
+        if self.mode == "batch":
+            if self.C > 32:
+                raise SystemExit("the frame batch composites at most 32 channels per call")
+            self.batch = FrameBatch(self.F, N, self.W, self.H, self.C, device)
+            self.off_all = torch.stack(self.offs).contiguous()
+            self.dL_all = self.dL_dout.unsqueeze(0).repeat(self.F, 1, 1, 1).contiguous()
         self.last = {}
 
     def offsets(self, f):
@@ -147,13 +184,28 @@ class FrameRenderer:
         off[:, 1] = d
         return off
 
+    # ------------------------------------------------------------------ all local frames of a step, one launch sequence
+    def frames_batched(self):
+        p = self.p
+        g = {k: self.bucket.grad(k) for k in p}
+        feat = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"]) if self.use_sh else p["feature"]
+        sink = {"xyz": g["xyz"], "scales": g["scale"], "uquats": g["rotate"], "opacity": g["opacity"]}
+        if not self.use_sh:
+            sink["feature"] = g["feature"]
+        out = self.batch.render(p["xyz"], p["scale"], p["rotate"], p["opacity"], feat, self.off_all, self.extr,
+                                bg=self.sc.bg, nearest=0.01, grad_sink=sink)
+        out.backward(self.dL_all)
+        self.last = dict(M=self.last.get("M", 0), T=self.batch.T)
+
+    # ------------------------------------------------------------------ one frame (round-1 paths)
     def frame(self, off):
-        """one frame, forward + backward.  ``fused`` path: fused per-frame operators whose backward adds the parameter
-        gradients straight into the flat bucket, sort without a host sync; ``ops`` path: the reference's operator
+        """one frame, forward + backward.  ``frame`` mode: fused per-frame operators whose backward adds the parameter
+        gradients straight into the flat bucket, sort without a host sync; ``ops`` mode: the reference's operator
         sequence (dptr_ortho_enhanced.py:282-349) through autograd.  Same images, same gradients."""
         p = self.p
         W, H = self.W, self.H
         opacity = p["opacity"]
+        fused = self.mode == "frame"
         if self.dynamic:
             from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, frame_preprocess
             g = {k: self.bucket.grad(k) for k in self.p}
@@ -163,24 +215,12 @@ class FrameRenderer:
                 rotation=p["rotation"], rot_poly_feat=self.rot_poly, rot_fourier_feat=self.rot_fourier,
                 opacity=p["opacity"], scaling=p["scaling"], nearest=0.01, cubic_layout=SEGMENT_MAJOR,
                 grad_sink={k: g[k] for k in ("pos_cubic_node", "rotation", "opacity", "scaling")})
-            if self.capacity is None:
-                idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
-                self.capacity = int(idx.numel() * 1.25) + 1024
-            else:
-                idx, tr, st = gs.sort_gaussian_capped(uv, depth, W, H, radius, self.capacity)
-                self.sort_status.append(st)
-        elif self.fused:
+        elif fused:
             g = {k: self.bucket.grad(k) for k in self.p}
             feat = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"]) if self.use_sh else p["feature"]
             uv, depth, conic, radius, tiles = gs.preprocess_ortho(
                 p["xyz"], p["scale"], p["rotate"], self.extr, W, H, nearest=0.01, offset=off,
                 grad_sink={"xyz": g["xyz"], "scales": g["scale"], "uquats": g["rotate"]})
-            if self.capacity is None:   # first frame: learn the pair count with the synchronising sort
-                idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
-                self.capacity = int(idx.numel() * 1.25) + 1024
-            else:
-                idx, tr, st = gs.sort_gaussian_capped(uv, depth, W, H, radius, self.capacity)
-                self.sort_status.append(st)
         else:
             pos = p["xyz"] + off
             feat = gs.compute_sh(p["shs"], 3, self.dirs) if self.use_sh else p["feature"]
@@ -188,23 +228,35 @@ class FrameRenderer:
             visible = depth != 0
             cov3d = gs.compute_cov3d(p["scale"], p["rotate"], visible)
             conic, radius, tiles = gs.ewa_project_ortho(pos, cov3d, self.extr, uv, W, H, visible)
+        if not fused and not self.dynamic:
             idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        elif self.capacity is None:   # first frame: learn the pair count with the synchronising sort
+            idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+            self.capacity = int(idx.numel() * 1.25) + 1024
+        else:
+            idx, tr, st = gs.sort_gaussian_capped(uv, depth, W, H, radius, self.capacity)
+            self.sort_status.append(st)
         # densification tap, as the reference renderers create it (dptr.py:151-162)
         ndc = torch.zeros_like(uv, requires_grad=True)
         img = gs.alpha_blending(uv, conic, opacity, feat, idx, tr, self.sc.bg, W, H, ndc)
         img.backward(self.dL_dout)
-        self.last = dict(M=idx.numel() if not self.fused else self.last.get("M", idx.numel()), T=tr.shape[0])
+        self.last = dict(M=idx.numel() if self.mode == "ops" else self.last.get("M", idx.numel()), T=tr.shape[0])
         return img
 
-    def step(self, offs, collective=True):
-        """one gradient step: local frames forward+backward, then ONE all-reduce of the flat bucket
-        (skipped when no process group exists, and in rank 0's private kernel-timing pass)"""
-        self.bucket.swap()        # double-buffered: waits for the collective that last used the buffer we switch to
+    def step(self, collective=True):
+        """one gradient step: local frames forward+backward, ONE all-reduce of the flat bucket (skipped when no process
+        group exists, and in rank 0's private kernel-timing pass), one Adam step; returns when everything is enqueued"""
+        self.bucket.swap()        # stale-1 mode: waits for the collective that last used the buffer we switch to
         self.bucket.zero_grad()
-        for off in offs:
-            self.frame(off)
+        if self.mode == "batch":
+            self.frames_batched()
+        else:
+            for off in self.offs:
+                self.frame(off)
         if collective and dist.is_available() and dist.is_initialized():
-            self.bucket.all_reduce(async_op=self.overlap)
+            self.bucket.all_reduce(async_op=self.overlap)     # synchronous unless --stale-overlap
+        if self.opt is not None:
+            self.opt.step()
 
     def finish(self):
         """all outstanding gradient collectives have completed (end of the timed region / of training)"""
@@ -213,6 +265,8 @@ class FrameRenderer:
     def check_sorts(self):
         """after the timed region: every capacity-bounded sort of the run fitted (host sync)"""
         m = 0
+        if self.mode == "batch":
+            m = self.batch.check()
         for st in self.sort_status:
             m = max(m, st.check())
         self.sort_status.clear()
@@ -220,9 +274,11 @@ class FrameRenderer:
             self.last["M"] = m
 
 
-def kernel_bytes(name, N, M, HW, C, T, use_sh):
-    """Algorithmic HBM bytes of one launch (SURVEY.md 8d bookkeeping, per kernel)."""
+def kernel_bytes(name, N, M, HW, C, T, use_sh, F):
+    """Algorithmic HBM bytes of one FRAME's share of a launch (SURVEY.md 8d bookkeeping, per kernel); kernels that run
+    once per step (SH, Adam, batched Gaussian-side backward) are priced for the whole launch (F given where it matters)."""
     F_in = 192 if use_sh else 0
+    nparam = N * (3 + 3 + 4 + 1 + (48 if use_sh else C))
     table = {
         "sh_fwd": N * (F_in + 12 + 1 + 12 + 3),
         "sh_bwd": N * (F_in + 12 + 1 + 3 + 12 + F_in + 12),   # (+F_in read when it accumulates into the bucket)
@@ -250,12 +306,46 @@ def kernel_bytes(name, N, M, HW, C, T, use_sh):
         "blend_bwd": M * (28 + 4 * C) + M * (32 + 4 * C) + HW * (4 * C + 8),
         # reads the records through the inverse pair map, writes the per-Gaussian gradients
         "pair_reduce": M * (4 + 32 + 4 * C) + N * (4 + 32 + 4 * C),
+        # frame batch: per frame the records + prefix + radius; once per launch the parameters and their gradients
+        "gauss_bwd": M * (32 + 4 * C) + N * 8 + (N * (40 + 2 * (44 + 4 * C)) // max(F, 1)),
+        "adam_step": 7 * 4 * nparam // max(F, 1),
     }
     return table.get(name, 0)
 
 
-def cpu_baseline(sc, C_extra):
-    """One frame forward+backward of the same workload with the C oracle on the host cores."""
+def cpu_baseline_torch(sc, C_extra, budget_s=45.0):
+    """the PyTorch-eager restatement of the reference's semantics (oracle/torch_eager.py), float32,
+    all host cores, one frame forward+backward per run: configs[0] (10k Gaussians, 256x256) median of 5 runs after one
+    warm-up, and the bench's own workload with as many runs (at most 1 warm-up + 5) as fit `budget_s` of CPU time."""
+    from oracle import torch_eager as te
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    C = C_extra if C_extra else 3
+
+    def runs(scene, n, budget):
+        g = np.random.default_rng(4321).normal(size=(C, scene.H, scene.W)).astype(np.float32)
+        ts, M = [], None
+        for _ in range(n + 1):
+            t0 = time.perf_counter()
+            M = te.frame_forward_backward(scene, 0, g, use_sh=not C_extra)
+            ts.append(time.perf_counter() - t0)
+            if sum(ts) > budget:
+                break
+        timed = ts[1:] if len(ts) > 1 else ts
+        return statistics.median(timed), len(timed), len(ts) > 1, M
+
+    c1 = make_scene(10000, 256, 256, F=sc.F, C=C_extra, seed=1234)
+    m1, n1, _, M1 = runs(c1, 5, 30.0)
+    m2, n2, warm, M2 = runs(sc, 5, budget_s)
+    return {"value": 1.0 / m2, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 frame fwd+bwd of the same workload ({sc.N} Gaussians, {sc.W}x{sc.H}, M={M2}), PyTorch-eager float32 "
+                      f"restatement (oracle/torch_eager.py), median of {n2} run(s){' after 1 warm-up' if warm else ''}: "
+                      f"{m2:.2f} s; configs[0] (10k Gaussians, 256x256, M={M1}): median of {n1} runs after 1 warm-up "
+                      f"{m1 * 1e3:.0f} ms = {1.0 / m1:.2f} frames/s"}
+
+
+def cpu_baseline_c(sc, C_extra):
+    """Second, stronger baseline: one frame forward+backward with the C oracle, OpenMP over tiles on all host cores."""
     import oracle
     threads = os.cpu_count() or 1
     if not oracle.has_openmp():
@@ -273,8 +363,8 @@ def cpu_baseline(sc, C_extra):
                            ortho=True, shs=shs)
     dt = time.perf_counter() - t0
     return {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"1 frame fwd+bwd of the same workload ({sc.N} Gaussians, {sc.W}x{sc.H}, M={saved['idx_sorted'].size}), "
-                      f"C oracle with OpenMP over tiles, {dt:.2f} s wall"}
+            "sample": f"1 frame fwd+bwd of the same workload (M={saved['idx_sorted'].size}), C oracle with OpenMP over "
+                      f"tiles, {dt:.2f} s wall"}
 
 
 def main():
@@ -297,14 +387,11 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    mode = "ops" if a.ops else "frame" if (a.per_frame or a.dynamic) else "batch"
     clip = max(a.clip, 25 * world)
     sc = make_scene(a.gaussians, a.width, a.height, F=clip, C=a.channels, seed=1234)
-    R = FrameRenderer(sc, dev, a.channels, fused=not a.ops, dynamic=a.dynamic, overlap_allreduce=not a.sync_allreduce)
     # rank r renders frames {f : f mod world == r} of the step's frame batch
-    if a.dynamic:
-        offs = [((i * world + rank) % clip) for i in range(a.frames)]      # frame times of the dynamic model
-    else:
-        offs = [R.offsets(((i * world + rank) % clip)) for i in range(a.frames)]
+    frames = [((i * world + rank) % clip) for i in range(a.frames)]
 
     def sync():
         torch.cuda.synchronize()
@@ -312,11 +399,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # setup, not workload: one frame of a 512-Gaussian 64x64 scene through the same operators loads the library's code
+    # setup, not workload: one step of a 512-Gaussian 64x64 scene through the same operators loads the library's code
     # objects and initialises the allocator, so that `--warmup 0` does not time HIP module loading
     tiny = make_scene(512, 64, 64, F=clip, C=a.channels, seed=1)
-    Rt = FrameRenderer(tiny, dev, a.channels, fused=not a.ops, dynamic=a.dynamic, overlap_allreduce=False)
-    Rt.step([0 if a.dynamic else Rt.offsets(0)], collective=False)
+    Rt = FrameRenderer(tiny, dev, frames[:2], a.channels, mode=mode, dynamic=a.dynamic, optimizer=not a.no_optimizer)
+    Rt.step(collective=False)
     torch.cuda.synchronize()
     del Rt, tiny
     if launched:   # communicator / channel set-up is setup as well (first collective of the process group)
@@ -325,14 +412,16 @@ def main():
         torch.cuda.synchronize()
         del prime
 
+    R = FrameRenderer(sc, dev, frames, a.channels, mode=mode, dynamic=a.dynamic, stale_overlap=a.stale_overlap,
+                      optimizer=not a.no_optimizer)
     for _ in range(a.warmup):
-        R.step(offs)
+        R.step()
     R.finish()
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        R.step(offs)
-    R.finish()                # the last step's all-reduce is inside the timed region
+        R.step()
+    R.finish()                # stale-1 mode: the last step's all-reduce is inside the timed region
     sync()
     dt = time.perf_counter() - t0
     R.check_sorts()   # the sync-free sorts of the timed steps all fitted their capacity (raises otherwise)
@@ -345,47 +434,60 @@ def main():
     fps = frames_total / dt
     M, T = R.last["M"], R.last["T"]
     HW = a.width * a.height
+    tag_cfg = f"{a.gaussians}x{a.width}x{a.height}x{a.channels}:{mode}"
 
     roofline = None
     kernels = {}
-    fwd_ms = bwd_ms = None
+    fwd_ms = bwd_ms = opt_ms = None
     if rank == 0 and not a.no_kernel_timing:
         # same step again with per-kernel HIP events recorded on the launch stream
+        torch.cuda.synchronize()
         L.profile_reset()
         L.profile_enable(True)
-        R.step(offs, collective=False)  # rank-0 only: must not enter a collective
+        R.step(collective=False)  # rank-0 only: must not enter a collective
         torch.cuda.synchronize()
         L.profile_enable(False)
         names = ["sh_fwd", "frame_preprocess_fwd", "frame_preprocess_bwd", "preprocess_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
-                 "bin_scatter", "tile_sort", "blend_pack", "blend_fwd", "blend_bwd", "pair_reduce", "preprocess_bwd", "ewa_bwd", "project_point_bwd",
-                 "cov3d_bwd", "sh_bwd"]
+                 "bin_scatter", "tile_sort", "blend_pack", "blend_fwd", "blend_bwd", "pair_reduce", "gauss_bwd", "preprocess_bwd", "ewa_bwd", "project_point_bwd",
+                 "cov3d_bwd", "sh_bwd", "adam_step"]
+        per_step = {"adam_step", "gauss_bwd"} | ({"sh_fwd", "sh_bwd"} if mode == "batch" else set())
         for n in names:
             ms, cnt = L.profile_read(n)
             if cnt:
                 avg = ms / cnt
-                b = kernel_bytes(n, a.gaussians, M, HW, R.C, T, R.use_sh)
-                kernels[n] = {"avg_us": round(avg * 1e3, 2), "launches": cnt, "alg_MB": round(b / 1e6, 2),
+                fpl = a.frames / cnt       # frames one launch covers (1 on the per-frame paths, F in the batch)
+                b = kernel_bytes(n, a.gaussians, M, HW, R.C, T, R.use_sh, a.frames if n in per_step else 1) * fpl
+                kernels[n] = {"avg_us": round(avg * 1e3, 2), "launches": cnt, "frames_per_launch": round(fpl, 2),
+                              "us_per_frame": round(ms * 1e3 / a.frames, 2), "alg_MB": round(b / 1e6, 2),
                               "GBps": round(b / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
         if kernels:
-            dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
+            dom = max(kernels, key=lambda k: kernels[k]["us_per_frame"])
             ach = kernels[dom]["GBps"]
-            default_cfg = (a.gaussians, a.width, a.height, a.channels) == (300000, 854, 480, 0)
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, default_cfg),
-                        "traffic_source": f"profiles/{PMC_TAG}_pmc_traffic.json (rocprofv3 --pmc, offline)" if default_cfg else None,
-                        # the compositing kernels are bound by instruction issue, not by HBM: secondary ceiling
-                        "issue": pmc_issue(dom, default_cfg),
-                        "avg_us": kernels[dom]["avg_us"], "alg_bytes_per_launch": int(kernel_bytes(dom, a.gaussians, M, HW, R.C, T, R.use_sh))}
+            traffic, tsrc = pmc_traffic(dom, tag_cfg)
+            roofline = {"kernel": dom,
+                        # priced against HBM as the contract asks; what bounds the compositing kernels is instruction
+                        # issue / latency (see "issue"), not bandwidth
+                        "bound": "hbm", "limited_by": "issue" if dom.startswith("blend") else "hbm",
+                        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
+                        "issue": pmc_issue(dom, tag_cfg),
+                        "avg_us": kernels[dom]["avg_us"], "frames_per_launch": kernels[dom]["frames_per_launch"],
+                        "alg_bytes_per_launch": int(kernels[dom]["alg_MB"] * 1e6)}
             is_bwd = lambda k: k.endswith("_bwd") or k == "pair_reduce"
-            fwd_ms = sum(kernels[k]["avg_us"] for k in kernels if not is_bwd(k)) / 1e3
-            bwd_ms = sum(kernels[k]["avg_us"] for k in kernels if is_bwd(k)) / 1e3
+            fwd_ms = sum(kernels[k]["us_per_frame"] for k in kernels if not is_bwd(k) and k != "adam_step") / 1e3
+            bwd_ms = sum(kernels[k]["us_per_frame"] for k in kernels if is_bwd(k)) / 1e3
+            opt_ms = kernels.get("adam_step", {}).get("us_per_frame", 0.0) / 1e3
         L.profile_reset()
 
-    cpu = None
+    cpu = cpu_c = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(sc, a.channels)
+        cpu = cpu_baseline_torch(sc, a.channels)
+        cpu_c = cpu_baseline_c(sc, a.channels)
 
     if rank == 0:
+        par = f"frame-sharded dp{world}, " + ("stale-1: all-reduce overlapped with the next step, no optimiser" if R.overlap else
+                                              "synchronous: all-reduce -> Adam -> next forward" if R.opt is not None else
+                                              "synchronous all-reduce, no optimiser")
         line = {
             "metric": "rendered frames/sec fwd+bwd @480p, 300k Gaussians",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -393,16 +495,21 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.gaussians} dynamic Gaussians, {a.frames} frames/rank/step of a {clip}-frame "
                                    f"{a.width}x{a.height} clip, fwd+bwd, ortho camera, "
-                                   + ("SH deg 3 -> RGB" if R.use_sh else f"{a.channels} feature channels"),
+                                   + ("SH deg 3 -> RGB" if R.use_sh else f"{a.channels} feature channels")
+                                   + (", Adam step on the flat parameter buffer" if R.opt is not None else ""),
                        "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
-                       "tile_pairs_M": M, "channels": R.C, "parallelism": f"frame-sharded dp{world}" + (", all-reduce overlapped with the next step" if R.overlap and world > 1 else ""),
-                       "path": ("dynamic-Gaussian evaluation fused into the preprocess + gradient sinks" if R.dynamic else
-                                "fused frame operators + gradient sinks" if R.fused else "per-operator autograd chain"),
-                       "grad_bucket_MB": round(R.flat_grad.numel() * 4 / 1e6, 1)},
+                       "tile_pairs_M": M, "channels": R.C, "parallelism": par,
+                       "path": ("dynamic-Gaussian evaluation fused into the per-frame preprocess + gradient sinks" if R.dynamic else
+                                "frame batch: the frame is a grid dimension of every kernel; SH and the Gaussian-side backward once per step"
+                                if mode == "batch" else
+                                "fused per-frame operators + gradient sinks" if mode == "frame" else "per-operator autograd chain"),
+                       "grad_bucket_MB": round(R.flat_grad.numel() * 4 / 1e6, 1),
+                       "batch_buffers_MB": round(R.batch.memory_bytes() / 1e6, 1) if mode == "batch" else None},
             "ms_per_frame": round(dt / (a.frames * a.steps) * 1e3, 4),
             "gpu_kernel_ms_per_frame": {"forward": None if fwd_ms is None else round(fwd_ms, 4),
-                                        "backward": None if bwd_ms is None else round(bwd_ms, 4)},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+                                        "backward": None if bwd_ms is None else round(bwd_ms, 4),
+                                        "optimizer": None if opt_ms is None else round(opt_ms, 4)},
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c_oracle": cpu_c, "kernels": kernels,
         }
         print(json.dumps(line))
     if launched:

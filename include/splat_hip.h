@@ -266,6 +266,56 @@ int splat_knn_search(int N, const float *query, const int32_t *query_order, int 
                      const int32_t *cell_start, const void *plan, int K, float *dists, int32_t *idx,
                      splat_stream_t stream);
 
+/* ---- frame batch: F frames of ONE Gaussian set per launch (SURVEY 7 stage 6 / 8f: the reference renders the frames
+ *      of a batch one after the other, dptr_ortho_enhanced.py:385-433, ~13 launches each; here every kernel of the
+ *      per-frame path takes the frame as a grid dimension, so a batch costs the launches of one frame, the short
+ *      kernels fill the chip, and the compositing kernels see F * T tiles -- no half-empty last round).
+ *      Layout: per-Gaussian arrays [F,P,..]; tile_range [F,T,2] (positions relative to the frame's segment);
+ *      idx_sorted / slot_sorted / keys / owner [F,capacity]; images [F,C,H,W]; pair records [F,capacity,stride]. ---- */
+int splat_preprocess_ortho_forward_batch(int F, int P, const float *xyz, const float *offsets /*[F,P,3]*/,
+                                         const float *scales, const float *uquats, const float *extr, int W, int H,
+                                         float nearest, float extent, float *uv, float *depth, float *conic,
+                                         int32_t *radius, splat_stream_t stream);
+/* scratch: F * splat_bin_scratch_bytes(P, W, H) bytes; M_out[F] = pairs of each frame */
+int splat_bin_count_batch(int F, int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
+                          int32_t *tile_range, int32_t *M_out, splat_stream_t stream);
+int splat_bin_sort_batch(int F, int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
+                         void *scratch, int32_t *tile_range, int64_t capacity, uint64_t *keys, int32_t *idx_sorted,
+                         int32_t *overflow_out, int32_t *goff_incl /*[F,P] out*/, int32_t *owner, int32_t *slot_sorted,
+                         splat_stream_t stream);
+/* C <= 32.  opacity / feature: stride in elements between two frames' arrays, 0 = shared by all frames.
+ * pack_scratch: F * P * splat_blend_pack_floats(C) floats (kept for the backward). */
+int splat_alpha_blending_forward_batch(int F, int P, int C, const float *uv, const float *conic, const float *opacity,
+                                       int64_t opacity_frame_stride, const float *feature, int64_t feature_frame_stride,
+                                       const int32_t *idx_sorted, const int32_t *tile_range, int64_t capacity, float bg,
+                                       const float *bg_channels, int W, int H, int K, int enable_truncation, float *out,
+                                       float *final_T, int32_t *ncontrib, int32_t *gs_idx, float *pack_scratch,
+                                       splat_stream_t stream);
+/* exact stride (floats) of a pair record for this configuration: [ux uy ca cb cc o | ax ay (abs) | bias | features] padded
+ * to whole 16-byte chunks */
+size_t splat_blend_pair_stride(int C, int want_abs, int has_bias);
+/* tile kernels of the backward only: one gradient record per (frame, tile, splat) pair at frame * capacity + slot
+ * (pair_records: F * capacity * splat_blend_pair_stride(C, want_abs, 0) floats, uninitialised).  `pack` = the packed
+ * records the forward left in its pack_scratch. */
+int splat_alpha_blending_backward_batch(int F, int P, int C, const int32_t *idx_sorted, const int32_t *tile_range,
+                                        int64_t capacity, float bg, int W, int H, const float *final_T,
+                                        const int32_t *ncontrib, const float *dL_dout, int want_abs,
+                                        const int32_t *slot_sorted, float *pair_records, const float *pack,
+                                        float *dbg_T_front /*NULL or [F,H,W]*/, splat_stream_t stream);
+/* Gaussian-side backward of a batch of static Gaussians + per-frame offsets under the orthographic camera: sums every
+ * Gaussian's pair records over all frames and runs the preprocess backward (projection, EWA, cov3d: linear in the
+ * summed dL_duv / dL_dconic because conic and Jacobian do not depend on the frame) once.  Replaces, per batch, F x
+ * (pair reduce + splat_preprocess_ortho_backward).  accumulate: add into the parameter gradients (gradient sinks).
+ * tap / abs_tap (optional, [P,2]): sum over the frames of the densification taps dL_duv * (W/2, H/2) and its abs twin
+ * (what the reference accumulates from ndc.grad / abs_ndc.grad, frag_model.py:326-343); radii_max (optional, [P], needs
+ * radius [F,P]): max over the frames of the screen radius. */
+int splat_frames_gauss_backward_static(int F, int P, int C, int W, int H, int64_t capacity, int want_abs,
+                                       const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
+                                       const float *xyz, const float *scales, const float *uquats, const float *extr,
+                                       int accumulate, float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                       float *d_feature, float *tap, float *abs_tap, int32_t *radii_max,
+                                       splat_stream_t stream);
+
 /* ---- optimiser step of the frame-sharded data-parallel renderer: replaces the per-group
  *      torch.optim.Adam.step() the reference reaches through src/pointrix/optimizer/optimizer.py:70-83 (Adam built in
  *      atlas_gs_optimizer / configs with eps = 1e-15, one learning rate per parameter group), as one launch over the

@@ -35,6 +35,9 @@ SYMBOLS = [
     "splat_compact_scratch_bytes", "splat_compact_scan", "splat_compact_rows",
     "splat_knn_grid_cells", "splat_knn_plan_bytes", "splat_knn_build", "splat_knn_scatter", "splat_knn_search",
     "splat_adam_step",
+    "splat_preprocess_ortho_forward_batch", "splat_bin_count_batch", "splat_bin_sort_batch",
+    "splat_alpha_blending_forward_batch", "splat_blend_pair_stride", "splat_alpha_blending_backward_batch",
+    "splat_frames_gauss_backward_static",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]
 
@@ -62,6 +65,8 @@ def lib() -> ctypes.CDLL:
         L.splat_blend_pack_floats.argtypes = [ctypes.c_int]
         L.splat_blend_pair_floats.restype = ctypes.c_size_t
         L.splat_blend_pair_floats.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.splat_blend_pair_stride.restype = ctypes.c_size_t
+        L.splat_blend_pair_stride.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.splat_profile_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
         if L.splat_abi_version() != ABI_VERSION:
             raise SplatError("libsplat_hip.so ABI version mismatch; rebuild it")

@@ -73,10 +73,16 @@ static BinPlan make_plan(int P, int W, int H) {
 template <bool LDS>
 __global__ void __launch_bounds__(BIN_BLOCK)
 bin_count_kernel(int P, const float2 *__restrict__ uv, const int *__restrict__ radius, int gx, int gy, int T,
-                 int chunk, int *__restrict__ matrix, int *__restrict__ gcount, int *__restrict__ chunk_sum) {
+                 int chunk, int *__restrict__ matrix, int *__restrict__ gcount, int *__restrict__ chunk_sum,
+                 long long S) {
     extern __shared__ __attribute__((aligned(16))) int cnt[];
     __shared__ int wave_pairs[BIN_BLOCK / 64];
     const int wg = blockIdx.x;
+    {   // frame batch: blockIdx.y = frame; per-Gaussian arrays are [F,P,..], scratch blocks S ints apart
+        const size_t f = blockIdx.y;
+        uv += f * P; radius += f * P; matrix += f * S; chunk_sum += f * S;
+        if (gcount) gcount += f * P;
+    }
     int pairs = 0;  // this thread's share of the chunk's pair count
     if (LDS) {
         for (int t = threadIdx.x; t < T; t += BIN_BLOCK) cnt[t] = 0;
@@ -135,8 +141,9 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
 #define COLSCAN_GROUPS (1024 / COLSCAN_COLS)
 #define COLSCAN_ROWS (BIN_MAX_NB / COLSCAN_GROUPS)
 __global__ void __launch_bounds__(COLSCAN_COLS * COLSCAN_GROUPS)
-bin_colscan_kernel(int T, int NB, int *__restrict__ matrix, int *__restrict__ tile_count) {
+bin_colscan_kernel(int T, int NB, int *__restrict__ matrix, int *__restrict__ tile_count, long long S) {
     __shared__ int gsum[COLSCAN_GROUPS][COLSCAN_COLS + 1];
+    matrix += (size_t)blockIdx.y * S; tile_count += (size_t)blockIdx.y * S;
     const int c = threadIdx.x & (COLSCAN_COLS - 1), g = threadIdx.x / COLSCAN_COLS;
     const int t = blockIdx.x * COLSCAN_COLS + c;
     const int rpg = (NB + COLSCAN_GROUPS - 1) / COLSCAN_GROUPS;  // rows per group, <= COLSCAN_ROWS
@@ -169,9 +176,15 @@ bin_colscan_kernel(int T, int NB, int *__restrict__ matrix, int *__restrict__ ti
 // ------------------------------------------------------------------ K2b: scan over tiles (single workgroup)
 __global__ void __launch_bounds__(1024)
 bin_tilescan_kernel(int T, const int *__restrict__ tile_count, int *__restrict__ tile_range, int *__restrict__ M_out,
-                    int *__restrict__ total_scratch, int nchunk, int *__restrict__ chunk_sum) {
+                    int *__restrict__ total_scratch, int nchunk, int *__restrict__ chunk_sum, long long S) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
+    {
+        const size_t f = blockIdx.y;
+        tile_count += f * S; total_scratch += f * S; chunk_sum += f * S;
+        tile_range += f * 2 * T;
+        if (M_out) M_out += f;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -224,7 +237,7 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
                    const int *__restrict__ radius, int gx, int gy, int T, int chunk, int *__restrict__ matrix,
                    const int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
                    int *__restrict__ overflow, int *__restrict__ goff_incl, int *__restrict__ owner,
-                   const int *__restrict__ chunk_off) {
+                   const int *__restrict__ chunk_off, long long S) {
     // Pair-map mode (goff_incl != null): the kernel also produces goff_incl, the inclusive prefix of tiles per
     // Gaussian (chunk offset from K2b + a workgroup scan of the rectangle areas), and the low key word is the pair
     // slot j = goff_excl[i] + k (k-th tile of the splat's rectangle) instead of the Gaussian id: slots grow with
@@ -233,6 +246,12 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
     __shared__ int wave_pairs[BIN_BLOCK / 64];
     const int wg = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {   // frame batch: every frame owns `capacity` key / owner slots
+        const size_t f = blockIdx.y;
+        uv += f * P; depth += f * P; radius += f * P; matrix += f * S; chunk_off += f * S;
+        tile_range += f * 2 * T; keys += f * capacity;
+        if (goff_incl) { goff_incl += f * P; owner += f * capacity; }
+    }
     int running = goff_incl ? chunk_off[wg] : 0;
     if (LDS) {
         const int *row = matrix + (size_t)wg * T;
@@ -457,6 +476,11 @@ tile_sort_kernel(int *__restrict__ tile_range, long long capacity, unsigned long
                  int *__restrict__ idx_sorted, const int *__restrict__ owner, int *__restrict__ slot_sorted) {
     __shared__ __attribute__((aligned(16))) unsigned long long sk[SORT_LDS_KEYS];
     const int t = blockIdx.x;
+    {   // frame batch: blockIdx.y = frame (gridDim.x tiles per frame)
+        const size_t f = blockIdx.y;
+        tile_range += f * 2 * gridDim.x; keys += f * capacity; idx_sorted += f * capacity;
+        if (slot_sorted) { owner += f * capacity; slot_sorted += f * capacity; }
+    }
     long long r0 = tile_range[2 * t];
     long long r1 = tile_range[2 * t + 1];
     if (r1 > capacity) {  // overflow (already flagged by K3): the range the blend kernels will read never leaves the buffers
@@ -496,41 +520,79 @@ extern "C" size_t splat_bin_scratch_bytes(int P, int W, int H) {
     return make_plan(P, W, H).bytes;
 }
 
-extern "C" int splat_bin_count(int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
-                               int32_t *tile_range, int32_t *M_out, int32_t *gcount, splat_stream_t stream) {
-    SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0, "bad sizes");
-    SPLAT_CHECK_ARG(scratch && tile_range, "null pointer");
-    SPLAT_CHECK_ARG(P == 0 || (uv && radius), "null pointer");
-    hipStream_t s = (hipStream_t)stream;
+static int bin_count_impl(int F, int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
+                          int32_t *tile_range, int32_t *M_out, int32_t *gcount, hipStream_t s) {
     const BinPlan p = make_plan(P, W, H);
+    const long long S = (long long)(p.bytes / sizeof(int));
     char *base = (char *)scratch;
     int *matrix = (int *)(base + p.off_matrix);
     int *tile_count = (int *)(base + p.off_tilecount);
     int *total = (int *)(base + p.off_total);
     int *chunk_sum = (int *)(base + p.off_chunksum);
     if (p.lds) {
-        SPLAT_LAUNCH("bin_count", bin_count_kernel<true>, dim3(p.NB), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
-                     P, (const float2 *)uv, radius, p.gx, p.gy, p.T, p.chunk, matrix, gcount, chunk_sum);
+        SPLAT_LAUNCH("bin_count", bin_count_kernel<true>, dim3(p.NB, F), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
+                     P, (const float2 *)uv, radius, p.gx, p.gy, p.T, p.chunk, matrix, gcount, chunk_sum, S);
     } else {
         // rows: [0] counts, [1] fill counters of K3
-        SPLAT_CHECK_HIP(hipMemsetAsync(matrix, 0, (size_t)p.T * sizeof(int), s));
+        for (int f = 0; f < F; ++f)
+            SPLAT_CHECK_HIP(hipMemsetAsync(matrix + (size_t)f * S, 0, (size_t)p.T * sizeof(int), s));
         const int nblk = p.nchunk;
         const int chunk = (P + nblk - 1) / nblk;
-        SPLAT_LAUNCH("bin_count", bin_count_kernel<false>, dim3(nblk), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
-                     radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, gcount, chunk_sum);
+        SPLAT_LAUNCH("bin_count", bin_count_kernel<false>, dim3(nblk, F), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
+                     radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, gcount, chunk_sum, S);
     }
     SPLAT_POST_LAUNCH();
     if (p.lds) {
-        SPLAT_LAUNCH("bin_colscan", bin_colscan_kernel, dim3((p.T + COLSCAN_COLS - 1) / COLSCAN_COLS),
-                     dim3(COLSCAN_COLS * COLSCAN_GROUPS), 0, s, p.T, p.NB, matrix, tile_count);
+        SPLAT_LAUNCH("bin_colscan", bin_colscan_kernel, dim3((p.T + COLSCAN_COLS - 1) / COLSCAN_COLS, F),
+                     dim3(COLSCAN_COLS * COLSCAN_GROUPS), 0, s, p.T, p.NB, matrix, tile_count, S);
         SPLAT_POST_LAUNCH();
     } else {
-        SPLAT_CHECK_HIP(hipMemcpyAsync(tile_count, matrix, (size_t)p.T * sizeof(int), hipMemcpyDeviceToDevice, s));
+        for (int f = 0; f < F; ++f)
+            SPLAT_CHECK_HIP(hipMemcpyAsync(tile_count + (size_t)f * S, matrix + (size_t)f * S, (size_t)p.T * sizeof(int),
+                                           hipMemcpyDeviceToDevice, s));
     }
-    SPLAT_LAUNCH("bin_tilescan", bin_tilescan_kernel, dim3(1), dim3(1024), 0, s, p.T, tile_count, tile_range, M_out, total,
-                 p.nchunk, chunk_sum);
+    SPLAT_LAUNCH("bin_tilescan", bin_tilescan_kernel, dim3(1, F), dim3(1024), 0, s, p.T, tile_count, tile_range, M_out, total,
+                 p.nchunk, chunk_sum, S);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
+}
+
+static int bin_sort_impl(int F, int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
+                         void *scratch, int32_t *tile_range, int64_t capacity, uint64_t *keys, int32_t *idx_sorted,
+                         int32_t *overflow_out, int32_t *goff_incl, int32_t *owner_scratch, int32_t *slot_sorted,
+                         hipStream_t s) {
+    const BinPlan p = make_plan(P, W, H);
+    const long long S = (long long)(p.bytes / sizeof(int));
+    char *base = (char *)scratch;
+    int *matrix = (int *)(base + p.off_matrix);
+    const int *chunk_off = (const int *)(base + p.off_chunksum);
+    if (p.lds) {
+        SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<true>, dim3(p.NB, F), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
+                     P, (const float2 *)uv, depth, radius, p.gx, p.gy, p.T, p.chunk, matrix, tile_range,
+                     (long long)capacity, (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off, S);
+    } else {
+        // fill counters live in tile_count's neighbour: reuse matrix row "1" = matrix + T (allocated: NB=1 -> need 2 rows)
+        for (int f = 0; f < F; ++f)
+            SPLAT_CHECK_HIP(hipMemsetAsync(matrix + (size_t)f * S + p.T, 0, (size_t)p.T * sizeof(int), s));
+        const int nblk = p.nchunk;
+        const int chunk = (P + nblk - 1) / nblk;
+        SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<false>, dim3(nblk, F), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
+                     depth, radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, tile_range, (long long)capacity,
+                     (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off, S);
+    }
+    SPLAT_POST_LAUNCH();
+    SPLAT_LAUNCH("tile_sort", tile_sort_kernel, dim3(p.T, F), dim3(SORT_BLOCK), 0, s, tile_range, (long long)capacity,
+                 (unsigned long long *)keys, idx_sorted, owner_scratch, slot_sorted);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_bin_count(int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
+                               int32_t *tile_range, int32_t *M_out, int32_t *gcount, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0, "bad sizes");
+    SPLAT_CHECK_ARG(scratch && tile_range, "null pointer");
+    SPLAT_CHECK_ARG(P == 0 || (uv && radius), "null pointer");
+    return bin_count_impl(1, P, uv, radius, W, H, scratch, tile_range, M_out, gcount, (hipStream_t)stream);
 }
 
 extern "C" int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
@@ -545,27 +607,28 @@ extern "C" int splat_bin_sort(int P, const float *uv, const float *depth, const 
         const int npm = (goff_incl != nullptr) + (owner_scratch != nullptr) + (slot_sorted != nullptr);
         SPLAT_CHECK_ARG(npm == 0 || npm == 3, "goff_incl, owner_scratch and slot_sorted go together");
     }
-    hipStream_t s = (hipStream_t)stream;
-    const BinPlan p = make_plan(P, W, H);
-    char *base = (char *)scratch;
-    int *matrix = (int *)(base + p.off_matrix);
-    const int *chunk_off = (const int *)(base + p.off_chunksum);
-    if (p.lds) {
-        SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<true>, dim3(p.NB), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
-                     P, (const float2 *)uv, depth, radius, p.gx, p.gy, p.T, p.chunk, matrix, tile_range,
-                     (long long)capacity, (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off);
-    } else {
-        // fill counters live in tile_count's neighbour: reuse matrix row "1" = matrix + T (allocated: NB=1 -> need 2 rows)
-        SPLAT_CHECK_HIP(hipMemsetAsync(matrix + p.T, 0, (size_t)p.T * sizeof(int), s));
-        const int nblk = p.nchunk;
-        const int chunk = (P + nblk - 1) / nblk;
-        SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<false>, dim3(nblk), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
-                     depth, radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, tile_range, (long long)capacity,
-                     (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off);
-    }
-    SPLAT_POST_LAUNCH();
-    SPLAT_LAUNCH("tile_sort", tile_sort_kernel, dim3(p.T), dim3(SORT_BLOCK), 0, s, tile_range, (long long)capacity,
-                 (unsigned long long *)keys, idx_sorted, owner_scratch, slot_sorted);
-    SPLAT_POST_LAUNCH();
-    return SPLAT_OK;
+    return bin_sort_impl(1, P, uv, depth, radius, W, H, scratch, tile_range, capacity, keys, idx_sorted, overflow_out,
+                         goff_incl, owner_scratch, slot_sorted, (hipStream_t)stream);
+}
+
+// ---- frame batch: F frames of the same P Gaussians in one set of launches (grid.y = frame).  Per-Gaussian arrays are
+// [F,P,..], tile_range [F,T,2], M_out [F], scratch F blocks of splat_bin_scratch_bytes(P, W, H); keys / idx_sorted /
+// owner / slot_sorted hold `capacity` entries per frame (tile ranges are relative to the frame's segment).
+extern "C" int splat_bin_count_batch(int F, int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
+                                     int32_t *tile_range, int32_t *M_out, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(F >= 1 && F <= 65535 && P >= 1 && W > 0 && H > 0, "bad sizes");
+    SPLAT_CHECK_ARG(scratch && tile_range && uv && radius, "null pointer");
+    return bin_count_impl(F, P, uv, radius, W, H, scratch, tile_range, M_out, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int splat_bin_sort_batch(int F, int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
+                                    void *scratch, int32_t *tile_range, int64_t capacity, uint64_t *keys,
+                                    int32_t *idx_sorted, int32_t *overflow_out, int32_t *goff_incl,
+                                    int32_t *owner_scratch, int32_t *slot_sorted, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(F >= 1 && F <= 65535 && P >= 1 && W > 0 && H > 0 && capacity >= 1, "bad sizes");
+    SPLAT_CHECK_ARG(scratch && tile_range && overflow_out && uv && depth && radius && keys && idx_sorted && goff_incl &&
+                        owner_scratch && slot_sorted,
+                    "null pointer");
+    return bin_sort_impl(F, P, uv, depth, radius, W, H, scratch, tile_range, capacity, keys, idx_sorted, overflow_out,
+                         goff_incl, owner_scratch, slot_sorted, (hipStream_t)stream);
 }

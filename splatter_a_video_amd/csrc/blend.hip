@@ -92,6 +92,7 @@ struct BlendArgs {
     // frame batch: F frames of one Gaussian set in a single launch (workgroup -> (frame, tile)); every per-frame array
     // is the frame-0 pointer plus frame * stride.  F = 1: the single-frame operators.
     int F, T;               // frames, tiles per frame
+    int tile_only;          // backward: stop after the pair records (the caller reduces them over the frames)
     long long cap;          // pair capacity per frame: stride of idx_sorted / slot_sorted / pair_buf records
     long long pack_fs;      // floats between two frames' packed records
     long long opacity_fs, feature_fs, bias_fs;  // element strides of the per-Gaussian inputs (0: shared by all frames)
@@ -102,10 +103,12 @@ __device__ __forceinline__ BlendArgs frame_args(const BlendArgs &B, int f) {
     BlendArgs A = B;
     if (B.F > 1) {
         const size_t HW = (size_t)B.H * B.W, fz = (size_t)f;
-        A.uv = B.uv + fz * B.P;
-        A.conic = B.conic + fz * 3 * B.P;
-        A.opacity = B.opacity + fz * B.opacity_fs;
-        A.feature = B.feature + fz * B.feature_fs;
+        if (B.uv) {  // inputs of the pack kernel (absent when the backward reuses the forward's records)
+            A.uv = B.uv + fz * B.P;
+            A.conic = B.conic + fz * 3 * B.P;
+            A.opacity = B.opacity + fz * B.opacity_fs;
+            A.feature = B.feature + fz * B.feature_fs;
+        }
         if (B.bias) A.bias = B.bias + fz * B.bias_fs;
         A.idx_sorted = B.idx_sorted + fz * B.cap;
         A.tile_range = B.tile_range + fz * B.T;
@@ -687,16 +690,7 @@ __device__ __forceinline__ void wave_sum_n_to_lane63(float (&v)[N]) {
     for (int k = N4 + N3; k < N; ++k) v[k] = wave_sum_to_lane63(v[k]);
 }
 
-// per-pixel replay of one survivor in the backward (shared by pair and atomic kernels).
-// r[] = [ux uy ca cb cc o | ax ay (ABS) | bias (BIAS) | CH feature terms]  -- one array so that the wave
-// reduction can interleave all chains.
-template <bool ABS, bool BIAS>
-struct GradLayout {
-    static constexpr int NG = 6 + (ABS ? 2 : 0) + (BIAS ? 1 : 0);
-    static constexpr int I_ABS = 6;
-    static constexpr int I_BIAS = 6 + (ABS ? 2 : 0);
-};
-
+// per-pixel replay of one survivor in the backward (shared by pair and atomic kernels); GradLayout: common.h
 template <int CH, bool ABS, bool BIAS>
 __device__ __forceinline__ void replay_one(const float4 &g0, const float4 &g1, const float (&f)[CH], float dx, float dy,
                                            float G, float a, float Tf, float bgdot, const float (&gp)[CH], float &T,
@@ -732,9 +726,6 @@ __device__ __forceinline__ void replay_one(const float4 &g0, const float4 &g1, c
 }
 
 // ------------------------------------------------------------------ backward, atomic-free ("pair" mode)
-// stride of a pair record in floats: the used floats rounded up to whole 16-byte chunks (a Gaussian's records are
-// contiguous, pair_reduce streams them with float4 loads; padding every record to a 64-byte sector cost 30 % more traffic)
-#define PAIR_STRIDE(nc) (((nc) + 3) & ~3)
 template <int CH, bool ABS, bool BIAS>
 struct PairCfg {
     static constexpr int NG = GradLayout<ABS, BIAS>::NG;  // ux uy ca cb cc o [ax ay] [bias]
@@ -1485,7 +1476,7 @@ static int launch_bwd_ab(const BlendArgs &A, int T, bool pair, hipStream_t s) {
         else SPLAT_LAUNCH("blend_bwd", (blend_bwd_atomic_kernel<CH, ABS, BIAS, false>), grid, block, 0, s, A);
     }
     SPLAT_POST_LAUNCH();
-    if (pair && A.F == 1) {  // frame batches reduce their records in the Gaussian-side backward (frames.hip)
+    if (pair && !A.tile_only) {  // frame batches reduce their records in the Gaussian-side backward (preprocess.hip)
         const dim3 rgrid((unsigned)(((size_t)A.P * 4 + 255) / 256));
         SPLAT_LAUNCH("pair_reduce", (pair_reduce_kernel<ABS, BIAS, PairCfg<CH, ABS, BIAS>::NCP>), rgrid, dim3(256), 0, s, A);
         SPLAT_POST_LAUNCH();
@@ -1616,4 +1607,74 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
         if (rc != SPLAT_OK) return rc;
     }
     return SPLAT_OK;
+}
+
+
+// ================================================================== frame batch (F frames of one Gaussian set per launch)
+// The tile kernels take workgroup b -> (frame, tile) through the same XCD-aware mapping over the F * T tiles; per-frame
+// arrays are stacked [F, ...], the pair arrays (idx_sorted, slot_sorted, pair records) hold `capacity` entries per frame.
+// C <= 32 (one channel chunk).  opacity / feature may be shared by all frames (stride 0) or per frame.
+extern "C" size_t splat_blend_pair_stride(int C, int want_abs, int has_bias) {
+    // exact record stride (floats) the backward kernels use for this configuration
+    const int ng = 6 + (want_abs ? 2 : 0) + (has_bias ? 1 : 0);
+    return (size_t)PAIR_STRIDE(ng + chunk_ch(C > 32 ? 32 : C));
+}
+
+extern "C" int splat_alpha_blending_forward_batch(int F, int P, int C, const float *uv, const float *conic,
+                                                  const float *opacity, int64_t opacity_frame_stride,
+                                                  const float *feature, int64_t feature_frame_stride,
+                                                  const int32_t *idx_sorted, const int32_t *tile_range, int64_t capacity,
+                                                  float bg, const float *bg_channels, int W, int H, int K,
+                                                  int enable_truncation, float *out, float *final_T, int32_t *ncontrib,
+                                                  int32_t *gs_idx, float *pack_scratch, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 32 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 32)");
+    SPLAT_CHECK_ARG(uv && conic && opacity && feature && idx_sorted && tile_range && out && final_T && ncontrib &&
+                        pack_scratch,
+                    "null pointer");
+    const bool enh = (gs_idx != nullptr) && K > 0;
+    BlendArgs A;
+    memset(&A, 0, sizeof(A));
+    A.P = P; A.C = C;
+    A.uv = (const float2 *)uv; A.conic = conic; A.opacity = opacity; A.feature = feature;
+    A.idx_sorted = idx_sorted; A.tile_range = (const int2 *)tile_range;
+    A.bg = bg; A.bgc = bg_channels; A.W = W; A.H = H; A.gx = (W + TILE - 1) / TILE;
+    A.K = enh ? K : 0; A.trunc = enable_truncation ? 1 : 0;
+    A.out = out; A.final_T = final_T; A.ncontrib = ncontrib; A.gs_idx = gs_idx;
+    A.pack = pack_scratch;
+    const int T = A.gx * ((H + TILE - 1) / TILE);
+    SPLAT_CHECK_ARG((long long)F * T < (1ll << 31), "too many tiles");
+    A.F = F; A.T = T; A.cap = capacity;
+    A.pack_fs = (long long)P * (long long)splat_blend_pack_floats(C);
+    A.opacity_fs = opacity_frame_stride; A.feature_fs = feature_frame_stride;
+    A.c0 = 0; A.cn = C;
+    return fwd_chunk(A, T, enh, false, (hipStream_t)stream);
+}
+
+extern "C" int splat_alpha_blending_backward_batch(int F, int P, int C, const int32_t *idx_sorted,
+                                                   const int32_t *tile_range, int64_t capacity, float bg, int W, int H,
+                                                   const float *final_T, const int32_t *ncontrib, const float *dL_dout,
+                                                   int want_abs, const int32_t *slot_sorted, float *pair_records,
+                                                   const float *pack, float *dbg_T_front, splat_stream_t stream) {
+    // writes one gradient record per (frame, tile, splat) pair at frame * capacity + slot; the records are summed per
+    // Gaussian by the Gaussian-side backward (splat_frames_gauss_backward_*).  `pack` = the forward's packed records.
+    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 32 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 32)");
+    SPLAT_CHECK_ARG(idx_sorted && tile_range && final_T && ncontrib && dL_dout && slot_sorted && pair_records && pack,
+                    "null pointer");
+    BlendArgs A;
+    memset(&A, 0, sizeof(A));
+    A.P = P; A.C = C;
+    A.idx_sorted = idx_sorted; A.tile_range = (const int2 *)tile_range;
+    A.bg = bg; A.W = W; A.H = H; A.gx = (W + TILE - 1) / TILE;
+    A.final_T = const_cast<float *>(final_T); A.ncontrib = const_cast<int *>(ncontrib);
+    A.dL_dout = dL_dout;
+    A.slot_sorted = slot_sorted; A.pair_buf = pair_records;
+    A.pack = const_cast<float *>(pack); A.pack_valid = 1;
+    A.dbg_T_front = dbg_T_front;
+    const int T = A.gx * ((H + TILE - 1) / TILE);
+    A.F = F; A.T = T; A.cap = capacity; A.tile_only = 1;
+    A.pack_fs = (long long)P * (long long)splat_blend_pack_floats(C);
+    A.c0 = 0; A.cn = C;
+    // tile kernels only: the abs sums are requested through a non-null marker (nothing is written through it here)
+    A.dL_dabs_uv = want_abs ? pair_records : nullptr;
+    return bwd_chunk(A, T, false, true, (hipStream_t)stream);
 }

@@ -105,3 +105,17 @@ __device__ __forceinline__ int wave_max_i(int v) {
 __device__ __forceinline__ void atomic_add_f32(float *p, float v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// ---------------------------------------------------------------- pair records of the atomic-free blend backward
+// One record per (tile, splat) pair at its Gaussian-major slot: r[] = [ux uy ca cb cc o | ax ay (ABS) | bias (BIAS) |
+// CH feature terms] -- written by the tile kernels of blend.hip, summed per Gaussian by pair_reduce (blend.hip) or by
+// the frame-batch Gaussian-side backward (preprocess.hip).
+template <bool ABS, bool BIAS>
+struct GradLayout {
+    static constexpr int NG = 6 + (ABS ? 2 : 0) + (BIAS ? 1 : 0);
+    static constexpr int I_ABS = 6;
+    static constexpr int I_BIAS = 6 + (ABS ? 2 : 0);
+};
+// stride of a pair record in floats: the used floats rounded up to whole 16-byte chunks (a Gaussian's records are
+// contiguous and streamed with float4 loads; padding every record to a 64-byte sector cost 30 % more traffic)
+#define PAIR_STRIDE(nc) (((nc) + 3) & ~3)

@@ -21,6 +21,12 @@ preprocess_ortho_fwd_kernel(int P, const float *__restrict__ xyz, const float *_
                             int *__restrict__ radius, int *__restrict__ tiles) {
     const int i = blockIdx.x * PP_BLOCK + threadIdx.x;
     if (i >= P) return;
+    {   // frame batch: blockIdx.y = frame; offsets [F,P,3] in, [F,P,..] out
+        const size_t f = blockIdx.y;
+        if (offset) offset += f * 3 * P;
+        uv += f * P; depth += f * P; conic += f * 3 * P; radius += f * P;
+        if (tiles) tiles += f * P;
+    }
     Cam c;
     load_cam(nullptr, extr, c);
     float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
@@ -46,7 +52,7 @@ preprocess_ortho_fwd_kernel(int P, const float *__restrict__ xyz, const float *_
     depth[i] = d;
     conic[3 * i] = o0; conic[3 * i + 1] = o1; conic[3 * i + 2] = o2;
     radius[i] = orad;
-    tiles[i] = otiles;
+    if (tiles) tiles[i] = otiles;
 }
 
 template <bool ACC>
@@ -252,7 +258,196 @@ frame_preprocess_bwd_kernel(int P, CubicAddr ca, float d, DynBasis b, const floa
 
 inline dim3 dyn_grid(int P) { return dim3((unsigned)(((size_t)P * 4 + DYN_BLOCK - 1) / DYN_BLOCK)); }
 
+// ------------------------------------------------------------------ Gaussian-side backward of a frame batch
+// After the tile kernels of a frame batch every (frame, tile, splat) pair owns one gradient record
+// [ux uy ca cb cc o | ax ay | features] at frame * cap + slot, a Gaussian's records of one frame being contiguous
+// (goff = inclusive prefix of tiles per Gaussian, per frame).  One quad of lanes per Gaussian streams them -- lane `sub`
+// owns the 16-byte chunks sub, sub + 4, .. of every record, as pair_reduce does for one frame -- over ALL frames, then
+// runs the preprocess backward and writes every parameter gradient once per batch.
+//
+// Static parameters + per-frame offsets under the orthographic camera: conic, radius and the projection Jacobian do not
+// depend on the frame (the offsets only move the centre), and the whole backward chain is linear in (dL_duv,
+// dL_dconic): the records of all frames are summed first and the chain runs ONCE per Gaussian.
+struct GaussBwdArgs {
+    int F, P, W, H;
+    int C, cn;              // row stride of d_feature, channels carried by the records
+    long long cap;          // records per frame
+    const float *pair;      // [F, cap, NCP]
+    const int *goff;        // [F, P]
+    const int *radius;      // [F, P] (optional: radii_max / visibility output)
+    const float *xyz, *scales;
+    const float4 *uquats;
+    const float *extr;
+    float *d_xyz, *d_scales, *d_uquats, *d_opacity, *d_feature;
+    float *tap, *abs_tap;   // optional [P,2]: sum over the frames of dL_duv * (W/2, H/2) (and of its abs twin)
+    int *radii_max;         // optional [P]: max over the frames of the screen radius (visibility = radii_max > 0)
+    int accumulate;         // add to the parameter gradients instead of storing
+};
+
+template <bool ABS, int NCP>
+__global__ void __launch_bounds__(256)
+frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
+    constexpr int NG = GradLayout<ABS, false>::NG;
+    constexpr int NQ = NCP / 4, NS = (NQ + 3) / 4;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 2, sub = t & 3;
+    if (i >= A.P) return;  // whole quads leave together
+    float4 a[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int rmax = 0;
+    bool any = false;
+    for (int f = 0; f < A.F; ++f) {
+        const int *goff = A.goff + (size_t)f * A.P;
+        const int beg = i > 0 ? goff[i - 1] : 0, end = goff[i];
+        if (A.radii_max && sub == 0) rmax = imax_(rmax, A.radius[(size_t)f * A.P + i]);
+        any = any || end > beg;
+        const float *base = A.pair + (size_t)f * (size_t)A.cap * NCP + 4 * sub;
+        int j = beg;
+        for (; j + 1 < end; j += 2) {  // two records in flight
+            float4 v0[NS], v1[NS];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                const bool mine = 4 * c + sub < NQ;
+                v0[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v1[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)(j + 1) * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                a[c].x += v0[c].x; a[c].y += v0[c].y; a[c].z += v0[c].z; a[c].w += v0[c].w;
+                a[c].x += v1[c].x; a[c].y += v1[c].y; a[c].z += v1[c].z; a[c].w += v1[c].w;
+            }
+        }
+        if (j < end) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                if (4 * c + sub < NQ) {
+                    const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c);
+                    a[c].x += v.x; a[c].y += v.y; a[c].z += v.z; a[c].w += v.w;
+                }
+            }
+        }
+    }
+    // geometry sums: chunk 0 (lane 0) = ux uy ca cb, chunk 1 (lane 1) = cc o [ax ay]
+    const float ux = quad_bcast<0>(a[0].x), uy = quad_bcast<0>(a[0].y);
+    const float g3[3] = {quad_bcast<0>(a[0].z), quad_bcast<0>(a[0].w), quad_bcast<1>(a[0].x)};
+    const float dop = quad_bcast<1>(a[0].y);
+    float gp[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (any) {  // a record exists: the Gaussian was visible with radius > 0 in that frame (the chain's preconditions)
+        Cam c;
+        load_cam(nullptr, A.extr, c);
+        project_ortho_grad_pt(c, A.W, A.H, ux, uy, 0.f, gp);
+        const float p[3] = {A.xyz[3 * i], A.xyz[3 * i + 1], A.xyz[3 * i + 2]};
+        const float4 q4 = A.uquats[i];
+        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float s[3] = {A.scales[3 * i], A.scales[3 * i + 1], A.scales[3 * i + 2]};
+        float c3[6], ea[3], eb[3], et[3], Jm[4], cov[3];
+        cov3d_pt(s, q, c3);
+        ewa_T<true>(c, p, A.W, A.H, ea, eb, et, Jm);
+        ewa_cov2d<true>(ea, eb, c3, cov);
+        const float det = cov[0] * cov[2] - cov[1] * cov[1];
+        if (det != 0.0f) {
+            float dcx, dcy, dcz, g6[6];
+            ewa_grad_cov_pt(ea, eb, cov, det, g3, dcx, dcy, dcz, g6);
+            cov3d_grad_pt(s, q, g6, ds, dq);
+        }
+    }
+    const bool acc = A.accumulate != 0;
+    auto put1 = [acc](float *p, float v) { *p = acc ? *p + v : v; };
+    if (sub == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) put1(A.d_xyz + 3 * i + k, gp[k]);
+        put1(A.d_opacity + i, dop);
+        if (A.radii_max) A.radii_max[i] = rmax;
+    } else if (sub == 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) put1(A.d_scales + 3 * i + k, ds[k]);
+    } else if (sub == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) put1(A.d_uquats + 4 * i + k, dq[k]);
+    } else {
+        if (A.tap) {
+            A.tap[2 * i] = ux * (0.5f * (float)A.W);
+            A.tap[2 * i + 1] = uy * (0.5f * (float)A.H);
+        }
+    }
+    if (ABS) {
+        const float ax = quad_bcast<1>(a[0].z), ay = quad_bcast<1>(a[0].w);
+        if (sub == 3 && A.abs_tap) {
+            A.abs_tap[2 * i] = ax * (0.5f * (float)A.W);
+            A.abs_tap[2 * i + 1] = ay * (0.5f * (float)A.H);
+        }
+    }
+    // features: component k of the record lives in chunk k / 4 = lane (k / 4) & 3, register a[k / 16]
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        if (4 * c + sub < NQ) {
+            const int k0 = 16 * c + 4 * sub;
+            const float v[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = k0 + e - NG;
+                if (ch >= 0 && ch < A.cn) put1(A.d_feature + (size_t)i * A.C + ch, v[e]);
+            }
+        }
+    }
+}
+
+template <bool ABS>
+int launch_gauss_bwd_static(const GaussBwdArgs &A, int ncp, hipStream_t s) {
+    const dim3 grid((unsigned)(((size_t)A.P * 4 + 255) / 256)), block(256);
+#define GB(N) case N: SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_static_kernel<ABS, N>), grid, block, 0, s, A); break
+    switch (ncp) {
+        GB(8); GB(12); GB(16); GB(20); GB(24); GB(28); GB(32); GB(36); GB(40);
+        default: splat_set_error("gauss_bwd: unsupported record stride %d", ncp); return SPLAT_E_ARG;
+    }
+#undef GB
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
 }  // namespace
+
+extern "C" size_t splat_blend_pair_stride(int C, int want_abs, int has_bias);
+
+extern "C" int splat_preprocess_ortho_forward_batch(int F, int P, const float *xyz, const float *offsets,
+                                                    const float *scales, const float *uquats, const float *extr, int W,
+                                                    int H, float nearest, float extent, float *uv, float *depth,
+                                                    float *conic, int32_t *radius, void *stream) {
+    SPLAT_CHECK_ARG(F >= 1 && F <= 65535 && P >= 1 && W > 0 && H > 0, "bad sizes");
+    SPLAT_CHECK_ARG(xyz && scales && uquats && extr && uv && depth && conic && radius, "null pointer");
+    SPLAT_CHECK_ARG(F == 1 || offsets, "several frames of static Gaussians need per-frame offsets [F,P,3]");
+    const dim3 grid = pp_grid(P);
+    SPLAT_LAUNCH("preprocess_fwd", preprocess_ortho_fwd_kernel, dim3(grid.x, F), dim3(PP_BLOCK), 0, (hipStream_t)stream, P,
+                 xyz, offsets, scales, (const float4 *)uquats, extr, W, H, nearest, extent, (float2 *)uv, depth, conic,
+                 radius, (int *)nullptr);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_frames_gauss_backward_static(int F, int P, int C, int W, int H, int64_t capacity, int want_abs,
+                                                  const float *pair_records, const int32_t *goff_incl,
+                                                  const int32_t *radius, const float *xyz, const float *scales,
+                                                  const float *uquats, const float *extr, int accumulate,
+                                                  float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                                  float *d_feature, float *tap, float *abs_tap, int32_t *radii_max,
+                                                  void *stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 32 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 32)");
+    SPLAT_CHECK_ARG(pair_records && goff_incl && xyz && scales && uquats && extr, "null input pointer");
+    SPLAT_CHECK_ARG(d_xyz && d_scales && d_uquats && d_opacity && d_feature, "null gradient pointer");
+    SPLAT_CHECK_ARG(!abs_tap || want_abs, "abs_tap needs records with the abs sums");
+    SPLAT_CHECK_ARG(!radii_max || radius, "radii_max needs the per-frame radius");
+    GaussBwdArgs A;
+    memset(&A, 0, sizeof(A));
+    A.F = F; A.P = P; A.W = W; A.H = H; A.C = C; A.cn = C; A.cap = capacity;
+    A.pair = pair_records; A.goff = goff_incl; A.radius = radius;
+    A.xyz = xyz; A.scales = scales; A.uquats = (const float4 *)uquats; A.extr = extr;
+    A.d_xyz = d_xyz; A.d_scales = d_scales; A.d_uquats = d_uquats; A.d_opacity = d_opacity; A.d_feature = d_feature;
+    A.tap = tap; A.abs_tap = abs_tap; A.radii_max = radii_max; A.accumulate = accumulate;
+    const int ncp = (int)splat_blend_pair_stride(C, want_abs, 0);
+    return want_abs ? launch_gauss_bwd_static<true>(A, ncp, (hipStream_t)stream)
+                    : launch_gauss_bwd_static<false>(A, ncp, (hipStream_t)stream);
+}
 
 extern "C" int splat_preprocess_ortho_forward(int P, const float *xyz, const float *offset, const float *scales,
                                               const float *uquats, const float *extr, int W, int H, float nearest,

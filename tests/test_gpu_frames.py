@@ -1,0 +1,114 @@
+"""Frame-batched rendering (splatter_a_video_amd.frames.FrameBatch: every kernel takes the frame as a grid dimension,
+the Gaussian-side backward runs once per batch) against F calls of the per-frame operators."""
+import numpy as np
+import pytest
+import torch
+
+import dptr.gs as gs
+from splatter_a_video_amd._lib import SplatError
+from splatter_a_video_amd.frames import FrameBatch
+from splatter_a_video_amd.gs.raster_ops import capture_T_front
+from splatter_a_video_amd.synth import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, grad=False):
+    return torch.tensor(np.asarray(a), device="cuda", requires_grad=grad)
+
+
+def _offsets(sc, F):
+    return np.stack([sc.positions(f) - sc.xyz for f in range(F)]).astype(np.float32)
+
+
+def _per_frame(sc, p, off, feat, g, W, H, bg, abs_tap=False):
+    """the per-frame operator path (fused preprocess -> sort -> blend), frame by frame through autograd"""
+    imgs, taps, atap, rad = [], [], [], []
+    extr = _t(sc.extr)
+    for f in range(off.shape[0]):
+        uv, depth, conic, radius, tiles = gs.preprocess_ortho(p["xyz"], p["scales"], p["uquats"], extr, W, H, nearest=0.01,
+                                                              offset=off[f])
+        idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        ndc = torch.zeros_like(uv, requires_grad=True)
+        andc = torch.zeros_like(uv, requires_grad=True) if abs_tap else None
+        img = gs.alpha_blending(uv, conic, p["opacity"], feat, idx, tr, bg, W, H, ndc, andc)
+        (img * g[f]).sum().backward()
+        imgs.append(img.detach()); taps.append(ndc.grad); rad.append(radius)
+        if abs_tap:
+            atap.append(andc.grad)
+    return torch.stack(imgs), sum(taps), (sum(atap) if abs_tap else None), torch.stack(rad).max(0).values
+
+
+@pytest.mark.parametrize("N,W,H,F,C,abs_tap", [(3000, 100, 60, 3, 3, False), (20000, 256, 192, 4, 3, True),
+                                               (5000, 96, 64, 2, 19, False), (1, 16, 16, 2, 1, False),
+                                               (60000, 854, 480, 2, 3, False)])
+def test_batch_equals_per_frame_operators(N, W, H, F, C, abs_tap):
+    sc = make_scene(N, W, H, seed=N + C)
+    rng = np.random.default_rng(N)
+    off = _t(_offsets(sc, F))
+    featv = rng.uniform(size=(N, C)).astype(np.float32)
+    g = _t(rng.normal(size=(F, C, H, W)).astype(np.float32))
+    bg = 0.3
+
+    def params():
+        return {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity).items()}
+
+    pa, fa = params(), _t(featv, True)
+    ref_img, ref_tap, ref_atap, ref_rad = _per_frame(sc, pa, off, fa, g, W, H, bg, abs_tap)
+
+    pb, fb_ = params(), _t(featv, True)
+    B = FrameBatch(F, N, W, H, C, "cuda", want_abs=abs_tap)
+    out = B.render(pb["xyz"], pb["scales"], pb["uquats"], pb["opacity"], fb_, off, _t(sc.extr), bg=bg)
+    assert out.shape == (F, C, H, W)
+    assert torch.equal(out, ref_img)                      # same kernels, same arithmetic: bit-identical images
+    with capture_T_front() as cap:
+        out.backward(g)
+    torch.cuda.synchronize()
+    assert B.check() > 0 or N == 1
+    assert float((cap.maps[0] - 1).abs().max()) < 2e-4      # every frame's backward replays its forward's decisions
+    for k in pa:
+        a, b = pb[k].grad, pa[k].grad
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max()) + 1e-12), k
+    assert torch.allclose(fb_.grad, fa.grad, rtol=2e-4, atol=2e-6 * float(fa.grad.abs().max()) + 1e-12)
+    assert torch.allclose(B.tap, ref_tap, rtol=2e-4, atol=2e-6 * float(ref_tap.abs().max()) + 1e-12)
+    if abs_tap:
+        assert torch.allclose(B.abs_tap, ref_atap, rtol=2e-4, atol=2e-6 * float(ref_atap.abs().max()) + 1e-12)
+    assert torch.equal(B.radii_max, ref_rad)
+
+
+def test_batch_gradient_sinks_and_reuse():
+    """the backward adds into caller-owned buffers (FlatGradBucket views); a FrameBatch is reused step after step
+    without a host sync"""
+    N, W, H, F, C = 4000, 128, 96, 3, 3
+    sc = make_scene(N, W, H, seed=4)
+    rng = np.random.default_rng(0)
+    off = _t(_offsets(sc, F))
+    g = _t(rng.normal(size=(F, C, H, W)).astype(np.float32))
+    p = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity,
+                                         feature=rng.uniform(size=(N, C)).astype(np.float32)).items()}
+    B = FrameBatch(F, N, W, H, C, "cuda")
+    B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], off, _t(sc.extr)).backward(g)
+    want = {k: v.grad.clone() for k, v in p.items()}
+    sink = {k: torch.full_like(v, 0.5) for k, v in p.items()}
+    q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    for _ in range(2):      # two batches accumulate twice
+        B.render(q["xyz"], q["scales"], q["uquats"], q["opacity"], q["feature"], off, _t(sc.extr), grad_sink=sink).backward(g)
+    for k in p:
+        assert q[k].grad is None
+        assert torch.allclose(sink[k], 0.5 + 2 * want[k], rtol=1e-5, atol=1e-6 * float(want[k].abs().max()) + 1e-7), k
+    B.check()
+
+
+def test_batch_capacity_overflow_is_flagged_and_safe():
+    N, W, H, F, C = 8000, 128, 96, 2, 3
+    sc = make_scene(N, W, H, seed=9)
+    off = _t(_offsets(sc, F))
+    p = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity,
+                                         feature=np.ones((N, C), np.float32)).items()}
+    B = FrameBatch(F, N, W, H, C, "cuda", capacity=2000)
+    out = B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], off, _t(sc.extr))
+    out.sum().backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(p["xyz"].grad).all()
+    with pytest.raises(SplatError):
+        B.check()
