@@ -108,6 +108,15 @@ int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *ra
                    int32_t *idx_sorted, int32_t *overflow_out, int32_t *goff_incl /*out*/,
                    int32_t *owner, int32_t *slot_sorted, splat_stream_t stream);
 
+/* ---- the reference's own two sort helpers, for callers that keep its sort_gaussian.py (cumsum -> keys -> torch.sort ->
+ *      gather -> ranges): replace computeGaussianKey / computeTileGaussianRange (src/sort_gaussian.cu:72-146).
+ *      gaussian_key[M] = tile << 32 | depth bits, gaussian_idx[M] = Gaussian id (M = tiles_cumsum[P-1]; caller-allocated);
+ *      tile_range must be zero-filled by the caller (tiles without pairs keep (0,0)). ---- */
+int splat_compute_gaussian_key(int P, const float *uv, const float *depth, const int32_t *radius,
+                               const int32_t *tiles_cumsum, int W, int H, int64_t *gaussian_key, int32_t *gaussian_idx,
+                               splat_stream_t stream);
+int splat_compute_tile_gaussian_range(int64_t M, const int64_t *key_sorted, int32_t *tile_range, splat_stream_t stream);
+
 /* ---- alpha blending : replaces alphaBlendingForward/Backward, ...Enhanced, ...WithBias
  *      (src/alpha_blending.cu:251-582, src/alpha_blending_enhanced.cu:275-627,
  *       src/alpha_blending_with_bias.cu:266-621).

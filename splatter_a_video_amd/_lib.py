@@ -27,6 +27,7 @@ SYMBOLS = [
     "splat_ewa_project_forward", "splat_ewa_project_backward",
     "splat_compute_sh_forward", "splat_compute_sh_backward",
     "splat_bin_scratch_bytes", "splat_bin_count", "splat_bin_sort",
+    "splat_compute_gaussian_key", "splat_compute_tile_gaussian_range",
     "splat_alpha_blending_forward", "splat_alpha_blending_backward", "splat_blend_pair_floats", "splat_blend_pack_floats",
     "splat_dynamic_eval_forward", "splat_dynamic_eval_backward",
     "splat_preprocess_ortho_forward", "splat_preprocess_ortho_backward",

@@ -632,3 +632,68 @@ extern "C" int splat_bin_sort_batch(int F, int P, const float *uv, const float *
     return bin_sort_impl(F, P, uv, depth, radius, W, H, scratch, tile_range, capacity, keys, idx_sorted, overflow_out,
                          goff_incl, owner_scratch, slot_sorted, (hipStream_t)stream);
 }
+
+
+// ================================================================== the reference's two sort helpers (dptr.gs._C names)
+// For callers that keep the reference's own sort_gaussian.py (cumsum -> compute_gaussian_key -> torch.sort -> gather ->
+// compute_tile_gaussian_range, sort_gaussian.py:42-52): same keys (tile << 32 | depth bits, src/sort_gaussian.cu:24-44)
+// and the same range rule (:46-70).  The native sort above does not use them.
+__global__ void __launch_bounds__(256)
+gaussian_key_kernel(int P, const float2 *__restrict__ uv, const float *__restrict__ depth, const int *__restrict__ radius,
+                    const int *__restrict__ tiles_cumsum, int gx, int gy, long long *__restrict__ key,
+                    int *__restrict__ gidx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radius[i];
+    if (r <= 0) return;
+    const float2 q = uv[i];
+    int x0, y0, x1, y1;
+    tile_rect(q.x, q.y, r, gx, gy, x0, y0, x1, y1);
+    int cur = i == 0 ? 0 : tiles_cumsum[i - 1];
+    const long long d = (long long)__float_as_int(depth[i]);
+    for (int ty = y0; ty < y1; ++ty)
+        for (int tx = x0; tx < x1; ++tx) {
+            key[cur] = ((long long)(ty * gx + tx) << 32) | d;
+            gidx[cur] = i;
+            ++cur;
+        }
+}
+
+__global__ void __launch_bounds__(256)
+tile_gaussian_range_kernel(long long M, const long long *__restrict__ key_sorted, int2 *__restrict__ tile_range) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int cur = (int)(key_sorted[i] >> 32);
+    if (i == 0) tile_range[cur].x = 0;
+    if (i == M - 1) tile_range[cur].y = (int)M;
+    if (i == 0) return;
+    const int prev = (int)(key_sorted[i - 1] >> 32);
+    if (prev != cur) {
+        tile_range[prev].y = (int)i;
+        tile_range[cur].x = (int)i;
+    }
+}
+
+extern "C" int splat_compute_gaussian_key(int P, const float *uv, const float *depth, const int32_t *radius,
+                                          const int32_t *tiles_cumsum, int W, int H, int64_t *gaussian_key,
+                                          int32_t *gaussian_idx, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0, "bad sizes");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(uv && depth && radius && tiles_cumsum, "null pointer");
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    SPLAT_LAUNCH("gaussian_key", gaussian_key_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P,
+                 (const float2 *)uv, depth, radius, tiles_cumsum, gx, gy, (long long *)gaussian_key, gaussian_idx);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_compute_tile_gaussian_range(int64_t M, const int64_t *key_sorted, int32_t *tile_range /*[T,2], zero-filled*/,
+                                                 splat_stream_t stream) {
+    SPLAT_CHECK_ARG(M >= 0, "bad sizes");
+    if (M == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(key_sorted && tile_range, "null pointer");
+    SPLAT_LAUNCH("tile_gaussian_range", tile_gaussian_range_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
+                 (hipStream_t)stream, (long long)M, (const long long *)key_sorted, (int2 *)tile_range);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}

@@ -159,3 +159,16 @@ def test_diff_gaussian_rasterization_shim_surface():
         rast(xyz, None, op, colors_precomp=torch.rand(8, 3))
     with pytest.raises((ValueError, RuntimeError)):
         rast(xyz, None, op, colors_precomp=torch.rand(8, 3), scales=torch.rand(8, 3), rotations=torch.rand(8, 4))
+
+
+def test_dptr_C_shim_exports_the_reference_pybind_names():
+    """dptr.gs._C carries the 18 names of the reference's pybind module (src/submodules/dptr/dptr/gs/src/ext.cpp:14-33)"""
+    import dptr.gs._C as _C
+    names = ["project_point_forward", "project_point_backward", "compute_cov3d_forward", "compute_cov3d_backward",
+             "ewa_project_forward", "ewa_project_backward", "compute_gaussian_key", "compute_tile_gaussian_range",
+             "compute_sh_forward", "compute_sh_backward", "alpha_blending_forward", "alpha_blending_backward",
+             "alpha_blending_forward_enhanced", "alpha_blending_backward_enhanced", "compute_sh_free_forward",
+             "compute_sh_free_backward", "alpha_blending_forward_with_bias", "alpha_blending_backward_with_bias"]
+    assert sorted(names) == sorted(_C.__all__)
+    for n in names:
+        assert callable(getattr(_C, n))

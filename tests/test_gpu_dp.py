@@ -1,0 +1,72 @@
+"""Two data-parallel ranks on ONE device (gloo; RCCL needs one GPU per rank) through the bench's synchronous step --
+local frames forward+backward on the frame batch, all-reduce of the flat bucket, Adam on the flat parameters -- against a
+single process that renders all frames: same reduced gradient, same parameters after the step, and identical replicas."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+N, W, H, FRAMES = 6000, 128, 96, 6
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(frames, steps=2):
+    import bench
+    from splatter_a_video_amd.synth import make_scene
+    sc = make_scene(N, W, H, F=12, seed=77)
+    R = bench.FrameRenderer(sc, torch.device("cuda:0"), frames, mode="batch")
+    R.opt.seg_lr[0] = 1e-3          # a visible update: step 2's forward must see step 1's parameters
+    grads = []
+    for _ in range(steps):
+        R.step()
+        grads.append(R.flat_grad.clone())
+    torch.cuda.synchronize()
+    R.check_sorts()
+    return grads, R.bucket.flat_param.detach().clone()
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grads, param = _run([f for f in range(FRAMES) if f % world == rank])
+        torch.save({"grads": [g.cpu() for g in grads], "param": param.cpu()}, out + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_device_match_single_process(tmp_path):
+    out = str(tmp_path / "dp")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["param"], r1["param"])                    # replicas stay bit-identical
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(a, b)
+    grads, param = _run(list(range(FRAMES)))
+    for s, (g2, g1) in enumerate(zip(r0["grads"], grads)):
+        g1 = g1.cpu()
+        assert torch.allclose(g2, g1, rtol=2e-4, atol=2e-6 * float(g1.abs().max())), f"step {s}"
+    # Adam normalises every element's step to ~lr whatever the gradient's size: where the gradient is rounding noise its
+    # SIGN may differ between the two summation orders, so single elements differ by up to 2 lr per step -- but almost
+    # all parameters agree closely
+    d = (r0["param"] - param.cpu()).abs()
+    assert float(d.max()) <= 2.1 * 1e-3 * 2
+    assert float(d.median()) < 1e-6 and float((d > 1e-5).float().mean()) < 0.02
+    assert float(g1.abs().max()) > 0
