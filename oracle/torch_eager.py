@@ -12,6 +12,7 @@ backward is autograd's.  It is checked against the C oracle in tests/test_oracle
 from __future__ import annotations
 
 import math
+import time
 
 import numpy as np
 import torch
@@ -82,11 +83,12 @@ def tile_lists(u, v, d, radius, W, H):
     return gid, start, end, gx, gy
 
 
-def composite(u, v, conic, opacity, feat, gid, start, end, gx, gy, W, H, bg, dL_dout=None, group=48):
+def composite(u, v, conic, opacity, feat, gid, start, end, gx, gy, W, H, bg, dL_dout=None, group=48, deadline=None, stats=None):
     """alpha_blending.cu:32-109, vectorised: per group of tiles (lists padded to the group's longest), pixel x entry
     matrices, transmittance by cumulative product, the T < 1e-4 stop as a mask (T is monotone).  With ``dL_dout`` the
     group's share of sum(image * dL_dout) is back-propagated right away (the inputs' .grad accumulate), so that only one
-    group's intermediates are alive at a time."""
+    group's intermediates are alive at a time.  ``deadline`` (time.perf_counter() value): stop after the group that
+    crosses it (bounded CPU-baseline sample); ``stats["done"]`` = fraction of the tile-list entries composited."""
     C = feat.shape[1]
     out = torch.zeros(C, H, W)
     lens = end - start
@@ -99,11 +101,15 @@ def composite(u, v, conic, opacity, feat, gid, start, end, gx, gy, W, H, bg, dL_
     if dL_dout is not None:
         gpad = torch.zeros(C, gy * 16, gx * 16)
         gpad[:, :H, :W] = dL_dout
+    total, done = float(max(int(lens.sum()), 1)), 0
     for g0 in range(0, order.size, group):
+        if deadline is not None and time.perf_counter() > deadline:
+            break
         tiles = order[g0:g0 + group]
         Lmax = int(lens[tiles].max())
         if Lmax == 0:
             break
+        done += int(lens[tiles].sum())
         nt = tiles.size
         idx = torch.zeros(nt, Lmax, dtype=torch.int64)
         valid = torch.zeros(nt, Lmax, dtype=torch.bool)
@@ -134,6 +140,8 @@ def composite(u, v, conic, opacity, feat, gid, start, end, gx, gy, W, H, bg, dL_
             x0, y0 = (int(t) % gx) * 16, (int(t) // gx) * 16
             hh, ww = min(16, H - y0), min(16, W - x0)
             out[:, y0:y0 + hh, x0:x0 + ww] = img[k].reshape(16, 16, C)[:hh, :ww].permute(2, 0, 1)
+    if stats is not None:
+        stats["done"] = done / total
     # tiles without pairs keep the background
     for t in np.nonzero(lens == 0)[0]:
         x0, y0 = (int(t) % gx) * 16, (int(t) // gx) * 16
@@ -141,11 +149,13 @@ def composite(u, v, conic, opacity, feat, gid, start, end, gx, gy, W, H, bg, dL_
     return out
 
 
-def frame_forward(sc, f, use_sh=True, dL_dout=None):
+def frame_forward(sc, f, use_sh=True, dL_dout=None, budget_s=None, stats=None):
     """-> (image [C,H,W], dict of parameter tensors, M); with ``dL_dout`` [C,H,W] the parameters' .grad hold the gradient
     of sum(image * dL_dout) afterwards (compositing back-propagated group by group into its per-Gaussian inputs, then
-    one backward through the eager preprocess)"""
+    one backward through the eager preprocess).  ``budget_s``: stop compositing after that many seconds (``stats``
+    receives the fraction of the tile lists done and the seconds spent outside / inside the compositing loop)."""
     rg = dL_dout is not None
+    t0 = time.perf_counter()
     p = {k: torch.tensor(v, requires_grad=rg) for k, v in
          dict(xyz=sc.positions(f), scale=sc.scale, rotate=sc.rotate, opacity=sc.opacity.reshape(-1)).items()}
     if use_sh:
@@ -157,17 +167,29 @@ def frame_forward(sc, f, use_sh=True, dL_dout=None):
     extr = torch.tensor(sc.extr)
     u, v, d, conic, radius, vis = preprocess(p["xyz"], p["scale"], p["rotate"], extr, sc.W, sc.H)
     gid, start, end, gx, gy = tile_lists(u, v, d, radius, sc.W, sc.H)
+    t1 = time.perf_counter()
+    st = {} if stats is None else stats
+    deadline = None if budget_s is None else t1 + budget_s
     if not rg:
         with torch.no_grad():
-            img = composite(u, v, conic, p["opacity"], feat, gid, start, end, gx, gy, sc.W, sc.H, sc.bg)
+            img = composite(u, v, conic, p["opacity"], feat, gid, start, end, gx, gy, sc.W, sc.H, sc.bg, deadline=deadline, stats=st)
         return img, p, int(gid.size)
     mids = [u, v, conic, p["opacity"], feat]
     leaf = [m.detach().requires_grad_(True) for m in mids]
-    img = composite(*leaf, gid, start, end, gx, gy, sc.W, sc.H, sc.bg, dL_dout=torch.as_tensor(dL_dout))
+    img = composite(*leaf, gid, start, end, gx, gy, sc.W, sc.H, sc.bg, dL_dout=torch.as_tensor(dL_dout), deadline=deadline, stats=st)
+    t2 = time.perf_counter()
     grads = [l.grad if l.grad is not None else torch.zeros_like(l) for l in leaf]
     torch.autograd.backward([m for m in mids if m.requires_grad], [g for m, g in zip(mids, grads) if m.requires_grad])
+    t3 = time.perf_counter()
+    st["outside_s"] = (t1 - t0) + (t3 - t2)
+    st["composite_s"] = t2 - t1
     return img, p, int(gid.size)
 
 
-def frame_forward_backward(sc, f, g, use_sh=True) -> int:
-    return frame_forward(sc, f, use_sh, dL_dout=g)[2]
+def frame_forward_backward(sc, f, g, use_sh=True, budget_s=None) -> dict:
+    """one frame forward + backward; -> {"M", "seconds" (extrapolated to the whole frame when the compositing loop was
+    cut at ``budget_s``), "fraction" (of the tile-list entries actually composited)}"""
+    st = {}
+    M = frame_forward(sc, f, use_sh, dL_dout=g, budget_s=budget_s, stats=st)[2]
+    frac = max(st.get("done", 1.0), 1e-9)
+    return {"M": M, "fraction": frac, "seconds": st["outside_s"] + st["composite_s"] / frac}

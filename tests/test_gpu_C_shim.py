@@ -82,7 +82,7 @@ def test_shim_sh_and_blend_variants(gpu, oracle_mod):
     assert_grad(dshs, dshs_r, "dshs")
     assert_grad(ddirs, ddirs_r, "ddirs")
     free = _C.compute_sh_free_forward(_t(sc.shs), 3, _t(dirs), vis)
-    free_r = o.compute_sh_forward(sc.shs, 3, dirs, free=True)[0]
+    free_r = o.compute_sh_forward(sc.shs, 3, dirs, free=True)
     np.testing.assert_allclose(free.cpu().numpy(), free_r, rtol=1e-5, atol=1e-6)
     dshs_f, _ = _C.compute_sh_free_backward(_t(sc.shs), 3, _t(dirs), vis, _t(gcol))
     assert_grad(dshs_f, o.compute_sh_backward(sc.shs, 3, dirs, None, None, gcol, free=True)[0], "dshs free")
