@@ -1046,14 +1046,6 @@ __device__ __forceinline__ void row_shr1_add4(float (&R)[4], const float (&rs)[4
         : "v"(rs[0]), "v"(rs[1]), "v"(rs[2]), "v"(rs[3]), "v"(base[0]), "v"(base[1]), "v"(base[2]), "v"(base[3]));
 }
 
-// Pixel numbering of a wave's 8x8 block in this kernel: quarter-major, p = 16 q + m with q = qx + 2 qy one of the four 4x4
-// quarters and m = 4 ry + rx inside it -- a quarter is exactly the M = 16 rows of one MFMA.  The survivors of the
-// cooperative cull carry one bit per quarter (bounding-box test of the quarter's pixel centres); every quarter walks
-// its OWN order-preserving list in chunks of 16 splats, so a splat is replayed only on the quarters it can reach
-// (about half of the (pixel, splat) evaluations of one list per 8x8 block, and half the chunk tails).
-__device__ __forceinline__ int qpix_x(int p) { return 4 * ((p >> 4) & 1) + (p & 3); }
-__device__ __forceinline__ int qpix_y(int p) { return 4 * (p >> 5) + ((p >> 2) & 3); }
-
 template <int CH, bool ABS, bool EXACT>
 __global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_MFMA_MINW : 1))
 blend_bwd_mfma_kernel(const BlendArgs B) {
@@ -1061,11 +1053,10 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     constexpr int SB = Cfg::SB, NG = Cfg::NG, NC = Cfg::NC, NCP = Cfg::NCP, PW = Cfg::PW, NA = Cfg::NA, NK = Cfg::NK;
     constexpr int PZ = Cfg::PZ, PS = Cfg::PS;
     constexpr int I_ABS = GradLayout<ABS, false>::I_ABS;
-    static_assert(SB <= 254, "list entries are bytes");
     __shared__ TileLDS<CH, SB> L;
     __shared__ float s_acc[4][SB * NC];      // private slab per wave
     __shared__ __attribute__((aligned(16))) float s_pix[4][64 * PW];
-    __shared__ float s_mom[16 * 64];         // A operand of the moment product: [step 4 q + i][lane]
+    __shared__ float s_mom[16 * 64];         // A operand of the moment product: [step 4 G + i][lane]
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int gtile = xcd_tile(blockIdx.x, gridDim.x);
@@ -1080,12 +1071,12 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     const int cn = EXACT ? CH : A.cn;
     const int nl = lane & 15, kk = lane >> 4;
     int wmax;
-    // ---- operand tables (block-centred pixel coordinates x, y in [-3.5, 3.5])
+    // ---- operand tables (block-centred pixel coordinates x, y in [-3.5, 3.5]; pixel q = 8 row + column)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int st = 4 * w + r, qs = st >> 2, is = st & 3;  // step = (quarter, sub-step)
-        const int pq = 16 * qs + 4 * kk + is;                 // the pixel lane-group kk handles in this step
-        const float x = (float)qpix_x(pq) - 3.5f, y = (float)qpix_y(pq) - 3.5f;
+        const int st = 4 * w + r, Gs = st >> 2, is = st & 3;  // step = (strip, sub-step)
+        const int q = 16 * Gs + 4 * kk + is;                 // the pixel lane-group kk handles in this step
+        const float x = (float)(q & 7) - 3.5f, y = (float)(q >> 3) - 3.5f;
         // rows 0-3: 1 x y xx | rows 4-7: 1 x y xy | rows 8-11: 1 y yy 0 | rows 12-15: 0
         const int grp = nl >> 2, i = nl & 3;
         float v = 0.f;
@@ -1094,20 +1085,19 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         if (grp == 2) v = i == 0 ? 1.f : i == 1 ? y : i == 2 ? y * y : 0.f;
         s_mom[64 * st + lane] = v;
     }
-    // A operand of the power product, A[m = pixel nl of quarter q][k = kk]: monomials 1 x y xx | xy yy 0 0 of the pixel's
+    // A operand of the power product, A[m = pixel nl of strip G][k = kk]: monomials 1 x y xx | xy yy 0 0 of the pixel's
     // position relative to the TILE centre -- with the coefficients of power_coeffs() the two MFMAs below are the fma
     // chain power_poly() runs in the forward kernel, bit for bit
     float phi1[4], phi2[4];
 #pragma unroll
-    for (int qs = 0; qs < 4; ++qs) {
-        const int pq = 16 * qs + nl;
-        const float x = (float)qpix_x(pq) + ox, y = (float)qpix_y(pq) + oy;
-        phi1[qs] = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
-        phi2[qs] = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
+    for (int Gs = 0; Gs < 4; ++Gs) {
+        const int q = 16 * Gs + nl;
+        const float x = (float)(q & 7) + ox, y = (float)(q >> 3) + oy;
+        phi1[Gs] = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
+        phi2[Gs] = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
     }
-    const int mypx = bx + qpix_x(lane), mypy = by + qpix_y(lane);  // lane p <-> pixel p of the block (quarter-major)
-    {   // per-pixel constants
-        const int px = mypx, py = mypy;
+    {   // per-pixel constants: lane q <-> pixel (q & 7, q >> 3) of the wave's block
+        const int px = bx + (lane & 7), py = by + (lane >> 3);
         const size_t HW = (size_t)A.H * A.W;
         const bool inside = (px < A.W) && (py < A.H);
         const size_t pix = (size_t)A.W * (size_t)py + px;
@@ -1142,20 +1132,24 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         for (int ql = n + ce; ql < len; ql += EPI)  // entries nobody replays: zero record
             pair_buf[(size_t)slots[ql] * NCP + cc] = 0.f;
     if (n <= 0) {
-        if (A.dbg_T_front && mypx < A.W && mypy < A.H) A.dbg_T_front[(size_t)A.W * mypy + mypx] = s_pix[w][lane * PW + PS + 2];
+        if (A.dbg_T_front) {
+            const int px = bx + (lane & 7), py = by + (lane >> 3);
+            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_pix[w][lane * PW + PS + 2];
+        }
         return;
     }
 
-    // ---- per-lane addressing: pixel (q, kk, i) is p = 16 q + 4 kk + i
-    float *pixrow = s_pix[w] + 4 * kk * PW;        // own pixel of step (q, i): pixrow + (16 q + i) * PW
-    const float *pixcol = s_pix[w] + nl * PW;      // pixel nl of quarter q (cg product, A operand): pixcol + 16 q * PW
-    const float *momrow = s_mom + lane;            // + 64 * (4 q + i)
+    // ---- per-lane addressing: pixel (G, kk, i) is q = 16 G + 4 kk + i
+    float *pixrow = s_pix[w] + 4 * kk * PW;        // own pixel of step (G, i): pixrow + (16 G + i) * PW
+    const float *pixcol = s_pix[w] + nl * PW;      // pixel nl of strip G (cg product, A operand): pixcol + 16 G * PW
+    const float *momrow = s_mom + lane;            // + 64 * (4 G + i)
     int gch[NA], kch[NK];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) gch[a] = 16 * a + nl < CH ? 16 * a + nl : PZ;  // channel row of the feature product
+    for (int q = 0; q < NA; ++q) gch[q] = 16 * q + nl < CH ? 16 * q + nl : PZ;  // channel row of the feature product
 #pragma unroll
     for (int j = 0; j < NK; ++j) kch[j] = 4 * j + kk < CH ? 4 * j + kk : PZ;    // K index of the cg product
     const float a_one = nl == 0 ? 1.f : 0.f;
+    const float xk = (float)(4 * (kk & 1)) - 3.5f, yk = (float)(kk >> 1) - 3.5f;  // own pixel: x = xk + i, y = yk + 2 G
 
     // reverse walk: entry e of super-batch b sits at list position n-1 - b*SB - e
     auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };  // negative = past the front
@@ -1172,148 +1166,126 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
 
-        tile_cull<CH, SB, false, true, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
-                                [&](int e, int ww) { return top - e < s_wmax[ww]; });
+        tile_cull<CH, SB, false, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+                                 [&](int e, int ww) { return top - e < s_wmax[ww]; });
         __syncthreads();
+        const int cnt = build_list(L, w, lane);  // every survivor gets a slab record: keep flags = written flags
         float *slab = s_acc[w];
-        unsigned char *ql = reinterpret_cast<unsigned char *>(L.list[w]);  // the wave's survivor list of the quarter in flight
+        for (int j0 = 0; j0 < cnt; j0 += 16) {
+            const int e = L.list[w][j0 + nl];  // ascending e = back to front; slot SB (inert) past the end
+            const float4 g0 = L.g0(e), g1 = L.g1(e);
+            const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
+            const float uc = g0.x - bx0 - 3.5f, vc = g0.y - by0 - 3.5f;  // centre in block-centred pixel coordinates
+            const int qn = top - e;  // list position of this survivor (negative for the inert slot: harmless, alpha = 0)
+            // B operands: this lane's K-slice of the splat's power coefficients (x log2 e) and features
+            float bq1, bq2, bf[NK];
+            {
+                const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, tcx, tcy);
+                bq1 = kk == 0 ? pc.q0 : kk == 1 ? pc.qx : kk == 2 ? pc.qy : pc.qxx;
+                bq2 = kk == 0 ? pc.qxy : kk == 1 ? pc.qyy : 0.f;
+                const float *fr = reinterpret_cast<const float *>(&L.rec[e * Rec<CH>::RQ + 2]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            // ---- this quarter's survivor list (ascending e = back to front), padded with the inert entry
-            int cnt = 0;
-#pragma unroll
-            for (int r = 0; r < SB / WAVE; ++r) {
-                const int e = r * WAVE + lane;
-                const bool keep = (L.keep[e] >> (8 * w + q)) & 1u;
-                const unsigned long long m = __ballot(keep);
-                const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (keep) ql[cnt + before] = (unsigned char)e;
-                cnt += __popcll(m);
+                for (int j = 0; j < NK; ++j) bf[j] = fr[4 * j + kk];  // padded with zeros past CH (pack_kernel)
             }
-            if (lane < 16) ql[cnt + lane] = (unsigned char)SB;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const float xq = (float)(4 * (q & 1)) - 3.5f, yq = (float)(4 * (q >> 1) + kk) - 3.5f;  // own pixels: x = xq + i, y = yq
-            for (int j0 = 0; j0 < cnt; j0 += 16) {
-                const int e = ql[j0 + nl];  // slot SB (inert) past the end
-                const float4 g0 = L.g0(e), g1 = L.g1(e);
-                const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
-                const float uc = g0.x - bx0 - 3.5f, vc = g0.y - by0 - 3.5f;  // centre in block-centred pixel coordinates
-                const int qn = top - e;  // list position of this survivor (negative for the inert slot: harmless, alpha = 0)
-                // B operands: this lane's K-slice of the splat's power coefficients (x log2 e) and features
-                float bq1, bq2, bf[NK];
-                {
-                    const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, tcx, tcy);
-                    bq1 = kk == 0 ? pc.q0 : kk == 1 ? pc.qx : kk == 2 ? pc.qy : pc.qxx;
-                    bq2 = kk == 0 ? pc.qxy : kk == 1 ? pc.qyy : 0.f;
-                    const float *fr = reinterpret_cast<const float *>(&L.rec[e * Rec<CH>::RQ + 2]);
+            f32x4 d_mom = {0.f, 0.f, 0.f, 0.f}, d_ax = {0.f, 0.f, 0.f, 0.f}, d_ay = {0.f, 0.f, 0.f, 0.f};
+            f32x4 d_f[NA];
 #pragma unroll
-                    for (int j = 0; j < NK; ++j) bf[j] = fr[4 * j + kk];  // padded with zeros past CH (pack_kernel)
+            for (int a = 0; a < NA; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" ::: "memory");  // keep the per-pixel LDS reads inside the chunk (registers, not hoisted copies)
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {  // strip G: four independent sub-steps, their DPP scans interleave
+                f32x4 pw = {0.f, 0.f, 0.f, 0.f}, cgv = {0.f, 0.f, 0.f, 0.f};
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bq1, pw, 0, 0, 0);
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi2[G], bq2, pw, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NK; ++j)
+                    cgv = __builtin_amdgcn_mfma_f32_16x16x4f32(pixcol[16 * G * PW + kch[j]], bf[j], cgv, 0, 0, 0);
+                float cg[4], araw[4], a[4], r1a[4], rp[4], Tb[4], Ts4[4], Rs4[4];
+                bool ok[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 stv = *reinterpret_cast<const float4 *>(pixrow + (16 * G + i) * PW + PS);
+                    cg[i] = cgv[i];
+                    Tb[i] = stv.x;
+                    const int last = __float_as_int(stv.y);
+                    Ts4[i] = stv.z;
+                    Rs4[i] = stv.w;
+                    const float Gs = __builtin_amdgcn_exp2f(pw[i]);
+                    araw[i] = o * Gs;
+                    const float alpha = fminf(0.99f, araw[i]);
+                    ok[i] = (qn < last) && !(pw[i] > BLEND_PW_MAX) && !(alpha < (1.0f / 255.0f));
+                    a[i] = ok[i] ? alpha : 0.f;
+                    r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
+                    rp[i] = r1a[i];
                 }
-                f32x4 d_mom = {0.f, 0.f, 0.f, 0.f}, d_ax = {0.f, 0.f, 0.f, 0.f}, d_ay = {0.f, 0.f, 0.f, 0.f};
-                f32x4 d_f[NA];
+                row_scan_mul4(rp[0], rp[1], rp[2], rp[3]);
+                float T[4], wgt[4], rs[4], R[4];
 #pragma unroll
-                for (int a = 0; a < NA; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-                asm volatile("" ::: "memory");  // keep the per-pixel LDS reads inside the chunk (registers, not hoisted copies)
-                {
-                    f32x4 pw = {0.f, 0.f, 0.f, 0.f}, cgv = {0.f, 0.f, 0.f, 0.f};
-                    pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[q], bq1, pw, 0, 0, 0);
-                    pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi2[q], bq2, pw, 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < NK; ++j)
-                        cgv = __builtin_amdgcn_mfma_f32_16x16x4f32(pixcol[16 * q * PW + kch[j]], bf[j], cgv, 0, 0, 0);
-                    float cg[4], araw[4], a[4], r1a[4], rp[4], Tb[4], Ts4[4], Rs4[4];
-                    bool ok[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float4 stv = *reinterpret_cast<const float4 *>(pixrow + (16 * q + i) * PW + PS);
-                        cg[i] = cgv[i];
-                        Tb[i] = stv.x;
-                        const int last = __float_as_int(stv.y);
-                        Ts4[i] = stv.z;
-                        Rs4[i] = stv.w;
-                        const float Gs = __builtin_amdgcn_exp2f(pw[i]);
-                        araw[i] = o * Gs;
-                        const float alpha = fminf(0.99f, araw[i]);
-                        ok[i] = (qn < last) && !(pw[i] > BLEND_PW_MAX) && !(alpha < (1.0f / 255.0f));
-                        a[i] = ok[i] ? alpha : 0.f;
-                        r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
-                        rp[i] = r1a[i];
-                    }
-                    row_scan_mul4(rp[0], rp[1], rp[2], rp[3]);
-                    float T[4], wgt[4], rs[4], R[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        T[i] = Ts4[i] * rp[i];  // transmittance in front of this splat
-                        wgt[i] = a[i] * T[i];
-                        rs[i] = cg[i] * wgt[i];
-                    }
-                    row_scan_add4(rs[0], rs[1], rs[2], rs[3]);
-                    row_shr1_add4(R, rs, Rs4);  // R = R_state + colour of the deeper splats of this chunk
-                    // the row's last lane holds the new state of its pixel: store from lanes 15/31/47/63 only, without a
-                    // branch (the chunk stays one basic block)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        lds_store2_lane15(pixrow + (16 * q + i) * PW + PS + 2, T[i], Rs4[i] + rs[i]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int s = 4 * q + i;
-                        const float dLa = T[i] * cg[i] - (R[i] + Tb[i]) * r1a[i];
-                        const float dLp = ok[i] ? araw[i] * dLa : 0.f;  // dL/dpower
-                        d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[64 * s], dLp, d_mom, 0, 0, 0);
-#pragma unroll
-                        for (int c = 0; c < NA; ++c)
-                            d_f[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(pixrow[(16 * q + i) * PW + gch[c]], wgt[i], d_f[c], 0, 0, 0);
-                        if (ABS) {
-                            const float dx = uc - (xq + (float)i), dy = vc - yq;
-                            d_ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cA * dx + cB * dy)), d_ax, 0, 0, 0);
-                            d_ay = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cB * dx + cC * dy)), d_ay, 0, 0, 0);
-                        }
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    T[i] = Ts4[i] * rp[i];  // transmittance in front of this splat
+                    wgt[i] = a[i] * T[i];
+                    rs[i] = cg[i] * wgt[i];
                 }
-                // ---- chunk epilogue: lane (n, kk) holds rows 4kk..4kk+3 of every accumulator for survivor n; the
-                //      record of a splat collects its quarters: the first quarter it reaches stores, the others add
-                if (j0 + nl < cnt) {
-                    float *rec = slab + e * NC;
-                    const bool first = (((L.keep[e] >> (8 * w)) & 0xfu) & ((1u << q) - 1u)) == 0u;
-                    auto put = [first](float *p, float v) { *p = first ? v : *p + v; };
-                    const float D0 = d_mom[0];
-                    if (kk == 0) {
-                        const float Dx = d_mom[1], Dy = d_mom[2], Dxx = d_mom[3];
-                        put(rec + 0, cA * Dx + cB * Dy - (cA * uc + cB * vc) * D0);
-                        put(rec + 1, cB * Dx + cC * Dy - (cB * uc + cC * vc) * D0);
-                        put(rec + 2, -0.5f * (uc * uc * D0 - 2.f * uc * Dx + Dxx));
-                        put(rec + 5, o > 0.f ? D0 / o : 0.f);
-                        if (ABS) {
-                            put(rec + I_ABS, d_ax[0]);
-                            put(rec + I_ABS + 1, d_ay[0]);
-                        }
-                    } else if (kk == 1) {
-                        const float Dx = d_mom[1], Dy = d_mom[2], Dxy = d_mom[3];
-                        put(rec + 3, -(uc * vc * D0 - uc * Dy - vc * Dx + Dxy));
-                    } else if (kk == 2) {
-                        const float Dy = d_mom[1], Dyy = d_mom[2];
-                        put(rec + 4, -0.5f * (vc * vc * D0 - 2.f * vc * Dy + Dyy));
+                row_scan_add4(rs[0], rs[1], rs[2], rs[3]);
+                row_shr1_add4(R, rs, Rs4);  // R = R_state + colour of the deeper splats of this chunk
+                // the row's last lane holds the new state of its pixel: store from lanes 15/31/47/63 only, without a
+                // branch (the chunk stays one basic block, so the four strips' instruction streams interleave)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    lds_store2_lane15(pixrow + (16 * G + i) * PW + PS + 2, T[i], Rs4[i] + rs[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int s = 4 * G + i;
+                    const float dLa = T[i] * cg[i] - (R[i] + Tb[i]) * r1a[i];
+                    const float dLp = ok[i] ? araw[i] * dLa : 0.f;  // dL/dpower
+                    d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[64 * s], dLp, d_mom, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NA; ++q)
+                        d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(pixrow[(16 * G + i) * PW + gch[q]], wgt[i], d_f[q], 0, 0, 0);
+                    if (ABS) {
+                        const float dx = uc - (xk + (float)i), dy = vc - (yk + (float)(2 * G));
+                        d_ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cA * dx + cB * dy)), d_ax, 0, 0, 0);
+                        d_ay = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cB * dx + cC * dy)), d_ay, 0, 0, 0);
                     }
-#pragma unroll
-                    for (int c = 0; c < NA; ++c)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int ch = 16 * c + 4 * kk + i;
-                            if (ch < CH) put(rec + NG + ch, d_f[c][i]);
-                        }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next quarter rewrites the list
-            __builtin_amdgcn_wave_barrier();
+            // ---- chunk epilogue: lane (n, kk) holds rows 4kk..4kk+3 of every accumulator for survivor n
+            if (j0 + nl < cnt) {
+                float *rec = slab + e * NC;
+                const float D0 = d_mom[0];
+                if (kk == 0) {
+                    const float Dx = d_mom[1], Dy = d_mom[2], Dxx = d_mom[3];
+                    rec[0] = cA * Dx + cB * Dy - (cA * uc + cB * vc) * D0;
+                    rec[1] = cB * Dx + cC * Dy - (cB * uc + cC * vc) * D0;
+                    rec[2] = -0.5f * (uc * uc * D0 - 2.f * uc * Dx + Dxx);
+                    rec[5] = o > 0.f ? D0 / o : 0.f;
+                    if (ABS) {
+                        rec[I_ABS] = d_ax[0];
+                        rec[I_ABS + 1] = d_ay[0];
+                    }
+                } else if (kk == 1) {
+                    const float Dx = d_mom[1], Dy = d_mom[2], Dxy = d_mom[3];
+                    rec[3] = -(uc * vc * D0 - uc * Dy - vc * Dx + Dxy);
+                } else if (kk == 2) {
+                    const float Dy = d_mom[1], Dyy = d_mom[2];
+                    rec[4] = -0.5f * (vc * vc * D0 - 2.f * vc * Dy + Dyy);
+                }
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = 16 * q + 4 * kk + i;
+                        if (c < CH) rec[NG + c] = d_f[q][i];
+                    }
+            }
         }
         __syncthreads();
         // ---- combine the four slabs: thread (ce, cc) sums component cc of every EPI-th entry and stores it at the
         //      entry's pair slot (the NCP - NC pad floats of a record are never written; pair_reduce ignores them)
         if (ce < EPI) {
             const int lo = top - nb + 1;
-            for (int qlp = ce; qlp < nb; qlp += EPI) {
-                const int e = nb - 1 - qlp;
+            for (int ql = ce; ql < nb; ql += EPI) {
+                const int e = nb - 1 - ql;
                 const unsigned int fl = L.keep[e];
                 float v = 0.f;
 #pragma unroll
@@ -1321,13 +1293,15 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                     const float x = s_acc[ww][e * NC + cc];
                     v += ((fl >> (8 * ww)) & 0xffu) ? x : 0.f;
                 }
-                pair_buf[(size_t)slots[lo + qlp] * NCP + cc] = v;
+                pair_buf[(size_t)slots[lo + ql] * NCP + cc] = v;
             }
         }
         __syncthreads();
     }
-    if (A.dbg_T_front && mypx < A.W && mypy < A.H)  // per-pixel transmittance after the last (front-most) replayed splat
-        A.dbg_T_front[(size_t)A.W * mypy + mypx] = s_pix[w][lane * PW + PS + 2];
+    if (A.dbg_T_front) {  // per-pixel transmittance after the last (front-most) replayed splat: lane q <-> pixel q of the block
+        const int px = bx + (lane & 7), py = by + (lane >> 3);
+        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_pix[w][lane * PW + PS + 2];
+    }
 }
 
 // ------------------------------------------------------------------ backward, atomic mode (foreign idx_sorted)

@@ -150,6 +150,8 @@ def main():
         np.array([[1, 0, 0], [0, np.cos(0.2), -np.sin(0.2)], [0, np.sin(0.2), np.cos(0.2)]], np.float32)
     E[:3, 3] = np.array([0.05, -0.1, 0.3], np.float32)
     make_case(ortho_mod, sh_mod, "ortho_1k5_100x60_rot", 1500, 100, 60, 13, extr=E)  # rotated camera, ragged W and H
+    # BASELINE configs[0] size: 10k static Gaussians, one 256x256 frame (the bench generator's seed)
+    make_case(ortho_mod, sh_mod, "ortho_c1_10k_256x256", 10000, 256, 256, 1234)
 
 
 if __name__ == "__main__":

@@ -56,3 +56,35 @@ def test_hip_matches_reference_twins(gpu, path):
         np.testing.assert_allclose(c.cpu().numpy(), g[f"sh_deg{deg}"], rtol=1e-5, atol=2e-6)
         c2 = gs.compute_sh(shs, deg, dev(g["dirs"], gpu))
         np.testing.assert_allclose(c2.cpu().numpy(), np.maximum(g[f"sh_deg{deg}"] + 0.5, 0), rtol=1e-5, atol=2e-6)
+
+
+def test_c1_compositing_on_reference_geometry(gpu, oracle_mod):
+    """BASELINE configs[0] (10k Gaussians, one 256x256 frame): screen-space geometry PRODUCED BY THE REFERENCE's own torch
+    functions (golden uv / depth / conic / radius / tiles) sorted and composited forward + backward on the GPU, against
+    the oracle's restatement of the CUDA sort / blend on the same reference geometry."""
+    import dptr.gs as gs
+    from test_gpu_parity import assert_grad
+    o = oracle_mod
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ortho_c1_10k_256x256.npz")))
+    W, H, N = int(g["W"]), int(g["H"]), g["xyz"].shape[0]
+    rng = np.random.default_rng(7)
+    opacity = (1.0 / (1.0 + np.exp(-rng.normal(0.0, 1.5, size=(N, 1))))).astype(np.float32)
+    rgb = np.maximum(g["sh_deg3"] + 0.5, 0).astype(np.float32)            # the reference's eval_sh colours (+0.5, clamp)
+    idx_r, tr_r = o.sort_gaussian(g["uv"], g["depth"], W, H, g["radius"], g["tiles"])
+    out_r, fT_r, nc_r = o.alpha_blending_forward(g["uv"], g["conic"], opacity, rgb, idx_r, tr_r, 0.0, W, H)[:3]
+    t = {k: dev(v, gpu).requires_grad_(True) for k, v in dict(uv=g["uv"], conic=g["conic"], opacity=opacity, rgb=rgb).items()}
+    idx, tr = gs.sort_gaussian(t["uv"].detach(), dev(g["depth"], gpu), W, H, dev(g["radius"], gpu), dev(g["tiles"], gpu))
+    assert (idx.cpu().numpy() == idx_r).all() and (tr.cpu().numpy() == tr_r).all()          # bit-exact sort
+    assert idx.numel() == int(g["tiles"].sum())
+    ndc = torch.zeros(N, 2, device=gpu, requires_grad=True)
+    img = gs.alpha_blending(t["uv"], t["conic"], t["opacity"], t["rgb"], idx, tr, 0.0, W, H, ndc)
+    bad = np.abs(img.detach().cpu().numpy() - out_r) > 1e-5 + 1e-4 * np.abs(out_r)
+    assert bad.mean() < 1e-3
+    gout = rng.normal(size=(3, H, W)).astype(np.float32)
+    (img * dev(gout, gpu)).sum().backward()
+    gr = o.alpha_blending_backward(g["uv"], g["conic"], opacity, rgb, idx_r, tr_r, 0.0, W, H, fT_r, nc_r, gout)
+    assert_grad(t["uv"].grad, gr[0], "dL_duv")
+    assert_grad(t["conic"].grad, gr[1], "dL_dconic")
+    assert_grad(t["opacity"].grad, gr[2], "dL_dopacity")
+    assert_grad(t["rgb"].grad, gr[3], "dL_dfeature")
+    assert_grad(ndc.grad, gr[0] * np.array([[0.5 * W, 0.5 * H]], np.float32), "dL_dndc")
