@@ -1003,6 +1003,12 @@ struct MfmaCfg {
     static constexpr int PW = PS + 4;             // floats per pixel record: g[CH], 0.., state block
     static constexpr int NA = (CH + 15) / 16;     // feature-gradient accumulators (16 channels each)
     static constexpr int NK = (CH + 3) / 4;       // K-slabs of the cg product (4 channels each)
+    // widest records: the four waves add into ONE slab with LDS float atomics (ds_add_f32) instead of owning a private
+    // slab each -- at 32 channels that is 10 KB instead of 39 KB of LDS, two workgroups per CU instead of one (828 ->
+    // 748 us at BASELINE configs[4]); at 16 / 20 channels the atomics cost more than the third workgroup gains
+    // (19-channel blend 750 -> 805 us), so those keep the private slabs
+    static constexpr bool SHARED = CH > 20;
+    static constexpr int NSLAB = SHARED ? 1 : 4;
 };
 
 // four interleaved inclusive row scans (lane 0 first): dependent DPP instructions are 4 issue slots apart; lanes
@@ -1054,7 +1060,8 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     constexpr int PZ = Cfg::PZ, PS = Cfg::PS;
     constexpr int I_ABS = GradLayout<ABS, false>::I_ABS;
     __shared__ TileLDS<CH, SB> L;
-    __shared__ float s_acc[4][SB * NC];      // private slab per wave
+    constexpr bool SHARED = Cfg::SHARED;
+    __shared__ float s_acc[Cfg::NSLAB][SB * NC];  // private slab per wave, or one shared slab (wide records)
     __shared__ __attribute__((aligned(16))) float s_pix[4][64 * PW];
     __shared__ float s_mom[16 * 64];         // A operand of the moment product: [step 4 G + i][lane]
     __shared__ int s_wmax[4];
@@ -1168,9 +1175,11 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
 
         tile_cull<CH, SB, false, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
                                  [&](int e, int ww) { return top - e < s_wmax[ww]; });
+        if (SHARED)
+            for (int i = tid; i < nb * NC; i += 256) s_acc[0][i] = 0.f;
         __syncthreads();
         const int cnt = build_list(L, w, lane);  // every survivor gets a slab record: keep flags = written flags
-        float *slab = s_acc[w];
+        float *slab = s_acc[SHARED ? 0 : w];
         for (int j0 = 0; j0 < cnt; j0 += 16) {
             const int e = L.list[w][j0 + nl];  // ascending e = back to front; slot SB (inert) past the end
             const float4 g0 = L.g0(e), g1 = L.g1(e);
@@ -1252,30 +1261,34 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
             // ---- chunk epilogue: lane (n, kk) holds rows 4kk..4kk+3 of every accumulator for survivor n
             if (j0 + nl < cnt) {
                 float *rec = slab + e * NC;
+                auto put = [](float *p, float v) {
+                    if (SHARED) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f32
+                    else *p = v;
+                };
                 const float D0 = d_mom[0];
                 if (kk == 0) {
                     const float Dx = d_mom[1], Dy = d_mom[2], Dxx = d_mom[3];
-                    rec[0] = cA * Dx + cB * Dy - (cA * uc + cB * vc) * D0;
-                    rec[1] = cB * Dx + cC * Dy - (cB * uc + cC * vc) * D0;
-                    rec[2] = -0.5f * (uc * uc * D0 - 2.f * uc * Dx + Dxx);
-                    rec[5] = o > 0.f ? D0 / o : 0.f;
+                    put(rec + 0, cA * Dx + cB * Dy - (cA * uc + cB * vc) * D0);
+                    put(rec + 1, cB * Dx + cC * Dy - (cB * uc + cC * vc) * D0);
+                    put(rec + 2, -0.5f * (uc * uc * D0 - 2.f * uc * Dx + Dxx));
+                    put(rec + 5, o > 0.f ? D0 / o : 0.f);
                     if (ABS) {
-                        rec[I_ABS] = d_ax[0];
-                        rec[I_ABS + 1] = d_ay[0];
+                        put(rec + I_ABS, d_ax[0]);
+                        put(rec + I_ABS + 1, d_ay[0]);
                     }
                 } else if (kk == 1) {
                     const float Dx = d_mom[1], Dy = d_mom[2], Dxy = d_mom[3];
-                    rec[3] = -(uc * vc * D0 - uc * Dy - vc * Dx + Dxy);
+                    put(rec + 3, -(uc * vc * D0 - uc * Dy - vc * Dx + Dxy));
                 } else if (kk == 2) {
                     const float Dy = d_mom[1], Dyy = d_mom[2];
-                    rec[4] = -0.5f * (vc * vc * D0 - 2.f * vc * Dy + Dyy);
+                    put(rec + 4, -0.5f * (vc * vc * D0 - 2.f * vc * Dy + Dyy));
                 }
 #pragma unroll
                 for (int q = 0; q < NA; ++q)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int c = 16 * q + 4 * kk + i;
-                        if (c < CH) rec[NG + c] = d_f[q][i];
+                        if (c < CH) put(rec + NG + c, d_f[q][i]);
                     }
             }
         }
@@ -1288,10 +1301,14 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                 const int e = nb - 1 - ql;
                 const unsigned int fl = L.keep[e];
                 float v = 0.f;
+                if (SHARED) {
+                    v = s_acc[0][e * NC + cc];
+                } else {
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) {
-                    const float x = s_acc[ww][e * NC + cc];
-                    v += ((fl >> (8 * ww)) & 0xffu) ? x : 0.f;
+                    for (int ww = 0; ww < Cfg::NSLAB; ++ww) {
+                        const float x = s_acc[ww][e * NC + cc];
+                        v += ((fl >> (8 * ww)) & 0xffu) ? x : 0.f;
+                    }
                 }
                 pair_buf[(size_t)slots[lo + ql] * NCP + cc] = v;
             }

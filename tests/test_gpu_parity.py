@@ -418,7 +418,8 @@ def test_full_size_linearity_and_weight_sum(gpu, N, W, H, C):
     total_w = float(oT.double().sum())
     got = float(f1.grad[:, C // 2].double().sum())
     assert abs(got - total_w) < 1e-4 * total_w
-    assert float((f1.grad - f2.grad).abs().max()) == 0.0 or float((f1.grad - f2.grad).abs().max()) < 1e-6
+    # (the 32-channel backward sums its four waves' contributions with LDS float atomics: order-dependent rounding)
+    assert float((f1.grad - f2.grad).abs().max()) <= 1e-5 * float(f1.grad.abs().max())
     assert float(f1.grad[:, :C // 2].abs().max()) == 0.0                          # untouched channels stay 0
 
 
