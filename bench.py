@@ -103,6 +103,10 @@ def parse():
     ap.add_argument("--dynamic", action="store_true",
                     help="parameterise the scene as the reference's dynamic Gaussians and run their per-frame evaluation "
                          "inside the fused preprocess (row a15 on the path; per-frame operators)")
+    ap.add_argument("--render-iter", action="store_true",
+                    help="the reference's real frame (row a1, dptr_ortho_enhanced.py:205-383): rgb through alpha_blending_enhanced "
+                         "(K = 20, ndc + abs_ndc taps), depth (bg = 1) and 19 attribute channels (opacity detached) per frame, "
+                         "through the native OrthoEnhancedRenderer (per-frame operators, shared forward pass)")
     ap.add_argument("--stale-overlap", action="store_true",
                     help="stale-1 mode: double-buffered gradient bucket, the all-reduce of step s overlaps step s+1's frames "
                          "and no optimiser runs (NOT synchronous data parallelism; for comparison only)")
@@ -147,6 +151,8 @@ class FrameRenderer:
             src["shs"] = sc.shs
         else:
             src["feature"] = sc.feature
+        if mode == "render_iter":
+            src["attrs"] = np.random.default_rng(7).uniform(-1, 1, size=(N, 19)).astype(np.float32)
         # stale-1 mode only: two gradient buffers, the all-reduce of step s runs on RCCL's stream while step s+1 fills the other
         self.overlap = bool(stale_overlap) and dist.is_available() and dist.is_initialized()
         self.bucket = FlatGradBucket({k: torch.as_tensor(v, device=device) for k, v in src.items()},
@@ -169,6 +175,11 @@ class FrameRenderer:
             self.offs = self.frames
         else:
             self.offs = [self.offsets(f) for f in self.frames]
+        if self.mode == "render_iter":
+            from splatter_a_video_amd.renderer import OrthoEnhancedRenderer
+            self.renderer = OrthoEnhancedRenderer(densify_abs_grad_enable=True)
+            self.dL_depth = torch.randn(1, self.H, self.W, generator=g).to(device)
+            self.dL_attr = torch.randn(19, self.H, self.W, generator=g).to(device)
         if self.mode == "batch":
             if self.C > 32:
                 raise SystemExit("the frame batch composites at most 32 channels per call")
@@ -196,6 +207,21 @@ class FrameRenderer:
                                 bg=self.sc.bg, nearest=0.01, grad_sink=sink)
         out.backward(self.dL_all)
         self.last = dict(M=self.last.get("M", 0), T=self.batch.T)
+
+    # ------------------------------------------------------------------ the reference's real frame (row a1)
+    def frames_render_iter(self):
+        p = self.p
+        rgb = self.renderer.colors(p["shs"])          # once per batch: the view direction is constant (render_batch)
+        rgb_in = rgb.detach().requires_grad_(True)    # the frames' colour gradients are summed before the one SH backward
+        for off in self.offs:
+            r = self.renderer.render_iter(self.H, self.W, self.extr, p["xyz"] + off, p["opacity"], p["scale"], p["rotate"], None,
+                                          num_idx=20, rgb=rgb_in,
+                                          render_attributes={"mask_attribute": p["attrs"][:, :1], "dino_attribute": p["attrs"][:, 1:]})
+            f = r["rendered_features_split"]
+            torch.autograd.backward([f["rgb"], f["depth"], f["mask_attribute"], f["dino_attribute"]],
+                                    [self.dL_dout, self.dL_depth, self.dL_attr[:1], self.dL_attr[1:]])
+        rgb.backward(rgb_in.grad)
+        self.last = dict(M=self.last.get("M", 0), T=((self.W + 15) // 16) * ((self.H + 15) // 16))
 
     # ------------------------------------------------------------------ one frame (round-1 paths)
     def frame(self, off):
@@ -250,6 +276,8 @@ class FrameRenderer:
         self.bucket.zero_grad()
         if self.mode == "batch":
             self.frames_batched()
+        elif self.mode == "render_iter":
+            self.frames_render_iter()
         else:
             for off in self.offs:
                 self.frame(off)
@@ -387,7 +415,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    mode = "ops" if a.ops else "frame" if (a.per_frame or a.dynamic) else "batch"
+    mode = "render_iter" if a.render_iter else "ops" if a.ops else "frame" if (a.per_frame or a.dynamic) else "batch"
     clip = max(a.clip, 25 * world)
     sc = make_scene(a.gaussians, a.width, a.height, F=clip, C=a.channels, seed=1234)
     # rank r renders frames {f : f mod world == r} of the step's frame batch
@@ -489,7 +517,7 @@ def main():
                                               "synchronous: all-reduce -> Adam -> next forward" if R.opt is not None else
                                               "synchronous all-reduce, no optimiser")
         line = {
-            "metric": "rendered frames/sec fwd+bwd @480p, 300k Gaussians",
+            "metric": "rendered frames/sec fwd+bwd @480p, 300k Gaussians" + (" (render_iter: three blends, 23 channels)" if mode == "render_iter" else ""),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -500,6 +528,8 @@ def main():
                        "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
                        "tile_pairs_M": M, "channels": R.C, "parallelism": par,
                        "path": ("dynamic-Gaussian evaluation fused into the per-frame preprocess + gradient sinks" if R.dynamic else
+                                "render_iter of the reference's renderer (rgb enhanced K=20 + depth + 19 attribute channels per "
+                                "frame), native OrthoEnhancedRenderer, per-frame operators" if mode == "render_iter" else
                                 "frame batch: the frame is a grid dimension of every kernel; SH and the Gaussian-side backward once per step"
                                 if mode == "batch" else
                                 "fused per-frame operators + gradient sinks" if mode == "frame" else "per-operator autograd chain"),

@@ -253,6 +253,21 @@ int splat_compact_scan(int P, const uint8_t *mask, int32_t *index, int32_t *coun
                        splat_stream_t stream);
 int splat_compact_rows(int P, const uint8_t *mask, const int32_t *index, int row_words, const void *src, void *dst,
                        splat_stream_t stream);
+/* ---- clone / split on the device (reference: atlas_gs_optimizer.py:255-349 new_pos_scale /
+ *      densify_clone / densify_split, points.py:225-395 extend / remove with the optimiser state).  With the prefix of a
+ *      selection mask (splat_compact_scan: index, n_sel) every per-Gaussian tensor -- parameters and Adam moments alike --
+ *      is extended by the same gather: dst row (r * n_sel + index[i]) = src row i, r < repeat (torch's
+ *      x[mask].repeat(r, 1, ..)); dst = the append area behind the existing rows. ---- */
+int splat_gather_rows_repeat(int P, const uint8_t *mask, const int32_t *index, int n_sel, int repeat, int row_words,
+                             const void *src, void *dst, splat_stream_t stream);
+/* positions and (log) scales of the split_num children of every selected Gaussian: R(rotation) (z * scale) + position,
+ * log(scale / (0.8 split_num)).  z: unit normals from Philox-4x32-10 keyed by `seed` with counter (Gaussian id, replica):
+ * no generator state, so all data-parallel ranks draw identical children; or, for parity tests, caller-supplied
+ * unit_normals [split_num * n_sel, 3] in output-row order. */
+int splat_densify_split_sample(int P, const uint8_t *mask, const int32_t *index, int n_sel, int split_num, uint64_t seed,
+                               const float *position, const float *scaling_raw, const float *rotation_raw,
+                               const float *unit_normals, float *new_pos, float *new_scaling, splat_stream_t stream);
+
 
 /* ---- exact K nearest neighbours on a uniform grid ---------------------------------------------
  * Replaces pytorch3d.ops.knn_points(points[None], points[None], K=K+1) of src/geometry_utils.py:17-19 (un-vendored CUDA

@@ -445,3 +445,45 @@ def knn_points(query, points, K):
     d = np.zeros((q.shape[0], K), np.float32); i = np.zeros((q.shape[0], K), np.int32)
     lib().oracle_knn_points(q.shape[0], _p(q, _f32p), p.shape[0], _p(p, _f32p), int(K), _p(d, _f32p), _p(i, _i32p))
     return d, i
+
+
+# ------------------------------------------------------------------ structure surgery of densification (numpy restatement)
+def _quat_R_np(q):
+    q = q / np.sqrt((q * q).sum(1, keepdims=True))
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.zeros((q.shape[0], 3, 3), np.float32)
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - r * z); R[:, 0, 2] = 2 * (x * z + r * y)
+    R[:, 1, 0] = 2 * (x * y + r * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - r * x)
+    R[:, 2, 0] = 2 * (x * z - r * y); R[:, 2, 1] = 2 * (y * z + r * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def structure_clone(params, moments, mask):
+    """densify_clone (reference: src/pointrix/optimizer/atlas_gs_optimizer.py:289-304; extend_optimizer
+    src/pointrix/point_cloud/points.py:332-375): selected rows appended, their Adam moments zero"""
+    m = np.asarray(mask, bool)
+    p = {k: np.concatenate([v, v[m]]) for k, v in params.items()}
+    mo = {k: tuple(np.concatenate([x, np.zeros_like(x[m])]) for x in mv) for k, mv in moments.items()}
+    return p, mo
+
+
+def structure_split(params, moments, mask, split_num, unit_normals):
+    """densify_split + new_pos_scale (atlas_gs_optimizer.py:255-287,306-349; prune_optimizer points.py:279-330) with the
+    normal draws given: children appended (sampled position, log(scale / (0.8 split_num)), other attributes repeated, zero
+    moments), parents removed"""
+    m = np.asarray(mask, bool)
+    n = int(m.sum())
+    scl = np.exp(params["scaling"][m]).astype(np.float32)
+    stds = np.tile(scl, (split_num, 1))
+    samples = (np.asarray(unit_normals, np.float32) * stds).astype(np.float32)
+    R = np.tile(_quat_R_np(params["rotation"][m].astype(np.float32)), (split_num, 1, 1))
+    new_pos = np.einsum("nij,nj->ni", R, samples).astype(np.float32) + np.tile(params["position"][m], (split_num, 1))
+    new_scl = np.log(stds / np.float32(0.8 * split_num)).astype(np.float32)
+    valid = np.concatenate([~m, np.ones(split_num * n, bool)])
+    p, mo = {}, {}
+    for k, v in params.items():
+        tail = new_pos if k == "position" else new_scl if k == "scaling" else np.tile(v[m], (split_num,) + (1,) * (v.ndim - 1))
+        p[k] = np.concatenate([v, tail.astype(v.dtype)])[valid]
+    for k, mv in moments.items():
+        mo[k] = tuple(np.concatenate([x, np.zeros((split_num * n,) + x.shape[1:], x.dtype)])[valid] for x in mv)
+    return p, mo, new_pos, new_scl

@@ -136,7 +136,104 @@ compact_rows_kernel(size_t total_words, int row_words, const unsigned char *__re
     dst[(size_t)index[i] * row_words + w] = src[e];
 }
 
+// ---- structure surgery: selected rows appended `repeat` times (clone: 1, split: split_num) behind the existing rows
+// dst row (r * n_sel + index[i]) = src row i for every selected i (the order of torch's x[mask].repeat(r, 1, ...))
+__global__ void __launch_bounds__(DB)
+gather_rows_repeat_kernel(size_t total_words, int row_words, const unsigned char *__restrict__ mask,
+                          const int *__restrict__ index, int n_sel, int repeat, const unsigned int *__restrict__ src,
+                          unsigned int *__restrict__ dst) {
+    const size_t e = (size_t)blockIdx.x * DB + threadIdx.x;
+    if (e >= total_words) return;
+    const size_t i = e / (size_t)row_words;
+    if (!mask[i]) return;
+    const size_t w = e - i * (size_t)row_words;
+    const unsigned int v = src[e];
+    for (int r = 0; r < repeat; ++r) dst[((size_t)r * n_sel + index[i]) * row_words + w] = v;
+}
+
+// Philox-4x32-10 (Salmon et al., SC'11): counter-based, so every rank draws the SAME normals for Gaussian i, replica r
+// from (seed, i, r) without any shared generator state -- data-parallel replicas split identically.
+__device__ __forceinline__ void philox_round(unsigned &c0, unsigned &c1, unsigned &c2, unsigned &c3, unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                           unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0, 1)
+
+// new_pos_scale of the reference (atlas_gs_optimizer.py:255-287): samples ~ N(0, diag(scaling^2)) rotated by the
+// Gaussian's (normalised) rotation and added to its position; new scaling = log(scaling / (0.8 split_num)).
+__global__ void __launch_bounds__(DB)
+split_sample_kernel(int P, const unsigned char *__restrict__ mask, const int *__restrict__ index, int n_sel, int split_num,
+                    unsigned seed_lo, unsigned seed_hi, const float *__restrict__ position,
+                    const float *__restrict__ scaling_raw, const float4 *__restrict__ rotation_raw,
+                    const float *__restrict__ unit_normals, float *__restrict__ new_pos, float *__restrict__ new_scaling) {
+    const int i = blockIdx.x * DB + threadIdx.x;
+    if (i >= P || !mask[i]) return;
+    const float s[3] = {expf(scaling_raw[3 * i]), expf(scaling_raw[3 * i + 1]), expf(scaling_raw[3 * i + 2])};
+    float4 q = rotation_raw[i];
+    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    q.x /= nrm; q.y /= nrm; q.z /= nrm; q.w /= nrm;
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                           {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                           {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+    for (int rep = 0; rep < split_num; ++rep) {
+        const size_t row = (size_t)rep * n_sel + index[i];
+        float zn[3];
+        if (unit_normals) {
+            zn[0] = unit_normals[3 * row]; zn[1] = unit_normals[3 * row + 1]; zn[2] = unit_normals[3 * row + 2];
+        } else {
+            unsigned u[4];
+            philox4x32((unsigned)i, (unsigned)rep, 0u, 0u, seed_lo, seed_hi, u);
+            const float r0 = sqrtf(-2.f * logf(u01(u[0]))), a0 = 6.283185307179586f * u01(u[1]);
+            const float r1 = sqrtf(-2.f * logf(u01(u[2]))), a1 = 6.283185307179586f * u01(u[3]);
+            zn[0] = r0 * cosf(a0); zn[1] = r0 * sinf(a0); zn[2] = r1 * cosf(a1);
+        }
+        const float sm[3] = {zn[0] * s[0], zn[1] * s[1], zn[2] * s[2]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            new_pos[3 * row + k] = R[k][0] * sm[0] + R[k][1] * sm[1] + R[k][2] * sm[2] + position[3 * i + k];
+            new_scaling[3 * row + k] = logf(s[k] / (0.8f * (float)split_num));
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int splat_gather_rows_repeat(int P, const uint8_t *mask, const int32_t *index, int n_sel, int repeat,
+                                        int row_words, const void *src, void *dst, void *stream) {
+    SPLAT_CHECK_ARG(P >= 0 && row_words >= 1 && repeat >= 1 && n_sel >= 0, "bad sizes");
+    if (P == 0 || n_sel == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(mask && index && src && dst, "null pointer");
+    const size_t total = (size_t)P * (size_t)row_words;
+    SPLAT_LAUNCH("gather_rows", gather_rows_repeat_kernel, dgrid(total), dim3(DB), 0, (hipStream_t)stream, total, row_words,
+                 mask, index, n_sel, repeat, (const unsigned int *)src, (unsigned int *)dst);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_densify_split_sample(int P, const uint8_t *mask, const int32_t *index, int n_sel, int split_num,
+                                          uint64_t seed, const float *position, const float *scaling_raw,
+                                          const float *rotation_raw, const float *unit_normals, float *new_pos,
+                                          float *new_scaling, void *stream) {
+    SPLAT_CHECK_ARG(P >= 0 && n_sel >= 0 && split_num >= 1, "bad sizes");
+    if (P == 0 || n_sel == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(mask && index && position && scaling_raw && rotation_raw && new_pos && new_scaling, "null pointer");
+    SPLAT_LAUNCH("split_sample", split_sample_kernel, dgrid(P), dim3(DB), 0, (hipStream_t)stream, P, mask, index, n_sel,
+                 split_num, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), position, scaling_raw,
+                 (const float4 *)rotation_raw, unit_normals, new_pos, new_scaling);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
 
 extern "C" int splat_densify_accumulate(int P, const int32_t *radius, const float *tap, float sx, float sy,
                                         float *viewspace_grad, uint8_t *visible, int32_t *radii, void *stream) {

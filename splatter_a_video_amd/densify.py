@@ -129,3 +129,121 @@ def compact(mask: Tensor, tensors: Dict[str, Tensor]) -> Dict[str, Tensor]:
                                            ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), L.stream()))
         out[name] = dst
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# structure surgery: clone / split / prune of every per-Gaussian tensor together with its Adam moments
+# ---------------------------------------------------------------------------------------------------------------------
+def _scan(mask: Tensor):
+    """(mask as uint8, exclusive prefix index[N] int32, number selected) -- one host synchronisation"""
+    mask_u8 = L.need(mask, "mask", torch.uint8)
+    N, dev = mask_u8.numel(), mask_u8.device
+    lib = L.lib()
+    index = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    scratch = torch.empty(max(int(lib.splat_compact_scratch_bytes(N)), 4), dtype=torch.uint8, device=dev)
+    L.check(lib.splat_compact_scan(L.ci(N), L.ptr(mask_u8), L.ptr(index), L.ptr(count), L.ptr(scratch), L.stream()))
+    return mask_u8, index, int(count.item())
+
+
+def _append(t: Tensor, mask_u8: Tensor, index: Tensor, n_sel: int, repeat: int, fill: Optional[Tensor] = None,
+            zeros: bool = False) -> Tensor:
+    """cat(t, rows) where rows = t[mask].repeat(repeat, 1, ..) -- or ``fill`` ([repeat * n_sel, ...], e.g. the children's new
+    positions), or zeros (fresh Adam moments, points.py:332-360)"""
+    N = t.shape[0]
+    if t.element_size() != 4:
+        raise ValueError("only 32-bit element types are supported")
+    src = t.detach().contiguous()
+    out = torch.empty((N + repeat * n_sel,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    out[:N].copy_(src)
+    if n_sel == 0:
+        return out
+    tail = out[N:]
+    if zeros:
+        tail.zero_()
+    elif fill is not None:
+        tail.copy_(fill.reshape(tail.shape))
+    else:
+        row_words = src.numel() // N
+        L.check(L.lib().splat_gather_rows_repeat(L.ci(N), L.ptr(mask_u8), L.ptr(index), L.ci(n_sel), L.ci(repeat), L.ci(row_words),
+                                                 ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(tail.data_ptr()), L.stream()))
+    return out
+
+
+Moments = Dict[str, Tuple[Tensor, Tensor]]
+
+
+def densify_clone(params: Dict[str, Tensor], moments: Optional[Moments], mask: Tensor):
+    """``densify_clone`` of the reference (atlas_gs_optimizer.py:289-304 + points.py:225-249,332-375): the selected
+    Gaussians are appended once more; the new rows' Adam moments (``moments[name] = (exp_avg, exp_avg_sq)``) are zero.
+    One prefix sum of the mask serves every tensor.  -> (params, moments, number cloned)"""
+    mask_u8, index, n = _scan(mask)
+    new_p = {k: _append(v, mask_u8, index, n, 1) for k, v in params.items()}
+    new_m = None
+    if moments is not None:
+        new_m = {k: tuple(_append(m, mask_u8, index, n, 1, zeros=True) for m in mv) for k, mv in moments.items()}
+    return new_p, new_m, n
+
+
+def split_children(position: Tensor, scaling_raw: Tensor, rotation_raw: Tensor, mask: Tensor, split_num: int = 2, seed: int = 0,
+                   unit_normals: Optional[Tensor] = None):
+    """``new_pos_scale`` (atlas_gs_optimizer.py:255-287): positions [split_num * n, 3] and log-scales of the children of
+    the selected Gaussians.  The normal draws come from a counter-based generator keyed by ``seed`` and addressed by
+    (Gaussian id, replica): every data-parallel rank that passes the same seed gets the same children, with no generator
+    state to keep in step.  ``unit_normals`` replaces the draws (parity tests)."""
+    mask_u8, index, n = _scan(mask)
+    return _split_children(position, scaling_raw, rotation_raw, mask_u8, index, n, split_num, seed, unit_normals) + (n,)
+
+
+def _split_children(position, scaling_raw, rotation_raw, mask_u8, index, n, split_num, seed, unit_normals):
+    N, dev = position.shape[0], position.device
+    new_pos = torch.empty(split_num * n, 3, dtype=torch.float32, device=dev)
+    new_scl = torch.empty(split_num * n, 3, dtype=torch.float32, device=dev)
+    zn = None
+    if unit_normals is not None:
+        zn = L.need(unit_normals, "unit_normals")
+        if zn.numel() != split_num * n * 3:
+            raise ValueError("unit_normals must be [split_num * n_selected, 3]")
+    L.check(L.lib().splat_densify_split_sample(
+        L.ci(N), L.ptr(mask_u8), L.ptr(index), L.ci(n), L.ci(split_num), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
+        L.ptr(L.need(position.detach(), "position")), L.ptr(L.need(scaling_raw.detach(), "scaling")),
+        L.ptr(L.need(rotation_raw.detach(), "rotation")), L.ptr(zn), L.ptr(new_pos), L.ptr(new_scl), L.stream()))
+    return new_pos, new_scl
+
+
+def densify_split(params: Dict[str, Tensor], moments: Optional[Moments], mask: Tensor, split_num: int = 2, seed: int = 0,
+                  unit_normals: Optional[Tensor] = None, position: str = "position", scaling: str = "scaling",
+                  rotation: str = "rotation"):
+    """``densify_split`` of the reference (atlas_gs_optimizer.py:306-349): every selected Gaussian is replaced by
+    ``split_num`` children (sampled positions, shrunk scales, every other attribute repeated, fresh Adam moments)
+    appended at the end, then the parents are removed (parameters and moments compacted with one shared prefix sum).
+    -> (params, moments, valid_points_mask over the extended cloud [for prune_postprocess], number split)"""
+    mask_u8, index, n = _scan(mask)
+    new_pos, new_scl = _split_children(params[position], params[scaling], params[rotation], mask_u8, index, n, split_num, seed,
+                                       unit_normals)
+    fills = {position: new_pos, scaling: new_scl}
+    ext_p = {k: _append(v, mask_u8, index, n, split_num, fill=fills.get(k)) for k, v in params.items()}
+    ext_m = None
+    if moments is not None:
+        ext_m = {k: tuple(_append(m, mask_u8, index, n, split_num, zeros=True) for m in mv) for k, mv in moments.items()}
+    valid = torch.cat([~mask.bool(), torch.ones(split_num * n, dtype=torch.bool, device=mask.device)])
+    flat = dict(ext_p)
+    if ext_m is not None:
+        for k, (a, b) in ext_m.items():
+            flat["\x00a" + k], flat["\x00b" + k] = a, b
+    kept = compact(valid, flat)
+    out_p = {k: kept[k] for k in ext_p}
+    out_m = None if ext_m is None else {k: (kept["\x00a" + k], kept["\x00b" + k]) for k in ext_m}
+    return out_p, out_m, valid, n
+
+
+def prune_points(params: Dict[str, Tensor], moments: Optional[Moments], valid_points_mask: Tensor):
+    """``remove_points`` (points.py:251-277,279-330): keep the rows of ``valid_points_mask`` in every parameter and moment"""
+    flat = dict(params)
+    if moments is not None:
+        for k, (a, b) in moments.items():
+            flat["\x00a" + k], flat["\x00b" + k] = a, b
+    kept = compact(valid_points_mask, flat)
+    out_p = {k: kept[k] for k in params}
+    out_m = None if moments is None else {k: (kept["\x00a" + k], kept["\x00b" + k]) for k in moments}
+    return out_p, out_m

@@ -55,3 +55,25 @@ def test_compact_rows_is_boolean_indexing():
     m = np.zeros(300, bool)
     assert oracle.compact_rows(m, idx).shape[0] == 0
     np.testing.assert_array_equal(oracle.compact_rows(~m, idx), idx)
+
+
+def test_structure_surgery_restatement_matches_reference():
+    """clone / split with the optimiser state: the numpy restatement against the vectors the reference's own
+    AtlasGaussianSplattingOptimizer / PointCloud methods produced (tests/golden/make_golden_structure.py)"""
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "structure_3000.npz")))
+    names = ["position", "scaling", "rotation", "opacity", "features"]
+    st = lambda tag: ({n: g[f"{tag}_{n}"] for n in names}, {n: (g[f"{tag}_{n}_exp_avg"], g[f"{tag}_{n}_exp_avg_sq"]) for n in names})
+    p0, m0 = st("s0")
+    p1, m1 = oracle.structure_clone(p0, m0, g["clone_mask"])
+    for n in names:
+        np.testing.assert_array_equal(p1[n], g[f"s1_{n}"])
+        np.testing.assert_array_equal(m1[n][0], g[f"s1_{n}_exp_avg"])
+        np.testing.assert_array_equal(m1[n][1], g[f"s1_{n}_exp_avg_sq"])
+    p2, m2, new_pos, new_scl = oracle.structure_split(p1, m1, g["split_mask"], int(g["split_num"]), g["unit_normals"])
+    np.testing.assert_allclose(new_pos, g["new_pos"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(new_scl, g["new_scaling"], rtol=2e-6, atol=2e-6)
+    for n in names:
+        assert p2[n].shape == g[f"s2_{n}"].shape
+        np.testing.assert_allclose(p2[n], g[f"s2_{n}"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_array_equal(m2[n][0], g[f"s2_{n}_exp_avg"])
+    assert int(g["clone_mask"].sum()) > 100 and int(g["split_mask"].sum()) > 100
