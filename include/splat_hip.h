@@ -187,6 +187,16 @@ int splat_dynamic_eval_backward(int P, int I, int seg, float d, const float *bas
                                 const float *g_scl, int accumulate, int cubic_layout, float *d_position, float *d_cubic,
                                 float *d_rotation, float *d_opacity, float *d_scaling, splat_stream_t stream);
 
+/* Polynomial + Fourier position model of the reference's first dynamic point cloud (src/dynamic_gaussian_points.py:169-186
+ * get_position): pos_t = position + sum_k pos_poly_feat[N,4,3][:,k,:] t'^k + sum_m pos_fourier_feat[N,8,3][:,m,:] basis_m(t')
+ * with the same 12 host basis values as the rotation (t'^0..3, cos(t' l pi), sin(t' l pi), l = 1..4).  Both tables
+ * receive gradients (the reference does not detach them here). */
+int splat_position_poly_fourier_forward(int P, const float *basis_host, const float *position, const float *pos_poly_feat,
+                                        const float *pos_fourier_feat, float *pos_t, splat_stream_t stream);
+int splat_position_poly_fourier_backward(int P, const float *basis_host, const float *g_pos, int accumulate,
+                                         float *d_position, float *d_pos_poly_feat, float *d_pos_fourier_feat,
+                                         splat_stream_t stream);
+
 /* ---- fused per-frame preprocess of the orthographic renderer (rows a2 + a5 + a3 in one pass) -------------------
  * Replaces, per rendered frame, the eager-torch orthographic projection and EWA of the reference renderer plus its
  * compute_cov3d call (src/pointrix/renderer/dptr_ortho_enhanced.py:145-202 project_point, :282-310 call sites,

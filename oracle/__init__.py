@@ -487,3 +487,26 @@ def structure_split(params, moments, mask, split_num, unit_normals):
     for k, mv in moments.items():
         mo[k] = tuple(np.concatenate([x, np.zeros((split_num * n,) + x.shape[1:], x.dtype)])[valid] for x in mv)
     return p, mo, new_pos, new_scl
+
+
+# ------------------------------------------------------------------ polynomial / Fourier position model (numpy restatement)
+def time_basis(time, start_frame_id, time_len):
+    """the 12 basis values of get_position / get_rotation (reference: src/dynamic_gaussian_points.py:138-150,169-180) in
+    float32: t'^0..3, cos(t' l pi), sin(t' l pi), l = 1..4, t' = (time - start_frame_id) / time_len"""
+    rt = np.float32((float(time) - float(start_frame_id)) / float(time_len))
+    k = np.arange(4, dtype=np.float32)
+    arg = (rt * (k + np.float32(1.0)) * np.float32(np.pi)).astype(np.float32)
+    return np.concatenate([np.power(rt, k), np.cos(arg), np.sin(arg)]).astype(np.float32)
+
+
+def position_poly_fourier_forward(position, pos_poly_feat, pos_fourier_feat, basis):
+    """get_position (src/dynamic_gaussian_points.py:169-186)"""
+    b = np.asarray(basis, np.float32)
+    return (_f(position, (-1, 3)) + (np.asarray(pos_poly_feat, np.float32) * b[None, :4, None]).sum(1)
+            + (np.asarray(pos_fourier_feat, np.float32) * b[None, 4:, None]).sum(1)).astype(np.float32)
+
+
+def position_poly_fourier_backward(g_pos, basis):
+    """-> (d_position, d_pos_poly_feat [N,4,3], d_pos_fourier_feat [N,8,3])"""
+    g = _f(g_pos, (-1, 3)); b = np.asarray(basis, np.float32)
+    return g.copy(), g[:, None, :] * b[None, :4, None], g[:, None, :] * b[None, 4:, None]

@@ -30,6 +30,7 @@ SYMBOLS = [
     "splat_compute_gaussian_key", "splat_compute_tile_gaussian_range",
     "splat_alpha_blending_forward", "splat_alpha_blending_backward", "splat_blend_pair_floats", "splat_blend_pack_floats",
     "splat_dynamic_eval_forward", "splat_dynamic_eval_backward",
+    "splat_position_poly_fourier_forward", "splat_position_poly_fourier_backward",
     "splat_preprocess_ortho_forward", "splat_preprocess_ortho_backward",
     "splat_frame_preprocess_forward", "splat_frame_preprocess_backward",
     "splat_densify_accumulate", "splat_densify_update", "splat_densify_masks",

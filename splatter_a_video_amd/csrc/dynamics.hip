@@ -94,7 +94,81 @@ __global__ __launch_bounds__(DYN_BLOCK) void dynamic_eval_bwd_kernel(
 
 inline dim3 dyn_grid(int P) { return dim3((unsigned)(((size_t)P * 4 + DYN_BLOCK - 1) / DYN_BLOCK)); }
 
+// ---- polynomial + Fourier position model of the reference's first dynamic point cloud
+// (src/dynamic_gaussian_points.py:169-186 get_position): position(t) = position + sum_k pos_poly_feat[:, k, :] t'^k
+//   + sum_m pos_fourier_feat[:, m, :] basis_m(t'),  t' = (time - start_frame_id) / time_len, basis = cos(t' l pi), sin(t' l pi)
+// (l = 1..4).  Unlike the rotation tables these are NOT detached: both tables receive gradients.  One lane per
+// (Gaussian, axis): the [N,4,3] / [N,8,3] tables are read with stride-3 accesses that together cover whole lines.
+__global__ __launch_bounds__(DYN_BLOCK) void position_pf_fwd_kernel(int P, DynBasis b, const float *__restrict__ position,
+                                                                    const float *__restrict__ pos_poly,
+                                                                    const float *__restrict__ pos_fourier,
+                                                                    float *__restrict__ pos_t) {
+    const size_t t = (size_t)blockIdx.x * DYN_BLOCK + threadIdx.x;
+    if (t >= (size_t)P * 3) return;
+    const size_t n = t / 3, j = t - 3 * n;
+    float acc = position[t];
+    float ps = 0.f, fs = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ps += pos_poly[n * 12 + k * 3 + j] * b.poly[k];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) fs += pos_fourier[n * 24 + m * 3 + j] * b.fourier[m];
+    pos_t[t] = (acc + ps) + fs;
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(DYN_BLOCK) void position_pf_bwd_kernel(int P, DynBasis b, const float *__restrict__ g_pos,
+                                                                    float *__restrict__ d_position,
+                                                                    float *__restrict__ d_pos_poly,
+                                                                    float *__restrict__ d_pos_fourier) {
+    const size_t t = (size_t)blockIdx.x * DYN_BLOCK + threadIdx.x;
+    if (t >= (size_t)P * 3) return;
+    const size_t n = t / 3, j = t - 3 * n;
+    const float g = g_pos[t];
+    if (d_position) put<ACC>(d_position + t, g);
+    if (d_pos_poly) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) put<ACC>(d_pos_poly + n * 12 + k * 3 + j, g * b.poly[k]);
+    }
+    if (d_pos_fourier) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) put<ACC>(d_pos_fourier + n * 24 + m * 3 + j, g * b.fourier[m]);
+    }
+}
+
 }  // namespace
+
+extern "C" int splat_position_poly_fourier_forward(int P, const float *basis_host, const float *position,
+                                                   const float *pos_poly_feat, const float *pos_fourier_feat, float *pos_t,
+                                                   void *stream) {
+    SPLAT_CHECK_ARG(P >= 0, "bad size");
+    SPLAT_CHECK_ARG(basis_host != nullptr, "basis_host (12 host floats) is required");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(position && pos_poly_feat && pos_fourier_feat && pos_t, "null pointer");
+    const unsigned blocks = (unsigned)(((size_t)P * 3 + DYN_BLOCK - 1) / DYN_BLOCK);
+    SPLAT_LAUNCH("position_pf_fwd", position_pf_fwd_kernel, dim3(blocks), dim3(DYN_BLOCK), 0, (hipStream_t)stream, P,
+                 load_basis(basis_host), position, pos_poly_feat, pos_fourier_feat, pos_t);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_position_poly_fourier_backward(int P, const float *basis_host, const float *g_pos, int accumulate,
+                                                    float *d_position, float *d_pos_poly_feat, float *d_pos_fourier_feat,
+                                                    void *stream) {
+    SPLAT_CHECK_ARG(P >= 0, "bad size");
+    SPLAT_CHECK_ARG(basis_host != nullptr, "basis_host (12 host floats) is required");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(g_pos != nullptr, "null pointer");
+    const unsigned blocks = (unsigned)(((size_t)P * 3 + DYN_BLOCK - 1) / DYN_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    if (accumulate)
+        SPLAT_LAUNCH("position_pf_bwd", position_pf_bwd_kernel<true>, dim3(blocks), dim3(DYN_BLOCK), 0, s, P,
+                     load_basis(basis_host), g_pos, d_position, d_pos_poly_feat, d_pos_fourier_feat);
+    else
+        SPLAT_LAUNCH("position_pf_bwd", position_pf_bwd_kernel<false>, dim3(blocks), dim3(DYN_BLOCK), 0, s, P,
+                     load_basis(basis_host), g_pos, d_position, d_pos_poly_feat, d_pos_fourier_feat);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
 
 extern "C" int splat_dynamic_eval_forward(int P, int I, int seg, float d, const float *basis_host,
                                           const float *position, const float *cubic, int cubic_layout, const float *rotation,

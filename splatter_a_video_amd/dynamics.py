@@ -53,7 +53,9 @@ class FrameClock:
         self.num_frames = int(num_frames)
         if intervals is None:
             n_seg = math.ceil(num_frames / 5)
-            idx = np.linspace(0, num_frames - 1, n_seg + 1, dtype=np.float32).astype(np.int64)
+            # exactly the reference's construction (float32 torch.linspace, then .long(): :64-66) -- numpy's linspace
+            # rounds differently when the step is not representable and can land one frame off
+            idx = torch.linspace(0, num_frames - 1, n_seg + 1).long().numpy()
             intervals = idx.astype(np.float32) / np.float32(num_frames - 1)
         self.intervals = np.ascontiguousarray(np.asarray(intervals, dtype=np.float32))
         if self.intervals.ndim != 1 or self.intervals.size < 2:
@@ -273,6 +275,42 @@ class _FramePreprocess(torch.autograd.Function):
                 L.stream()))
         # rot_poly / rot_fourier: detached in the reference (:195-197) -> no gradient
         return (r_pos, r_cub, r_rot, None, None, r_opa, r_scl) + (None,) * 11
+
+
+class _PositionPolyFourier(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, position, pos_poly_feat, pos_fourier_feat, basis):
+        position = L.need(position, "position")
+        N = position.shape[0]
+        poly = _opt(pos_poly_feat, "pos_poly_feat", N, 12)
+        four = _opt(pos_fourier_feat, "pos_fourier_feat", N, 24)
+        out = torch.empty(N, 3, dtype=torch.float32, device=position.device)
+        L.check(L.lib().splat_position_poly_fourier_forward(L.ci(N), basis, L.ptr(position), L.ptr(poly), L.ptr(four), L.ptr(out),
+                                                            L.stream()))
+        ctx.basis, ctx.shapes = basis, (position.shape, pos_poly_feat.shape, pos_fourier_feat.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = L.need(g, "dL_dposition_t")
+        N = g.shape[0]
+        dev = g.device
+        need = ctx.needs_input_grad
+        d_pos = torch.empty(ctx.shapes[0], dtype=torch.float32, device=dev) if need[0] else None
+        d_poly = torch.empty(ctx.shapes[1], dtype=torch.float32, device=dev) if need[1] else None
+        d_four = torch.empty(ctx.shapes[2], dtype=torch.float32, device=dev) if need[2] else None
+        L.check(L.lib().splat_position_poly_fourier_backward(L.ci(N), ctx.basis, L.ptr(g), L.ci(0), L.ptr(d_pos), L.ptr(d_poly),
+                                                             L.ptr(d_four), L.stream()))
+        return d_pos, d_poly, d_four, None
+
+
+def position_poly_fourier(clock: FrameClock, time, position: Tensor, pos_poly_feat: Tensor, pos_fourier_feat: Tensor,
+                          detach_pos: bool = False) -> Tensor:
+    """``get_position(time, detach_pos)`` of the reference's polynomial / Fourier point cloud
+    (src/dynamic_gaussian_points.py:169-186): position + sum_k pos_poly_feat[:, k] t'^k + sum_m pos_fourier_feat[:, m]
+    basis_m(t'); one native launch each way, gradients for all three inputs (none for ``position`` with ``detach_pos``)."""
+    _, _, basis = clock.scalars(time)
+    return _PositionPolyFourier.apply(position.detach() if detach_pos else position, pos_poly_feat, pos_fourier_feat, basis)
 
 
 def frame_preprocess(clock: FrameClock, time, extr: Tensor, W: int, H: int, *, position: Tensor, pos_cubic_node: Tensor,

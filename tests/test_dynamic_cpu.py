@@ -90,3 +90,30 @@ def test_dynamic_eval_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises((ValueError, RuntimeError)):
         evaluate(FrameClock(10), 3, opacity=torch.zeros(4, 1))
+
+
+def test_poly_fourier_position_restatement_matches_reference():
+    """the second dynamic point cloud's position model (src/dynamic_gaussian_points.py:169-186): numpy restatement against
+    the vectors of the reference's own get_position (tests/golden/make_golden_polyfourier.py), values and gradients"""
+    import os
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "polyfourier_300x40.npz")))
+    for t in g["times"]:
+        b = oracle.time_basis(int(t), int(g["start_frame_id"]), int(g["time_len"]))
+        pos = oracle.position_poly_fourier_forward(g["position"], g["pos_poly_feat"], g["pos_fourier_feat"], b)
+        np.testing.assert_allclose(pos, g[f"t{t}_pos"], rtol=2e-6, atol=2e-6)
+        dp, dpoly, dfour = oracle.position_poly_fourier_backward(g[f"t{t}_g_pos"], b)
+        np.testing.assert_allclose(dp, g[f"t{t}_d_position"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(dpoly, g[f"t{t}_d_pos_poly"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(dfour, g[f"t{t}_d_pos_fourier"], rtol=2e-6, atol=1e-6)
+        assert float(np.abs(g[f"t{t}_det_d_position"]).max()) == 0.0        # detach_pos: no gradient to the base position
+
+
+def test_frame_clock_default_knots_follow_torch_linspace():
+    """the default knots are the reference's float32 torch.linspace(...).long() for every clip length"""
+    import math
+    import torch
+    from splatter_a_video_amd.dynamics import FrameClock
+    for n in range(2, 400):
+        k = math.ceil(n / 5)
+        want = torch.linspace(0, n - 1, k + 1).long().numpy().astype(np.float32) / np.float32(n - 1)
+        np.testing.assert_array_equal(FrameClock(n).intervals, want)

@@ -306,3 +306,30 @@ def test_dynamic_pipeline_end_to_end_against_oracle():
     err = np.abs(shs_sink.cpu().numpy() - want_shs).max() / np.abs(want_shs).max()
     assert err < 5e-3, err
     assert all(p[k].grad is None for k in sink) and shs_d.grad is None
+
+
+def test_poly_fourier_position_matches_reference():
+    """splat_position_poly_fourier_* (dynamics.position_poly_fourier) against the reference's own get_position
+    (src/dynamic_gaussian_points.py:169-186; tests/golden/make_golden_polyfourier.py), values and gradients, with and
+    without detach_pos; the rotation of that class is the same getter the spline class uses (checked alongside)."""
+    from splatter_a_video_amd.dynamics import FrameClock, evaluate, position_poly_fourier
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "polyfourier_300x40.npz")))
+    clock = FrameClock(int(g["T"]), start_frame_id=int(g["start_frame_id"]), time_len=int(g["time_len"]))
+    dev = "cuda"
+    for t in g["times"]:
+        for det in (False, True):
+            pre = f"t{t}_{'det_' if det else ''}"
+            p = {k: torch.tensor(g[k], device=dev, requires_grad=True) for k in ("position", "pos_poly_feat", "pos_fourier_feat", "rotation")}
+            pos = position_poly_fourier(clock, int(t), p["position"], p["pos_poly_feat"], p["pos_fourier_feat"], detach_pos=det)
+            np.testing.assert_allclose(pos.detach().cpu().numpy(), g[pre + "pos"], rtol=2e-6, atol=2e-6)
+            (pos * torch.tensor(g[pre + "g_pos"], device=dev)).sum().backward()
+            if det:
+                assert p["position"].grad is None
+            else:
+                np.testing.assert_allclose(p["position"].grad.cpu().numpy(), g[pre + "d_position"], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(p["pos_poly_feat"].grad.cpu().numpy(), g[pre + "d_pos_poly"], rtol=2e-6, atol=1e-6)
+            np.testing.assert_allclose(p["pos_fourier_feat"].grad.cpu().numpy(), g[pre + "d_pos_fourier"], rtol=2e-6, atol=1e-6)
+        out = evaluate(clock, int(t), rotation=p["rotation"], rot_poly_feat=torch.tensor(g["rot_poly_feat"], device=dev),
+                       rot_fourier_feat=torch.tensor(g["rot_fourier_feat"], device=dev))
+        rot = out[1]
+        np.testing.assert_allclose(rot.detach().cpu().numpy(), g[f"t{t}_rot"], rtol=2e-5, atol=2e-6)
