@@ -151,7 +151,7 @@ class FrameRenderer:
             src["shs"] = sc.shs
         else:
             src["feature"] = sc.feature
-        if mode == "render_iter":
+        if mode in ("render_iter", "render_iter_frame"):
             src["attrs"] = np.random.default_rng(7).uniform(-1, 1, size=(N, 19)).astype(np.float32)
         # stale-1 mode only: two gradient buffers, the all-reduce of step s runs on RCCL's stream while step s+1 fills the other
         self.overlap = bool(stale_overlap) and dist.is_available() and dist.is_initialized()
@@ -175,11 +175,16 @@ class FrameRenderer:
             self.offs = self.frames
         else:
             self.offs = [self.offsets(f) for f in self.frames]
-        if self.mode == "render_iter":
+        if self.mode in ("render_iter", "render_iter_frame"):
             from splatter_a_video_amd.renderer import OrthoEnhancedRenderer
             self.renderer = OrthoEnhancedRenderer(densify_abs_grad_enable=True)
             self.dL_depth = torch.randn(1, self.H, self.W, generator=g).to(device)
             self.dL_attr = torch.randn(19, self.H, self.W, generator=g).to(device)
+        if self.mode == "render_iter":
+            self.batch = FrameBatch(self.F, N, self.W, self.H, 3 + 1 + 19, device, want_abs=True)
+            self.off_all = torch.stack(self.offs).contiguous()
+            rep = lambda t: t.unsqueeze(0).repeat(self.F, 1, 1, 1).contiguous()
+            self.dL_sets = [rep(self.dL_dout), rep(self.dL_depth), rep(self.dL_attr)]
         if self.mode == "batch":
             if self.C > 32:
                 raise SystemExit("the frame batch composites at most 32 channels per call")
@@ -208,7 +213,19 @@ class FrameRenderer:
         out.backward(self.dL_all)
         self.last = dict(M=self.last.get("M", 0), T=self.batch.T)
 
-    # ------------------------------------------------------------------ the reference's real frame (row a1)
+    # ------------------------------------------------------------------ the reference's real frame (row a1), frame batch
+    def frames_render_iter_batched(self):
+        p = self.p
+        g = {k: self.bucket.grad(k) for k in p}
+        rgb = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"])      # once per step (constant view direction)
+        sets = [dict(feature=rgb, bg=self.sc.bg, taps=True), dict(feature="depth", bg=1.0),
+                dict(feature=p["attrs"], bg=0.0, detach_opacity=True)]
+        out = self.batch.render_sets(p["xyz"], p["scale"], p["rotate"], p["opacity"], sets, self.off_all, self.extr, K=20,
+                                     grad_sink={"xyz": g["xyz"], "scales": g["scale"], "uquats": g["rotate"], "opacity": g["opacity"]})
+        torch.autograd.backward(list(out[:3]), self.dL_sets)
+        self.last = dict(M=self.last.get("M", 0), T=self.batch.T)
+
+    # ------------------------------------------------------------------ the reference's real frame (row a1), frame by frame
     def frames_render_iter(self):
         p = self.p
         rgb = self.renderer.colors(p["shs"])          # once per batch: the view direction is constant (render_batch)
@@ -277,6 +294,8 @@ class FrameRenderer:
         if self.mode == "batch":
             self.frames_batched()
         elif self.mode == "render_iter":
+            self.frames_render_iter_batched()
+        elif self.mode == "render_iter_frame":
             self.frames_render_iter()
         else:
             for off in self.offs:
@@ -293,7 +312,7 @@ class FrameRenderer:
     def check_sorts(self):
         """after the timed region: every capacity-bounded sort of the run fitted (host sync)"""
         m = 0
-        if self.mode == "batch":
+        if self.mode in ("batch", "render_iter"):
             m = self.batch.check()
         for st in self.sort_status:
             m = max(m, st.check())
@@ -415,7 +434,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    mode = "render_iter" if a.render_iter else "ops" if a.ops else "frame" if (a.per_frame or a.dynamic) else "batch"
+    mode = ("render_iter_frame" if a.per_frame else "render_iter") if a.render_iter else "ops" if a.ops else "frame" if (a.per_frame or a.dynamic) else "batch"
     clip = max(a.clip, 25 * world)
     sc = make_scene(a.gaussians, a.width, a.height, F=clip, C=a.channels, seed=1234)
     # rank r renders frames {f : f mod world == r} of the step's frame batch
@@ -478,7 +497,7 @@ def main():
         names = ["sh_fwd", "frame_preprocess_fwd", "frame_preprocess_bwd", "preprocess_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
                  "bin_scatter", "tile_sort", "blend_pack", "blend_fwd", "blend_bwd", "pair_reduce", "gauss_bwd", "preprocess_bwd", "ewa_bwd", "project_point_bwd",
                  "cov3d_bwd", "sh_bwd", "adam_step"]
-        per_step = {"adam_step", "gauss_bwd"} | ({"sh_fwd", "sh_bwd"} if mode == "batch" else set())
+        per_step = {"adam_step", "gauss_bwd"} | ({"sh_fwd", "sh_bwd"} if mode in ("batch", "render_iter") else set())
         for n in names:
             ms, cnt = L.profile_read(n)
             if cnt:
@@ -517,7 +536,7 @@ def main():
                                               "synchronous: all-reduce -> Adam -> next forward" if R.opt is not None else
                                               "synchronous all-reduce, no optimiser")
         line = {
-            "metric": "rendered frames/sec fwd+bwd @480p, 300k Gaussians" + (" (render_iter: three blends, 23 channels)" if mode == "render_iter" else ""),
+            "metric": "rendered frames/sec fwd+bwd @480p, 300k Gaussians" + (" (render_iter: three blends, 23 channels)" if mode.startswith("render_iter") else ""),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -529,12 +548,15 @@ def main():
                        "tile_pairs_M": M, "channels": R.C, "parallelism": par,
                        "path": ("dynamic-Gaussian evaluation fused into the per-frame preprocess + gradient sinks" if R.dynamic else
                                 "render_iter of the reference's renderer (rgb enhanced K=20 + depth + 19 attribute channels per "
-                                "frame), native OrthoEnhancedRenderer, per-frame operators" if mode == "render_iter" else
+                                "frame), native OrthoEnhancedRenderer, per-frame operators" if mode == "render_iter_frame" else
+                                "render_iter of the reference's renderer (rgb enhanced K=20 + depth + 19 attribute channels per frame) "
+                                "as a frame batch: one forward over the 23-channel row, one backward pass per feature set"
+                                if mode == "render_iter" else
                                 "frame batch: the frame is a grid dimension of every kernel; SH and the Gaussian-side backward once per step"
                                 if mode == "batch" else
                                 "fused per-frame operators + gradient sinks" if mode == "frame" else "per-operator autograd chain"),
                        "grad_bucket_MB": round(R.flat_grad.numel() * 4 / 1e6, 1),
-                       "batch_buffers_MB": round(R.batch.memory_bytes() / 1e6, 1) if mode == "batch" else None},
+                       "batch_buffers_MB": round(R.batch.memory_bytes() / 1e6, 1) if mode in ("batch", "render_iter") else None},
             "ms_per_frame": round(dt / (a.frames * a.steps) * 1e3, 4),
             "gpu_kernel_ms_per_frame": {"forward": None if fwd_ms is None else round(fwd_ms, 4),
                                         "backward": None if bwd_ms is None else round(bwd_ms, 4),

@@ -350,6 +350,29 @@ int splat_frames_gauss_backward_static(int F, int P, int C, int W, int H, int64_
                                        float *d_feature, float *tap, float *abs_tap, int32_t *radii_max,
                                        splat_stream_t stream);
 
+/* Several feature SETS of one geometry in a frame batch -- the reference renderer's three blends (rgb through
+ * alpha_blending_enhanced with the taps; depth, bg = 1; the extra attributes with opacity.detach(),
+ * dptr_ortho_enhanced.py:331-375): ONE forward over the concatenated row [F,P,C] (splat_alpha_blending_forward_batch with
+ * per-channel backgrounds and K ids), then per set [c0, c0 + cn) one backward pass of the tile kernels
+ * (..._backward_batch_set: packs the set's own records, pair stride splat_blend_pair_stride(cn, want_abs, 0)) and one
+ * Gaussian-side reduction (..._gauss_backward_static_set: accumulate = 1 after the first set; skip_opacity for a set
+ * blended with a detached opacity; depth_channel >= 0 when that channel is the per-frame depth feature, whose gradient
+ * goes to the position through the projection; taps only from the set that feeds them). */
+int splat_alpha_blending_backward_batch_set(int F, int P, int C, int c0, int cn, const float *uv, const float *conic,
+                                            const float *opacity, int64_t opacity_frame_stride, const float *feature,
+                                            int64_t feature_frame_stride, const int32_t *idx_sorted,
+                                            const int32_t *tile_range, int64_t capacity, float bg, int W, int H,
+                                            const float *final_T, const int32_t *ncontrib, const float *dL_dout,
+                                            int want_abs, const int32_t *slot_sorted, float *pair_records,
+                                            float *pack_scratch, float *dbg_T_front, splat_stream_t stream);
+int splat_frames_gauss_backward_static_set(int F, int P, int cn, int W, int H, int64_t capacity, int want_abs,
+                                           const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
+                                           const float *xyz, const float *scales, const float *uquats, const float *extr,
+                                           int accumulate, float *d_xyz, float *d_scales, float *d_uquats,
+                                           float *d_opacity, float *d_feature /*NULL: none*/, int feature_stride,
+                                           int skip_opacity, int depth_channel, float *tap, float *abs_tap,
+                                           int32_t *radii_max, splat_stream_t stream);
+
 /* ---- optimiser step of the frame-sharded data-parallel renderer: replaces the per-group
  *      torch.optim.Adam.step() the reference reaches through src/pointrix/optimizer/optimizer.py:70-83 (Adam built in
  *      atlas_gs_optimizer / configs with eps = 1e-15, one learning rate per parameter group), as one launch over the

@@ -1695,3 +1695,41 @@ extern "C" int splat_alpha_blending_backward_batch(int F, int P, int C, const in
     A.dL_dabs_uv = want_abs ? pair_records : nullptr;
     return bwd_chunk(A, T, false, true, (hipStream_t)stream);
 }
+
+// One feature SET [c0, c0 + cn) of a wider composited row (the reference's renderer blends rgb / depth / attributes of one
+// geometry, dptr_ortho_enhanced.py:331-375): packs its own records from (uv, conic, opacity, feature[.., c0:c0+cn]) and
+// writes the set's pair records (stride splat_blend_pair_stride(cn, want_abs, 0)).  dL_dout is the [F,C,H,W] gradient of
+// the whole row.
+extern "C" int splat_alpha_blending_backward_batch_set(int F, int P, int C, int c0, int cn, const float *uv,
+                                                       const float *conic, const float *opacity,
+                                                       int64_t opacity_frame_stride, const float *feature,
+                                                       int64_t feature_frame_stride, const int32_t *idx_sorted,
+                                                       const int32_t *tile_range, int64_t capacity, float bg, int W, int H,
+                                                       const float *final_T, const int32_t *ncontrib,
+                                                       const float *dL_dout, int want_abs, const int32_t *slot_sorted,
+                                                       float *pair_records, float *pack_scratch, float *dbg_T_front,
+                                                       splat_stream_t stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && W > 0 && H > 0 && capacity >= 1, "bad sizes");
+    SPLAT_CHECK_ARG(c0 >= 0 && cn >= 1 && cn <= 32 && c0 + cn <= C, "the set must be 1..32 channels inside the row");
+    SPLAT_CHECK_ARG(uv && conic && opacity && feature && idx_sorted && tile_range && final_T && ncontrib && dL_dout &&
+                        slot_sorted && pair_records && pack_scratch,
+                    "null pointer");
+    BlendArgs A;
+    memset(&A, 0, sizeof(A));
+    A.P = P; A.C = C;
+    A.uv = (const float2 *)uv; A.conic = conic; A.opacity = opacity; A.feature = feature;
+    A.idx_sorted = idx_sorted; A.tile_range = (const int2 *)tile_range;
+    A.bg = bg; A.W = W; A.H = H; A.gx = (W + TILE - 1) / TILE;
+    A.final_T = const_cast<float *>(final_T); A.ncontrib = const_cast<int *>(ncontrib);
+    A.dL_dout = dL_dout;
+    A.slot_sorted = slot_sorted; A.pair_buf = pair_records;
+    A.pack = pack_scratch; A.pack_valid = 0;
+    A.dbg_T_front = dbg_T_front;
+    const int T = A.gx * ((H + TILE - 1) / TILE);
+    A.F = F; A.T = T; A.cap = capacity; A.tile_only = 1;
+    A.pack_fs = (long long)P * (long long)splat_blend_pack_floats(cn);
+    A.opacity_fs = opacity_frame_stride; A.feature_fs = feature_frame_stride;
+    A.c0 = c0; A.cn = cn;
+    A.dL_dabs_uv = want_abs ? pair_records : nullptr;
+    return bwd_chunk(A, T, false, true, (hipStream_t)stream);
+}

@@ -282,6 +282,9 @@ struct GaussBwdArgs {
     float *tap, *abs_tap;   // optional [P,2]: sum over the frames of dL_duv * (W/2, H/2) (and of its abs twin)
     int *radii_max;         // optional [P]: max over the frames of the screen radius (visibility = radii_max > 0)
     int accumulate;         // add to the parameter gradients instead of storing
+    int skip_opacity;       // this feature set was blended with opacity.detach(): no opacity gradient
+    int depth_channel;      // >= 0: that channel of the set is the per-frame depth feature -- its summed gradient is
+                            // dL/ddepth of the projection (-> position), not a feature gradient
 };
 
 template <bool ABS, int NCP>
@@ -332,11 +335,24 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
     const float ux = quad_bcast<0>(a[0].x), uy = quad_bcast<0>(a[0].y);
     const float g3[3] = {quad_bcast<0>(a[0].z), quad_bcast<0>(a[0].w), quad_bcast<1>(a[0].x)};
     const float dop = quad_bcast<1>(a[0].y);
+    float gdep = 0.f;  // dL/ddepth (a set whose channel `depth_channel` is the depth feature): component NG + channel
+    if (A.depth_channel >= 0) {
+        const int k = NG + A.depth_channel;  // chunk k / 4 -> lane (k / 4) & 3, register a[k / 16], element k & 3
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            const float e4[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k == 16 * c + 4 * sub + e) v = e4[e];
+        }
+        gdep = quad_sum(v);  // exactly one lane holds it
+    }
     float gp[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
     if (any) {  // a record exists: the Gaussian was visible with radius > 0 in that frame (the chain's preconditions)
         Cam c;
         load_cam(nullptr, A.extr, c);
-        project_ortho_grad_pt(c, A.W, A.H, ux, uy, 0.f, gp);
+        project_ortho_grad_pt(c, A.W, A.H, ux, uy, gdep, gp);
         const float p[3] = {A.xyz[3 * i], A.xyz[3 * i + 1], A.xyz[3 * i + 2]};
         const float4 q4 = A.uquats[i];
         const float q[4] = {q4.x, q4.y, q4.z, q4.w};
@@ -357,7 +373,7 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
     if (sub == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) put1(A.d_xyz + 3 * i + k, gp[k]);
-        put1(A.d_opacity + i, dop);
+        if (!A.skip_opacity) put1(A.d_opacity + i, dop);
         if (A.radii_max) A.radii_max[i] = rmax;
     } else if (sub == 1) {
 #pragma unroll
@@ -387,7 +403,7 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ch = k0 + e - NG;
-                if (ch >= 0 && ch < A.cn) put1(A.d_feature + (size_t)i * A.C + ch, v[e]);
+                if (ch >= 0 && ch < A.cn && ch != A.depth_channel && A.d_feature) put1(A.d_feature + (size_t)i * A.C + ch, v[e]);
             }
         }
     }
@@ -425,6 +441,13 @@ extern "C" int splat_preprocess_ortho_forward_batch(int F, int P, const float *x
     return SPLAT_OK;
 }
 
+static int gauss_backward_static(int F, int P, int C, int W, int H, int64_t capacity, int want_abs,
+                                 const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
+                                 const float *xyz, const float *scales, const float *uquats, const float *extr,
+                                 int accumulate, float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                 float *d_feature, int feature_stride, int skip_opacity, int depth_channel, float *tap,
+                                 float *abs_tap, int32_t *radii_max, void *stream);
+
 extern "C" int splat_frames_gauss_backward_static(int F, int P, int C, int W, int H, int64_t capacity, int want_abs,
                                                   const float *pair_records, const int32_t *goff_incl,
                                                   const int32_t *radius, const float *xyz, const float *scales,
@@ -432,14 +455,44 @@ extern "C" int splat_frames_gauss_backward_static(int F, int P, int C, int W, in
                                                   float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
                                                   float *d_feature, float *tap, float *abs_tap, int32_t *radii_max,
                                                   void *stream) {
+    SPLAT_CHECK_ARG(d_opacity && d_feature, "null gradient pointer");
+    return gauss_backward_static(F, P, C, W, H, capacity, want_abs, pair_records, goff_incl, radius, xyz, scales, uquats, extr,
+                                 accumulate, d_xyz, d_scales, d_uquats, d_opacity, d_feature, C, 0, -1, tap, abs_tap, radii_max,
+                                 stream);
+}
+
+// one feature SET of a multi-set batch (see splat_alpha_blending_backward_batch_set): cn channels per record,
+// d_feature rows `feature_stride` floats apart (NULL: no feature gradient wanted), the set's routing flags
+extern "C" int splat_frames_gauss_backward_static_set(int F, int P, int cn, int W, int H, int64_t capacity, int want_abs,
+                                                      const float *pair_records, const int32_t *goff_incl,
+                                                      const int32_t *radius, const float *xyz, const float *scales,
+                                                      const float *uquats, const float *extr, int accumulate,
+                                                      float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                                      float *d_feature, int feature_stride, int skip_opacity,
+                                                      int depth_channel, float *tap, float *abs_tap, int32_t *radii_max,
+                                                      void *stream) {
+    SPLAT_CHECK_ARG(skip_opacity || d_opacity, "null gradient pointer");
+    SPLAT_CHECK_ARG(depth_channel < cn, "depth_channel outside the set");
+    return gauss_backward_static(F, P, cn, W, H, capacity, want_abs, pair_records, goff_incl, radius, xyz, scales, uquats, extr,
+                                 accumulate, d_xyz, d_scales, d_uquats, d_opacity, d_feature, feature_stride, skip_opacity,
+                                 depth_channel, tap, abs_tap, radii_max, stream);
+}
+
+static int gauss_backward_static(int F, int P, int C, int W, int H, int64_t capacity, int want_abs,
+                                 const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
+                                 const float *xyz, const float *scales, const float *uquats, const float *extr,
+                                 int accumulate, float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                 float *d_feature, int feature_stride, int skip_opacity, int depth_channel, float *tap,
+                                 float *abs_tap, int32_t *radii_max, void *stream) {
     SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 32 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 32)");
     SPLAT_CHECK_ARG(pair_records && goff_incl && xyz && scales && uquats && extr, "null input pointer");
-    SPLAT_CHECK_ARG(d_xyz && d_scales && d_uquats && d_opacity && d_feature, "null gradient pointer");
+    SPLAT_CHECK_ARG(d_xyz && d_scales && d_uquats, "null gradient pointer");
     SPLAT_CHECK_ARG(!abs_tap || want_abs, "abs_tap needs records with the abs sums");
     SPLAT_CHECK_ARG(!radii_max || radius, "radii_max needs the per-frame radius");
     GaussBwdArgs A;
     memset(&A, 0, sizeof(A));
-    A.F = F; A.P = P; A.W = W; A.H = H; A.C = C; A.cn = C; A.cap = capacity;
+    A.F = F; A.P = P; A.W = W; A.H = H; A.C = feature_stride; A.cn = C; A.cap = capacity;
+    A.skip_opacity = skip_opacity; A.depth_channel = depth_channel;
     A.pair = pair_records; A.goff = goff_incl; A.radius = radius;
     A.xyz = xyz; A.scales = scales; A.uquats = (const float4 *)uquats; A.extr = extr;
     A.d_xyz = d_xyz; A.d_scales = d_scales; A.d_uquats = d_uquats; A.d_opacity = d_opacity; A.d_feature = d_feature;

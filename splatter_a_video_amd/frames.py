@@ -80,6 +80,15 @@ class FrameBatch:
         self.slot_sorted = torch.empty(F_, capacity, dtype=torch.int32, device=dev)
         self.pair_records = torch.empty(F_ * capacity * self.ncp, dtype=torch.float32, device=dev)
 
+    def _set_buffer(self, key, numel: int) -> Tensor:
+        """scratch of the multi-set backward (pair records / packed records per feature set), kept across steps"""
+        cache = self.__dict__.setdefault("_set_buffers", {})
+        t = cache.get(key)
+        if t is None or t.numel() < numel:
+            t = torch.empty(numel, dtype=torch.float32, device=self.dev)
+            cache[key] = t
+        return t
+
     def check(self) -> int:
         """host sync; raises when a frame's pairs exceeded the capacity (its surplus pairs were dropped), else returns the
         largest per-frame pair count"""
@@ -92,9 +101,10 @@ class FrameBatch:
         return sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, Tensor))
 
     # ------------------------------------------------------------------ forward / backward launch sequences
-    def _forward(self, xyz, scales, uquats, opacity, feature, offsets, extr, bg, nearest, extent):
+    def _geometry(self, xyz, scales, uquats, offsets, extr, nearest, extent):
+        """orthographic preprocess + tile binning + per-tile depth sort of all frames"""
         lib, st = L.lib(), L.stream()
-        F_, P_, W, H, C = self.F, self.P, self.W, self.H, self.C
+        F_, P_, W, H = self.F, self.P, self.W, self.H
         L.check(lib.splat_preprocess_ortho_forward_batch(
             L.ci(F_), L.ci(P_), L.ptr(xyz), L.ptr(offsets), L.ptr(scales), L.ptr(uquats), L.ptr(extr), L.ci(W), L.ci(H),
             L.cf(nearest), L.cf(extent), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.conic), L.ptr(self.radius), st))
@@ -107,14 +117,21 @@ class FrameBatch:
             L.ci(F_), L.ci(P_), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.radius), L.ci(W), L.ci(H),
             L.ptr(self.bin_scratch), L.ptr(self.tile_range), ctypes.c_int64(cap), L.ptr(self.keys), L.ptr(self.idx_sorted),
             L.ptr(self.overflow), L.ptr(self.goff), L.ptr(self.owner), L.ptr(self.slot_sorted), st))
+
+    def _forward(self, xyz, scales, uquats, opacity, feature, offsets, extr, bg, nearest, extent, bgc=None, K=0):
+        self._geometry(xyz, scales, uquats, offsets, extr, nearest, extent)
+        lib, st = L.lib(), L.stream()
+        F_, P_, W, H, C = self.F, self.P, self.W, self.H, self.C
+        cap = self.capacity
         out = torch.empty(F_, C, H, W, dtype=torch.float32, device=self.dev)
+        self.gs_idx = torch.empty(F_, H, W, K, dtype=torch.int32, device=self.dev) if K > 0 else None
         op_fs = 0 if opacity.numel() == P_ else P_
         ft_fs = 0 if feature.numel() == P_ * C else P_ * C
         L.check(lib.splat_alpha_blending_forward_batch(
             L.ci(F_), L.ci(P_), L.ci(C), L.ptr(self.uv), L.ptr(self.conic), L.ptr(opacity), ctypes.c_int64(op_fs),
             L.ptr(feature), ctypes.c_int64(ft_fs), L.ptr(self.idx_sorted), L.ptr(self.tile_range), ctypes.c_int64(cap),
-            L.cf(bg), L.ptr(None), L.ci(W), L.ci(H), L.ci(0), L.ci(0), L.ptr(out), L.ptr(self.final_T),
-            L.ptr(self.ncontrib), L.ptr(None), L.ptr(self.pack), st))
+            L.cf(bg), L.ptr(bgc), L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(self.final_T),
+            L.ptr(self.ncontrib), L.ptr(self.gs_idx), L.ptr(self.pack), st))
         return out
 
     def _backward(self, dL_dout, xyz, scales, uquats, extr, bg, bufs, accumulate, dbg=None):
@@ -144,6 +161,127 @@ class FrameBatch:
         sink = check_sink(grad_sink, {"xyz": xyz, "scales": scales, "uquats": uquats, "opacity": opacity, "feature": feature})
         return _RenderFrames.apply(xyz, scales, uquats, opacity, feature, offsets, extr, self, float(bg), float(nearest),
                                    float(extent), sink)
+
+
+    # ------------------------------------------------------------------ several feature sets of one geometry (row a1)
+    def render_sets(self, xyz: Tensor, scales: Tensor, uquats: Tensor, opacity: Tensor, sets, offsets: Optional[Tensor],
+                    extr: Tensor, K: int = 0, nearest: float = 0.01, extent: float = 1.3,
+                    grad_sink: Optional[Dict[str, Tensor]] = None):
+        """The reference renderer's blends of ONE geometry over all frames of the batch (render_iter,
+        src/pointrix/renderer/dptr_ortho_enhanced.py:331-375: rgb through alpha_blending_enhanced with the taps; depth with
+        bg = 1; the extra attributes with opacity.detach()).  ``sets``: a list of dicts ``feature`` ([P,c] tensor shared by
+        the frames, or the string "depth" for the per-frame depth of the projection), ``bg``, ``detach_opacity``, ``taps``.
+        The widths must add up to the batch's ``C``.  One forward pass composites the concatenated row; per set one
+        backward pass of the tile kernels and one Gaussian-side reduction.  Returns ``(images per set ..., gs_idx)`` with
+        images [F,c,H,W] and gs_idx [F,H,W,K] (None for K = 0)."""
+        feats = [s_["feature"] for s_ in sets if not isinstance(s_["feature"], str)]
+        meta = tuple((("depth" if isinstance(s_["feature"], str) else int(s_["feature"].shape[1])), float(s_.get("bg", 0.0)),
+                      bool(s_.get("detach_opacity", False)), bool(s_.get("taps", False))) for s_ in sets)
+        width = sum(1 if m[0] == "depth" else m[0] for m in meta)
+        if width != self.C:
+            raise ValueError(f"the sets hold {width} channels, the batch was built for C = {self.C}")
+        if sum(1 for m in meta if m[3]) > 1:
+            raise ValueError("at most one set feeds the densification taps")
+        sink = check_sink(grad_sink, {"xyz": xyz, "scales": scales, "uquats": uquats, "opacity": opacity})
+        res = _RenderSets.apply(xyz, scales, uquats, opacity, offsets, extr, self, meta, int(K), float(nearest), float(extent),
+                                sink, *feats)
+        return res
+
+
+class _RenderSets(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, scales, uquats, opacity, offsets, extr, fb, meta, K, nearest, extent, sink, *feats):
+        xyz = _points(xyz, "xyz", 3)
+        scales = _points(scales, "scales", 3)
+        uquats = _points(uquats, "uquats", 4)
+        opacity = L.need(opacity, "opacity")
+        extr_c = _extr12(extr)
+        P, F = fb.P, fb.F
+        off = L.need(offsets, "offsets") if offsets is not None else None
+        if off is not None and tuple(off.shape) != (F, P, 3):
+            raise ValueError(f"offsets must be [F={F}, P={P}, 3]")
+        fb._geometry(xyz, scales, uquats, off, extr_c, nearest, extent)
+        # the composited row [F,P,C]: shared features repeated per frame, the depth of every frame in its slot
+        cols, bgs, it = [], [], iter(feats)
+        for w, bg, _, _ in meta:
+            if w == "depth":
+                cols.append(fb.depth)
+                bgs.append(torch.full((1,), bg, dtype=torch.float32, device=fb.dev))
+            else:
+                f = _points(next(it), "feature", w)
+                cols.append(f.unsqueeze(0).expand(F, P, w))
+                bgs.append(torch.full((w,), bg, dtype=torch.float32, device=fb.dev))
+        row = torch.cat(cols, dim=2).contiguous()
+        bgc = torch.cat(bgs)
+        lib, st = L.lib(), L.stream()
+        W, H, C, cap = fb.W, fb.H, fb.C, fb.capacity
+        out = torch.empty(F, C, H, W, dtype=torch.float32, device=fb.dev)
+        gs_idx = torch.empty(F, H, W, K, dtype=torch.int32, device=fb.dev) if K > 0 else None
+        op_fs = 0 if opacity.numel() == P else P
+        L.check(lib.splat_alpha_blending_forward_batch(
+            L.ci(F), L.ci(P), L.ci(C), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity), ctypes.c_int64(op_fs), L.ptr(row),
+            ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.cf(0.0), L.ptr(bgc),
+            L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx),
+            L.ptr(fb.pack), st))
+        ctx.fb, ctx.meta, ctx.sink, ctx.K = fb, meta, sink, K
+        ctx.row = row
+        ctx.save_for_backward(xyz, scales, uquats, opacity, extr_c, *feats)
+        ctx.set_materialize_grads(False)
+        imgs, c0 = [], 0
+        for w, _, _, _ in meta:
+            w = 1 if w == "depth" else w
+            imgs.append(out[:, c0:c0 + w])
+            c0 += w
+        if gs_idx is not None:
+            ctx.mark_non_differentiable(gs_idx)
+            return tuple(imgs) + (gs_idx,)
+        return tuple(imgs) + (None,)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        fb: FrameBatch = ctx.fb
+        xyz, scales, uquats, opacity, extr_c = ctx.saved_tensors[:5]
+        feats = ctx.saved_tensors[5:]
+        meta, sink = ctx.meta, (ctx.sink or {})
+        lib, st = L.lib(), L.stream()
+        F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
+        dev = fb.dev
+        widths = [1 if m[0] == "depth" else m[0] for m in meta]
+        dL = torch.cat([(g if g is not None else torch.zeros(F, w, H, W, dtype=torch.float32, device=dev))
+                        for g, w in zip(grads[:len(meta)], widths)], dim=1).contiguous()
+        like = {"xyz": xyz, "scales": scales, "uquats": uquats, "opacity": opacity}
+        bufs = {k: (sink[k] if k in sink else torch.zeros_like(v)) for k, v in like.items()}   # every set accumulates
+        dfe = []
+        op_fs = 0 if opacity.numel() == P else P
+        from .gs.raster_ops import _debug_T_front
+        c0, fi = 0, 0
+        for si, ((w, bg, detach, taps), g) in enumerate(zip(meta, grads[:len(meta)])):
+            cn = widths[si]
+            is_depth = w == "depth"
+            dfeat = None
+            if not is_depth:
+                dfeat = torch.zeros_like(feats[fi]) if g is not None and ctx.needs_input_grad[12 + fi] else None
+                dfe.append(dfeat)
+                fi += 1
+            if g is not None:
+                want_abs = 1 if (taps and fb.want_abs) else 0
+                ncp = int(lib.splat_blend_pair_stride(cn, want_abs, 0))
+                rec = fb._set_buffer(("rec", si), F * cap * ncp)
+                pack = fb._set_buffer(("pack", si), F * P * int(lib.splat_blend_pack_floats(cn)))
+                L.check(lib.splat_alpha_blending_backward_batch_set(
+                    L.ci(F), L.ci(P), L.ci(C), L.ci(c0), L.ci(cn), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity),
+                    ctypes.c_int64(op_fs), L.ptr(ctx.row), ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range),
+                    ctypes.c_int64(cap), L.cf(bg), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(dL),
+                    L.ci(want_abs), L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(_debug_T_front(F * H, W, dev)), st))
+                L.check(lib.splat_frames_gauss_backward_static_set(
+                    L.ci(F), L.ci(P), L.ci(cn), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ci(want_abs), L.ptr(rec), L.ptr(fb.goff),
+                    L.ptr(fb.radius), L.ptr(xyz), L.ptr(scales), L.ptr(uquats), L.ptr(extr_c), L.ci(1), L.ptr(bufs["xyz"]),
+                    L.ptr(bufs["scales"]), L.ptr(bufs["uquats"]), L.ptr(bufs["opacity"]), L.ptr(dfeat), L.ci(cn),
+                    L.ci(1 if detach else 0), L.ci(0 if is_depth else -1), L.ptr(fb.tap if taps else None),
+                    L.ptr(fb.abs_tap if (taps and want_abs) else None), L.ptr(fb.radii_max if taps else None), st))
+            c0 += cn
+        ret = tuple(None if k in sink else bufs[k] for k in ("xyz", "scales", "uquats", "opacity"))
+        return ret + (None,) * 8 + tuple(dfe)
 
 
 class _RenderFrames(torch.autograd.Function):

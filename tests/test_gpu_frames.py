@@ -112,3 +112,75 @@ def test_batch_capacity_overflow_is_flagged_and_safe():
     assert torch.isfinite(out).all() and torch.isfinite(p["xyz"].grad).all()
     with pytest.raises(SplatError):
         B.check()
+
+
+def test_render_sets_equals_the_native_renderer_frame_by_frame():
+    """row a1 in a frame batch: rgb (enhanced K ids, ndc + abs_ndc taps) + depth (bg = 1) + 19 attribute channels
+    (opacity detached) of every frame in one set of launches, against OrthoEnhancedRenderer.render_iter frame by frame
+    (which tests/test_gpu_renderer_native.py / test_gpu_renderer_flow.py tie to the reference's call sequence)."""
+    from splatter_a_video_amd.renderer import OrthoEnhancedRenderer
+    N, W, H, F, K = 9000, 192, 128, 3, 20
+    sc = make_scene(N, W, H, seed=15)
+    rng = np.random.default_rng(3)
+    off = _t(_offsets(sc, F))
+    attrs_np = rng.uniform(-1, 1, size=(N, 19)).astype(np.float32)
+    rgb_np = rng.uniform(0, 1, size=(N, 3)).astype(np.float32)
+    g_rgb, g_dep, g_att = (_t(rng.normal(size=(F, c, H, W)).astype(np.float32)) for c in (3, 1, 19))
+    extr = _t(sc.extr)
+
+    def params():
+        return {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity, rgb=rgb_np,
+                                                attrs=attrs_np).items()}
+
+    # ---- reference path: the native per-frame renderer
+    pa = params()
+    R = OrthoEnhancedRenderer(densify_abs_grad_enable=True)
+    imgs, taps, gids, radii = [], [], [], []
+    for f in range(F):
+        r = R.render_iter(H, W, extr, pa["xyz"] + off[f], pa["opacity"], pa["scales"], pa["uquats"], None, num_idx=K, rgb=pa["rgb"],
+                          render_attributes={"mask_attribute": pa["attrs"][:, :1], "dino_attribute": pa["attrs"][:, 1:]})
+        fs = r["rendered_features_split"]
+        att = torch.cat([fs["mask_attribute"], fs["dino_attribute"]], 0)
+        torch.autograd.backward([fs["rgb"], fs["depth"], att], [g_rgb[f], g_dep[f], g_att[f]])
+        imgs.append((fs["rgb"].detach(), fs["depth"].detach(), att.detach()))
+        taps.append(r["viewspace_points"].grad.clone()); gids.append(r["gs_idx"]); radii.append(r["radii"])
+
+    # ---- frame batch
+    pb = params()
+    B = FrameBatch(F, N, W, H, 23, "cuda", want_abs=True)
+    sets = [dict(feature=pb["rgb"], bg=0.0, taps=True), dict(feature="depth", bg=1.0),
+            dict(feature=pb["attrs"], bg=0.0, detach_opacity=True)]
+    o_rgb, o_dep, o_att, gs_idx = B.render_sets(pb["xyz"], pb["scales"], pb["uquats"], pb["opacity"], sets, off, extr, K=K)
+    assert o_rgb.shape == (F, 3, H, W) and o_dep.shape == (F, 1, H, W) and o_att.shape == (F, 19, H, W) and gs_idx.shape == (F, H, W, K)
+    for f in range(F):
+        assert torch.equal(o_rgb[f], imgs[f][0]) and torch.equal(o_dep[f], imgs[f][1]) and torch.equal(o_att[f], imgs[f][2])
+        assert torch.equal(gs_idx[f], gids[f])
+    torch.autograd.backward([o_rgb, o_dep, o_att], [g_rgb, g_dep, g_att])
+    torch.cuda.synchronize()
+    B.check()
+    for k in pa:
+        a, b = pb[k].grad, pa[k].grad
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-5 * float(b.abs().max()) + 1e-12), k
+    want_tap = sum(taps)             # abs_ndc taps (densify_abs_grad_enable)
+    assert torch.allclose(B.abs_tap, want_tap, rtol=1e-3, atol=1e-5 * float(want_tap.abs().max()))
+    assert torch.equal(B.radii_max, torch.stack(radii).max(0).values)
+
+
+def test_render_sets_skips_sets_without_gradient():
+    N, W, H, F = 3000, 96, 64, 2
+    sc = make_scene(N, W, H, seed=2)
+    off = _t(_offsets(sc, F))
+    p = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity).items()}
+    rgb = _t(np.random.default_rng(0).uniform(size=(N, 3)).astype(np.float32), True)
+    B = FrameBatch(F, N, W, H, 4, "cuda")
+    o_rgb, o_dep, gi = B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"],
+                                     [dict(feature=rgb, taps=True), dict(feature="depth", bg=1.0)], off, _t(sc.extr))
+    assert gi is None
+    o_rgb.sum().backward()           # the depth image is unused: its set launches nothing
+    ref = FrameBatch(F, N, W, H, 3, "cuda")
+    q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    rgb2 = rgb.detach().clone().requires_grad_(True)
+    ref.render(q["xyz"], q["scales"], q["uquats"], q["opacity"], rgb2, off, _t(sc.extr)).sum().backward()
+    for k in p:
+        assert torch.allclose(p[k].grad, q[k].grad, rtol=1e-4, atol=1e-6 * float(q[k].grad.abs().max()) + 1e-12), k
+    assert torch.allclose(rgb.grad, rgb2.grad, rtol=1e-4, atol=1e-6)
