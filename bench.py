@@ -102,7 +102,7 @@ def parse():
     ap.add_argument("--ops", action="store_true", help="per-operator chain through autograd")
     ap.add_argument("--dynamic", action="store_true",
                     help="parameterise the scene as the reference's dynamic Gaussians and run their per-frame evaluation "
-                         "inside the fused preprocess (row a15 on the path; per-frame operators)")
+                         "inside the fused preprocess (row a15 on the path; frame batch, or per-frame operators with --per-frame)")
     ap.add_argument("--render-iter", action="store_true",
                     help="the reference's real frame (row a1, dptr_ortho_enhanced.py:205-383): rgb through alpha_blending_enhanced "
                          "(K = 20, ndc + abs_ndc taps), depth (bg = 1) and 19 attribute channels (opacity detached) per frame, "
@@ -122,7 +122,7 @@ class FrameRenderer:
 
     def __init__(self, sc, device, frames, C_extra=0, mode="batch", dynamic=False, stale_overlap=False, optimizer=True):
         self.sc = sc
-        self.mode = "frame" if dynamic else mode
+        self.mode = mode
         self.dynamic = dynamic
         self.capacity = None      # pair capacity of the sync-free sort (learned on the first frame)
         self.sort_status = []
@@ -189,7 +189,7 @@ class FrameRenderer:
             if self.C > 32:
                 raise SystemExit("the frame batch composites at most 32 channels per call")
             self.batch = FrameBatch(self.F, N, self.W, self.H, self.C, device)
-            self.off_all = torch.stack(self.offs).contiguous()
+            self.off_all = None if dynamic else torch.stack(self.offs).contiguous()
             self.dL_all = self.dL_dout.unsqueeze(0).repeat(self.F, 1, 1, 1).contiguous()
         self.last = {}
 
@@ -205,6 +205,19 @@ class FrameRenderer:
         p = self.p
         g = {k: self.bucket.grad(k) for k in p}
         feat = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"]) if self.use_sh else p["feature"]
+        if self.dynamic:
+            from splatter_a_video_amd.dynamics import SEGMENT_MAJOR
+            sink = {k: g[k] for k in ("pos_cubic_node", "rotation", "opacity", "scaling")}
+            if not self.use_sh:
+                sink["feature"] = g["feature"]
+            out = self.batch.render_dynamic(self.clock, self.frames, self.extr, feat, position=self.position,
+                                            pos_cubic_node=p["pos_cubic_node"], rotation=p["rotation"],
+                                            rot_poly_feat=self.rot_poly, rot_fourier_feat=self.rot_fourier, opacity=p["opacity"],
+                                            scaling=p["scaling"], cubic_layout=SEGMENT_MAJOR, bg=self.sc.bg, nearest=0.01,
+                                            grad_sink=sink)
+            out.backward(self.dL_all)
+            self.last = dict(M=self.last.get("M", 0), T=self.batch.T)
+            return
         sink = {"xyz": g["xyz"], "scales": g["scale"], "uquats": g["rotate"], "opacity": g["opacity"]}
         if not self.use_sh:
             sink["feature"] = g["feature"]
@@ -434,7 +447,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    mode = ("render_iter_frame" if a.per_frame else "render_iter") if a.render_iter else "ops" if a.ops else "frame" if (a.per_frame or a.dynamic) else "batch"
+    mode = ("render_iter_frame" if a.per_frame else "render_iter") if a.render_iter else "ops" if a.ops else "frame" if a.per_frame else "batch"
     clip = max(a.clip, 25 * world)
     sc = make_scene(a.gaussians, a.width, a.height, F=clip, C=a.channels, seed=1234)
     # rank r renders frames {f : f mod world == r} of the step's frame batch
@@ -546,7 +559,9 @@ def main():
                                    + (", Adam step on the flat parameter buffer" if R.opt is not None else ""),
                        "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
                        "tile_pairs_M": M, "channels": R.C, "parallelism": par,
-                       "path": ("dynamic-Gaussian evaluation fused into the per-frame preprocess + gradient sinks" if R.dynamic else
+                       "path": ("frame batch of the reference's dynamic Gaussians: their per-frame evaluation inside the batched "
+                                "preprocess, the Gaussian-side backward walks all frames" if (R.dynamic and mode == "batch") else
+                                "dynamic-Gaussian evaluation fused into the per-frame preprocess + gradient sinks" if R.dynamic else
                                 "render_iter of the reference's renderer (rgb enhanced K=20 + depth + 19 attribute channels per "
                                 "frame), native OrthoEnhancedRenderer, per-frame operators" if mode == "render_iter_frame" else
                                 "render_iter of the reference's renderer (rgb enhanced K=20 + depth + 19 attribute channels per frame) "

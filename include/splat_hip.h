@@ -373,6 +373,28 @@ int splat_frames_gauss_backward_static_set(int F, int P, int cn, int W, int H, i
                                            int skip_opacity, int depth_channel, float *tap, float *abs_tap,
                                            int32_t *radii_max, splat_stream_t stream);
 
+/* Frame batch of DYNAMIC Gaussians (rows a15 + f1: the per-frame evaluation of the reference's spline point cloud inside
+ * the preprocess, for all frames of a batch at once).  tab: F entries of 64 bytes in DEVICE memory, one per frame:
+ * {int32 seg; float d; float basis[12]; float pad[2]} (segment index, offset inside it, t'^0..3, cos / sin(t' l pi)).
+ * Forward: uv / depth / conic / radius [F,P,..], opa_t [P] (sigmoid(opacity): frame independent).
+ * Backward (after splat_alpha_blending_backward_batch): one quad per Gaussian walks all frames -- sums the frame's pair
+ * records, re-evaluates position / rotation of that frame, projection + EWA + cov3d backward, activations -- and ADDS
+ * the parameter gradients into d_* (zero-filled or gradient sinks; d_cubic in the table's layout, only the segments
+ * the batch touches). */
+int splat_frame_preprocess_forward_batch(int F, int P, int I, const void *tab, const float *position, const float *cubic,
+                                         int cubic_layout, const float *rotation, const float *rot_poly,
+                                         const float *rot_fourier, const float *opacity, const float *scaling,
+                                         const float *extr, int W, int H, float nearest, float extent, float *uv,
+                                         float *depth, float *conic, int32_t *radius, float *opa_t, splat_stream_t stream);
+int splat_frames_gauss_backward_dynamic(int F, int P, int I, int C, int W, int H, int64_t capacity, int want_abs,
+                                        const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
+                                        const void *tab, const float *position, const float *cubic, int cubic_layout,
+                                        const float *rotation, const float *rot_poly, const float *rot_fourier,
+                                        const float *opacity, const float *scaling, const float *extr, float *d_position,
+                                        float *d_cubic, float *d_rotation, float *d_opacity, float *d_scaling,
+                                        float *d_feature, float *tap, float *abs_tap, int32_t *radii_max,
+                                        splat_stream_t stream);
+
 /* ---- optimiser step of the frame-sharded data-parallel renderer: replaces the per-group
  *      torch.optim.Adam.step() the reference reaches through src/pointrix/optimizer/optimizer.py:70-83 (Adam built in
  *      atlas_gs_optimizer / configs with eps = 1e-15, one learning rate per parameter group), as one launch over the

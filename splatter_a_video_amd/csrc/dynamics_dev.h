@@ -53,10 +53,43 @@ __device__ __forceinline__ float quat_component(int n, int j, const DynBasis &b,
 }
 
 
+// the same with the lane's table rows already in registers (frame loops: the frozen tables are read once per Gaussian)
+struct QuatRows {
+    float rot;          // rotation[n][j]
+    float4 rp, f0, f1;  // rot_poly[n][j][:], rot_fourier[n][j][:], rot_fourier[n][4 + j][:]
+};
+__device__ __forceinline__ QuatRows load_quat_rows(int n, int j, const float *rotation, const float4 *rot_poly,
+                                                   const float4 *rot_fourier) {
+    QuatRows r;
+    r.rot = rotation[(size_t)n * 4 + j];
+    r.rp = rot_poly[(size_t)n * 4 + j];
+    r.f0 = rot_fourier[(size_t)n * 8 + j];
+    r.f1 = rot_fourier[(size_t)n * 8 + 4 + j];
+    return r;
+}
+__device__ __forceinline__ float quat_component_rows(const QuatRows &r, int j, const DynBasis &b) {
+    const float wp = b.poly[j], w0 = b.fourier[j], w1 = b.fourier[4 + j];
+    float4 part;
+    part.x = r.rp.x * wp + r.f0.x * w0 + r.f1.x * w1;
+    part.y = r.rp.y * wp + r.f0.y * w0 + r.f1.y * w1;
+    part.z = r.rp.z * wp + r.f0.z * w0 + r.f1.z * w1;
+    part.w = r.rp.w * wp + r.f0.w * w0 + r.f1.w * w1;
+    return r.rot + quad_transpose_sum(part, j);
+}
+
 // ---- host side
 // SPLAT_CUBIC_GAUSSIAN_MAJOR: the reference's [N,4,I,3]; SPLAT_CUBIC_SEGMENT_MAJOR: [I,N,4,3], one contiguous
 // 48-byte record per Gaussian and frame
-static inline CubicAddr cubic_addr(int layout, int P, int I, int seg) {
+// per-frame scalars of a frame batch, one entry per frame in device memory (built on the host from the clip's knots:
+// segment index, offset inside the segment, the 12 time-basis values)
+struct DynTab {
+    int seg;
+    float d;
+    float basis[12];
+    float pad[2];  // 64-byte entries
+};
+
+__host__ __device__ static inline CubicAddr cubic_addr(int layout, int P, int I, int seg) {
     CubicAddr a;
     if (layout == SPLAT_CUBIC_SEGMENT_MAJOR) {
         a.seg_off = (size_t)seg * (size_t)P * 12;

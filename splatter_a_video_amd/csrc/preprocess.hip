@@ -149,6 +149,43 @@ __device__ __forceinline__ DynFrame dyn_frame(int n, int j, const CubicAddr &ca,
     return f;
 }
 
+// frame-loop form: position row, log-scale and the rotation table rows stay in registers across the frames
+struct DynStatic {
+    float pos_j, scl_j;  // position[n][j], exp(scaling[n][j])  (j < 3)
+    QuatRows rows;
+};
+__device__ __forceinline__ DynStatic dyn_static(int n, int j, const float *position, const float *rotation,
+                                                const float4 *rot_poly, const float4 *rot_fourier, const float *scaling) {
+    DynStatic s;
+    s.pos_j = j < 3 ? position[(size_t)n * 3 + j] : 0.f;
+    s.scl_j = j < 3 ? expf(scaling[(size_t)n * 3 + j]) : 0.f;
+    s.rows = load_quat_rows(n, j, rotation, rot_poly, rot_fourier);
+    return s;
+}
+__device__ __forceinline__ DynFrame dyn_frame_rows(int n, int j, const CubicAddr &ca, float d, const DynBasis &b,
+                                                   const DynStatic &st, const float *cubic) {
+    float pj = 0.f;
+    if (j < 3) {
+        const float *c = cubic + ca.seg_off + (size_t)n * ca.stride_n + j;
+        const size_t row = ca.stride_k;
+        const float c0 = c[0], c1 = c[row], c2 = c[2 * row], c3 = c[3 * row];
+        float p = c3 + c2 * d;
+        p = p + c1 * (d * d);
+        p = p + c0 * (d * d * d);
+        pj = p + st.pos_j;
+    }
+    const float qj = quat_component_rows(st.rows, j, b);
+    const float nr = sqrtf(quad_sum(qj * qj));
+    const float qn = qj / fmaxf(nr, 1e-12f);
+    DynFrame f;
+    f.pos[0] = quad_bcast<0>(pj); f.pos[1] = quad_bcast<1>(pj); f.pos[2] = quad_bcast<2>(pj);
+    f.scl[0] = quad_bcast<0>(st.scl_j); f.scl[1] = quad_bcast<1>(st.scl_j); f.scl[2] = quad_bcast<2>(st.scl_j);
+    f.q[0] = quad_bcast<0>(qn); f.q[1] = quad_bcast<1>(qn); f.q[2] = quad_bcast<2>(qn); f.q[3] = quad_bcast<3>(qn);
+    f.qraw[0] = quad_bcast<0>(qj); f.qraw[1] = quad_bcast<1>(qj); f.qraw[2] = quad_bcast<2>(qj); f.qraw[3] = quad_bcast<3>(qj);
+    f.nrm = nr;
+    return f;
+}
+
 __global__ void __launch_bounds__(DYN_BLOCK)
 frame_preprocess_fwd_kernel(int P, CubicAddr ca, float d, DynBasis b, const float *__restrict__ position,
                             const float *__restrict__ cubic, const float *__restrict__ rotation,
@@ -409,6 +446,228 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
     }
 }
 
+// ------------------------------------------------------------------ frame batch of DYNAMIC Gaussians (rows a15 + f1)
+// Forward: frame_preprocess_fwd_kernel with the frame as grid.y and the per-frame scalars read from a device table.
+__global__ void __launch_bounds__(DYN_BLOCK)
+frame_preprocess_fwd_batch_kernel(int F, int P, int I, int layout, const DynTab *__restrict__ tab, const float *__restrict__ position,
+                                  const float *__restrict__ cubic, const float *__restrict__ rotation,
+                                  const float4 *__restrict__ rot_poly, const float4 *__restrict__ rot_fourier,
+                                  const float *__restrict__ opacity, const float *__restrict__ scaling,
+                                  const float *__restrict__ extr, int W, int H, float nearest, float extent,
+                                  float *__restrict__ uv, float *__restrict__ depth, float *__restrict__ conic,
+                                  int *__restrict__ radius, float *__restrict__ opa_t) {
+    // one quad per Gaussian loops over the frames of its slice (grid.y slices of the batch keep the chip full): the
+    // frozen rotation tables (192 B), position and scale are read once, only the 48-byte spline segment per frame
+    const int t = blockIdx.x * DYN_BLOCK + threadIdx.x;
+    const int n = t >> 2, j = t & 3;
+    if (n >= P) return;  // whole quads leave together
+    const DynStatic stc = dyn_static(n, j, position, rotation, rot_poly, rot_fourier, scaling);
+    Cam c;
+    load_cam(nullptr, extr, c);
+    const int per = (F + gridDim.y - 1) / gridDim.y;
+    const int f0 = blockIdx.y * per, f1 = imin_(F, f0 + per);
+    if (blockIdx.y == 0 && j == 3) opa_t[n] = 1.0f / (1.0f + expf(-opacity[n]));  // frame independent
+    for (int f = f0; f < f1; ++f) {
+        const DynTab tb = tab[f];
+        DynBasis b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b.poly[k] = tb.basis[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b.fourier[k] = tb.basis[4 + k];
+        const CubicAddr ca = cubic_addr(layout, P, I, tb.seg);
+        const DynFrame fr = dyn_frame_rows(n, j, ca, tb.d, b, stc, cubic);
+        float u, v, dep;
+        const bool cull = project_ortho_pt(c, fr.pos[0], fr.pos[1], fr.pos[2], W, H, nearest, extent, u, v, dep);
+        u = cull ? 0.f : u; v = cull ? 0.f : v; dep = cull ? 0.f : dep;
+        float o[3] = {0.f, 0.f, 0.f};
+        int orad = 0, otiles = 0;
+        if (dep != 0.f) {
+            float c3[6], a[3], bb[3], tt[3], Jm[4], cov[3];
+            cov3d_pt(fr.scl, fr.q, c3);
+            ewa_T<true>(c, fr.pos, W, H, a, bb, tt, Jm);
+            ewa_cov2d<true>(a, bb, c3, cov);
+            ewa_finish_pt<true>(cov, make_float2(u, v), W, H, o[0], o[1], o[2], orad, otiles);
+        }
+        const size_t fn = (size_t)f * P + n;
+        if (j < 2) uv[fn * 2 + j] = j == 0 ? u : v;
+        if (j < 3) conic[fn * 3 + j] = j == 0 ? o[0] : j == 1 ? o[1] : o[2];
+        if (j == 2) depth[fn] = dep;
+        if (j == 3) radius[fn] = orad;
+    }
+}
+
+// Backward: one quad per Gaussian walks ALL frames: per frame it sums the Gaussian's pair records (lane `sub` owns the
+// record chunks sub, sub + 4, ..), re-evaluates the frame's position / rotation (dyn_frame), runs projection + EWA +
+// cov3d backward and chains through the activations -- scale = exp, rotation = normalize(raw + detached sums), opacity =
+// sigmoid, position = base + cubic segment.  Everything accumulates in registers; the spline segment's four coefficient
+// rows are flushed when the walk leaves the segment (frames of a batch are time-ordered: a handful of flushes).
+struct GaussDynArgs {
+    int F, P, W, H, I, layout;
+    int C, cn;
+    long long cap;
+    const float *pair;
+    const int *goff;
+    const int *radius;
+    const DynTab *tab;
+    const float *position, *cubic, *rotation;
+    const float4 *rot_poly, *rot_fourier;
+    const float *opacity, *scaling, *extr;
+    float *d_position, *d_cubic, *d_rotation, *d_opacity, *d_scaling, *d_feature;  // d_cubic / d_* are ADDED to
+    float *tap, *abs_tap;
+    int *radii_max;
+};
+
+template <bool ABS, int NCP>
+__global__ void __launch_bounds__(256)
+frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
+    constexpr int NG = GradLayout<ABS, false>::NG;
+    constexpr int NQ = NCP / 4, NS = (NQ + 3) / 4;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int n = t >> 2, j = t & 3;
+    if (n >= A.P) return;
+    float4 atot[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) atot[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    Cam cam;
+    load_cam(nullptr, A.extr, cam);
+    const DynStatic stc = dyn_static(n, j, A.position, A.rotation, A.rot_poly, A.rot_fourier, A.scaling);
+    float acc_c[4] = {0.f, 0.f, 0.f, 0.f};  // gradient of the active segment's coefficient rows c0..c3, component j
+    float d_pos = 0.f, d_rot = 0.f, d_scl = 0.f, tap_u = 0.f, tap_v = 0.f, atap_u = 0.f, atap_v = 0.f;
+    int cur_seg = -1, rmax = 0;
+    auto flush = [&](int seg) {
+        if (seg < 0 || !A.d_cubic || j >= 3) return;
+        const CubicAddr ca = cubic_addr(A.layout, A.P, A.I, seg);
+        float *c = A.d_cubic + ca.seg_off + (size_t)n * ca.stride_n + j;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k * ca.stride_k] += acc_c[k];
+    };
+    for (int f = 0; f < A.F; ++f) {
+        const int *goff = A.goff + (size_t)f * A.P;
+        const int beg = n > 0 ? goff[n - 1] : 0, end = goff[n];
+        if (A.radii_max && j == 0) rmax = imax_(rmax, A.radius[(size_t)f * A.P + n]);
+        if (end <= beg) continue;  // quad-uniform
+        float4 af[NS];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) af[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *base = A.pair + (size_t)f * (size_t)A.cap * NCP + 4 * j;
+        for (int r = beg; r < end; ++r) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                if (4 * c + j < NQ) {
+                    const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)r * NCP + 16 * c);
+                    af[c].x += v.x; af[c].y += v.y; af[c].z += v.z; af[c].w += v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            atot[c].x += af[c].x; atot[c].y += af[c].y; atot[c].z += af[c].z; atot[c].w += af[c].w;
+        }
+        const float ux = quad_bcast<0>(af[0].x), uy = quad_bcast<0>(af[0].y);
+        const float g3[3] = {quad_bcast<0>(af[0].z), quad_bcast<0>(af[0].w), quad_bcast<1>(af[0].x)};
+        tap_u += ux; tap_v += uy;
+        if (ABS) {
+            atap_u += quad_bcast<1>(af[0].z); atap_v += quad_bcast<1>(af[0].w);
+        }
+        const DynTab tb = A.tab[f];
+        if (tb.seg != cur_seg) {
+            flush(cur_seg);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc_c[k] = 0.f;
+            cur_seg = tb.seg;
+        }
+        DynBasis b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b.poly[k] = tb.basis[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b.fourier[k] = tb.basis[4 + k];
+        const CubicAddr ca = cubic_addr(A.layout, A.P, A.I, tb.seg);
+        const DynFrame fr = dyn_frame_rows(n, j, ca, tb.d, b, stc, A.cubic);
+        float gp[3], ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+        project_ortho_grad_pt(cam, A.W, A.H, ux, uy, 0.f, gp);
+        {
+            float c3[6], ea[3], eb[3], et[3], Jm[4], cov[3];
+            cov3d_pt(fr.scl, fr.q, c3);
+            ewa_T<true>(cam, fr.pos, A.W, A.H, ea, eb, et, Jm);
+            ewa_cov2d<true>(ea, eb, c3, cov);
+            const float det = cov[0] * cov[2] - cov[1] * cov[1];
+            if (det != 0.0f) {
+                float dcx, dcy, dcz, g6[6];
+                ewa_grad_cov_pt(ea, eb, cov, det, g3, dcx, dcy, dcz, g6);
+                cov3d_grad_pt(fr.scl, fr.q, g6, ds, dq);
+            }
+        }
+        if (j < 3) {
+            const float g = j == 0 ? gp[0] : j == 1 ? gp[1] : gp[2];
+            const float d = tb.d;
+            d_pos += g;
+            acc_c[0] += g * (d * d * d); acc_c[1] += g * (d * d); acc_c[2] += g * d; acc_c[3] += g;
+            const float dsj = j == 0 ? ds[0] : j == 1 ? ds[1] : ds[2];
+            const float sj = j == 0 ? fr.scl[0] : j == 1 ? fr.scl[1] : fr.scl[2];
+            d_scl += dsj * sj;
+        }
+        {
+            const float gq = j == 0 ? dq[0] : j == 1 ? dq[1] : j == 2 ? dq[2] : dq[3];
+            float r;
+            if (fr.nrm < 1e-12f) {
+                r = gq / 1e-12f;
+            } else {
+                const float dot = fr.q[0] * dq[0] + fr.q[1] * dq[1] + fr.q[2] * dq[2] + fr.q[3] * dq[3];
+                const float qh = j == 0 ? fr.q[0] : j == 1 ? fr.q[1] : j == 2 ? fr.q[2] : fr.q[3];
+                r = (gq - qh * dot) / fr.nrm;
+            }
+            d_rot += r;
+        }
+    }
+    flush(cur_seg);
+    if (j < 3) {
+        if (A.d_position) A.d_position[(size_t)n * 3 + j] += d_pos;
+        if (A.d_scaling) A.d_scaling[(size_t)n * 3 + j] += d_scl;
+    }
+    if (A.d_rotation) A.d_rotation[(size_t)n * 4 + j] += d_rot;
+    const float dop = quad_bcast<1>(atot[0].y);
+    if (j == 3) {
+        if (A.d_opacity) {
+            const float s = 1.0f / (1.0f + expf(-A.opacity[n]));
+            A.d_opacity[n] += dop * s * (1.0f - s);
+        }
+        if (A.tap) {
+            A.tap[2 * n] = tap_u * (0.5f * (float)A.W);
+            A.tap[2 * n + 1] = tap_v * (0.5f * (float)A.H);
+        }
+        if (ABS && A.abs_tap) {
+            A.abs_tap[2 * n] = atap_u * (0.5f * (float)A.W);
+            A.abs_tap[2 * n + 1] = atap_v * (0.5f * (float)A.H);
+        }
+    }
+    if (j == 0 && A.radii_max) A.radii_max[n] = rmax;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        if (4 * c + j < NQ) {
+            const int k0 = 16 * c + 4 * j;
+            const float v[4] = {atot[c].x, atot[c].y, atot[c].z, atot[c].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = k0 + e - NG;
+                if (ch >= 0 && ch < A.cn && A.d_feature) A.d_feature[(size_t)n * A.C + ch] += v[e];
+            }
+        }
+    }
+}
+
+template <bool ABS>
+int launch_gauss_bwd_dynamic(const GaussDynArgs &A, int ncp, hipStream_t s) {
+    const dim3 grid((unsigned)(((size_t)A.P * 4 + 255) / 256)), block(256);
+#define GD(N) case N: SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_dynamic_kernel<ABS, N>), grid, block, 0, s, A); break
+    switch (ncp) {
+        GD(8); GD(12); GD(16); GD(20); GD(24); GD(28); GD(32); GD(36); GD(40);
+        default: splat_set_error("gauss_bwd: unsupported record stride %d", ncp); return SPLAT_E_ARG;
+    }
+#undef GD
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
 template <bool ABS>
 int launch_gauss_bwd_static(const GaussBwdArgs &A, int ncp, hipStream_t s) {
     const dim3 grid((unsigned)(((size_t)A.P * 4 + 255) / 256)), block(256);
@@ -595,4 +854,58 @@ extern "C" int splat_frame_preprocess_backward(int P, int I, int seg, float d, c
                      d_rotation, d_opacity, d_scaling);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
+}
+
+
+// ---- frame batch of dynamic Gaussians (SURVEY 8 rows a15 + f1): `tab` = F entries {int seg; float d; float basis[12];
+// float pad[2]} (64 bytes each) in DEVICE memory, one per frame; cubic in either layout; outputs [F,P,..], opa_t [P].
+extern "C" int splat_frame_preprocess_forward_batch(int F, int P, int I, const void *tab, const float *position,
+                                                    const float *cubic, int cubic_layout, const float *rotation,
+                                                    const float *rot_poly, const float *rot_fourier, const float *opacity,
+                                                    const float *scaling, const float *extr, int W, int H, float nearest,
+                                                    float extent, float *uv, float *depth, float *conic, int32_t *radius,
+                                                    float *opa_t, void *stream) {
+    SPLAT_CHECK_ARG(F >= 1 && F <= 65535 && P >= 1 && I >= 1 && W > 0 && H > 0, "bad sizes");
+    SPLAT_CHECK_ARG(cubic_layout == SPLAT_CUBIC_GAUSSIAN_MAJOR || cubic_layout == SPLAT_CUBIC_SEGMENT_MAJOR, "unknown cubic_layout");
+    SPLAT_CHECK_ARG(tab && position && cubic && rotation && rot_poly && rot_fourier && opacity && scaling && extr, "null input pointer");
+    SPLAT_CHECK_ARG(uv && depth && conic && radius && opa_t, "null output pointer");
+    const dim3 g = dyn_grid(P);
+    // frames per thread: as many as keep >= ~4096 workgroups in flight
+    int slices = (int)((4096 + g.x - 1) / g.x);
+    if (slices < 1) slices = 1;
+    if (slices > F) slices = F;
+    SPLAT_LAUNCH("frame_preprocess_fwd", frame_preprocess_fwd_batch_kernel, dim3(g.x, slices), dim3(DYN_BLOCK), 0, (hipStream_t)stream,
+                 F, P, I, cubic_layout, (const DynTab *)tab, position, cubic, rotation, (const float4 *)rot_poly,
+                 (const float4 *)rot_fourier, opacity, scaling, extr, W, H, nearest, extent, uv, depth, conic, radius, opa_t);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_frames_gauss_backward_dynamic(int F, int P, int I, int C, int W, int H, int64_t capacity, int want_abs,
+                                                   const float *pair_records, const int32_t *goff_incl,
+                                                   const int32_t *radius, const void *tab, const float *position,
+                                                   const float *cubic, int cubic_layout, const float *rotation,
+                                                   const float *rot_poly, const float *rot_fourier, const float *opacity,
+                                                   const float *scaling, const float *extr, float *d_position,
+                                                   float *d_cubic, float *d_rotation, float *d_opacity, float *d_scaling,
+                                                   float *d_feature, float *tap, float *abs_tap, int32_t *radii_max,
+                                                   void *stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && I >= 1 && C >= 1 && C <= 32 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 32)");
+    SPLAT_CHECK_ARG(cubic_layout == SPLAT_CUBIC_GAUSSIAN_MAJOR || cubic_layout == SPLAT_CUBIC_SEGMENT_MAJOR, "unknown cubic_layout");
+    SPLAT_CHECK_ARG(pair_records && goff_incl && tab && position && cubic && rotation && rot_poly && rot_fourier && opacity &&
+                        scaling && extr,
+                    "null input pointer");
+    SPLAT_CHECK_ARG(!abs_tap || want_abs, "abs_tap needs records with the abs sums");
+    SPLAT_CHECK_ARG(!radii_max || radius, "radii_max needs the per-frame radius");
+    GaussDynArgs A;
+    memset(&A, 0, sizeof(A));
+    A.F = F; A.P = P; A.W = W; A.H = H; A.I = I; A.layout = cubic_layout; A.C = C; A.cn = C; A.cap = capacity;
+    A.pair = pair_records; A.goff = goff_incl; A.radius = radius; A.tab = (const DynTab *)tab;
+    A.position = position; A.cubic = cubic; A.rotation = rotation; A.rot_poly = (const float4 *)rot_poly;
+    A.rot_fourier = (const float4 *)rot_fourier; A.opacity = opacity; A.scaling = scaling; A.extr = extr;
+    A.d_position = d_position; A.d_cubic = d_cubic; A.d_rotation = d_rotation; A.d_opacity = d_opacity; A.d_scaling = d_scaling;
+    A.d_feature = d_feature; A.tap = tap; A.abs_tap = abs_tap; A.radii_max = radii_max;
+    const int ncp = (int)splat_blend_pair_stride(C, want_abs, 0);
+    return want_abs ? launch_gauss_bwd_dynamic<true>(A, ncp, (hipStream_t)stream)
+                    : launch_gauss_bwd_dynamic<false>(A, ncp, (hipStream_t)stream);
 }

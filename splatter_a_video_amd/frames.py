@@ -108,6 +108,11 @@ class FrameBatch:
         L.check(lib.splat_preprocess_ortho_forward_batch(
             L.ci(F_), L.ci(P_), L.ptr(xyz), L.ptr(offsets), L.ptr(scales), L.ptr(uquats), L.ptr(extr), L.ci(W), L.ci(H),
             L.cf(nearest), L.cf(extent), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.conic), L.ptr(self.radius), st))
+        self._bin_and_sort()
+
+    def _bin_and_sort(self):
+        lib, st = L.lib(), L.stream()
+        F_, P_, W, H = self.F, self.P, self.W, self.H
         L.check(lib.splat_bin_count_batch(L.ci(F_), L.ci(P_), L.ptr(self.uv), L.ptr(self.radius), L.ci(W), L.ci(H),
                                           L.ptr(self.bin_scratch), L.ptr(self.tile_range), L.ptr(self.pairs), st))
         if self.capacity is None:      # first batch: size the pair buffers (the only host sync of the object's life)
@@ -163,6 +168,41 @@ class FrameBatch:
                                    float(extent), sink)
 
 
+    # ------------------------------------------------------------------ dynamic Gaussians (rows a15 + f1)
+    def frame_table(self, clock, times) -> Tensor:
+        """device table of the per-frame scalars (segment, offset inside it, time bases) of ``times`` (cached)"""
+        key = (id(clock), tuple(float(t) for t in times))
+        cache = self.__dict__.setdefault("_tables", {})
+        tab = cache.get(key)
+        if tab is None:
+            import numpy as np
+            if len(times) != self.F:
+                raise ValueError(f"the batch holds {self.F} frames")
+            host = np.zeros((self.F, 16), np.float32)
+            for f, t in enumerate(times):
+                seg, d, basis = clock.scalars(t)
+                host[f, 0] = np.array([seg], np.int32).view(np.float32)[0]
+                host[f, 1] = d
+                host[f, 2:14] = np.frombuffer(basis, dtype=np.float32, count=12)
+            tab = torch.from_numpy(host).to(self.dev)
+            cache[key] = tab
+        return tab
+
+    def render_dynamic(self, clock, times, extr: Tensor, feature: Tensor, *, position: Tensor, pos_cubic_node: Tensor,
+                       rotation: Tensor, rot_poly_feat: Tensor, rot_fourier_feat: Tensor, opacity: Tensor, scaling: Tensor,
+                       cubic_layout: int = 1, bg: float = 0.0, nearest: float = 0.01, extent: float = 1.3,
+                       grad_sink: Optional[Dict[str, Tensor]] = None) -> Tensor:
+        """images [F,C,H,W] of the reference's dynamic Gaussians (spline position, normalised rotation with the detached
+        polynomial / Fourier sums, sigmoid opacity, exp scale: src/dynamic_gaussian_with_base_point_cloud.py:171-250) at the
+        frame times ``times`` of ``clock``, evaluated inside the batched preprocess.  Differentiable w.r.t. position,
+        pos_cubic_node, rotation, opacity, scaling and feature; ``grad_sink`` as in ``render``."""
+        tab = self.frame_table(clock, times)
+        sink = check_sink(grad_sink, {"position": position, "pos_cubic_node": pos_cubic_node, "rotation": rotation,
+                                      "opacity": opacity, "scaling": scaling, "feature": feature})
+        return _RenderDynamic.apply(position, pos_cubic_node, rotation, opacity, scaling, feature, rot_poly_feat, rot_fourier_feat,
+                                    extr, tab, self, int(clock.interval_num), int(cubic_layout), float(bg), float(nearest),
+                                    float(extent), sink)
+
     # ------------------------------------------------------------------ several feature sets of one geometry (row a1)
     def render_sets(self, xyz: Tensor, scales: Tensor, uquats: Tensor, opacity: Tensor, sets, offsets: Optional[Tensor],
                     extr: Tensor, K: int = 0, nearest: float = 0.01, extent: float = 1.3,
@@ -186,6 +226,67 @@ class FrameBatch:
         res = _RenderSets.apply(xyz, scales, uquats, opacity, offsets, extr, self, meta, int(K), float(nearest), float(extent),
                                 sink, *feats)
         return res
+
+
+class _RenderDynamic(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, position, cubic, rotation, opacity, scaling, feature, rot_poly, rot_fourier, extr, tab, fb, I, layout, bg,
+                nearest, extent, sink):
+        P, F = fb.P, fb.F
+        position = _points(position, "position", 3)
+        rotation = _points(rotation, "rotation", 4)
+        scaling = _points(scaling, "scaling", 3)
+        opacity = L.need(opacity, "opacity")
+        cubic = L.need(cubic, "pos_cubic_node")
+        feature = _points(feature, "feature", fb.C)
+        rot_poly, rot_fourier = L.need(rot_poly, "rot_poly_feat"), L.need(rot_fourier, "rot_fourier_feat")
+        if cubic.numel() != P * 4 * I * 3 or rot_poly.numel() != P * 16 or rot_fourier.numel() != P * 32 or opacity.numel() != P:
+            raise ValueError("parameter shapes do not match the batch (P Gaussians, I spline segments)")
+        extr_c = _extr12(extr)
+        lib, st = L.lib(), L.stream()
+        W, H, C = fb.W, fb.H, fb.C
+        opa_t = torch.empty(P, 1, dtype=torch.float32, device=fb.dev)
+        L.check(lib.splat_frame_preprocess_forward_batch(
+            L.ci(F), L.ci(P), L.ci(I), L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(layout), L.ptr(rotation), L.ptr(rot_poly),
+            L.ptr(rot_fourier), L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c), L.ci(W), L.ci(H), L.cf(nearest), L.cf(extent),
+            L.ptr(fb.uv), L.ptr(fb.depth), L.ptr(fb.conic), L.ptr(fb.radius), L.ptr(opa_t), st))
+        fb._bin_and_sort()
+        cap = fb.capacity
+        out = torch.empty(F, C, H, W, dtype=torch.float32, device=fb.dev)
+        L.check(lib.splat_alpha_blending_forward_batch(
+            L.ci(F), L.ci(P), L.ci(C), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opa_t), ctypes.c_int64(0), L.ptr(feature),
+            ctypes.c_int64(0), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.cf(bg), L.ptr(None), L.ci(W),
+            L.ci(H), L.ci(0), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(None), L.ptr(fb.pack), st))
+        ctx.fb, ctx.meta, ctx.sink = fb, (I, layout, bg), sink
+        ctx.save_for_backward(position, cubic, rotation, opacity, scaling, feature, rot_poly, rot_fourier, extr_c, tab)
+        return out
+
+    @staticmethod
+    def backward(ctx, dL_dout):
+        fb: FrameBatch = ctx.fb
+        position, cubic, rotation, opacity, scaling, feature, rot_poly, rot_fourier, extr_c, tab = ctx.saved_tensors
+        I, layout, bg = ctx.meta
+        sink = ctx.sink or {}
+        g = L.need(dL_dout, "dL_dout")
+        lib, st = L.lib(), L.stream()
+        F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
+        from .gs.raster_ops import _debug_T_front
+        L.check(lib.splat_alpha_blending_backward_batch(
+            L.ci(F), L.ci(P), L.ci(C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.cf(bg), L.ci(W), L.ci(H),
+            L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(g), L.ci(1 if fb.want_abs else 0), L.ptr(fb.slot_sorted),
+            L.ptr(fb.pair_records), L.ptr(fb.pack), L.ptr(_debug_T_front(F * H, W, g.device)), st))
+        like = {"position": position, "pos_cubic_node": cubic, "rotation": rotation, "opacity": opacity, "scaling": scaling,
+                "feature": feature}
+        need = dict(zip(like, ctx.needs_input_grad[:6]))
+        bufs = {k: (sink[k] if k in sink else (torch.zeros_like(v) if need[k] else None)) for k, v in like.items()}
+        L.check(lib.splat_frames_gauss_backward_dynamic(
+            L.ci(F), L.ci(P), L.ci(I), L.ci(C), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ci(1 if fb.want_abs else 0),
+            L.ptr(fb.pair_records), L.ptr(fb.goff), L.ptr(fb.radius), L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(layout),
+            L.ptr(rotation), L.ptr(rot_poly), L.ptr(rot_fourier), L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c),
+            L.ptr(bufs["position"]), L.ptr(bufs["pos_cubic_node"]), L.ptr(bufs["rotation"]), L.ptr(bufs["opacity"]),
+            L.ptr(bufs["scaling"]), L.ptr(bufs["feature"]), L.ptr(fb.tap), L.ptr(fb.abs_tap), L.ptr(fb.radii_max), st))
+        ret = tuple(None if (k in sink or bufs[k] is None) else bufs[k] for k in like)
+        return ret + (None,) * 11
 
 
 class _RenderSets(torch.autograd.Function):

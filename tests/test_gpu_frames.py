@@ -184,3 +184,67 @@ def test_render_sets_skips_sets_without_gradient():
     for k in p:
         assert torch.allclose(p[k].grad, q[k].grad, rtol=1e-4, atol=1e-6 * float(q[k].grad.abs().max()) + 1e-12), k
     assert torch.allclose(rgb.grad, rgb2.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("layout", ["segment_major", "gaussian_major"])
+def test_dynamic_batch_equals_per_frame_dynamic_path(layout):
+    """rows a15 + f1 in a frame batch: the reference's dynamic Gaussians evaluated inside the batched preprocess, the
+    Gaussian-side backward walking all frames -- against the per-frame fused path (dynamics.frame_preprocess -> sort ->
+    blend), which tests/test_gpu_dynamic.py pins to the oracle and to the reference's getters."""
+    from splatter_a_video_amd.dynamics import GAUSSIAN_MAJOR, SEGMENT_MAJOR, FrameClock, frame_preprocess, to_segment_major
+    N, W, H, T, C = 5000, 128, 96, 30, 3
+    times = [0, 3, 4, 5, 17, 29]
+    F = len(times)
+    sc = make_scene(N, W, H, F=T, seed=23)
+    rng = np.random.default_rng(9)
+    clock = FrameClock(T)
+    I = clock.interval_num
+    lay = SEGMENT_MAJOR if layout == "segment_major" else GAUSSIAN_MAJOR
+    cub = (0.01 * rng.normal(size=(N, 4 * I * 3))).astype(np.float32)
+    cub_t = to_segment_major(torch.as_tensor(cub), I).numpy() if lay == SEGMENT_MAJOR else cub
+    op = np.clip(sc.opacity, 1e-4, 1 - 1e-4)
+    base = dict(position=sc.xyz, pos_cubic_node=cub_t, rotation=sc.rotate + 0.1 * rng.normal(size=(N, 4)).astype(np.float32),
+                opacity=np.log(op / (1 - op)).astype(np.float32), scaling=np.log(sc.scale).astype(np.float32),
+                feature=rng.uniform(size=(N, C)).astype(np.float32))
+    rot_poly = _t((0.02 * rng.normal(size=(N, 4, 4))).astype(np.float32))
+    rot_four = _t((0.02 * rng.normal(size=(N, 8, 4))).astype(np.float32))
+    g = _t(rng.normal(size=(F, C, H, W)).astype(np.float32))
+    extr = _t(sc.extr)
+
+    pa = {k: _t(v, True) for k, v in base.items()}
+    ref_imgs, ref_tap = [], 0
+    for f, t in enumerate(times):
+        uv, depth, conic, radius, tiles, opa = frame_preprocess(
+            clock, t, extr, W, H, position=pa["position"], pos_cubic_node=pa["pos_cubic_node"], rotation=pa["rotation"],
+            rot_poly_feat=rot_poly, rot_fourier_feat=rot_four, opacity=pa["opacity"], scaling=pa["scaling"], nearest=0.01,
+            cubic_layout=lay)
+        idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        ndc = torch.zeros_like(uv, requires_grad=True)
+        img = gs.alpha_blending(uv, conic, opa, pa["feature"], idx, tr, 0.1, W, H, ndc)
+        (img * g[f]).sum().backward()
+        ref_imgs.append(img.detach()); ref_tap = ref_tap + ndc.grad
+
+    pb = {k: _t(v, True) for k, v in base.items()}
+    B = FrameBatch(F, N, W, H, C, "cuda")
+    out = B.render_dynamic(clock, times, extr, pb["feature"], position=pb["position"], pos_cubic_node=pb["pos_cubic_node"],
+                           rotation=pb["rotation"], rot_poly_feat=rot_poly, rot_fourier_feat=rot_four, opacity=pb["opacity"],
+                           scaling=pb["scaling"], cubic_layout=lay, bg=0.1)
+    # (the frame-loop kernels keep the table rows in registers: same formulas, different FMA contraction -> not bit-equal)
+    assert torch.allclose(out, torch.stack(ref_imgs), rtol=1e-4, atol=1e-5)
+    with capture_T_front() as cap:
+        out.backward(g)
+    torch.cuda.synchronize()
+    B.check()
+    assert float((cap.maps[0] - 1).abs().max()) < 2e-4
+    for k in pa:
+        a, b = pb[k].grad, pa[k].grad
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-5 * float(b.abs().max()) + 1e-12), k
+    assert torch.allclose(B.tap, ref_tap, rtol=1e-3, atol=1e-5 * float(ref_tap.abs().max()))
+    # gradient sinks: the same gradients land in caller-owned buffers
+    pc = {k: _t(v, True) for k, v in base.items()}
+    sink = {k: torch.zeros_like(v) for k, v in pc.items()}
+    B.render_dynamic(clock, times, extr, pc["feature"], position=pc["position"], pos_cubic_node=pc["pos_cubic_node"],
+                     rotation=pc["rotation"], rot_poly_feat=rot_poly, rot_fourier_feat=rot_four, opacity=pc["opacity"],
+                     scaling=pc["scaling"], cubic_layout=lay, bg=0.1, grad_sink=sink).backward(g)
+    for k in pc:
+        assert pc[k].grad is None and torch.allclose(sink[k], pb[k].grad, rtol=1e-5, atol=1e-7 * float(pb[k].grad.abs().max()) + 1e-12), k
