@@ -50,6 +50,10 @@ class SplatError(RuntimeError):
     pass
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
@@ -87,10 +91,6 @@ def ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
-_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-_cur_device = getattr(torch._C, "_cuda_getDevice", None)
-
-
 def stream() -> ctypes.c_void_p:
     """the current HIP stream of the current device (raw handle).  torch.cuda.current_stream() builds a Stream object
     through several Python layers (~10 us per call, once per native launch); the raw getter is one C call."""
@@ -113,6 +113,10 @@ def need(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
         raise TypeError(f"{name} must be a torch.Tensor")
     if not t.is_cuda:
         raise ValueError(f"{name} must be a CUDA (ROCm) tensor")
+    if _cur_device is not None and t.device.index != _cur_device():
+        # kernels are launched on the CURRENT device's stream (stream() below): a tensor of another device would be
+        # dereferenced there.  One process drives one GPU (frame-sharded DP); otherwise wrap the call in torch.cuda.device(...)
+        raise ValueError(f"{name} lives on cuda:{t.device.index} but the current device is cuda:{_cur_device()}")
     if t.dtype != dtype:
         if dtype == torch.uint8 and t.dtype == torch.bool:
             t = t.contiguous().view(torch.uint8)

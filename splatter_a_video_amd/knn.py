@@ -4,7 +4,8 @@
 (reference: src/geometry_utils.py:17-19 -- ``knn_points(points[None], points[None], None, None, K=K+1)``; pytorch3d is an
 un-vendored CUDA dependency without a ROCm build): batched point sets ``[B, N, 3]``, result fields ``dists`` (squared
 Euclidean, ascending), ``idx`` (int64) and ``knn`` (None unless ``return_nn``).  Uniform-grid search, exact; ties between
-equal distances resolve to the smaller index.  There is no CPU fallback.
+equal distances resolve to the smaller index.  ``dists`` (and ``knn``) carry gradients to ``p1`` / ``p2`` when those
+require grad, as pytorch3d's do.  There is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -65,9 +66,14 @@ def knn_points(p1: Tensor, p2: Tensor, lengths1: Optional[Tensor] = None, length
         db, ib = _knn_single(p1c[b], p2c[b], K)
         d.append(db); i.append(ib)
     dists, idx = torch.stack(d), torch.stack(i)
+    if (p1.requires_grad or p2.requires_grad) and torch.is_grad_enabled():
+        # pytorch3d's dists are differentiable w.r.t. both point sets (the neighbour choice is not): rebuild them from
+        # the gathered neighbours through autograd; the search itself ran on detached coordinates
+        gathered = torch.stack([p2[b][idx[b].clamp(min=0)] for b in range(p1.shape[0])])
+        dists = ((p1[:, :, None, :] - gathered) ** 2).sum(-1)
     nn = None
     if return_nn:
-        nn = torch.stack([p2c[b][idx[b].clamp(min=0)] for b in range(p1c.shape[0])])
+        nn = torch.stack([p2[b][idx[b].clamp(min=0)] for b in range(p1.shape[0])])
     return KNN(dists=dists, idx=idx, knn=nn)
 
 

@@ -85,3 +85,21 @@ def test_distCUDA2_is_mean_of_three_nearest():
     od, _ = oracle.knn_points(pts, pts, 4)
     np.testing.assert_allclose(got, od[:, 1:].mean(axis=1), rtol=3e-6, atol=1e-12)
     assert (got > 0).all()
+
+
+def test_knn_dists_are_differentiable():
+    """pytorch3d.ops.knn_points returns dists that carry gradients to both point sets (the reference builds its
+    ARAP weights from them, src/geometry_utils.py:17-38)"""
+    import torch
+    from splatter_a_video_amd.knn import knn_points
+    g = torch.Generator(device="cpu").manual_seed(0)
+    p = torch.rand(1, 500, 3, generator=g).cuda().requires_grad_(True)
+    out = knn_points(p, p, None, None, K=4)
+    assert out.dists.requires_grad
+    out.dists[..., 1:].sum().backward()
+    ref = p.detach().clone().requires_grad_(True)
+    d = ((ref[0][:, None, :] - ref[0][out.idx[0]]) ** 2).sum(-1)
+    d[:, 1:].sum().backward()
+    assert torch.allclose(p.grad, ref.grad, rtol=1e-5, atol=1e-7)
+    with torch.no_grad():
+        assert not knn_points(p, p, None, None, K=2).dists.requires_grad

@@ -9,16 +9,25 @@ from collections import defaultdict
 
 out, dirs = sys.argv[1], sys.argv[2:]
 KERNELS = {"blend_fwd_kernel": "blend_fwd", "blend_bwd_mfma_kernel": "blend_bwd"}
-acc = defaultdict(lambda: [0.0, 0])
+rows = []
 for d in dirs:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             for k in KERNELS:
                 if k in r["Kernel_Name"]:
-                    a = acc[(k, r["Counter_Name"])]
-                    a[0] += float(r["Counter_Value"]); a[1] += 1
-res = {"source": "rocprofv3 --pmc, three passes of tools/blend_bench.py --reps 2 (300k Gaussians, 854x480, 3 channels), per launch, "
-                 "summed over the 8 XCDs; SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES in quad-cycles (guides/MI355X_MICROARCH.md)",
+                    rows.append((k, int(r.get("Grid_Size", 0) or 0), r["Counter_Name"], float(r["Counter_Value"])))
+big = defaultdict(int)          # only the largest launches of a kernel are the workload (a tiny set-up scene runs first)
+for k, g, _, _ in rows:
+    big[k] = max(big[k], g)
+acc = defaultdict(lambda: [0.0, 0])
+for k, g, c, v in rows:
+    if g == big[k]:
+        a = acc[(k, c)]
+        a[0] += v; a[1] += 1
+import os
+res = {"source": os.environ.get("PMC_SOURCE", "rocprofv3 --pmc, three passes, per launch (largest launches of each kernel), summed over the 8 "
+                 "XCDs; SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES in quad-cycles (guides/MI355X_MICROARCH.md)"),
+       "config": os.environ.get("PMC_CONFIG"),
        "kernels": {}}
 SIMDS, WAVE_SLOTS, XCDS = 1024, 256 * 16, 8
 for k in KERNELS:
