@@ -350,6 +350,43 @@ int splat_frames_gauss_backward_static(int F, int P, int C, int W, int H, int64_
                                        float *d_feature, float *tap, float *abs_tap, int32_t *radii_max,
                                        splat_stream_t stream);
 
+/* One call per direction for a whole batch (static Gaussians + per-frame offsets, orthographic camera, one feature set):
+ * the sequences above behind a single crossing of the ABI.  splat_frames_t holds every pointer; set struct_bytes =
+ * sizeof(splat_frames_t).  splat_frames_count = preprocess + pair counts (pairs[F], device) to size `capacity` before the
+ * first splat_frames_forward; forward = preprocess, binning, sort, pack, compositing; backward = tile kernels +
+ * Gaussian-side reduction (accumulate: add into the parameter gradients). */
+typedef struct splat_frames_t {
+    size_t struct_bytes;
+    int32_t F, P, W, H, C;
+    int32_t want_abs, accumulate;
+    int64_t capacity;                 /* pairs reserved per frame */
+    float nearest, extent, bg;
+    splat_stream_t stream;
+    /* scene (shared by the frames) + per-frame offsets [F,P,3] */
+    const float *xyz, *offsets, *scales, *uquats, *opacity, *feature, *extr;
+    /* per-frame geometry [F,P,..] */
+    float *uv, *depth, *conic;
+    int32_t *radius;
+    /* binning / sort */
+    void *bin_scratch;                /* F * splat_bin_scratch_bytes(P, W, H) */
+    int32_t *tile_range, *pairs, *overflow, *goff_incl, *owner, *idx_sorted, *slot_sorted;
+    uint64_t *keys;
+    /* compositing */
+    float *pack;                      /* F * P * splat_blend_pack_floats(C) */
+    float *out, *final_T;             /* [F,C,H,W], [F,H,W] */
+    int32_t *ncontrib;
+    /* backward */
+    const float *dL_dout;             /* [F,C,H,W] */
+    float *pair_records;              /* F * capacity * splat_blend_pair_stride(C, want_abs, 0) */
+    float *d_xyz, *d_scales, *d_uquats, *d_opacity, *d_feature;
+    float *tap, *abs_tap;             /* optional [P,2] */
+    int32_t *radii_max;               /* optional [P] */
+    float *dbg_T_front;               /* optional [F,H,W] */
+} splat_frames_t;
+int splat_frames_count(const splat_frames_t *batch);
+int splat_frames_forward(const splat_frames_t *batch);
+int splat_frames_backward(const splat_frames_t *batch);
+
 /* Several feature SETS of one geometry in a frame batch -- the reference renderer's three blends (rgb through
  * alpha_blending_enhanced with the taps; depth, bg = 1; the extra attributes with opacity.detach(),
  * dptr_ortho_enhanced.py:331-375): ONE forward over the concatenated row [F,P,C] (splat_alpha_blending_forward_batch with

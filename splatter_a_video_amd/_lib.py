@@ -41,6 +41,7 @@ SYMBOLS = [
     "splat_preprocess_ortho_forward_batch", "splat_bin_count_batch", "splat_bin_sort_batch",
     "splat_alpha_blending_forward_batch", "splat_blend_pair_stride", "splat_alpha_blending_backward_batch",
     "splat_frame_preprocess_forward_batch", "splat_frames_gauss_backward_dynamic",
+    "splat_frames_count", "splat_frames_forward", "splat_frames_backward",
     "splat_frames_gauss_backward_static", "splat_alpha_blending_backward_batch_set", "splat_frames_gauss_backward_static_set",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]

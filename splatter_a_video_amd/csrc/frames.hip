@@ -1,0 +1,44 @@
+// One call per direction for a whole frame batch (SURVEY 7 stage 6): the sequences FrameBatch (frames.py) composes from the
+// *_batch entry points, for callers that want a single crossing of the C ABI per gradient step -- static Gaussians +
+// per-frame offsets under the orthographic camera, one feature set.  Every buffer is caller-owned (splat_frames_t holds
+// the pointers); nothing is allocated, nothing synchronises with the host.
+#include "common.h"
+
+extern "C" int splat_frames_forward(const splat_frames_t *b) {
+    SPLAT_CHECK_ARG(b != nullptr && b->struct_bytes == sizeof(splat_frames_t), "splat_frames_t of another ABI version");
+    SPLAT_CHECK_ARG(b->capacity >= 1, "capacity (pairs reserved per frame) must be set: run splat_frames_count first");
+    int rc = splat_preprocess_ortho_forward_batch(b->F, b->P, b->xyz, b->offsets, b->scales, b->uquats, b->extr, b->W, b->H,
+                                                  b->nearest, b->extent, b->uv, b->depth, b->conic, b->radius, b->stream);
+    if (rc != SPLAT_OK) return rc;
+    rc = splat_bin_count_batch(b->F, b->P, b->uv, b->radius, b->W, b->H, b->bin_scratch, b->tile_range, b->pairs, b->stream);
+    if (rc != SPLAT_OK) return rc;
+    rc = splat_bin_sort_batch(b->F, b->P, b->uv, b->depth, b->radius, b->W, b->H, b->bin_scratch, b->tile_range, b->capacity,
+                              b->keys, b->idx_sorted, b->overflow, b->goff_incl, b->owner, b->slot_sorted, b->stream);
+    if (rc != SPLAT_OK) return rc;
+    return splat_alpha_blending_forward_batch(b->F, b->P, b->C, b->uv, b->conic, b->opacity, 0, b->feature, 0, b->idx_sorted,
+                                              b->tile_range, b->capacity, b->bg, nullptr, b->W, b->H, 0, 0, b->out, b->final_T,
+                                              b->ncontrib, nullptr, b->pack, b->stream);
+}
+
+// geometry + pair counts only: pairs[F] (device) tells the caller how much capacity to reserve before the first
+// splat_frames_forward
+extern "C" int splat_frames_count(const splat_frames_t *b) {
+    SPLAT_CHECK_ARG(b != nullptr && b->struct_bytes == sizeof(splat_frames_t), "splat_frames_t of another ABI version");
+    int rc = splat_preprocess_ortho_forward_batch(b->F, b->P, b->xyz, b->offsets, b->scales, b->uquats, b->extr, b->W, b->H,
+                                                  b->nearest, b->extent, b->uv, b->depth, b->conic, b->radius, b->stream);
+    if (rc != SPLAT_OK) return rc;
+    return splat_bin_count_batch(b->F, b->P, b->uv, b->radius, b->W, b->H, b->bin_scratch, b->tile_range, b->pairs, b->stream);
+}
+
+extern "C" int splat_frames_backward(const splat_frames_t *b) {
+    SPLAT_CHECK_ARG(b != nullptr && b->struct_bytes == sizeof(splat_frames_t), "splat_frames_t of another ABI version");
+    SPLAT_CHECK_ARG(b->dL_dout && b->pair_records, "null pointer");
+    int rc = splat_alpha_blending_backward_batch(b->F, b->P, b->C, b->idx_sorted, b->tile_range, b->capacity, b->bg, b->W, b->H,
+                                                 b->final_T, b->ncontrib, b->dL_dout, b->want_abs, b->slot_sorted,
+                                                 b->pair_records, b->pack, b->dbg_T_front, b->stream);
+    if (rc != SPLAT_OK) return rc;
+    return splat_frames_gauss_backward_static(b->F, b->P, b->C, b->W, b->H, b->capacity, b->want_abs, b->pair_records,
+                                              b->goff_incl, b->radius, b->xyz, b->scales, b->uquats, b->extr, b->accumulate,
+                                              b->d_xyz, b->d_scales, b->d_uquats, b->d_opacity, b->d_feature, b->tap, b->abs_tap,
+                                              b->radii_max, b->stream);
+}

@@ -9,7 +9,9 @@ the compositing kernels see F x T tiles in one launch (no half-empty last round 
 gradients as F calls of the per-frame operators (tests/test_gpu_frames.py).
 
 ``FrameBatch`` owns the batch's device buffers (allocated once, ~140 MB per 480p frame of 300k Gaussians); ``render`` is
-autograd-aware.  No CPU fallback.
+autograd-aware and crosses the C ABI ONCE per direction (``splat_frames_forward`` / ``splat_frames_backward``: the struct
+``splat_frames_t`` carries every pointer); ``render_sets`` / ``render_dynamic`` compose the ``*_batch`` entry points.
+No CPU fallback.
 """
 from __future__ import annotations
 
@@ -22,6 +24,23 @@ from torch import Tensor
 from . import _lib as L
 from .gs.fused_ops import check_sink
 from .gs.point_ops import _extr12, _points
+
+
+_FRAMES_FIELDS = ([("struct_bytes", ctypes.c_size_t)]
+                  + [(n, ctypes.c_int32) for n in ("F", "P", "W", "H", "C", "want_abs", "accumulate")]
+                  + [("capacity", ctypes.c_int64)] + [(n, ctypes.c_float) for n in ("nearest", "extent", "bg")]
+                  + [("stream", ctypes.c_void_p)]
+                  + [(n, ctypes.c_void_p) for n in (
+                      "xyz", "offsets", "scales", "uquats", "opacity", "feature", "extr", "uv", "depth", "conic", "radius",
+                      "bin_scratch", "tile_range", "pairs", "overflow", "goff_incl", "owner", "idx_sorted", "slot_sorted", "keys",
+                      "pack", "out", "final_T", "ncontrib", "dL_dout", "pair_records", "d_xyz", "d_scales", "d_uquats",
+                      "d_opacity", "d_feature", "tap", "abs_tap", "radii_max", "dbg_T_front")])
+
+
+class _SplatFrames(ctypes.Structure):
+    """mirror of splat_frames_t (include/splat_hip.h): every pointer of a batch, for the one-call entry points (the
+    library checks ``struct_bytes`` against its own sizeof)"""
+    _fields_ = _FRAMES_FIELDS
 
 
 def _tiles(W: int, H: int) -> int:
@@ -123,35 +142,45 @@ class FrameBatch:
             L.ptr(self.bin_scratch), L.ptr(self.tile_range), ctypes.c_int64(cap), L.ptr(self.keys), L.ptr(self.idx_sorted),
             L.ptr(self.overflow), L.ptr(self.goff), L.ptr(self.owner), L.ptr(self.slot_sorted), st))
 
-    def _forward(self, xyz, scales, uquats, opacity, feature, offsets, extr, bg, nearest, extent, bgc=None, K=0):
-        self._geometry(xyz, scales, uquats, offsets, extr, nearest, extent)
-        lib, st = L.lib(), L.stream()
-        F_, P_, W, H, C = self.F, self.P, self.W, self.H, self.C
-        cap = self.capacity
-        out = torch.empty(F_, C, H, W, dtype=torch.float32, device=self.dev)
-        self.gs_idx = torch.empty(F_, H, W, K, dtype=torch.int32, device=self.dev) if K > 0 else None
-        op_fs = 0 if opacity.numel() == P_ else P_
-        ft_fs = 0 if feature.numel() == P_ * C else P_ * C
-        L.check(lib.splat_alpha_blending_forward_batch(
-            L.ci(F_), L.ci(P_), L.ci(C), L.ptr(self.uv), L.ptr(self.conic), L.ptr(opacity), ctypes.c_int64(op_fs),
-            L.ptr(feature), ctypes.c_int64(ft_fs), L.ptr(self.idx_sorted), L.ptr(self.tile_range), ctypes.c_int64(cap),
-            L.cf(bg), L.ptr(bgc), L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(self.final_T),
-            L.ptr(self.ncontrib), L.ptr(self.gs_idx), L.ptr(self.pack), st))
+    def _struct(self, xyz, scales, uquats, opacity, feature, offsets, extr, bg, nearest=0.01, extent=1.3) -> _SplatFrames:
+        b = _SplatFrames()
+        b.struct_bytes = ctypes.sizeof(_SplatFrames)
+        b.F, b.P, b.W, b.H, b.C = self.F, self.P, self.W, self.H, self.C
+        b.want_abs = 1 if self.want_abs else 0
+        b.capacity = self.capacity or 0
+        b.nearest, b.extent, b.bg = nearest, extent, bg
+        b.stream = L.stream()
+        dp = lambda t: None if t is None else t.data_ptr()
+        for name, t in dict(xyz=xyz, offsets=offsets, scales=scales, uquats=uquats, opacity=opacity, feature=feature, extr=extr,
+                            uv=self.uv, depth=self.depth, conic=self.conic, radius=self.radius, bin_scratch=self.bin_scratch,
+                            tile_range=self.tile_range, pairs=self.pairs, overflow=self.overflow, goff_incl=self.goff,
+                            owner=self.owner, idx_sorted=self.idx_sorted, slot_sorted=self.slot_sorted, keys=self.keys,
+                            pack=self.pack, final_T=self.final_T, ncontrib=self.ncontrib, pair_records=self.pair_records,
+                            tap=self.tap, abs_tap=self.abs_tap, radii_max=self.radii_max).items():
+            setattr(b, name, dp(t))
+        return b
+
+    def _forward_onecall(self, xyz, scales, uquats, opacity, feature, offsets, extr, bg, nearest, extent):
+        """the whole forward of the batch behind ONE crossing of the C ABI (splat_frames_forward)"""
+        lib = L.lib()
+        if self.capacity is None:      # first batch: size the pair buffers (the only host sync of the object's life)
+            L.check(lib.splat_frames_count(ctypes.byref(self._struct(xyz, scales, uquats, opacity, feature, offsets, extr, bg,
+                                                                     nearest, extent))))
+            self._reserve(int(int(self.pairs.max().item()) * self.slack) + 1024)
+        out = torch.empty(self.F, self.C, self.H, self.W, dtype=torch.float32, device=self.dev)
+        b = self._struct(xyz, scales, uquats, opacity, feature, offsets, extr, bg, nearest, extent)
+        b.out = out.data_ptr()
+        L.check(lib.splat_frames_forward(ctypes.byref(b)))
         return out
 
-    def _backward(self, dL_dout, xyz, scales, uquats, extr, bg, bufs, accumulate, dbg=None):
-        lib, st = L.lib(), L.stream()
-        F_, P_, W, H, C = self.F, self.P, self.W, self.H, self.C
-        cap = self.capacity
-        L.check(lib.splat_alpha_blending_backward_batch(
-            L.ci(F_), L.ci(P_), L.ci(C), L.ptr(self.idx_sorted), L.ptr(self.tile_range), ctypes.c_int64(cap), L.cf(bg),
-            L.ci(W), L.ci(H), L.ptr(self.final_T), L.ptr(self.ncontrib), L.ptr(dL_dout), L.ci(1 if self.want_abs else 0),
-            L.ptr(self.slot_sorted), L.ptr(self.pair_records), L.ptr(self.pack), L.ptr(dbg), st))
-        L.check(lib.splat_frames_gauss_backward_static(
-            L.ci(F_), L.ci(P_), L.ci(C), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ci(1 if self.want_abs else 0),
-            L.ptr(self.pair_records), L.ptr(self.goff), L.ptr(self.radius), L.ptr(xyz), L.ptr(scales), L.ptr(uquats),
-            L.ptr(extr), L.ci(1 if accumulate else 0), L.ptr(bufs["xyz"]), L.ptr(bufs["scales"]), L.ptr(bufs["uquats"]),
-            L.ptr(bufs["opacity"]), L.ptr(bufs["feature"]), L.ptr(self.tap), L.ptr(self.abs_tap), L.ptr(self.radii_max), st))
+    def _backward_onecall(self, dL_dout, xyz, scales, uquats, extr, bg, bufs, accumulate, dbg=None):
+        b = self._struct(xyz, scales, uquats, None, None, None, extr, bg)
+        b.accumulate = 1 if accumulate else 0
+        b.dL_dout = dL_dout.data_ptr()
+        b.d_xyz, b.d_scales, b.d_uquats = bufs["xyz"].data_ptr(), bufs["scales"].data_ptr(), bufs["uquats"].data_ptr()
+        b.d_opacity, b.d_feature = bufs["opacity"].data_ptr(), bufs["feature"].data_ptr()
+        b.dbg_T_front = None if dbg is None else dbg.data_ptr()
+        L.check(L.lib().splat_frames_backward(ctypes.byref(b)))
 
     # ------------------------------------------------------------------ public
     def render(self, xyz: Tensor, scales: Tensor, uquats: Tensor, opacity: Tensor, feature: Tensor, offsets: Optional[Tensor],
@@ -404,7 +433,7 @@ class _RenderFrames(torch.autograd.Function):
                 raise ValueError(f"offsets must be [F={F}, P={P}, 3]")
         elif F > 1:
             raise ValueError("several frames of static Gaussians need per-frame offsets")
-        out = fb._forward(xyz, scales, uquats, opacity, feature, off, extr_c, bg, nearest, extent)
+        out = fb._forward_onecall(xyz, scales, uquats, opacity, feature, off, extr_c, bg, nearest, extent)
         ctx.fb, ctx.bg, ctx.sink = fb, bg, sink
         ctx.save_for_backward(xyz, scales, uquats, opacity, feature, extr_c)
         return out
@@ -422,5 +451,5 @@ class _RenderFrames(torch.autograd.Function):
         ret = tuple(None if k in sink else bufs[k] for k in ("xyz", "scales", "uquats", "opacity", "feature"))
         from .gs.raster_ops import _debug_T_front
         dbg = _debug_T_front(fb.F * fb.H, fb.W, g.device)
-        fb._backward(g, xyz, scales, uquats, extr_c, ctx.bg, bufs, accumulate=bool(sink), dbg=dbg)
+        fb._backward_onecall(g, xyz, scales, uquats, extr_c, ctx.bg, bufs, accumulate=bool(sink), dbg=dbg)
         return ret + (None,) * 7

@@ -172,3 +172,18 @@ def test_dptr_C_shim_exports_the_reference_pybind_names():
     assert sorted(names) == sorted(_C.__all__)
     for n in names:
         assert callable(getattr(_C, n))
+
+
+def test_frames_struct_mirror_matches_the_header(built_lib):
+    """splat_frames_t (one-call frame batch): the ctypes mirror has the library's sizeof -- a struct of the right size
+    gets past the ABI check and is then refused for its missing capacity; a wrong size is refused as such"""
+    import ctypes
+    from splatter_a_video_amd.frames import _SplatFrames
+    lib = built_lib.lib()
+    b = _SplatFrames()
+    b.struct_bytes = ctypes.sizeof(_SplatFrames)
+    assert lib.splat_frames_forward(ctypes.byref(b)) != 0
+    assert b"capacity" in lib.splat_last_error()
+    b.struct_bytes = ctypes.sizeof(_SplatFrames) - 8
+    assert lib.splat_frames_forward(ctypes.byref(b)) != 0
+    assert b"ABI version" in lib.splat_last_error()
