@@ -444,6 +444,16 @@ int splat_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, 
                     const int64_t *seg_end_host, const float *seg_lr_host, float beta1, float beta2, float eps,
                     int step, float grad_scale, splat_stream_t stream);
 
+/* ---- as-rigid-as-possible energy: replaces estimate_rotation + cal_arap_error of
+ *      src/geometry_utils.py:50-123 (~50 eager launches per frame pair incl. torch.svd) by one launch.
+ *      nodes [Nt,Nv,3]; nbr [Nv,K] neighbour ids (-1: none; slot k = the reference's `nn`); weight [Nv,K] or NULL (1 per
+ *      edge); sample_idx [S] vertex ids.  energy (1 float, zero-filled by the caller) += sum over sampled vertices, frames
+ *      t >= 1 and edges of w |e_tgt - R e_src|^2 (NOT yet divided by Nt); d_nodes (optional [Nt,Nv,3], zero-filled) +=
+ *      d energy / d nodes with R held constant (the reference estimates it under no_grad); rotations (optional
+ *      [Nt-1,S,3,3]) = the rotation of every (frame, sample). ---- */
+int splat_arap_energy(int Nt, int Nv, int K, int S, const float *nodes, const int32_t *nbr, const float *weight,
+                      const int64_t *sample_idx, float *energy, float *d_nodes, float *rotations, splat_stream_t stream);
+
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */
 void splat_profile_enable(int on);
 void splat_profile_reset(void);

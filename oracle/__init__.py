@@ -510,3 +510,57 @@ def position_poly_fourier_backward(g_pos, basis):
     """-> (d_position, d_pos_poly_feat [N,4,3], d_pos_fourier_feat [N,8,3])"""
     g = _f(g_pos, (-1, 3)); b = np.asarray(basis, np.float32)
     return g.copy(), g[:, None, :] * b[None, :4, None], g[:, None, :] * b[None, 4:, None]
+
+
+# ------------------------------------------------------------------ ARAP energy (numpy restatement)
+def arap_energy(nodes, nbr, weight, sample_idx):
+    """cal_arap_error + estimate_rotation (reference: src/geometry_utils.py:50-123) in numpy float32 / LAPACK SVD:
+    nodes [Nt,Nv,3], nbr [Nv,K] (-1: none), weight [Nv,K] or None, sample_idx [S] -> (energy / Nt, d energy / d nodes with
+    the rotations held constant, rotations [Nt-1,S,3,3])"""
+    nodes = np.asarray(nodes, np.float32)
+    Nt, Nv, _ = nodes.shape
+    nbr = np.asarray(nbr)
+    K = nbr.shape[1]
+    has = nbr >= 0
+    w_all = has.astype(np.float32) if weight is None else np.asarray(weight, np.float32)
+    sidx = np.asarray(sample_idx, np.int64)
+
+    def edges(v):
+        E = np.zeros((Nv, K, 3), np.float32)
+        ii, kk = np.nonzero(has)
+        E[ii, kk] = v[ii] - v[nbr[ii, kk]]
+        return E
+
+    Es = edges(nodes[0])[sidx]
+    w = w_all[sidx]
+    total = 0.0
+    grad = np.zeros(nodes.shape, np.float64)
+    rots = np.zeros((Nt - 1, sidx.size, 3, 3), np.float32)
+    for t in range(1, Nt):
+        Et = edges(nodes[t])[sidx]
+        S = np.einsum("ski,sk,skj->sij", Es, w, Et)
+        unchanged = (Es == Et).all(axis=(1, 2))
+        S[unchanged] = 0
+        U, sig, Wt = np.linalg.svd(S.astype(np.float64))
+        W = np.transpose(Wt, (0, 2, 1))
+        R = W @ np.transpose(U, (0, 2, 1))
+        flip = np.linalg.det(R) <= 0
+        if flip.any():
+            Um = U.copy()
+            cols = np.argmin(sig[flip], axis=1)
+            idxs = np.nonzero(flip)[0]
+            Um[idxs, :, cols] *= -1
+            R[flip] = W[flip] @ np.transpose(Um[flip], (0, 2, 1))
+        rots[t - 1] = R.astype(np.float32)
+        st = Et.astype(np.float64) - np.einsum("sij,skj->ski", R, Es.astype(np.float64))
+        total += float((w * (st ** 2).sum(-1)).sum())
+        gt = 2.0 * w[..., None] * st                                    # d / d e_tgt
+        gs = -2.0 * w[..., None] * np.einsum("sji,skj->ski", R, st)      # d / d e_src = -2 w R^T st
+        for s, i in enumerate(sidx):
+            for k in range(K):
+                j = nbr[i, k]
+                if j < 0:
+                    continue
+                grad[t, i] += gt[s, k]; grad[t, j] -= gt[s, k]
+                grad[0, i] += gs[s, k]; grad[0, j] -= gs[s, k]
+    return np.float32(total / Nt), (grad / Nt).astype(np.float32), rots

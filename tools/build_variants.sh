@@ -12,6 +12,6 @@ done
 wait
 for spec in "$@"; do
   name="${spec%%:*}"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libsplat_$name.so build/runtime.o build/pointwise.o build/binning.o build/dynamics.o build/preprocess.o build/densify.o build/knn.o build/optim.o build/frames.o build/blend_$name.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libsplat_$name.so build/runtime.o build/pointwise.o build/binning.o build/dynamics.o build/preprocess.o build/densify.o build/knn.o build/optim.o build/frames.o build/arap.o build/blend_$name.o
   echo built variants/libsplat_$name.so
 done
