@@ -142,3 +142,62 @@ def test_adapter_argument_errors():
     with pytest.raises(Exception, match="3D covariance"):
         rast(p["xyz"], None, p["opacity"], shs=p["shs"], scales=p["scale"], rotations=p["rotate"],
              cov3D_precomp=torch.zeros(sc.N, 6, device="cuda"))
+
+
+def test_adapter_against_the_cpu_oracle(oracle_mod):
+    """What ``GaussianRasterizer`` must return at the reference's call site (base_splatting.py:123-174), stated with the CPU
+    oracle and nothing of this package: SH colours for the directions from ``campos`` (+0.5, clamp), perspective
+    projection / cov3d / EWA, (tile, depth) order, compositing with ONE BACKGROUND PER CHANNEL (one scalar-background oracle
+    blend per channel), radii, and the gradients of every input incl. the ``means2D`` screen-space tap."""
+    from test_gpu_parity import assert_grad
+    o = oracle_mod
+    sc = make_scene(2500, 112, 80, seed=14, ortho=False)
+    cam, intr, extr = _camera(sc)
+    bg = np.array([0.15, 0.4, 0.8], np.float32)
+    rng = np.random.default_rng(2)
+    g = rng.normal(size=(3, sc.H, sc.W)).astype(np.float32)
+    q = _leaves(sc)
+    means2D = torch.zeros(sc.N, 3, device="cuda", requires_grad=True)
+    settings = _settings(sc, cam, _t(bg))
+    img, radii = GaussianRasterizer(settings)(means3D=q["xyz"], means2D=means2D, shs=q["shs"], opacities=q["opacity"],
+                                              scales=q["scale"], rotations=q["rotate"])
+    (img * _t(g)).sum().backward()
+    # ---- oracle, with the float32 camera the adapter derives from the transposed matrices
+    intr_a, extr_a = adapter_camera(settings, torch.device("cuda"))
+    intr_n, extr_n = intr_a.cpu().numpy(), np.vstack([extr_a.cpu().numpy(), [[0, 0, 0, 1]]]).astype(np.float32)
+    W, H = sc.W, sc.H
+    campos = cam["campos"].cpu().numpy()
+    uv, depth = o.project_point_forward(sc.xyz, intr_n, extr_n, W, H, 0.2)
+    vis = depth.reshape(-1) != 0
+    cov = o.compute_cov3d_forward(sc.scale, sc.rotate, vis)
+    conic, radius, tiles = o.ewa_project_forward(sc.xyz, cov, intr_n, extr_n, uv, W, H, vis)
+    d = sc.xyz - campos[None, :]
+    nrm = np.linalg.norm(d, axis=1, keepdims=True)
+    dirs = (d / nrm).astype(np.float32)
+    rgb, clamped = o.compute_sh_forward(sc.shs, 3, dirs, vis)
+    idx, tr = o.sort_gaussian(uv, depth, W, H, radius, tiles)
+    assert (radii.cpu().numpy() != radius).mean() < 1e-3
+    out = np.zeros((3, H, W), np.float32)
+    duv = np.zeros((sc.N, 2)); dcon = np.zeros((sc.N, 3)); dop = np.zeros((sc.N, 1)); drgb = np.zeros((sc.N, 3))
+    for c in range(3):
+        r = o.alpha_blending_forward(uv, conic, sc.opacity, rgb[:, c:c + 1], idx, tr, float(bg[c]), W, H)
+        out[c] = r[0][0]
+        gr = o.alpha_blending_backward(uv, conic, sc.opacity, rgb[:, c:c + 1], idx, tr, float(bg[c]), W, H, r[1], r[2], g[c:c + 1])
+        duv += gr[0]; dcon += gr[1]; dop += gr[2].reshape(-1, 1); drgb[:, c] = gr[3][:, 0]
+    bad = np.abs(img.detach().cpu().numpy() - out) > 1e-5 + 1e-4 * np.abs(out)
+    assert bad.mean() < 1e-3
+    half = np.array([[0.5 * W, 0.5 * H]])
+    assert_grad(means2D.grad[:, :2], (duv * half).astype(np.float32), "means2D tap")
+    assert_grad(q["opacity"].grad, dop.astype(np.float32), "opacity")
+    dxyz_e, dcov, _, _ = o.ewa_project_backward(sc.xyz, cov, intr_n, extr_n, radius, dcon.astype(np.float32), W, H, need_intr=False,
+                                                need_extr=False)
+    dxyz_p, _, _ = o.project_point_backward(sc.xyz, intr_n, extr_n, W, H, uv, depth, duv.astype(np.float32),
+                                            np.zeros((sc.N, 1), np.float32), need_intr=False, need_extr=False)
+    dscale, dquat = o.compute_cov3d_backward(sc.scale, sc.rotate, vis, dcov)
+    dshs, ddirs = o.compute_sh_backward(sc.shs, 3, dirs, vis, clamped, drgb.astype(np.float32))
+    # the direction depends on the position: d dirs / d xyz = (I - dir dir^T) / |d|
+    dxyz_d = (ddirs - dirs * (ddirs * dirs).sum(1, keepdims=True)) / nrm
+    assert_grad(q["scale"].grad, dscale, "scale")
+    assert_grad(q["rotate"].grad, dquat, "rotate")
+    assert_grad(q["shs"].grad, dshs, "shs")
+    assert_grad(q["xyz"].grad, (dxyz_e + dxyz_p + dxyz_d).astype(np.float32), "xyz")
