@@ -1040,6 +1040,21 @@ __device__ __forceinline__ void lds_store2_lane15(float *p, float a, float b) {
         : "memory");
 }
 
+// sum over the four 16-lane rows of a wave (lanes n, n + 16, n + 32, n + 48): two VALU-only swaps (gfx950 v_permlane16_swap /
+// v_permlane32_swap), every lane ends up with the total
+typedef unsigned u32x2_b __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rows_sum(float v, int lane) {
+    {
+        const u32x2_b r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v += __uint_as_float((lane & 16) ? r[0] : r[1]);   // value of lane ^ 16
+    }
+    {
+        const u32x2_b r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v += __uint_as_float((lane & 32) ? r[0] : r[1]);   // value of lane ^ 32
+    }
+    return v;
+}
+
 // R[i] = base[i] + (rs[i] of the previous lane of the row; 0 for lane 0): exclusive scan from the inclusive one
 __device__ __forceinline__ void row_shr1_add4(float (&R)[4], const float (&rs)[4], const float (&base)[4]) {
     asm volatile(
@@ -1061,6 +1076,10 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     constexpr int I_ABS = GradLayout<ABS, false>::I_ABS;
     __shared__ TileLDS<CH, SB> L;
     constexpr bool SHARED = Cfg::SHARED;
+    // narrow feature rows: dL_dfeature = sum_p g[p,c] w[p,n] as per-lane FMAs over the lane's own pixels + one cross-row sum
+    // per chunk, instead of four MFMAs per strip whose A operand would use 3 of its 16 rows (the matrix pipe's time is on
+    // this kernel's critical path: dropping those products saved 13 % of it, the VALU form gives back a third)
+    constexpr bool FEAT_VALU = CH <= 4;
     __shared__ float s_acc[Cfg::NSLAB][SB * NC];  // private slab per wave, or one shared slab (wide records)
     __shared__ __attribute__((aligned(16))) float s_pix[4][64 * PW];
     __shared__ float s_mom[16 * 64];         // A operand of the moment product: [step 4 G + i][lane]
@@ -1200,6 +1219,9 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
             f32x4 d_f[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float dfv[FEAT_VALU ? CH : 1];
+#pragma unroll
+            for (int c = 0; c < (FEAT_VALU ? CH : 1); ++c) dfv[c] = 0.f;
             asm volatile("" ::: "memory");  // keep the per-pixel LDS reads inside the chunk (registers, not hoisted copies)
 #pragma unroll
             for (int G = 0; G < 4; ++G) {  // strip G: four independent sub-steps, their DPP scans interleave
@@ -1248,9 +1270,17 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                     const float dLa = T[i] * cg[i] - (R[i] + Tb[i]) * r1a[i];
                     const float dLp = ok[i] ? araw[i] * dLa : 0.f;  // dL/dpower
                     d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[64 * s], dLp, d_mom, 0, 0, 0);
+                    if (FEAT_VALU) {
+                        const float4 gq = *reinterpret_cast<const float4 *>(pixrow + (16 * G + i) * PW);  // g[own pixel][0..3]
+                        dfv[0] = __builtin_fmaf(gq.x, wgt[i], dfv[0]);
+                        if (CH > 1) dfv[1 % (FEAT_VALU ? CH : 1)] = __builtin_fmaf(gq.y, wgt[i], dfv[1 % (FEAT_VALU ? CH : 1)]);
+                        if (CH > 2) dfv[2 % (FEAT_VALU ? CH : 1)] = __builtin_fmaf(gq.z, wgt[i], dfv[2 % (FEAT_VALU ? CH : 1)]);
+                        if (CH > 3) dfv[3 % (FEAT_VALU ? CH : 1)] = __builtin_fmaf(gq.w, wgt[i], dfv[3 % (FEAT_VALU ? CH : 1)]);
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < NA; ++q)
-                        d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(pixrow[(16 * G + i) * PW + gch[q]], wgt[i], d_f[q], 0, 0, 0);
+                        for (int q = 0; q < NA; ++q)
+                            d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(pixrow[(16 * G + i) * PW + gch[q]], wgt[i], d_f[q], 0, 0, 0);
+                    }
                     if (ABS) {
                         const float dx = uc - (xk + (float)i), dy = vc - (yk + (float)(2 * G));
                         d_ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cA * dx + cB * dy)), d_ax, 0, 0, 0);
@@ -1259,6 +1289,10 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                 }
             }
             // ---- chunk epilogue: lane (n, kk) holds rows 4kk..4kk+3 of every accumulator for survivor n
+            if (FEAT_VALU) {
+#pragma unroll
+                for (int c = 0; c < (FEAT_VALU ? CH : 1); ++c) dfv[c] = rows_sum(dfv[c], lane);  // over the four pixel groups
+            }
             if (j0 + nl < cnt) {
                 float *rec = slab + e * NC;
                 auto put = [](float *p, float v) {
@@ -1283,13 +1317,20 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                     const float Dy = d_mom[1], Dyy = d_mom[2];
                     put(rec + 4, -0.5f * (vc * vc * D0 - 2.f * vc * Dy + Dyy));
                 }
+                if (FEAT_VALU) {
+                    if (kk == 3) {   // (kk 0..2 write the geometry terms above)
 #pragma unroll
-                for (int q = 0; q < NA; ++q)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int c = 16 * q + 4 * kk + i;
-                        if (c < CH) put(rec + NG + c, d_f[q][i]);
+                        for (int c = 0; c < (FEAT_VALU ? CH : 1); ++c) put(rec + NG + c, dfv[c]);
                     }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NA; ++q)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int c = 16 * q + 4 * kk + i;
+                            if (c < CH) put(rec + NG + c, d_f[q][i]);
+                        }
+                }
             }
         }
         __syncthreads();
