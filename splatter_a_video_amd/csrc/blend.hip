@@ -1174,7 +1174,6 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     for (int q = 0; q < NA; ++q) gch[q] = 16 * q + nl < CH ? 16 * q + nl : PZ;  // channel row of the feature product
 #pragma unroll
     for (int j = 0; j < NK; ++j) kch[j] = 4 * j + kk < CH ? 4 * j + kk : PZ;    // K index of the cg product
-    const float a_one = nl == 0 ? 1.f : 0.f;
     const float xk = (float)(4 * (kk & 1)) - 3.5f, yk = (float)(kk >> 1) - 3.5f;  // own pixel: x = xk + i, y = yk + 2 G
 
     // reverse walk: entry e of super-batch b sits at list position n-1 - b*SB - e
@@ -1215,7 +1214,8 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
 #pragma unroll
                 for (int j = 0; j < NK; ++j) bf[j] = fr[4 * j + kk];  // padded with zeros past CH (pack_kernel)
             }
-            f32x4 d_mom = {0.f, 0.f, 0.f, 0.f}, d_ax = {0.f, 0.f, 0.f, 0.f}, d_ay = {0.f, 0.f, 0.f, 0.f};
+            f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
+            float s_ax = 0.f, s_ay = 0.f;  // |d uv| sums over the lane's own pixels (summed over the rows at the chunk's end)
             f32x4 d_f[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1236,7 +1236,7 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float4 stv = *reinterpret_cast<const float4 *>(pixrow + (16 * G + i) * PW + PS);
-                    cg[i] = cgv[i];
+                    cg[i] = cgv[i];  // (the colour dot product stays on the matrix cores: as per-lane FMAs it was 6 % slower)
                     Tb[i] = stv.x;
                     const int last = __float_as_int(stv.y);
                     Ts4[i] = stv.z;
@@ -1283,8 +1283,8 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                     }
                     if (ABS) {
                         const float dx = uc - (xk + (float)i), dy = vc - (yk + (float)(2 * G));
-                        d_ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cA * dx + cB * dy)), d_ax, 0, 0, 0);
-                        d_ay = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, fabsf(dLp * (cB * dx + cC * dy)), d_ay, 0, 0, 0);
+                        s_ax += fabsf(dLp * (cA * dx + cB * dy));
+                        s_ay += fabsf(dLp * (cB * dx + cC * dy));
                     }
                 }
             }
@@ -1292,6 +1292,10 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
             if (FEAT_VALU) {
 #pragma unroll
                 for (int c = 0; c < (FEAT_VALU ? CH : 1); ++c) dfv[c] = rows_sum(dfv[c], lane);  // over the four pixel groups
+            }
+            if (ABS) {
+                s_ax = rows_sum(s_ax, lane);
+                s_ay = rows_sum(s_ay, lane);
             }
             if (j0 + nl < cnt) {
                 float *rec = slab + e * NC;
@@ -1307,8 +1311,8 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                     put(rec + 2, -0.5f * (uc * uc * D0 - 2.f * uc * Dx + Dxx));
                     put(rec + 5, o > 0.f ? D0 / o : 0.f);
                     if (ABS) {
-                        put(rec + I_ABS, d_ax[0]);
-                        put(rec + I_ABS + 1, d_ay[0]);
+                        put(rec + I_ABS, s_ax);
+                        put(rec + I_ABS + 1, s_ay);
                     }
                 } else if (kk == 1) {
                     const float Dx = d_mom[1], Dy = d_mom[2], Dxy = d_mom[3];
