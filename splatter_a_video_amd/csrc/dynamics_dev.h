@@ -67,8 +67,9 @@ __device__ __forceinline__ QuatRows load_quat_rows(int n, int j, const float *ro
     r.f1 = rot_fourier[(size_t)n * 8 + 4 + j];
     return r;
 }
-__device__ __forceinline__ float quat_component_rows(const QuatRows &r, int j, const DynBasis &b) {
-    const float wp = b.poly[j], w0 = b.fourier[j], w1 = b.fourier[4 + j];
+// wp / w0 / w1: this lane's basis values t'^j, cos(t' (j+1) pi), sin(t' (j+1) pi) -- read per lane from the frame table
+// (a register copy of the 12 values indexed by the lane's j would live in scratch memory)
+__device__ __forceinline__ float quat_component_rows(const QuatRows &r, int j, float wp, float w0, float w1) {
     float4 part;
     part.x = r.rp.x * wp + r.f0.x * w0 + r.f1.x * w1;
     part.y = r.rp.y * wp + r.f0.y * w0 + r.f1.y * w1;

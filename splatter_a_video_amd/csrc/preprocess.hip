@@ -162,7 +162,7 @@ __device__ __forceinline__ DynStatic dyn_static(int n, int j, const float *posit
     s.rows = load_quat_rows(n, j, rotation, rot_poly, rot_fourier);
     return s;
 }
-__device__ __forceinline__ DynFrame dyn_frame_rows(int n, int j, const CubicAddr &ca, float d, const DynBasis &b,
+__device__ __forceinline__ DynFrame dyn_frame_rows(int n, int j, const CubicAddr &ca, float d, const float *basis12,
                                                    const DynStatic &st, const float *cubic) {
     float pj = 0.f;
     if (j < 3) {
@@ -174,7 +174,7 @@ __device__ __forceinline__ DynFrame dyn_frame_rows(int n, int j, const CubicAddr
         p = p + c0 * (d * d * d);
         pj = p + st.pos_j;
     }
-    const float qj = quat_component_rows(st.rows, j, b);
+    const float qj = quat_component_rows(st.rows, j, basis12[j], basis12[4 + j], basis12[8 + j]);
     const float nr = sqrtf(quad_sum(qj * qj));
     const float qn = qj / fmaxf(nr, 1e-12f);
     DynFrame f;
@@ -468,14 +468,10 @@ frame_preprocess_fwd_batch_kernel(int F, int P, int I, int layout, const DynTab 
     const int f0 = blockIdx.y * per, f1 = imin_(F, f0 + per);
     if (blockIdx.y == 0 && j == 3) opa_t[n] = 1.0f / (1.0f + expf(-opacity[n]));  // frame independent
     for (int f = f0; f < f1; ++f) {
-        const DynTab tb = tab[f];
-        DynBasis b;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) b.poly[k] = tb.basis[k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) b.fourier[k] = tb.basis[4 + k];
-        const CubicAddr ca = cubic_addr(layout, P, I, tb.seg);
-        const DynFrame fr = dyn_frame_rows(n, j, ca, tb.d, b, stc, cubic);
+        const int seg = tab[f].seg;
+        const float dd = tab[f].d;
+        const CubicAddr ca = cubic_addr(layout, P, I, seg);
+        const DynFrame fr = dyn_frame_rows(n, j, ca, dd, tab[f].basis, stc, cubic);
         float u, v, dep;
         const bool cull = project_ortho_pt(c, fr.pos[0], fr.pos[1], fr.pos[2], W, H, nearest, extent, u, v, dep);
         u = cull ? 0.f : u; v = cull ? 0.f : v; dep = cull ? 0.f : dep;
@@ -518,7 +514,7 @@ struct GaussDynArgs {
 };
 
 template <bool ABS, int NCP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
     constexpr int NG = GradLayout<ABS, false>::NG;
     constexpr int NQ = NCP / 4, NS = (NQ + 3) / 4;
@@ -569,20 +565,16 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
         if (ABS) {
             atap_u += quad_bcast<1>(af[0].z); atap_v += quad_bcast<1>(af[0].w);
         }
-        const DynTab tb = A.tab[f];
-        if (tb.seg != cur_seg) {
+        const int seg = A.tab[f].seg;
+        const float dseg = A.tab[f].d;
+        if (seg != cur_seg) {
             flush(cur_seg);
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc_c[k] = 0.f;
-            cur_seg = tb.seg;
+            cur_seg = seg;
         }
-        DynBasis b;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) b.poly[k] = tb.basis[k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) b.fourier[k] = tb.basis[4 + k];
-        const CubicAddr ca = cubic_addr(A.layout, A.P, A.I, tb.seg);
-        const DynFrame fr = dyn_frame_rows(n, j, ca, tb.d, b, stc, A.cubic);
+        const CubicAddr ca = cubic_addr(A.layout, A.P, A.I, seg);
+        const DynFrame fr = dyn_frame_rows(n, j, ca, dseg, A.tab[f].basis, stc, A.cubic);
         float gp[3], ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
         project_ortho_grad_pt(cam, A.W, A.H, ux, uy, 0.f, gp);
         {
@@ -599,7 +591,7 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
         }
         if (j < 3) {
             const float g = j == 0 ? gp[0] : j == 1 ? gp[1] : gp[2];
-            const float d = tb.d;
+            const float d = dseg;
             d_pos += g;
             acc_c[0] += g * (d * d * d); acc_c[1] += g * (d * d); acc_c[2] += g * d; acc_c[3] += g;
             const float dsj = j == 0 ? ds[0] : j == 1 ? ds[1] : ds[2];
