@@ -250,6 +250,7 @@ class FrameRenderer:
             f = r["rendered_features_split"]
             torch.autograd.backward([f["rgb"], f["depth"], f["mask_attribute"], f["dino_attribute"]],
                                     [self.dL_dout, self.dL_depth, self.dL_attr[:1], self.dL_attr[1:]])
+            self._radii = r["radii"]
         rgb.backward(rgb_in.grad)
         self.last = dict(M=self.last.get("M", 0), T=((self.W + 15) // 16) * ((self.H + 15) // 16))
 
@@ -330,6 +331,13 @@ class FrameRenderer:
         for st in self.sort_status:
             m = max(m, st.check())
         self.sort_status.clear()
+        if self.mode == "render_iter_frame" and getattr(self, "_radii", None) is not None:
+            # pairs of the last frame, re-derived from its screen-space geometry (the renderer's synchronising sort does
+            # not expose its count)
+            with torch.no_grad():
+                uv, depth, conic, radius, tiles = gs.preprocess_ortho(self.p["xyz"] + self.offs[-1], self.p["scale"], self.p["rotate"],
+                                                                      self.extr, self.W, self.H, nearest=0.01)
+                m = int(tiles.sum().item())
         if m:
             self.last["M"] = m
 
@@ -516,7 +524,16 @@ def main():
             if cnt:
                 avg = ms / cnt
                 fpl = a.frames / cnt       # frames one launch covers (1 on the per-frame paths, F in the batch)
-                b = kernel_bytes(n, a.gaussians, M, HW, R.C, T, R.use_sh, a.frames if n in per_step else 1) * fpl
+                if mode.startswith("render_iter") and n in ("blend_fwd", "blend_bwd", "blend_pack", "pair_reduce", "gauss_bwd"):
+                    # three feature sets (3 + 1 + 19 channels): one forward over the 23-channel row, one backward launch per
+                    # set -> the per-launch figure is the mean over the sets
+                    if n == "blend_fwd":
+                        b = kernel_bytes(n, a.gaussians, M, HW, 23, T, False, 1) * fpl
+                    else:
+                        b = sum(kernel_bytes(n, a.gaussians, M, HW, c, T, False, a.frames if n in per_step else 1)
+                                for c in (3, 1, 19)) / 3.0 * fpl
+                else:
+                    b = kernel_bytes(n, a.gaussians, M, HW, R.C, T, R.use_sh, a.frames if n in per_step else 1) * fpl
                 kernels[n] = {"avg_us": round(avg * 1e3, 2), "launches": cnt, "frames_per_launch": round(fpl, 2),
                               "us_per_frame": round(ms * 1e3 / a.frames, 2), "alg_MB": round(b / 1e6, 2),
                               "GBps": round(b / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}

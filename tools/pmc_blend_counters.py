@@ -42,7 +42,11 @@ for k in KERNELS:
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
             d["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * cyc), 3)
         if "SQ_WAVE_CYCLES" in c:
-            d["wave_slot_residency"] = round(4.0 * c["SQ_WAVE_CYCLES"] / (WAVE_SLOTS * cyc), 3)  # resident waves / (16 per CU)
+            # average resident waves per SIMD over the kernel's life (the kernel's own limit: 4 for blend_bwd by registers / LDS,
+            # 7 for blend_fwd); wave_slot_residency = the same relative to 4 waves per SIMD (16 per CU), kept for comparison
+            # with the round-1 record
+            d["waves_per_simd"] = round(4.0 * c["SQ_WAVE_CYCLES"] / (SIMDS * cyc), 3)
+            d["wave_slot_residency"] = round(4.0 * c["SQ_WAVE_CYCLES"] / (WAVE_SLOTS * cyc), 3)
         d["duration_cycles"] = round(cyc, 1)
     res["kernels"][KERNELS[k]] = {"counters": c, "derived": d}
 json.dump(res, open(out, "w"), indent=1)
