@@ -410,6 +410,31 @@ int splat_frames_gauss_backward_static_set(int F, int P, int cn, int W, int H, i
                                            int skip_opacity, int depth_channel, float *tap, float *abs_tap,
                                            int32_t *radii_max, splat_stream_t stream);
 
+/* The same three blends' backward in ONE pass of the tile kernels (the sets share the alpha / transmittance replay; only
+ * the routing of dL/dalpha differs: d uv, d conic <- every set; d opacity <- tap set + second set; taps <- tap set).
+ * set 0 = the tap set (<= 4 channels), set 1 = a second set blended with the live opacity (<= 4), set 2 = the set blended
+ * with opacity.detach() (<= 20); set_cn[g] = 0: no such set; the sets must tile the row's C <= 28 channels.  set_c0 /
+ * set_cn / set_bg / set_stride / set_dfeature are HOST arrays of three entries.  Pair records: stride
+ * splat_blend_sets_pair_stride(C) floats, layout [ux uy ca cb | cc o ax ay | tx ty | dL_dfeature[0..C-1]];
+ * pack_scratch: F * P * splat_blend_sets_pack_floats() floats.  Other widths / routings: the per-set calls above. */
+size_t splat_blend_sets_pair_stride(int C);
+size_t splat_blend_sets_pack_floats(void);
+int splat_alpha_blending_backward_batch_sets(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
+                                             const float *set_bg, const float *uv, const float *conic,
+                                             const float *opacity, int64_t opacity_frame_stride, const float *feature,
+                                             int64_t feature_frame_stride, const int32_t *idx_sorted,
+                                             const int32_t *tile_range, int64_t capacity, int W, int H,
+                                             const float *final_T, const int32_t *ncontrib, const float *dL_dout,
+                                             int want_abs, const int32_t *slot_sorted, float *pair_records,
+                                             float *pack_scratch, float *dbg_T_front, splat_stream_t stream);
+int splat_frames_gauss_backward_static_sets(int F, int P, int C, int W, int H, int64_t capacity, const float *pair_records,
+                                            const int32_t *goff_incl, const int32_t *radius, const float *xyz,
+                                            const float *scales, const float *uquats, const float *extr, int accumulate,
+                                            float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                            const int32_t *set_c0, const int32_t *set_cn, float *const *set_dfeature,
+                                            const int32_t *set_stride, int depth_channel /* row channel or -1 */,
+                                            float *tap, float *abs_tap, int32_t *radii_max, splat_stream_t stream);
+
 /* Frame batch of DYNAMIC Gaussians (rows a15 + f1: the per-frame evaluation of the reference's spline point cloud inside
  * the preprocess, for all frames of a batch at once).  tab: F entries of 64 bytes in DEVICE memory, one per frame:
  * {int32 seg; float d; float basis[12]; float pad[2]} (segment index, offset inside it, t'^0..3, cos / sin(t' l pi)).

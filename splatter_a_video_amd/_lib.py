@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -43,6 +43,8 @@ SYMBOLS = [
     "splat_frame_preprocess_forward_batch", "splat_frames_gauss_backward_dynamic",
     "splat_frames_count", "splat_frames_forward", "splat_frames_backward",
     "splat_frames_gauss_backward_static", "splat_alpha_blending_backward_batch_set", "splat_frames_gauss_backward_static_set",
+    "splat_blend_sets_pair_stride", "splat_blend_sets_pack_floats", "splat_alpha_blending_backward_batch_sets",
+    "splat_frames_gauss_backward_static_sets",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]
 
@@ -76,6 +78,10 @@ def lib() -> ctypes.CDLL:
         L.splat_blend_pair_floats.argtypes = [ctypes.c_int, ctypes.c_int]
         L.splat_blend_pair_stride.restype = ctypes.c_size_t
         L.splat_blend_pair_stride.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.splat_blend_sets_pair_stride.restype = ctypes.c_size_t
+        L.splat_blend_sets_pair_stride.argtypes = [ctypes.c_int]
+        L.splat_blend_sets_pack_floats.restype = ctypes.c_size_t
+        L.splat_blend_sets_pack_floats.argtypes = []
         L.splat_profile_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
         if L.splat_abi_version() != ABI_VERSION:
             raise SplatError("libsplat_hip.so ABI version mismatch; rebuild it")

@@ -52,6 +52,15 @@
 #ifndef BLEND_MFMA_MINW
 #define BLEND_MFMA_MINW 4  // 128 VGPRs: 4 workgroups per CU (what 40 KB of LDS allow as well)
 #endif
+#ifndef BLEND_WIDE_SB
+#define BLEND_WIDE_SB 64
+#endif
+#ifndef BLEND_WIDE_MINW
+#define BLEND_WIDE_MINW 1
+#endif
+#ifndef BLEND_WIDE_HOIST
+#define BLEND_WIDE_HOIST 0
+#endif
 // power is a negative-semidefinite form: it can only exceed 0 by rounding.  The matrix-core kernels evaluate it as
 // an expanded polynomial (absolute error up to ~5e-6 in log2 units), so their "power > 0" guard of the reference
 // (src/alpha_blending.cu:93) sits just above that noise; it still rejects genuinely indefinite conics.
@@ -96,6 +105,10 @@ struct BlendArgs {
     long long cap;          // pair capacity per frame: stride of idx_sorted / slot_sorted / pair_buf records
     long long pack_fs;      // floats between two frames' packed records
     long long opacity_fs, feature_fs, bias_fs;  // element strides of the per-Gaussian inputs (0: shared by all frames)
+    // several feature sets in one backward pass (blend_bwd_sets_kernel): first row channel, width and background of the
+    // tap set (0), the second set (1) and the opacity-detached set (2); width 0 = no such set
+    int s0c0, s0cn, s1c0, s1cn, s2c0, s2cn;
+    float s0bg, s1bg, s2bg;
 };
 
 // per-frame view of the argument block (all uniform: scalar address arithmetic)
@@ -997,7 +1010,7 @@ struct MfmaCfg {
     static constexpr int NG = GradLayout<ABS, false>::NG;
     static constexpr int NC = NG + CH;
     static constexpr int NCP = PAIR_STRIDE(NC);
-    static constexpr int SB = CH <= 8 ? BLEND_MFMA_SB : 64;
+    static constexpr int SB = CH <= 8 ? BLEND_MFMA_SB : (CH <= 20 ? BLEND_WIDE_SB : 64);
     static constexpr int PZ = CH;                 // a zero slot (lanes without a channel feed it to the MFMAs)
     static constexpr int PS = (CH + 1 + 3) & ~3;  // state block [T_final*bg.g, ncontrib, T_state, R_state] (16-B aligned)
     static constexpr int PW = PS + 4;             // floats per pixel record: g[CH], 0.., state block
@@ -1068,7 +1081,7 @@ __device__ __forceinline__ void row_shr1_add4(float (&R)[4], const float (&rs)[4
 }
 
 template <int CH, bool ABS, bool EXACT>
-__global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_MFMA_MINW : 1))
+__global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_MFMA_MINW : (CH <= 20 ? BLEND_WIDE_MINW : 1)))
 blend_bwd_mfma_kernel(const BlendArgs B) {
     using Cfg = MfmaCfg<CH, ABS>;
     constexpr int SB = Cfg::SB, NG = Cfg::NG, NC = Cfg::NC, NCP = Cfg::NCP, PW = Cfg::PW, NA = Cfg::NA, NK = Cfg::NK;
@@ -1176,6 +1189,23 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     for (int j = 0; j < NK; ++j) kch[j] = 4 * j + kk < CH ? 4 * j + kk : PZ;    // K index of the cg product
     const float xk = (float)(4 * (kk & 1)) - 3.5f, yk = (float)(kk >> 1) - 3.5f;  // own pixel: x = xk + i, y = yk + 2 G
 
+    // wide rows: the A operands of the colour and feature-gradient products are the same in every chunk (dL_dout of the
+    // wave's pixels) -- held in registers instead of re-read from LDS per chunk
+    constexpr bool HOIST = BLEND_WIDE_HOIST && CH > 8;
+    float hcg[HOIST ? 4 : 1][HOIST ? NK : 1], hft[HOIST ? 16 : 1][HOIST ? NA : 1], hmom[HOIST ? 16 : 1];
+    if (HOIST) {
+#pragma unroll
+        for (int G = 0; G < 4; ++G)
+#pragma unroll
+            for (int j = 0; j < NK; ++j) hcg[G][j] = pixcol[16 * G * PW + kch[j]];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) hft[s][q] = pixrow[(16 * (s >> 2) + (s & 3)) * PW + gch[q]];
+            hmom[s] = momrow[64 * s];
+        }
+    }
+
     // reverse walk: entry e of super-batch b sits at list position n-1 - b*SB - e
     auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };  // negative = past the front
     Stager<CH, SB> st;
@@ -1230,7 +1260,8 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                 pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi2[G], bq2, pw, 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < NK; ++j)
-                    cgv = __builtin_amdgcn_mfma_f32_16x16x4f32(pixcol[16 * G * PW + kch[j]], bf[j], cgv, 0, 0, 0);
+                    cgv = __builtin_amdgcn_mfma_f32_16x16x4f32(HOIST ? hcg[HOIST ? G : 0][HOIST ? j : 0] : pixcol[16 * G * PW + kch[j]],
+                                                               bf[j], cgv, 0, 0, 0);
                 float cg[4], araw[4], a[4], r1a[4], rp[4], Tb[4], Ts4[4], Rs4[4];
                 bool ok[4];
 #pragma unroll
@@ -1269,7 +1300,7 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                     const int s = 4 * G + i;
                     const float dLa = T[i] * cg[i] - (R[i] + Tb[i]) * r1a[i];
                     const float dLp = ok[i] ? araw[i] * dLa : 0.f;  // dL/dpower
-                    d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[64 * s], dLp, d_mom, 0, 0, 0);
+                    d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(HOIST ? hmom[HOIST ? s : 0] : momrow[64 * s], dLp, d_mom, 0, 0, 0);
                     if (FEAT_VALU) {
                         const float4 gq = *reinterpret_cast<const float4 *>(pixrow + (16 * G + i) * PW);  // g[own pixel][0..3]
                         dfv[0] = __builtin_fmaf(gq.x, wgt[i], dfv[0]);
@@ -1279,7 +1310,8 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                     } else {
 #pragma unroll
                         for (int q = 0; q < NA; ++q)
-                            d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(pixrow[(16 * G + i) * PW + gch[q]], wgt[i], d_f[q], 0, 0, 0);
+                            d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                HOIST ? hft[HOIST ? s : 0][HOIST ? q : 0] : pixrow[(16 * G + i) * PW + gch[q]], wgt[i], d_f[q], 0, 0, 0);
                     }
                     if (ABS) {
                         const float dx = uc - (xk + (float)i), dy = vc - (yk + (float)(2 * G));
@@ -1363,6 +1395,347 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     if (A.dbg_T_front) {  // per-pixel transmittance after the last (front-most) replayed splat: lane q <-> pixel q of the block
         const int px = bx + (lane & 7), py = by + (lane >> 3);
         if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_pix[w][lane * PW + PS + 2];
+    }
+}
+
+// ------------------------------------------------------------------ backward of several feature SETS in ONE pass
+// The reference renderer composites up to three feature sets over one geometry (reference:
+// src/pointrix/renderer/dptr_ortho_enhanced.py:331-375): the TAP set (alpha_blending_enhanced: every gradient + the ndc /
+// abs_ndc taps), a SECOND set blended with the live opacity (the depth) and a DETACHED set (alpha_blending with
+// opacity.detach(): the extra attributes).  The three share the alpha / transmittance chain and differ only in where their
+// dL/dalpha goes:
+//       d uv, d conic <- every set        d opacity <- tap + second set        taps, |taps| <- tap set
+// One replay of the chain serves all of them: a colour dot product, a behind-colour scan and a dL/dalpha per set, the moment
+// product on their sum, the opacity and tap sums as per-lane sums over the lane's own pixels (+ one cross-row sum per chunk).
+// Channel slots: [0,4) tap set | [4,8) second set | [8,28) detached set, zero padded (whole K-slabs of the cg product).
+// dL_dout of the wave's pixels lives in REGISTERS in both MFMA operand layouts (staged once through the slab memory); LDS
+// keeps the 8-float replay state of a pixel.  Pair record:
+//       [ux uy ca cb | cc o ax ay | tx ty | dL_dfeature of the row's channels 0 .. C-1]      (NG = 10, NC = 10 + C)
+struct SetsCfg {
+    static constexpr int CH = 28, NK = 7, NA = 2, SB = 64;
+    static constexpr int NG = 10, NCMAX = NG + CH;
+    static constexpr int PS = 8;  // state floats per pixel: [T_final bg.g of set 0 1 2, ncontrib | T, R of set 0 1 2]
+};
+
+// slot -> row channel (or -1): uniform selects on the kernel arguments
+__device__ __forceinline__ int sets_slot_channel(const BlendArgs &A, int slot) {
+    const int g = slot < 4 ? 0 : slot < 8 ? 1 : 2;
+    const int o = slot - (g == 0 ? 0 : g == 1 ? 4 : 8);
+    const int c0 = g == 0 ? A.s0c0 : g == 1 ? A.s1c0 : A.s2c0, cn = g == 0 ? A.s0cn : g == 1 ? A.s1cn : A.s2cn;
+    return (slot < SetsCfg::CH && o < cn) ? c0 + o : -1;
+}
+
+__global__ void __launch_bounds__(256)
+pack_sets_kernel(const BlendArgs B) {
+    const BlendArgs A = frame_args(B, blockIdx.y);
+    constexpr int CH = SetsCfg::CH, RS = Rec<CH>::RS, CO = Rec<CH>::CULL;
+    static_assert(CO >= 0, "the cull parameters ride in the record's padding");
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.P) return;
+    float r[RS];
+#pragma unroll
+    for (int k = 0; k < RS; ++k) r[k] = 0.f;
+    const float2 q = A.uv[i];
+    r[0] = q.x; r[1] = q.y;
+    r[2] = A.conic[3 * i]; r[3] = A.conic[3 * i + 1]; r[4] = A.conic[3 * i + 2];
+    r[5] = A.opacity[i];
+    r[7] = __int_as_float(i);
+    const float *f = A.feature + (size_t)i * A.C;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int c = sets_slot_channel(A, k);
+        if (c >= 0) r[8 + k] = f[c];
+    }
+    const CullP cp = cull_params(r[2], r[3], r[4], r[5]);
+    r[CO] = cp.hx; r[CO + 1] = cp.hy; r[CO + 2] = cp.tauq; r[CO + 3] = cp.ia; r[CO + 4] = cp.ic;
+    float4 *dst = reinterpret_cast<float4 *>(A.pack + (size_t)i * RS);
+#pragma unroll
+    for (int k = 0; k < RS; k += 4) dst[k / 4] = make_float4(r[k], r[k + 1], r[k + 2], r[k + 3]);
+}
+
+template <bool ABS>
+__global__ void __launch_bounds__(256, 2)
+blend_bwd_sets_kernel(const BlendArgs B) {
+    using Cfg = SetsCfg;
+    constexpr int CH = Cfg::CH, SB = Cfg::SB, NG = Cfg::NG, NK = Cfg::NK, NA = Cfg::NA, PS = Cfg::PS;
+    __shared__ TileLDS<CH, SB> L;
+    __shared__ float s_acc[4][SB * Cfg::NCMAX];  // private slab per wave (first: staging of the wave's dL_dout)
+    __shared__ __attribute__((aligned(16))) float s_state[4][64 * PS];
+    __shared__ float s_mom[16 * 64];             // A operand of the moment product: [step 4 G + i][lane]
+    __shared__ int s_wmax[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int gtile = xcd_tile(blockIdx.x, gridDim.x);
+    const int frame = gtile / B.T, tile = gtile - frame * B.T;
+    const BlendArgs A = frame_args(B, frame);
+    const int NC = NG + A.C, NCP = PAIR_STRIDE(NC);
+    float *const pair_buf = B.pair_buf + (size_t)frame * (size_t)B.cap * NCP;
+    const int tx = tile % A.gx, ty = tile / A.gx;
+    const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
+    const float bx0 = (float)bx, by0 = (float)by;
+    const float tcx = (float)(tx * TILE) + 7.5f, tcy = (float)(ty * TILE) + 7.5f;
+    const float ox = (float)((w & 1) * 8) - 7.5f, oy = (float)((w >> 1) * 8) - 7.5f;
+    const int nl = lane & 15, kk = lane >> 4;
+    int wmax;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // moment operand table (see blend_bwd_mfma_kernel)
+        const int st = 4 * w + r, Gs = st >> 2, is = st & 3;
+        const int q = 16 * Gs + 4 * kk + is;
+        const float x = (float)(q & 7) - 3.5f, y = (float)(q >> 3) - 3.5f;
+        const int grp = nl >> 2, i = nl & 3;
+        float v = 0.f;
+        if (grp == 0) v = i == 0 ? 1.f : i == 1 ? x : i == 2 ? y : x * x;
+        if (grp == 1) v = i == 0 ? 1.f : i == 1 ? x : i == 2 ? y : x * y;
+        if (grp == 2) v = i == 0 ? 1.f : i == 1 ? y : i == 2 ? y * y : 0.f;
+        s_mom[64 * st + lane] = v;
+    }
+    float phi1[4], phi2[4];
+#pragma unroll
+    for (int Gs = 0; Gs < 4; ++Gs) {
+        const int q = 16 * Gs + nl;
+        const float x = (float)(q & 7) + ox, y = (float)(q >> 3) + oy;
+        phi1[Gs] = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
+        phi2[Gs] = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
+    }
+    float *stage = s_acc[w];  // [pixel][slot]
+    {   // per-pixel constants: lane q <-> pixel (q & 7, q >> 3) of the wave's block
+        const int px = bx + (lane & 7), py = by + (lane >> 3);
+        const size_t HW = (size_t)A.H * A.W;
+        const bool inside = (px < A.W) && (py < A.H);
+        const size_t pix = (size_t)A.W * (size_t)py + px;
+        const float Tf = inside ? A.final_T[pix] : 0.f;
+        const int last = inside ? A.ncontrib[pix] : 0;
+        float bgd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = sets_slot_channel(A, k);
+            const float g = (inside && c >= 0) ? A.dL_dout[(size_t)c * HW + pix] : 0.f;
+            stage[lane * CH + k] = g;
+            const int gi = k < 4 ? 0 : k < 8 ? 1 : 2;
+            bgd[gi] += (gi == 0 ? A.s0bg : gi == 1 ? A.s1bg : A.s2bg) * g;
+        }
+        float *r = s_state[w] + lane * PS;
+        r[0] = Tf * bgd[0]; r[1] = Tf * bgd[1]; r[2] = Tf * bgd[2];
+        r[3] = __int_as_float(last);
+        r[4] = Tf;    // T_state: transmittance behind the splats replayed so far
+        r[5] = 0.f; r[6] = 0.f; r[7] = 0.f;  // R_state of the three sets
+        wmax = wave_max_i(last);
+        if (lane == 0) s_wmax[w] = wmax;
+    }
+    if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
+    __syncthreads();
+    // ---- the two MFMA operand layouts of dL_dout, and the moment table, into registers
+    float hcg[4][NK], hft[16][NA];
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+#pragma unroll
+        for (int j = 0; j < NK; ++j) hcg[G][j] = stage[(16 * G + nl) * CH + 4 * j + kk];  // A[m = pixel nl of strip G][k = slot]
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q)  // A[m = slot 16 q + nl][k = own pixel of step st]
+            hft[st][q] = 16 * q + nl < CH ? stage[(16 * (st >> 2) + 4 * kk + (st & 3)) * CH + 16 * q + nl] : 0.f;
+    }
+    const float *momrow = s_mom + lane;  // + 64 * (4 G + i)
+    // the feature accumulators of this lane hold slots 16 q + 4 kk + i (rows of the product): one group per (q, kk) --
+    // record component of the first of them and how many are real channels
+    int fbase[NA], fcnt[NA];
+    {
+        const int c0[3] = {__builtin_amdgcn_readfirstlane(A.s0c0), __builtin_amdgcn_readfirstlane(A.s1c0),
+                           __builtin_amdgcn_readfirstlane(A.s2c0)};
+        const int cn[3] = {__builtin_amdgcn_readfirstlane(A.s0cn), __builtin_amdgcn_readfirstlane(A.s1cn),
+                           __builtin_amdgcn_readfirstlane(A.s2cn)};
+        const int o2 = 4 * (kk - 2);  // q = 0, kk >= 2: slots 8 + o2 ..
+        fbase[0] = NG + (kk == 0 ? c0[0] : kk == 1 ? c0[1] : c0[2] + o2);
+        fcnt[0] = kk == 0 ? cn[0] : kk == 1 ? cn[1] : cn[2] - o2;
+        fbase[1] = NG + c0[2] + 8 + 4 * kk;  // q = 1: slots 16 + 4 kk .. = offset 8 + 4 kk of the detached set
+        fcnt[1] = cn[2] - (8 + 4 * kk);
+    }
+    const int2 range = A.tile_range[tile];
+    const int len = range.y - range.x;
+    const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
+    const int *slots = A.slot_sorted + range.x;
+    const int EPI = 256 / NC;                        // pair records the 256 threads write per pass, NC floats each
+    const int ce = tid / NC, cc = tid - ce * NC;     // this thread's (entry within the pass, component)
+    if (ce < EPI)
+        for (int ql = n + ce; ql < len; ql += EPI)   // entries nobody replays: zero record
+            pair_buf[(size_t)slots[ql] * NCP + cc] = 0.f;
+    float *state = s_state[w] + 4 * kk * PS;         // own pixel of step (G, i): state + (16 G + i) * PS
+    if (n <= 0) {
+        if (A.dbg_T_front) {
+            const int px = bx + (lane & 7), py = by + (lane >> 3);
+            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][lane * PS + 4];
+        }
+        return;
+    }
+    const float xk = (float)(4 * (kk & 1)) - 3.5f, yk = (float)(kk >> 1) - 3.5f;  // own pixel: x = xk + i, y = yk + 2 G
+
+    auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };
+    Stager<CH, SB> st;
+    st.load_ids(A, tid, range.x, pos, 0);
+    st.load_payload(A, tid);
+    st.load_ids(A, tid, range.x, pos, 1);
+    __syncthreads();  // every wave has read its staging rows: the slabs are free
+
+    int batch = 0;
+    for (int top = n - 1; top >= 0; top -= SB, ++batch) {
+        const int nb = imin_(SB, top + 1);
+        st.park(L, tid);
+        st.load_payload(A, tid);
+        st.load_ids(A, tid, range.x, pos, batch + 2);
+        __syncthreads();
+        tile_cull<CH, SB, false, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+                                               [&](int e, int ww) { return top - e < s_wmax[ww]; });
+        __syncthreads();
+        const int cnt = build_list(L, w, lane);
+        float *slab = s_acc[w];
+        for (int j0 = 0; j0 < cnt; j0 += 16) {
+            const int e = L.list[w][j0 + nl];
+            const float4 g0 = L.g0(e), g1 = L.g1(e);
+            const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
+            const float uc = g0.x - bx0 - 3.5f, vc = g0.y - by0 - 3.5f;
+            const int qn = top - e;
+            float bq1, bq2, bf[NK];
+            {
+                const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, tcx, tcy);
+                bq1 = kk == 0 ? pc.q0 : kk == 1 ? pc.qx : kk == 2 ? pc.qy : pc.qxx;
+                bq2 = kk == 0 ? pc.qxy : kk == 1 ? pc.qyy : 0.f;
+                const float *fr = reinterpret_cast<const float *>(&L.rec[e * Rec<CH>::RQ + 2]);
+#pragma unroll
+                for (int j = 0; j < NK; ++j) bf[j] = fr[4 * j + kk];
+            }
+            f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
+            f32x4 d_f[NA];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float s_op = 0.f, s_tx = 0.f, s_ty = 0.f, s_ax = 0.f, s_ay = 0.f;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {
+                f32x4 pw = {0.f, 0.f, 0.f, 0.f}, cv0 = {0.f, 0.f, 0.f, 0.f}, cv1 = {0.f, 0.f, 0.f, 0.f}, cv2 = {0.f, 0.f, 0.f, 0.f};
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bq1, pw, 0, 0, 0);
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi2[G], bq2, pw, 0, 0, 0);
+                cv0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][0], bf[0], cv0, 0, 0, 0);
+                cv1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][1], bf[1], cv1, 0, 0, 0);
+#pragma unroll
+                for (int j = 2; j < NK; ++j) cv2 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][j], bf[j], cv2, 0, 0, 0);
+                float araw[4], a[4], r1a[4], rp[4], Ts4[4], Tb[3][4], Rs[3][4], cg[3][4];
+                bool ok[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 sa = *reinterpret_cast<const float4 *>(state + (16 * G + i) * PS);
+                    const float4 sb = *reinterpret_cast<const float4 *>(state + (16 * G + i) * PS + 4);
+                    Tb[0][i] = sa.x; Tb[1][i] = sa.y; Tb[2][i] = sa.z;
+                    const int last = __float_as_int(sa.w);
+                    Ts4[i] = sb.x;
+                    Rs[0][i] = sb.y; Rs[1][i] = sb.z; Rs[2][i] = sb.w;
+                    cg[0][i] = cv0[i]; cg[1][i] = cv1[i]; cg[2][i] = cv2[i];
+                    const float Gs = __builtin_amdgcn_exp2f(pw[i]);
+                    araw[i] = o * Gs;
+                    const float alpha = fminf(0.99f, araw[i]);
+                    ok[i] = (qn < last) && !(pw[i] > BLEND_PW_MAX) && !(alpha < (1.0f / 255.0f));
+                    a[i] = ok[i] ? alpha : 0.f;
+                    r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
+                    rp[i] = r1a[i];
+                }
+                row_scan_mul4(rp[0], rp[1], rp[2], rp[3]);
+                float T[4], wgt[4], rs[3][4], R[3][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    T[i] = Ts4[i] * rp[i];
+                    wgt[i] = a[i] * T[i];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) rs[g][i] = cg[g][i] * wgt[i];
+                }
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    row_scan_add4(rs[g][0], rs[g][1], rs[g][2], rs[g][3]);
+                    row_shr1_add4(R[g], rs[g], Rs[g]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lds_store2_lane15(state + (16 * G + i) * PS + 4, T[i], Rs[0][i] + rs[0][i]);
+                    lds_store2_lane15(state + (16 * G + i) * PS + 6, Rs[1][i] + rs[1][i], Rs[2][i] + rs[2][i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int s = 4 * G + i;
+                    const float dLa0 = T[i] * cg[0][i] - (R[0][i] + Tb[0][i]) * r1a[i];
+                    const float dLa1 = T[i] * cg[1][i] - (R[1][i] + Tb[1][i]) * r1a[i];
+                    const float dLa2 = T[i] * cg[2][i] - (R[2][i] + Tb[2][i]) * r1a[i];
+                    const float am = ok[i] ? araw[i] : 0.f;
+                    const float dLp_tap = am * dLa0;            // dL/dpower of the tap set
+                    const float dLp_op = am * (dLa0 + dLa1);     // ... of the sets blended with the live opacity
+                    const float dLp = am * (dLa0 + dLa1 + dLa2);  // ... of all sets
+                    d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[64 * s], dLp, d_mom, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NA; ++q) d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(hft[s][q], wgt[i], d_f[q], 0, 0, 0);
+                    s_op += dLp_op;
+                    const float dx = uc - (xk + (float)i), dy = vc - (yk + (float)(2 * G));
+                    const float gx = dLp_tap * (cA * dx + cB * dy), gy = dLp_tap * (cB * dx + cC * dy);
+                    s_tx += gx;
+                    s_ty += gy;
+                    if (ABS) {
+                        s_ax += fabsf(gx);
+                        s_ay += fabsf(gy);
+                    }
+                }
+            }
+            // ---- chunk epilogue
+            s_op = rows_sum(s_op, lane);
+            s_tx = rows_sum(s_tx, lane);
+            s_ty = rows_sum(s_ty, lane);
+            if (ABS) {
+                s_ax = rows_sum(s_ax, lane);
+                s_ay = rows_sum(s_ay, lane);
+            }
+            if (j0 + nl < cnt) {
+                float *rec = slab + e * NC;
+                const float D0 = d_mom[0];
+                if (kk == 0) {
+                    const float Dx = d_mom[1], Dy = d_mom[2], Dxx = d_mom[3];
+                    rec[0] = cA * Dx + cB * Dy - (cA * uc + cB * vc) * D0;
+                    rec[1] = cB * Dx + cC * Dy - (cB * uc + cC * vc) * D0;
+                    rec[2] = -0.5f * (uc * uc * D0 - 2.f * uc * Dx + Dxx);
+                    rec[5] = o > 0.f ? s_op / o : 0.f;
+                } else if (kk == 1) {
+                    const float Dx = d_mom[1], Dy = d_mom[2], Dxy = d_mom[3];
+                    rec[3] = -(uc * vc * D0 - uc * Dy - vc * Dx + Dxy);
+                    rec[6] = ABS ? s_ax : 0.f;
+                    rec[7] = ABS ? s_ay : 0.f;
+                } else if (kk == 2) {
+                    const float Dy = d_mom[1], Dyy = d_mom[2];
+                    rec[4] = -0.5f * (vc * vc * D0 - 2.f * vc * Dy + Dyy);
+                } else {
+                    rec[8] = -s_tx;   // d uv of the tap set alone: sum dLp (conic (pixel - centre))
+                    rec[9] = -s_ty;
+                }
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < fcnt[q]) rec[fbase[q] + i] = d_f[q][i];
+            }
+        }
+        __syncthreads();
+        if (ce < EPI) {  // combine the four slabs into the entries' pair slots
+            const int lo = top - nb + 1;
+            for (int ql = ce; ql < nb; ql += EPI) {
+                const int e = nb - 1 - ql;
+                const unsigned int fl = L.keep[e];
+                float v = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const float x = s_acc[ww][e * NC + cc];
+                    v += ((fl >> (8 * ww)) & 0xffu) ? x : 0.f;
+                }
+                pair_buf[(size_t)slots[lo + ql] * NCP + cc] = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (A.dbg_T_front) {
+        const int px = bx + (lane & 7), py = by + (lane >> 3);
+        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][lane * PS + 4];
     }
 }
 
@@ -1777,4 +2150,69 @@ extern "C" int splat_alpha_blending_backward_batch_set(int F, int P, int C, int 
     A.c0 = c0; A.cn = cn;
     A.dL_dabs_uv = want_abs ? pair_records : nullptr;
     return bwd_chunk(A, T, false, true, (hipStream_t)stream);
+}
+
+// Backward tile pass of up to three feature sets of one geometry in ONE launch (blend_bwd_sets_kernel): set 0 = the tap set
+// (<= 4 channels: full gradients + the densification taps), set 1 = a second set blended with the live opacity (<= 4
+// channels), set 2 = the set blended with opacity.detach() (<= 20 channels); set_cn[g] = 0: no such set.  The sets must tile
+// the row's C channels exactly.  set_c0 / set_cn / set_bg are HOST arrays of three entries.  Records: stride
+// splat_blend_sets_pair_stride(C), layout [ux uy ca cb | cc o ax ay | tx ty | dL_dfeature[0..C-1]] (reduce them with
+// splat_frames_gauss_backward_static_sets); pack_scratch: F * P * splat_blend_sets_pack_floats() floats.
+extern "C" size_t splat_blend_sets_pair_stride(int C) { return (size_t)PAIR_STRIDE(SetsCfg::NG + C); }
+extern "C" size_t splat_blend_sets_pack_floats(void) { return (size_t)Rec<SetsCfg::CH>::RS; }
+
+extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
+                                                        const float *set_bg, const float *uv, const float *conic,
+                                                        const float *opacity, int64_t opacity_frame_stride,
+                                                        const float *feature, int64_t feature_frame_stride,
+                                                        const int32_t *idx_sorted, const int32_t *tile_range,
+                                                        int64_t capacity, int W, int H, const float *final_T,
+                                                        const int32_t *ncontrib, const float *dL_dout, int want_abs,
+                                                        const int32_t *slot_sorted, float *pair_records,
+                                                        float *pack_scratch, float *dbg_T_front, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= SetsCfg::CH && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 28)");
+    SPLAT_CHECK_ARG(set_c0 && set_cn && set_bg, "null set table");
+    SPLAT_CHECK_ARG(uv && conic && opacity && feature && idx_sorted && tile_range && final_T && ncontrib && dL_dout &&
+                        slot_sorted && pair_records && pack_scratch,
+                    "null pointer");
+    SPLAT_CHECK_ARG(set_cn[0] >= 0 && set_cn[0] <= 4 && set_cn[1] >= 0 && set_cn[1] <= 4 && set_cn[2] >= 0 && set_cn[2] <= 20,
+                    "set widths: tap set <= 4, second set <= 4, detached set <= 20 channels");
+    {   // the sets tile [0, C): every row channel has exactly one slot (every record component is written)
+        unsigned covered = 0u;
+        for (int g = 0; g < 3; ++g) {
+            SPLAT_CHECK_ARG(set_cn[g] == 0 || (set_c0[g] >= 0 && set_c0[g] + set_cn[g] <= C), "set outside the row");
+            for (int k = 0; k < set_cn[g]; ++k) {
+                SPLAT_CHECK_ARG(!(covered & (1u << (set_c0[g] + k))), "the sets overlap");
+                covered |= 1u << (set_c0[g] + k);
+            }
+        }
+        SPLAT_CHECK_ARG(covered == (C == 32 ? 0xffffffffu : (1u << C) - 1u), "the sets do not cover the row's channels");
+    }
+    BlendArgs A;
+    memset(&A, 0, sizeof(A));
+    A.P = P; A.C = C;
+    A.uv = (const float2 *)uv; A.conic = conic; A.opacity = opacity; A.feature = feature;
+    A.idx_sorted = idx_sorted; A.tile_range = (const int2 *)tile_range;
+    A.W = W; A.H = H; A.gx = (W + TILE - 1) / TILE;
+    A.final_T = const_cast<float *>(final_T); A.ncontrib = const_cast<int *>(ncontrib);
+    A.dL_dout = dL_dout;
+    A.slot_sorted = slot_sorted; A.pair_buf = pair_records;
+    A.pack = pack_scratch;
+    A.dbg_T_front = dbg_T_front;
+    const int T = A.gx * ((H + TILE - 1) / TILE);
+    A.F = F; A.T = T; A.cap = capacity; A.tile_only = 1;
+    A.pack_fs = (long long)P * (long long)Rec<SetsCfg::CH>::RS;
+    A.opacity_fs = opacity_frame_stride; A.feature_fs = feature_frame_stride;
+    A.c0 = 0; A.cn = C;
+    A.s0c0 = set_c0[0]; A.s0cn = set_cn[0]; A.s0bg = set_bg[0];
+    A.s1c0 = set_c0[1]; A.s1cn = set_cn[1]; A.s1bg = set_bg[1];
+    A.s2c0 = set_c0[2]; A.s2cn = set_cn[2]; A.s2bg = set_bg[2];
+    hipStream_t s = (hipStream_t)stream;
+    SPLAT_LAUNCH("blend_pack", pack_sets_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)F), dim3(256), 0, s, A);
+    SPLAT_POST_LAUNCH();
+    const dim3 grid((unsigned)(T * F)), block(256);
+    if (want_abs) SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_kernel<true>, grid, block, 0, s, A);
+    else SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_kernel<false>, grid, block, 0, s, A);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
 }

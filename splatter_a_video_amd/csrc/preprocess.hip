@@ -322,12 +322,16 @@ struct GaussBwdArgs {
     int skip_opacity;       // this feature set was blended with opacity.detach(): no opacity gradient
     int depth_channel;      // >= 0: that channel of the set is the per-frame depth feature -- its summed gradient is
                             // dL/ddepth of the projection (-> position), not a feature gradient
+    // SETS records (blend_bwd_sets_kernel: [ux uy ca cb | cc o ax ay | tx ty | row channels]): per set the first row
+    // channel, the width, the gradient rows (NULL: not wanted) and their stride
+    int sc0[3], scn[3], sstride[3];
+    float *sdf[3];
 };
 
-template <bool ABS, int NCP>
+template <bool ABS, int NCP, bool SETS = false>
 __global__ void __launch_bounds__(256)
 frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
-    constexpr int NG = GradLayout<ABS, false>::NG;
+    constexpr int NG = SETS ? 10 : GradLayout<ABS, false>::NG;
     constexpr int NQ = NCP / 4, NS = (NQ + 3) / 4;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 2, sub = t & 3;
@@ -418,10 +422,12 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
     } else if (sub == 2) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) put1(A.d_uquats + 4 * i + k, dq[k]);
-    } else {
-        if (A.tap) {
-            A.tap[2 * i] = ux * (0.5f * (float)A.W);
-            A.tap[2 * i + 1] = uy * (0.5f * (float)A.H);
+    }
+    {   // densification tap: d uv of the whole blend -- SETS records: of the tap set alone (components 8, 9 = chunk 2)
+        const float tu = SETS ? quad_bcast<2>(a[0].x) : ux, tv = SETS ? quad_bcast<2>(a[0].y) : uy;
+        if (sub == 3 && A.tap) {
+            A.tap[2 * i] = tu * (0.5f * (float)A.W);
+            A.tap[2 * i + 1] = tv * (0.5f * (float)A.H);
         }
     }
     if (ABS) {
@@ -440,7 +446,14 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ch = k0 + e - NG;
-                if (ch >= 0 && ch < A.cn && ch != A.depth_channel && A.d_feature) put1(A.d_feature + (size_t)i * A.C + ch, v[e]);
+                if (SETS) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        if (ch >= A.sc0[g] && ch < A.sc0[g] + A.scn[g] && ch != A.depth_channel && A.sdf[g])
+                            put1(A.sdf[g] + (size_t)i * A.sstride[g] + (ch - A.sc0[g]), v[e]);
+                } else if (ch >= 0 && ch < A.cn && ch != A.depth_channel && A.d_feature) {
+                    put1(A.d_feature + (size_t)i * A.C + ch, v[e]);
+                }
             }
         }
     }
@@ -673,9 +686,55 @@ int launch_gauss_bwd_static(const GaussBwdArgs &A, int ncp, hipStream_t s) {
     return SPLAT_OK;
 }
 
+int launch_gauss_bwd_static_sets(const GaussBwdArgs &A, int ncp, hipStream_t s) {
+    const dim3 grid((unsigned)(((size_t)A.P * 4 + 255) / 256)), block(256);
+#define GS(N) case N: SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_static_kernel<true, N, true>), grid, block, 0, s, A); break
+    switch (ncp) {
+        GS(12); GS(16); GS(20); GS(24); GS(28); GS(32); GS(36); GS(40);
+        default: splat_set_error("gauss_bwd: unsupported record stride %d", ncp); return SPLAT_E_ARG;
+    }
+#undef GS
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
 }  // namespace
 
 extern "C" size_t splat_blend_pair_stride(int C, int want_abs, int has_bias);
+extern "C" size_t splat_blend_sets_pair_stride(int C);
+
+// Gaussian side of splat_alpha_blending_backward_batch_sets: sums the SETS records of every Gaussian over the F frames and
+// runs the projection chain once.  set_dfeature: HOST array of three device pointers (NULL entries: no gradient wanted for
+// that set; the channel `depth_channel` of the row, if >= 0, is the per-frame depth and feeds d_xyz instead).
+extern "C" int splat_frames_gauss_backward_static_sets(int F, int P, int C, int W, int H, int64_t capacity,
+                                                       const float *pair_records, const int32_t *goff_incl,
+                                                       const int32_t *radius, const float *xyz, const float *scales,
+                                                       const float *uquats, const float *extr, int accumulate,
+                                                       float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                                       const int32_t *set_c0, const int32_t *set_cn,
+                                                       float *const *set_dfeature, const int32_t *set_stride,
+                                                       int depth_channel, float *tap, float *abs_tap,
+                                                       int32_t *radii_max, void *stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 28 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 28)");
+    SPLAT_CHECK_ARG(pair_records && goff_incl && xyz && scales && uquats && extr, "null input pointer");
+    SPLAT_CHECK_ARG(d_xyz && d_scales && d_uquats && d_opacity, "null gradient pointer");
+    SPLAT_CHECK_ARG(set_c0 && set_cn && set_dfeature && set_stride, "null set table");
+    SPLAT_CHECK_ARG(depth_channel < C, "depth_channel outside the row");
+    SPLAT_CHECK_ARG(!radii_max || radius, "radii_max needs the per-frame radius");
+    GaussBwdArgs A;
+    memset(&A, 0, sizeof(A));
+    A.F = F; A.P = P; A.W = W; A.H = H; A.C = C; A.cn = C; A.cap = capacity;
+    A.skip_opacity = 0; A.depth_channel = depth_channel;
+    A.pair = pair_records; A.goff = goff_incl; A.radius = radius;
+    A.xyz = xyz; A.scales = scales; A.uquats = (const float4 *)uquats; A.extr = extr;
+    A.d_xyz = d_xyz; A.d_scales = d_scales; A.d_uquats = d_uquats; A.d_opacity = d_opacity;
+    A.tap = tap; A.abs_tap = abs_tap; A.radii_max = radii_max; A.accumulate = accumulate;
+    for (int g = 0; g < 3; ++g) {
+        A.sc0[g] = set_c0[g]; A.scn[g] = set_cn[g]; A.sstride[g] = set_stride[g]; A.sdf[g] = set_dfeature[g];
+        SPLAT_CHECK_ARG(set_cn[g] == 0 || !set_dfeature[g] || set_stride[g] >= set_cn[g], "feature stride below the set width");
+    }
+    return launch_gauss_bwd_static_sets(A, (int)splat_blend_sets_pair_stride(C), (hipStream_t)stream);
+}
 
 extern "C" int splat_preprocess_ortho_forward_batch(int F, int P, const float *xyz, const float *offsets,
                                                     const float *scales, const float *uquats, const float *extr, int W,

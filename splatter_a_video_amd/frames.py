@@ -16,6 +16,7 @@ No CPU fallback.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch
@@ -318,6 +319,34 @@ class _RenderDynamic(torch.autograd.Function):
         return ret + (None,) * 11
 
 
+def _set_groups(meta):
+    """Routing group of every set: 0 = feeds the taps, 1 = live opacity without taps, 2 = opacity.detach()."""
+    return [0 if taps else (2 if detach else 1) for (_, _, detach, taps) in meta]
+
+
+def _one_pass_plan(meta, widths, C):
+    """Can ONE pass of splat_alpha_blending_backward_batch_sets serve these sets?  At most one set per routing group, the
+    tap set blended with the live opacity, widths <= (4, 4, 20), C <= 28.  Returns (c0[3], cn[3], bg[3], depth row channel
+    or -1, index of the tap set or None), or None: the per-set passes run."""
+    if C > 28:
+        return None
+    groups = _set_groups(meta)
+    if len(set(groups)) != len(groups):
+        return None
+    c0s, cns, bgs, depth_ch, tap_set = [0, 0, 0], [0, 0, 0], [0.0, 0.0, 0.0], -1, None
+    c0 = 0
+    for si, ((w, bg, detach, taps), cn, g) in enumerate(zip(meta, widths, groups)):
+        if (taps and detach) or cn > (4, 4, 20)[g]:
+            return None
+        c0s[g], cns[g], bgs[g] = c0, cn, bg
+        if w == "depth":
+            depth_ch = c0
+        if taps:
+            tap_set = si
+        c0 += cn
+    return c0s, cns, bgs, depth_ch, tap_set
+
+
 class _RenderSets(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, scales, uquats, opacity, offsets, extr, fb, meta, K, nearest, extent, sink, *feats):
@@ -384,6 +413,41 @@ class _RenderSets(torch.autograd.Function):
         dfe = []
         op_fs = 0 if opacity.numel() == P else P
         from .gs.raster_ops import _debug_T_front
+        plan = _one_pass_plan(meta, widths, C) if os.environ.get("SPLAT_SETS_ONE_PASS", "1") != "0" else None
+        if plan is not None:
+            # the sets share the alpha / transmittance replay: ONE pass of the tile kernels and ONE Gaussian-side reduction
+            # route dL/dalpha of every set where the reference's three autograd nodes would
+            c0s, cns, bgs, depth_ch, tap_set = plan
+            want_abs = 1 if (tap_set is not None and fb.want_abs) else 0
+            fi, dfs, strides = 0, [None, None, None], [0, 0, 0]
+            group_of = _set_groups(meta)
+            for si, (w, _, _, _) in enumerate(meta):
+                if w == "depth":
+                    continue
+                need = grads[si] is not None and ctx.needs_input_grad[12 + fi]
+                dfeat = torch.zeros_like(feats[fi]) if need else None
+                dfe.append(dfeat)
+                dfs[group_of[si]], strides[group_of[si]] = dfeat, int(feats[fi].shape[1])
+                fi += 1
+            ncp = int(lib.splat_blend_sets_pair_stride(C))
+            rec = fb._set_buffer(("rec", "sets"), F * cap * ncp)
+            pack = fb._set_buffer(("pack", "sets"), F * P * int(lib.splat_blend_sets_pack_floats()))
+            i3, f3 = ctypes.c_int32 * 3, ctypes.c_float * 3
+            L.check(lib.splat_alpha_blending_backward_batch_sets(
+                L.ci(F), L.ci(P), L.ci(C), i3(*c0s), i3(*cns), f3(*bgs), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity),
+                ctypes.c_int64(op_fs), L.ptr(ctx.row), ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range),
+                ctypes.c_int64(cap), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(dL), L.ci(want_abs),
+                L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(_debug_T_front(F * H, W, dev)), st))
+            p3 = (ctypes.c_void_p * 3)(*[0 if d is None else d.data_ptr() for d in dfs])
+            has_tap = tap_set is not None
+            L.check(lib.splat_frames_gauss_backward_static_sets(
+                L.ci(F), L.ci(P), L.ci(C), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ptr(rec), L.ptr(fb.goff), L.ptr(fb.radius),
+                L.ptr(xyz), L.ptr(scales), L.ptr(uquats), L.ptr(extr_c), L.ci(1), L.ptr(bufs["xyz"]), L.ptr(bufs["scales"]),
+                L.ptr(bufs["uquats"]), L.ptr(bufs["opacity"]), i3(*c0s), i3(*cns), p3, i3(*strides), L.ci(depth_ch),
+                L.ptr(fb.tap if has_tap else None), L.ptr(fb.abs_tap if (has_tap and want_abs) else None),
+                L.ptr(fb.radii_max if has_tap else None), st))
+            ret = tuple(None if k in sink else bufs[k] for k in ("xyz", "scales", "uquats", "opacity"))
+            return ret + (None,) * 8 + tuple(dfe)
         c0, fi = 0, 0
         for si, ((w, bg, detach, taps), g) in enumerate(zip(meta, grads[:len(meta)])):
             cn = widths[si]

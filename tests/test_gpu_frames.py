@@ -114,11 +114,14 @@ def test_batch_capacity_overflow_is_flagged_and_safe():
         B.check()
 
 
-def test_render_sets_equals_the_native_renderer_frame_by_frame():
-    """row a1 in a frame batch: rgb (enhanced K ids, ndc + abs_ndc taps) + depth (bg = 1) + 19 attribute channels
+@pytest.mark.parametrize("one_pass", ["1", "0"])
+def test_render_sets_equals_the_native_renderer_frame_by_frame(one_pass, monkeypatch):
+    """(one_pass: the three sets' backward in ONE pass of the tile kernels, or one pass per set.)
+    row a1 in a frame batch: rgb (enhanced K ids, ndc + abs_ndc taps) + depth (bg = 1) + 19 attribute channels
     (opacity detached) of every frame in one set of launches, against OrthoEnhancedRenderer.render_iter frame by frame
     (which tests/test_gpu_renderer_native.py / test_gpu_renderer_flow.py tie to the reference's call sequence)."""
     from splatter_a_video_amd.renderer import OrthoEnhancedRenderer
+    monkeypatch.setenv("SPLAT_SETS_ONE_PASS", one_pass)
     N, W, H, F, K = 9000, 192, 128, 3, 20
     sc = make_scene(N, W, H, seed=15)
     rng = np.random.default_rng(3)
@@ -164,6 +167,50 @@ def test_render_sets_equals_the_native_renderer_frame_by_frame():
     want_tap = sum(taps)             # abs_ndc taps (densify_abs_grad_enable)
     assert torch.allclose(B.abs_tap, want_tap, rtol=1e-3, atol=1e-5 * float(want_tap.abs().max()))
     assert torch.equal(B.radii_max, torch.stack(radii).max(0).values)
+
+
+@pytest.mark.parametrize("case", ["detached_first", "two_live_sets", "tap_only"])
+def test_render_sets_one_pass_equals_the_per_set_passes(case, monkeypatch):
+    """splat_alpha_blending_backward_batch_sets (one replay of the alpha / T chain, dL/dalpha routed per set) against the
+    per-set passes, for set orders and routings other than the reference renderer's: parameter gradients, feature
+    gradients, both taps and the replay check (the one-pass kernel reproduces every inclusion decision of the forward)."""
+    N, W, H, F = 6000, 160, 96, 2
+    sc = make_scene(N, W, H, seed=31)
+    rng = np.random.default_rng(5)
+    off, extr = _t(_offsets(sc, F)), _t(sc.extr)
+    widths = {"detached_first": (8, 3), "two_live_sets": (4, 2), "tap_only": (3,)}[case]
+    feats_np = [rng.uniform(-1, 1, size=(N, w)).astype(np.float32) for w in widths]
+    gs_ = [_t(rng.normal(size=(F, w, H, W)).astype(np.float32)) for w in widths]
+
+    def run(flag):
+        monkeypatch.setenv("SPLAT_SETS_ONE_PASS", flag)
+        p = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity).items()}
+        fe = [_t(f, True) for f in feats_np]
+        if case == "detached_first":
+            sets = [dict(feature=fe[0], bg=0.3, detach_opacity=True), dict(feature=fe[1], bg=0.1, taps=True)]
+        elif case == "two_live_sets":
+            sets = [dict(feature=fe[0], bg=0.0, taps=True), dict(feature=fe[1], bg=0.5)]
+        else:
+            sets = [dict(feature=fe[0], bg=0.2, taps=True)]
+        B = FrameBatch(F, N, W, H, sum(widths), "cuda", want_abs=True)
+        res = B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], sets, off, extr)
+        with capture_T_front() as cap:
+            torch.autograd.backward(list(res[:-1]), gs_)
+        torch.cuda.synchronize()
+        B.check()
+        assert float((cap.maps[-1] - 1).abs().max()) < 2e-4
+        return [x.detach() for x in res[:-1]], {k: v.grad for k, v in p.items()}, [f.grad for f in fe], B.tap.clone(), B.abs_tap.clone()
+
+    i1, g1, f1, t1, a1 = run("1")
+    i0, g0, f0, t0, a0 = run("0")
+    for x, y in zip(i1, i0):
+        assert torch.equal(x, y)
+    close = lambda a, b: torch.allclose(a, b, rtol=1e-3, atol=2e-5 * float(b.abs().max()) + 1e-12)
+    for k in g0:
+        assert close(g1[k], g0[k]), k
+    for x, y in zip(f1, f0):
+        assert close(x, y)
+    assert close(t1, t0) and close(a1, a0)
 
 
 def test_render_sets_skips_sets_without_gradient():
