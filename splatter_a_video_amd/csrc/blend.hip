@@ -58,6 +58,9 @@
 #ifndef BLEND_WIDE_MINW
 #define BLEND_WIDE_MINW 1
 #endif
+#ifndef BLEND_CARRY
+#define BLEND_CARRY 1
+#endif
 #ifndef BLEND_WIDE_HOIST
 #define BLEND_WIDE_HOIST 0
 #endif
@@ -335,19 +338,20 @@ pack_kernel(const BlendArgs B) {
 // slot SB = inert (all-zero) record for the padded tail of the survivor lists
 // COEF: the staging threads also leave the exponent's polynomial [q0 qx qy qxx | qxy qyy o id] of every entry (tile-centred,
 // power_coeffs) for the lane = pixel kernels; slot SB is the inert entry (opacity 0).
-template <int CH, int SB, bool COEF = false>
+// XR: extra record rows behind the inert one (rows SB + 1 + 15 w + j: wave w's carried survivors, see CarryLDS)
+template <int CH, int SB, bool COEF = false, int XR = 0>
 struct TileLDS {
     static constexpr int RQ = Rec<CH>::RQ;
-    float4 rec[(SB + 1) * RQ];
+    float4 rec[(SB + 1 + XR) * RQ];
     float4 coef[COEF ? 2 * (SB + 1) : 1];
     unsigned int keep[SB];  // byte w of entry e: wave w's 8x8 block can be reached by the splat (and passes its predicate)
-    unsigned short list[4][SB + 16];
+    unsigned short list[4][SB + 16 + XR / 4];
     __device__ __forceinline__ const float4 &g0(int e) const { return rec[e * RQ]; }      // u v A B
     __device__ __forceinline__ const float4 &g1(int e) const { return rec[e * RQ + 1]; }  // C o bias id
 };
 
-template <int CH, int SB, bool COEF>
-__device__ __forceinline__ void read_feat(const TileLDS<CH, SB, COEF> &L, int e, float f[CH]) {
+template <int CH, int SB, bool COEF, int XR>
+__device__ __forceinline__ void read_feat(const TileLDS<CH, SB, COEF, XR> &L, int e, float f[CH]) {
     constexpr int RQ = Rec<CH>::RQ;
 #pragma unroll
     for (int k = 0; k < CH; k += 4) {
@@ -389,8 +393,8 @@ struct Stager {
                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    template <bool COEF>
-    __device__ __forceinline__ void park(TileLDS<CH, SB, COEF> &L, int tid) const {
+    template <bool COEF, int XR>
+    __device__ __forceinline__ void park(TileLDS<CH, SB, COEF, XR> &L, int tid) const {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = tid + 256 * k;
@@ -404,8 +408,8 @@ struct Stager {
 // need before the geometric test.  Callers put a __syncthreads() between tile_cull and build_list.
 // SUB: the flag byte of a kept block carries one bit per 4x4 quarter (bit sx + 2 sy) from a bounding-box test of the
 // quarter's pixel centres, for kernels that keep a survivor list per quarter; otherwise the byte is 0 / 1.
-template <int CH, int SB, bool BIAS, bool SUB, bool COEF, typename Pred>
-__device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF> &L, int tid, int nb, float tx0, float ty0, Pred pred) {
+template <int CH, int SB, bool BIAS, bool SUB, bool COEF, int XR, typename Pred>
+__device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR> &L, int tid, int nb, float tx0, float ty0, Pred pred) {
     constexpr int TPE = 256 / SB;  // threads per entry (1, 2 or 4): each tests 4 / TPE of the blocks
     constexpr int BPT = 4 / TPE;
     static_assert(SB == 64 || SB == 128 || SB == 256, "super-batch sizes the 256-thread cull supports");
@@ -459,8 +463,8 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF> &L, int tid, int
 }
 
 // wave w's order-preserving survivor list from the flag bytes; returns the count.
-template <int CH, int SB, bool COEF>
-__device__ __forceinline__ int build_list(TileLDS<CH, SB, COEF> &L, int w, int lane) {
+template <int CH, int SB, bool COEF, int XR>
+__device__ __forceinline__ int build_list(TileLDS<CH, SB, COEF, XR> &L, int w, int lane) {
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < SB / WAVE; ++r) {
@@ -475,6 +479,68 @@ __device__ __forceinline__ int build_list(TileLDS<CH, SB, COEF> &L, int w, int l
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return cnt;
+}
+
+// ---- survivors carried over a super-batch boundary (strip-walk backward kernels).  A chunk of the matrix-core kernels
+// replays 16 survivors of a wave's list; a list of 38 costs three chunks, the third 62 % empty.  Instead, the last
+// (list length mod 16) survivors of a super-batch wait in the wave's carry rows of the staging area (payload copied, list
+// position and pair slot kept) and head the wave's list of the next super-batch -- they are the deepest splats of it, the
+// replay order is unchanged; only the tile's last super-batch pads its final chunk.  The slabs are indexed by list POSITION
+// (CAP rows per wave; a longer list takes another round of chunks + combine); an entry's record is stored by the combine
+// of its own super-batch without the waves that carried it, and those add their part one super-batch later with float
+// atomics (<= 15 records per wave and super-batch).
+template <int SB>
+struct CarryLDS {
+    static constexpr int CQ = 15;
+    unsigned int pos4[SB];     // byte w: list position of entry e in wave w's list; 255 = not replayed by that wave now
+    int cslot[4][16];          // pair slot of the carried survivors
+    int more[4];               // wave w has chunks left for another round
+};
+
+// build_list behind `base` carried survivors: positions base .. base + cnt - 1, and the entries' positions
+template <int CH, int SB, bool COEF, int XR>
+__device__ __forceinline__ int build_list_at(TileLDS<CH, SB, COEF, XR> &L, CarryLDS<SB> &C, int w, int lane, int base) {
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < SB / WAVE; ++r) {
+        const int e = r * WAVE + lane;
+        const bool keep = ((L.keep[e] >> (8 * w)) & 0xffu) != 0u;
+        const unsigned long long m = __ballot(keep);
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (keep) L.list[w][base + cnt + before] = (unsigned short)e;
+        reinterpret_cast<unsigned char *>(C.pos4)[4 * e + w] = keep ? (unsigned char)(base + cnt + before) : (unsigned char)255;
+        cnt += __popcll(m);
+    }
+    if (lane < 16) L.list[w][base + cnt + lane] = (unsigned short)SB;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+}
+
+// The last `left` survivors of wave w's list (positions first .. first + left - 1, all entries of the staged super-batch)
+// become its carry rows j0 .. j0 + left - 1: payload (the RQC leading chunks: geometry + features; chunk 1's w = the list
+// position in the tile, which the replay's `q < ncontrib` test needs), pair slot, list head; their position bytes become
+// 255 so that the combine leaves this wave out.
+template <int CH, int SB, bool COEF, int XR>
+__device__ __forceinline__ void carry_out(TileLDS<CH, SB, COEF, XR> &L, CarryLDS<SB> &C, int w, int lane, int first, int left,
+                                          int j0, int top, const int *slots) {
+    constexpr int RQ = Rec<CH>::RQ, RQC = 2 + (CH + 3) / 4, CQ = CarryLDS<SB>::CQ;
+    for (int idx = lane; idx < left * RQC; idx += WAVE) {
+        const int k = idx / RQC, part = idx - k * RQC;
+        const int e = L.list[w][first + k];
+        float4 v = L.rec[e * RQ + part];
+        if (part == 1) v.w = __int_as_float(top - e);
+        L.rec[(SB + 1 + CQ * w + j0 + k) * RQ + part] = v;
+    }
+    int e = 0;
+    if (lane < left) {
+        e = L.list[w][first + lane];
+        C.cslot[w][j0 + lane] = slots[top - e];
+        reinterpret_cast<unsigned char *>(C.pos4)[4 * e + w] = (unsigned char)255;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // (the list reads above are done before the head of the list is rewritten)
+    if (lane < left) L.list[w][j0 + lane] = (unsigned short)(SB + 1 + CQ * w + j0 + lane);
 }
 
 // ------------------------------------------------------------------ forward
@@ -1087,13 +1153,20 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     constexpr int SB = Cfg::SB, NG = Cfg::NG, NC = Cfg::NC, NCP = Cfg::NCP, PW = Cfg::PW, NA = Cfg::NA, NK = Cfg::NK;
     constexpr int PZ = Cfg::PZ, PS = Cfg::PS;
     constexpr int I_ABS = GradLayout<ABS, false>::I_ABS;
-    __shared__ TileLDS<CH, SB> L;
     constexpr bool SHARED = Cfg::SHARED;
+    // survivors that do not fill a chunk are carried into the next super-batch (CarryLDS); slab rows by list position
+    constexpr bool CARRY = BLEND_CARRY && !SHARED;
+    constexpr int CQ = CarryLDS<SB>::CQ, XR = CARRY ? 4 * CQ : 0;
+    constexpr int CAP = !CARRY ? SB : ((SB == 128 && NC <= 9) ? 80 : 64);  // slab rows per wave (whole chunks)
+    __shared__ TileLDS<CH, SB, false, XR> L;
+    __shared__ CarryLDS<SB> CL;
     // narrow feature rows: dL_dfeature = sum_p g[p,c] w[p,n] as per-lane FMAs over the lane's own pixels + one cross-row sum
     // per chunk, instead of four MFMAs per strip whose A operand would use 3 of its 16 rows (the matrix pipe's time is on
     // this kernel's critical path: dropping those products saved 13 % of it, the VALU form gives back a third)
     constexpr bool FEAT_VALU = CH <= 4;
-    __shared__ float s_acc[Cfg::NSLAB][SB * NC];  // private slab per wave, or one shared slab (wide records)
+    // private slab per wave, or one shared slab (wide records); CARRY: row CAP stays zero (what the combine reads for a
+    // wave that has nothing for an entry)
+    __shared__ float s_acc[Cfg::NSLAB][(CAP + (CARRY ? 1 : 0)) * NC];
     __shared__ __attribute__((aligned(16))) float s_pix[4][64 * PW];
     __shared__ float s_mom[16 * 64];         // A operand of the moment product: [step 4 G + i][lane]
     __shared__ int s_wmax[4];
@@ -1160,6 +1233,7 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         if (lane == 0) s_wmax[w] = wmax;
     }
     if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
+    if (CARRY && lane < NC) s_acc[w][CAP * NC + lane] = 0.f;                                 // the slab's zero row
     __syncthreads();
     const int2 range = A.tile_range[tile];
     const int len = range.y - range.x;
@@ -1214,6 +1288,7 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     st.load_ids(A, tid, range.x, pos, 1);
 
     int batch = 0;
+    int ncarry = 0;  // survivors waiting in this wave's carry rows
     for (int top = n - 1; top >= 0; top -= SB, ++batch) {
         const int nb = imin_(SB, top + 1);
         st.park(L, tid);
@@ -1226,14 +1301,20 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         if (SHARED)
             for (int i = tid; i < nb * NC; i += 256) s_acc[0][i] = 0.f;
         __syncthreads();
-        const int cnt = build_list(L, w, lane);  // every survivor gets a slab record: keep flags = written flags
+        // every survivor gets a slab record: keep flags = written flags
+        const int ncin = ncarry;
+        const int total = ncin + (CARRY ? build_list_at(L, CL, w, lane, ncin) : build_list(L, w, lane));
+        const int nproc = (!CARRY || top - SB < 0) ? total : (total & ~15);  // whole chunks; the tile's last batch pads
         float *slab = s_acc[SHARED ? 0 : w];
-        for (int j0 = 0; j0 < cnt; j0 += 16) {
+        for (int p0 = 0;; p0 += CAP) {  // rounds of at most CAP list positions (one, unless more than CAP survive)
+        const int p1 = CARRY ? imin_(nproc, p0 + CAP) : nproc;
+        for (int j0 = p0; j0 < p1; j0 += 16) {
             const int e = L.list[w][j0 + nl];  // ascending e = back to front; slot SB (inert) past the end
             const float4 g0 = L.g0(e), g1 = L.g1(e);
             const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
             const float uc = g0.x - bx0 - 3.5f, vc = g0.y - by0 - 3.5f;  // centre in block-centred pixel coordinates
-            const int qn = top - e;  // list position of this survivor (negative for the inert slot: harmless, alpha = 0)
+            // list position of this survivor in the tile (negative for the inert slot: harmless, alpha = 0)
+            const int qn = (CARRY && e > SB) ? __float_as_int(g1.w) : top - e;
             // B operands: this lane's K-slice of the splat's power coefficients (x log2 e) and features
             float bq1, bq2, bf[NK];
             {
@@ -1329,8 +1410,8 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                 s_ax = rows_sum(s_ax, lane);
                 s_ay = rows_sum(s_ay, lane);
             }
-            if (j0 + nl < cnt) {
-                float *rec = slab + e * NC;
+            if (j0 + nl < nproc) {
+                float *rec = slab + (CARRY ? j0 + nl - p0 : e) * NC;
                 auto put = [](float *p, float v) {
                     if (SHARED) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f32
                     else *p = v;
@@ -1369,6 +1450,21 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                 }
             }
         }
+        if (CARRY && p0 == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (nproc > 0)  // the carried survivors were replayed (rows 0 .. ncin - 1): their part of last batch's records
+                for (int idx = lane; idx < ncin * NC; idx += 64) {
+                    const int k = idx / NC, c = idx - k * NC;
+                    __hip_atomic_fetch_add(pair_buf + (size_t)CL.cslot[w][k] * NCP + c, slab[idx], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+            const int left = total - nproc;  // 0 .. 15 survivors wait for the next super-batch
+            if (left > 0) carry_out<CH, SB>(L, CL, w, lane, nproc > 0 ? nproc : ncin, nproc > 0 ? left : left - ncin,
+                                            nproc > 0 ? 0 : ncin, top, slots);
+            ncarry = left;
+        }
+        if (CARRY && lane == 0) CL.more[w] = nproc > p0 + CAP;
         __syncthreads();
         // ---- combine the four slabs: thread (ce, cc) sums component cc of every EPI-th entry and stores it at the
         //      entry's pair slot (the NCP - NC pad floats of a record are never written; pair_reduce ignores them)
@@ -1380,6 +1476,13 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                 float v = 0.f;
                 if (SHARED) {
                     v = s_acc[0][e * NC + cc];
+                } else if (CARRY) {
+                    const unsigned int p4 = CL.pos4[e];
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) {  // row of this round's slab if the wave replayed the entry now, else the zero row
+                        const unsigned int pp = umin_(((p4 >> (8 * ww)) & 0xffu) - (unsigned)p0, (unsigned)CAP);
+                        v += s_acc[ww][pp * NC + cc];
+                    }
                 } else {
 #pragma unroll
                     for (int ww = 0; ww < Cfg::NSLAB; ++ww) {
@@ -1387,10 +1490,15 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                         v += ((fl >> (8 * ww)) & 0xffu) ? x : 0.f;
                     }
                 }
-                pair_buf[(size_t)slots[lo + ql] * NCP + cc] = v;
+                float *dst = pair_buf + (size_t)slots[lo + ql] * NCP + cc;
+                if (!CARRY || p0 == 0) *dst = v;
+                else *dst += v;  // a further round of the same super-batch: the same thread stored the record before
             }
         }
+        const bool more = CARRY && (CL.more[0] | CL.more[1] | CL.more[2] | CL.more[3]);
         __syncthreads();
+        if (!more) break;
+        }
     }
     if (A.dbg_T_front) {  // per-pixel transmittance after the last (front-most) replayed splat: lane q <-> pixel q of the block
         const int px = bx + (lane & 7), py = by + (lane >> 3);

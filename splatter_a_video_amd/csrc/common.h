@@ -59,6 +59,7 @@ struct ProfiledLaunch {
 
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
 
 // Tile rectangle of a splat: float arithmetic, truncation toward zero, clamp to [0, grid]
