@@ -111,6 +111,9 @@ def parse():
                     help="stale-1 mode: double-buffered gradient bucket, the all-reduce of step s overlaps step s+1's frames "
                          "and no optimiser runs (NOT synchronous data parallelism; for comparison only)")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the Adam step (forward+backward+all-reduce only)")
+    ap.add_argument("--no-spatial-order", action="store_true",
+                    help="keep the synthetic scene's random Gaussian order (default: Morton order of the screen positions, as "
+                         "densify.spatial_order / reorder_points maintain it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -458,6 +461,17 @@ def main():
     mode = ("render_iter_frame" if a.per_frame else "render_iter") if a.render_iter else "ops" if a.ops else "frame" if a.per_frame else "batch"
     clip = max(a.clip, 25 * world)
     sc = make_scene(a.gaussians, a.width, a.height, F=clip, C=a.channels, seed=1234)
+    if not a.no_spatial_order:
+        # setup, as a trainer does after initialisation and after every densification: Gaussians in Morton order of their
+        # screen positions (densify.spatial_order; results do not depend on the order, the binning kernels' locality does)
+        from splatter_a_video_amd.densify import spatial_order
+        uv0, _ = gs.project_point_ortho(torch.tensor(sc.positions(0), device=dev), torch.tensor(sc.extr, device=dev), a.width,
+                                        a.height, nearest=0.01)
+        order = spatial_order(uv0, a.width, a.height).cpu().numpy()
+        for k in ("xyz", "phase", "scale", "rotate", "opacity", "shs", "feature"):
+            v = getattr(sc, k)
+            if v is not None:
+                setattr(sc, k, np.ascontiguousarray(v[order]))
     # rank r renders frames {f : f mod world == r} of the step's frame batch
     frames = [((i * world + rank) % clip) for i in range(a.frames)]
 
@@ -502,7 +516,7 @@ def main():
     fps = frames_total / dt
     M, T = R.last["M"], R.last["T"]
     HW = a.width * a.height
-    tag_cfg = f"{a.gaussians}x{a.width}x{a.height}x{a.channels}:{mode}"
+    tag_cfg = f"{a.gaussians}x{a.width}x{a.height}x{a.channels}:{mode}" + ("" if a.no_spatial_order else ":morton")
 
     roofline = None
     kernels = {}
@@ -576,13 +590,14 @@ def main():
                                    + (", Adam step on the flat parameter buffer" if R.opt is not None else ""),
                        "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
                        "tile_pairs_M": M, "channels": R.C, "parallelism": par,
+                       "gaussian_order": "random" if a.no_spatial_order else "morton (densify.spatial_order at setup)",
                        "path": ("frame batch of the reference's dynamic Gaussians: their per-frame evaluation inside the batched "
                                 "preprocess, the Gaussian-side backward walks all frames" if (R.dynamic and mode == "batch") else
                                 "dynamic-Gaussian evaluation fused into the per-frame preprocess + gradient sinks" if R.dynamic else
                                 "render_iter of the reference's renderer (rgb enhanced K=20 + depth + 19 attribute channels per "
                                 "frame), native OrthoEnhancedRenderer, per-frame operators" if mode == "render_iter_frame" else
                                 "render_iter of the reference's renderer (rgb enhanced K=20 + depth + 19 attribute channels per frame) "
-                                "as a frame batch: one forward over the 23-channel row, one backward pass per feature set"
+                                "as a frame batch: one forward over the 23-channel row, one backward pass for the three feature sets"
                                 if mode == "render_iter" else
                                 "frame batch: the frame is a grid dimension of every kernel; SH and the Gaussian-side backward once per step"
                                 if mode == "batch" else

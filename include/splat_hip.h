@@ -237,6 +237,12 @@ int splat_frame_preprocess_backward(int P, int I, int seg, float d, const float 
                                     float *d_cubic, float *d_rotation, float *d_opacity, float *d_scaling,
                                     splat_stream_t stream);
 
+/* Spatial (Morton / Z-curve) order of the Gaussians: keys[i] = interleaved bits of (u / W, v / H) of uv[i] quantised to
+ * 15 bits each, >= 0.  A stable argsort of the keys is the order in which the binning / compositing kernels see
+ * neighbouring Gaussians next to each other in memory (densify.py::spatial_order / reorder_points apply it whenever the
+ * per-Gaussian arrays are rebuilt).  Not in the reference; results do not depend on the order. */
+int splat_morton_keys(int P, const float *uv, int W, int H, int32_t *keys, splat_stream_t stream);
+
 /* ---- densification statistics and structure updates -----------------------------------------
  * accumulate: one frame of a batch -- viewspace_grad[P,2] += tap[P,2] * (sx, sy) (tap = the frame's ndc / abs_ndc
  *   gradient, or dL_duv with sx = W/2, sy = H/2; tap and viewspace_grad may both be NULL), visible[P] |= radius > 0,

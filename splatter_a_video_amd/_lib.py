@@ -35,7 +35,7 @@ SYMBOLS = [
     "splat_frame_preprocess_forward", "splat_frame_preprocess_backward",
     "splat_densify_accumulate", "splat_densify_update", "splat_densify_masks",
     "splat_compact_scratch_bytes", "splat_compact_scan", "splat_compact_rows",
-    "splat_gather_rows_repeat", "splat_densify_split_sample",
+    "splat_gather_rows_repeat", "splat_densify_split_sample", "splat_morton_keys",
     "splat_knn_grid_cells", "splat_knn_plan_bytes", "splat_knn_build", "splat_knn_scatter", "splat_knn_search",
     "splat_adam_step", "splat_arap_energy",
     "splat_preprocess_ortho_forward_batch", "splat_bin_count_batch", "splat_bin_sort_batch",

@@ -207,7 +207,42 @@ split_sample_kernel(int P, const unsigned char *__restrict__ mask, const int *__
     }
 }
 
+// ---- spatial order of the Gaussians (Morton / Z-curve of the screen position).  The binning kernels walk the Gaussians in
+// index order and write every (Gaussian, tile) pair into its tile's key segment; with neighbours in the image next to each
+// other in memory those writes, the sort's owner gathers and the compositing kernels' record gathers touch a few tiles'
+// worth of lines per workgroup instead of the whole image's (c2: bin_scatter 17.8 -> 9.4 us, tile_sort 17.1 -> 12.3 us per
+// frame).  Densification rebuilds every per-Gaussian array anyway -- that is when the order is (re)established; between two
+// densifications the Gaussians move by a fraction of a tile.  Results do not depend on the order (ties of exactly equal
+// depths aside, which sort by Gaussian index as in the reference).
+__device__ __forceinline__ unsigned int spread15(unsigned int v) {  // bits of a 15-bit number to the even positions
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    return (v | (v << 1)) & 0x55555555u;
+}
+
+__global__ void __launch_bounds__(DB)
+morton_keys_kernel(int P, const float2 *__restrict__ uv, float sx, float sy, int *__restrict__ keys) {
+    const int i = blockIdx.x * DB + threadIdx.x;
+    if (i >= P) return;
+    const float2 q = uv[i];
+    const float fx = fminf(fmaxf(q.x * sx, 0.f), 32767.f), fy = fminf(fmaxf(q.y * sy, 0.f), 32767.f);  // NaN -> 0
+    keys[i] = (int)(spread15((unsigned int)fx) | (spread15((unsigned int)fy) << 1));
+}
+
 }  // namespace
+
+// keys [P] int32 (>= 0): Morton code of (u / W, v / H) quantised to 15 bits each (positions outside the image clamp to its
+// border).  argsort(keys, stable) is the spatial order; see densify.py::spatial_order.
+extern "C" int splat_morton_keys(int P, const float *uv, int W, int H, int32_t *keys, void *stream) {
+    SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0, "bad sizes");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(uv && keys, "null pointer");
+    SPLAT_LAUNCH("morton_keys", morton_keys_kernel, dgrid(P), dim3(DB), 0, (hipStream_t)stream, P, (const float2 *)uv,
+                 32768.f / (float)W, 32768.f / (float)H, keys);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
 
 extern "C" int splat_gather_rows_repeat(int P, const uint8_t *mask, const int32_t *index, int n_sel, int repeat,
                                         int row_words, const void *src, void *dst, void *stream) {

@@ -247,3 +247,29 @@ def prune_points(params: Dict[str, Tensor], moments: Optional[Moments], valid_po
     out_p = {k: kept[k] for k in params}
     out_m = None if moments is None else {k: (kept["\x00a" + k], kept["\x00b" + k]) for k in moments}
     return out_p, out_m
+
+
+def spatial_order(uv: Tensor, W: int, H: int) -> Tensor:
+    """Permutation (int64 [P]) that puts the Gaussians in Morton (Z-curve) order of their screen positions ``uv`` [P,2]
+    (pixels; any frame of the clip serves -- the Gaussians move by a fraction of a tile).  The binning kernels walk the
+    Gaussians in index order and scatter their (Gaussian, tile) pairs into per-tile segments; with image neighbours next to
+    each other in memory those writes and the later gathers stay inside a few tiles' worth of cache lines (BASELINE
+    configs[1]: bin_scatter 17.8 -> 9.4 us, tile_sort 17.1 -> 12.3 us per frame).  Apply it with ``reorder_points`` when the
+    per-Gaussian arrays are rebuilt anyway (after initialisation and after every densification).  The reference keeps
+    whatever order its point cloud has; rendering results do not depend on it."""
+    uv = L.need(uv.detach(), "uv")
+    P = uv.shape[0]
+    if uv.dim() != 2 or uv.shape[1] != 2:
+        raise ValueError("uv must be [P, 2]")
+    keys = torch.empty(P, dtype=torch.int32, device=uv.device)
+    L.check(L.lib().splat_morton_keys(L.ci(P), L.ptr(uv), L.ci(W), L.ci(H), L.ptr(keys), L.stream()))
+    return torch.sort(keys, stable=True).indices
+
+
+def reorder_points(params: Dict[str, Tensor], moments: Optional[Moments], perm: Tensor):
+    """Rows of every parameter (and of the two Adam moments of each) in the order ``perm`` -- the structural counterpart of
+    ``prune_points`` / ``densify_clone`` for a pure permutation (``spatial_order``)."""
+    out_p = {k: v.index_select(0, perm).contiguous() for k, v in params.items()}
+    out_m = None if moments is None else {k: (a.index_select(0, perm).contiguous(), b.index_select(0, perm).contiguous())
+                                          for k, (a, b) in moments.items()}
+    return out_p, out_m

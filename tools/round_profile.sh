@@ -25,10 +25,10 @@ find $O/prof -name '*kernel_stats*' | head -3
 B1="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing"
 bash tools/pmc_run.sh ${TAG}_rd "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum" $B1 < /dev/null > /dev/null
 bash tools/pmc_run.sh ${TAG}_wr "WRITE_SIZE" $B1 < /dev/null > /dev/null
-python tools/pmc_traffic.py gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr $O/pmc_traffic.json "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum (bytes = 32*n32+64*n64+128*n128) and WRITE_SIZE (KiB), separate passes, one step of the default bench.py (frame batch: 25 frames per launch), per launch" "300000x854x480x0:batch" > /dev/null
+python tools/pmc_traffic.py gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr $O/pmc_traffic.json "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum (bytes = 32*n32+64*n64+128*n128) and WRITE_SIZE (KiB), separate passes, one step of the default bench.py (frame batch: 25 frames per launch), per launch" "300000x854x480x0:batch:morton" > /dev/null
 # issue counters of the two compositing kernels on the same command (three passes)
 bash tools/pmc_run.sh ${TAG}_b1 "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA" $B1 < /dev/null > /dev/null
 bash tools/pmc_run.sh ${TAG}_b2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES" $B1 < /dev/null > /dev/null
 bash tools/pmc_run.sh ${TAG}_b3 "SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE" $B1 < /dev/null > /dev/null
-PMC_CONFIG="300000x854x480x0:batch" PMC_SOURCE="rocprofv3 --pmc, three passes over one step of the default bench.py (frame batch: 25 frames per launch), per launch, summed over the 8 XCDs; SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES in quad-cycles (guides/MI355X_MICROARCH.md)" python tools/pmc_blend_counters.py $O/pmc_blend_counters.json gpurun_out/pmc_${TAG}_b1 gpurun_out/pmc_${TAG}_b2 gpurun_out/pmc_${TAG}_b3
+PMC_CONFIG="300000x854x480x0:batch:morton" PMC_SOURCE="rocprofv3 --pmc, three passes over one step of the default bench.py (frame batch: 25 frames per launch), per launch, summed over the 8 XCDs; SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES in quad-cycles (guides/MI355X_MICROARCH.md)" python tools/pmc_blend_counters.py $O/pmc_blend_counters.json gpurun_out/pmc_${TAG}_b1 gpurun_out/pmc_${TAG}_b2 gpurun_out/pmc_${TAG}_b3
 ls $O
