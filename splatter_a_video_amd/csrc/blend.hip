@@ -58,9 +58,6 @@
 #ifndef BLEND_WIDE_MINW
 #define BLEND_WIDE_MINW 1
 #endif
-#ifndef BLEND_ENH_LDS
-#define BLEND_ENH_LDS 1
-#endif
 #ifndef BLEND_CARRY
 #define BLEND_CARRY 1
 #endif
@@ -563,13 +560,6 @@ blend_fwd_kernel(const BlendArgs B) {
     __shared__ TileLDS<CH, SB, !BIAS> L;
     __shared__ __attribute__((aligned(8))) unsigned short s_qlist[4][4][SB];  // [wave][quarter] survivor lists (32 e: coefficient-block byte offsets)
     __shared__ int s_done[4];
-    // ENH: the first K contributors of every pixel (gs_idx).  A store per applied splat straight to gs_idx[pixel, layer] is
-    // 64 four-byte writes 4 K bytes apart per instruction (+75 us per frame at K = 20, 300k Gaussians / 854x480); instead
-    // the LIST POSITION of the splat (16 bits) goes to LDS, and the tile's rows -- 16 K contiguous ints each in gs_idx's
-    // [H, W, K] layout -- are written coalesced at the end (position -> Gaussian id through the tile's sorted ids).
-    constexpr bool IDLDS = ENH && BLEND_ENH_LDS;
-    constexpr int IDK = 20;  // lists up to this K are staged in LDS; longer ones use the direct stores
-    __shared__ unsigned short s_ids[IDLDS ? 256 * IDK : 2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int gtile = xcd_tile(blockIdx.x, gridDim.x);
     const int frame = gtile / B.T, tile = gtile - frame * B.T;
@@ -591,9 +581,6 @@ blend_fwd_kernel(const BlendArgs B) {
     for (int k = 0; k < CH; ++k) F[k] = 0.f;
     const int2 range = A.tile_range[tile];
     const int n = range.y - range.x;
-    const bool idl = IDLDS && A.K <= IDK && n < 65535;  // uniform
-    if (idl)
-        for (int i = tid; i < 256 * IDK / 2; i += 256) reinterpret_cast<unsigned int *>(s_ids)[i] = 0xffffffffu;  // "no splat"
 
     if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
     if (!BIAS && tid < 2) L.coef[2 * SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -707,12 +694,10 @@ blend_fwd_kernel(const BlendArgs B) {
                     lastoff = app ? (int)off[u] : lastoff;
                     if (ENH) {
                         if (app && (A.trunc || layer < A.K)) {
-                            if (idl) {
-                                s_ids[tid * IDK + layer] = (unsigned short)(base + (int)(off[u] >> 5));
-                            } else {
-                                const size_t pix = (size_t)A.W * (size_t)py + px;
-                                A.gs_idx[pix * A.K + layer] = __float_as_int(g1[u].w);
-                            }
+                            // (staging the ids in LDS and writing the tile's rows coalesced at the end was slower:
+                            // 23-channel row, K = 20: 179 vs 161 us per frame)
+                            const size_t pix = (size_t)A.W * (size_t)py + px;
+                            A.gs_idx[pix * A.K + layer] = __float_as_int(g1[u].w);
                             layer++;
                             if (A.trunc && layer >= A.K) done = true;
                         }
@@ -731,21 +716,8 @@ blend_fwd_kernel(const BlendArgs B) {
 #pragma unroll
         for (int k = 0; k < CH; ++k)
             if (k < cn) A.out[(size_t)(A.c0 + k) * HW + pix] = F[k] + T * (A.bgc ? A.bgc[A.c0 + k] : A.bg);
-        if (ENH && !idl)
+        if (ENH)
             for (int l = layer; l < A.K; ++l) A.gs_idx[pix * A.K + l] = -1;  // unused slots (reference: -1 init)
-    }
-    if (idl) {  // the tile's 16 rows of gs_idx: wc * K contiguous ints each
-        __syncthreads();
-        const int K = A.K, wc = imin_(TILE, A.W - tx * TILE), hc = imin_(TILE, A.H - ty * TILE);
-        const int per_row = wc * K;
-        const int *ids = A.idx_sorted + range.x;
-        for (int i = tid; i < hc * per_row; i += 256) {
-            const int row = i / per_row, r = i - row * per_row;
-            const int col = r / K, l = r - col * K;
-            const int t = 64 * ((col >> 3) + 2 * (row >> 3)) + (col & 7) + 8 * (row & 7);  // thread that owns the pixel
-            const unsigned int q = s_ids[t * IDK + l];
-            A.gs_idx[((size_t)A.W * (size_t)(ty * TILE + row) + tx * TILE) * K + r] = q == 0xffffu ? -1 : ids[q];
-        }
     }
 }
 

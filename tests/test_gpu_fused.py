@@ -138,8 +138,9 @@ def test_sort_gaussian_capped_matches_sort_gaussian():
         img = gs.alpha_blending(uvg, cg, op, feat, i_, t_, 0.0, W, H)
         img.backward(g)
         outs.append([img.detach(), uvg.grad, cg.grad, op.grad.clone(), feat.grad.clone()])
-    for x, y in zip(*outs):
-        assert torch.equal(x, y)
+    assert torch.equal(outs[0][0], outs[1][0])
+    for x, y in zip(outs[0][1:], outs[1][1:]):   # (survivors carried over a super-batch boundary add their part with float
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-7 * float(y.abs().max()))   # atomics: not bit-reproducible)
     # too small: flagged, and check() raises
     _, _, st3 = gs.sort_gaussian_capped(uv, depth, W, H, radius, capacity=M // 2)
     with pytest.raises(Exception):

@@ -9,6 +9,7 @@ mkdir -p $O
 run() { name=$1; shift; timeout 400 python bench.py "$@" < /dev/null 2> $O/$name.err | tail -1 > $O/$name.json; cut -c1-160 $O/$name.json; }
 timeout 900 python -m pytest tests -m gpu -q < /dev/null > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 run bench_line                                   # default: frame batch, synchronous step with Adam, CPU baselines
+run bench_random_order --no-spatial-order --no-cpu-baseline
 run bench_per_frame --per-frame --no-cpu-baseline
 run bench_operator_chain --ops --no-cpu-baseline
 run bench_c4_1M_720p --gaussians 1000000 --width 1280 --height 720 --no-cpu-baseline
