@@ -330,7 +330,7 @@ int splat_alpha_blending_forward_batch(int F, int P, int C, const float *uv, con
                                        const int32_t *idx_sorted, const int32_t *tile_range, int64_t capacity, float bg,
                                        const float *bg_channels, int W, int H, int K, int enable_truncation, float *out,
                                        float *final_T, int32_t *ncontrib, int32_t *gs_idx, float *pack_scratch,
-                                       splat_stream_t stream);
+                                       uint32_t *cull_flags /*NULL or [F,capacity]: see below*/, splat_stream_t stream);
 /* exact stride (floats) of a pair record for this configuration: [ux uy ca cb cc o | ax ay (abs) | bias | features] padded
  * to whole 16-byte chunks */
 size_t splat_blend_pair_stride(int C, int want_abs, int has_bias);
@@ -341,7 +341,12 @@ int splat_alpha_blending_backward_batch(int F, int P, int C, const int32_t *idx_
                                         int64_t capacity, float bg, int W, int H, const float *final_T,
                                         const int32_t *ncontrib, const float *dL_dout, int want_abs,
                                         const int32_t *slot_sorted, float *pair_records, const float *pack,
+                                        const uint32_t *cull_flags /*NULL or the forward's*/,
                                         float *dbg_T_front /*NULL or [F,H,W]*/, splat_stream_t stream);
+/* cull_flags: one 32-bit word per sorted tile entry (frame stride = capacity), byte w != 0 = the forward kept the entry for
+ * the tile's 8x8 block w.  The forward writes them when the pointer is given; the backward then reads them instead of repeating the
+ * cull (the same decisions: both passes skip exactly the splats that cannot reach alpha >= 1/255 in a block, and the
+ * blocks that were saturated).  NULL on either side: that pass culls for itself. */
 /* Gaussian-side backward of a batch of static Gaussians + per-frame offsets under the orthographic camera: sums every
  * Gaussian's pair records over all frames and runs the preprocess backward (projection, EWA, cov3d: linear in the
  * summed dL_duv / dL_dconic because conic and Jacobian do not depend on the frame) once.  Replaces, per batch, F x
@@ -388,6 +393,7 @@ typedef struct splat_frames_t {
     float *tap, *abs_tap;             /* optional [P,2] */
     int32_t *radii_max;               /* optional [P] */
     float *dbg_T_front;               /* optional [F,H,W] */
+    uint32_t *cull_flags;              /* optional [F,capacity]: the forward's cull decisions, reused by the backward */
 } splat_frames_t;
 int splat_frames_count(const splat_frames_t *batch);
 int splat_frames_forward(const splat_frames_t *batch);
@@ -432,7 +438,8 @@ int splat_alpha_blending_backward_batch_sets(int F, int P, int C, const int32_t 
                                              const int32_t *tile_range, int64_t capacity, int W, int H,
                                              const float *final_T, const int32_t *ncontrib, const float *dL_dout,
                                              int want_abs, const int32_t *slot_sorted, float *pair_records,
-                                             float *pack_scratch, float *dbg_T_front, splat_stream_t stream);
+                                             float *pack_scratch, const uint32_t *cull_flags /*NULL or the forward's*/,
+                                             float *dbg_T_front, splat_stream_t stream);
 int splat_frames_gauss_backward_static_sets(int F, int P, int C, int W, int H, int64_t capacity, const float *pair_records,
                                             const int32_t *goff_incl, const int32_t *radius, const float *xyz,
                                             const float *scales, const float *uquats, const float *extr, int accumulate,

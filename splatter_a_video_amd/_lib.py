@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [

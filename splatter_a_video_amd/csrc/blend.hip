@@ -37,8 +37,9 @@
 #define BLEND_FWD_SB 128   // forward super-batch (narrow channel counts): 14 KB of LDS per workgroup
 #endif
 #ifndef BLEND_FWD_MINW
-#define BLEND_FWD_MINW 7   // __launch_bounds__ min waves per SIMD for the forward: 72 VGPRs, 7 workgroups per CU --
-                           // all 1620 tiles of a 480p frame are resident at once (no half-empty second round)
+#define BLEND_FWD_MINW 6   // __launch_bounds__ min waves per SIMD for the forward: 80 VGPRs, 6 workgroups per CU (with the
+                           // frame batch's 40 500 tiles per launch; 7 -- all tiles of ONE 480p frame resident -- costs 18
+                           // spilled registers once the cull flags are written: 84 vs 77 us per frame; 5: 80 us, 4: 88 us)
 #endif
 #ifndef BLEND_BWD_U
 #define BLEND_BWD_U 2
@@ -112,6 +113,10 @@ struct BlendArgs {
     // tap set (0), the second set (1) and the opacity-detached set (2); width 0 = no such set
     int s0c0, s0cn, s1c0, s1cn, s2c0, s2cn;
     float s0bg, s1bg, s2bg;
+    // optional [F, cap] words, one per sorted tile entry: byte w != 0 = the forward's cull kept the entry for the tile's
+    // block w (the keep word of tile_cull).  The forward writes them, the strip-walk backward kernels read them instead
+    // of repeating the cull (13 % of their VALU instructions); NULL: every kernel culls for itself.
+    unsigned int *cull_flags;
 };
 
 // per-frame view of the argument block (all uniform: scalar address arithmetic)
@@ -137,6 +142,7 @@ __device__ __forceinline__ BlendArgs frame_args(const BlendArgs &B, int f) {
         if (B.slot_sorted) A.slot_sorted = B.slot_sorted + fz * B.cap;
         if (B.goff_incl) A.goff_incl = B.goff_incl + fz * B.P;
         if (B.dbg_T_front) A.dbg_T_front = B.dbg_T_front + fz * HW;
+        if (B.cull_flags) A.cull_flags = B.cull_flags + fz * B.cap;
     }
     return A;
 }
@@ -408,8 +414,10 @@ struct Stager {
 // need before the geometric test.  Callers put a __syncthreads() between tile_cull and build_list.
 // SUB: the flag byte of a kept block carries one bit per 4x4 quarter (bit sx + 2 sy) from a bounding-box test of the
 // quarter's pixel centres, for kernels that keep a survivor list per quarter; otherwise the byte is 0 / 1.
+// gflags: optional global copy of the staged entries' keep words (BlendArgs::cull_flags + the super-batch's first position).
 template <int CH, int SB, bool BIAS, bool SUB, bool COEF, int XR, typename Pred>
-__device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR> &L, int tid, int nb, float tx0, float ty0, Pred pred) {
+__device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR> &L, int tid, int nb, float tx0, float ty0, Pred pred,
+                                          unsigned int *gflags = nullptr) {
     constexpr int TPE = 256 / SB;  // threads per entry (1, 2 or 4): each tests 4 / TPE of the blocks
     constexpr int BPT = 4 / TPE;
     static_assert(SB == 64 || SB == 128 || SB == 256, "super-batch sizes the 256-thread cull supports");
@@ -460,6 +468,12 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR> &L, int tid,
     }
 #pragma unroll
     for (int j = 0; j < BPT; ++j) flags[j] = (unsigned char)k[j];
+    if (gflags && e < nb) {  // the same bytes, for the backward (thread (e, part) owns bytes BPT part .. of word e)
+        unsigned char *g = reinterpret_cast<unsigned char *>(gflags) + 4 * e + BPT * part;
+        if (BPT == 4) *reinterpret_cast<unsigned int *>(g) = k[0] | (k[1 % BPT] << 8) | (k[2 % BPT] << 16) | (k[3 % BPT] << 24);
+        else if (BPT == 2) *reinterpret_cast<unsigned short *>(g) = (unsigned short)(k[0] | (k[1 % BPT] << 8));
+        else *g = (unsigned char)k[0];
+    }
 }
 
 // wave w's order-preserving survivor list from the flag bytes; returns the count.
@@ -479,6 +493,21 @@ __device__ __forceinline__ int build_list(TileLDS<CH, SB, COEF, XR> &L, int w, i
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return cnt;
+}
+
+// The forward's cull decisions instead of a second cull (BlendArgs::cull_flags): thread e turns the entry's flag byte into
+// the keep word tile_cull would have produced (byte w != 0: wave w replays the entry), with the same predicate.
+template <int CH, int SB, bool COEF, int XR, typename Pred>
+__device__ __forceinline__ void keep_from_flags(TileLDS<CH, SB, COEF, XR> &L, int tid, int nb, unsigned flags, Pred pred) {
+    if (tid < SB) {
+        unsigned kw = 0u;
+        if (tid < nb) {
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww)
+                if (((flags >> (8 * ww)) & 0xffu) && pred(tid, ww)) kw |= 1u << (8 * ww);
+        }
+        L.keep[tid] = kw;
+    }
 }
 
 // ---- survivors carried over a super-batch boundary (strip-walk backward kernels).  A chunk of the matrix-core kernels
@@ -600,7 +629,9 @@ blend_fwd_kernel(const BlendArgs B) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
         if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;  // every pixel of the tile is saturated
-        tile_cull<CH, SB, BIAS, true, !BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE), [&](int, int ww) { return !s_done[ww]; });
+        // (the keep words also go to A.cull_flags: what the backward needs of this cull -- a saturated block keeps nothing)
+        tile_cull<CH, SB, BIAS, true, !BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE), [&](int, int ww) { return !s_done[ww]; },
+                                             A.cull_flags ? A.cull_flags + range.x + base : nullptr);
         __syncthreads();
         if (!alld) {
             // one order-preserving survivor list per 4x4 quarter of the wave's block: the 16 lanes of a quarter walk
@@ -1288,6 +1319,12 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     st.load_ids(A, tid, range.x, pos, 0);
     st.load_payload(A, tid);
     st.load_ids(A, tid, range.x, pos, 1);
+    // the forward's cull flags of the super-batch (thread e: entry e), one super-batch ahead
+    auto load_flags = [&](int topb) -> unsigned {
+        const int q = topb - tid;
+        return (A.cull_flags && tid < SB && q >= 0) ? (unsigned)A.cull_flags[range.x + q] : 0u;
+    };
+    unsigned fl_next = load_flags(n - 1);
 
     int batch = 0;
     int ncarry = 0;  // survivors waiting in this wave's carry rows
@@ -1296,9 +1333,14 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         st.park(L, tid);
         st.load_payload(A, tid);                       // payload of the next super-batch
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
+        const unsigned fl = fl_next;
+        fl_next = load_flags(top - SB);
         __syncthreads();
 
-        tile_cull<CH, SB, false, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+        if (A.cull_flags)
+            keep_from_flags(L, tid, nb, fl, [&](int e, int ww) { return top - e < s_wmax[ww]; });
+        else
+            tile_cull<CH, SB, false, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
                                  [&](int e, int ww) { return top - e < s_wmax[ww]; });
         if (SHARED)
             for (int i = tid; i < nb * NC; i += 256) s_acc[0][i] = 0.f;
@@ -1684,6 +1726,12 @@ blend_bwd_sets_kernel(const BlendArgs B) {
     st.load_ids(A, tid, range.x, pos, 0);
     st.load_payload(A, tid);
     st.load_ids(A, tid, range.x, pos, 1);
+    // the forward's cull flags of the super-batch (thread e: entry e), one super-batch ahead
+    auto load_flags = [&](int topb) -> unsigned {
+        const int q = topb - tid;
+        return (A.cull_flags && tid < SB && q >= 0) ? (unsigned)A.cull_flags[range.x + q] : 0u;
+    };
+    unsigned fl_next = load_flags(n - 1);
     __syncthreads();  // every wave has read its staging rows: the slabs are free
 
     int batch = 0;
@@ -1692,8 +1740,13 @@ blend_bwd_sets_kernel(const BlendArgs B) {
         st.park(L, tid);
         st.load_payload(A, tid);
         st.load_ids(A, tid, range.x, pos, batch + 2);
+        const unsigned fl = fl_next;
+        fl_next = load_flags(top - SB);
         __syncthreads();
-        tile_cull<CH, SB, false, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
+        if (A.cull_flags)
+            keep_from_flags(L, tid, nb, fl, [&](int e, int ww) { return top - e < s_wmax[ww]; });
+        else
+            tile_cull<CH, SB, false, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
                                                [&](int e, int ww) { return top - e < s_wmax[ww]; });
         __syncthreads();
         const int cnt = build_list(L, w, lane);
@@ -2173,7 +2226,8 @@ extern "C" int splat_alpha_blending_forward_batch(int F, int P, int C, const flo
                                                   const int32_t *idx_sorted, const int32_t *tile_range, int64_t capacity,
                                                   float bg, const float *bg_channels, int W, int H, int K,
                                                   int enable_truncation, float *out, float *final_T, int32_t *ncontrib,
-                                                  int32_t *gs_idx, float *pack_scratch, splat_stream_t stream) {
+                                                  int32_t *gs_idx, float *pack_scratch, uint32_t *cull_flags,
+                                                  splat_stream_t stream) {
     SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 32 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 32)");
     SPLAT_CHECK_ARG(uv && conic && opacity && feature && idx_sorted && tile_range && out && final_T && ncontrib &&
                         pack_scratch,
@@ -2188,6 +2242,7 @@ extern "C" int splat_alpha_blending_forward_batch(int F, int P, int C, const flo
     A.K = enh ? K : 0; A.trunc = enable_truncation ? 1 : 0;
     A.out = out; A.final_T = final_T; A.ncontrib = ncontrib; A.gs_idx = gs_idx;
     A.pack = pack_scratch;
+    A.cull_flags = cull_flags;
     const int T = A.gx * ((H + TILE - 1) / TILE);
     SPLAT_CHECK_ARG((long long)F * T < (1ll << 31), "too many tiles");
     A.F = F; A.T = T; A.cap = capacity;
@@ -2201,7 +2256,8 @@ extern "C" int splat_alpha_blending_backward_batch(int F, int P, int C, const in
                                                    const int32_t *tile_range, int64_t capacity, float bg, int W, int H,
                                                    const float *final_T, const int32_t *ncontrib, const float *dL_dout,
                                                    int want_abs, const int32_t *slot_sorted, float *pair_records,
-                                                   const float *pack, float *dbg_T_front, splat_stream_t stream) {
+                                                   const float *pack, const uint32_t *cull_flags, float *dbg_T_front,
+                                                   splat_stream_t stream) {
     // writes one gradient record per (frame, tile, splat) pair at frame * capacity + slot; the records are summed per
     // Gaussian by the Gaussian-side backward (splat_frames_gauss_backward_*).  `pack` = the forward's packed records.
     SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 32 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 32)");
@@ -2217,6 +2273,7 @@ extern "C" int splat_alpha_blending_backward_batch(int F, int P, int C, const in
     A.slot_sorted = slot_sorted; A.pair_buf = pair_records;
     A.pack = const_cast<float *>(pack); A.pack_valid = 1;
     A.dbg_T_front = dbg_T_front;
+    A.cull_flags = const_cast<uint32_t *>(cull_flags);
     const int T = A.gx * ((H + TILE - 1) / TILE);
     A.F = F; A.T = T; A.cap = capacity; A.tile_only = 1;
     A.pack_fs = (long long)P * (long long)splat_blend_pack_floats(C);
@@ -2281,7 +2338,8 @@ extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, con
                                                         int64_t capacity, int W, int H, const float *final_T,
                                                         const int32_t *ncontrib, const float *dL_dout, int want_abs,
                                                         const int32_t *slot_sorted, float *pair_records,
-                                                        float *pack_scratch, float *dbg_T_front, splat_stream_t stream) {
+                                                        float *pack_scratch, const uint32_t *cull_flags,
+                                                        float *dbg_T_front, splat_stream_t stream) {
     SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= SetsCfg::CH && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 28)");
     SPLAT_CHECK_ARG(set_c0 && set_cn && set_bg, "null set table");
     SPLAT_CHECK_ARG(uv && conic && opacity && feature && idx_sorted && tile_range && final_T && ncontrib && dL_dout &&
@@ -2311,6 +2369,7 @@ extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, con
     A.slot_sorted = slot_sorted; A.pair_buf = pair_records;
     A.pack = pack_scratch;
     A.dbg_T_front = dbg_T_front;
+    A.cull_flags = const_cast<uint32_t *>(cull_flags);
     const int T = A.gx * ((H + TILE - 1) / TILE);
     A.F = F; A.T = T; A.cap = capacity; A.tile_only = 1;
     A.pack_fs = (long long)P * (long long)Rec<SetsCfg::CH>::RS;

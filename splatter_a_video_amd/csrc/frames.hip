@@ -17,7 +17,7 @@ extern "C" int splat_frames_forward(const splat_frames_t *b) {
     if (rc != SPLAT_OK) return rc;
     return splat_alpha_blending_forward_batch(b->F, b->P, b->C, b->uv, b->conic, b->opacity, 0, b->feature, 0, b->idx_sorted,
                                               b->tile_range, b->capacity, b->bg, nullptr, b->W, b->H, 0, 0, b->out, b->final_T,
-                                              b->ncontrib, nullptr, b->pack, b->stream);
+                                              b->ncontrib, nullptr, b->pack, b->cull_flags, b->stream);
 }
 
 // geometry + pair counts only: pairs[F] (device) tells the caller how much capacity to reserve before the first
@@ -35,7 +35,7 @@ extern "C" int splat_frames_backward(const splat_frames_t *b) {
     SPLAT_CHECK_ARG(b->dL_dout && b->pair_records, "null pointer");
     int rc = splat_alpha_blending_backward_batch(b->F, b->P, b->C, b->idx_sorted, b->tile_range, b->capacity, b->bg, b->W, b->H,
                                                  b->final_T, b->ncontrib, b->dL_dout, b->want_abs, b->slot_sorted,
-                                                 b->pair_records, b->pack, b->dbg_T_front, b->stream);
+                                                 b->pair_records, b->pack, b->cull_flags, b->dbg_T_front, b->stream);
     if (rc != SPLAT_OK) return rc;
     return splat_frames_gauss_backward_static(b->F, b->P, b->C, b->W, b->H, b->capacity, b->want_abs, b->pair_records,
                                               b->goff_incl, b->radius, b->xyz, b->scales, b->uquats, b->extr, b->accumulate,

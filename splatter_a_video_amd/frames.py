@@ -35,7 +35,7 @@ _FRAMES_FIELDS = ([("struct_bytes", ctypes.c_size_t)]
                       "xyz", "offsets", "scales", "uquats", "opacity", "feature", "extr", "uv", "depth", "conic", "radius",
                       "bin_scratch", "tile_range", "pairs", "overflow", "goff_incl", "owner", "idx_sorted", "slot_sorted", "keys",
                       "pack", "out", "final_T", "ncontrib", "dL_dout", "pair_records", "d_xyz", "d_scales", "d_uquats",
-                      "d_opacity", "d_feature", "tap", "abs_tap", "radii_max", "dbg_T_front")])
+                      "d_opacity", "d_feature", "tap", "abs_tap", "radii_max", "dbg_T_front", "cull_flags")])
 
 
 class _SplatFrames(ctypes.Structure):
@@ -86,7 +86,7 @@ class FrameBatch:
         self.abs_tap = torch.zeros(P_, 2, dtype=f32, device=dev) if want_abs else None
         self.radii_max = torch.zeros(P_, dtype=i32, device=dev)
         self.capacity = None
-        self.keys = self.owner = self.idx_sorted = self.slot_sorted = self.pair_records = None
+        self.keys = self.owner = self.idx_sorted = self.slot_sorted = self.pair_records = self.cull_flags = None
         if capacity is not None:
             self._reserve(int(capacity))
 
@@ -99,6 +99,7 @@ class FrameBatch:
         self.idx_sorted = torch.empty(F_, capacity, dtype=torch.int32, device=dev)
         self.slot_sorted = torch.empty(F_, capacity, dtype=torch.int32, device=dev)
         self.pair_records = torch.empty(F_ * capacity * self.ncp, dtype=torch.float32, device=dev)
+        self.cull_flags = torch.empty(F_, capacity, dtype=torch.int32, device=dev)   # the forward's cull, for the backward
 
     def _set_buffer(self, key, numel: int) -> Tensor:
         """scratch of the multi-set backward (pair records / packed records per feature set), kept across steps"""
@@ -157,7 +158,8 @@ class FrameBatch:
                             tile_range=self.tile_range, pairs=self.pairs, overflow=self.overflow, goff_incl=self.goff,
                             owner=self.owner, idx_sorted=self.idx_sorted, slot_sorted=self.slot_sorted, keys=self.keys,
                             pack=self.pack, final_T=self.final_T, ncontrib=self.ncontrib, pair_records=self.pair_records,
-                            tap=self.tap, abs_tap=self.abs_tap, radii_max=self.radii_max).items():
+                            tap=self.tap, abs_tap=self.abs_tap, radii_max=self.radii_max,
+                            cull_flags=self.cull_flags).items():
             setattr(b, name, dp(t))
         return b
 
@@ -286,7 +288,8 @@ class _RenderDynamic(torch.autograd.Function):
         L.check(lib.splat_alpha_blending_forward_batch(
             L.ci(F), L.ci(P), L.ci(C), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opa_t), ctypes.c_int64(0), L.ptr(feature),
             ctypes.c_int64(0), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.cf(bg), L.ptr(None), L.ci(W),
-            L.ci(H), L.ci(0), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(None), L.ptr(fb.pack), st))
+            L.ci(H), L.ci(0), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(None), L.ptr(fb.pack),
+            L.ptr(fb.cull_flags), st))
         ctx.fb, ctx.meta, ctx.sink = fb, (I, layout, bg), sink
         ctx.save_for_backward(position, cubic, rotation, opacity, scaling, feature, rot_poly, rot_fourier, extr_c, tab)
         return out
@@ -304,7 +307,7 @@ class _RenderDynamic(torch.autograd.Function):
         L.check(lib.splat_alpha_blending_backward_batch(
             L.ci(F), L.ci(P), L.ci(C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.cf(bg), L.ci(W), L.ci(H),
             L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(g), L.ci(1 if fb.want_abs else 0), L.ptr(fb.slot_sorted),
-            L.ptr(fb.pair_records), L.ptr(fb.pack), L.ptr(_debug_T_front(F * H, W, g.device)), st))
+            L.ptr(fb.pair_records), L.ptr(fb.pack), L.ptr(fb.cull_flags), L.ptr(_debug_T_front(F * H, W, g.device)), st))
         like = {"position": position, "pos_cubic_node": cubic, "rotation": rotation, "opacity": opacity, "scaling": scaling,
                 "feature": feature}
         need = dict(zip(like, ctx.needs_input_grad[:6]))
@@ -381,7 +384,7 @@ class _RenderSets(torch.autograd.Function):
             L.ci(F), L.ci(P), L.ci(C), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity), ctypes.c_int64(op_fs), L.ptr(row),
             ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.cf(0.0), L.ptr(bgc),
             L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx),
-            L.ptr(fb.pack), st))
+            L.ptr(fb.pack), L.ptr(fb.cull_flags), st))
         ctx.fb, ctx.meta, ctx.sink, ctx.K = fb, meta, sink, K
         ctx.row = row
         ctx.save_for_backward(xyz, scales, uquats, opacity, extr_c, *feats)
@@ -437,7 +440,7 @@ class _RenderSets(torch.autograd.Function):
                 L.ci(F), L.ci(P), L.ci(C), i3(*c0s), i3(*cns), f3(*bgs), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity),
                 ctypes.c_int64(op_fs), L.ptr(ctx.row), ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range),
                 ctypes.c_int64(cap), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(dL), L.ci(want_abs),
-                L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(_debug_T_front(F * H, W, dev)), st))
+                L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(fb.cull_flags), L.ptr(_debug_T_front(F * H, W, dev)), st))
             p3 = (ctypes.c_void_p * 3)(*[0 if d is None else d.data_ptr() for d in dfs])
             has_tap = tap_set is not None
             L.check(lib.splat_frames_gauss_backward_static_sets(

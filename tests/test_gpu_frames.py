@@ -76,6 +76,42 @@ def test_batch_equals_per_frame_operators(N, W, H, F, C, abs_tap):
     assert torch.equal(B.radii_max, ref_rad)
 
 
+@pytest.mark.parametrize("C", [3, 16])
+def test_batch_dense_saturating_scene(C):
+    """Long tile lists of large, faint splats: pixels saturate a few hundred splats in, long before their list ends (the forward stops
+    whole blocks -- their cull flags stay 0 for the backward), more than half of a super-batch survives a block's cull (the
+    backward's slabs take a second round), survivors are carried across many super-batches."""
+    N, W, H, F = 12000, 64, 48, 2
+    sc = make_scene(N, W, H, seed=77)
+    sc.scale[:] = sc.scale * 6.0
+    sc.opacity[:] = np.clip(sc.opacity * 0.08 + 0.03, 0.0, 0.97)
+    rng = np.random.default_rng(1)
+    off = _t(_offsets(sc, F))
+    featv = rng.uniform(size=(N, C)).astype(np.float32)
+    g = _t(rng.normal(size=(F, C, H, W)).astype(np.float32))
+
+    def params():
+        return {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity).items()}
+
+    pa, fa = params(), _t(featv, True)
+    ref_img, ref_tap, _, _ = _per_frame(sc, pa, off, fa, g, W, H, 0.0)
+    pb, fb_ = params(), _t(featv, True)
+    B = FrameBatch(F, N, W, H, C, "cuda")
+    out = B.render(pb["xyz"], pb["scales"], pb["uquats"], pb["opacity"], fb_, off, _t(sc.extr), bg=0.0)
+    assert torch.equal(out, ref_img)
+    assert int(B.ncontrib.max()) > 200 and float(B.final_T.min()) < 1.1e-4     # long replays, saturated pixels
+    with capture_T_front() as cap:
+        out.backward(g)
+    torch.cuda.synchronize()
+    assert B.check() > 100 * B.T
+    assert float((cap.maps[0] - 1).abs().max()) < 2e-4
+    for k in pa:
+        a, b = pb[k].grad, pa[k].grad
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-5 * float(b.abs().max()) + 1e-12), k
+    assert torch.allclose(fb_.grad, fa.grad, rtol=1e-3, atol=1e-5 * float(fa.grad.abs().max()) + 1e-12)
+    assert torch.allclose(B.tap, ref_tap, rtol=1e-3, atol=1e-5 * float(ref_tap.abs().max()) + 1e-12)
+
+
 def test_batch_gradient_sinks_and_reuse():
     """the backward adds into caller-owned buffers (FlatGradBucket views); a FrameBatch is reused step after step
     without a host sync"""
