@@ -63,7 +63,7 @@
 #define BLEND_CARRY 1
 #endif
 #ifndef BLEND_WIDE_HOIST
-#define BLEND_WIDE_HOIST 0
+#define BLEND_WIDE_HOIST 1
 #endif
 // power is a negative-semidefinite form: it can only exceed 0 by rounding.  The matrix-core kernels evaluate it as
 // an expanded polynomial (absolute error up to ~5e-6 in log2 units), so their "power > 0" guard of the reference

@@ -341,9 +341,14 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
     for (int c = 0; c < NS; ++c) a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     int rmax = 0;
     bool any = false;
+    int nbeg = i > 0 ? A.goff[i - 1] : 0, nend = A.goff[i];
     for (int f = 0; f < A.F; ++f) {
-        const int *goff = A.goff + (size_t)f * A.P;
-        const int beg = i > 0 ? goff[i - 1] : 0, end = goff[i];
+        const int beg = nbeg, end = nend;
+        if (f + 1 < A.F) {  // the next frame's slot range is in flight while this frame's records are summed
+            const int *goff = A.goff + (size_t)(f + 1) * A.P;
+            nbeg = i > 0 ? goff[i - 1] : 0;
+            nend = goff[i];
+        }
         if (A.radii_max && sub == 0) rmax = imax_(rmax, A.radius[(size_t)f * A.P + i]);
         any = any || end > beg;
         const float *base = A.pair + (size_t)f * (size_t)A.cap * NCP + 4 * sub;
@@ -510,6 +515,9 @@ frame_preprocess_fwd_batch_kernel(int F, int P, int I, int layout, const DynTab 
 // cov3d backward and chains through the activations -- scale = exp, rotation = normalize(raw + detached sums), opacity =
 // sigmoid, position = base + cubic segment.  Everything accumulates in registers; the spline segment's four coefficient
 // rows are flushed when the walk leaves the segment (frames of a batch are time-ordered: a handful of flushes).
+#ifndef GAUSS_DYN_MINW
+#define GAUSS_DYN_MINW 4
+#endif
 struct GaussDynArgs {
     int F, P, W, H, I, layout;
     int C, cn;
@@ -527,7 +535,7 @@ struct GaussDynArgs {
 };
 
 template <bool ABS, int NCP>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, GAUSS_DYN_MINW)
 frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
     constexpr int NG = GradLayout<ABS, false>::NG;
     constexpr int NQ = NCP / 4, NS = (NQ + 3) / 4;
@@ -550,36 +558,14 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k * ca.stride_k] += acc_c[k];
     };
-    for (int f = 0; f < A.F; ++f) {
-        const int *goff = A.goff + (size_t)f * A.P;
-        const int beg = n > 0 ? goff[n - 1] : 0, end = goff[n];
-        if (A.radii_max && j == 0) rmax = imax_(rmax, A.radius[(size_t)f * A.P + n]);
-        if (end <= beg) continue;  // quad-uniform
-        float4 af[NS];
-#pragma unroll
-        for (int c = 0; c < NS; ++c) af[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float *base = A.pair + (size_t)f * (size_t)A.cap * NCP + 4 * j;
-        for (int r = beg; r < end; ++r) {
-#pragma unroll
-            for (int c = 0; c < NS; ++c) {
-                if (4 * c + j < NQ) {
-                    const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)r * NCP + 16 * c);
-                    af[c].x += v.x; af[c].y += v.y; af[c].z += v.z; af[c].w += v.w;
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NS; ++c) {
-            atot[c].x += af[c].x; atot[c].y += af[c].y; atot[c].z += af[c].z; atot[c].w += af[c].w;
-        }
-        const float ux = quad_bcast<0>(af[0].x), uy = quad_bcast<0>(af[0].y);
-        const float g3[3] = {quad_bcast<0>(af[0].z), quad_bcast<0>(af[0].w), quad_bcast<1>(af[0].x)};
-        tap_u += ux; tap_v += uy;
-        if (ABS) {
-            atap_u += quad_bcast<1>(af[0].z); atap_v += quad_bcast<1>(af[0].w);
-        }
+    // The frames are walked in groups of (up to) four of one spline segment: the quad sums frame f + k's records and
+    // re-evaluates its position / rotation together (lane j = component j), lane k KEEPS frame f + k; then every lane runs
+    // the projection / EWA / cov3d / normalisation chain ONCE, for its own frame (the chain on all four lanes for every
+    // frame was 4x redundant), and quad sums hand component j of the four frames' results to lane j.
+    float scl3[3] = {quad_bcast<0>(stc.scl_j), quad_bcast<1>(stc.scl_j), quad_bcast<2>(stc.scl_j)};
+    int f = 0;
+    while (f < A.F) {
         const int seg = A.tab[f].seg;
-        const float dseg = A.tab[f].d;
         if (seg != cur_seg) {
             flush(cur_seg);
 #pragma unroll
@@ -587,41 +573,92 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
             cur_seg = seg;
         }
         const CubicAddr ca = cubic_addr(A.layout, A.P, A.I, seg);
-        const DynFrame fr = dyn_frame_rows(n, j, ca, dseg, A.tab[f].basis, stc, A.cubic);
-        float gp[3], ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
-        project_ortho_grad_pt(cam, A.W, A.H, ux, uy, 0.f, gp);
-        {
+        float m_ux = 0.f, m_uy = 0.f, m_g3[3] = {0.f, 0.f, 0.f}, m_pos[3] = {0.f, 0.f, 0.f}, m_q[4] = {1.f, 0.f, 0.f, 0.f};
+        float m_nrm = 1.f, m_d = 0.f;
+        bool m_valid = false;
+        int took = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ff = f + k;
+            if (ff >= A.F || A.tab[ff].seg != seg) break;  // grid-uniform
+            took = k + 1;
+            const int *goff = A.goff + (size_t)ff * A.P;
+            const int beg = n > 0 ? goff[n - 1] : 0, end = goff[n];
+            if (A.radii_max && j == 0) rmax = imax_(rmax, A.radius[(size_t)ff * A.P + n]);
+            if (end <= beg) continue;  // quad-uniform: no record of this Gaussian in frame ff
+            float4 af[NS];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) af[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *base = A.pair + (size_t)ff * (size_t)A.cap * NCP + 4 * j;
+            for (int r = beg; r < end; ++r) {
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    if (4 * c + j < NQ) {
+                        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)r * NCP + 16 * c);
+                        af[c].x += v.x; af[c].y += v.y; af[c].z += v.z; af[c].w += v.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                atot[c].x += af[c].x; atot[c].y += af[c].y; atot[c].z += af[c].z; atot[c].w += af[c].w;
+            }
+            const float ux = quad_bcast<0>(af[0].x), uy = quad_bcast<0>(af[0].y);
+            const float ga = quad_bcast<0>(af[0].z), gb = quad_bcast<0>(af[0].w), gc = quad_bcast<1>(af[0].x);
+            tap_u += ux; tap_v += uy;
+            if (ABS) {
+                atap_u += quad_bcast<1>(af[0].z); atap_v += quad_bcast<1>(af[0].w);
+            }
+            const float dseg = A.tab[ff].d;
+            const DynFrame fr = dyn_frame_rows(n, j, ca, dseg, A.tab[ff].basis, stc, A.cubic);
+            if (j == k) {
+                m_ux = ux; m_uy = uy; m_g3[0] = ga; m_g3[1] = gb; m_g3[2] = gc;
+                m_pos[0] = fr.pos[0]; m_pos[1] = fr.pos[1]; m_pos[2] = fr.pos[2];
+                m_q[0] = fr.q[0]; m_q[1] = fr.q[1]; m_q[2] = fr.q[2]; m_q[3] = fr.q[3];
+                m_nrm = fr.nrm; m_d = dseg; m_valid = true;
+            }
+        }
+        f += took;
+        // ---- the chain, once per lane for the lane's own frame
+        float gp[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m_valid) {
+            float dq[4] = {0.f, 0.f, 0.f, 0.f};
+            project_ortho_grad_pt(cam, A.W, A.H, m_ux, m_uy, 0.f, gp);
             float c3[6], ea[3], eb[3], et[3], Jm[4], cov[3];
-            cov3d_pt(fr.scl, fr.q, c3);
-            ewa_T<true>(cam, fr.pos, A.W, A.H, ea, eb, et, Jm);
+            cov3d_pt(scl3, m_q, c3);
+            ewa_T<true>(cam, m_pos, A.W, A.H, ea, eb, et, Jm);
             ewa_cov2d<true>(ea, eb, c3, cov);
             const float det = cov[0] * cov[2] - cov[1] * cov[1];
             if (det != 0.0f) {
                 float dcx, dcy, dcz, g6[6];
-                ewa_grad_cov_pt(ea, eb, cov, det, g3, dcx, dcy, dcz, g6);
-                cov3d_grad_pt(fr.scl, fr.q, g6, ds, dq);
+                ewa_grad_cov_pt(ea, eb, cov, det, m_g3, dcx, dcy, dcz, g6);
+                cov3d_grad_pt(scl3, m_q, g6, ds, dq);
             }
-        }
-        if (j < 3) {
-            const float g = j == 0 ? gp[0] : j == 1 ? gp[1] : gp[2];
-            const float d = dseg;
-            d_pos += g;
-            acc_c[0] += g * (d * d * d); acc_c[1] += g * (d * d); acc_c[2] += g * d; acc_c[3] += g;
-            const float dsj = j == 0 ? ds[0] : j == 1 ? ds[1] : ds[2];
-            const float sj = j == 0 ? fr.scl[0] : j == 1 ? fr.scl[1] : fr.scl[2];
-            d_scl += dsj * sj;
-        }
-        {
-            const float gq = j == 0 ? dq[0] : j == 1 ? dq[1] : j == 2 ? dq[2] : dq[3];
-            float r;
-            if (fr.nrm < 1e-12f) {
-                r = gq / 1e-12f;
+            if (m_nrm < 1e-12f) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rq[c] = dq[c] / 1e-12f;
             } else {
-                const float dot = fr.q[0] * dq[0] + fr.q[1] * dq[1] + fr.q[2] * dq[2] + fr.q[3] * dq[3];
-                const float qh = j == 0 ? fr.q[0] : j == 1 ? fr.q[1] : j == 2 ? fr.q[2] : fr.q[3];
-                r = (gq - qh * dot) / fr.nrm;
+                const float dot = m_q[0] * dq[0] + m_q[1] * dq[1] + m_q[2] * dq[2] + m_q[3] * dq[3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rq[c] = (dq[c] - m_q[c] * dot) / m_nrm;
             }
-            d_rot += r;
+        }
+        // ---- component jj of the four frames' results to lane jj
+        const float d1 = m_d, d2 = m_d * m_d, d3 = m_d * m_d * m_d;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const float s0 = quad_sum(gp[jj]), s1 = quad_sum(gp[jj] * d1), s2 = quad_sum(gp[jj] * d2), s3 = quad_sum(gp[jj] * d3);
+            const float ss = quad_sum(ds[jj] * scl3[jj]);
+            if (j == jj) {
+                d_pos += s0;
+                acc_c[0] += s3; acc_c[1] += s2; acc_c[2] += s1; acc_c[3] += s0;
+                d_scl += ss;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float sr = quad_sum(rq[jj]);
+            if (j == jj) d_rot += sr;
         }
     }
     flush(cur_seg);

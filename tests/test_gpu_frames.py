@@ -131,7 +131,7 @@ def test_batch_gradient_sinks_and_reuse():
         B.render(q["xyz"], q["scales"], q["uquats"], q["opacity"], q["feature"], off, _t(sc.extr), grad_sink=sink).backward(g)
     for k in p:
         assert q[k].grad is None
-        assert torch.allclose(sink[k], 0.5 + 2 * want[k], rtol=1e-5, atol=1e-6 * float(want[k].abs().max()) + 1e-7), k
+        assert torch.allclose(sink[k], 0.5 + 2 * want[k], rtol=2e-4, atol=2e-6 * float(want[k].abs().max()) + 1e-7), k
     B.check()
 
 
@@ -330,4 +330,4 @@ def test_dynamic_batch_equals_per_frame_dynamic_path(layout):
                      rotation=pc["rotation"], rot_poly_feat=rot_poly, rot_fourier_feat=rot_four, opacity=pc["opacity"],
                      scaling=pc["scaling"], cubic_layout=lay, bg=0.1, grad_sink=sink).backward(g)
     for k in pc:
-        assert pc[k].grad is None and torch.allclose(sink[k], pb[k].grad, rtol=1e-5, atol=1e-7 * float(pb[k].grad.abs().max()) + 1e-12), k
+        assert pc[k].grad is None and torch.allclose(sink[k], pb[k].grad, rtol=2e-4, atol=2e-6 * float(pb[k].grad.abs().max()) + 1e-12), k
