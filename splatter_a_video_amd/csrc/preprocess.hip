@@ -485,28 +485,40 @@ frame_preprocess_fwd_batch_kernel(int F, int P, int I, int layout, const DynTab 
     const int per = (F + gridDim.y - 1) / gridDim.y;
     const int f0 = blockIdx.y * per, f1 = imin_(F, f0 + per);
     if (blockIdx.y == 0 && j == 3) opa_t[n] = 1.0f / (1.0f + expf(-opacity[n]));  // frame independent
-    for (int f = f0; f < f1; ++f) {
-        const int seg = tab[f].seg;
-        const float dd = tab[f].d;
-        const CubicAddr ca = cubic_addr(layout, P, I, seg);
-        const DynFrame fr = dyn_frame_rows(n, j, ca, dd, tab[f].basis, stc, cubic);
+    // four frames per trip: the quad evaluates frame f + k's position / rotation together (lane j = component j), lane k
+    // keeps it and runs the projection / cov3d / EWA chain for that frame alone (the chain on all four lanes per frame was
+    // 4x redundant), then writes its frame's seven outputs
+    const float scl3[3] = {quad_bcast<0>(stc.scl_j), quad_bcast<1>(stc.scl_j), quad_bcast<2>(stc.scl_j)};
+    for (int f = f0; f < f1; f += 4) {
+        float m_pos[3] = {0.f, 0.f, 0.f}, m_q[4] = {1.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ff = imin_(f + k, f1 - 1);  // (a repeated last frame: its lane does not store)
+            const CubicAddr ca = cubic_addr(layout, P, I, tab[ff].seg);
+            const DynFrame fr = dyn_frame_rows(n, j, ca, tab[ff].d, tab[ff].basis, stc, cubic);
+            if (j == k) {
+                m_pos[0] = fr.pos[0]; m_pos[1] = fr.pos[1]; m_pos[2] = fr.pos[2];
+                m_q[0] = fr.q[0]; m_q[1] = fr.q[1]; m_q[2] = fr.q[2]; m_q[3] = fr.q[3];
+            }
+        }
+        if (f + j >= f1) continue;
         float u, v, dep;
-        const bool cull = project_ortho_pt(c, fr.pos[0], fr.pos[1], fr.pos[2], W, H, nearest, extent, u, v, dep);
+        const bool cull = project_ortho_pt(c, m_pos[0], m_pos[1], m_pos[2], W, H, nearest, extent, u, v, dep);
         u = cull ? 0.f : u; v = cull ? 0.f : v; dep = cull ? 0.f : dep;
         float o[3] = {0.f, 0.f, 0.f};
         int orad = 0, otiles = 0;
         if (dep != 0.f) {
             float c3[6], a[3], bb[3], tt[3], Jm[4], cov[3];
-            cov3d_pt(fr.scl, fr.q, c3);
-            ewa_T<true>(c, fr.pos, W, H, a, bb, tt, Jm);
+            cov3d_pt(scl3, m_q, c3);
+            ewa_T<true>(c, m_pos, W, H, a, bb, tt, Jm);
             ewa_cov2d<true>(a, bb, c3, cov);
             ewa_finish_pt<true>(cov, make_float2(u, v), W, H, o[0], o[1], o[2], orad, otiles);
         }
-        const size_t fn = (size_t)f * P + n;
-        if (j < 2) uv[fn * 2 + j] = j == 0 ? u : v;
-        if (j < 3) conic[fn * 3 + j] = j == 0 ? o[0] : j == 1 ? o[1] : o[2];
-        if (j == 2) depth[fn] = dep;
-        if (j == 3) radius[fn] = orad;
+        const size_t fn = (size_t)(f + j) * P + n;
+        *reinterpret_cast<float2 *>(uv + fn * 2) = make_float2(u, v);
+        conic[fn * 3] = o[0]; conic[fn * 3 + 1] = o[1]; conic[fn * 3 + 2] = o[2];
+        depth[fn] = dep;
+        radius[fn] = orad;
     }
 }
 
