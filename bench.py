@@ -185,7 +185,7 @@ class FrameRenderer:
             self.dL_attr = torch.randn(19, self.H, self.W, generator=g).to(device)
         if self.mode == "render_iter":
             self.batch = FrameBatch(self.F, N, self.W, self.H, 3 + 1 + 19, device, want_abs=True)
-            self.off_all = torch.stack(self.offs).contiguous()
+            self.off_all = None if dynamic else torch.stack(self.offs).contiguous()
             rep = lambda t: t.unsqueeze(0).repeat(self.F, 1, 1, 1).contiguous()
             self.dL_sets = [rep(self.dL_dout), rep(self.dL_depth), rep(self.dL_attr)]
         if self.mode == "batch":
@@ -236,6 +236,16 @@ class FrameRenderer:
         rgb = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"])      # once per step (constant view direction)
         sets = [dict(feature=rgb, bg=self.sc.bg, taps=True), dict(feature="depth", bg=1.0),
                 dict(feature=p["attrs"], bg=0.0, detach_opacity=True)]
+        if self.dynamic:   # the reference's real training frame: its dynamic Gaussians through the three blends
+            from splatter_a_video_amd.dynamics import SEGMENT_MAJOR
+            out = self.batch.render_dynamic_sets(
+                self.clock, self.frames, self.extr, sets, position=self.position, pos_cubic_node=p["pos_cubic_node"],
+                rotation=p["rotation"], rot_poly_feat=self.rot_poly, rot_fourier_feat=self.rot_fourier, opacity=p["opacity"],
+                scaling=p["scaling"], cubic_layout=SEGMENT_MAJOR, K=20,
+                grad_sink={k: g[k] for k in ("pos_cubic_node", "rotation", "opacity", "scaling")})
+            torch.autograd.backward(list(out[:3]), self.dL_sets)
+            self.last = dict(M=self.last.get("M", 0), T=self.batch.T)
+            return
         out = self.batch.render_sets(p["xyz"], p["scale"], p["rotate"], p["opacity"], sets, self.off_all, self.extr, K=20,
                                      grad_sink={"xyz": g["xyz"], "scales": g["scale"], "uquats": g["rotate"], "opacity": g["opacity"]})
         torch.autograd.backward(list(out[:3]), self.dL_sets)
@@ -591,7 +601,11 @@ def main():
                        "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
                        "tile_pairs_M": M, "channels": R.C, "parallelism": par,
                        "gaussian_order": "random" if a.no_spatial_order else "morton (densify.spatial_order at setup)",
-                       "path": ("frame batch of the reference's dynamic Gaussians: their per-frame evaluation inside the batched "
+                       "path": ("the reference's real training frame as a frame batch: its dynamic Gaussians (per-frame evaluation "
+                                "inside the batched preprocess) through render_iter's three blends (rgb enhanced K=20 + depth + 19 "
+                                "attribute channels), one forward over the 23-channel row, one backward pass for the three sets"
+                                if (R.dynamic and mode == "render_iter") else
+                                "frame batch of the reference's dynamic Gaussians: their per-frame evaluation inside the batched "
                                 "preprocess, the Gaussian-side backward walks all frames" if (R.dynamic and mode == "batch") else
                                 "dynamic-Gaussian evaluation fused into the per-frame preprocess + gradient sinks" if R.dynamic else
                                 "render_iter of the reference's renderer (rgb enhanced K=20 + depth + 19 attribute channels per "

@@ -469,6 +469,19 @@ int splat_frames_gauss_backward_dynamic(int F, int P, int I, int C, int W, int H
                                         float *d_cubic, float *d_rotation, float *d_opacity, float *d_scaling,
                                         float *d_feature, float *tap, float *abs_tap, int32_t *radii_max,
                                         splat_stream_t stream);
+/* The same for the SETS records of splat_alpha_blending_backward_batch_sets (the reference's real training frame: its dynamic
+ * Gaussians through render_iter's three blends): taps from the tap set, feature gradients ADDED per set (set_dfeature: HOST
+ * array of three device pointers, NULL entries skipped), row channel depth_channel (>= 0) = the per-frame depth, whose
+ * gradient reaches the position through the projection. */
+int splat_frames_gauss_backward_dynamic_sets(int F, int P, int I, int C, int W, int H, int64_t capacity,
+                                             const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
+                                             const void *tab, const float *position, const float *cubic, int cubic_layout,
+                                             const float *rotation, const float *rot_poly, const float *rot_fourier,
+                                             const float *opacity, const float *scaling, const float *extr,
+                                             float *d_position, float *d_cubic, float *d_rotation, float *d_opacity,
+                                             float *d_scaling, const int32_t *set_c0, const int32_t *set_cn,
+                                             float *const *set_dfeature, const int32_t *set_stride, int depth_channel,
+                                             float *tap, float *abs_tap, int32_t *radii_max, splat_stream_t stream);
 
 /* ---- optimiser step of the frame-sharded data-parallel renderer: replaces the per-group
  *      torch.optim.Adam.step() the reference reaches through src/pointrix/optimizer/optimizer.py:70-83 (Adam built in

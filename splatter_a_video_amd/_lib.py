@@ -44,7 +44,7 @@ SYMBOLS = [
     "splat_frames_count", "splat_frames_forward", "splat_frames_backward",
     "splat_frames_gauss_backward_static", "splat_alpha_blending_backward_batch_set", "splat_frames_gauss_backward_static_set",
     "splat_blend_sets_pair_stride", "splat_blend_sets_pack_floats", "splat_alpha_blending_backward_batch_sets",
-    "splat_frames_gauss_backward_static_sets",
+    "splat_frames_gauss_backward_static_sets", "splat_frames_gauss_backward_dynamic_sets",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]
 

@@ -544,12 +544,16 @@ struct GaussDynArgs {
     float *d_position, *d_cubic, *d_rotation, *d_opacity, *d_scaling, *d_feature;  // d_cubic / d_* are ADDED to
     float *tap, *abs_tap;
     int *radii_max;
+    // SETS records (blend_bwd_sets_kernel): see GaussBwdArgs
+    int sc0[3], scn[3], sstride[3];
+    float *sdf[3];
+    int depth_channel;
 };
 
-template <bool ABS, int NCP>
+template <bool ABS, int NCP, bool SETS = false>
 __global__ void __launch_bounds__(256, GAUSS_DYN_MINW)
 frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
-    constexpr int NG = GradLayout<ABS, false>::NG;
+    constexpr int NG = SETS ? 10 : GradLayout<ABS, false>::NG;
     constexpr int NQ = NCP / 4, NS = (NQ + 3) / 4;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int n = t >> 2, j = t & 3;
@@ -586,7 +590,7 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
         }
         const CubicAddr ca = cubic_addr(A.layout, A.P, A.I, seg);
         float m_ux = 0.f, m_uy = 0.f, m_g3[3] = {0.f, 0.f, 0.f}, m_pos[3] = {0.f, 0.f, 0.f}, m_q[4] = {1.f, 0.f, 0.f, 0.f};
-        float m_nrm = 1.f, m_d = 0.f;
+        float m_nrm = 1.f, m_d = 0.f, m_gdep = 0.f;
         bool m_valid = false;
         int took = 0;
 #pragma unroll
@@ -617,9 +621,24 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
             }
             const float ux = quad_bcast<0>(af[0].x), uy = quad_bcast<0>(af[0].y);
             const float ga = quad_bcast<0>(af[0].z), gb = quad_bcast<0>(af[0].w), gc = quad_bcast<1>(af[0].x);
-            tap_u += ux; tap_v += uy;
+            // densification taps: d uv of the whole blend -- SETS records: of the tap set alone (components 8, 9 = chunk 2)
+            tap_u += SETS ? quad_bcast<2>(af[0].x) : ux;
+            tap_v += SETS ? quad_bcast<2>(af[0].y) : uy;
             if (ABS) {
                 atap_u += quad_bcast<1>(af[0].z); atap_v += quad_bcast<1>(af[0].w);
+            }
+            float gdep = 0.f;  // SETS: the frame's gradient of the depth channel = dL/ddepth of the projection
+            if (SETS && A.depth_channel >= 0) {
+                const int kd = NG + A.depth_channel;  // chunk kd / 4 -> lane (kd / 4) & 3, register af[kd / 16], element kd & 3
+                float v = 0.f;
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    const float e4[4] = {af[c].x, af[c].y, af[c].z, af[c].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (kd == 16 * c + 4 * j + e) v = e4[e];
+                }
+                gdep = quad_sum(v);
             }
             const float dseg = A.tab[ff].d;
             const DynFrame fr = dyn_frame_rows(n, j, ca, dseg, A.tab[ff].basis, stc, A.cubic);
@@ -627,7 +646,7 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
                 m_ux = ux; m_uy = uy; m_g3[0] = ga; m_g3[1] = gb; m_g3[2] = gc;
                 m_pos[0] = fr.pos[0]; m_pos[1] = fr.pos[1]; m_pos[2] = fr.pos[2];
                 m_q[0] = fr.q[0]; m_q[1] = fr.q[1]; m_q[2] = fr.q[2]; m_q[3] = fr.q[3];
-                m_nrm = fr.nrm; m_d = dseg; m_valid = true;
+                m_nrm = fr.nrm; m_d = dseg; m_gdep = gdep; m_valid = true;
             }
         }
         f += took;
@@ -635,7 +654,7 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
         float gp[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f};
         if (m_valid) {
             float dq[4] = {0.f, 0.f, 0.f, 0.f};
-            project_ortho_grad_pt(cam, A.W, A.H, m_ux, m_uy, 0.f, gp);
+            project_ortho_grad_pt(cam, A.W, A.H, m_ux, m_uy, m_gdep, gp);
             float c3[6], ea[3], eb[3], et[3], Jm[4], cov[3];
             cov3d_pt(scl3, m_q, c3);
             ewa_T<true>(cam, m_pos, A.W, A.H, ea, eb, et, Jm);
@@ -703,7 +722,14 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ch = k0 + e - NG;
-                if (ch >= 0 && ch < A.cn && A.d_feature) A.d_feature[(size_t)n * A.C + ch] += v[e];
+                if (SETS) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        if (ch >= A.sc0[g] && ch < A.sc0[g] + A.scn[g] && ch != A.depth_channel && A.sdf[g])
+                            A.sdf[g][(size_t)n * A.sstride[g] + (ch - A.sc0[g])] += v[e];
+                } else if (ch >= 0 && ch < A.cn && A.d_feature) {
+                    A.d_feature[(size_t)n * A.C + ch] += v[e];
+                }
             }
         }
     }
@@ -731,6 +757,18 @@ int launch_gauss_bwd_static(const GaussBwdArgs &A, int ncp, hipStream_t s) {
         default: splat_set_error("gauss_bwd: unsupported record stride %d", ncp); return SPLAT_E_ARG;
     }
 #undef GB
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+int launch_gauss_bwd_dynamic_sets(const GaussDynArgs &A, int ncp, hipStream_t s) {
+    const dim3 grid((unsigned)(((size_t)A.P * 4 + 255) / 256)), block(256);
+#define GDS(N) case N: SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_dynamic_kernel<true, N, true>), grid, block, 0, s, A); break
+    switch (ncp) {
+        GDS(12); GDS(16); GDS(20); GDS(24); GDS(28); GDS(32); GDS(36); GDS(40);
+        default: splat_set_error("gauss_bwd: unsupported record stride %d", ncp); return SPLAT_E_ARG;
+    }
+#undef GDS
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }
@@ -1008,4 +1046,42 @@ extern "C" int splat_frames_gauss_backward_dynamic(int F, int P, int I, int C, i
     const int ncp = (int)splat_blend_pair_stride(C, want_abs, 0);
     return want_abs ? launch_gauss_bwd_dynamic<true>(A, ncp, (hipStream_t)stream)
                     : launch_gauss_bwd_dynamic<false>(A, ncp, (hipStream_t)stream);
+}
+
+// Gaussian side of splat_alpha_blending_backward_batch_sets for DYNAMIC Gaussians (the reference's real training frame:
+// dynamic_gaussian_with_base_point_cloud.py getters + render_iter's three blends): splat_frames_gauss_backward_dynamic with
+// the SETS records -- taps from the tap set, per-set feature gradients (ADDED to set_dfeature[g], HOST array of three device
+// pointers), the row channel `depth_channel` (>= 0) is the per-frame depth and feeds the position through the projection.
+extern "C" int splat_frames_gauss_backward_dynamic_sets(int F, int P, int I, int C, int W, int H, int64_t capacity,
+                                                        const float *pair_records, const int32_t *goff_incl,
+                                                        const int32_t *radius, const void *tab, const float *position,
+                                                        const float *cubic, int cubic_layout, const float *rotation,
+                                                        const float *rot_poly, const float *rot_fourier, const float *opacity,
+                                                        const float *scaling, const float *extr, float *d_position,
+                                                        float *d_cubic, float *d_rotation, float *d_opacity, float *d_scaling,
+                                                        const int32_t *set_c0, const int32_t *set_cn,
+                                                        float *const *set_dfeature, const int32_t *set_stride,
+                                                        int depth_channel, float *tap, float *abs_tap, int32_t *radii_max,
+                                                        void *stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && I >= 1 && C >= 1 && C <= 28 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 28)");
+    SPLAT_CHECK_ARG(cubic_layout == SPLAT_CUBIC_GAUSSIAN_MAJOR || cubic_layout == SPLAT_CUBIC_SEGMENT_MAJOR, "unknown cubic_layout");
+    SPLAT_CHECK_ARG(pair_records && goff_incl && tab && position && cubic && rotation && rot_poly && rot_fourier && opacity &&
+                        scaling && extr,
+                    "null input pointer");
+    SPLAT_CHECK_ARG(set_c0 && set_cn && set_dfeature && set_stride, "null set table");
+    SPLAT_CHECK_ARG(depth_channel < C, "depth_channel outside the row");
+    SPLAT_CHECK_ARG(!radii_max || radius, "radii_max needs the per-frame radius");
+    GaussDynArgs A;
+    memset(&A, 0, sizeof(A));
+    A.F = F; A.P = P; A.W = W; A.H = H; A.I = I; A.layout = cubic_layout; A.C = C; A.cn = C; A.cap = capacity;
+    A.pair = pair_records; A.goff = goff_incl; A.radius = radius; A.tab = (const DynTab *)tab;
+    A.position = position; A.cubic = cubic; A.rotation = rotation; A.rot_poly = (const float4 *)rot_poly;
+    A.rot_fourier = (const float4 *)rot_fourier; A.opacity = opacity; A.scaling = scaling; A.extr = extr;
+    A.d_position = d_position; A.d_cubic = d_cubic; A.d_rotation = d_rotation; A.d_opacity = d_opacity; A.d_scaling = d_scaling;
+    A.tap = tap; A.abs_tap = abs_tap; A.radii_max = radii_max; A.depth_channel = depth_channel;
+    for (int g = 0; g < 3; ++g) {
+        A.sc0[g] = set_c0[g]; A.scn[g] = set_cn[g]; A.sstride[g] = set_stride[g]; A.sdf[g] = set_dfeature[g];
+        SPLAT_CHECK_ARG(set_cn[g] == 0 || !set_dfeature[g] || set_stride[g] >= set_cn[g], "feature stride below the set width");
+    }
+    return launch_gauss_bwd_dynamic_sets(A, (int)splat_blend_sets_pair_stride(C), (hipStream_t)stream);
 }

@@ -235,6 +235,29 @@ class FrameBatch:
                                     extr, tab, self, int(clock.interval_num), int(cubic_layout), float(bg), float(nearest),
                                     float(extent), sink)
 
+    def render_dynamic_sets(self, clock, times, extr: Tensor, sets, *, position: Tensor, pos_cubic_node: Tensor,
+                            rotation: Tensor, rot_poly_feat: Tensor, rot_fourier_feat: Tensor, opacity: Tensor, scaling: Tensor,
+                            cubic_layout: int = 1, K: int = 0, nearest: float = 0.01, extent: float = 1.3,
+                            grad_sink: Optional[Dict[str, Tensor]] = None):
+        """The reference's real training frame, for all frames of the batch: its dynamic Gaussians (``render_dynamic``)
+        through the three blends of ``render_iter`` (``render_sets``: same ``sets`` list, same return value).  The sets must
+        fit the one-pass backward (one set per routing group, <= 4 / 4 / 20 channels)."""
+        tab = self.frame_table(clock, times)
+        feats = [s_["feature"] for s_ in sets if not isinstance(s_["feature"], str)]
+        meta = tuple((("depth" if isinstance(s_["feature"], str) else int(s_["feature"].shape[1])), float(s_.get("bg", 0.0)),
+                      bool(s_.get("detach_opacity", False)), bool(s_.get("taps", False))) for s_ in sets)
+        widths = [1 if m[0] == "depth" else m[0] for m in meta]
+        if sum(widths) != self.C:
+            raise ValueError(f"the sets hold {sum(widths)} channels, the batch was built for C = {self.C}")
+        if _one_pass_plan(meta, widths, self.C) is None:
+            raise ValueError("render_dynamic_sets needs sets that fit the one-pass backward: one set per routing group "
+                             "(taps / live opacity / detached opacity) of at most 4 / 4 / 20 channels")
+        sink = check_sink(grad_sink, {"position": position, "pos_cubic_node": pos_cubic_node, "rotation": rotation,
+                                      "opacity": opacity, "scaling": scaling})
+        return _RenderDynamicSets.apply(position, pos_cubic_node, rotation, opacity, scaling, rot_poly_feat, rot_fourier_feat, extr,
+                                        tab, self, int(clock.interval_num), int(cubic_layout), meta, int(K), float(nearest),
+                                        float(extent), sink, *feats)
+
     # ------------------------------------------------------------------ several feature sets of one geometry (row a1)
     def render_sets(self, xyz: Tensor, scales: Tensor, uquats: Tensor, opacity: Tensor, sets, offsets: Optional[Tensor],
                     extr: Tensor, K: int = 0, nearest: float = 0.01, extent: float = 1.3,
@@ -320,6 +343,113 @@ class _RenderDynamic(torch.autograd.Function):
             L.ptr(bufs["scaling"]), L.ptr(bufs["feature"]), L.ptr(fb.tap), L.ptr(fb.abs_tap), L.ptr(fb.radii_max), st))
         ret = tuple(None if (k in sink or bufs[k] is None) else bufs[k] for k in like)
         return ret + (None,) * 11
+
+
+class _RenderDynamicSets(torch.autograd.Function):
+    N_FIXED = 17      # arguments in front of the feature tensors
+
+    @staticmethod
+    def forward(ctx, position, cubic, rotation, opacity, scaling, rot_poly, rot_fourier, extr, tab, fb, I, layout, meta, K,
+                nearest, extent, sink, *feats):
+        P, F = fb.P, fb.F
+        position = _points(position, "position", 3)
+        rotation = _points(rotation, "rotation", 4)
+        scaling = _points(scaling, "scaling", 3)
+        opacity = L.need(opacity, "opacity")
+        cubic = L.need(cubic, "pos_cubic_node")
+        rot_poly, rot_fourier = L.need(rot_poly, "rot_poly_feat"), L.need(rot_fourier, "rot_fourier_feat")
+        if cubic.numel() != P * 4 * I * 3 or rot_poly.numel() != P * 16 or rot_fourier.numel() != P * 32 or opacity.numel() != P:
+            raise ValueError("parameter shapes do not match the batch (P Gaussians, I spline segments)")
+        extr_c = _extr12(extr)
+        lib, st = L.lib(), L.stream()
+        W, H, C = fb.W, fb.H, fb.C
+        opa_t = torch.empty(P, 1, dtype=torch.float32, device=fb.dev)
+        L.check(lib.splat_frame_preprocess_forward_batch(
+            L.ci(F), L.ci(P), L.ci(I), L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(layout), L.ptr(rotation), L.ptr(rot_poly),
+            L.ptr(rot_fourier), L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c), L.ci(W), L.ci(H), L.cf(nearest), L.cf(extent),
+            L.ptr(fb.uv), L.ptr(fb.depth), L.ptr(fb.conic), L.ptr(fb.radius), L.ptr(opa_t), st))
+        fb._bin_and_sort()
+        cols, bgs, it = [], [], iter(feats)
+        for w, bg, _, _ in meta:
+            if w == "depth":
+                cols.append(fb.depth)
+                bgs.append(torch.full((1,), bg, dtype=torch.float32, device=fb.dev))
+            else:
+                f = _points(next(it), "feature", w)
+                cols.append(f.unsqueeze(0).expand(F, P, w))
+                bgs.append(torch.full((w,), bg, dtype=torch.float32, device=fb.dev))
+        row = torch.cat(cols, dim=2).contiguous()
+        bgc = torch.cat(bgs)
+        cap = fb.capacity
+        out = torch.empty(F, C, H, W, dtype=torch.float32, device=fb.dev)
+        gs_idx = torch.empty(F, H, W, K, dtype=torch.int32, device=fb.dev) if K > 0 else None
+        L.check(lib.splat_alpha_blending_forward_batch(
+            L.ci(F), L.ci(P), L.ci(C), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opa_t), ctypes.c_int64(0), L.ptr(row),
+            ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.cf(0.0), L.ptr(bgc),
+            L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx),
+            L.ptr(fb.pack), L.ptr(fb.cull_flags), st))
+        ctx.fb, ctx.meta, ctx.sink, ctx.geo = fb, meta, sink, (I, layout)
+        ctx.row, ctx.opa_t = row, opa_t
+        ctx.save_for_backward(position, cubic, rotation, opacity, scaling, rot_poly, rot_fourier, extr_c, tab, *feats)
+        ctx.set_materialize_grads(False)
+        imgs, c0 = [], 0
+        for w, _, _, _ in meta:
+            w = 1 if w == "depth" else w
+            imgs.append(out[:, c0:c0 + w])
+            c0 += w
+        if gs_idx is not None:
+            ctx.mark_non_differentiable(gs_idx)
+        return tuple(imgs) + (gs_idx,)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        fb: FrameBatch = ctx.fb
+        position, cubic, rotation, opacity, scaling, rot_poly, rot_fourier, extr_c, tab = ctx.saved_tensors[:9]
+        feats = ctx.saved_tensors[9:]
+        meta, sink = ctx.meta, (ctx.sink or {})
+        I, layout = ctx.geo
+        lib, st = L.lib(), L.stream()
+        F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
+        dev = fb.dev
+        widths = [1 if m[0] == "depth" else m[0] for m in meta]
+        dL = torch.cat([(g if g is not None else torch.zeros(F, w, H, W, dtype=torch.float32, device=dev))
+                        for g, w in zip(grads[:len(meta)], widths)], dim=1).contiguous()
+        like = {"position": position, "pos_cubic_node": cubic, "rotation": rotation, "opacity": opacity, "scaling": scaling}
+        bufs = {k: (sink[k] if k in sink else torch.zeros_like(v)) for k, v in like.items()}
+        c0s, cns, bgs, depth_ch, tap_set = _one_pass_plan(meta, widths, C)
+        want_abs = 1 if (tap_set is not None and fb.want_abs) else 0
+        group_of = _set_groups(meta)
+        fi, dfe, dfs, strides = 0, [], [None, None, None], [0, 0, 0]
+        NF = _RenderDynamicSets.N_FIXED
+        for si, (w, _, _, _) in enumerate(meta):
+            if w == "depth":
+                continue
+            need = grads[si] is not None and ctx.needs_input_grad[NF + fi]
+            dfeat = torch.zeros_like(feats[fi]) if need else None
+            dfe.append(dfeat)
+            dfs[group_of[si]], strides[group_of[si]] = dfeat, int(feats[fi].shape[1])
+            fi += 1
+        from .gs.raster_ops import _debug_T_front
+        ncp = int(lib.splat_blend_sets_pair_stride(C))
+        rec = fb._set_buffer(("rec", "sets"), F * cap * ncp)
+        pack = fb._set_buffer(("pack", "sets"), F * P * int(lib.splat_blend_sets_pack_floats()))
+        i3, f3 = ctypes.c_int32 * 3, ctypes.c_float * 3
+        L.check(lib.splat_alpha_blending_backward_batch_sets(
+            L.ci(F), L.ci(P), L.ci(C), i3(*c0s), i3(*cns), f3(*bgs), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(ctx.opa_t),
+            ctypes.c_int64(0), L.ptr(ctx.row), ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range),
+            ctypes.c_int64(cap), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(dL), L.ci(want_abs),
+            L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(fb.cull_flags), L.ptr(_debug_T_front(F * H, W, dev)), st))
+        p3 = (ctypes.c_void_p * 3)(*[0 if d is None else d.data_ptr() for d in dfs])
+        has_tap = tap_set is not None
+        L.check(lib.splat_frames_gauss_backward_dynamic_sets(
+            L.ci(F), L.ci(P), L.ci(I), L.ci(C), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ptr(rec), L.ptr(fb.goff), L.ptr(fb.radius),
+            L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(layout), L.ptr(rotation), L.ptr(rot_poly), L.ptr(rot_fourier),
+            L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c), L.ptr(bufs["position"]), L.ptr(bufs["pos_cubic_node"]),
+            L.ptr(bufs["rotation"]), L.ptr(bufs["opacity"]), L.ptr(bufs["scaling"]), i3(*c0s), i3(*cns), p3, i3(*strides),
+            L.ci(depth_ch), L.ptr(fb.tap if has_tap else None), L.ptr(fb.abs_tap if (has_tap and want_abs) else None),
+            L.ptr(fb.radii_max if has_tap else None), st))
+        ret = tuple(None if k in sink else bufs[k] for k in like)
+        return ret + (None,) * (NF - 5) + tuple(dfe)
 
 
 def _set_groups(meta):

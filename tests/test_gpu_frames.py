@@ -331,3 +331,72 @@ def test_dynamic_batch_equals_per_frame_dynamic_path(layout):
                      scaling=pc["scaling"], cubic_layout=lay, bg=0.1, grad_sink=sink).backward(g)
     for k in pc:
         assert pc[k].grad is None and torch.allclose(sink[k], pb[k].grad, rtol=2e-4, atol=2e-6 * float(pb[k].grad.abs().max()) + 1e-12), k
+
+
+def test_dynamic_sets_batch_equals_per_frame_three_blends():
+    """the reference's real training frame in a frame batch -- its dynamic Gaussians (rows a15 + f1) through render_iter's
+    three blends (row a1: rgb enhanced with the taps, depth with bg = 1, attributes with opacity.detach()) -- against the
+    per-frame operators (dynamics.frame_preprocess -> sort -> alpha_blending_enhanced / alpha_blending x 2) through autograd."""
+    from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, FrameClock, frame_preprocess, to_segment_major
+    N, W, H, T, K = 5000, 128, 96, 30, 8
+    times = [0, 3, 4, 5, 17, 29]
+    F = len(times)
+    sc = make_scene(N, W, H, F=T, seed=41)
+    rng = np.random.default_rng(12)
+    clock = FrameClock(T)
+    I = clock.interval_num
+    cub = to_segment_major(torch.as_tensor((0.01 * rng.normal(size=(N, 4 * I * 3))).astype(np.float32)), I).numpy()
+    op = np.clip(sc.opacity, 1e-4, 1 - 1e-4)
+    base = dict(position=sc.xyz, pos_cubic_node=cub, rotation=sc.rotate + 0.1 * rng.normal(size=(N, 4)).astype(np.float32),
+                opacity=np.log(op / (1 - op)).astype(np.float32), scaling=np.log(sc.scale).astype(np.float32),
+                rgb=rng.uniform(size=(N, 3)).astype(np.float32), attrs=rng.uniform(-1, 1, size=(N, 19)).astype(np.float32))
+    rot_poly = _t((0.02 * rng.normal(size=(N, 4, 4))).astype(np.float32))
+    rot_four = _t((0.02 * rng.normal(size=(N, 8, 4))).astype(np.float32))
+    g_rgb, g_dep, g_att = (_t(rng.normal(size=(F, c, H, W)).astype(np.float32)) for c in (3, 1, 19))
+    extr = _t(sc.extr)
+
+    pa = {k: _t(v, True) for k, v in base.items()}
+    ref, ref_tap, ref_atap, ref_ids = [], 0, 0, []
+    for f, t in enumerate(times):
+        uv, depth, conic, radius, tiles, opa = frame_preprocess(
+            clock, t, extr, W, H, position=pa["position"], pos_cubic_node=pa["pos_cubic_node"], rotation=pa["rotation"],
+            rot_poly_feat=rot_poly, rot_fourier_feat=rot_four, opacity=pa["opacity"], scaling=pa["scaling"], nearest=0.01,
+            cubic_layout=SEGMENT_MAJOR)
+        idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        ndc = torch.zeros_like(uv, requires_grad=True)
+        andc = torch.zeros_like(uv, requires_grad=True)
+        rgb_i, _, ids = gs.alpha_blending_enhanced(uv, conic, opa, pa["rgb"], idx, tr, 0.2, W, H, ndc, andc, K=K)
+        dep_i = gs.alpha_blending(uv, conic, opa, depth, idx, tr, 1.0, W, H, ndc.detach())
+        att_i = gs.alpha_blending(uv, conic, opa.detach(), pa["attrs"], idx, tr, 0.0, W, H, ndc.detach())
+        torch.autograd.backward([rgb_i, dep_i, att_i], [g_rgb[f], g_dep[f], g_att[f]])
+        ref.append((rgb_i.detach(), dep_i.detach(), att_i.detach()))
+        ref_tap = ref_tap + ndc.grad; ref_atap = ref_atap + andc.grad; ref_ids.append(ids)
+
+    pb = {k: _t(v, True) for k, v in base.items()}
+    B = FrameBatch(F, N, W, H, 23, "cuda", want_abs=True)
+    sets = [dict(feature=pb["rgb"], bg=0.2, taps=True), dict(feature="depth", bg=1.0),
+            dict(feature=pb["attrs"], bg=0.0, detach_opacity=True)]
+    o_rgb, o_dep, o_att, ids = B.render_dynamic_sets(
+        clock, times, extr, sets, position=pb["position"], pos_cubic_node=pb["pos_cubic_node"], rotation=pb["rotation"],
+        rot_poly_feat=rot_poly, rot_fourier_feat=rot_four, opacity=pb["opacity"], scaling=pb["scaling"],
+        cubic_layout=SEGMENT_MAJOR, K=K)
+    for f in range(F):
+        # the batched preprocess contracts its FMAs differently from the per-frame one: last-bit geometry, and once in a
+        # while a splat that sits on the alpha = 1/255 threshold of a pixel is applied on one side only (<= 4e-3 there)
+        for name, got, want in zip(("rgb", "depth", "attrs"), (o_rgb[f], o_dep[f], o_att[f]), ref[f]):
+            off_ = ((got - want).abs() > 1e-5 + 1e-4 * want.abs())
+            assert int(off_.any(0).sum()) <= 3 and float((got - want).abs().max()) < 5e-3, (f, name)
+        assert int((ids[f] != ref_ids[f]).any(-1).sum()) <= 3
+    with capture_T_front() as cap:
+        torch.autograd.backward([o_rgb, o_dep, o_att], [g_rgb, g_dep, g_att])
+    torch.cuda.synchronize()
+    B.check()
+    assert float((cap.maps[0] - 1).abs().max()) < 2e-4
+    for k in pa:
+        a, b = pb[k].grad, pa[k].grad
+        bad = (a - b).abs() > 1e-3 * b.abs() + 1e-5 * float(b.abs().max())
+        # (the one or two splats of the flipped decisions: up to a row of 19 attribute gradients each)
+        assert int(bad.sum()) <= 40 and float(bad.float().mean()) < 1e-3, (k, int(bad.sum()), float((a - b).abs().max()))
+    for name, a, b in (("tap", B.tap, ref_tap), ("abs_tap", B.abs_tap, ref_atap)):
+        bad = (a - b).abs() > 1e-3 * b.abs() + 1e-5 * float(b.abs().max())
+        assert int(bad.sum()) <= 4, (name, int(bad.sum()), float((a - b).abs().max()))

@@ -17,6 +17,7 @@ run bench_c5_32ch --channels 32 --no-cpu-baseline
 run bench_dynamic_a15 --dynamic --no-cpu-baseline
 run bench_render_iter --render-iter --no-cpu-baseline
 run bench_render_iter_per_frame --render-iter --per-frame --no-cpu-baseline
+run bench_render_iter_dynamic --render-iter --dynamic --no-cpu-baseline   # the reference's real training frame
 # kernel trace of the default bench command (2 timed steps of 25 frames)
 export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
