@@ -187,3 +187,38 @@ def test_frames_struct_mirror_matches_the_header(built_lib):
     b.struct_bytes = ctypes.sizeof(_SplatFrames) - 8
     assert lib.splat_frames_forward(ctypes.byref(b)) != 0
     assert b"ABI version" in lib.splat_last_error()
+
+
+def test_one_pass_plan_routes_feature_sets_to_the_three_groups():
+    """frames._one_pass_plan: which set lists the three-set backward kernel can serve (one set per routing group -- taps /
+    live opacity / detached opacity -- of at most 4 / 4 / 20 channels, C <= 28), and the (c0, cn, bg) tables it gets."""
+    from splatter_a_video_amd.frames import _one_pass_plan, _set_groups
+    real = (((3, 0.2, False, True), ("depth", 1.0, False, False), (19, 0.0, True, False)), [3, 1, 19])     # render_iter
+    assert _set_groups(real[0]) == [0, 1, 2]
+    c0, cn, bg, depth_ch, tap = _one_pass_plan(real[0], real[1], 23)
+    assert (c0, cn, bg, depth_ch, tap) == ([0, 3, 4], [3, 1, 19], [0.2, 1.0, 0.0], 3, 0)
+    # any order of the sets; a missing group has width 0
+    c0, cn, bg, depth_ch, tap = _one_pass_plan(((8, 0.3, True, False), (3, 0.1, False, True)), [8, 3], 11)
+    assert (c0, cn, depth_ch, tap) == ([8, 0, 0], [3, 0, 8], -1, 1)
+    assert _one_pass_plan(((3, 0.0, False, True),), [3], 3)[1] == [3, 0, 0]
+    # not servable: two sets of one group, a group too wide, taps from a detached set, a row wider than 28
+    assert _one_pass_plan(((3, 0.0, False, False), (2, 0.0, False, False)), [3, 2], 5) is None
+    assert _one_pass_plan(((5, 0.0, False, True),), [5], 5) is None
+    assert _one_pass_plan(((21, 0.0, True, False),), [21], 21) is None
+    assert _one_pass_plan(((3, 0.0, True, True),), [3], 3) is None
+    assert _one_pass_plan(((4, 0.0, False, True), (4, 0.0, False, False), (20, 0.0, True, False)), [4, 4, 20], 28) is not None
+
+
+def test_sets_entry_points_validate_arguments(built_lib):
+    L = built_lib.lib()
+    i3, f3 = ctypes.c_int32 * 3, ctypes.c_float * 3
+    assert L.splat_blend_sets_pair_stride(23) == 36 and L.splat_blend_sets_pair_stride(28) == 40
+    # sets that do not tile the row / too wide / null tables: refused before any launch
+    one = ctypes.c_void_p(8)
+    args = lambda c0, cn, C: (1, 10, C, i3(*c0), i3(*cn), f3(0, 0, 0), one, one, one, ctypes.c_int64(0), one, ctypes.c_int64(0), one,
+                              one, ctypes.c_int64(100), 32, 32, one, one, one, 0, one, one, one, None, None, None)
+    assert L.splat_alpha_blending_backward_batch_sets(*args([0, 3, 4], [3, 1, 18], 23)) == -1     # channel 22 uncovered
+    assert b"cover" in L.splat_last_error()
+    assert L.splat_alpha_blending_backward_batch_sets(*args([0, 3, 3], [3, 1, 19], 23)) == -1     # overlap
+    assert L.splat_alpha_blending_backward_batch_sets(*args([0, 5, 6], [5, 1, 17], 23)) == -1     # tap set wider than 4
+    assert L.splat_alpha_blending_backward_batch_sets(*args([0, 3, 4], [3, 1, 25], 29)) == -1     # C > 28
