@@ -429,15 +429,29 @@ int splat_frames_gauss_backward_static_set(int F, int P, int cn, int W, int H, i
  * set_cn / set_bg / set_stride / set_dfeature are HOST arrays of three entries.  Pair records: stride
  * splat_blend_sets_pair_stride(C) floats, layout [ux uy ca cb | cc o ax ay | tx ty | dL_dfeature[0..C-1]];
  * pack_scratch: F * P * splat_blend_sets_pack_floats() floats.  Other widths / routings: the per-set calls above. */
+/* forward of a row whose feature sets live in their own tensors (no concatenated [F,P,C] row; same tables as below, in any
+ * routing: set g = row channels [set_c0[g], + set_cn[g]) from set_feature[g]); otherwise splat_alpha_blending_forward_batch */
+int splat_alpha_blending_forward_batch_sets(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
+                                            const float *const *set_feature, const int64_t *set_feature_fs,
+                                            const float *uv, const float *conic, const float *opacity,
+                                            int64_t opacity_frame_stride, const int32_t *idx_sorted,
+                                            const int32_t *tile_range, int64_t capacity, const float *bg_channels, int W,
+                                            int H, int K, int enable_truncation, float *out, float *final_T,
+                                            int32_t *ncontrib, int32_t *gs_idx, float *pack_scratch, uint32_t *cull_flags,
+                                            splat_stream_t stream);
 size_t splat_blend_sets_pair_stride(int C);
 size_t splat_blend_sets_pack_floats(void);
 int splat_alpha_blending_backward_batch_sets(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
                                              const float *set_bg, const float *uv, const float *conic,
-                                             const float *opacity, int64_t opacity_frame_stride, const float *feature,
-                                             int64_t feature_frame_stride, const int32_t *idx_sorted,
-                                             const int32_t *tile_range, int64_t capacity, int W, int H,
-                                             const float *final_T, const int32_t *ncontrib, const float *dL_dout,
-                                             int want_abs, const int32_t *slot_sorted, float *pair_records,
+                                             const float *opacity, int64_t opacity_frame_stride,
+                                             const float *feature /* row [F,P,C], or NULL: */, int64_t feature_frame_stride,
+                                             const float *const *set_feature /* [P,cn] per set */,
+                                             const int64_t *set_feature_fs /* floats between frames, 0 = shared */,
+                                             const int32_t *idx_sorted, const int32_t *tile_range, int64_t capacity, int W,
+                                             int H, const float *final_T, const int32_t *ncontrib,
+                                             const float *dL_dout /* [F,C,H,W], or NULL: */,
+                                             const float *const *set_dL /* [F,cn,H,W] per set */, int want_abs,
+                                             const int32_t *slot_sorted, float *pair_records,
                                              float *pack_scratch, const uint32_t *cull_flags /*NULL or the forward's*/,
                                              float *dbg_T_front, splat_stream_t stream);
 int splat_frames_gauss_backward_static_sets(int F, int P, int C, int W, int H, int64_t capacity, const float *pair_records,

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -44,6 +44,7 @@ SYMBOLS = [
     "splat_frames_count", "splat_frames_forward", "splat_frames_backward",
     "splat_frames_gauss_backward_static", "splat_alpha_blending_backward_batch_set", "splat_frames_gauss_backward_static_set",
     "splat_blend_sets_pair_stride", "splat_blend_sets_pack_floats", "splat_alpha_blending_backward_batch_sets",
+    "splat_alpha_blending_forward_batch_sets",
     "splat_frames_gauss_backward_static_sets", "splat_frames_gauss_backward_dynamic_sets",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]

@@ -113,6 +113,10 @@ struct BlendArgs {
     // tap set (0), the second set (1) and the opacity-detached set (2); width 0 = no such set
     int s0c0, s0cn, s1c0, s1cn, s2c0, s2cn;
     float s0bg, s1bg, s2bg;
+    // ... each set's features [P, cn] (frame stride sfs: 0 = shared by the frames) and image gradient [F, cn, H, W] in its own
+    // tensor (the caller does not concatenate a row / a gradient image); NULL: `feature` / `dL_dout` hold the whole row
+    const float *sf0, *sf1, *sf2, *sdl0, *sdl1, *sdl2;
+    long long sfs0, sfs1, sfs2;
     // optional [F, cap] words, one per sorted tile entry: byte w != 0 = the forward's cull kept the entry for the tile's
     // block w (the keep word of tile_cull).  The forward writes them, the strip-walk backward kernels read them instead
     // of repeating the cull (13 % of their VALU instructions); NULL: every kernel culls for itself.
@@ -128,7 +132,7 @@ __device__ __forceinline__ BlendArgs frame_args(const BlendArgs &B, int f) {
             A.uv = B.uv + fz * B.P;
             A.conic = B.conic + fz * 3 * B.P;
             A.opacity = B.opacity + fz * B.opacity_fs;
-            A.feature = B.feature + fz * B.feature_fs;
+            A.feature = B.feature ? B.feature + fz * B.feature_fs : nullptr;
         }
         if (B.bias) A.bias = B.bias + fz * B.bias_fs;
         A.idx_sorted = B.idx_sorted + fz * B.cap;
@@ -143,6 +147,12 @@ __device__ __forceinline__ BlendArgs frame_args(const BlendArgs &B, int f) {
         if (B.goff_incl) A.goff_incl = B.goff_incl + fz * B.P;
         if (B.dbg_T_front) A.dbg_T_front = B.dbg_T_front + fz * HW;
         if (B.cull_flags) A.cull_flags = B.cull_flags + fz * B.cap;
+        if (B.sf0) A.sf0 = B.sf0 + fz * B.sfs0;
+        if (B.sf1) A.sf1 = B.sf1 + fz * B.sfs1;
+        if (B.sf2) A.sf2 = B.sf2 + fz * B.sfs2;
+        if (B.sdl0) A.sdl0 = B.sdl0 + fz * B.s0cn * HW;
+        if (B.sdl1) A.sdl1 = B.sdl1 + fz * B.s1cn * HW;
+        if (B.sdl2) A.sdl2 = B.sdl2 + fz * B.s2cn * HW;
     }
     return A;
 }
@@ -292,6 +302,14 @@ __device__ __forceinline__ bool cull_test(float u, float v, float a, float b, fl
     return qmin <= p.tauq + qerr;
 }
 
+// feature of row channel c of Gaussian i when the sets' features live in their own tensors (BlendArgs::sf0..2)
+__device__ __forceinline__ float sets_feature(const BlendArgs &A, int i, int c) {
+    if (c >= A.s0c0 && c < A.s0c0 + A.s0cn) return A.sf0[(size_t)i * A.s0cn + (c - A.s0c0)];
+    if (c >= A.s1c0 && c < A.s1c0 + A.s1cn) return A.sf1[(size_t)i * A.s1cn + (c - A.s1c0)];
+    if (c >= A.s2c0 && c < A.s2c0 + A.s2cn) return A.sf2[(size_t)i * A.s2cn + (c - A.s2c0)];
+    return 0.f;
+}
+
 template <int CH, bool BIAS, bool EXACT>
 __global__ void __launch_bounds__(256)
 pack_kernel(const BlendArgs B) {
@@ -311,10 +329,16 @@ pack_kernel(const BlendArgs B) {
         r[5] = A.opacity[i];
         if (BIAS) r[6] = A.bias[i];
         r[7] = __int_as_float(i);
-        const float *f = A.feature + (size_t)i * A.C + A.c0;
+        if (A.feature) {
+            const float *f = A.feature + (size_t)i * A.C + A.c0;
 #pragma unroll
-        for (int k = 0; k < CH; ++k)
-            if (EXACT || k < A.cn) r[8 + k] = f[k];
+            for (int k = 0; k < CH; ++k)
+                if (EXACT || k < A.cn) r[8 + k] = f[k];
+        } else {  // the row's sets in their own tensors
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (EXACT || k < A.cn) r[8 + k] = sets_feature(A, i, A.c0 + k);
+        }
         if (Rec<CH>::CULL >= 0) {
             constexpr int CO = Rec<CH>::CULL >= 0 ? Rec<CH>::CULL : 0;
             const CullP cp = cull_params(r[2], r[3], r[4], r[5]);
@@ -1596,7 +1620,7 @@ pack_sets_kernel(const BlendArgs B) {
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
         const int c = sets_slot_channel(A, k);
-        if (c >= 0) r[8 + k] = f[c];
+        if (c >= 0) r[8 + k] = A.feature ? f[c] : sets_feature(A, i, c);
     }
     const CullP cp = cull_params(r[2], r[3], r[4], r[5]);
     r[CO] = cp.hx; r[CO + 1] = cp.hy; r[CO + 2] = cp.tauq; r[CO + 3] = cp.ia; r[CO + 4] = cp.ic;
@@ -1660,9 +1684,18 @@ blend_bwd_sets_kernel(const BlendArgs B) {
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const int c = sets_slot_channel(A, k);
-            const float g = (inside && c >= 0) ? A.dL_dout[(size_t)c * HW + pix] : 0.f;
-            stage[lane * CH + k] = g;
             const int gi = k < 4 ? 0 : k < 8 ? 1 : 2;
+            float g = 0.f;
+            if (inside && c >= 0) {
+                if (A.dL_dout) {
+                    g = A.dL_dout[(size_t)c * HW + pix];
+                } else {  // the set's own gradient image [cn, H, W]
+                    const float *d = gi == 0 ? A.sdl0 : gi == 1 ? A.sdl1 : A.sdl2;
+                    const int o = k - (gi == 0 ? 0 : gi == 1 ? 4 : 8);
+                    g = d[(size_t)o * HW + pix];
+                }
+            }
+            stage[lane * CH + k] = g;
             bgd[gi] += (gi == 0 ? A.s0bg : gi == 1 ? A.s1bg : A.s2bg) * g;
         }
         float *r = s_state[w] + lane * PS;
@@ -2252,6 +2285,55 @@ extern "C" int splat_alpha_blending_forward_batch(int F, int P, int C, const flo
     return fwd_chunk(A, T, enh, false, (hipStream_t)stream);
 }
 
+// splat_alpha_blending_forward_batch over a row whose feature sets live in their own tensors (no concatenated [F,P,C] row):
+// set g = row channels [set_c0[g], + set_cn[g]) from set_feature[g] ([P, cn] rows; frame stride set_feature_fs[g] floats, 0 =
+// shared by the frames).  HOST arrays of three entries; set_cn[g] = 0: no such set; the sets must tile the row.
+extern "C" int splat_alpha_blending_forward_batch_sets(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
+                                                       const float *const *set_feature, const int64_t *set_feature_fs,
+                                                       const float *uv, const float *conic, const float *opacity,
+                                                       int64_t opacity_frame_stride, const int32_t *idx_sorted,
+                                                       const int32_t *tile_range, int64_t capacity,
+                                                       const float *bg_channels, int W, int H, int K, int enable_truncation,
+                                                       float *out, float *final_T, int32_t *ncontrib, int32_t *gs_idx,
+                                                       float *pack_scratch, uint32_t *cull_flags, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 32 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 32)");
+    SPLAT_CHECK_ARG(set_c0 && set_cn && set_feature && set_feature_fs && bg_channels, "null set table");
+    SPLAT_CHECK_ARG(uv && conic && opacity && idx_sorted && tile_range && out && final_T && ncontrib && pack_scratch, "null pointer");
+    {
+        unsigned long long covered = 0ull;
+        for (int g = 0; g < 3; ++g) {
+            SPLAT_CHECK_ARG(set_cn[g] >= 0 && (set_cn[g] == 0 || (set_c0[g] >= 0 && set_c0[g] + set_cn[g] <= C && set_feature[g])),
+                            "set outside the row / null set feature pointer");
+            for (int k = 0; k < set_cn[g]; ++k) {
+                SPLAT_CHECK_ARG(!(covered & (1ull << (set_c0[g] + k))), "the sets overlap");
+                covered |= 1ull << (set_c0[g] + k);
+            }
+        }
+        SPLAT_CHECK_ARG(covered == (1ull << C) - 1ull, "the sets do not cover the row's channels");
+    }
+    const bool enh = (gs_idx != nullptr) && K > 0;
+    BlendArgs A;
+    memset(&A, 0, sizeof(A));
+    A.P = P; A.C = C;
+    A.uv = (const float2 *)uv; A.conic = conic; A.opacity = opacity;
+    A.idx_sorted = idx_sorted; A.tile_range = (const int2 *)tile_range;
+    A.bgc = bg_channels; A.W = W; A.H = H; A.gx = (W + TILE - 1) / TILE;
+    A.K = enh ? K : 0; A.trunc = enable_truncation ? 1 : 0;
+    A.out = out; A.final_T = final_T; A.ncontrib = ncontrib; A.gs_idx = gs_idx;
+    A.pack = pack_scratch;
+    A.cull_flags = cull_flags;
+    const int T = A.gx * ((H + TILE - 1) / TILE);
+    SPLAT_CHECK_ARG((long long)F * T < (1ll << 31), "too many tiles");
+    A.F = F; A.T = T; A.cap = capacity;
+    A.pack_fs = (long long)P * (long long)splat_blend_pack_floats(C);
+    A.opacity_fs = opacity_frame_stride;
+    A.c0 = 0; A.cn = C;
+    A.s0c0 = set_c0[0]; A.s0cn = set_cn[0]; A.s1c0 = set_c0[1]; A.s1cn = set_cn[1]; A.s2c0 = set_c0[2]; A.s2cn = set_cn[2];
+    A.sf0 = set_feature[0]; A.sf1 = set_feature[1]; A.sf2 = set_feature[2];
+    A.sfs0 = set_feature_fs[0]; A.sfs1 = set_feature_fs[1]; A.sfs2 = set_feature_fs[2];
+    return fwd_chunk(A, T, enh, false, (hipStream_t)stream);
+}
+
 extern "C" int splat_alpha_blending_backward_batch(int F, int P, int C, const int32_t *idx_sorted,
                                                    const int32_t *tile_range, int64_t capacity, float bg, int W, int H,
                                                    const float *final_T, const int32_t *ncontrib, const float *dL_dout,
@@ -2334,17 +2416,21 @@ extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, con
                                                         const float *set_bg, const float *uv, const float *conic,
                                                         const float *opacity, int64_t opacity_frame_stride,
                                                         const float *feature, int64_t feature_frame_stride,
+                                                        const float *const *set_feature, const int64_t *set_feature_fs,
                                                         const int32_t *idx_sorted, const int32_t *tile_range,
                                                         int64_t capacity, int W, int H, const float *final_T,
-                                                        const int32_t *ncontrib, const float *dL_dout, int want_abs,
+                                                        const int32_t *ncontrib, const float *dL_dout,
+                                                        const float *const *set_dL, int want_abs,
                                                         const int32_t *slot_sorted, float *pair_records,
                                                         float *pack_scratch, const uint32_t *cull_flags,
                                                         float *dbg_T_front, splat_stream_t stream) {
     SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= SetsCfg::CH && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 28)");
     SPLAT_CHECK_ARG(set_c0 && set_cn && set_bg, "null set table");
-    SPLAT_CHECK_ARG(uv && conic && opacity && feature && idx_sorted && tile_range && final_T && ncontrib && dL_dout &&
-                        slot_sorted && pair_records && pack_scratch,
+    SPLAT_CHECK_ARG(uv && conic && opacity && idx_sorted && tile_range && final_T && ncontrib && slot_sorted && pair_records &&
+                        pack_scratch,
                     "null pointer");
+    SPLAT_CHECK_ARG(feature || (set_feature && set_feature_fs), "features: the row [F,P,C] or the sets' own tensors");
+    SPLAT_CHECK_ARG(dL_dout || set_dL, "image gradient: the row [F,C,H,W] or the sets' own tensors");
     SPLAT_CHECK_ARG(set_cn[0] >= 0 && set_cn[0] <= 4 && set_cn[1] >= 0 && set_cn[1] <= 4 && set_cn[2] >= 0 && set_cn[2] <= 20,
                     "set widths: tap set <= 4, second set <= 4, detached set <= 20 channels");
     {   // the sets tile [0, C): every row channel has exactly one slot (every record component is written)
@@ -2378,6 +2464,15 @@ extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, con
     A.s0c0 = set_c0[0]; A.s0cn = set_cn[0]; A.s0bg = set_bg[0];
     A.s1c0 = set_c0[1]; A.s1cn = set_cn[1]; A.s1bg = set_bg[1];
     A.s2c0 = set_c0[2]; A.s2cn = set_cn[2]; A.s2bg = set_bg[2];
+    if (!feature) {
+        A.sf0 = set_feature[0]; A.sf1 = set_feature[1]; A.sf2 = set_feature[2];
+        A.sfs0 = set_feature_fs[0]; A.sfs1 = set_feature_fs[1]; A.sfs2 = set_feature_fs[2];
+        SPLAT_CHECK_ARG((!set_cn[0] || A.sf0) && (!set_cn[1] || A.sf1) && (!set_cn[2] || A.sf2), "null set feature pointer");
+    }
+    if (!dL_dout) {
+        A.sdl0 = set_dL[0]; A.sdl1 = set_dL[1]; A.sdl2 = set_dL[2];
+        SPLAT_CHECK_ARG((!set_cn[0] || A.sdl0) && (!set_cn[1] || A.sdl1) && (!set_cn[2] || A.sdl2), "null set gradient pointer");
+    }
     hipStream_t s = (hipStream_t)stream;
     SPLAT_LAUNCH("blend_pack", pack_sets_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)F), dim3(256), 0, s, A);
     SPLAT_POST_LAUNCH();

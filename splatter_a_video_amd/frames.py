@@ -369,27 +369,11 @@ class _RenderDynamicSets(torch.autograd.Function):
             L.ptr(rot_fourier), L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c), L.ci(W), L.ci(H), L.cf(nearest), L.cf(extent),
             L.ptr(fb.uv), L.ptr(fb.depth), L.ptr(fb.conic), L.ptr(fb.radius), L.ptr(opa_t), st))
         fb._bin_and_sort()
-        cols, bgs, it = [], [], iter(feats)
-        for w, bg, _, _ in meta:
-            if w == "depth":
-                cols.append(fb.depth)
-                bgs.append(torch.full((1,), bg, dtype=torch.float32, device=fb.dev))
-            else:
-                f = _points(next(it), "feature", w)
-                cols.append(f.unsqueeze(0).expand(F, P, w))
-                bgs.append(torch.full((w,), bg, dtype=torch.float32, device=fb.dev))
-        row = torch.cat(cols, dim=2).contiguous()
-        bgc = torch.cat(bgs)
-        cap = fb.capacity
-        out = torch.empty(F, C, H, W, dtype=torch.float32, device=fb.dev)
-        gs_idx = torch.empty(F, H, W, K, dtype=torch.int32, device=fb.dev) if K > 0 else None
-        L.check(lib.splat_alpha_blending_forward_batch(
-            L.ci(F), L.ci(P), L.ci(C), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opa_t), ctypes.c_int64(0), L.ptr(row),
-            ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.cf(0.0), L.ptr(bgc),
-            L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx),
-            L.ptr(fb.pack), L.ptr(fb.cull_flags), st))
+        out, gs_idx, ctx.blend = _blend_sets_forward(fb, meta, feats, opa_t, 0, K)
+        if ctx.blend["plan"] is None:
+            raise ValueError("render_dynamic_sets needs sets that fit the one-pass backward")
         ctx.fb, ctx.meta, ctx.sink, ctx.geo = fb, meta, sink, (I, layout)
-        ctx.row, ctx.opa_t = row, opa_t
+        ctx.opa_t = opa_t
         ctx.save_for_backward(position, cubic, rotation, opacity, scaling, rot_poly, rot_fourier, extr_c, tab, *feats)
         ctx.set_materialize_grads(False)
         imgs, c0 = [], 0
@@ -411,9 +395,7 @@ class _RenderDynamicSets(torch.autograd.Function):
         lib, st = L.lib(), L.stream()
         F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
         dev = fb.dev
-        widths = [1 if m[0] == "depth" else m[0] for m in meta]
-        dL = torch.cat([(g if g is not None else torch.zeros(F, w, H, W, dtype=torch.float32, device=dev))
-                        for g, w in zip(grads[:len(meta)], widths)], dim=1).contiguous()
+        widths = ctx.blend["widths"]
         like = {"position": position, "pos_cubic_node": cubic, "rotation": rotation, "opacity": opacity, "scaling": scaling}
         bufs = {k: (sink[k] if k in sink else torch.zeros_like(v)) for k, v in like.items()}
         c0s, cns, bgs, depth_ch, tap_set = _one_pass_plan(meta, widths, C)
@@ -429,16 +411,8 @@ class _RenderDynamicSets(torch.autograd.Function):
             dfe.append(dfeat)
             dfs[group_of[si]], strides[group_of[si]] = dfeat, int(feats[fi].shape[1])
             fi += 1
-        from .gs.raster_ops import _debug_T_front
-        ncp = int(lib.splat_blend_sets_pair_stride(C))
-        rec = fb._set_buffer(("rec", "sets"), F * cap * ncp)
-        pack = fb._set_buffer(("pack", "sets"), F * P * int(lib.splat_blend_sets_pack_floats()))
-        i3, f3 = ctypes.c_int32 * 3, ctypes.c_float * 3
-        L.check(lib.splat_alpha_blending_backward_batch_sets(
-            L.ci(F), L.ci(P), L.ci(C), i3(*c0s), i3(*cns), f3(*bgs), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(ctx.opa_t),
-            ctypes.c_int64(0), L.ptr(ctx.row), ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range),
-            ctypes.c_int64(cap), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(dL), L.ci(want_abs),
-            L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(fb.cull_flags), L.ptr(_debug_T_front(F * H, W, dev)), st))
+        rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], ctx.opa_t, 0, want_abs)
+        i3 = ctypes.c_int32 * 3
         p3 = (ctypes.c_void_p * 3)(*[0 if d is None else d.data_ptr() for d in dfs])
         has_tap = tap_set is not None
         L.check(lib.splat_frames_gauss_backward_dynamic_sets(
@@ -450,6 +424,83 @@ class _RenderDynamicSets(torch.autograd.Function):
             L.ptr(fb.radii_max if has_tap else None), st))
         ret = tuple(None if k in sink else bufs[k] for k in like)
         return ret + (None,) * (NF - 5) + tuple(dfe)
+
+
+def _blend_sets_forward(fb, meta, feats, opacity, op_fs, K):
+    """Forward compositing of the sets' row for all frames.  When the sets fit the one-pass backward every set is read from its
+    own tensor (shared features [P,c], the per-frame depth [F,P,1]) -- no [F,P,C] row is materialised; otherwise the row is
+    concatenated and the per-set passes use it.  Returns (out [F,C,H,W], gs_idx, state for _blend_sets_backward)."""
+    lib, st = L.lib(), L.stream()
+    F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
+    widths = [1 if m[0] == "depth" else m[0] for m in meta]
+    plan = _one_pass_plan(meta, widths, C) if os.environ.get("SPLAT_SETS_ONE_PASS", "1") != "0" else None
+    tens, it = [], iter(feats)
+    for w, _, _, _ in meta:
+        tens.append(fb.depth if w == "depth" else _points(next(it), "feature", w))
+    cache = fb.__dict__.setdefault("_bgc", {})
+    bgc = cache.get(meta)
+    if bgc is None:
+        bgc = torch.tensor([bg for (w, bg, _, _), n in zip(meta, widths) for _ in range(n)], dtype=torch.float32, device=fb.dev)
+        cache[meta] = bgc
+    out = torch.empty(F, C, H, W, dtype=torch.float32, device=fb.dev)
+    gs_idx = torch.empty(F, H, W, K, dtype=torch.int32, device=fb.dev) if K > 0 else None
+    row = None
+    if plan is None:
+        row = torch.cat([t if m[0] == "depth" else t.unsqueeze(0).expand(F, P, t.shape[1]) for t, m in zip(tens, meta)],
+                        dim=2).contiguous()
+        L.check(lib.splat_alpha_blending_forward_batch(
+            L.ci(F), L.ci(P), L.ci(C), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity), ctypes.c_int64(op_fs), L.ptr(row),
+            ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.cf(0.0), L.ptr(bgc),
+            L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx),
+            L.ptr(fb.pack), L.ptr(fb.cull_flags), st))
+    else:
+        tabs = _set_tables(meta, plan, tens, P)
+        L.check(lib.splat_alpha_blending_forward_batch_sets(
+            L.ci(F), L.ci(P), L.ci(C), tabs["c0"], tabs["cn"], tabs["feat"], tabs["fs"], L.ptr(fb.uv), L.ptr(fb.conic),
+            L.ptr(opacity), ctypes.c_int64(op_fs), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.ptr(bgc),
+            L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx),
+            L.ptr(fb.pack), L.ptr(fb.cull_flags), st))
+    return out, gs_idx, dict(plan=plan, tens=tens, row=row, widths=widths)
+
+
+def _set_tables(meta, plan, tens, P):
+    """ctypes tables (three routing groups) of a one-pass plan: first row channel, width, feature pointer, frame stride"""
+    c0s, cns, bgs, _, _ = plan
+    groups = _set_groups(meta)
+    ptr, fs = [0, 0, 0], [0, 0, 0]
+    for (w, _, _, _), t, g in zip(meta, tens, groups):
+        ptr[g] = t.data_ptr()
+        fs[g] = P if w == "depth" else 0        # the depth [F,P,1] is per frame, feature rows are shared
+    i3, f3 = ctypes.c_int32 * 3, ctypes.c_float * 3
+    return dict(c0=i3(*c0s), cn=i3(*cns), bg=f3(*bgs), feat=(ctypes.c_void_p * 3)(*ptr), fs=(ctypes.c_int64 * 3)(*fs))
+
+
+def _blend_sets_backward_one_pass(fb, meta, state, grads, opacity, op_fs, want_abs):
+    """ONE pass of the tile kernels for the three sets (splat_alpha_blending_backward_batch_sets): every set's image gradient
+    from its own tensor.  Returns the pair-record buffer."""
+    lib, st = L.lib(), L.stream()
+    F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
+    plan, tens = state["plan"], state["tens"]
+    tabs = _set_tables(meta, plan, tens, P)
+    groups = _set_groups(meta)
+    dl = [0, 0, 0]
+    keep = []
+    for g_, w, grp in zip(grads, state["widths"], groups):
+        t = L.need(g_, "dL_dout") if g_ is not None else torch.zeros(F, w, H, W, dtype=torch.float32, device=fb.dev)
+        if tuple(t.shape) != (F, w, H, W):
+            raise ValueError("image gradient of a set must be [F, c, H, W]")
+        keep.append(t)
+        dl[grp] = t.data_ptr()
+    from .gs.raster_ops import _debug_T_front
+    rec = fb._set_buffer(("rec", "sets"), F * cap * int(lib.splat_blend_sets_pair_stride(C)))
+    pack = fb._set_buffer(("pack", "sets"), F * P * int(lib.splat_blend_sets_pack_floats()))
+    L.check(lib.splat_alpha_blending_backward_batch_sets(
+        L.ci(F), L.ci(P), L.ci(C), tabs["c0"], tabs["cn"], tabs["bg"], L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity),
+        ctypes.c_int64(op_fs), L.ptr(None), ctypes.c_int64(0), tabs["feat"], tabs["fs"], L.ptr(fb.idx_sorted),
+        L.ptr(fb.tile_range), ctypes.c_int64(cap), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(None),
+        (ctypes.c_void_p * 3)(*dl), L.ci(want_abs), L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(fb.cull_flags),
+        L.ptr(_debug_T_front(F * H, W, fb.dev)), st))
+    return rec
 
 
 def _set_groups(meta):
@@ -493,30 +544,10 @@ class _RenderSets(torch.autograd.Function):
         if off is not None and tuple(off.shape) != (F, P, 3):
             raise ValueError(f"offsets must be [F={F}, P={P}, 3]")
         fb._geometry(xyz, scales, uquats, off, extr_c, nearest, extent)
-        # the composited row [F,P,C]: shared features repeated per frame, the depth of every frame in its slot
-        cols, bgs, it = [], [], iter(feats)
-        for w, bg, _, _ in meta:
-            if w == "depth":
-                cols.append(fb.depth)
-                bgs.append(torch.full((1,), bg, dtype=torch.float32, device=fb.dev))
-            else:
-                f = _points(next(it), "feature", w)
-                cols.append(f.unsqueeze(0).expand(F, P, w))
-                bgs.append(torch.full((w,), bg, dtype=torch.float32, device=fb.dev))
-        row = torch.cat(cols, dim=2).contiguous()
-        bgc = torch.cat(bgs)
-        lib, st = L.lib(), L.stream()
-        W, H, C, cap = fb.W, fb.H, fb.C, fb.capacity
-        out = torch.empty(F, C, H, W, dtype=torch.float32, device=fb.dev)
-        gs_idx = torch.empty(F, H, W, K, dtype=torch.int32, device=fb.dev) if K > 0 else None
         op_fs = 0 if opacity.numel() == P else P
-        L.check(lib.splat_alpha_blending_forward_batch(
-            L.ci(F), L.ci(P), L.ci(C), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity), ctypes.c_int64(op_fs), L.ptr(row),
-            ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.cf(0.0), L.ptr(bgc),
-            L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx),
-            L.ptr(fb.pack), L.ptr(fb.cull_flags), st))
+        C = fb.C
+        out, gs_idx, ctx.blend = _blend_sets_forward(fb, meta, feats, opacity, op_fs, K)
         ctx.fb, ctx.meta, ctx.sink, ctx.K = fb, meta, sink, K
-        ctx.row = row
         ctx.save_for_backward(xyz, scales, uquats, opacity, extr_c, *feats)
         ctx.set_materialize_grads(False)
         imgs, c0 = [], 0
@@ -538,15 +569,13 @@ class _RenderSets(torch.autograd.Function):
         lib, st = L.lib(), L.stream()
         F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
         dev = fb.dev
-        widths = [1 if m[0] == "depth" else m[0] for m in meta]
-        dL = torch.cat([(g if g is not None else torch.zeros(F, w, H, W, dtype=torch.float32, device=dev))
-                        for g, w in zip(grads[:len(meta)], widths)], dim=1).contiguous()
+        widths = ctx.blend["widths"]
         like = {"xyz": xyz, "scales": scales, "uquats": uquats, "opacity": opacity}
         bufs = {k: (sink[k] if k in sink else torch.zeros_like(v)) for k, v in like.items()}   # every set accumulates
         dfe = []
         op_fs = 0 if opacity.numel() == P else P
         from .gs.raster_ops import _debug_T_front
-        plan = _one_pass_plan(meta, widths, C) if os.environ.get("SPLAT_SETS_ONE_PASS", "1") != "0" else None
+        plan = ctx.blend["plan"]
         if plan is not None:
             # the sets share the alpha / transmittance replay: ONE pass of the tile kernels and ONE Gaussian-side reduction
             # route dL/dalpha of every set where the reference's three autograd nodes would
@@ -562,15 +591,8 @@ class _RenderSets(torch.autograd.Function):
                 dfe.append(dfeat)
                 dfs[group_of[si]], strides[group_of[si]] = dfeat, int(feats[fi].shape[1])
                 fi += 1
-            ncp = int(lib.splat_blend_sets_pair_stride(C))
-            rec = fb._set_buffer(("rec", "sets"), F * cap * ncp)
-            pack = fb._set_buffer(("pack", "sets"), F * P * int(lib.splat_blend_sets_pack_floats()))
-            i3, f3 = ctypes.c_int32 * 3, ctypes.c_float * 3
-            L.check(lib.splat_alpha_blending_backward_batch_sets(
-                L.ci(F), L.ci(P), L.ci(C), i3(*c0s), i3(*cns), f3(*bgs), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity),
-                ctypes.c_int64(op_fs), L.ptr(ctx.row), ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range),
-                ctypes.c_int64(cap), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(dL), L.ci(want_abs),
-                L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(fb.cull_flags), L.ptr(_debug_T_front(F * H, W, dev)), st))
+            rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], opacity, op_fs, want_abs)
+            i3 = ctypes.c_int32 * 3
             p3 = (ctypes.c_void_p * 3)(*[0 if d is None else d.data_ptr() for d in dfs])
             has_tap = tap_set is not None
             L.check(lib.splat_frames_gauss_backward_static_sets(
@@ -581,6 +603,9 @@ class _RenderSets(torch.autograd.Function):
                 L.ptr(fb.radii_max if has_tap else None), st))
             ret = tuple(None if k in sink else bufs[k] for k in ("xyz", "scales", "uquats", "opacity"))
             return ret + (None,) * 8 + tuple(dfe)
+        row = ctx.blend["row"]
+        dL = torch.cat([(g if g is not None else torch.zeros(F, w, H, W, dtype=torch.float32, device=dev))
+                        for g, w in zip(grads[:len(meta)], widths)], dim=1).contiguous()
         c0, fi = 0, 0
         for si, ((w, bg, detach, taps), g) in enumerate(zip(meta, grads[:len(meta)])):
             cn = widths[si]
@@ -597,7 +622,7 @@ class _RenderSets(torch.autograd.Function):
                 pack = fb._set_buffer(("pack", si), F * P * int(lib.splat_blend_pack_floats(cn)))
                 L.check(lib.splat_alpha_blending_backward_batch_set(
                     L.ci(F), L.ci(P), L.ci(C), L.ci(c0), L.ci(cn), L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity),
-                    ctypes.c_int64(op_fs), L.ptr(ctx.row), ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range),
+                    ctypes.c_int64(op_fs), L.ptr(row), ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range),
                     ctypes.c_int64(cap), L.cf(bg), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(dL),
                     L.ci(want_abs), L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(_debug_T_front(F * H, W, dev)), st))
                 L.check(lib.splat_frames_gauss_backward_static_set(

@@ -215,8 +215,8 @@ def test_sets_entry_points_validate_arguments(built_lib):
     assert L.splat_blend_sets_pair_stride(23) == 36 and L.splat_blend_sets_pair_stride(28) == 40
     # sets that do not tile the row / too wide / null tables: refused before any launch
     one = ctypes.c_void_p(8)
-    args = lambda c0, cn, C: (1, 10, C, i3(*c0), i3(*cn), f3(0, 0, 0), one, one, one, ctypes.c_int64(0), one, ctypes.c_int64(0), one,
-                              one, ctypes.c_int64(100), 32, 32, one, one, one, 0, one, one, one, None, None, None)
+    args = lambda c0, cn, C: (1, 10, C, i3(*c0), i3(*cn), f3(0, 0, 0), one, one, one, ctypes.c_int64(0), one, ctypes.c_int64(0), None,
+                              None, one, one, ctypes.c_int64(100), 32, 32, one, one, one, None, 0, one, one, one, None, None, None)
     assert L.splat_alpha_blending_backward_batch_sets(*args([0, 3, 4], [3, 1, 18], 23)) == -1     # channel 22 uncovered
     assert b"cover" in L.splat_last_error()
     assert L.splat_alpha_blending_backward_batch_sets(*args([0, 3, 3], [3, 1, 19], 23)) == -1     # overlap
