@@ -606,7 +606,22 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
 #pragma unroll
             for (int c = 0; c < NS; ++c) af[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             const float *base = A.pair + (size_t)ff * (size_t)A.cap * NCP + 4 * j;
-            for (int r = beg; r < end; ++r) {
+            int r = beg;
+            for (; r + 1 < end; r += 2) {  // two records in flight
+                float4 v0[NS], v1[NS];
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    const bool mine = 4 * c + j < NQ;
+                    v0[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)r * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v1[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)(r + 1) * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    af[c].x += v0[c].x; af[c].y += v0[c].y; af[c].z += v0[c].z; af[c].w += v0[c].w;
+                    af[c].x += v1[c].x; af[c].y += v1[c].y; af[c].z += v1[c].z; af[c].w += v1[c].w;
+                }
+            }
+            if (r < end) {
 #pragma unroll
                 for (int c = 0; c < NS; ++c) {
                     if (4 * c + j < NQ) {
