@@ -76,8 +76,8 @@ def test_batch_equals_per_frame_operators(N, W, H, F, C, abs_tap):
     assert torch.equal(B.radii_max, ref_rad)
 
 
-@pytest.mark.parametrize("C", [3, 16])
-def test_batch_dense_saturating_scene(C):
+@pytest.mark.parametrize("C,abs_tap", [(3, False), (3, True), (16, False)])
+def test_batch_dense_saturating_scene(C, abs_tap):
     """Long tile lists of large, faint splats: pixels saturate a few hundred splats in, long before their list ends (the forward stops
     whole blocks -- their cull flags stay 0 for the backward), more than half of a super-batch survives a block's cull (the
     backward's slabs take a second round), survivors are carried across many super-batches."""
@@ -94,9 +94,9 @@ def test_batch_dense_saturating_scene(C):
         return {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity).items()}
 
     pa, fa = params(), _t(featv, True)
-    ref_img, ref_tap, _, _ = _per_frame(sc, pa, off, fa, g, W, H, 0.0)
+    ref_img, ref_tap, ref_atap, _ = _per_frame(sc, pa, off, fa, g, W, H, 0.0, abs_tap)
     pb, fb_ = params(), _t(featv, True)
-    B = FrameBatch(F, N, W, H, C, "cuda")
+    B = FrameBatch(F, N, W, H, C, "cuda", want_abs=abs_tap)
     out = B.render(pb["xyz"], pb["scales"], pb["uquats"], pb["opacity"], fb_, off, _t(sc.extr), bg=0.0)
     assert torch.equal(out, ref_img)
     assert int(B.ncontrib.max()) > 200 and float(B.final_T.min()) < 1.1e-4     # long replays, saturated pixels
@@ -110,6 +110,8 @@ def test_batch_dense_saturating_scene(C):
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-5 * float(b.abs().max()) + 1e-12), k
     assert torch.allclose(fb_.grad, fa.grad, rtol=1e-3, atol=1e-5 * float(fa.grad.abs().max()) + 1e-12)
     assert torch.allclose(B.tap, ref_tap, rtol=1e-3, atol=1e-5 * float(ref_tap.abs().max()) + 1e-12)
+    if abs_tap:
+        assert torch.allclose(B.abs_tap, ref_atap, rtol=1e-3, atol=1e-5 * float(ref_atap.abs().max()) + 1e-12)
 
 
 def test_batch_gradient_sinks_and_reuse():
