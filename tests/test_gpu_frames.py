@@ -207,18 +207,19 @@ def test_render_sets_equals_the_native_renderer_frame_by_frame(one_pass, monkeyp
     assert torch.equal(B.radii_max, torch.stack(radii).max(0).values)
 
 
-@pytest.mark.parametrize("case", ["detached_first", "two_live_sets", "tap_only"])
+@pytest.mark.parametrize("case", ["detached_first", "two_live_sets", "tap_only", "odd_sizes_one_frame"])
 def test_render_sets_one_pass_equals_the_per_set_passes(case, monkeypatch):
     """splat_alpha_blending_backward_batch_sets (one replay of the alpha / T chain, dL/dalpha routed per set) against the
     per-set passes, for set orders and routings other than the reference renderer's: parameter gradients, feature
     gradients, both taps and the replay check (the one-pass kernel reproduces every inclusion decision of the forward)."""
-    N, W, H, F = 6000, 160, 96, 2
+    N, W, H, F = (777, 50, 34, 1) if case == "odd_sizes_one_frame" else (6000, 160, 96, 2)
     sc = make_scene(N, W, H, seed=31)
     rng = np.random.default_rng(5)
     off, extr = _t(_offsets(sc, F)), _t(sc.extr)
-    widths = {"detached_first": (8, 3), "two_live_sets": (4, 2), "tap_only": (3,)}[case]
+    widths = {"detached_first": (8, 3), "two_live_sets": (4, 2), "tap_only": (3,), "odd_sizes_one_frame": (3, 5)}[case]
     feats_np = [rng.uniform(-1, 1, size=(N, w)).astype(np.float32) for w in widths]
-    gs_ = [_t(rng.normal(size=(F, w, H, W)).astype(np.float32)) for w in widths]
+    gw = (3, 1, 5) if case == "odd_sizes_one_frame" else widths        # image gradients per set (incl. the depth set)
+    gs_ = [_t(rng.normal(size=(F, w, H, W)).astype(np.float32)) for w in gw]
 
     def run(flag):
         monkeypatch.setenv("SPLAT_SETS_ONE_PASS", flag)
@@ -228,9 +229,12 @@ def test_render_sets_one_pass_equals_the_per_set_passes(case, monkeypatch):
             sets = [dict(feature=fe[0], bg=0.3, detach_opacity=True), dict(feature=fe[1], bg=0.1, taps=True)]
         elif case == "two_live_sets":
             sets = [dict(feature=fe[0], bg=0.0, taps=True), dict(feature=fe[1], bg=0.5)]
+        elif case == "odd_sizes_one_frame":   # P, W, H no multiples of the block sizes; the per-frame depth as the middle set
+            sets = [dict(feature=fe[0], bg=0.1, taps=True), dict(feature="depth", bg=1.0),
+                    dict(feature=fe[1], bg=0.0, detach_opacity=True)]
         else:
             sets = [dict(feature=fe[0], bg=0.2, taps=True)]
-        B = FrameBatch(F, N, W, H, sum(widths), "cuda", want_abs=True)
+        B = FrameBatch(F, N, W, H, sum(gw), "cuda", want_abs=True)
         res = B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], sets, off, extr)
         with capture_T_front() as cap:
             torch.autograd.backward(list(res[:-1]), gs_)
