@@ -37,9 +37,22 @@ class SynthScene:
 
 
 def make_scene(N: int, W: int, H: int, F: int = 50, C: int = 0, seed: int = 1234,
-               sigma_px: float = 2.0, ortho: bool = True) -> SynthScene:
+               sigma_px: float = 2.0, ortho: bool = True, clustered: float = 0.0, cluster_area: float = 0.1,
+               blobs: int = 6) -> SynthScene:
+    """``clustered`` > 0: that fraction of the Gaussians sits inside ``blobs`` discs that together cover ``cluster_area`` of
+    the image (foreground objects of a DAVIS clip), the rest is spread uniformly -- long tile lists next to short ones."""
     rng = np.random.default_rng(seed)
     xy = rng.uniform(-1.0, 1.0, size=(N, 2))
+    if clustered > 0.0:
+        crng = np.random.default_rng(seed + 7919)          # (separate stream: the uniform scene's draws stay what they were)
+        r = math.sqrt(cluster_area * 4.0 / (blobs * math.pi))   # NDC radius of one disc: blobs * pi r^2 = area * 4
+        centres = crng.uniform(-1.0 + r, 1.0 - r, size=(blobs, 2))
+        n_in = int(round(clustered * N))
+        which = crng.integers(0, blobs, size=n_in)
+        rad = r * np.sqrt(crng.uniform(0.0, 1.0, size=n_in))
+        ang = crng.uniform(0.0, 2.0 * math.pi, size=n_in)
+        members = crng.permutation(N)[:n_in]
+        xy[members] = centres[which] + np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1)
     z = rng.uniform(0.1, 1.0, size=(N, 1))
     scale = np.exp(rng.normal(math.log(2.0 * sigma_px / W), 0.5, size=(N, 3)))
     q = rng.normal(0.0, 1.0, size=(N, 4))

@@ -70,3 +70,27 @@ def test_two_ranks_on_one_device_match_single_process(tmp_path):
     assert float(d.max()) <= 2.1 * 1e-3 * 2
     assert float(d.median()) < 1e-6 and float((d > 1e-5).float().mean()) < 0.02
     assert float(g1.abs().max()) > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_launches_and_reports_two_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment starts two ranks itself (gloo: both share this box's GPU;
+    over RCCL the same code path needs one GPU per rank) and its line says n_gpus 2, ranks_seen 2; N = 1 stays a plain run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, SPLAT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    small = ["--gaussians", "6000", "--width", "128", "--height", "96", "--frames", "3", "--steps", "2", "--warmup", "1",
+             "--no-cpu-baseline", "--no-kernel-timing", "--no-extra-lines"]
+    lines = {}
+    for n in (2, 1):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)] + small, env=env, capture_output=True,
+                           text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines[n] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert lines[2]["n_gpus"] == 2 and lines[2]["ranks_seen"] == 2
+    assert lines[1]["n_gpus"] == 1 and lines[1]["ranks_seen"] == 1
+    assert lines[2]["config"]["frames_per_rank_per_step"] == 3 and lines[2]["value"] > 0

@@ -1,0 +1,269 @@
+"""The frame-batch entry points -- the path bench.py times -- straight against the CPU oracle and the reference-made golden
+fixtures (no intermediate HIP path in between): FrameBatch.render, render_sets (K = 20, 3 + 1 + 19), render_dynamic and
+render_dynamic_sets at BASELINE configs[0] size (10k Gaussians, 256 x 256, F = 3), and the 32-channel width of configs[4].
+Kernels under test: frame_preprocess_fwd_batch / preprocess_ortho_forward_batch, the batched binning + sort, pack /
+pack_sets, blend_fwd, blend_bwd_mfma, blend_bwd_sets, frames_gauss_bwd_static(_sets), frames_gauss_bwd_dynamic(_sets).
+Semantics: src/pointrix/renderer/dptr_ortho_enhanced.py:331-376,385-433; src/alpha_blending.cu:112-249 (reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_chain as oc
+from splatter_a_video_amd.frames import FrameBatch
+from splatter_a_video_amd.gs.raster_ops import capture_T_front
+from test_gpu_parity import GRAD_RTOL, IMG_ATOL, IMG_RTOL, assert_grad
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _t(a, grad=False):
+    return torch.tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda", requires_grad=grad)
+
+
+def _c1_scene(F, seed=0):
+    """geometry of the reference-made c1 fixture (10k Gaussians, 256 x 256) + seeded opacities and per-frame offsets
+    (frame 0 unmoved: its projection is the fixture's)"""
+    g = dict(np.load(os.path.join(GOLD, "ortho_c1_10k_256x256.npz")))
+    rng = np.random.default_rng(seed)
+    N = g["xyz"].shape[0]
+    opacity = (1.0 / (1.0 + np.exp(-rng.normal(0.0, 1.5, size=(N, 1))))).astype(np.float32)
+    off = np.zeros((F, N, 3), np.float32)
+    for f in range(1, F):
+        d = 0.05 * np.sin(2.0 * np.pi * f / 7.0 + rng.uniform(0, 2 * np.pi, size=N))
+        off[f, :, 0] = d; off[f, :, 1] = -0.5 * d
+    return g, opacity, off, rng
+
+
+def _check_images(got, per, c0, name):
+    for f, r in enumerate(per):
+        c = c0
+        for img in r["imgs"]:
+            a = got[f, c:c + img.shape[0]].detach().cpu().numpy()
+            bad = np.abs(a - img) > (IMG_ATOL + IMG_RTOL * np.abs(img))
+            assert bad.mean() < 1e-3, (name, f, float(bad.mean()))
+            c += img.shape[0]
+
+
+def _same_geometry(B, per):
+    rad = B.radius.cpu().numpy()
+    same = all((rad[f] == r["radius"]).all() for f, r in enumerate(per))
+    for f, r in enumerate(per):
+        assert (rad[f] != r["radius"]).mean() <= 1e-4        # ceil(3 sqrt(lambda)) may flip on a rounding tie
+    return same
+
+
+def test_frame_batch_render_against_oracle_and_reference_geometry(oracle_mod):
+    """FrameBatch.render (the default bench path): images, final_T, ncontrib, every parameter gradient and the taps of three
+    frames against the oracle chain; frame 0's batched preprocess against the REFERENCE's own uv / conic / radius."""
+    F, C, bg = 3, 3, 0.3
+    g, opacity, off, rng = _c1_scene(F)
+    N, W, H = g["xyz"].shape[0], int(g["W"]), int(g["H"])
+    feat = rng.uniform(size=(N, C)).astype(np.float32)
+    gimg = rng.normal(size=(F, C, H, W)).astype(np.float32)
+    p = {k: _t(v, True) for k, v in dict(xyz=g["xyz"], scales=g["scale"], uquats=g["rotate"], opacity=opacity, feature=feat).items()}
+    B = FrameBatch(F, N, W, H, C, "cuda", want_abs=True)
+    out = B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], _t(off), _t(g["extr"]), bg=bg)
+    # ---- frame 0 of the batched preprocess vs the reference's torch functions (tests/golden/make_golden.py)
+    np.testing.assert_allclose(B.uv[0].cpu().numpy(), g["uv"], rtol=1e-5, atol=2e-4)
+    same0 = B.radius[0].cpu().numpy() == g["radius"]
+    assert same0.mean() > 0.9999
+    np.testing.assert_allclose(B.conic[0].cpu().numpy()[same0], g["conic"][same0], rtol=2e-5, atol=2e-6 * float(np.abs(g["conic"]).max()))
+    with capture_T_front() as cap:
+        out.backward(_t(gimg))
+    torch.cuda.synchronize()
+    assert float((cap.maps[0] - 1).abs().max()) < 2e-4
+    # ---- oracle chain, frame by frame
+    sets = [dict(feature=feat, bg=bg, taps=True)]
+    per, tot = oc.static_frames(oracle_mod, g["xyz"], off, g["scale"], g["rotate"], opacity, g["extr"], W, H, sets, [gimg])
+    same = _same_geometry(B, per)
+    assert B.check() == max(r["M"] for r in per) or not same
+    _check_images(out, per, 0, "render")
+    for f, r in enumerate(per):
+        assert (B.ncontrib[f].cpu().numpy() != r["ncontrib"]).mean() < 1e-3
+        assert np.abs(B.final_T[f].cpu().numpy() - r["final_T"]).max() < 5e-3
+    tol = GRAD_RTOL if same else 5e-3
+    assert_grad(p["xyz"].grad, tot["xyz"], "xyz", tol)
+    assert_grad(p["scales"].grad, tot["scale"], "scales", tol)
+    assert_grad(p["uquats"].grad, tot["rotate"], "uquats", tol)
+    assert_grad(p["opacity"].grad, tot["opacity"], "opacity", tol)
+    assert_grad(p["feature"].grad, tot["feats"][0], "feature", tol)
+    assert_grad(B.tap, tot["tap"], "tap", tol)
+    assert_grad(B.abs_tap, tot["abs_tap"], "abs_tap", tol)
+    assert (B.radii_max.cpu().numpy() == np.max([r["radius"] for r in per], 0)).mean() > 0.9999
+
+
+def test_render_sets_against_oracle(oracle_mod):
+    """render_sets = the reference's render_iter over a batch: rgb enhanced (K = 20 ids, ndc + abs_ndc taps), depth (bg 1),
+    19 attribute channels with opacity.detach() -- one forward over the 23-channel row, the ONE-pass three-set backward
+    (blend_bwd_sets_kernel) and frames_gauss_bwd_static_sets -- against three oracle blends per frame."""
+    F, K = 3, 20
+    g, opacity, off, rng = _c1_scene(F, seed=3)
+    N, W, H = g["xyz"].shape[0], int(g["W"]), int(g["H"])
+    rgb = rng.uniform(size=(N, 3)).astype(np.float32)
+    attrs = rng.uniform(-1, 1, size=(N, 19)).astype(np.float32)
+    gs_ = [rng.normal(size=(F, c, H, W)).astype(np.float32) for c in (3, 1, 19)]
+    p = {k: _t(v, True) for k, v in dict(xyz=g["xyz"], scales=g["scale"], uquats=g["rotate"], opacity=opacity, rgb=rgb,
+                                         attrs=attrs).items()}
+    B = FrameBatch(F, N, W, H, 23, "cuda", want_abs=True)
+    sets = [dict(feature=p["rgb"], bg=0.2, taps=True), dict(feature="depth", bg=1.0),
+            dict(feature=p["attrs"], bg=0.0, detach_opacity=True)]
+    o_rgb, o_dep, o_att, ids = B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], sets, _t(off), _t(g["extr"]), K=K)
+    with capture_T_front() as cap:
+        torch.autograd.backward([o_rgb, o_dep, o_att], [_t(x) for x in gs_])
+    torch.cuda.synchronize()
+    B.check()
+    assert float((cap.maps[-1] - 1).abs().max()) < 2e-4
+    osets = [dict(feature=rgb, bg=0.2, taps=True), dict(feature="depth", bg=1.0), dict(feature=attrs, bg=0.0, detach_opacity=True)]
+    per, tot = oc.static_frames(oracle_mod, g["xyz"], off, g["scale"], g["rotate"], opacity, g["extr"], W, H, osets, gs_, K=K)
+    same = _same_geometry(B, per)
+    _check_images(torch.cat([o_rgb, o_dep, o_att], 1), per, 0, "render_sets")
+    for f, r in enumerate(per):
+        assert (ids[f].cpu().numpy() != r["gs_idx"]).any(-1).mean() < 1e-3
+    tol = GRAD_RTOL if same else 5e-3
+    assert_grad(p["xyz"].grad, tot["xyz"], "xyz", tol)
+    assert_grad(p["scales"].grad, tot["scale"], "scales", tol)
+    assert_grad(p["uquats"].grad, tot["rotate"], "uquats", tol)
+    assert_grad(p["opacity"].grad, tot["opacity"], "opacity (rgb + depth sets only)", tol)
+    assert_grad(p["rgb"].grad, tot["feats"][0], "rgb", tol)
+    assert_grad(p["attrs"].grad, tot["feats"][2], "attributes", tol)
+    assert_grad(B.tap, tot["tap"], "tap", tol)
+    assert_grad(B.abs_tap, tot["abs_tap"], "abs_tap", tol)
+
+
+def _dynamic_host(N, T, seed):
+    from splatter_a_video_amd.dynamics import FrameClock
+    clock = FrameClock(T)
+    I = clock.interval_num
+    rng = np.random.default_rng(seed)
+    f = lambda *s, scale=1.0: rng.normal(0, scale, size=s).astype(np.float32)
+    host = dict(position=np.concatenate([rng.uniform(-1.1, 1.1, size=(N, 2)), rng.uniform(2.0, 4.0, size=(N, 1))], 1).astype(np.float32),
+                pos_cubic_node=f(N, 4 * I * 3, scale=0.02), rotation=f(N, 4), rot_poly_feat=f(N, 4, 4, scale=0.05),
+                rot_fourier_feat=f(N, 8, 4, scale=0.05), opacity=f(N, 1, scale=1.5),
+                scaling=np.log(rng.uniform(0.006, 0.03, size=(N, 3))).astype(np.float32))
+    return clock, host, rng
+
+
+def _dyn_check(p, tot, tol, to_gm, I):
+    N = p["position"].shape[0]
+    assert_grad(to_gm(p["pos_cubic_node"].grad).reshape(N, 4, I, 3), tot["pos_cubic_node"], "pos_cubic_node", tol)
+    assert_grad(p["rotation"].grad, tot["rotation"], "rotation", tol)
+    assert_grad(p["opacity"].grad, tot["opacity"], "opacity", tol)
+    assert_grad(p["scaling"].grad, tot["scaling"], "scaling", tol)
+    if p["position"].grad is not None:
+        assert_grad(p["position"].grad, tot["position"], "position", tol)
+
+
+def test_render_dynamic_against_oracle(oracle_mod):
+    """render_dynamic (rows a15 + f1 in a batch): frame_preprocess_fwd_batch + frames_gauss_bwd_dynamic against the oracle's
+    dynamic_eval around its static chain, at c1 size"""
+    from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, to_gaussian_major, to_segment_major
+    N, W, H, T, C = 10000, 256, 256, 30, 3
+    times = [0, 14, 15, 29]
+    F = len(times)
+    clock, host, rng = _dynamic_host(N, T, 5)
+    I = clock.interval_num
+    feat = rng.uniform(size=(N, C)).astype(np.float32)
+    gimg = rng.normal(size=(F, C, H, W)).astype(np.float32)
+    extr = np.eye(4, dtype=np.float32)
+    p = {k: _t(v, k not in ("rot_poly_feat", "rot_fourier_feat")) for k, v in host.items()}
+    p["pos_cubic_node"] = to_segment_major(_t(host["pos_cubic_node"]), I).requires_grad_(True)
+    ft = _t(feat, True)
+    B = FrameBatch(F, N, W, H, C, "cuda")
+    out = B.render_dynamic(clock, times, _t(extr), ft, position=p["position"], pos_cubic_node=p["pos_cubic_node"],
+                           rotation=p["rotation"], rot_poly_feat=p["rot_poly_feat"], rot_fourier_feat=p["rot_fourier_feat"],
+                           opacity=p["opacity"], scaling=p["scaling"], cubic_layout=SEGMENT_MAJOR, bg=0.1)
+    with capture_T_front() as cap:
+        out.backward(_t(gimg))
+    torch.cuda.synchronize()
+    B.check()
+    assert float((cap.maps[0] - 1).abs().max()) < 2e-4
+    per, tot = oc.dynamic_frames(oracle_mod, clock, times, host, extr, W, H, [dict(feature=feat, bg=0.1, taps=True)], [gimg])
+    same = _same_geometry(B, per)
+    _check_images(out, per, 0, "render_dynamic")
+    tol = GRAD_RTOL if same else 5e-3
+    _dyn_check(p, tot, tol, lambda x: to_gaussian_major(x), I)
+    assert_grad(ft.grad, tot["feats"][0], "feature", tol)
+    assert_grad(B.tap, tot["tap"], "tap", tol)
+
+
+def test_render_dynamic_sets_against_oracle_with_reference_parameters(oracle_mod):
+    """render_dynamic_sets = the reference's training frame over a batch, on the parameters of the reference-made dynamic fixture
+    (400 Gaussians x 50 frames, tests/golden/make_golden_dynamic.py; its activations are pinned in test_gpu_dynamic.py) tiled
+    to fill a 96 x 64 view: dynamic evaluation -> three blends -> one-pass backward -> frames_gauss_bwd_dynamic_sets."""
+    from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, FrameClock, to_gaussian_major, to_segment_major
+    g = dict(np.load(os.path.join(GOLD, "dynamic_400x50.npz")))
+    clock = FrameClock(int(g["T"]), g["intervals"], int(g["start_frame_id"]), int(g["time_len"]))
+    I = clock.interval_num
+    names = ("position", "pos_cubic_node", "rotation", "rot_poly_feat", "rot_fourier_feat", "opacity", "scaling")
+    host = {k: np.ascontiguousarray(g[k], np.float32) for k in names}
+    N, W, H, K = host["position"].shape[0], 96, 64, 8
+    times = [int(t) for t in g["times"]][:6]
+    F = len(times)
+    # the fixture's Gaussians are N(0,1) positions with scales around e^-4: a camera that maps them into the view
+    extr = np.eye(4, dtype=np.float32)
+    extr[0, 0] = extr[1, 1] = 0.3; extr[2, 2] = 0.1; extr[2, 3] = 2.0
+    host["scaling"] = host["scaling"] + 2.0      # a few pixels wide under that camera (same raw-parameter chain)
+    rng = np.random.default_rng(8)
+    rgb = rng.uniform(size=(N, 3)).astype(np.float32)
+    attrs = rng.uniform(-1, 1, size=(N, 19)).astype(np.float32)
+    gs_ = [rng.normal(size=(F, c, H, W)).astype(np.float32) for c in (3, 1, 19)]
+    p = {k: _t(v, k not in ("rot_poly_feat", "rot_fourier_feat", "position")) for k, v in host.items()}
+    p["pos_cubic_node"] = to_segment_major(_t(host["pos_cubic_node"]), I).requires_grad_(True)
+    t_rgb, t_att = _t(rgb, True), _t(attrs, True)
+    B = FrameBatch(F, N, W, H, 23, "cuda", want_abs=True)
+    sets = [dict(feature=t_rgb, bg=0.2, taps=True), dict(feature="depth", bg=1.0), dict(feature=t_att, bg=0.0, detach_opacity=True)]
+    o_rgb, o_dep, o_att, ids = B.render_dynamic_sets(
+        clock, times, _t(extr), sets, position=p["position"], pos_cubic_node=p["pos_cubic_node"], rotation=p["rotation"],
+        rot_poly_feat=p["rot_poly_feat"], rot_fourier_feat=p["rot_fourier_feat"], opacity=p["opacity"], scaling=p["scaling"],
+        cubic_layout=SEGMENT_MAJOR, K=K)
+    with capture_T_front() as cap:
+        torch.autograd.backward([o_rgb, o_dep, o_att], [_t(x) for x in gs_])
+    torch.cuda.synchronize()
+    B.check()
+    assert float((cap.maps[-1] - 1).abs().max()) < 2e-4
+    osets = [dict(feature=rgb, bg=0.2, taps=True), dict(feature="depth", bg=1.0), dict(feature=attrs, bg=0.0, detach_opacity=True)]
+    per, tot = oc.dynamic_frames(oracle_mod, clock, times, host, extr, W, H, osets, gs_, K=K)
+    assert sum(r["M"] for r in per) > 2000      # the view is populated
+    same = _same_geometry(B, per)
+    _check_images(torch.cat([o_rgb, o_dep, o_att], 1), per, 0, "render_dynamic_sets")
+    for f, r in enumerate(per):
+        assert (ids[f].cpu().numpy() != r["gs_idx"]).any(-1).mean() < 2e-3
+    tol = GRAD_RTOL if same else 5e-3
+    _dyn_check(p, tot, tol, lambda x: to_gaussian_major(x), I)
+    assert_grad(t_rgb.grad, tot["feats"][0], "rgb", tol)
+    assert_grad(t_att.grad, tot["feats"][2], "attributes", tol)
+    assert_grad(B.tap, tot["tap"], "tap", tol)
+    assert_grad(B.abs_tap, tot["abs_tap"], "abs_tap", tol)
+
+
+def test_wide_row_batch_against_oracle(oracle_mod):
+    """configs[4] width: 32 feature channels (the shared-slab matrix-core backward) at 12k Gaussians, two frames, vs the oracle"""
+    from splatter_a_video_amd.synth import make_scene
+    N, W, H, F, C = 12000, 256, 160, 2, 32
+    sc = make_scene(N, W, H, seed=321)
+    rng = np.random.default_rng(11)
+    off = np.stack([sc.positions(f) - sc.xyz for f in (0, 9)]).astype(np.float32)
+    feat = rng.uniform(-1, 1, size=(N, C)).astype(np.float32)
+    gimg = rng.normal(size=(F, C, H, W)).astype(np.float32)
+    p = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity, feature=feat).items()}
+    B = FrameBatch(F, N, W, H, C, "cuda")
+    out = B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], _t(off), _t(sc.extr), bg=0.0)
+    with capture_T_front() as cap:
+        out.backward(_t(gimg))
+    torch.cuda.synchronize()
+    B.check()
+    assert float((cap.maps[0] - 1).abs().max()) < 2e-4
+    per, tot = oc.static_frames(oracle_mod, sc.xyz, off, sc.scale, sc.rotate, sc.opacity, sc.extr, W, H,
+                                [dict(feature=feat, bg=0.0, taps=True)], [gimg])
+    same = _same_geometry(B, per)
+    _check_images(out, per, 0, "wide row")
+    tol = GRAD_RTOL if same else 5e-3
+    assert_grad(p["xyz"].grad, tot["xyz"], "xyz", tol)
+    assert_grad(p["scales"].grad, tot["scale"], "scales", tol)
+    assert_grad(p["uquats"].grad, tot["rotate"], "uquats", tol)
+    assert_grad(p["opacity"].grad, tot["opacity"], "opacity", tol)
+    assert_grad(p["feature"].grad, tot["feats"][0], "feature", tol)
+    assert_grad(B.tap, tot["tap"], "tap", tol)
