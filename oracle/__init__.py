@@ -539,7 +539,7 @@ def arap_energy(nodes, nbr, weight, sample_idx):
     for t in range(1, Nt):
         Et = edges(nodes[t])[sidx]
         S = np.einsum("ski,sk,skj->sij", Es, w, Et)
-        unchanged = (Es == Et).all(axis=(1, 2))
+        unchanged = (Es == Et).all(axis=1).any(axis=1)      # (:66: reduced over the K edges, any axis -- as the reference)
         S[unchanged] = 0
         U, sig, Wt = np.linalg.svd(S.astype(np.float64))
         W = np.transpose(Wt, (0, 2, 1))

@@ -110,7 +110,10 @@ arap_kernel(int Nt, int Nv, int K, int S_, const float *__restrict__ nodes, cons
     const float pi0[3] = {src[3 * i], src[3 * i + 1], src[3 * i + 2]}, pit[3] = {tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2]};
     float es[ARAP_MAXK][3], et[ARAP_MAXK][3], w[ARAP_MAXK];
     float S[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    bool unchanged = true;
+    // the reference's shortcut (:66-67): torch.where((source_edge == target_edge).all(dim=1))[0] -- the comparison is reduced
+    // over the K edges only, so a vertex counts as undeformed as soon as ONE coordinate axis of all its edges is unchanged
+    // (planar or axis-constant motion), not only when all K x 3 entries are
+    bool same_axis[3] = {true, true, true};
     for (int k = 0; k < K; ++k) {
         const int j = nbr[(size_t)i * K + k];
         w[k] = weight ? weight[(size_t)i * K + k] : (j >= 0 ? 1.f : 0.f);
@@ -118,14 +121,14 @@ arap_kernel(int Nt, int Nv, int K, int S_, const float *__restrict__ nodes, cons
         for (int c = 0; c < 3; ++c) {
             es[k][c] = j >= 0 ? pi0[c] - src[3 * j + c] : 0.f;
             et[k][c] = j >= 0 ? pit[c] - tgt[3 * j + c] : 0.f;
-            unchanged = unchanged && (es[k][c] == et[k][c]);
+            same_axis[c] = same_axis[c] && (es[k][c] == et[k][c]);
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) S[r][c] += es[k][r] * (w[k] * et[k][c]);  // source^T D target (:64)
     }
-    if (unchanged) {  // undeformed vertex: S = 0 so that R = I (:66-67)
+    if (same_axis[0] || same_axis[1] || same_axis[2]) {  // "undeformed" vertex: S = 0 so that R = I (:66-67)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll

@@ -185,12 +185,25 @@ def densify_clone(params: Dict[str, Tensor], moments: Optional[Moments], mask: T
     return new_p, new_m, n
 
 
-def split_children(position: Tensor, scaling_raw: Tensor, rotation_raw: Tensor, mask: Tensor, split_num: int = 2, seed: int = 0,
-                   unit_normals: Optional[Tensor] = None):
+def _need_seed(seed, unit_normals) -> int:
+    """The Philox counter is (Gaussian index, replica) only: the SAME seed draws the SAME unit normals for a Gaussian index at
+    every densification round, so the caller passes a seed that changes from round to round (e.g. base_seed + iteration; every
+    data-parallel rank the same one).  No default: a forgotten seed would correlate the children of successive rounds."""
+    if unit_normals is not None:
+        return 0 if seed is None else int(seed)
+    if seed is None:
+        raise ValueError("densify split: pass `seed` (a value that differs from one densification round to the next, identical "
+                         "on every rank, e.g. base_seed + iteration) or explicit `unit_normals`")
+    return int(seed)
+
+
+def split_children(position: Tensor, scaling_raw: Tensor, rotation_raw: Tensor, mask: Tensor, split_num: int = 2,
+                   seed: Optional[int] = None, unit_normals: Optional[Tensor] = None):
     """``new_pos_scale`` (atlas_gs_optimizer.py:255-287): positions [split_num * n, 3] and log-scales of the children of
     the selected Gaussians.  The normal draws come from a counter-based generator keyed by ``seed`` and addressed by
     (Gaussian id, replica): every data-parallel rank that passes the same seed gets the same children, with no generator
     state to keep in step.  ``unit_normals`` replaces the draws (parity tests)."""
+    seed = _need_seed(seed, unit_normals)
     mask_u8, index, n = _scan(mask)
     return _split_children(position, scaling_raw, rotation_raw, mask_u8, index, n, split_num, seed, unit_normals) + (n,)
 
@@ -211,13 +224,15 @@ def _split_children(position, scaling_raw, rotation_raw, mask_u8, index, n, spli
     return new_pos, new_scl
 
 
-def densify_split(params: Dict[str, Tensor], moments: Optional[Moments], mask: Tensor, split_num: int = 2, seed: int = 0,
-                  unit_normals: Optional[Tensor] = None, position: str = "position", scaling: str = "scaling",
-                  rotation: str = "rotation"):
+def densify_split(params: Dict[str, Tensor], moments: Optional[Moments], mask: Tensor, split_num: int = 2,
+                  seed: Optional[int] = None, unit_normals: Optional[Tensor] = None, position: str = "position",
+                  scaling: str = "scaling", rotation: str = "rotation"):
     """``densify_split`` of the reference (atlas_gs_optimizer.py:306-349): every selected Gaussian is replaced by
     ``split_num`` children (sampled positions, shrunk scales, every other attribute repeated, fresh Adam moments)
     appended at the end, then the parents are removed (parameters and moments compacted with one shared prefix sum).
+    ``seed``: required unless ``unit_normals`` is given -- see ``_need_seed``.
     -> (params, moments, valid_points_mask over the extended cloud [for prune_postprocess], number split)"""
+    seed = _need_seed(seed, unit_normals)
     mask_u8, index, n = _scan(mask)
     new_pos, new_scl = _split_children(params[position], params[scaling], params[rotation], mask_u8, index, n, split_num, seed,
                                        unit_normals)

@@ -87,6 +87,10 @@ class FrameBatch:
         self.radii_max = torch.zeros(P_, dtype=i32, device=dev)
         self.capacity = None
         self.keys = self.owner = self.idx_sorted = self.slot_sorted = self.pair_records = self.cull_flags = None
+        # one forward, one backward: every render* call overwrites the batch's buffers (sorted lists, packed records, final_T,
+        # ncontrib, cull flags ...) that its own backward reads.  `generation` counts the forwards; a backward whose forward
+        # is not the latest one raises instead of silently using another call's lists.
+        self.generation = 0
         if capacity is not None:
             self._reserve(int(capacity))
 
@@ -117,6 +121,18 @@ class FrameBatch:
         if self.capacity is not None and m > self.capacity:
             raise L.SplatError(f"FrameBatch: {m} tile-Gaussian pairs in one frame exceed the capacity {self.capacity}")
         return m
+
+    def _begin_forward(self) -> int:
+        self.generation += 1
+        return self.generation
+
+    def _check_generation(self, gen: int) -> None:
+        if gen != self.generation:
+            raise L.SplatError(
+                f"FrameBatch: backward of render call #{gen} after render call #{self.generation} on the same batch -- the later "
+                "forward has overwritten the buffers this backward reads (sorted lists, packed records, final_T, ncontrib).  "
+                "A FrameBatch holds ONE forward at a time: run the backward before the next render* (also under no_grad), or "
+                "use one FrameBatch per micro-batch.")
 
     def memory_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, Tensor))
@@ -297,9 +313,12 @@ class _RenderDynamic(torch.autograd.Function):
         rot_poly, rot_fourier = L.need(rot_poly, "rot_poly_feat"), L.need(rot_fourier, "rot_fourier_feat")
         if cubic.numel() != P * 4 * I * 3 or rot_poly.numel() != P * 16 or rot_fourier.numel() != P * 32 or opacity.numel() != P:
             raise ValueError("parameter shapes do not match the batch (P Gaussians, I spline segments)")
+        if position.shape[0] != P or rotation.shape[0] != P or scaling.shape[0] != P or feature.shape[0] != P:
+            raise ValueError(f"the batch was built for {P} Gaussians")
         extr_c = _extr12(extr)
         lib, st = L.lib(), L.stream()
         W, H, C = fb.W, fb.H, fb.C
+        ctx.gen = fb._begin_forward()
         opa_t = torch.empty(P, 1, dtype=torch.float32, device=fb.dev)
         L.check(lib.splat_frame_preprocess_forward_batch(
             L.ci(F), L.ci(P), L.ci(I), L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(layout), L.ptr(rotation), L.ptr(rot_poly),
@@ -320,6 +339,7 @@ class _RenderDynamic(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dL_dout):
         fb: FrameBatch = ctx.fb
+        fb._check_generation(ctx.gen)
         position, cubic, rotation, opacity, scaling, feature, rot_poly, rot_fourier, extr_c, tab = ctx.saved_tensors
         I, layout, bg = ctx.meta
         sink = ctx.sink or {}
@@ -360,9 +380,13 @@ class _RenderDynamicSets(torch.autograd.Function):
         rot_poly, rot_fourier = L.need(rot_poly, "rot_poly_feat"), L.need(rot_fourier, "rot_fourier_feat")
         if cubic.numel() != P * 4 * I * 3 or rot_poly.numel() != P * 16 or rot_fourier.numel() != P * 32 or opacity.numel() != P:
             raise ValueError("parameter shapes do not match the batch (P Gaussians, I spline segments)")
+        if position.shape[0] != P or rotation.shape[0] != P or scaling.shape[0] != P:
+            raise ValueError(f"the batch was built for {P} Gaussians")
+        _check_set_features(meta, feats, P)
         extr_c = _extr12(extr)
         lib, st = L.lib(), L.stream()
         W, H, C = fb.W, fb.H, fb.C
+        ctx.gen = fb._begin_forward()
         opa_t = torch.empty(P, 1, dtype=torch.float32, device=fb.dev)
         L.check(lib.splat_frame_preprocess_forward_batch(
             L.ci(F), L.ci(P), L.ci(I), L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(layout), L.ptr(rotation), L.ptr(rot_poly),
@@ -388,6 +412,7 @@ class _RenderDynamicSets(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         fb: FrameBatch = ctx.fb
+        fb._check_generation(ctx.gen)
         position, cubic, rotation, opacity, scaling, rot_poly, rot_fourier, extr_c, tab = ctx.saved_tensors[:9]
         feats = ctx.saved_tensors[9:]
         meta, sink = ctx.meta, (ctx.sink or {})
@@ -503,6 +528,17 @@ def _blend_sets_backward_one_pass(fb, meta, state, grads, opacity, op_fs, want_a
     return rec
 
 
+def _check_set_features(meta, feats, P):
+    """every shared feature tensor of the sets is [P, c] with the width its set declares (the kernels index rows 0 .. P-1)"""
+    it = iter(feats)
+    for w, _, _, _ in meta:
+        if w == "depth":
+            continue
+        t = next(it)
+        if t.dim() != 2 or t.shape[0] != P or t.shape[1] != w:
+            raise ValueError(f"a set's feature must be [P={P}, {w}], got {tuple(t.shape)}")
+
+
 def _set_groups(meta):
     """Routing group of every set: 0 = feeds the taps, 1 = live opacity without taps, 2 = opacity.detach()."""
     return [0 if taps else (2 if detach else 1) for (_, _, detach, taps) in meta]
@@ -540,11 +576,20 @@ class _RenderSets(torch.autograd.Function):
         opacity = L.need(opacity, "opacity")
         extr_c = _extr12(extr)
         P, F = fb.P, fb.F
+        if xyz.shape[0] != P or scales.shape[0] != P or uquats.shape[0] != P:
+            raise ValueError(f"the batch was built for {P} Gaussians")
+        if opacity.numel() != P:
+            # (the Gaussian-side backward sums the opacity gradient over the frames: a per-frame opacity [F,P,1] has no entry point)
+            raise ValueError(f"opacity must hold one value per Gaussian ({P}), shared by the frames; got {tuple(opacity.shape)}")
+        _check_set_features(meta, feats, P)
         off = L.need(offsets, "offsets") if offsets is not None else None
         if off is not None and tuple(off.shape) != (F, P, 3):
             raise ValueError(f"offsets must be [F={F}, P={P}, 3]")
+        if off is None and F > 1:
+            raise ValueError("several frames of static Gaussians need per-frame offsets")
+        ctx.gen = fb._begin_forward()
         fb._geometry(xyz, scales, uquats, off, extr_c, nearest, extent)
-        op_fs = 0 if opacity.numel() == P else P
+        op_fs = 0
         C = fb.C
         out, gs_idx, ctx.blend = _blend_sets_forward(fb, meta, feats, opacity, op_fs, K)
         ctx.fb, ctx.meta, ctx.sink, ctx.K = fb, meta, sink, K
@@ -563,6 +608,7 @@ class _RenderSets(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         fb: FrameBatch = ctx.fb
+        fb._check_generation(ctx.gen)
         xyz, scales, uquats, opacity, extr_c = ctx.saved_tensors[:5]
         feats = ctx.saved_tensors[5:]
         meta, sink = ctx.meta, (ctx.sink or {})
@@ -573,7 +619,7 @@ class _RenderSets(torch.autograd.Function):
         like = {"xyz": xyz, "scales": scales, "uquats": uquats, "opacity": opacity}
         bufs = {k: (sink[k] if k in sink else torch.zeros_like(v)) for k, v in like.items()}   # every set accumulates
         dfe = []
-        op_fs = 0 if opacity.numel() == P else P
+        op_fs = 0
         from .gs.raster_ops import _debug_T_front
         plan = ctx.blend["plan"]
         if plan is not None:
@@ -655,6 +701,7 @@ class _RenderFrames(torch.autograd.Function):
                 raise ValueError(f"offsets must be [F={F}, P={P}, 3]")
         elif F > 1:
             raise ValueError("several frames of static Gaussians need per-frame offsets")
+        ctx.gen = fb._begin_forward()
         out = fb._forward_onecall(xyz, scales, uquats, opacity, feature, off, extr_c, bg, nearest, extent)
         ctx.fb, ctx.bg, ctx.sink = fb, bg, sink
         ctx.save_for_backward(xyz, scales, uquats, opacity, feature, extr_c)
@@ -663,6 +710,7 @@ class _RenderFrames(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dL_dout):
         fb: FrameBatch = ctx.fb
+        fb._check_generation(ctx.gen)
         xyz, scales, uquats, opacity, feature, extr_c = ctx.saved_tensors
         g = L.need(dL_dout, "dL_dout")
         sink = ctx.sink or {}

@@ -18,30 +18,54 @@ from .parallel import FlatGradBucket
 MAX_SEGMENTS = 16
 
 
+def lr_segments(slices: Dict[str, tuple], lrs: Dict[str, float]):
+    """(segment ends, segment learning rates) of the flat buffer: neighbouring groups with equal rates share a segment (the
+    kernel looks a segment up per element).  Pure host logic."""
+    ends, seg_lr = [], []
+    for n, (_, e) in slices.items():
+        r = float(lrs[n])
+        if seg_lr and seg_lr[-1] == r:
+            ends[-1] = e
+        else:
+            ends.append(e); seg_lr.append(r)
+    if len(ends) > MAX_SEGMENTS:
+        raise ValueError(f"at most {MAX_SEGMENTS} learning-rate segments")
+    return ends, seg_lr
+
+
 class FlatAdam:
     def __init__(self, bucket: FlatGradBucket, lr: Union[float, Dict[str, float]], betas=(0.9, 0.999), eps: float = 1e-15):
         if not bucket.flat_param.is_cuda:
             raise ValueError("FlatAdam steps GPU buffers (there is no CPU path)")
         self.bucket = bucket
-        names = list(bucket.slices)
-        lrs = [float(lr[n]) if isinstance(lr, dict) else float(lr) for n in names]
-        # merge neighbouring groups with equal learning rates (the kernel looks a segment up per element)
-        ends, seg_lr = [], []
-        for n, r in zip(names, lrs):
-            e = bucket.slices[n][1]
-            if seg_lr and seg_lr[-1] == r:
-                ends[-1] = e
-            else:
-                ends.append(e); seg_lr.append(r)
-        if len(ends) > MAX_SEGMENTS:
-            raise ValueError(f"at most {MAX_SEGMENTS} learning-rate segments")
-        self.nseg = len(ends)
-        self.seg_end = (ctypes.c_int64 * self.nseg)(*ends)
-        self.seg_lr = (ctypes.c_float * self.nseg)(*seg_lr)
+        self.lr = {n: (float(lr[n]) if isinstance(lr, dict) else float(lr)) for n in bucket.slices}
+        self._build_segments()
         self.beta1, self.beta2, self.eps = float(betas[0]), float(betas[1]), float(eps)
         self.exp_avg = torch.zeros_like(bucket.flat_param)
         self.exp_avg_sq = torch.zeros_like(bucket.flat_param)
         self.t = 0
+
+    def _build_segments(self) -> None:
+        ends, seg_lr = lr_segments(self.bucket.slices, self.lr)
+        self.nseg = len(ends)
+        self.seg_end = (ctypes.c_int64 * self.nseg)(*ends)
+        self.seg_lr = (ctypes.c_float * self.nseg)(*seg_lr)
+
+    def set_lr(self, lr: Union[float, Dict[str, float]]) -> None:
+        """New learning rate(s) -- one number for every group or ``{group name: rate}`` for some of them -- from the next
+        ``step`` on; moments and step count are kept.  What the reference's scheduler does to the position group every
+        iteration (src/pointrix/optimizer/scheduler.py: the exponential position-lr decay): call it before each step.
+        Segments are re-derived, so groups whose rates diverge split and groups that meet merge again."""
+        if isinstance(lr, dict):
+            unknown = [n for n in lr if n not in self.lr]
+            if unknown:
+                raise KeyError(f"no parameter group(s) {unknown}; groups: {list(self.lr)}")
+            for n, r in lr.items():
+                self.lr[n] = float(r)
+        else:
+            for n in self.lr:
+                self.lr[n] = float(lr)
+        self._build_segments()
 
     def step(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0) -> None:
         """one Adam step with the bucket's active gradient buffer (or ``grad``), scaled by ``grad_scale`` first"""

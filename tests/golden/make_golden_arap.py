@@ -31,7 +31,7 @@ def main():
     gu.produce_edge_matrix_nfmt = lambda verts, shape, ii, jj, nn, device="cpu": _orig(verts, shape, ii, jj, nn, device="cpu")
 
     rng = np.random.default_rng(11)
-    Nv, K, Kc, Nt, SN = 2000, 10, 5, 3, 256
+    Nv, K, Kc, Nt, SN = 2000, 10, 5, 4, 256
     base = rng.uniform(-1, 1, size=(Nv, 3)).astype(np.float32)
     # connectivity as cal_connectivity_from_points builds it (K = 5 neighbours in a K = 10 edge matrix; some slots cut)
     d2 = ((base[:, None, :] - base[None, :, :]) ** 2).sum(-1)
@@ -50,7 +50,11 @@ def main():
     f1 = base @ rot(2, 0.4).T + 0.02 * rng.normal(size=(Nv, 3)).astype(np.float32)
     f1[:150] = base[:150]
     f2 = (base * np.array([1.0, 1.0, -1.0], np.float32)) @ rot(0, 1.1).T + 0.05 * rng.normal(size=(Nv, 3)).astype(np.float32)
-    nodes = np.stack([base, f1.astype(np.float32), f2.astype(np.float32)])
+    # frame 3: planar motion -- rotation about z, every z coordinate (hence every edge's z component) exactly unchanged: the
+    # reference's `(source_edge == target_edge).all(dim=1)` is true on that axis, so it zeroes S (R = I) for EVERY vertex
+    f3 = (base @ rot(2, 0.7).T).astype(np.float32)
+    f3[:, 2] = base[:, 2]
+    nodes = np.stack([base, f1.astype(np.float32), f2.astype(np.float32), f3])
     weight = rng.uniform(0.2, 1.0, size=(Nv, K)).astype(np.float32)
     out = dict(nodes=nodes, ii=ii.astype(np.int64), jj=jj.astype(np.int64), nn=nn.astype(np.int64), K=np.int32(K), weight=weight,
                sample_num=np.int32(SN))
@@ -67,8 +71,11 @@ def main():
             R1 = gu.estimate_rotation(x[0], x[1], T(ii), T(jj), T(nn), K=K,
                                       weight=(torch.zeros(Nv, K).index_put_((T(ii), T(nn)), torch.ones(len(ii))) if w is None else T(w))[sample_idx],
                                       sample_idx=T(sample_idx))
+            R3 = gu.estimate_rotation(x[0], x[3], T(ii), T(jj), T(nn), K=K,
+                                      weight=(torch.zeros(Nv, K).index_put_((T(ii), T(nn)), torch.ones(len(ii))) if w is None else T(w))[sample_idx],
+                                      sample_idx=T(sample_idx))
         out.update({f"{tag}_sample_idx": sample_idx.astype(np.int64), f"{tag}_error": np.float32(err.item()),
-                    f"{tag}_grad": x.grad.numpy(), f"{tag}_rot1": R1.numpy()})
+                    f"{tag}_grad": x.grad.numpy(), f"{tag}_rot1": R1.numpy(), f"{tag}_rot3": R3.numpy()})
         print(tag, float(err), float(x.grad.abs().max()))
     np.savez_compressed(os.path.join(HERE, "arap_2000.npz"), **out)
 

@@ -33,6 +33,9 @@ def test_arap_matches_reference(tag):
     wt = w if w is not None else (nbr >= 0).float()
     rot = arap_rotations(x, nbr, wt, sidx)
     np.testing.assert_allclose(rot[0].cpu().numpy(), g[f"{tag}_rot1"], rtol=0, atol=5e-5)
+    # frame 3 moves in the xy plane only (z edges exactly unchanged): the reference zeroes S there -> R = I for every vertex
+    np.testing.assert_allclose(rot[2].cpu().numpy(), g[f"{tag}_rot3"], rtol=0, atol=5e-5)
+    assert np.abs(g[f"{tag}_rot3"] - np.eye(3)).max() < 1e-6
     assert float(torch.linalg.det(rot.double()).min()) > 0.99
 
 

@@ -28,7 +28,7 @@ def _run(frames, steps=2):
     from splatter_a_video_amd.synth import make_scene
     sc = make_scene(N, W, H, F=12, seed=77)
     R = bench.FrameRenderer(sc, torch.device("cuda:0"), frames, mode="batch")
-    R.opt.seg_lr[0] = 1e-3          # a visible update: step 2's forward must see step 1's parameters
+    R.opt.set_lr(1e-3)              # a visible update: step 2's forward must see step 1's parameters
     grads = []
     for _ in range(steps):
         R.step()

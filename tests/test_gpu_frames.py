@@ -406,3 +406,51 @@ def test_dynamic_sets_batch_equals_per_frame_three_blends():
     for name, a, b in (("tap", B.tap, ref_tap), ("abs_tap", B.abs_tap, ref_atap)):
         bad = (a - b).abs() > 1e-3 * b.abs() + 1e-5 * float(b.abs().max())
         assert int(bad.sum()) <= 4, (name, int(bad.sum()), float((a - b).abs().max()))
+
+
+def test_one_forward_one_backward_contract_is_enforced():
+    """a second render* on the same FrameBatch overwrites the buffers the first call's backward reads: that backward raises
+    instead of returning gradients of the wrong lists (gradient accumulation over micro-batches, a no_grad eval render in
+    between); sequential forward -> backward pairs stay legal"""
+    N, W, H, F, C = 3000, 96, 64, 2, 3
+    sc = make_scene(N, W, H, seed=6)
+    off = _t(_offsets(sc, F))
+    p = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity,
+                                         feature=np.ones((N, C), np.float32)).items()}
+    B = FrameBatch(F, N, W, H, C, "cuda")
+    args = (p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], off, _t(sc.extr))
+    first = B.render(*args)
+    with torch.no_grad():
+        B.render(*args)                       # e.g. an evaluation render between forward and backward
+    with pytest.raises(SplatError, match="ONE forward at a time"):
+        first.sum().backward()
+    a = B.render(*args)
+    b = B.render(*args)                       # two micro-batches, backward afterwards: the first graph is stale
+    b.sum().backward()
+    with pytest.raises(SplatError):
+        a.sum().backward()
+    B.render(*args).sum().backward()          # the normal sequence still works
+    sets = [dict(feature=p["feature"], taps=True)]
+    s1 = B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], sets, off, _t(sc.extr))
+    B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], sets, off, _t(sc.extr))
+    with pytest.raises(SplatError):
+        s1[0].sum().backward()
+
+
+def test_render_sets_validates_shapes():
+    N, W, H, F = 2000, 64, 48, 2
+    sc = make_scene(N, W, H, seed=8)
+    off, extr = _t(_offsets(sc, F)), _t(sc.extr)
+    p = {k: _t(v) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity).items()}
+    rgb = _t(np.ones((N, 3), np.float32))
+    B = FrameBatch(F, N, W, H, 3, "cuda")
+    ok = [dict(feature=rgb, taps=True)]
+    B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], ok, off, extr)
+    with pytest.raises(ValueError):           # a parameter with the wrong number of rows
+        B.render_sets(p["xyz"][:-1], p["scales"], p["uquats"], p["opacity"], ok, off, extr)
+    with pytest.raises(ValueError):
+        B.render_sets(p["xyz"], p["scales"][:-1], p["uquats"], p["opacity"], ok, off, extr)
+    with pytest.raises(ValueError):           # per-frame opacity has no entry point in the Gaussian-side backward
+        B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"].unsqueeze(0).repeat(F, 1, 1), ok, off, extr)
+    with pytest.raises(ValueError):           # a set's feature rows
+        B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], [dict(feature=rgb[:-1], taps=True)], off, extr)

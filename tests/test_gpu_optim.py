@@ -46,3 +46,33 @@ def test_flat_adam_grad_scale_and_validation():
         o1.step(grad=torch.zeros(3, device="cuda"))
     with pytest.raises(ValueError):
         FlatAdam(FlatGradBucket({"a": torch.ones(4)}), 1e-3)
+
+
+def test_flat_adam_follows_a_learning_rate_schedule():
+    """set_lr before every step = the reference's scheduler on the position group (src/pointrix/optimizer/scheduler.py):
+    moments and step count survive, groups whose rates diverge split, groups that meet again merge"""
+    g = torch.Generator(device="cpu").manual_seed(1)
+    sizes = {"position": (5001, 3), "scaling": (5001, 3), "opacity": (5001, 1)}
+    init = {n: torch.randn(*s, generator=g) for n, s in sizes.items()}
+    bucket = FlatGradBucket({n: t.cuda() for n, t in init.items()})
+    opt = FlatAdam(bucket, 1e-3, eps=1e-15)                 # one segment to start with
+    assert opt.nseg == 1
+    ref_p = {n: init[n].clone().cuda().requires_grad_(True) for n in sizes}
+    ref = torch.optim.Adam([{"params": [p], "lr": 1e-3, "name": n} for n, p in ref_p.items()], lr=0.0, eps=1e-15)
+    for step in range(6):
+        lr_pos = 1e-3 * (0.5 ** step) if step < 4 else 1e-3   # decays, then meets the other groups again
+        opt.set_lr({"position": lr_pos})
+        for grp in ref.param_groups:
+            if grp["name"] == "position":
+                grp["lr"] = lr_pos
+        assert opt.nseg == (1 if lr_pos == 1e-3 else 2)
+        for n, p in ref_p.items():
+            gr = torch.randn(*sizes[n], generator=g)
+            p.grad = gr.cuda()
+            bucket.grad(n).copy_(gr.cuda())
+        ref.step()
+        opt.step()
+        for n, p in ref_p.items():
+            torch.testing.assert_close(bucket.params[n].detach(), p.detach(), rtol=2e-5, atol=1e-7)
+    with pytest.raises(KeyError):
+        opt.set_lr({"nope": 1.0})

@@ -238,3 +238,26 @@ def test_two_ranks_take_identical_densification_decisions(tmp_path):
         assert (a[k] != r).sum() <= 1
     assert ref[0].sum() > 5 and ref[1].sum() > 0
     assert any((u != r).sum() > 5 for u, r in zip(unreduced, ref))     # without the reduction the ranks would diverge
+
+
+def test_lr_segments_merge_and_split():
+    """host logic of FlatAdam's per-segment learning rates (optim.lr_segments)"""
+    from splatter_a_video_amd.optim import MAX_SEGMENTS, lr_segments
+    sl = {"a": (0, 10), "b": (10, 25), "c": (25, 26), "d": (26, 100)}
+    assert lr_segments(sl, dict(a=1e-3, b=1e-3, c=1e-3, d=1e-3)) == ([100], [1e-3])
+    assert lr_segments(sl, dict(a=1e-3, b=2e-3, c=2e-3, d=1e-3)) == ([10, 26, 100], [1e-3, 2e-3, 1e-3])
+    many = {f"p{i}": (i, i + 1) for i in range(MAX_SEGMENTS + 1)}
+    with pytest.raises(ValueError):
+        lr_segments(many, {k: float(i) for i, k in enumerate(many)})
+
+
+def test_split_needs_a_round_dependent_seed():
+    """densify.split_children / densify_split refuse to draw without a seed (the Philox counter is (Gaussian, replica) only:
+    a constant seed would repeat the same normals at every densification round)"""
+    import torch
+    from splatter_a_video_amd import densify as D
+    z = torch.zeros(4, 3)
+    with pytest.raises(ValueError, match="seed"):
+        D.split_children(z, z, torch.zeros(4, 4), torch.ones(4, dtype=torch.bool))
+    with pytest.raises(ValueError, match="seed"):
+        D.densify_split({"position": z, "scaling": z, "rotation": torch.zeros(4, 4)}, None, torch.ones(4, dtype=torch.bool))
