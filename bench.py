@@ -477,6 +477,23 @@ def kernel_bytes(name, N, M, HW, C, T, use_sh, fpl=1.0, sets=False):
     return shared.get(name, 0) + fpl * per_frame.get(name, 0)
 
 
+def compute_rates(stats, kernels):
+    """pixel-Gaussian evaluations: list entries the pixels walk up to their last contributor (sum of ncontrib; the reference's
+    loops visit at least these) at the reference's arithmetic per visit -- 16 flops forward (alpha_blending.cu:78-100: dx dy
+    power exp alpha T), 14 flops recompute backward (:196-203) -- as a LOWER bound of the useful work (contributing visits add
+    2C resp. ~32 + 7C more); FP32 vector / matrix peak 157.3 TFLOP/s"""
+    ev = stats["walked_entries_per_frame"]
+    comp = {"evaluations_per_frame": ev, "peak_TFLOPs": 157.3, "unit": "TFLOP/s",
+            "definition": "sum over pixels of ncontrib (list entries walked up to the last contributor) x 16 flops "
+                          "(forward) / 14 flops (backward recompute): lower bound of the useful arithmetic"}
+    for kn, fl in (("blend_fwd", 16.0), ("blend_bwd", 14.0)):
+        if kn in kernels and kernels[kn]["us_per_frame"] > 0:
+            rate = ev / (kernels[kn]["us_per_frame"] * 1e-6)
+            comp[kn] = {"G_evaluations_per_s": round(rate / 1e9, 2), "TFLOPs_lower_bound": round(rate * fl / 1e12, 3),
+                        "frac_of_fp32_peak": round(rate * fl / 157.3e12, 4)}
+    return comp
+
+
 def cpu_baseline_torch(sc, C_extra, budget_s=12.0):
     """the PyTorch-eager restatement of the reference's semantics (oracle/torch_eager.py), float32,
     one frame forward+backward.  configs[0] (10k Gaussians, 256x256): median of 5 runs after one warm-up.  The bench's
@@ -634,20 +651,8 @@ def main():
                       optimizer=not a.no_optimizer)
     dt = timed(R.step, R.finish)
     R.check_sorts()   # the sync-free sorts of the timed steps all fitted their capacity (raises otherwise)
-    # forward only (the north star's render target: >= 149 frames/s at 480p / 300k), timed the same way
-    forward_only = None
-    if mode in ("batch", "render_iter"):
-        dtf = timed(R.forward_only)
-        R.check_sorts()
-        forward_only = {"value": round(a.frames * a.steps * world / dtf, 2), "unit": "frames/s",
-                        "ms_per_frame": round(dtf / (a.frames * a.steps) * 1e3, 4),
-                        "what": "forward pass alone (SH -> preprocess -> binning -> sort -> compositing), same frames, timed like `value`"}
-    stats = R.scene_stats() if rank == 0 else None
-
     frames_total = a.frames * a.steps * world
     fps = frames_total / dt
-    if stats is not None and mode in ("batch", "render_iter"):
-        stats["scene"] = a.scene
     M, T = R.last["M"], R.last["T"]
     HW = a.width * a.height
     tag_cfg = f"{a.gaussians}x{a.width}x{a.height}x{a.channels}:{mode}" + ("" if a.no_spatial_order else ":morton")
@@ -694,26 +699,26 @@ def main():
                         "issue": pmc_issue(dom, tag_cfg),
                         "avg_us": kernels[dom]["avg_us"], "frames_per_launch": kernels[dom]["frames_per_launch"],
                         "alg_bytes_per_launch": int(kernels[dom]["alg_MB_per_launch"] * 1e6)}
-            if stats is not None:
-                # pixel-Gaussian evaluations: list entries the pixels walk up to their last contributor (sum of ncontrib; the
-                # reference's loops visit at least these) at the reference's arithmetic per visit -- 16 flops forward
-                # (alpha_blending.cu:78-100: dx dy power exp alpha T), 14 flops recompute backward (:196-203) -- as a LOWER
-                # bound of the useful work (contributing visits add 2C resp. ~32 + 7C more); FP32 vector / matrix peak 157.3 TF
-                ev = stats["walked_entries_per_frame"]
-                comp = {"evaluations_per_frame": ev, "peak_TFLOPs": 157.3, "unit": "TFLOP/s",
-                        "definition": "sum over pixels of ncontrib (list entries walked up to the last contributor) x 16 flops "
-                                      "(forward) / 14 flops (backward recompute): lower bound of the useful arithmetic"}
-                for kn, fl in (("blend_fwd", 16.0), ("blend_bwd", 14.0)):
-                    if kn in kernels and kernels[kn]["us_per_frame"] > 0:
-                        rate = ev / (kernels[kn]["us_per_frame"] * 1e-6)
-                        comp[kn] = {"G_evaluations_per_s": round(rate / 1e9, 2), "TFLOPs_lower_bound": round(rate * fl / 1e12, 3),
-                                    "frac_of_fp32_peak": round(rate * fl / 157.3e12, 4)}
-                roofline["compute"] = comp
             is_bwd = lambda k: k.endswith("_bwd") or k == "pair_reduce"
             fwd_ms = sum(kernels[k]["us_per_frame"] for k in kernels if not is_bwd(k) and k != "adam_step") / 1e3
             bwd_ms = sum(kernels[k]["us_per_frame"] for k in kernels if is_bwd(k)) / 1e3
             opt_ms = kernels.get("adam_step", {}).get("us_per_frame", 0.0) / 1e3
         L.profile_reset()
+
+    # forward only (the north star's render target: >= 149 frames/s at 480p / 300k), timed the same way
+    forward_only = None
+    if mode in ("batch", "render_iter"):
+        dtf = timed(R.forward_only)
+        R.check_sorts()
+        forward_only = {"value": round(a.frames * a.steps * world / dtf, 2), "unit": "frames/s",
+                        "ms_per_frame": round(dtf / (a.frames * a.steps) * 1e3, 4),
+                        "what": "forward pass alone (SH -> preprocess -> binning -> sort -> compositing), same frames, timed like `value`"}
+    stats = R.scene_stats() if rank == 0 else None
+
+    if stats is not None:
+        stats["scene"] = a.scene
+    if roofline is not None and stats is not None:
+        roofline["compute"] = compute_rates(stats, kernels)
 
     # second workload of the line (N = 1, default configuration only): the reference's REAL training frame -- its dynamic
     # Gaussians (time-varying position and rotation) through render_iter's three blends (rgb enhanced K = 20 + depth + 19

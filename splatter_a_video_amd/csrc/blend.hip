@@ -65,6 +65,18 @@
 #ifndef BLEND_WIDE_HOIST
 #define BLEND_WIDE_HOIST 1
 #endif
+#ifndef BLEND_ABL
+#define BLEND_ABL 0        // ablation of the matrix-core backward for timing experiments (1: no combine, 2: no chunks); results invalid
+#endif
+#ifndef BLEND_SLOT_EARLY
+#define BLEND_SLOT_EARLY 0 // matrix-core backward: load the combine's pair slots at the top of the super-batch (1) or behind the chunks (0)
+#endif
+#ifndef BLEND_REC_SWZ
+#define BLEND_REC_SWZ 1    // strip-walk backward kernels: XOR swizzle of the staged records' 16-byte parts (bank conflicts)
+#endif
+#ifndef BLEND_STATE_SKEW
+#define BLEND_STATE_SKEW 1 // strip-walk backward kernels: per-pixel replay state rows skewed by lane group (bank conflicts)
+#endif
 // power is a negative-semidefinite form: it can only exceed 0 by rounding.  The matrix-core kernels evaluate it as
 // an expanded polynomial (absolute error up to ~5e-6 in log2 units), so their "power > 0" guard of the reference
 // (src/alpha_blending.cu:93) sits just above that noise; it still rejects genuinely indefinite conics.
@@ -371,15 +383,25 @@ pack_kernel(const BlendArgs B) {
 // COEF: the staging threads also leave the exponent's polynomial [q0 qx qy qxx | qxy qyy o id] of every entry (tile-centred,
 // power_coeffs) for the lane = pixel kernels; slot SB is the inert entry (opacity 0).
 // XR: extra record rows behind the inert one (rows SB + 1 + 15 w + j: wave w's carried survivors, see CarryLDS)
-template <int CH, int SB, bool COEF = false, int XR = 0>
+// SWZ: part p (16 bytes) of entry e's record sits at part (p & ~3) | ((p & 3) ^ ((e >> 2) & 3)).  A record is 16 or 48
+// dwords, so part p of every entry starts on one of FOUR bank quads (e mod 4): the matrix-core kernels' lanes read part 0 / 1
+// of 16 different survivors at once (ds_read_b128, 64 banks: 4-way conflict) and a K-slice of the features (ds_read_b32,
+// 32 banks: 8-way).  With the swizzle 16 consecutive entries hit 16 different quads.
+template <int CH, int SB, bool COEF = false, int XR = 0, bool SWZ = false>
 struct TileLDS {
     static constexpr int RQ = Rec<CH>::RQ;
+    static constexpr bool SWIZZLED = SWZ;
     float4 rec[(SB + 1 + XR) * RQ];
     float4 coef[COEF ? 2 * (SB + 1) : 1];
     unsigned int keep[SB];  // byte w of entry e: wave w's 8x8 block can be reached by the splat (and passes its predicate)
     unsigned short list[4][SB + 16 + XR / 4];
-    __device__ __forceinline__ const float4 &g0(int e) const { return rec[e * RQ]; }      // u v A B
-    __device__ __forceinline__ const float4 &g1(int e) const { return rec[e * RQ + 1]; }  // C o bias id
+    static __device__ __forceinline__ int part(int e, int p) {  // float4 index of part p of entry e
+        return SWZ ? e * RQ + ((p & ~3) | ((p & 3) ^ ((e >> 2) & 3))) : e * RQ + p;
+    }
+    __device__ __forceinline__ const float4 &g0(int e) const { return rec[part(e, 0)]; }  // u v A B
+    __device__ __forceinline__ const float4 &g1(int e) const { return rec[part(e, 1)]; }  // C o bias id
+    // float k of entry e's record (k need not be a constant)
+    __device__ __forceinline__ float f(int e, int k) const { return reinterpret_cast<const float *>(&rec[part(e, k >> 2)])[k & 3]; }
 };
 
 template <int CH, int SB, bool COEF, int XR>
@@ -425,12 +447,12 @@ struct Stager {
                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    template <bool COEF, int XR>
-    __device__ __forceinline__ void park(TileLDS<CH, SB, COEF, XR> &L, int tid) const {
+    template <bool COEF, int XR, bool SWZ>
+    __device__ __forceinline__ void park(TileLDS<CH, SB, COEF, XR, SWZ> &L, int tid) const {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = tid + 256 * k;
-            if (c < NCHUNK) L.rec[c] = v[k];
+            if (c < NCHUNK) L.rec[SWZ ? L.part(c / RQ, c % RQ) : c] = v[k];
         }
     }
 };
@@ -441,8 +463,8 @@ struct Stager {
 // SUB: the flag byte of a kept block carries one bit per 4x4 quarter (bit sx + 2 sy) from a bounding-box test of the
 // quarter's pixel centres, for kernels that keep a survivor list per quarter; otherwise the byte is 0 / 1.
 // gflags: optional global copy of the staged entries' keep words (BlendArgs::cull_flags + the super-batch's first position).
-template <int CH, int SB, bool BIAS, bool SUB, bool COEF, int XR, typename Pred>
-__device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR> &L, int tid, int nb, float tx0, float ty0, Pred pred,
+template <int CH, int SB, bool BIAS, bool SUB, bool COEF, int XR, bool SWZ, typename Pred>
+__device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ> &L, int tid, int nb, float tx0, float ty0, Pred pred,
                                           unsigned int *gflags = nullptr) {
     constexpr int TPE = 256 / SB;  // threads per entry (1, 2 or 4): each tests 4 / TPE of the blocks
     constexpr int BPT = 4 / TPE;
@@ -466,8 +488,7 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR> &L, int tid,
             CullP cp;
             if (Rec<CH>::CULL >= 0) {
                 constexpr int CO = Rec<CH>::CULL >= 0 ? Rec<CH>::CULL : 0;
-                const float *r = reinterpret_cast<const float *>(&L.rec[e * Rec<CH>::RQ]);
-                cp.hx = r[CO]; cp.hy = r[CO + 1]; cp.tauq = r[CO + 2]; cp.ia = r[CO + 3]; cp.ic = r[CO + 4];
+                cp.hx = L.f(e, CO); cp.hy = L.f(e, CO + 1); cp.tauq = L.f(e, CO + 2); cp.ia = L.f(e, CO + 3); cp.ic = L.f(e, CO + 4);
             } else {
                 cp = cull_params(a0.z, a0.w, a1.x, a1.y);
             }
@@ -503,8 +524,8 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR> &L, int tid,
 }
 
 // wave w's order-preserving survivor list from the flag bytes; returns the count.
-template <int CH, int SB, bool COEF, int XR>
-__device__ __forceinline__ int build_list(TileLDS<CH, SB, COEF, XR> &L, int w, int lane) {
+template <int CH, int SB, bool COEF, int XR, bool SWZ>
+__device__ __forceinline__ int build_list(TileLDS<CH, SB, COEF, XR, SWZ> &L, int w, int lane) {
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < SB / WAVE; ++r) {
@@ -523,8 +544,8 @@ __device__ __forceinline__ int build_list(TileLDS<CH, SB, COEF, XR> &L, int w, i
 
 // The forward's cull decisions instead of a second cull (BlendArgs::cull_flags): thread e turns the entry's flag byte into
 // the keep word tile_cull would have produced (byte w != 0: wave w replays the entry), with the same predicate.
-template <int CH, int SB, bool COEF, int XR, typename Pred>
-__device__ __forceinline__ void keep_from_flags(TileLDS<CH, SB, COEF, XR> &L, int tid, int nb, unsigned flags, Pred pred) {
+template <int CH, int SB, bool COEF, int XR, bool SWZ, typename Pred>
+__device__ __forceinline__ void keep_from_flags(TileLDS<CH, SB, COEF, XR, SWZ> &L, int tid, int nb, unsigned flags, Pred pred) {
     if (tid < SB) {
         unsigned kw = 0u;
         if (tid < nb) {
@@ -544,17 +565,18 @@ __device__ __forceinline__ void keep_from_flags(TileLDS<CH, SB, COEF, XR> &L, in
 // (CAP rows per wave; a longer list takes another round of chunks + combine); an entry's record is stored by the combine
 // of its own super-batch without the waves that carried it, and those add their part one super-batch later with float
 // atomics (<= 15 records per wave and super-batch).
-template <int SB>
+template <int SB, bool POS = true>
 struct CarryLDS {
     static constexpr int CQ = 15;
-    unsigned int pos4[SB];     // byte w: list position of entry e in wave w's list; 255 = not replayed by that wave now
+    // POS (slab rows by list position): byte w = list position of entry e in wave w's list; 255 = not replayed by that wave now
+    unsigned int pos4[POS ? SB : 1];
     int cslot[4][16];          // pair slot of the carried survivors
     int more[4];               // wave w has chunks left for another round
 };
 
 // build_list behind `base` carried survivors: positions base .. base + cnt - 1, and the entries' positions
-template <int CH, int SB, bool COEF, int XR>
-__device__ __forceinline__ int build_list_at(TileLDS<CH, SB, COEF, XR> &L, CarryLDS<SB> &C, int w, int lane, int base) {
+template <int CH, int SB, bool COEF, int XR, bool SWZ, bool POS>
+__device__ __forceinline__ int build_list_at(TileLDS<CH, SB, COEF, XR, SWZ> &L, CarryLDS<SB, POS> &C, int w, int lane, int base) {
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < SB / WAVE; ++r) {
@@ -563,7 +585,7 @@ __device__ __forceinline__ int build_list_at(TileLDS<CH, SB, COEF, XR> &L, Carry
         const unsigned long long m = __ballot(keep);
         const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         if (keep) L.list[w][base + cnt + before] = (unsigned short)e;
-        reinterpret_cast<unsigned char *>(C.pos4)[4 * e + w] = keep ? (unsigned char)(base + cnt + before) : (unsigned char)255;
+        if (POS) reinterpret_cast<unsigned char *>(C.pos4)[4 * e + w] = keep ? (unsigned char)(base + cnt + before) : (unsigned char)255;
         cnt += __popcll(m);
     }
     if (lane < 16) L.list[w][base + cnt + lane] = (unsigned short)SB;
@@ -576,22 +598,22 @@ __device__ __forceinline__ int build_list_at(TileLDS<CH, SB, COEF, XR> &L, Carry
 // become its carry rows j0 .. j0 + left - 1: payload (the RQC leading chunks: geometry + features; chunk 1's w = the list
 // position in the tile, which the replay's `q < ncontrib` test needs), pair slot, list head; their position bytes become
 // 255 so that the combine leaves this wave out.
-template <int CH, int SB, bool COEF, int XR>
-__device__ __forceinline__ void carry_out(TileLDS<CH, SB, COEF, XR> &L, CarryLDS<SB> &C, int w, int lane, int first, int left,
+template <int CH, int SB, bool COEF, int XR, bool SWZ, bool POS>
+__device__ __forceinline__ void carry_out(TileLDS<CH, SB, COEF, XR, SWZ> &L, CarryLDS<SB, POS> &C, int w, int lane, int first, int left,
                                           int j0, int top, const int *slots) {
-    constexpr int RQ = Rec<CH>::RQ, RQC = 2 + (CH + 3) / 4, CQ = CarryLDS<SB>::CQ;
+    constexpr int RQC = 2 + (CH + 3) / 4, CQ = CarryLDS<SB>::CQ;
     for (int idx = lane; idx < left * RQC; idx += WAVE) {
         const int k = idx / RQC, part = idx - k * RQC;
         const int e = L.list[w][first + k];
-        float4 v = L.rec[e * RQ + part];
+        float4 v = L.rec[L.part(e, part)];
         if (part == 1) v.w = __int_as_float(top - e);
-        L.rec[(SB + 1 + CQ * w + j0 + k) * RQ + part] = v;
+        L.rec[L.part(SB + 1 + CQ * w + j0 + k, part)] = v;
     }
     int e = 0;
     if (lane < left) {
         e = L.list[w][first + lane];
         C.cslot[w][j0 + lane] = slots[top - e];
-        reinterpret_cast<unsigned char *>(C.pos4)[4 * e + w] = (unsigned char)255;
+        if (POS) reinterpret_cast<unsigned char *>(C.pos4)[4 * e + w] = (unsigned char)255;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // (the list reads above are done before the head of the list is rewritten)
@@ -1145,6 +1167,8 @@ struct MfmaCfg {
     // slab each -- at 32 channels that is 10 KB instead of 39 KB of LDS, two workgroups per CU instead of one (828 ->
     // 748 us at BASELINE configs[4]); at 16 / 20 channels the atomics cost more than the third workgroup gains
     // (19-channel blend 750 -> 805 us), so those keep the private slabs
+    // (narrow records as well -- 5 KB of LDS less, one row per entry in the combine -- was tried in round 3: ds_add_f32 costs
+    // about 16 cycles per instruction of 16 lanes, 159 -> 184 us per frame at BASELINE configs[1])
     static constexpr bool SHARED = CH > 20;
     static constexpr int NSLAB = SHARED ? 1 : 4;
 };
@@ -1213,20 +1237,31 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     constexpr int PZ = Cfg::PZ, PS = Cfg::PS;
     constexpr int I_ABS = GradLayout<ABS, false>::I_ABS;
     constexpr bool SHARED = Cfg::SHARED;
-    // survivors that do not fill a chunk are carried into the next super-batch (CarryLDS); slab rows by list position
-    constexpr bool CARRY = BLEND_CARRY && !SHARED;
+    // survivors that do not fill a chunk are carried into the next super-batch (CarryLDS)
+    constexpr bool CARRY = BLEND_CARRY && CH <= 20;
     constexpr int CQ = CarryLDS<SB>::CQ, XR = CARRY ? 4 * CQ : 0;
-    constexpr int CAP = !CARRY ? SB : ((SB == 128 && NC <= 9) ? 80 : 64);  // slab rows per wave (whole chunks)
-    __shared__ TileLDS<CH, SB, false, XR> L;
-    __shared__ CarryLDS<SB> CL;
+    // private slabs (16 / 20 channels): rows by list position, CAP per wave (whole chunks; a longer list takes another round);
+    // shared slab: one row per staged entry + one per carry row, no limit
+    constexpr int CAP = SHARED ? (1 << 20) : (!CARRY ? SB : ((SB == 128 && NC <= 9) ? 80 : 64));
+    // the combine gives TPR threads to a record, three floats each (one 12-byte store per thread); shared slab: rows of NCS floats
+    constexpr int TPR = (NC + 2) / 3, NCS = SHARED ? 3 * TPR : NC;
+    constexpr int SROWS = SHARED ? SB + XR : CAP + (CARRY ? 1 : 0);
+    __shared__ TileLDS<CH, SB, false, XR, BLEND_REC_SWZ != 0> L;
+    __shared__ CarryLDS<SB, !SHARED> CL;
     // narrow feature rows: dL_dfeature = sum_p g[p,c] w[p,n] as per-lane FMAs over the lane's own pixels + one cross-row sum
     // per chunk, instead of four MFMAs per strip whose A operand would use 3 of its 16 rows (the matrix pipe's time is on
     // this kernel's critical path: dropping those products saved 13 % of it, the VALU form gives back a third)
     constexpr bool FEAT_VALU = CH <= 4;
-    // private slab per wave, or one shared slab (wide records); CARRY: row CAP stays zero (what the combine reads for a
-    // wave that has nothing for an entry)
-    __shared__ float s_acc[Cfg::NSLAB][(CAP + (CARRY ? 1 : 0)) * NC];
-    __shared__ __attribute__((aligned(16))) float s_pix[4][64 * PW];
+    // one shared slab (LDS float atomics; rows are cleared by whoever reads them out), or a private slab per wave whose
+    // row CAP stays zero (what the combine reads for a wave that has nothing for an entry)
+    __shared__ float s_acc[Cfg::NSLAB][SROWS * NCS];
+    // per-pixel rows [g[CH] 0.. | T_final*bg.g, ncontrib, T_state, R_state]: pixel q = 16 G + 4 kk + i of the wave's block at
+    // float G * GS + kk * KS + i * PW.  The four lane groups kk of a wave read / write the rows of their own pixels in one
+    // instruction; with dense rows (KS = 4 PW, a multiple of 32 dwords) all four hit the same banks (ds_write2_b32 from
+    // lanes 15 / 31 / 47 / 63: 4-way) -- 8 floats of skew per group spread them
+    constexpr int KS = 4 * PW + (BLEND_STATE_SKEW ? 8 : 0), GS = 4 * KS;
+    __shared__ __attribute__((aligned(16))) float s_pix[4][4 * GS];
+    auto pixoff = [](int q) { return (q >> 4) * GS + ((q >> 2) & 3) * KS + (q & 3) * PW; };
     __shared__ float s_mom[16 * 64];         // A operand of the moment product: [step 4 G + i][lane]
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1274,7 +1309,7 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         const size_t pix = (size_t)A.W * (size_t)py + px;
         const float Tf = inside ? A.final_T[pix] : 0.f;
         const int last = inside ? A.ncontrib[pix] : 0;
-        float *r = s_pix[w] + lane * PW;
+        float *r = s_pix[w] + pixoff(lane);
         float bgdot = 0.f;
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
@@ -1292,28 +1327,45 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         if (lane == 0) s_wmax[w] = wmax;
     }
     if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
-    if (CARRY && lane < NC) s_acc[w][CAP * NC + lane] = 0.f;                                 // the slab's zero row
+    if (SHARED) {
+        for (int i = tid; i < SROWS * NCS; i += 256) s_acc[0][i] = 0.f;
+    } else if (CARRY && lane < NC) {
+        s_acc[w][CAP * NC + lane] = 0.f;                                                     // the slab's zero row
+    }
     __syncthreads();
     const int2 range = A.tile_range[tile];
     const int len = range.y - range.x;
     const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
     const int *slots = A.slot_sorted + range.x;
-    constexpr int EPI = 256 / NC;                   // pair records the 256 threads write per pass, NC floats each
-    const int ce = tid / NC, cc = tid - ce * NC;    // this thread's (entry within the pass, component)
+    // combine: thread (ce, cc) of a pass writes floats [CW cc, CW cc + CW) of entry ce's record
+    constexpr int CW = 3, TPE = TPR;
+    constexpr int EPI = 256 / TPE;                  // pair records the 256 threads write per pass
+    constexpr int NPASS = (SB + EPI - 1) / EPI;
+    const int ce = tid / TPE, cc = tid - ce * TPE;  // this thread's (entry within the pass, part of the record)
+    auto store_part = [&](int slot, float v0, float v1, float v2) {
+        float *dst = pair_buf + (size_t)slot * NCP + CW * cc;
+        if (CW * cc + 2 < NCP) {
+            F3 t; t.x = v0; t.y = v1; t.z = v2;
+            *reinterpret_cast<F3 *>(dst) = t;       // (floats NC .. NCP - 1 of a record are padding: whatever lands there is ignored)
+        } else {
+            if (CW * cc < NCP) dst[0] = v0;
+            if (CW * cc + 1 < NCP) dst[1] = v1;
+        }
+    };
     if (ce < EPI)
         for (int ql = n + ce; ql < len; ql += EPI)  // entries nobody replays: zero record
-            pair_buf[(size_t)slots[ql] * NCP + cc] = 0.f;
+            store_part(slots[ql], 0.f, 0.f, 0.f);
     if (n <= 0) {
         if (A.dbg_T_front) {
             const int px = bx + (lane & 7), py = by + (lane >> 3);
-            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_pix[w][lane * PW + PS + 2];
+            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_pix[w][pixoff(lane) + PS + 2];
         }
         return;
     }
 
     // ---- per-lane addressing: pixel (G, kk, i) is q = 16 G + 4 kk + i
-    float *pixrow = s_pix[w] + 4 * kk * PW;        // own pixel of step (G, i): pixrow + (16 G + i) * PW
-    const float *pixcol = s_pix[w] + nl * PW;      // pixel nl of strip G (cg product, A operand): pixcol + 16 G * PW
+    float *pixrow = s_pix[w] + kk * KS;            // own pixel of step (G, i): pixrow + G * GS + i * PW
+    const float *pixcol = s_pix[w] + pixoff(nl);   // pixel nl of strip G (cg product, A operand): pixcol + G * GS
     const float *momrow = s_mom + lane;            // + 64 * (4 G + i)
     int gch[NA], kch[NK];
 #pragma unroll
@@ -1330,11 +1382,11 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
 #pragma unroll
         for (int G = 0; G < 4; ++G)
 #pragma unroll
-            for (int j = 0; j < NK; ++j) hcg[G][j] = pixcol[16 * G * PW + kch[j]];
+            for (int j = 0; j < NK; ++j) hcg[G][j] = pixcol[G * GS + kch[j]];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
 #pragma unroll
-            for (int q = 0; q < NA; ++q) hft[s][q] = pixrow[(16 * (s >> 2) + (s & 3)) * PW + gch[q]];
+            for (int q = 0; q < NA; ++q) hft[s][q] = pixrow[(s >> 2) * GS + (s & 3) * PW + gch[q]];
             hmom[s] = momrow[64 * s];
         }
     }
@@ -1361,15 +1413,27 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         const unsigned fl = fl_next;
         fl_next = load_flags(top - SB);
-        __syncthreads();
-
-        if (A.cull_flags)
+        // pair slots of the entries this thread writes in the combine: loaded ahead of the barrier in front of it (the
+        // combine used to wait for them iteration by iteration: 4.6 serial L2 round trips per super-batch)
+        int sl[NPASS <= 3 ? NPASS : 1];
+        auto load_slots = [&]() {
+            if (NPASS <= 3) {
+#pragma unroll
+                for (int r = 0; r < (NPASS <= 3 ? NPASS : 1); ++r) {
+                    const int ql = ce + r * EPI;
+                    sl[r] = (ce < EPI && ql < nb) ? slots[top - nb + 1 + ql] : 0;
+                }
+            }
+        };
+        if (BLEND_SLOT_EARLY) load_slots();
+        if (A.cull_flags) {
+            // (the forward's keep words need nothing of the staged records: one barrier serves the park and the keep words)
             keep_from_flags(L, tid, nb, fl, [&](int e, int ww) { return top - e < s_wmax[ww]; });
-        else
+        } else {
+            __syncthreads();
             tile_cull<CH, SB, false, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
                                  [&](int e, int ww) { return top - e < s_wmax[ww]; });
-        if (SHARED)
-            for (int i = tid; i < nb * NC; i += 256) s_acc[0][i] = 0.f;
+        }
         __syncthreads();
         // every survivor gets a slab record: keep flags = written flags
         const int ncin = ncarry;
@@ -1377,7 +1441,7 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         const int nproc = (!CARRY || top - SB < 0) ? total : (total & ~15);  // whole chunks; the tile's last batch pads
         float *slab = s_acc[SHARED ? 0 : w];
         for (int p0 = 0;; p0 += CAP) {  // rounds of at most CAP list positions (one, unless more than CAP survive)
-        const int p1 = CARRY ? imin_(nproc, p0 + CAP) : nproc;
+        const int p1 = (BLEND_ABL & 2) ? p0 : CARRY ? imin_(nproc, p0 + CAP) : nproc;
         for (int j0 = p0; j0 < p1; j0 += 16) {
             const int e = L.list[w][j0 + nl];  // ascending e = back to front; slot SB (inert) past the end
             const float4 g0 = L.g0(e), g1 = L.g1(e);
@@ -1391,9 +1455,9 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                 const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, tcx, tcy);
                 bq1 = kk == 0 ? pc.q0 : kk == 1 ? pc.qx : kk == 2 ? pc.qy : pc.qxx;
                 bq2 = kk == 0 ? pc.qxy : kk == 1 ? pc.qyy : 0.f;
-                const float *fr = reinterpret_cast<const float *>(&L.rec[e * Rec<CH>::RQ + 2]);
 #pragma unroll
-                for (int j = 0; j < NK; ++j) bf[j] = fr[4 * j + kk];  // padded with zeros past CH (pack_kernel)
+                for (int j = 0; j < NK; ++j)  // this lane's K index of slab j: float 8 + 4 j + kk (zeros past CH: pack_kernel)
+                    bf[j] = reinterpret_cast<const float *>(&L.rec[L.part(e, 2 + j)])[kk];
             }
             f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
             float s_ax = 0.f, s_ay = 0.f;  // |d uv| sums over the lane's own pixels (summed over the rows at the chunk's end)
@@ -1411,13 +1475,13 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                 pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi2[G], bq2, pw, 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < NK; ++j)
-                    cgv = __builtin_amdgcn_mfma_f32_16x16x4f32(HOIST ? hcg[HOIST ? G : 0][HOIST ? j : 0] : pixcol[16 * G * PW + kch[j]],
+                    cgv = __builtin_amdgcn_mfma_f32_16x16x4f32(HOIST ? hcg[HOIST ? G : 0][HOIST ? j : 0] : pixcol[G * GS + kch[j]],
                                                                bf[j], cgv, 0, 0, 0);
                 float cg[4], araw[4], a[4], r1a[4], rp[4], Tb[4], Ts4[4], Rs4[4];
                 bool ok[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float4 stv = *reinterpret_cast<const float4 *>(pixrow + (16 * G + i) * PW + PS);
+                    const float4 stv = *reinterpret_cast<const float4 *>(pixrow + G * GS + i * PW + PS);
                     cg[i] = cgv[i];  // (the colour dot product stays on the matrix cores: as per-lane FMAs it was 6 % slower)
                     Tb[i] = stv.x;
                     const int last = __float_as_int(stv.y);
@@ -1425,9 +1489,10 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                     Rs4[i] = stv.w;
                     const float Gs = __builtin_amdgcn_exp2f(pw[i]);
                     araw[i] = o * Gs;
-                    const float alpha = fminf(0.99f, araw[i]);
-                    ok[i] = (qn < last) && !(pw[i] > BLEND_PW_MAX) && !(alpha < (1.0f / 255.0f));
-                    a[i] = ok[i] ? alpha : 0.f;
+                    // (min(0.99, .) is monotone and 0.99 > 1/255: alpha < 1/255 <=> araw < 1/255 -- the forward's decision)
+                    ok[i] = (qn < last) && !(pw[i] > BLEND_PW_MAX) && !(araw[i] < (1.0f / 255.0f));
+                    araw[i] = ok[i] ? araw[i] : 0.f;   // 0 for a splat this pixel does not replay: alpha = 0, dL/dpower = 0
+                    a[i] = fminf(0.99f, araw[i]);
                     r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
                     rp[i] = r1a[i];
                 }
@@ -1445,15 +1510,15 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                 // branch (the chunk stays one basic block, so the four strips' instruction streams interleave)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    lds_store2_lane15(pixrow + (16 * G + i) * PW + PS + 2, T[i], Rs4[i] + rs[i]);
+                    lds_store2_lane15(pixrow + G * GS + i * PW + PS + 2, T[i], Rs4[i] + rs[i]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int s = 4 * G + i;
                     const float dLa = T[i] * cg[i] - (R[i] + Tb[i]) * r1a[i];
-                    const float dLp = ok[i] ? araw[i] * dLa : 0.f;  // dL/dpower
+                    const float dLp = araw[i] * dLa;  // dL/dpower (araw = 0 where the splat is not replayed)
                     d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(HOIST ? hmom[HOIST ? s : 0] : momrow[64 * s], dLp, d_mom, 0, 0, 0);
                     if (FEAT_VALU) {
-                        const float4 gq = *reinterpret_cast<const float4 *>(pixrow + (16 * G + i) * PW);  // g[own pixel][0..3]
+                        const float4 gq = *reinterpret_cast<const float4 *>(pixrow + G * GS + i * PW);  // g[own pixel][0..3]
                         dfv[0] = __builtin_fmaf(gq.x, wgt[i], dfv[0]);
                         if (CH > 1) dfv[1 % (FEAT_VALU ? CH : 1)] = __builtin_fmaf(gq.y, wgt[i], dfv[1 % (FEAT_VALU ? CH : 1)]);
                         if (CH > 2) dfv[2 % (FEAT_VALU ? CH : 1)] = __builtin_fmaf(gq.z, wgt[i], dfv[2 % (FEAT_VALU ? CH : 1)]);
@@ -1462,7 +1527,7 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
 #pragma unroll
                         for (int q = 0; q < NA; ++q)
                             d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                HOIST ? hft[HOIST ? s : 0][HOIST ? q : 0] : pixrow[(16 * G + i) * PW + gch[q]], wgt[i], d_f[q], 0, 0, 0);
+                                HOIST ? hft[HOIST ? s : 0][HOIST ? q : 0] : pixrow[G * GS + i * PW + gch[q]], wgt[i], d_f[q], 0, 0, 0);
                     }
                     if (ABS) {
                         const float dx = uc - (xk + (float)i), dy = vc - (yk + (float)(2 * G));
@@ -1481,7 +1546,8 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                 s_ay = rows_sum(s_ay, lane);
             }
             if (j0 + nl < nproc) {
-                float *rec = slab + (CARRY ? j0 + nl - p0 : e) * NC;
+                // shared slab: the entry's row (carried survivors: entries SB + 1 + .. -> rows SB + ..); private: list position
+                float *rec = slab + (SHARED ? (e > SB ? e - 1 : e) : (CARRY ? j0 + nl - p0 : e)) * NCS;
                 auto put = [](float *p, float v) {
                     if (SHARED) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f32
                     else *p = v;
@@ -1523,48 +1589,69 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         if (CARRY && p0 == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (nproc > 0)  // the carried survivors were replayed (rows 0 .. ncin - 1): their part of last batch's records
+            if (nproc > 0)  // the carried survivors were replayed (their rows: the wave's first ncin): their part of last batch's records
                 for (int idx = lane; idx < ncin * NC; idx += 64) {
                     const int k = idx / NC, c = idx - k * NC;
-                    __hip_atomic_fetch_add(pair_buf + (size_t)CL.cslot[w][k] * NCP + c, slab[idx], __ATOMIC_RELAXED,
+                    float *src = SHARED ? slab + (SB + CQ * w + k) * NCS + c : slab + idx;
+                    __hip_atomic_fetch_add(pair_buf + (size_t)CL.cslot[w][k] * NCP + c, *src, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
+                    if (SHARED) *src = 0.f;   // (only this wave adds to its carry rows)
                 }
             const int left = total - nproc;  // 0 .. 15 survivors wait for the next super-batch
             if (left > 0) carry_out<CH, SB>(L, CL, w, lane, nproc > 0 ? nproc : ncin, nproc > 0 ? left : left - ncin,
                                             nproc > 0 ? 0 : ncin, top, slots);
             ncarry = left;
         }
-        if (CARRY && lane == 0) CL.more[w] = nproc > p0 + CAP;
+        if (CARRY && !SHARED && lane == 0) CL.more[w] = nproc > p0 + CAP;
+        if (!BLEND_SLOT_EARLY && p0 == 0) load_slots();
         __syncthreads();
         // ---- combine the four slabs: thread (ce, cc) sums component cc of every EPI-th entry and stores it at the
         //      entry's pair slot (the NCP - NC pad floats of a record are never written; pair_reduce ignores them)
-        if (ce < EPI) {
+        if (ce < EPI && !(BLEND_ABL & 1)) {
             const int lo = top - nb + 1;
-            for (int ql = ce; ql < nb; ql += EPI) {
-                const int e = nb - 1 - ql;
-                const unsigned int fl = L.keep[e];
-                float v = 0.f;
-                if (SHARED) {
-                    v = s_acc[0][e * NC + cc];
-                } else if (CARRY) {
-                    const unsigned int p4 = CL.pos4[e];
+            if (SHARED) {
+                // one row per entry: read it out, clear it for the next super-batch, store it at the entry's pair slot
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) {  // row of this round's slab if the wave replayed the entry now, else the zero row
-                        const unsigned int pp = umin_(((p4 >> (8 * ww)) & 0xffu) - (unsigned)p0, (unsigned)CAP);
-                        v += s_acc[ww][pp * NC + cc];
-                    }
-                } else {
-#pragma unroll
-                    for (int ww = 0; ww < Cfg::NSLAB; ++ww) {
-                        const float x = s_acc[ww][e * NC + cc];
-                        v += ((fl >> (8 * ww)) & 0xffu) ? x : 0.f;
+                for (int r = 0; r < NPASS; ++r) {
+                    const int ql = ce + r * EPI;
+                    if (ql < nb) {
+                        float *row = s_acc[0] + (nb - 1 - ql) * NCS + CW * cc;
+                        const float v0 = row[0], v1 = row[CW > 1 ? 1 : 0], v2 = row[CW > 1 ? 2 : 0];
+                        row[0] = 0.f;
+                        if (CW > 1) { row[1] = 0.f; row[2] = 0.f; }
+                        store_part(NPASS <= 3 ? sl[NPASS <= 3 ? r : 0] : slots[lo + ql], v0, v1, v2);
                     }
                 }
-                float *dst = pair_buf + (size_t)slots[lo + ql] * NCP + cc;
-                if (!CARRY || p0 == 0) *dst = v;
-                else *dst += v;  // a further round of the same super-batch: the same thread stored the record before
+            } else {
+                // private slabs, rows by list position: the entry's row in every wave's slab (the zero row CAP where the wave
+                // did not replay it in this round), three floats per thread
+#pragma unroll
+                for (int r = 0; r < NPASS; ++r) {
+                    const int ql = ce + r * EPI;
+                    if (ql < nb) {
+                        const unsigned int p4 = CL.pos4[nb - 1 - ql];
+                        float v[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ww = 0; ww < 4; ++ww) {
+                            const unsigned int pp = umin_(((p4 >> (8 * ww)) & 0xffu) - (unsigned)p0, (unsigned)CAP);
+                            const float *row = s_acc[ww] + pp * NC + CW * cc;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j)
+                                if (CW * (TPR - 1) + j < NC || CW * cc + j < NC) v[j] += row[j];   // (floats >= NC: padding)
+                        }
+                        const int slot = NPASS <= 3 ? sl[NPASS <= 3 ? r : 0] : slots[lo + ql];
+                        if (p0 > 0) {  // a further round of the same super-batch: the same thread stored the record before
+                            const float *old = pair_buf + (size_t)slot * NCP + CW * cc;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j)
+                                if (CW * cc + j < NCP) v[j] += old[j];
+                        }
+                        store_part(slot, v[0], v[1], v[2]);
+                    }
+                }
             }
         }
+        if (SHARED) break;   // (no rounds; the next super-batch's barrier orders its slab adds behind this combine's clears)
         const bool more = CARRY && (CL.more[0] | CL.more[1] | CL.more[2] | CL.more[3]);
         __syncthreads();
         if (!more) break;
@@ -1572,7 +1659,7 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     }
     if (A.dbg_T_front) {  // per-pixel transmittance after the last (front-most) replayed splat: lane q <-> pixel q of the block
         const int px = bx + (lane & 7), py = by + (lane >> 3);
-        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_pix[w][lane * PW + PS + 2];
+        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_pix[w][pixoff(lane) + PS + 2];
     }
 }
 
