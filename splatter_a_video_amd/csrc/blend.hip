@@ -27,6 +27,8 @@
 //     atomic per (wave, splat, component).
 #include <stdlib.h>
 
+#include <utility>
+
 #include "common.h"
 
 // tuning knobs (compile time; tools/build_variants.sh builds alternatives for A/B runs)
@@ -68,6 +70,9 @@
 #ifndef BLEND_ABL
 #define BLEND_ABL 0        // ablation of the matrix-core backward for timing experiments (1: no combine, 2: no chunks); results invalid
 #endif
+#ifndef BLEND_LATE_STAGE
+#define BLEND_LATE_STAGE 1 // matrix-core backward: gather the next super-batch's records behind the chunk loop (1) or in front of it (0)
+#endif
 #ifndef BLEND_SLOT_EARLY
 #define BLEND_SLOT_EARLY 0 // matrix-core backward: load the combine's pair slots at the top of the super-batch (1) or behind the chunks (0)
 #endif
@@ -81,6 +86,23 @@
 // an expanded polynomial (absolute error up to ~5e-6 in log2 units), so their "power > 0" guard of the reference
 // (src/alpha_blending.cu:93) sits just above that noise; it still rejects genuinely indefinite conics.
 #define BLEND_PW_MAX 1.5e-4f
+// BLEND_EXP_CLAMP (default): the guard is the clamp bit of v_exp_f32 -- G = min(exp2(power), 1) -- instead of a compare per
+// (pixel, splat): identical wherever power <= 0 (every pixel of a positive-definite conic up to rounding; EWA only emits
+// those: cov2d + 0.3 I), a pixel on a splat's centre gets G = 1 exactly instead of 1 + 1e-5, and a NaN power still gives
+// alpha = 0 (DX10 clamp: NaN -> 0).  Forward and every backward kernel share exp2_guard(), so decisions stay reproducible.
+#ifndef BLEND_EXP_CLAMP
+#define BLEND_EXP_CLAMP 1
+#endif
+// G = exp2(pw) under the guard; `ok` = the splat is not rejected by the guard
+__device__ __forceinline__ float exp2_guard(float pw, bool &ok) {
+#if BLEND_EXP_CLAMP
+    ok = true;
+    return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(pw), 0.f, 1.f);   // folds into v_exp_f32 ... clamp
+#else
+    ok = !(pw > BLEND_PW_MAX);
+    return __builtin_amdgcn_exp2f(pw);
+#endif
+}
 
 struct BlendArgs {
     int P, C;          // C = row stride of feature / dL_dfeature
@@ -742,8 +764,9 @@ blend_fwd_kernel(const BlendArgs B) {
                         alpha[u] = (!(q < 0.f) && !(a < (1.0f / 255.0f))) ? a : 0.f;
                     } else {
                         const float pw = power_poly(g0[u], g1[u], x, y, xx, xy, yy);
-                        const float a = fminf(0.99f, g1[u].z * __builtin_amdgcn_exp2f(pw));
-                        alpha[u] = (!(pw > BLEND_PW_MAX) && !(a < (1.0f / 255.0f))) ? a : 0.f;
+                        bool pw_ok;
+                        const float a = fminf(0.99f, g1[u].z * exp2_guard(pw, pw_ok));
+                        alpha[u] = (pw_ok && !(a < (1.0f / 255.0f))) ? a : 0.f;
                     }
                     amax = fmaxf(amax, alpha[u]);
                 }
@@ -995,9 +1018,8 @@ blend_bwd_pair_kernel(const BlendArgs B) {
                     pw_ok = !(q < 0.f);
                 } else {
                     const float pw = power_poly(L.coef[2 * e[u]], L.coef[2 * e[u] + 1], x, y, xx, xy, yy);
-                    G[u] = __builtin_amdgcn_exp2f(pw);
+                    G[u] = exp2_guard(pw, pw_ok);
                     araw = g1[u].y * G[u];
-                    pw_ok = !(pw > BLEND_PW_MAX);
                 }
                 alpha[u] = fminf(0.99f, araw);
                 ok[u] = (j0 + u < cnt) && !done && (top - e[u] < last) && pw_ok && !(alpha[u] < (1.0f / 255.0f));
@@ -1189,6 +1211,28 @@ __device__ __forceinline__ void row_scan_add4(float &a, float &b, float &c, floa
     asm volatile("s_nop 1\n\t" SCAN4("v_add_f32_dpp", "1") SCAN4("v_add_f32_dpp", "2") SCAN4("v_add_f32_dpp", "4")
                      SCAN4("v_add_f32_dpp", "8")
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+// lds_store2_lane15 at a compile-time float offset OFF (< 255) from p: the offset rides in the instruction (no address add)
+template <int OFF>
+__device__ __forceinline__ void lds_store2_lane15_at(float *p, float a, float b) {
+    static_assert(OFF >= 0 && OFF + 1 <= 255, "ds_write2_b32 offsets are 8 bits, in dwords");
+    const unsigned addr = (unsigned)(size_t)p;
+    asm volatile(
+        "s_mov_b64 exec, %3\n\t"
+        "ds_write2_b32 %0, %1, %2 offset0:%4 offset1:%5\n\t"
+        "s_mov_b64 exec, -1"
+        :
+        : "v"(addr), "v"(a), "v"(b), "s"(0x8000800080008000ull), "n"(OFF), "n"(OFF + 1)
+        : "memory");
+}
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
 }
 // two floats to LDS from the last lane of every 16-lane row (EXEC is all ones in the callers: full waves, uniform flow)
 __device__ __forceinline__ void lds_store2_lane15(float *p, float a, float b) {
@@ -1409,8 +1453,10 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     for (int top = n - 1; top >= 0; top -= SB, ++batch) {
         const int nb = imin_(SB, top + 1);
         st.park(L, tid);
-        st.load_payload(A, tid);                       // payload of the next super-batch
-        st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
+        if (!BLEND_LATE_STAGE) {
+            st.load_payload(A, tid);                       // payload of the next super-batch
+            st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
+        }
         const unsigned fl = fl_next;
         fl_next = load_flags(top - SB);
         // pair slots of the entries this thread writes in the combine: loaded ahead of the barrier in front of it (the
@@ -1487,10 +1533,11 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                     const int last = __float_as_int(stv.y);
                     Ts4[i] = stv.z;
                     Rs4[i] = stv.w;
-                    const float Gs = __builtin_amdgcn_exp2f(pw[i]);
+                    bool pw_ok;
+                    const float Gs = exp2_guard(pw[i], pw_ok);
                     araw[i] = o * Gs;
                     // (min(0.99, .) is monotone and 0.99 > 1/255: alpha < 1/255 <=> araw < 1/255 -- the forward's decision)
-                    ok[i] = (qn < last) && !(pw[i] > BLEND_PW_MAX) && !(araw[i] < (1.0f / 255.0f));
+                    ok[i] = (qn < last) && pw_ok && !(araw[i] < (1.0f / 255.0f));
                     araw[i] = ok[i] ? araw[i] : 0.f;   // 0 for a splat this pixel does not replay: alpha = 0, dL/dpower = 0
                     a[i] = fminf(0.99f, araw[i]);
                     r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
@@ -1604,6 +1651,12 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         }
         if (CARRY && !SHARED && lane == 0) CL.more[w] = nproc > p0 + CAP;
         if (!BLEND_SLOT_EARLY && p0 == 0) load_slots();
+        if (BLEND_LATE_STAGE && p0 == 0) {
+            // the next super-batch's payload (8 registers) is requested behind the chunks, not across them: its latency
+            // hides under the barrier, the combine and the other workgroups of the CU
+            st.load_payload(A, tid);
+            st.load_ids(A, tid, range.x, pos, batch + 2);
+        }
         __syncthreads();
         // ---- combine the four slabs: thread (ce, cc) sums component cc of every EPI-th entry and stores it at the
         //      entry's pair slot (the NCP - NC pad floats of a record are never written; pair_reduce ignores them)
@@ -1935,10 +1988,11 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                     Ts4[i] = sb.x;
                     Rs[0][i] = sb.y; Rs[1][i] = sb.z; Rs[2][i] = sb.w;
                     cg[0][i] = cv0[i]; cg[1][i] = cv1[i]; cg[2][i] = cv2[i];
-                    const float Gs = __builtin_amdgcn_exp2f(pw[i]);
+                    bool pw_ok;
+                    const float Gs = exp2_guard(pw[i], pw_ok);
                     araw[i] = o * Gs;
                     const float alpha = fminf(0.99f, araw[i]);
-                    ok[i] = (qn < last) && !(pw[i] > BLEND_PW_MAX) && !(alpha < (1.0f / 255.0f));
+                    ok[i] = (qn < last) && pw_ok && !(alpha < (1.0f / 255.0f));
                     a[i] = ok[i] ? alpha : 0.f;
                     r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
                     rp[i] = r1a[i];
@@ -2122,9 +2176,8 @@ blend_bwd_atomic_kernel(const BlendArgs B) {
                 pw_ok = !(q < 0.f);
             } else {
                 const float pw = power_poly(L.coef[2 * e], L.coef[2 * e + 1], x, y, xx, xy, yy);
-                G = __builtin_amdgcn_exp2f(pw);
+                G = exp2_guard(pw, pw_ok);
                 araw = g1.y * G;
-                pw_ok = !(pw > BLEND_PW_MAX);
             }
             const float alpha = fminf(0.99f, araw);
             const bool ok = !done && (top - e < last) && pw_ok && !(alpha < (1.0f / 255.0f));
