@@ -70,6 +70,13 @@
 #ifndef BLEND_ABL
 #define BLEND_ABL 0        // ablation of the matrix-core backward for timing experiments (1: no combine, 2: no chunks); results invalid
 #endif
+#ifndef BLEND_SETS_MINW
+#define BLEND_SETS_MINW 2  // waves per SIMD the three-set backward is compiled for (3: 168 registers = 39 scratch accesses
+                           // inside the chunk loop, 1061 instead of 615 us per frame; its LDS would allow 3)
+#endif
+#ifndef BLEND_SETS_CAP
+#define BLEND_SETS_CAP 32  // slab rows per wave of the three-set backward (list positions per round)
+#endif
 #ifndef BLEND_LATE_STAGE
 #define BLEND_LATE_STAGE 1 // matrix-core backward: gather the next super-batch's records behind the chunk loop (1) or in front of it (0)
 #endif
@@ -1793,13 +1800,23 @@ pack_sets_kernel(const BlendArgs B) {
 }
 
 template <bool ABS>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, BLEND_SETS_MINW)
 blend_bwd_sets_kernel(const BlendArgs B) {
     using Cfg = SetsCfg;
     constexpr int CH = Cfg::CH, SB = Cfg::SB, NG = Cfg::NG, NK = Cfg::NK, NA = Cfg::NA, PS = Cfg::PS;
-    __shared__ TileLDS<CH, SB> L;
-    __shared__ float s_acc[4][SB * Cfg::NCMAX];  // private slab per wave (first: staging of the wave's dL_dout)
-    __shared__ __attribute__((aligned(16))) float s_state[4][64 * PS];
+    // private slab per wave, rows by the wave's list POSITION (CAP rows + a zero row; a longer survivor list takes another round
+    // of chunks + combine): 25 KB instead of the 39 KB of one row per staged entry -- three workgroups per CU.  (First: staging
+    // of the wave's dL_dout, half a block at a time.)
+    constexpr int CAP = BLEND_SETS_CAP;
+    static_assert(CAP % 16 == 0 && (CAP + 1) * Cfg::NCMAX >= 32 * CH, "whole chunks; the staging of 32 pixels fits a slab");
+    __shared__ TileLDS<CH, SB, false, 0, BLEND_REC_SWZ != 0> L;
+    __shared__ CarryLDS<SB, true> CL;              // (position bytes of the entries; nothing is carried here)
+    __shared__ float s_acc[4][(CAP + 1) * Cfg::NCMAX];
+    // replay state rows (8 floats per pixel), pixel q = 16 G + 4 kk + i at float G * GS + kk * KS + i * PS: 8 floats of skew
+    // per lane group, or the four groups' rows of one step share their banks (see blend_bwd_mfma_kernel)
+    constexpr int KS = 4 * PS + (BLEND_STATE_SKEW ? 8 : 0), GS = 4 * KS;
+    __shared__ __attribute__((aligned(16))) float s_state[4][4 * GS];
+    auto pixoff = [](int q) { return (q >> 4) * GS + ((q >> 2) & 3) * KS + (q & 3) * PS; };
     __shared__ float s_mom[16 * 64];             // A operand of the moment product: [step 4 G + i][lane]
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1835,7 +1852,8 @@ blend_bwd_sets_kernel(const BlendArgs B) {
         phi1[Gs] = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
         phi2[Gs] = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
     }
-    float *stage = s_acc[w];  // [pixel][slot]
+    float *stage = s_acc[w];  // [pixel of the half block][slot]
+    float gpix[CH];           // dL_dout of this lane's pixel, slot by slot
     {   // per-pixel constants: lane q <-> pixel (q & 7, q >> 3) of the wave's block
         const int px = bx + (lane & 7), py = by + (lane >> 3);
         const size_t HW = (size_t)A.H * A.W;
@@ -1858,10 +1876,10 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                     g = d[(size_t)o * HW + pix];
                 }
             }
-            stage[lane * CH + k] = g;
+            gpix[k] = g;
             bgd[gi] += (gi == 0 ? A.s0bg : gi == 1 ? A.s1bg : A.s2bg) * g;
         }
-        float *r = s_state[w] + lane * PS;
+        float *r = s_state[w] + pixoff(lane);
         r[0] = Tf * bgd[0]; r[1] = Tf * bgd[1]; r[2] = Tf * bgd[2];
         r[3] = __int_as_float(last);
         r[4] = Tf;    // T_state: transmittance behind the splats replayed so far
@@ -1870,19 +1888,32 @@ blend_bwd_sets_kernel(const BlendArgs B) {
         if (lane == 0) s_wmax[w] = wmax;
     }
     if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
-    __syncthreads();
-    // ---- the two MFMA operand layouts of dL_dout, and the moment table, into registers
+    // ---- the two MFMA operand layouts of dL_dout into registers: the wave's own slab memory stages 32 pixels at a time
+    //      (strips 0-1, then 2-3); wave-private, so wave barriers order it
     float hcg[4][NK], hft[16][NA];
 #pragma unroll
-    for (int G = 0; G < 4; ++G)
+    for (int h = 0; h < 2; ++h) {
+        if ((lane >> 5) == h) {
 #pragma unroll
-        for (int j = 0; j < NK; ++j) hcg[G][j] = stage[(16 * G + nl) * CH + 4 * j + kk];  // A[m = pixel nl of strip G][k = slot]
+            for (int k = 0; k < CH; ++k) stage[(lane & 31) * CH + k] = gpix[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int st = 0; st < 16; ++st) {
+        for (int G = 2 * h; G < 2 * h + 2; ++G)
 #pragma unroll
-        for (int q = 0; q < NA; ++q)  // A[m = slot 16 q + nl][k = own pixel of step st]
-            hft[st][q] = 16 * q + nl < CH ? stage[(16 * (st >> 2) + 4 * kk + (st & 3)) * CH + 16 * q + nl] : 0.f;
+            for (int j = 0; j < NK; ++j) hcg[G][j] = stage[(16 * (G & 1) + nl) * CH + 4 * j + kk];  // A[m = pixel nl of strip G][k = slot]
+#pragma unroll
+        for (int st = 8 * h; st < 8 * h + 8; ++st) {
+#pragma unroll
+            for (int q = 0; q < NA; ++q)  // A[m = slot 16 q + nl][k = own pixel of step st]
+                hft[st][q] = 16 * q + nl < CH ? stage[(16 * ((st >> 2) & 1) + 4 * kk + (st & 3)) * CH + 16 * q + nl] : 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
+    if (lane < NC) s_acc[w][CAP * NC + lane] = 0.f;   // the slab's zero row (what the combine reads where the wave has nothing)
+    __syncthreads();
     const float *momrow = s_mom + lane;  // + 64 * (4 G + i)
     // the feature accumulators of this lane hold slots 16 q + 4 kk + i (rows of the product): one group per (q, kk) --
     // record component of the first of them and how many are real channels
@@ -1902,16 +1933,27 @@ blend_bwd_sets_kernel(const BlendArgs B) {
     const int len = range.y - range.x;
     const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
     const int *slots = A.slot_sorted + range.x;
-    const int EPI = 256 / NC;                        // pair records the 256 threads write per pass, NC floats each
-    const int ce = tid / NC, cc = tid - ce * NC;     // this thread's (entry within the pass, component)
+    // combine: TPR threads per record, three floats each (one 12-byte store)
+    const int TPR = (NC + 2) / 3, EPI = 256 / TPR;   // pair records the 256 threads write per pass
+    const int ce = tid / TPR, cc = tid - ce * TPR;   // this thread's (entry within the pass, part of the record)
+    auto store_part = [&](int slot, float v0, float v1, float v2) {
+        float *dst = pair_buf + (size_t)slot * NCP + 3 * cc;
+        if (3 * cc + 2 < NCP) {
+            F3 t; t.x = v0; t.y = v1; t.z = v2;
+            *reinterpret_cast<F3 *>(dst) = t;        // (floats NC .. NCP - 1 of a record are padding)
+        } else {
+            if (3 * cc < NCP) dst[0] = v0;
+            if (3 * cc + 1 < NCP) dst[1] = v1;
+        }
+    };
     if (ce < EPI)
         for (int ql = n + ce; ql < len; ql += EPI)   // entries nobody replays: zero record
-            pair_buf[(size_t)slots[ql] * NCP + cc] = 0.f;
-    float *state = s_state[w] + 4 * kk * PS;         // own pixel of step (G, i): state + (16 G + i) * PS
+            store_part(slots[ql], 0.f, 0.f, 0.f);
+    float *state = s_state[w] + kk * KS;             // own pixel of step (G, i): state + G * GS + i * PS
     if (n <= 0) {
         if (A.dbg_T_front) {
             const int px = bx + (lane & 7), py = by + (lane >> 3);
-            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][lane * PS + 4];
+            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(lane) + 4];
         }
         return;
     }
@@ -1928,26 +1970,27 @@ blend_bwd_sets_kernel(const BlendArgs B) {
         return (A.cull_flags && tid < SB && q >= 0) ? (unsigned)A.cull_flags[range.x + q] : 0u;
     };
     unsigned fl_next = load_flags(n - 1);
-    __syncthreads();  // every wave has read its staging rows: the slabs are free
 
     int batch = 0;
     for (int top = n - 1; top >= 0; top -= SB, ++batch) {
         const int nb = imin_(SB, top + 1);
         st.park(L, tid);
-        st.load_payload(A, tid);
-        st.load_ids(A, tid, range.x, pos, batch + 2);
         const unsigned fl = fl_next;
         fl_next = load_flags(top - SB);
-        __syncthreads();
-        if (A.cull_flags)
+        if (A.cull_flags) {   // (the keep words need nothing of the staged records: one barrier serves both)
             keep_from_flags(L, tid, nb, fl, [&](int e, int ww) { return top - e < s_wmax[ww]; });
-        else
+        } else {
+            __syncthreads();
             tile_cull<CH, SB, false, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
                                                [&](int e, int ww) { return top - e < s_wmax[ww]; });
+        }
         __syncthreads();
-        const int cnt = build_list(L, w, lane);
+        const int cnt = build_list_at(L, CL, w, lane, 0);   // + the entries' list positions (CL.pos4)
         float *slab = s_acc[w];
-        for (int j0 = 0; j0 < cnt; j0 += 16) {
+        int sl[3];   // pair slots of the entries this thread writes in the combine (up to three passes)
+        for (int p0 = 0;; p0 += CAP) {   // rounds of at most CAP list positions (one, unless more than CAP survive)
+        const int p1 = imin_(cnt, p0 + CAP);
+        for (int j0 = p0; j0 < p1; j0 += 16) {
             const int e = L.list[w][j0 + nl];
             const float4 g0 = L.g0(e), g1 = L.g1(e);
             const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
@@ -1958,9 +2001,8 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                 const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, tcx, tcy);
                 bq1 = kk == 0 ? pc.q0 : kk == 1 ? pc.qx : kk == 2 ? pc.qy : pc.qxx;
                 bq2 = kk == 0 ? pc.qxy : kk == 1 ? pc.qyy : 0.f;
-                const float *fr = reinterpret_cast<const float *>(&L.rec[e * Rec<CH>::RQ + 2]);
 #pragma unroll
-                for (int j = 0; j < NK; ++j) bf[j] = fr[4 * j + kk];
+                for (int j = 0; j < NK; ++j) bf[j] = reinterpret_cast<const float *>(&L.rec[L.part(e, 2 + j)])[kk];
             }
             f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
             f32x4 d_f[NA];
@@ -1981,8 +2023,8 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                 bool ok[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float4 sa = *reinterpret_cast<const float4 *>(state + (16 * G + i) * PS);
-                    const float4 sb = *reinterpret_cast<const float4 *>(state + (16 * G + i) * PS + 4);
+                    const float4 sa = *reinterpret_cast<const float4 *>(state + G * GS + i * PS);
+                    const float4 sb = *reinterpret_cast<const float4 *>(state + G * GS + i * PS + 4);
                     Tb[0][i] = sa.x; Tb[1][i] = sa.y; Tb[2][i] = sa.z;
                     const int last = __float_as_int(sa.w);
                     Ts4[i] = sb.x;
@@ -2013,8 +2055,8 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    lds_store2_lane15(state + (16 * G + i) * PS + 4, T[i], Rs[0][i] + rs[0][i]);
-                    lds_store2_lane15(state + (16 * G + i) * PS + 6, Rs[1][i] + rs[1][i], Rs[2][i] + rs[2][i]);
+                    lds_store2_lane15(state + G * GS + i * PS + 4, T[i], Rs[0][i] + rs[0][i]);
+                    lds_store2_lane15(state + G * GS + i * PS + 6, Rs[1][i] + rs[1][i], Rs[2][i] + rs[2][i]);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -2049,7 +2091,7 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                 s_ay = rows_sum(s_ay, lane);
             }
             if (j0 + nl < cnt) {
-                float *rec = slab + e * NC;
+                float *rec = slab + (j0 + nl - p0) * NC;   // row = position in this round
                 const float D0 = d_mom[0];
                 if (kk == 0) {
                     const float Dx = d_mom[1], Dy = d_mom[2], Dxx = d_mom[3];
@@ -2076,26 +2118,52 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                         if (i < fcnt[q]) rec[fbase[q] + i] = d_f[q][i];
             }
         }
-        __syncthreads();
-        if (ce < EPI) {  // combine the four slabs into the entries' pair slots
-            const int lo = top - nb + 1;
-            for (int ql = ce; ql < nb; ql += EPI) {
-                const int e = nb - 1 - ql;
-                const unsigned int fl = L.keep[e];
-                float v = 0.f;
+        if (lane == 0) CL.more[w] = cnt > p0 + CAP;
+        if (p0 == 0) {
+            // behind the chunks, ahead of the barrier: the pair slots of this thread's combine passes and the next
+            // super-batch's records and ids (requested here their registers are not live across the chunk loop)
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) {
-                    const float x = s_acc[ww][e * NC + cc];
-                    v += ((fl >> (8 * ww)) & 0xffu) ? x : 0.f;
-                }
-                pair_buf[(size_t)slots[lo + ql] * NCP + cc] = v;
+            for (int r = 0; r < 3; ++r) {
+                const int ql = ce + r * EPI;
+                sl[r] = (ce < EPI && ql < nb) ? slots[top - nb + 1 + ql] : 0;
             }
+            st.load_payload(A, tid);
+            st.load_ids(A, tid, range.x, pos, batch + 2);
         }
         __syncthreads();
+        if (ce < EPI) {  // combine the four slabs into the entries' pair slots: the entry's row in every wave's slab (the zero
+                         // row CAP where the wave did not replay it in this round), three floats per thread
+            const int lo = top - nb + 1;
+            int r = 0;
+            for (int ql = ce; ql < nb; ql += EPI, ++r) {
+                const unsigned int p4 = CL.pos4[nb - 1 - ql];
+                float v[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const unsigned int pp = umin_(((p4 >> (8 * ww)) & 0xffu) - (unsigned)p0, (unsigned)CAP);
+                    const float *row = s_acc[ww] + pp * NC + 3 * cc;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (3 * cc + j < NC) v[j] += row[j];
+                }
+                const int slot = r == 0 ? sl[0] : r == 1 ? sl[1] : r == 2 ? sl[2] : slots[lo + ql];
+                if (p0 > 0) {   // a further round of the same super-batch: the same thread stored the record before
+                    const float *old = pair_buf + (size_t)slot * NCP + 3 * cc;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (3 * cc + j < NCP) v[j] += old[j];
+                }
+                store_part(slot, v[0], v[1], v[2]);
+            }
+        }
+        const bool more = CL.more[0] | CL.more[1] | CL.more[2] | CL.more[3];
+        __syncthreads();
+        if (!more) break;
+        }
     }
     if (A.dbg_T_front) {
         const int px = bx + (lane & 7), py = by + (lane >> 3);
-        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][lane * PS + 4];
+        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(lane) + 4];
     }
 }
 
