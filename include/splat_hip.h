@@ -366,6 +366,55 @@ int splat_frames_gauss_backward_static(int F, int P, int C, int W, int H, int64_
  * sizeof(splat_frames_t).  splat_frames_count = preprocess + pair counts (pairs[F], device) to size `capacity` before the
  * first splat_frames_forward; forward = preprocess, binning, sort, pack, compositing; backward = tile kernels +
  * Gaussian-side reduction (accumulate: add into the parameter gradients). */
+/* Camera of a frame batch.  perspective = 0: the orthographic camera of the video renderer (intr unused;
+ * dptr_ortho_enhanced.py:177-202); 1: the pinhole camera of gs.rasterization / DPTRRender (project_point.cu,
+ * ewa_project.cu).  Every frame may have its own camera -- render_batch gives each batch element its own
+ * (dptr_ortho_enhanced.py:409-411): frame f reads extr + f * extr_frame_stride (12 floats: the first three rows of the
+ * world-to-camera matrix) and intr + f * intr_frame_stride (fx fy cx cy); stride 0 = one camera for the batch.  With one
+ * orthographic camera the Gaussian-side backward runs its projection chain once on the sums of all frames; otherwise once
+ * per frame, and then needs the forward's `offsets` [F,P,3] (NULL: none were used). */
+typedef struct splat_camera_t {
+    int32_t perspective;
+    const float *intr;
+    int64_t intr_frame_stride;
+    const float *extr;
+    int64_t extr_frame_stride;
+    const float *offsets;
+} splat_camera_t;
+int splat_preprocess_forward_batch_cam(int F, int P, const float *xyz, const float *offsets, const float *scales,
+                                       const float *uquats, const splat_camera_t *cam, int W, int H, float nearest,
+                                       float extent, float *uv, float *depth, float *conic, int32_t *radius,
+                                       splat_stream_t stream);
+/* one feature set (arguments of splat_frames_gauss_backward_static_set) / the three sets of one pass under any camera */
+int splat_frames_gauss_backward_static_cam(int F, int P, int cn, int W, int H, int64_t capacity, int want_abs,
+                                           const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
+                                           const float *xyz, const float *scales, const float *uquats,
+                                           const splat_camera_t *cam, int accumulate, float *d_xyz, float *d_scales,
+                                           float *d_uquats, float *d_opacity, float *d_feature /*NULL: none*/,
+                                           int feature_stride, int skip_opacity, int depth_channel, float *tap,
+                                           float *abs_tap, int32_t *radii_max, splat_stream_t stream);
+int splat_frames_gauss_backward_static_sets_cam(int F, int P, int C, int W, int H, int64_t capacity,
+                                                const float *pair_records, const int32_t *goff_incl,
+                                                const int32_t *radius, const float *xyz, const float *scales,
+                                                const float *uquats, const splat_camera_t *cam, int accumulate,
+                                                float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                                const int32_t *set_c0, const int32_t *set_cn, float *const *set_dfeature,
+                                                const int32_t *set_stride, int depth_channel, float *tap, float *abs_tap,
+                                                int32_t *radii_max, splat_stream_t stream);
+/* The pinhole camera's operator chain of gs.rasterization (project_point -> compute_cov3d -> ewa_project:
+ * src/submodules/dptr/dptr/gs/__init__.py:55-77) fused into one pass per direction, like splat_preprocess_ortho_*; the
+ * backward returns the position gradient through the projection and the EWA Jacobian (camera gradients: the separate
+ * operators above). */
+int splat_preprocess_persp_forward(int P, const float *xyz, const float *offset, const float *scales, const float *uquats,
+                                   const float *intr, const float *extr, int W, int H, float nearest, float extent,
+                                   float *uv, float *depth, float *conic, int32_t *radius, int32_t *tiles,
+                                   splat_stream_t stream);
+int splat_preprocess_persp_backward(int P, const float *xyz, const float *offset, const float *scales, const float *uquats,
+                                    const float *intr, const float *extr, int W, int H, const float *depth,
+                                    const int32_t *radius, const float *dL_duv, const float *dL_ddepth,
+                                    const float *dL_dconic, int accumulate, float *dL_dxyz, float *dL_dscales,
+                                    float *dL_duquats, splat_stream_t stream);
+
 typedef struct splat_frames_t {
     size_t struct_bytes;
     int32_t F, P, W, H, C;
@@ -394,6 +443,10 @@ typedef struct splat_frames_t {
     int32_t *radii_max;               /* optional [P] */
     float *dbg_T_front;               /* optional [F,H,W] */
     uint32_t *cull_flags;              /* optional [F,capacity]: the forward's cull decisions, reused by the backward */
+    /* camera (ABI 16): `extr` above per frame when extr_frame_stride != 0; perspective = 1 with intr (fx fy cx cy) */
+    int64_t extr_frame_stride, intr_frame_stride;
+    const float *intr;
+    int32_t perspective;
 } splat_frames_t;
 int splat_frames_count(const splat_frames_t *batch);
 int splat_frames_forward(const splat_frames_t *batch);

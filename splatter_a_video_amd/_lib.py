@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -46,6 +46,8 @@ SYMBOLS = [
     "splat_blend_sets_pair_stride", "splat_blend_sets_pack_floats", "splat_alpha_blending_backward_batch_sets",
     "splat_alpha_blending_forward_batch_sets",
     "splat_frames_gauss_backward_static_sets", "splat_frames_gauss_backward_dynamic_sets",
+    "splat_preprocess_forward_batch_cam", "splat_frames_gauss_backward_static_cam", "splat_frames_gauss_backward_static_sets_cam",
+    "splat_preprocess_persp_forward", "splat_preprocess_persp_backward",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]
 

@@ -4,11 +4,20 @@
 // the pointers); nothing is allocated, nothing synchronises with the host.
 #include "common.h"
 
+static splat_camera_t batch_camera(const splat_frames_t *b) {
+    splat_camera_t cam;
+    memset(&cam, 0, sizeof(cam));
+    cam.perspective = b->perspective; cam.intr = b->intr; cam.intr_frame_stride = b->intr_frame_stride;
+    cam.extr = b->extr; cam.extr_frame_stride = b->extr_frame_stride; cam.offsets = b->offsets;
+    return cam;
+}
+
 extern "C" int splat_frames_forward(const splat_frames_t *b) {
     SPLAT_CHECK_ARG(b != nullptr && b->struct_bytes == sizeof(splat_frames_t), "splat_frames_t of another ABI version");
     SPLAT_CHECK_ARG(b->capacity >= 1, "capacity (pairs reserved per frame) must be set: run splat_frames_count first");
-    int rc = splat_preprocess_ortho_forward_batch(b->F, b->P, b->xyz, b->offsets, b->scales, b->uquats, b->extr, b->W, b->H,
-                                                  b->nearest, b->extent, b->uv, b->depth, b->conic, b->radius, b->stream);
+    const splat_camera_t cam = batch_camera(b);
+    int rc = splat_preprocess_forward_batch_cam(b->F, b->P, b->xyz, b->offsets, b->scales, b->uquats, &cam, b->W, b->H,
+                                                b->nearest, b->extent, b->uv, b->depth, b->conic, b->radius, b->stream);
     if (rc != SPLAT_OK) return rc;
     rc = splat_bin_count_batch(b->F, b->P, b->uv, b->radius, b->W, b->H, b->bin_scratch, b->tile_range, b->pairs, b->stream);
     if (rc != SPLAT_OK) return rc;
@@ -24,8 +33,9 @@ extern "C" int splat_frames_forward(const splat_frames_t *b) {
 // splat_frames_forward
 extern "C" int splat_frames_count(const splat_frames_t *b) {
     SPLAT_CHECK_ARG(b != nullptr && b->struct_bytes == sizeof(splat_frames_t), "splat_frames_t of another ABI version");
-    int rc = splat_preprocess_ortho_forward_batch(b->F, b->P, b->xyz, b->offsets, b->scales, b->uquats, b->extr, b->W, b->H,
-                                                  b->nearest, b->extent, b->uv, b->depth, b->conic, b->radius, b->stream);
+    const splat_camera_t cam = batch_camera(b);
+    int rc = splat_preprocess_forward_batch_cam(b->F, b->P, b->xyz, b->offsets, b->scales, b->uquats, &cam, b->W, b->H,
+                                                b->nearest, b->extent, b->uv, b->depth, b->conic, b->radius, b->stream);
     if (rc != SPLAT_OK) return rc;
     return splat_bin_count_batch(b->F, b->P, b->uv, b->radius, b->W, b->H, b->bin_scratch, b->tile_range, b->pairs, b->stream);
 }
@@ -37,8 +47,10 @@ extern "C" int splat_frames_backward(const splat_frames_t *b) {
                                                  b->final_T, b->ncontrib, b->dL_dout, b->want_abs, b->slot_sorted,
                                                  b->pair_records, b->pack, b->cull_flags, b->dbg_T_front, b->stream);
     if (rc != SPLAT_OK) return rc;
-    return splat_frames_gauss_backward_static(b->F, b->P, b->C, b->W, b->H, b->capacity, b->want_abs, b->pair_records,
-                                              b->goff_incl, b->radius, b->xyz, b->scales, b->uquats, b->extr, b->accumulate,
-                                              b->d_xyz, b->d_scales, b->d_uquats, b->d_opacity, b->d_feature, b->tap, b->abs_tap,
-                                              b->radii_max, b->stream);
+    SPLAT_CHECK_ARG(b->d_opacity && b->d_feature, "null gradient pointer");
+    const splat_camera_t cam = batch_camera(b);
+    return splat_frames_gauss_backward_static_cam(b->F, b->P, b->C, b->W, b->H, b->capacity, b->want_abs, b->pair_records,
+                                                  b->goff_incl, b->radius, b->xyz, b->scales, b->uquats, &cam, b->accumulate,
+                                                  b->d_xyz, b->d_scales, b->d_uquats, b->d_opacity, b->d_feature, b->C, 0, -1,
+                                                  b->tap, b->abs_tap, b->radii_max, b->stream);
 }

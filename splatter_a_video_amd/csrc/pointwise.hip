@@ -20,24 +20,9 @@ project_point_fwd_kernel(int P, const float *__restrict__ xyz, const float *__re
     Cam c;
     load_cam(ORTHO ? nullptr : intr, extr, c);
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    float tx, ty, tz;
-    cam_xform(c, x, y, z, tx, ty, tz);
     float u, v, d;
-    bool cull = false;
-    if (ORTHO) {
-        cull = project_ortho_pt(c, x, y, z, W, H, nearest, extent, u, v, d);
-    } else {
-        const float inv = (float)(1.0 / ((double)tz + 1e-7));
-        u = (float)((double)(c.fx * tx * inv + c.cx) - 0.5);
-        v = (float)((double)(c.fy * ty * inv + c.cy) - 0.5);
-        d = tz;
-        if (nearest > 0) cull = cull || (tz <= nearest);
-        if (extent > 0) {
-            const float xlo = (float)((double)((1 - extent) * W) * 0.5), xhi = (float)((double)((1 + extent) * W) * 0.5);
-            const float ylo = (float)((double)((1 - extent) * H) * 0.5), yhi = (float)((double)((1 + extent) * H) * 0.5);
-            cull = cull || (u < xlo) || (u > xhi) || (v < ylo) || (v > yhi);
-        }
-    }
+    const bool cull = ORTHO ? project_ortho_pt(c, x, y, z, W, H, nearest, extent, u, v, d)
+                            : project_persp_pt(c, x, y, z, W, H, nearest, extent, u, v, d);
     uv[2 * i] = cull ? 0.f : u;
     uv[2 * i + 1] = cull ? 0.f : v;
     depth[i] = cull ? 0.f : d;
@@ -70,14 +55,10 @@ project_point_bwd_kernel(int P, const float *__restrict__ xyz, const float *__re
             cam_xform(c, x, y, z, tx, ty, tz);
             const float n1 = (float)(1.0 / (double)tz);
             const float n2 = (float)(1.0 / (double)(tz * tz));
+            float g[3];
+            project_persp_grad_pt(c, x, y, z, gu, gv, gd, g);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                float g = 0.f;
-                g += (c.fx * (c.e[j] * tz - tx * c.e[8 + j]) * n2) * gu;
-                g += (c.fy * (c.e[4 + j] * tz - ty * c.e[8 + j]) * n2) * gv;
-                g += c.e[8 + j] * gd;
-                dL_dxyz[3 * i + j] = g;
-            }
+            for (int j = 0; j < 3; ++j) dL_dxyz[3 * i + j] = g[j];
             if (CAMGRAD) {
                 cg[0] = tx * n1 * gu; cg[1] = ty * n1 * gv; cg[2] = gu; cg[3] = gv;
                 const float p[4] = {x, y, z, 1.f};
@@ -216,27 +197,17 @@ ewa_bwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ c
             for (int k = 0; k < 6; ++k) o[k] = o6[k];
             wrote = true;
             if (!ORTHO) {
-                const float S[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
-                float da[3], db[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float Sa = a[0] * S[0][k] + a[1] * S[1][k] + a[2] * S[2][k];
-                    const float Sb = b[0] * S[0][k] + b[1] * S[1][k] + b[2] * S[2][k];
-                    da[k] = 2 * Sa * dcx + Sb * dcy;
-                    db[k] = Sa * dcy + 2 * Sb * dcz;
-                }
+                float da[3], db[3], dt[3], gpos[3];
+                ewa_grad_pos_persp_pt(c, t, a, b, c3, dcx, dcy, dcz, gpos, da, db, dt);
+                const float dtx = dt[0], dty = dt[1], dtz = dt[2];
                 const float dJ00 = c.e[0] * da[0] + c.e[1] * da[1] + c.e[2] * da[2];
                 const float dJ02 = c.e[8] * da[0] + c.e[9] * da[1] + c.e[10] * da[2];
                 const float dJ11 = c.e[4] * db[0] + c.e[5] * db[1] + c.e[6] * db[2];
                 const float dJ12 = c.e[8] * db[0] + c.e[9] * db[1] + c.e[10] * db[2];
-                const float tz = 1.f / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
-                const float dtx = -c.fx * tz2 * dJ02;
-                const float dty = -c.fy * tz2 * dJ12;
-                const float dtz = -c.fx * tz2 * dJ00 - c.fy * tz2 * dJ11 + (2 * c.fx * t[0]) * tz3 * dJ02 +
-                                  (2 * c.fy * t[1]) * tz3 * dJ12;
-                dL_dxyz[3 * i + 0] = c.e[0] * dtx + c.e[4] * dty + c.e[8] * dtz;
-                dL_dxyz[3 * i + 1] = c.e[1] * dtx + c.e[5] * dty + c.e[9] * dtz;
-                dL_dxyz[3 * i + 2] = c.e[2] * dtx + c.e[6] * dty + c.e[10] * dtz;
+                const float tz = 1.f / t[2], tz2 = tz * tz;
+                dL_dxyz[3 * i + 0] = gpos[0];
+                dL_dxyz[3 * i + 1] = gpos[1];
+                dL_dxyz[3 * i + 2] = gpos[2];
                 wrote_xyz = true;
                 if (CAMGRAD) {
                     cg[0] = tz * dJ00 - t[0] * tz2 * dJ02;

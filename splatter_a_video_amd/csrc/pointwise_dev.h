@@ -85,6 +85,67 @@ __device__ __forceinline__ bool project_ortho_pt(const Cam &c, float x, float y,
     return (d <= nearest) || (u < xlo) || (u > xhi) || (v < ylo) || (v > yhi);
 }
 
+// perspective projection + culling (reference: src/project_point.cu:23-56); returns the cull flag
+__device__ __forceinline__ bool project_persp_pt(const Cam &c, float x, float y, float z, int W, int H, float nearest,
+                                                 float extent, float &u, float &v, float &d) {
+    float tx, ty, tz;
+    cam_xform(c, x, y, z, tx, ty, tz);
+    const float inv = (float)(1.0 / ((double)tz + 1e-7));
+    u = (float)((double)(c.fx * tx * inv + c.cx) - 0.5);
+    v = (float)((double)(c.fy * ty * inv + c.cy) - 0.5);
+    d = tz;
+    bool cull = false;
+    if (nearest > 0) cull = cull || (tz <= nearest);
+    if (extent > 0) {
+        const float xlo = (float)((double)((1 - extent) * W) * 0.5), xhi = (float)((double)((1 + extent) * W) * 0.5);
+        const float ylo = (float)((double)((1 - extent) * H) * 0.5), yhi = (float)((double)((1 + extent) * H) * 0.5);
+        cull = cull || (u < xlo) || (u > xhi) || (v < ylo) || (v > yhi);
+    }
+    return cull;
+}
+
+// gradient of the perspective projection w.r.t. the point (reference: src/project_point.cu:72-105; no epsilon in 1 / tz)
+__device__ __forceinline__ void project_persp_grad_pt(const Cam &c, float x, float y, float z, float gu, float gv, float gd,
+                                                      float g[3]) {
+    float tx, ty, tz;
+    cam_xform(c, x, y, z, tx, ty, tz);
+    const float n2 = (float)(1.0 / (double)(tz * tz));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float a = 0.f;
+        a += (c.fx * (c.e[j] * tz - tx * c.e[8 + j]) * n2) * gu;
+        a += (c.fy * (c.e[4 + j] * tz - ty * c.e[8 + j]) * n2) * gv;
+        a += c.e[8 + j] * gd;
+        g[j] = a;
+    }
+}
+
+// position gradient of the perspective EWA projection (the Jacobian depends on the camera-space point): from dL/dcov2d
+// (dcx, dcy, dcz), the rows a, b of T = J R, the camera-space point t and the 3D covariance (reference: src/ewa_project.cu:152-205)
+__device__ __forceinline__ void ewa_grad_pos_persp_pt(const Cam &c, const float t[3], const float a[3], const float b[3],
+                                                      const float c3[6], float dcx, float dcy, float dcz, float g[3],
+                                                      float da[3], float db[3], float dt[3]) {
+    const float S[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float Sa = a[0] * S[0][k] + a[1] * S[1][k] + a[2] * S[2][k];
+        const float Sb = b[0] * S[0][k] + b[1] * S[1][k] + b[2] * S[2][k];
+        da[k] = 2 * Sa * dcx + Sb * dcy;
+        db[k] = Sa * dcy + 2 * Sb * dcz;
+    }
+    const float dJ00 = c.e[0] * da[0] + c.e[1] * da[1] + c.e[2] * da[2];
+    const float dJ02 = c.e[8] * da[0] + c.e[9] * da[1] + c.e[10] * da[2];
+    const float dJ11 = c.e[4] * db[0] + c.e[5] * db[1] + c.e[6] * db[2];
+    const float dJ12 = c.e[8] * db[0] + c.e[9] * db[1] + c.e[10] * db[2];
+    const float tz = 1.f / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+    dt[0] = -c.fx * tz2 * dJ02;
+    dt[1] = -c.fy * tz2 * dJ12;
+    dt[2] = -c.fx * tz2 * dJ00 - c.fy * tz2 * dJ11 + (2 * c.fx * t[0]) * tz3 * dJ02 + (2 * c.fy * t[1]) * tz3 * dJ12;
+    g[0] = c.e[0] * dt[0] + c.e[4] * dt[1] + c.e[8] * dt[2];
+    g[1] = c.e[1] * dt[0] + c.e[5] * dt[1] + c.e[9] * dt[2];
+    g[2] = c.e[2] * dt[0] + c.e[6] * dt[1] + c.e[10] * dt[2];
+}
+
 // gradient of the orthographic projection w.r.t. the point
 __device__ __forceinline__ void project_ortho_grad_pt(const Cam &c, int W, int H, float gu, float gv, float gd,
                                                       float g[3]) {

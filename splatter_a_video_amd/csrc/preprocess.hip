@@ -13,12 +13,18 @@ namespace {
 constexpr int PP_BLOCK = 256;
 inline dim3 pp_grid(int P) { return dim3((unsigned)((P + PP_BLOCK - 1) / PP_BLOCK)); }
 
+// ORTHO: the video renderer's camera (dptr_ortho_enhanced.py:177-202, 18-111); else the pinhole camera of gs.rasterization /
+// DPTRRender (project_point.cu, ewa_project.cu: reference src/submodules/dptr/dptr/gs/__init__.py:28-100, dptr.py:107-161).
+// The camera may differ from frame to frame (render_batch gives every batch element its own: dptr_ortho_enhanced.py:409-411):
+// frame f reads extr + f * extr_fs (and intr + f * intr_fs).
+template <bool ORTHO>
 __global__ void __launch_bounds__(PP_BLOCK)
-preprocess_ortho_fwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ offset,
-                            const float *__restrict__ scales, const float4 *__restrict__ uquats,
-                            const float *__restrict__ extr, int W, int H, float nearest, float extent,
-                            float2 *__restrict__ uv, float *__restrict__ depth, float *__restrict__ conic,
-                            int *__restrict__ radius, int *__restrict__ tiles) {
+preprocess_fwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ offset,
+                      const float *__restrict__ scales, const float4 *__restrict__ uquats,
+                      const float *__restrict__ intr, const float *__restrict__ extr, long long intr_fs, long long extr_fs,
+                      int W, int H, float nearest, float extent,
+                      float2 *__restrict__ uv, float *__restrict__ depth, float *__restrict__ conic,
+                      int *__restrict__ radius, int *__restrict__ tiles) {
     const int i = blockIdx.x * PP_BLOCK + threadIdx.x;
     if (i >= P) return;
     {   // frame batch: blockIdx.y = frame; offsets [F,P,3] in, [F,P,..] out
@@ -26,27 +32,30 @@ preprocess_ortho_fwd_kernel(int P, const float *__restrict__ xyz, const float *_
         if (offset) offset += f * 3 * P;
         uv += f * P; depth += f * P; conic += f * 3 * P; radius += f * P;
         if (tiles) tiles += f * P;
+        extr += f * extr_fs;
+        if (!ORTHO) intr += f * intr_fs;
     }
     Cam c;
-    load_cam(nullptr, extr, c);
+    load_cam(ORTHO ? nullptr : intr, extr, c);
     float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
     if (offset) {
         p[0] += offset[3 * i]; p[1] += offset[3 * i + 1]; p[2] += offset[3 * i + 2];
     }
     float u, v, d;
-    const bool cull = project_ortho_pt(c, p[0], p[1], p[2], W, H, nearest, extent, u, v, d);
+    const bool cull = ORTHO ? project_ortho_pt(c, p[0], p[1], p[2], W, H, nearest, extent, u, v, d)
+                            : project_persp_pt(c, p[0], p[1], p[2], W, H, nearest, extent, u, v, d);
     u = cull ? 0.f : u; v = cull ? 0.f : v; d = cull ? 0.f : d;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
     int orad = 0, otiles = 0;
-    if (d != 0.f) {  // the renderer's visibility mask (dptr_ortho_enhanced.py:288)
+    if (d != 0.f) {  // the renderers' visibility mask (dptr_ortho_enhanced.py:288, gs/__init__.py:60)
         const float4 q4 = uquats[i];
         const float q[4] = {q4.x, q4.y, q4.z, q4.w};
         const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
         float c3[6], a[3], b[3], t[3], Jm[4], cov[3];
         cov3d_pt(s, q, c3);
-        ewa_T<true>(c, p, W, H, a, b, t, Jm);
-        ewa_cov2d<true>(a, b, c3, cov);
-        ewa_finish_pt<true>(cov, make_float2(u, v), W, H, o0, o1, o2, orad, otiles);
+        ewa_T<ORTHO>(c, p, W, H, a, b, t, Jm);
+        ewa_cov2d<ORTHO>(a, b, c3, cov);
+        ewa_finish_pt<ORTHO>(cov, make_float2(u, v), W, H, o0, o1, o2, orad, otiles);
     }
     uv[i] = make_float2(u, v);
     depth[i] = d;
@@ -61,40 +70,50 @@ __device__ __forceinline__ void put(float *p, float v) {
     else *p = v;
 }
 
-template <bool ACC>
+template <bool ORTHO, bool ACC>
 __global__ void __launch_bounds__(PP_BLOCK)
-preprocess_ortho_bwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ offset,
-                            const float *__restrict__ scales, const float4 *__restrict__ uquats,
-                            const float *__restrict__ extr, int W, int H, const float *__restrict__ depth,
-                            const int *__restrict__ radius, const float *__restrict__ dL_duv,
-                            const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dconic,
-                            float *__restrict__ dL_dxyz, float *__restrict__ dL_dscales,
-                            float *__restrict__ dL_duquats) {
+preprocess_bwd_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ offset,
+                      const float *__restrict__ scales, const float4 *__restrict__ uquats,
+                      const float *__restrict__ intr, const float *__restrict__ extr, int W, int H,
+                      const float *__restrict__ depth,
+                      const int *__restrict__ radius, const float *__restrict__ dL_duv,
+                      const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dconic,
+                      float *__restrict__ dL_dxyz, float *__restrict__ dL_dscales,
+                      float *__restrict__ dL_duquats) {
     const int i = blockIdx.x * PP_BLOCK + threadIdx.x;
     if (i >= P) return;
     float gp[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
     if (depth[i] != 0.f) {
         Cam c;
-        load_cam(nullptr, extr, c);
-        if (dL_dxyz) project_ortho_grad_pt(c, W, H, dL_duv[2 * i], dL_duv[2 * i + 1], dL_ddepth ? dL_ddepth[i] : 0.f, gp);
-        if (radius[i] > 0 && (dL_dscales || dL_duquats)) {
-            float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-            if (offset) {
-                p[0] += offset[3 * i]; p[1] += offset[3 * i + 1]; p[2] += offset[3 * i + 2];
-            }
+        load_cam(ORTHO ? nullptr : intr, extr, c);
+        float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        if (offset) {
+            p[0] += offset[3 * i]; p[1] += offset[3 * i + 1]; p[2] += offset[3 * i + 2];
+        }
+        if (dL_dxyz) {
+            const float gu = dL_duv ? dL_duv[2 * i] : 0.f, gv = dL_duv ? dL_duv[2 * i + 1] : 0.f, gd = dL_ddepth ? dL_ddepth[i] : 0.f;
+            if (ORTHO) project_ortho_grad_pt(c, W, H, gu, gv, gd, gp);
+            else project_persp_grad_pt(c, p[0], p[1], p[2], gu, gv, gd, gp);
+        }
+        if (radius[i] > 0 && dL_dconic && (dL_dscales || dL_duquats || (!ORTHO && dL_dxyz))) {
             const float4 q4 = uquats[i];
             const float q[4] = {q4.x, q4.y, q4.z, q4.w};
             const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
             float c3[6], a[3], b[3], t[3], Jm[4], cov[3];
             cov3d_pt(s, q, c3);
-            ewa_T<true>(c, p, W, H, a, b, t, Jm);
-            ewa_cov2d<true>(a, b, c3, cov);
+            ewa_T<ORTHO>(c, p, W, H, a, b, t, Jm);
+            ewa_cov2d<ORTHO>(a, b, c3, cov);
             const float det = cov[0] * cov[2] - cov[1] * cov[1];
             if (det != 0.0f) {
                 const float g3[3] = {dL_dconic[3 * i], dL_dconic[3 * i + 1], dL_dconic[3 * i + 2]};
                 float dcx, dcy, dcz, g6[6];
                 ewa_grad_cov_pt(a, b, cov, det, g3, dcx, dcy, dcz, g6);
                 cov3d_grad_pt(s, q, g6, ds, dq);
+                if (!ORTHO) {  // the perspective Jacobian depends on the point (ewa_project.cu:152-205)
+                    float ge[3], da[3], db[3], dt[3];
+                    ewa_grad_pos_persp_pt(c, t, a, b, c3, dcx, dcy, dcz, ge, da, db, dt);
+                    gp[0] += ge[0]; gp[1] += ge[1]; gp[2] += ge[2];
+                }
             }
         }
     }
@@ -315,6 +334,10 @@ struct GaussBwdArgs {
     const float *xyz, *scales;
     const float4 *uquats;
     const float *extr;
+    // cameras that differ from frame to frame and / or the perspective camera: the projection chain runs per frame (CAM
+    // template parameter); frame f's camera = extr + f * extr_fs (intr + f * intr_fs), its positions = xyz + offsets[f]
+    const float *intr, *offsets;
+    long long extr_fs, intr_fs;
     float *d_xyz, *d_scales, *d_uquats, *d_opacity, *d_feature;
     float *tap, *abs_tap;   // optional [P,2]: sum over the frames of dL_duv * (W/2, H/2) (and of its abs twin)
     int *radii_max;         // optional [P]: max over the frames of the screen radius (visibility = radii_max > 0)
@@ -328,7 +351,26 @@ struct GaussBwdArgs {
     float *sdf[3];
 };
 
-template <bool ABS, int NCP, bool SETS = false>
+// component k of the quad's record sum (chunk k / 4 = lane (k / 4) & 3, register a[k / 16], element k & 3) on every lane
+template <int NS>
+__device__ __forceinline__ float record_component(const float4 (&a)[NS], int k, int sub) {
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        const float e4[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (k == 16 * c + 4 * sub + e) v = e4[e];
+    }
+    return quad_sum(v);  // exactly one lane holds it
+}
+
+// CAM: 0 = ONE orthographic camera for the batch: conic, radius and the projection Jacobian do not depend on the frame, the
+// chain is linear in the summed (dL_duv, dL_dconic): it runs once on the sums of all frames.  1 = orthographic cameras that
+// differ from frame to frame, 2 = perspective (its Jacobian depends on the point, hence on the frame's offset): the records
+// of every frame go through that frame's projection / EWA backward; only dL/dcov3d (linear into scale / rotation) is summed
+// over the frames first.
+template <bool ABS, int NCP, bool SETS = false, int CAM = 0>
 __global__ void __launch_bounds__(256)
 frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
     constexpr int NG = SETS ? 10 : GradLayout<ABS, false>::NG;
@@ -342,7 +384,24 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
     int rmax = 0;
     bool any = false;
     int nbeg = i > 0 ? A.goff[i - 1] : 0, nend = A.goff[i];
+    // per-frame chain (CAM > 0): position gradient and dL/dcov3d summed over the frames
+    float gpf[3] = {0.f, 0.f, 0.f}, g6f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float c3s[6], ss[3], qs[4];
+    if (CAM > 0) {
+        const float4 q4 = A.uquats[i];
+        qs[0] = q4.x; qs[1] = q4.y; qs[2] = q4.z; qs[3] = q4.w;
+        ss[0] = A.scales[3 * i]; ss[1] = A.scales[3 * i + 1]; ss[2] = A.scales[3 * i + 2];
+        cov3d_pt(ss, qs, c3s);
+    }
     for (int f = 0; f < A.F; ++f) {
+        float4 atot[CAM > 0 ? NS : 1];
+        if (CAM > 0) {   // this frame's records are summed on their own (a = this frame, atot = the frames before)
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                atot[c] = a[c];
+                a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         const int beg = nbeg, end = nend;
         if (f + 1 < A.F) {  // the next frame's slot range is in flight while this frame's records are summed
             const int *goff = A.goff + (size_t)(f + 1) * A.P;
@@ -376,26 +435,55 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
                 }
             }
         }
+        if (CAM > 0) {
+            if (end > beg) {  // a record exists: visible with radius > 0 in this frame (the chain's preconditions)
+                const float ux = quad_bcast<0>(a[0].x), uy = quad_bcast<0>(a[0].y);
+                const float g3[3] = {quad_bcast<0>(a[0].z), quad_bcast<0>(a[0].w), quad_bcast<1>(a[0].x)};
+                const float gdep = A.depth_channel >= 0 ? record_component<NS>(a, NG + A.depth_channel, sub) : 0.f;
+                Cam c;
+                load_cam(CAM == 2 ? A.intr + (size_t)f * A.intr_fs : nullptr, A.extr + (size_t)f * A.extr_fs, c);
+                float p[3] = {A.xyz[3 * i], A.xyz[3 * i + 1], A.xyz[3 * i + 2]};
+                if (A.offsets) {
+                    const float *o = A.offsets + ((size_t)f * A.P + i) * 3;
+                    p[0] += o[0]; p[1] += o[1]; p[2] += o[2];
+                }
+                float g[3];
+                if (CAM == 2) project_persp_grad_pt(c, p[0], p[1], p[2], ux, uy, gdep, g);
+                else project_ortho_grad_pt(c, A.W, A.H, ux, uy, gdep, g);
+                float ea[3], eb[3], et[3], Jm[4], cov[3];
+                ewa_T<CAM != 2>(c, p, A.W, A.H, ea, eb, et, Jm);
+                ewa_cov2d<CAM != 2>(ea, eb, c3s, cov);
+                const float det = cov[0] * cov[2] - cov[1] * cov[1];
+                if (det != 0.0f) {
+                    float dcx, dcy, dcz, g6[6];
+                    ewa_grad_cov_pt(ea, eb, cov, det, g3, dcx, dcy, dcz, g6);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) g6f[k] += g6[k];
+                    if (CAM == 2) {
+                        float ge[3], da[3], db[3], dt[3];
+                        ewa_grad_pos_persp_pt(c, et, ea, eb, c3s, dcx, dcy, dcz, ge, da, db, dt);
+                        g[0] += ge[0]; g[1] += ge[1]; g[2] += ge[2];
+                    }
+                }
+                gpf[0] += g[0]; gpf[1] += g[1]; gpf[2] += g[2];
+            }
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                a[c].x += atot[c].x; a[c].y += atot[c].y; a[c].z += atot[c].z; a[c].w += atot[c].w;
+            }
+        }
     }
     // geometry sums: chunk 0 (lane 0) = ux uy ca cb, chunk 1 (lane 1) = cc o [ax ay]
     const float ux = quad_bcast<0>(a[0].x), uy = quad_bcast<0>(a[0].y);
     const float g3[3] = {quad_bcast<0>(a[0].z), quad_bcast<0>(a[0].w), quad_bcast<1>(a[0].x)};
     const float dop = quad_bcast<1>(a[0].y);
-    float gdep = 0.f;  // dL/ddepth (a set whose channel `depth_channel` is the depth feature): component NG + channel
-    if (A.depth_channel >= 0) {
-        const int k = NG + A.depth_channel;  // chunk k / 4 -> lane (k / 4) & 3, register a[k / 16], element k & 3
-        float v = 0.f;
-#pragma unroll
-        for (int c = 0; c < NS; ++c) {
-            const float e4[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (k == 16 * c + 4 * sub + e) v = e4[e];
-        }
-        gdep = quad_sum(v);  // exactly one lane holds it
-    }
+    // dL/ddepth (a set whose channel `depth_channel` is the depth feature): component NG + channel
+    const float gdep = (CAM == 0 && A.depth_channel >= 0) ? record_component<NS>(a, NG + A.depth_channel, sub) : 0.f;
     float gp[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
-    if (any) {  // a record exists: the Gaussian was visible with radius > 0 in that frame (the chain's preconditions)
+    if (CAM > 0) {
+        gp[0] = gpf[0]; gp[1] = gpf[1]; gp[2] = gpf[2];
+        if (any) cov3d_grad_pt(ss, qs, g6f, ds, dq);
+    } else if (any) {  // a record exists: the Gaussian was visible with radius > 0 in that frame (the chain's preconditions)
         Cam c;
         load_cam(nullptr, A.extr, c);
         project_ortho_grad_pt(c, A.W, A.H, ux, uy, gdep, gp);
@@ -763,10 +851,10 @@ int launch_gauss_bwd_dynamic(const GaussDynArgs &A, int ncp, hipStream_t s) {
     return SPLAT_OK;
 }
 
-template <bool ABS>
+template <bool ABS, int CAM = 0>
 int launch_gauss_bwd_static(const GaussBwdArgs &A, int ncp, hipStream_t s) {
     const dim3 grid((unsigned)(((size_t)A.P * 4 + 255) / 256)), block(256);
-#define GB(N) case N: SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_static_kernel<ABS, N>), grid, block, 0, s, A); break
+#define GB(N) case N: SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_static_kernel<ABS, N, false, CAM>), grid, block, 0, s, A); break
     switch (ncp) {
         GB(8); GB(12); GB(16); GB(20); GB(24); GB(28); GB(32); GB(36); GB(40);
         default: splat_set_error("gauss_bwd: unsupported record stride %d", ncp); return SPLAT_E_ARG;
@@ -788,9 +876,10 @@ int launch_gauss_bwd_dynamic_sets(const GaussDynArgs &A, int ncp, hipStream_t s)
     return SPLAT_OK;
 }
 
+template <int CAM = 0>
 int launch_gauss_bwd_static_sets(const GaussBwdArgs &A, int ncp, hipStream_t s) {
     const dim3 grid((unsigned)(((size_t)A.P * 4 + 255) / 256)), block(256);
-#define GS(N) case N: SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_static_kernel<true, N, true>), grid, block, 0, s, A); break
+#define GS(N) case N: SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_static_kernel<true, N, true, CAM>), grid, block, 0, s, A); break
     switch (ncp) {
         GS(12); GS(16); GS(20); GS(24); GS(28); GS(32); GS(36); GS(40);
         default: splat_set_error("gauss_bwd: unsupported record stride %d", ncp); return SPLAT_E_ARG;
@@ -808,6 +897,25 @@ extern "C" size_t splat_blend_sets_pair_stride(int C);
 // Gaussian side of splat_alpha_blending_backward_batch_sets: sums the SETS records of every Gaussian over the F frames and
 // runs the projection chain once.  set_dfeature: HOST array of three device pointers (NULL entries: no gradient wanted for
 // that set; the channel `depth_channel` of the row, if >= 0, is the per-frame depth and feeds d_xyz instead).
+// camera of a batch -> kernel arguments; returns the chain mode (CAM of frames_gauss_bwd_static_kernel) or -1
+static int set_camera(GaussBwdArgs &A, const splat_camera_t *cam, int F) {
+    if (!cam || !cam->extr) return -1;
+    A.extr = cam->extr; A.intr = cam->intr; A.offsets = cam->offsets;
+    A.extr_fs = cam->extr_frame_stride; A.intr_fs = cam->intr_frame_stride;
+    if (cam->perspective) return cam->intr ? 2 : -1;
+    return (cam->extr_frame_stride != 0 && F > 1) ? 1 : 0;
+}
+
+extern "C" int splat_frames_gauss_backward_static_sets_cam(int F, int P, int C, int W, int H, int64_t capacity,
+                                                           const float *pair_records, const int32_t *goff_incl,
+                                                           const int32_t *radius, const float *xyz, const float *scales,
+                                                           const float *uquats, const splat_camera_t *cam, int accumulate,
+                                                           float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                                           const int32_t *set_c0, const int32_t *set_cn,
+                                                           float *const *set_dfeature, const int32_t *set_stride,
+                                                           int depth_channel, float *tap, float *abs_tap,
+                                                           int32_t *radii_max, void *stream);
+
 extern "C" int splat_frames_gauss_backward_static_sets(int F, int P, int C, int W, int H, int64_t capacity,
                                                        const float *pair_records, const int32_t *goff_incl,
                                                        const int32_t *radius, const float *xyz, const float *scales,
@@ -817,8 +925,25 @@ extern "C" int splat_frames_gauss_backward_static_sets(int F, int P, int C, int 
                                                        float *const *set_dfeature, const int32_t *set_stride,
                                                        int depth_channel, float *tap, float *abs_tap,
                                                        int32_t *radii_max, void *stream) {
+    splat_camera_t cam;
+    memset(&cam, 0, sizeof(cam));
+    cam.extr = extr;
+    return splat_frames_gauss_backward_static_sets_cam(F, P, C, W, H, capacity, pair_records, goff_incl, radius, xyz, scales, uquats,
+                                                       &cam, accumulate, d_xyz, d_scales, d_uquats, d_opacity, set_c0, set_cn,
+                                                       set_dfeature, set_stride, depth_channel, tap, abs_tap, radii_max, stream);
+}
+
+extern "C" int splat_frames_gauss_backward_static_sets_cam(int F, int P, int C, int W, int H, int64_t capacity,
+                                                           const float *pair_records, const int32_t *goff_incl,
+                                                           const int32_t *radius, const float *xyz, const float *scales,
+                                                           const float *uquats, const splat_camera_t *cam, int accumulate,
+                                                           float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                                           const int32_t *set_c0, const int32_t *set_cn,
+                                                           float *const *set_dfeature, const int32_t *set_stride,
+                                                           int depth_channel, float *tap, float *abs_tap,
+                                                           int32_t *radii_max, void *stream) {
     SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 28 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 28)");
-    SPLAT_CHECK_ARG(pair_records && goff_incl && xyz && scales && uquats && extr, "null input pointer");
+    SPLAT_CHECK_ARG(pair_records && goff_incl && xyz && scales && uquats && cam, "null input pointer");
     SPLAT_CHECK_ARG(d_xyz && d_scales && d_uquats && d_opacity, "null gradient pointer");
     SPLAT_CHECK_ARG(set_c0 && set_cn && set_dfeature && set_stride, "null set table");
     SPLAT_CHECK_ARG(depth_channel < C, "depth_channel outside the row");
@@ -828,37 +953,83 @@ extern "C" int splat_frames_gauss_backward_static_sets(int F, int P, int C, int 
     A.F = F; A.P = P; A.W = W; A.H = H; A.C = C; A.cn = C; A.cap = capacity;
     A.skip_opacity = 0; A.depth_channel = depth_channel;
     A.pair = pair_records; A.goff = goff_incl; A.radius = radius;
-    A.xyz = xyz; A.scales = scales; A.uquats = (const float4 *)uquats; A.extr = extr;
+    A.xyz = xyz; A.scales = scales; A.uquats = (const float4 *)uquats;
+    const int mode = set_camera(A, cam, F);
+    SPLAT_CHECK_ARG(mode >= 0, "camera: extr (and intr for the perspective camera) must be set");
     A.d_xyz = d_xyz; A.d_scales = d_scales; A.d_uquats = d_uquats; A.d_opacity = d_opacity;
     A.tap = tap; A.abs_tap = abs_tap; A.radii_max = radii_max; A.accumulate = accumulate;
     for (int g = 0; g < 3; ++g) {
         A.sc0[g] = set_c0[g]; A.scn[g] = set_cn[g]; A.sstride[g] = set_stride[g]; A.sdf[g] = set_dfeature[g];
         SPLAT_CHECK_ARG(set_cn[g] == 0 || !set_dfeature[g] || set_stride[g] >= set_cn[g], "feature stride below the set width");
     }
-    return launch_gauss_bwd_static_sets(A, (int)splat_blend_sets_pair_stride(C), (hipStream_t)stream);
+    const int ncp = (int)splat_blend_sets_pair_stride(C);
+    return mode == 0 ? launch_gauss_bwd_static_sets<0>(A, ncp, (hipStream_t)stream)
+         : mode == 1 ? launch_gauss_bwd_static_sets<1>(A, ncp, (hipStream_t)stream)
+                     : launch_gauss_bwd_static_sets<2>(A, ncp, (hipStream_t)stream);
+}
+
+extern "C" int splat_preprocess_forward_batch_cam(int F, int P, const float *xyz, const float *offsets,
+                                                  const float *scales, const float *uquats, const splat_camera_t *cam, int W,
+                                                  int H, float nearest, float extent, float *uv, float *depth,
+                                                  float *conic, int32_t *radius, void *stream) {
+    SPLAT_CHECK_ARG(F >= 1 && F <= 65535 && P >= 1 && W > 0 && H > 0, "bad sizes");
+    SPLAT_CHECK_ARG(xyz && scales && uquats && cam && cam->extr && uv && depth && conic && radius, "null pointer");
+    SPLAT_CHECK_ARG(!cam->perspective || cam->intr, "the perspective camera needs intr");
+    SPLAT_CHECK_ARG(F == 1 || offsets || cam->extr_frame_stride != 0,
+                    "several frames of static Gaussians need per-frame offsets [F,P,3] or per-frame cameras");
+    const dim3 grid = pp_grid(P);
+    if (cam->perspective)
+        SPLAT_LAUNCH("preprocess_fwd", preprocess_fwd_kernel<false>, dim3(grid.x, F), dim3(PP_BLOCK), 0, (hipStream_t)stream, P,
+                     xyz, offsets, scales, (const float4 *)uquats, cam->intr, cam->extr, (long long)cam->intr_frame_stride,
+                     (long long)cam->extr_frame_stride, W, H, nearest, extent, (float2 *)uv, depth, conic, radius, (int *)nullptr);
+    else
+        SPLAT_LAUNCH("preprocess_fwd", preprocess_fwd_kernel<true>, dim3(grid.x, F), dim3(PP_BLOCK), 0, (hipStream_t)stream, P,
+                     xyz, offsets, scales, (const float4 *)uquats, (const float *)nullptr, cam->extr, 0ll,
+                     (long long)cam->extr_frame_stride, W, H, nearest, extent, (float2 *)uv, depth, conic, radius, (int *)nullptr);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
 }
 
 extern "C" int splat_preprocess_ortho_forward_batch(int F, int P, const float *xyz, const float *offsets,
                                                     const float *scales, const float *uquats, const float *extr, int W,
                                                     int H, float nearest, float extent, float *uv, float *depth,
                                                     float *conic, int32_t *radius, void *stream) {
-    SPLAT_CHECK_ARG(F >= 1 && F <= 65535 && P >= 1 && W > 0 && H > 0, "bad sizes");
-    SPLAT_CHECK_ARG(xyz && scales && uquats && extr && uv && depth && conic && radius, "null pointer");
+    splat_camera_t cam;
+    memset(&cam, 0, sizeof(cam));
+    cam.extr = extr;
     SPLAT_CHECK_ARG(F == 1 || offsets, "several frames of static Gaussians need per-frame offsets [F,P,3]");
-    const dim3 grid = pp_grid(P);
-    SPLAT_LAUNCH("preprocess_fwd", preprocess_ortho_fwd_kernel, dim3(grid.x, F), dim3(PP_BLOCK), 0, (hipStream_t)stream, P,
-                 xyz, offsets, scales, (const float4 *)uquats, extr, W, H, nearest, extent, (float2 *)uv, depth, conic,
-                 radius, (int *)nullptr);
-    SPLAT_POST_LAUNCH();
-    return SPLAT_OK;
+    return splat_preprocess_forward_batch_cam(F, P, xyz, offsets, scales, uquats, &cam, W, H, nearest, extent, uv, depth, conic,
+                                              radius, stream);
 }
 
 static int gauss_backward_static(int F, int P, int C, int W, int H, int64_t capacity, int want_abs,
                                  const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
-                                 const float *xyz, const float *scales, const float *uquats, const float *extr,
+                                 const float *xyz, const float *scales, const float *uquats, const splat_camera_t *cam,
                                  int accumulate, float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
                                  float *d_feature, int feature_stride, int skip_opacity, int depth_channel, float *tap,
                                  float *abs_tap, int32_t *radii_max, void *stream);
+static splat_camera_t ortho_camera(const float *extr) {
+    splat_camera_t cam;
+    memset(&cam, 0, sizeof(cam));
+    cam.extr = extr;
+    return cam;
+}
+
+// one feature set under any camera of splat_camera_t (per-frame cameras, perspective): the general form of the two below
+extern "C" int splat_frames_gauss_backward_static_cam(int F, int P, int cn, int W, int H, int64_t capacity, int want_abs,
+                                                      const float *pair_records, const int32_t *goff_incl,
+                                                      const int32_t *radius, const float *xyz, const float *scales,
+                                                      const float *uquats, const splat_camera_t *cam, int accumulate,
+                                                      float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                                      float *d_feature, int feature_stride, int skip_opacity,
+                                                      int depth_channel, float *tap, float *abs_tap, int32_t *radii_max,
+                                                      void *stream) {
+    SPLAT_CHECK_ARG(skip_opacity || d_opacity, "null gradient pointer");
+    SPLAT_CHECK_ARG(depth_channel < cn, "depth_channel outside the set");
+    return gauss_backward_static(F, P, cn, W, H, capacity, want_abs, pair_records, goff_incl, radius, xyz, scales, uquats, cam,
+                                 accumulate, d_xyz, d_scales, d_uquats, d_opacity, d_feature, feature_stride, skip_opacity,
+                                 depth_channel, tap, abs_tap, radii_max, stream);
+}
 
 extern "C" int splat_frames_gauss_backward_static(int F, int P, int C, int W, int H, int64_t capacity, int want_abs,
                                                   const float *pair_records, const int32_t *goff_incl,
@@ -868,7 +1039,8 @@ extern "C" int splat_frames_gauss_backward_static(int F, int P, int C, int W, in
                                                   float *d_feature, float *tap, float *abs_tap, int32_t *radii_max,
                                                   void *stream) {
     SPLAT_CHECK_ARG(d_opacity && d_feature, "null gradient pointer");
-    return gauss_backward_static(F, P, C, W, H, capacity, want_abs, pair_records, goff_incl, radius, xyz, scales, uquats, extr,
+    const splat_camera_t cam = ortho_camera(extr);
+    return gauss_backward_static(F, P, C, W, H, capacity, want_abs, pair_records, goff_incl, radius, xyz, scales, uquats, &cam,
                                  accumulate, d_xyz, d_scales, d_uquats, d_opacity, d_feature, C, 0, -1, tap, abs_tap, radii_max,
                                  stream);
 }
@@ -885,19 +1057,20 @@ extern "C" int splat_frames_gauss_backward_static_set(int F, int P, int cn, int 
                                                       void *stream) {
     SPLAT_CHECK_ARG(skip_opacity || d_opacity, "null gradient pointer");
     SPLAT_CHECK_ARG(depth_channel < cn, "depth_channel outside the set");
-    return gauss_backward_static(F, P, cn, W, H, capacity, want_abs, pair_records, goff_incl, radius, xyz, scales, uquats, extr,
+    const splat_camera_t cam = ortho_camera(extr);
+    return gauss_backward_static(F, P, cn, W, H, capacity, want_abs, pair_records, goff_incl, radius, xyz, scales, uquats, &cam,
                                  accumulate, d_xyz, d_scales, d_uquats, d_opacity, d_feature, feature_stride, skip_opacity,
                                  depth_channel, tap, abs_tap, radii_max, stream);
 }
 
 static int gauss_backward_static(int F, int P, int C, int W, int H, int64_t capacity, int want_abs,
                                  const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
-                                 const float *xyz, const float *scales, const float *uquats, const float *extr,
+                                 const float *xyz, const float *scales, const float *uquats, const splat_camera_t *cam,
                                  int accumulate, float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
                                  float *d_feature, int feature_stride, int skip_opacity, int depth_channel, float *tap,
                                  float *abs_tap, int32_t *radii_max, void *stream) {
     SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 32 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 32)");
-    SPLAT_CHECK_ARG(pair_records && goff_incl && xyz && scales && uquats && extr, "null input pointer");
+    SPLAT_CHECK_ARG(pair_records && goff_incl && xyz && scales && uquats && cam, "null input pointer");
     SPLAT_CHECK_ARG(d_xyz && d_scales && d_uquats, "null gradient pointer");
     SPLAT_CHECK_ARG(!abs_tap || want_abs, "abs_tap needs records with the abs sums");
     SPLAT_CHECK_ARG(!radii_max || radius, "radii_max needs the per-frame radius");
@@ -906,12 +1079,16 @@ static int gauss_backward_static(int F, int P, int C, int W, int H, int64_t capa
     A.F = F; A.P = P; A.W = W; A.H = H; A.C = feature_stride; A.cn = C; A.cap = capacity;
     A.skip_opacity = skip_opacity; A.depth_channel = depth_channel;
     A.pair = pair_records; A.goff = goff_incl; A.radius = radius;
-    A.xyz = xyz; A.scales = scales; A.uquats = (const float4 *)uquats; A.extr = extr;
+    A.xyz = xyz; A.scales = scales; A.uquats = (const float4 *)uquats;
+    const int mode = set_camera(A, cam, F);
+    SPLAT_CHECK_ARG(mode >= 0, "camera: extr (and intr for the perspective camera) must be set");
     A.d_xyz = d_xyz; A.d_scales = d_scales; A.d_uquats = d_uquats; A.d_opacity = d_opacity; A.d_feature = d_feature;
     A.tap = tap; A.abs_tap = abs_tap; A.radii_max = radii_max; A.accumulate = accumulate;
     const int ncp = (int)splat_blend_pair_stride(C, want_abs, 0);
-    return want_abs ? launch_gauss_bwd_static<true>(A, ncp, (hipStream_t)stream)
-                    : launch_gauss_bwd_static<false>(A, ncp, (hipStream_t)stream);
+    hipStream_t hs = (hipStream_t)stream;
+    if (mode == 0) return want_abs ? launch_gauss_bwd_static<true, 0>(A, ncp, hs) : launch_gauss_bwd_static<false, 0>(A, ncp, hs);
+    if (mode == 1) return want_abs ? launch_gauss_bwd_static<true, 1>(A, ncp, hs) : launch_gauss_bwd_static<false, 1>(A, ncp, hs);
+    return want_abs ? launch_gauss_bwd_static<true, 2>(A, ncp, hs) : launch_gauss_bwd_static<false, 2>(A, ncp, hs);
 }
 
 extern "C" int splat_preprocess_ortho_forward(int P, const float *xyz, const float *offset, const float *scales,
@@ -921,9 +1098,48 @@ extern "C" int splat_preprocess_ortho_forward(int P, const float *xyz, const flo
     SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0, "bad sizes");
     if (P == 0) return SPLAT_OK;
     SPLAT_CHECK_ARG(xyz && scales && uquats && extr && uv && depth && conic && radius && tiles, "null pointer");
-    SPLAT_LAUNCH("preprocess_fwd", preprocess_ortho_fwd_kernel, pp_grid(P), dim3(PP_BLOCK), 0, (hipStream_t)stream, P, xyz,
-                 offset, scales, (const float4 *)uquats, extr, W, H, nearest, extent, (float2 *)uv, depth, conic, radius,
-                 tiles);
+    SPLAT_LAUNCH("preprocess_fwd", preprocess_fwd_kernel<true>, pp_grid(P), dim3(PP_BLOCK), 0, (hipStream_t)stream, P, xyz,
+                 offset, scales, (const float4 *)uquats, (const float *)nullptr, extr, 0ll, 0ll, W, H, nearest, extent,
+                 (float2 *)uv, depth, conic, radius, tiles);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+// The pinhole camera's chain of gs.rasterization / DPTRRender (project_point -> compute_cov3d -> ewa_project; reference
+// src/submodules/dptr/dptr/gs/__init__.py:55-77, dptr.py:107-147) in one pass, forward and backward (position gradient
+// through the projection AND the EWA Jacobian; camera gradients: the separate operators).
+extern "C" int splat_preprocess_persp_forward(int P, const float *xyz, const float *offset, const float *scales,
+                                              const float *uquats, const float *intr, const float *extr, int W, int H,
+                                              float nearest, float extent, float *uv, float *depth, float *conic,
+                                              int32_t *radius, int32_t *tiles, void *stream) {
+    SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0, "bad sizes");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(xyz && scales && uquats && intr && extr && uv && depth && conic && radius && tiles, "null pointer");
+    SPLAT_LAUNCH("preprocess_fwd", preprocess_fwd_kernel<false>, pp_grid(P), dim3(PP_BLOCK), 0, (hipStream_t)stream, P, xyz,
+                 offset, scales, (const float4 *)uquats, intr, extr, 0ll, 0ll, W, H, nearest, extent, (float2 *)uv, depth, conic,
+                 radius, tiles);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+extern "C" int splat_preprocess_persp_backward(int P, const float *xyz, const float *offset, const float *scales,
+                                               const float *uquats, const float *intr, const float *extr, int W, int H,
+                                               const float *depth, const int32_t *radius, const float *dL_duv,
+                                               const float *dL_ddepth, const float *dL_dconic, int accumulate,
+                                               float *dL_dxyz, float *dL_dscales, float *dL_duquats, void *stream) {
+    SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0, "bad sizes");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(xyz && scales && uquats && intr && extr && depth && radius, "null pointer");
+    SPLAT_CHECK_ARG(!(dL_dscales || dL_duquats) || dL_dconic, "scale / rotation gradients need dL_dconic");
+    hipStream_t s = (hipStream_t)stream;
+    if (accumulate)
+        SPLAT_LAUNCH("preprocess_bwd", (preprocess_bwd_kernel<false, true>), pp_grid(P), dim3(PP_BLOCK), 0, s, P, xyz, offset,
+                     scales, (const float4 *)uquats, intr, extr, W, H, depth, radius, dL_duv, dL_ddepth, dL_dconic, dL_dxyz,
+                     dL_dscales, dL_duquats);
+    else
+        SPLAT_LAUNCH("preprocess_bwd", (preprocess_bwd_kernel<false, false>), pp_grid(P), dim3(PP_BLOCK), 0, s, P, xyz, offset,
+                     scales, (const float4 *)uquats, intr, extr, W, H, depth, radius, dL_duv, dL_ddepth, dL_dconic, dL_dxyz,
+                     dL_dscales, dL_duquats);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }
@@ -940,13 +1156,13 @@ extern "C" int splat_preprocess_ortho_backward(int P, const float *xyz, const fl
     SPLAT_CHECK_ARG(!(dL_dscales || dL_duquats) || dL_dconic, "scale / rotation gradients need dL_dconic");
     hipStream_t s = (hipStream_t)stream;
     if (accumulate)
-        SPLAT_LAUNCH("preprocess_bwd", preprocess_ortho_bwd_kernel<true>, pp_grid(P), dim3(PP_BLOCK), 0, s, P, xyz, offset,
-                     scales, (const float4 *)uquats, extr, W, H, depth, radius, dL_duv, dL_ddepth, dL_dconic, dL_dxyz,
-                     dL_dscales, dL_duquats);
+        SPLAT_LAUNCH("preprocess_bwd", (preprocess_bwd_kernel<true, true>), pp_grid(P), dim3(PP_BLOCK), 0, s, P, xyz, offset,
+                     scales, (const float4 *)uquats, (const float *)nullptr, extr, W, H, depth, radius, dL_duv, dL_ddepth,
+                     dL_dconic, dL_dxyz, dL_dscales, dL_duquats);
     else
-        SPLAT_LAUNCH("preprocess_bwd", preprocess_ortho_bwd_kernel<false>, pp_grid(P), dim3(PP_BLOCK), 0, s, P, xyz, offset,
-                     scales, (const float4 *)uquats, extr, W, H, depth, radius, dL_duv, dL_ddepth, dL_dconic, dL_dxyz,
-                     dL_dscales, dL_duquats);
+        SPLAT_LAUNCH("preprocess_bwd", (preprocess_bwd_kernel<true, false>), pp_grid(P), dim3(PP_BLOCK), 0, s, P, xyz, offset,
+                     scales, (const float4 *)uquats, (const float *)nullptr, extr, W, H, depth, radius, dL_duv, dL_ddepth,
+                     dL_dconic, dL_dxyz, dL_dscales, dL_duquats);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }

@@ -35,13 +35,63 @@ _FRAMES_FIELDS = ([("struct_bytes", ctypes.c_size_t)]
                       "xyz", "offsets", "scales", "uquats", "opacity", "feature", "extr", "uv", "depth", "conic", "radius",
                       "bin_scratch", "tile_range", "pairs", "overflow", "goff_incl", "owner", "idx_sorted", "slot_sorted", "keys",
                       "pack", "out", "final_T", "ncontrib", "dL_dout", "pair_records", "d_xyz", "d_scales", "d_uquats",
-                      "d_opacity", "d_feature", "tap", "abs_tap", "radii_max", "dbg_T_front", "cull_flags")])
+                      "d_opacity", "d_feature", "tap", "abs_tap", "radii_max", "dbg_T_front", "cull_flags")]
+                  + [("extr_frame_stride", ctypes.c_int64), ("intr_frame_stride", ctypes.c_int64), ("intr", ctypes.c_void_p),
+                     ("perspective", ctypes.c_int32)])
 
 
 class _SplatFrames(ctypes.Structure):
     """mirror of splat_frames_t (include/splat_hip.h): every pointer of a batch, for the one-call entry points (the
     library checks ``struct_bytes`` against its own sizeof)"""
     _fields_ = _FRAMES_FIELDS
+
+
+class _SplatCamera(ctypes.Structure):
+    """mirror of splat_camera_t (include/splat_hip.h)"""
+    _fields_ = [("perspective", ctypes.c_int32), ("intr", ctypes.c_void_p), ("intr_frame_stride", ctypes.c_int64),
+                ("extr", ctypes.c_void_p), ("extr_frame_stride", ctypes.c_int64), ("offsets", ctypes.c_void_p)]
+
+
+class _Camera:
+    """Camera of a batch: ``extr`` one world-to-camera matrix ([4,4] / [3,4]) or one per frame ([F,4,4] / [F,3,4] -- the
+    reference's render_batch gives every batch element its own, dptr_ortho_enhanced.py:409-411); ``intr`` None: the
+    orthographic camera of the video renderer, else the pinhole camera's (fx, fy, cx, cy), [4] or [F,4]."""
+
+    def __init__(self, extr: Tensor, intr: Optional[Tensor], F: int):
+        extr = L.need(extr, "extr")
+        if extr.dim() == 3:
+            if extr.shape[0] != F or tuple(extr.shape[1:]) not in ((4, 4), (3, 4)):
+                raise ValueError(f"per-frame extr must be [F={F}, 4, 4] or [F, 3, 4]")
+            self.extr_fs = int(extr.shape[1] * extr.shape[2])
+        else:
+            if extr.numel() < 12:
+                raise ValueError("extr must hold at least 3x4 floats (row-major [R|T])")
+            self.extr_fs = 0
+        self.extr = extr
+        self.intr, self.intr_fs = None, 0
+        if intr is not None:
+            intr = L.need(intr, "intr")
+            if intr.dim() == 2:
+                if tuple(intr.shape) != (F, 4):
+                    raise ValueError(f"per-frame intr must be [F={F}, 4]")
+                self.intr_fs = 4
+            elif intr.numel() < 4:
+                raise ValueError("intr must be [fx, fy, cx, cy]")
+            self.intr = intr
+        self.perspective = intr is not None
+
+    def struct(self, offsets: Optional[Tensor] = None) -> _SplatCamera:
+        c = _SplatCamera()
+        c.perspective = 1 if self.perspective else 0
+        c.intr = None if self.intr is None else self.intr.data_ptr()
+        c.intr_frame_stride = self.intr_fs
+        c.extr = self.extr.data_ptr()
+        c.extr_frame_stride = self.extr_fs
+        c.offsets = None if offsets is None else offsets.data_ptr()
+        return c
+
+    def tensors(self):
+        return (self.extr,) if self.intr is None else (self.extr, self.intr)
 
 
 def _tiles(W: int, H: int) -> int:
@@ -138,13 +188,13 @@ class FrameBatch:
         return sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, Tensor))
 
     # ------------------------------------------------------------------ forward / backward launch sequences
-    def _geometry(self, xyz, scales, uquats, offsets, extr, nearest, extent):
-        """orthographic preprocess + tile binning + per-tile depth sort of all frames"""
+    def _geometry(self, xyz, scales, uquats, offsets, cam: "_Camera", nearest, extent):
+        """fused preprocess (projection + cov3d + EWA under the batch's camera) + tile binning + per-tile depth sort of all frames"""
         lib, st = L.lib(), L.stream()
         F_, P_, W, H = self.F, self.P, self.W, self.H
-        L.check(lib.splat_preprocess_ortho_forward_batch(
-            L.ci(F_), L.ci(P_), L.ptr(xyz), L.ptr(offsets), L.ptr(scales), L.ptr(uquats), L.ptr(extr), L.ci(W), L.ci(H),
-            L.cf(nearest), L.cf(extent), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.conic), L.ptr(self.radius), st))
+        L.check(lib.splat_preprocess_forward_batch_cam(
+            L.ci(F_), L.ci(P_), L.ptr(xyz), L.ptr(offsets), L.ptr(scales), L.ptr(uquats), ctypes.byref(cam.struct()), L.ci(W),
+            L.ci(H), L.cf(nearest), L.cf(extent), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.conic), L.ptr(self.radius), st))
         self._bin_and_sort()
 
     def _bin_and_sort(self):
@@ -160,8 +210,12 @@ class FrameBatch:
             L.ptr(self.bin_scratch), L.ptr(self.tile_range), ctypes.c_int64(cap), L.ptr(self.keys), L.ptr(self.idx_sorted),
             L.ptr(self.overflow), L.ptr(self.goff), L.ptr(self.owner), L.ptr(self.slot_sorted), st))
 
-    def _struct(self, xyz, scales, uquats, opacity, feature, offsets, extr, bg, nearest=0.01, extent=1.3) -> _SplatFrames:
+    def _struct(self, xyz, scales, uquats, opacity, feature, offsets, cam, bg, nearest=0.01, extent=1.3) -> _SplatFrames:
         b = _SplatFrames()
+        extr = cam.extr
+        b.extr_frame_stride, b.intr_frame_stride = cam.extr_fs, cam.intr_fs
+        b.intr = None if cam.intr is None else cam.intr.data_ptr()
+        b.perspective = 1 if cam.perspective else 0
         b.struct_bytes = ctypes.sizeof(_SplatFrames)
         b.F, b.P, b.W, b.H, b.C = self.F, self.P, self.W, self.H, self.C
         b.want_abs = 1 if self.want_abs else 0
@@ -179,21 +233,21 @@ class FrameBatch:
             setattr(b, name, dp(t))
         return b
 
-    def _forward_onecall(self, xyz, scales, uquats, opacity, feature, offsets, extr, bg, nearest, extent):
+    def _forward_onecall(self, xyz, scales, uquats, opacity, feature, offsets, cam, bg, nearest, extent):
         """the whole forward of the batch behind ONE crossing of the C ABI (splat_frames_forward)"""
         lib = L.lib()
         if self.capacity is None:      # first batch: size the pair buffers (the only host sync of the object's life)
-            L.check(lib.splat_frames_count(ctypes.byref(self._struct(xyz, scales, uquats, opacity, feature, offsets, extr, bg,
+            L.check(lib.splat_frames_count(ctypes.byref(self._struct(xyz, scales, uquats, opacity, feature, offsets, cam, bg,
                                                                      nearest, extent))))
             self._reserve(int(int(self.pairs.max().item()) * self.slack) + 1024)
         out = torch.empty(self.F, self.C, self.H, self.W, dtype=torch.float32, device=self.dev)
-        b = self._struct(xyz, scales, uquats, opacity, feature, offsets, extr, bg, nearest, extent)
+        b = self._struct(xyz, scales, uquats, opacity, feature, offsets, cam, bg, nearest, extent)
         b.out = out.data_ptr()
         L.check(lib.splat_frames_forward(ctypes.byref(b)))
         return out
 
-    def _backward_onecall(self, dL_dout, xyz, scales, uquats, extr, bg, bufs, accumulate, dbg=None):
-        b = self._struct(xyz, scales, uquats, None, None, None, extr, bg)
+    def _backward_onecall(self, dL_dout, xyz, scales, uquats, offsets, cam, bg, bufs, accumulate, dbg=None):
+        b = self._struct(xyz, scales, uquats, None, None, offsets, cam, bg)
         b.accumulate = 1 if accumulate else 0
         b.dL_dout = dL_dout.data_ptr()
         b.d_xyz, b.d_scales, b.d_uquats = bufs["xyz"].data_ptr(), bufs["scales"].data_ptr(), bufs["uquats"].data_ptr()
@@ -204,16 +258,19 @@ class FrameBatch:
     # ------------------------------------------------------------------ public
     def render(self, xyz: Tensor, scales: Tensor, uquats: Tensor, opacity: Tensor, feature: Tensor, offsets: Optional[Tensor],
                extr: Tensor, bg: float = 0.0, nearest: float = 0.01, extent: float = 1.3,
-               grad_sink: Optional[Dict[str, Tensor]] = None) -> Tensor:
+               grad_sink: Optional[Dict[str, Tensor]] = None, intr: Optional[Tensor] = None) -> Tensor:
         """images [F,C,H,W] of the F frames ``xyz + offsets[f]`` (static scale / rotation / opacity / feature [P,C]) under
-        the orthographic camera ``extr``.  Differentiable w.r.t. xyz, scales, uquats, opacity, feature; the backward ADDS
+        the orthographic camera ``extr`` -- or, with ``intr`` (fx, fy, cx, cy), the pinhole camera of gs.rasterization.
+        ``extr`` / ``intr`` may hold one camera per frame ([F,4,4] / [F,4]: render_batch's per-element cameras,
+        dptr_ortho_enhanced.py:409-411); ``offsets`` may then be None.  With one orthographic camera the Gaussian-side
+        backward runs its projection chain once per batch, otherwise once per frame (cameras are not differentiated).  Differentiable w.r.t. xyz, scales, uquats, opacity, feature; the backward ADDS
         the gradients of the names found in ``grad_sink`` into those buffers instead (e.g. FlatGradBucket views; autograd
         then sees no gradient for them), the others are returned to autograd.  After
         the backward, ``tap`` / ``abs_tap`` hold the batch's summed densification taps and ``radii_max`` the largest
         screen radius of every Gaussian over the frames."""
         sink = check_sink(grad_sink, {"xyz": xyz, "scales": scales, "uquats": uquats, "opacity": opacity, "feature": feature})
         return _RenderFrames.apply(xyz, scales, uquats, opacity, feature, offsets, extr, self, float(bg), float(nearest),
-                                   float(extent), sink)
+                                   float(extent), sink, intr)
 
 
     # ------------------------------------------------------------------ dynamic Gaussians (rows a15 + f1)
@@ -277,14 +334,14 @@ class FrameBatch:
     # ------------------------------------------------------------------ several feature sets of one geometry (row a1)
     def render_sets(self, xyz: Tensor, scales: Tensor, uquats: Tensor, opacity: Tensor, sets, offsets: Optional[Tensor],
                     extr: Tensor, K: int = 0, nearest: float = 0.01, extent: float = 1.3,
-                    grad_sink: Optional[Dict[str, Tensor]] = None):
+                    grad_sink: Optional[Dict[str, Tensor]] = None, intr: Optional[Tensor] = None):
         """The reference renderer's blends of ONE geometry over all frames of the batch (render_iter,
         src/pointrix/renderer/dptr_ortho_enhanced.py:331-375: rgb through alpha_blending_enhanced with the taps; depth with
         bg = 1; the extra attributes with opacity.detach()).  ``sets``: a list of dicts ``feature`` ([P,c] tensor shared by
         the frames, or the string "depth" for the per-frame depth of the projection), ``bg``, ``detach_opacity``, ``taps``.
         The widths must add up to the batch's ``C``.  One forward pass composites the concatenated row; per set one
         backward pass of the tile kernels and one Gaussian-side reduction.  Returns ``(images per set ..., gs_idx)`` with
-        images [F,c,H,W] and gs_idx [F,H,W,K] (None for K = 0)."""
+        images [F,c,H,W] and gs_idx [F,H,W,K] (None for K = 0).  Cameras (``extr`` per frame, ``intr``) as in ``render``."""
         feats = [s_["feature"] for s_ in sets if not isinstance(s_["feature"], str)]
         meta = tuple((("depth" if isinstance(s_["feature"], str) else int(s_["feature"].shape[1])), float(s_.get("bg", 0.0)),
                       bool(s_.get("detach_opacity", False)), bool(s_.get("taps", False))) for s_ in sets)
@@ -295,7 +352,7 @@ class FrameBatch:
             raise ValueError("at most one set feeds the densification taps")
         sink = check_sink(grad_sink, {"xyz": xyz, "scales": scales, "uquats": uquats, "opacity": opacity})
         res = _RenderSets.apply(xyz, scales, uquats, opacity, offsets, extr, self, meta, int(K), float(nearest), float(extent),
-                                sink, *feats)
+                                sink, intr, *feats)
         return res
 
 
@@ -569,13 +626,13 @@ def _one_pass_plan(meta, widths, C):
 
 class _RenderSets(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, scales, uquats, opacity, offsets, extr, fb, meta, K, nearest, extent, sink, *feats):
+    def forward(ctx, xyz, scales, uquats, opacity, offsets, extr, fb, meta, K, nearest, extent, sink, intr, *feats):
         xyz = _points(xyz, "xyz", 3)
         scales = _points(scales, "scales", 3)
         uquats = _points(uquats, "uquats", 4)
         opacity = L.need(opacity, "opacity")
-        extr_c = _extr12(extr)
         P, F = fb.P, fb.F
+        cam = _Camera(extr, intr, F)
         if xyz.shape[0] != P or scales.shape[0] != P or uquats.shape[0] != P:
             raise ValueError(f"the batch was built for {P} Gaussians")
         if opacity.numel() != P:
@@ -585,15 +642,16 @@ class _RenderSets(torch.autograd.Function):
         off = L.need(offsets, "offsets") if offsets is not None else None
         if off is not None and tuple(off.shape) != (F, P, 3):
             raise ValueError(f"offsets must be [F={F}, P={P}, 3]")
-        if off is None and F > 1:
-            raise ValueError("several frames of static Gaussians need per-frame offsets")
+        if off is None and F > 1 and cam.extr_fs == 0:
+            raise ValueError("several frames of static Gaussians need per-frame offsets or per-frame cameras")
         ctx.gen = fb._begin_forward()
-        fb._geometry(xyz, scales, uquats, off, extr_c, nearest, extent)
+        fb._geometry(xyz, scales, uquats, off, cam, nearest, extent)
         op_fs = 0
         C = fb.C
         out, gs_idx, ctx.blend = _blend_sets_forward(fb, meta, feats, opacity, op_fs, K)
         ctx.fb, ctx.meta, ctx.sink, ctx.K = fb, meta, sink, K
-        ctx.save_for_backward(xyz, scales, uquats, opacity, extr_c, *feats)
+        ctx.cam, ctx.off = cam, off
+        ctx.save_for_backward(xyz, scales, uquats, opacity, *feats)
         ctx.set_materialize_grads(False)
         imgs, c0 = [], 0
         for w, _, _, _ in meta:
@@ -609,8 +667,9 @@ class _RenderSets(torch.autograd.Function):
     def backward(ctx, *grads):
         fb: FrameBatch = ctx.fb
         fb._check_generation(ctx.gen)
-        xyz, scales, uquats, opacity, extr_c = ctx.saved_tensors[:5]
-        feats = ctx.saved_tensors[5:]
+        xyz, scales, uquats, opacity = ctx.saved_tensors[:4]
+        feats = ctx.saved_tensors[4:]
+        camc = ctx.cam.struct(ctx.off)
         meta, sink = ctx.meta, (ctx.sink or {})
         lib, st = L.lib(), L.stream()
         F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
@@ -632,7 +691,7 @@ class _RenderSets(torch.autograd.Function):
             for si, (w, _, _, _) in enumerate(meta):
                 if w == "depth":
                     continue
-                need = grads[si] is not None and ctx.needs_input_grad[12 + fi]
+                need = grads[si] is not None and ctx.needs_input_grad[13 + fi]
                 dfeat = torch.zeros_like(feats[fi]) if need else None
                 dfe.append(dfeat)
                 dfs[group_of[si]], strides[group_of[si]] = dfeat, int(feats[fi].shape[1])
@@ -641,14 +700,14 @@ class _RenderSets(torch.autograd.Function):
             i3 = ctypes.c_int32 * 3
             p3 = (ctypes.c_void_p * 3)(*[0 if d is None else d.data_ptr() for d in dfs])
             has_tap = tap_set is not None
-            L.check(lib.splat_frames_gauss_backward_static_sets(
+            L.check(lib.splat_frames_gauss_backward_static_sets_cam(
                 L.ci(F), L.ci(P), L.ci(C), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ptr(rec), L.ptr(fb.goff), L.ptr(fb.radius),
-                L.ptr(xyz), L.ptr(scales), L.ptr(uquats), L.ptr(extr_c), L.ci(1), L.ptr(bufs["xyz"]), L.ptr(bufs["scales"]),
+                L.ptr(xyz), L.ptr(scales), L.ptr(uquats), ctypes.byref(camc), L.ci(1), L.ptr(bufs["xyz"]), L.ptr(bufs["scales"]),
                 L.ptr(bufs["uquats"]), L.ptr(bufs["opacity"]), i3(*c0s), i3(*cns), p3, i3(*strides), L.ci(depth_ch),
                 L.ptr(fb.tap if has_tap else None), L.ptr(fb.abs_tap if (has_tap and want_abs) else None),
                 L.ptr(fb.radii_max if has_tap else None), st))
             ret = tuple(None if k in sink else bufs[k] for k in ("xyz", "scales", "uquats", "opacity"))
-            return ret + (None,) * 8 + tuple(dfe)
+            return ret + (None,) * 9 + tuple(dfe)
         row = ctx.blend["row"]
         dL = torch.cat([(g if g is not None else torch.zeros(F, w, H, W, dtype=torch.float32, device=dev))
                         for g, w in zip(grads[:len(meta)], widths)], dim=1).contiguous()
@@ -658,7 +717,7 @@ class _RenderSets(torch.autograd.Function):
             is_depth = w == "depth"
             dfeat = None
             if not is_depth:
-                dfeat = torch.zeros_like(feats[fi]) if g is not None and ctx.needs_input_grad[12 + fi] else None
+                dfeat = torch.zeros_like(feats[fi]) if g is not None and ctx.needs_input_grad[13 + fi] else None
                 dfe.append(dfeat)
                 fi += 1
             if g is not None:
@@ -671,27 +730,27 @@ class _RenderSets(torch.autograd.Function):
                     ctypes.c_int64(op_fs), L.ptr(row), ctypes.c_int64(P * C), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range),
                     ctypes.c_int64(cap), L.cf(bg), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(dL),
                     L.ci(want_abs), L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(_debug_T_front(F * H, W, dev)), st))
-                L.check(lib.splat_frames_gauss_backward_static_set(
+                L.check(lib.splat_frames_gauss_backward_static_cam(
                     L.ci(F), L.ci(P), L.ci(cn), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ci(want_abs), L.ptr(rec), L.ptr(fb.goff),
-                    L.ptr(fb.radius), L.ptr(xyz), L.ptr(scales), L.ptr(uquats), L.ptr(extr_c), L.ci(1), L.ptr(bufs["xyz"]),
+                    L.ptr(fb.radius), L.ptr(xyz), L.ptr(scales), L.ptr(uquats), ctypes.byref(camc), L.ci(1), L.ptr(bufs["xyz"]),
                     L.ptr(bufs["scales"]), L.ptr(bufs["uquats"]), L.ptr(bufs["opacity"]), L.ptr(dfeat), L.ci(cn),
                     L.ci(1 if detach else 0), L.ci(0 if is_depth else -1), L.ptr(fb.tap if taps else None),
                     L.ptr(fb.abs_tap if (taps and want_abs) else None), L.ptr(fb.radii_max if taps else None), st))
             c0 += cn
         ret = tuple(None if k in sink else bufs[k] for k in ("xyz", "scales", "uquats", "opacity"))
-        return ret + (None,) * 8 + tuple(dfe)
+        return ret + (None,) * 9 + tuple(dfe)
 
 
 class _RenderFrames(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, scales, uquats, opacity, feature, offsets, extr, fb: FrameBatch, bg, nearest, extent, sink):
+    def forward(ctx, xyz, scales, uquats, opacity, feature, offsets, extr, fb: FrameBatch, bg, nearest, extent, sink, intr=None):
         xyz = _points(xyz, "xyz", 3)
         scales = _points(scales, "scales", 3)
         uquats = _points(uquats, "uquats", 4)
         opacity = L.need(opacity, "opacity")
         feature = _points(feature, "feature", fb.C)
-        extr_c = _extr12(extr)
         P, F = fb.P, fb.F
+        cam = _Camera(extr, intr, F)
         if xyz.shape[0] != P or scales.shape[0] != P or uquats.shape[0] != P or opacity.numel() != P or feature.shape[0] != P:
             raise ValueError(f"the batch was built for {P} Gaussians")
         off = None
@@ -699,19 +758,20 @@ class _RenderFrames(torch.autograd.Function):
             off = L.need(offsets, "offsets")
             if tuple(off.shape) != (F, P, 3):
                 raise ValueError(f"offsets must be [F={F}, P={P}, 3]")
-        elif F > 1:
-            raise ValueError("several frames of static Gaussians need per-frame offsets")
+        elif F > 1 and cam.extr_fs == 0:
+            raise ValueError("several frames of static Gaussians need per-frame offsets or per-frame cameras")
         ctx.gen = fb._begin_forward()
-        out = fb._forward_onecall(xyz, scales, uquats, opacity, feature, off, extr_c, bg, nearest, extent)
+        out = fb._forward_onecall(xyz, scales, uquats, opacity, feature, off, cam, bg, nearest, extent)
         ctx.fb, ctx.bg, ctx.sink = fb, bg, sink
-        ctx.save_for_backward(xyz, scales, uquats, opacity, feature, extr_c)
+        ctx.cam, ctx.off = cam, off
+        ctx.save_for_backward(xyz, scales, uquats, opacity, feature)
         return out
 
     @staticmethod
     def backward(ctx, dL_dout):
         fb: FrameBatch = ctx.fb
         fb._check_generation(ctx.gen)
-        xyz, scales, uquats, opacity, feature, extr_c = ctx.saved_tensors
+        xyz, scales, uquats, opacity, feature = ctx.saved_tensors
         g = L.need(dL_dout, "dL_dout")
         sink = ctx.sink or {}
         like = {"xyz": xyz, "scales": scales, "uquats": uquats, "opacity": opacity, "feature": feature}
@@ -721,5 +781,5 @@ class _RenderFrames(torch.autograd.Function):
         ret = tuple(None if k in sink else bufs[k] for k in ("xyz", "scales", "uquats", "opacity", "feature"))
         from .gs.raster_ops import _debug_T_front
         dbg = _debug_T_front(fb.F * fb.H, fb.W, g.device)
-        fb._backward_onecall(g, xyz, scales, uquats, extr_c, ctx.bg, bufs, accumulate=bool(sink), dbg=dbg)
-        return ret + (None,) * 7
+        fb._backward_onecall(g, xyz, scales, uquats, ctx.off, ctx.cam, ctx.bg, bufs, accumulate=bool(sink), dbg=dbg)
+        return ret + (None,) * 8

@@ -3,7 +3,7 @@
 through the top-level ``dptr`` shim package of this repository."""
 from .point_ops import (compute_cov3d, compute_sh, compute_sh_free, ewa_project, ewa_project_ortho, project_point,
                         project_point_ortho)
-from .fused_ops import compute_sh_into, preprocess_ortho
+from .fused_ops import compute_sh_into, preprocess_ortho, preprocess_persp
 from .raster_ops import (SortStatus, alpha_blending, alpha_blending_shared, alpha_blending_enhanced, alpha_blending_with_bias, rasterization,
                          sort_gaussian, sort_gaussian_capped)
 
@@ -23,6 +23,7 @@ __all__ = [
     "ewa_project_ortho",
     # fused per-frame operators of the MI355X renderer
     "preprocess_ortho",
+    "preprocess_persp",
     "compute_sh_into",
     "alpha_blending_shared",
     "sort_gaussian_capped",

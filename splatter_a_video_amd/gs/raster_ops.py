@@ -468,10 +468,17 @@ def alpha_blending_shared(uv: Tensor, conic: Tensor, opacity: Tensor, features, 
 # ------------------------------------------------------------------ rasterization (5-op chain)
 def rasterization(xyz: Tensor, scale: Tensor, rotate: Tensor, opacity: Tensor, feature: Tensor, intr: Tensor,
                   extr: Tensor, W: int, H: int, bg: float, ndc: Optional[Tensor] = None) -> Tensor:
-    """project_point -> compute_cov3d -> ewa_project -> sort_gaussian -> alpha_blending."""
-    uv, depth = project_point(xyz, intr, extr, W, H)
-    visible = depth != 0
-    cov3d = compute_cov3d(scale, rotate, visible)
-    conic, radius, tiles = ewa_project(xyz, cov3d, intr, extr, uv, W, H, visible)
+    """project_point -> compute_cov3d -> ewa_project -> sort_gaussian -> alpha_blending (reference:
+    src/submodules/dptr/dptr/gs/__init__.py:28-100).  The three per-Gaussian operators run as ONE fused pass per direction
+    (``preprocess_persp``: same arithmetic, no visible mask / cov3d round trips) unless the camera itself requires grad."""
+    cam_grad = (isinstance(intr, Tensor) and intr.requires_grad) or (isinstance(extr, Tensor) and extr.requires_grad)
+    if cam_grad:
+        uv, depth = project_point(xyz, intr, extr, W, H)
+        visible = depth != 0
+        cov3d = compute_cov3d(scale, rotate, visible)
+        conic, radius, tiles = ewa_project(xyz, cov3d, intr, extr, uv, W, H, visible)
+    else:
+        from .fused_ops import preprocess_persp
+        uv, depth, conic, radius, tiles = preprocess_persp(xyz, scale, rotate, intr, extr, W, H)
     idx_sorted, tile_range = sort_gaussian(uv, depth, W, H, radius, tiles)
     return alpha_blending(uv, conic, opacity, feature, idx_sorted, tile_range, bg, W, H, ndc)

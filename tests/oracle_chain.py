@@ -6,15 +6,19 @@ Used by the frame-batch oracle tests (tests/test_gpu_frames_oracle.py)."""
 import numpy as np
 
 
-def frame(o, xyz, scale, rotate, opacity, extr, W, H, sets, grads, K=0, nearest=0.01):
+def frame(o, xyz, scale, rotate, opacity, extr, W, H, sets, grads, K=0, nearest=0.01, intr=None):
     """One frame.  ``sets``: dicts(feature=[P,c] array or "depth", bg, detach_opacity, taps); ``grads``: image gradient
     [c,H,W] per set.  Returns dict(imgs, gs_idx, ncontrib, final_T, radius, M, d=dict of float64 gradients: xyz, scale,
     rotate, opacity, feats (per set, None for depth), tap, abs_tap)."""
     P = xyz.shape[0]
-    uv, depth = o.project_point_ortho_forward(xyz, extr, W, H, nearest)
+    ortho = intr is None          # intr (fx, fy, cx, cy): the pinhole camera of gs.rasterization instead
+    if ortho:
+        uv, depth = o.project_point_ortho_forward(xyz, extr, W, H, nearest)
+    else:
+        uv, depth = o.project_point_forward(xyz, intr, extr, W, H, nearest)
     vis = depth.reshape(-1) != 0
     cov = o.compute_cov3d_forward(scale, rotate, vis)
-    conic, radius, tiles = o.ewa_project_forward(xyz, cov, None, extr, uv, W, H, vis, ortho=True)
+    conic, radius, tiles = o.ewa_project_forward(xyz, cov, intr, extr, uv, W, H, vis, ortho=ortho)
     idx, tr = o.sort_gaussian(uv, depth, W, H, radius, tiles)
     duv = np.zeros((P, 2), np.float64); dcon = np.zeros((P, 3), np.float64); dop = np.zeros((P, 1), np.float64)
     ddepth = np.zeros((P, 1), np.float64)
@@ -41,21 +45,29 @@ def frame(o, xyz, scale, rotate, opacity, extr, W, H, sets, grads, K=0, nearest=
             dfe.append(b[3].astype(np.float64))
         if s.get("taps"):
             tap, atap = b[0] * half, b[4] * half
-    dxyz_e, dcov, _, _ = o.ewa_project_backward(xyz, cov, None, extr, radius, dcon.astype(np.float32), W, H, ortho=True,
+    dxyz_e, dcov, _, _ = o.ewa_project_backward(xyz, cov, intr, extr, radius, dcon.astype(np.float32), W, H, ortho=ortho,
                                                 need_intr=False, need_extr=False)
-    dxyz = o.project_point_ortho_backward(extr, W, H, depth, duv.astype(np.float32), ddepth.astype(np.float32))
+    if ortho:
+        dxyz = o.project_point_ortho_backward(extr, W, H, depth, duv.astype(np.float32), ddepth.astype(np.float32))
+    else:
+        dxyz, _, _ = o.project_point_backward(xyz, intr, extr, W, H, uv, depth, duv.astype(np.float32), ddepth.astype(np.float32),
+                                              need_intr=False, need_extr=False)
     dscale, dquat = o.compute_cov3d_backward(scale, rotate, vis, dcov)
     return dict(imgs=imgs, gs_idx=gs_idx, ncontrib=nc0, final_T=fT0, radius=radius, M=int(idx.size), uv=uv, conic=conic,
                 d=dict(xyz=dxyz.astype(np.float64) + dxyz_e, scale=dscale.astype(np.float64), rotate=dquat.astype(np.float64),
                        opacity=dop, feats=dfe, tap=tap, abs_tap=atap))
 
 
-def static_frames(o, xyz, offsets, scale, rotate, opacity, extr, W, H, sets, grads, K=0):
-    """F frames xyz + offsets[f] of static Gaussians; gradients summed over the frames (what one backward of the batch gives)"""
-    F = offsets.shape[0]
+def static_frames(o, xyz, offsets, scale, rotate, opacity, extr, W, H, sets, grads, K=0, intr=None, nearest=0.01):
+    """F frames xyz + offsets[f] of static Gaussians; gradients summed over the frames (what one backward of the batch gives).
+    ``extr`` [4,4] or one per frame [F,4,4]; ``intr`` None (orthographic), [4] or [F,4]; ``offsets`` None: none."""
+    F = grads[0].shape[0]
     tot, per = None, []
     for f in range(F):
-        r = frame(o, (xyz + offsets[f]).astype(np.float32), scale, rotate, opacity, extr, W, H, sets, [g[f] for g in grads], K)
+        e = extr[f] if np.ndim(extr) == 3 else extr
+        k = None if intr is None else (intr[f] if np.ndim(intr) == 2 else intr)
+        pos = xyz if offsets is None else (xyz + offsets[f]).astype(np.float32)
+        r = frame(o, pos, scale, rotate, opacity, e, W, H, sets, [g[f] for g in grads], K, nearest=nearest, intr=k)
         per.append(r)
         tot = _add(tot, r["d"])
     return per, tot

@@ -267,3 +267,161 @@ def test_wide_row_batch_against_oracle(oracle_mod):
     assert_grad(p["opacity"].grad, tot["opacity"], "opacity", tol)
     assert_grad(p["feature"].grad, tot["feats"][0], "feature", tol)
     assert_grad(B.tap, tot["tap"], "tap", tol)
+
+
+def test_clustered_scene_against_oracle(oracle_mod):
+    """SURVEY 7 hard part (ii): a clustered scene (70 % of the Gaussians in blobs that cover 10 % of the image -- foreground
+    objects) gives tile lists from a few entries to thousands in one launch: long replays, many super-batches and overflow rounds
+    next to empty tiles.  Images and gradients against the oracle."""
+    from splatter_a_video_amd.synth import make_scene
+    N, W, H, F, C = 15000, 256, 160, 2, 3
+    sc = make_scene(N, W, H, seed=55, clustered=0.7)
+    sc.opacity[:] = np.clip(sc.opacity * 0.35, 0.0, 0.97)          # faint splats: the long lists are walked, not cut by saturation
+    rng = np.random.default_rng(4)
+    off = np.stack([sc.positions(f) - sc.xyz for f in (0, 13)]).astype(np.float32)
+    feat = rng.uniform(size=(N, C)).astype(np.float32)
+    gimg = rng.normal(size=(F, C, H, W)).astype(np.float32)
+    p = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity, feature=feat).items()}
+    B = FrameBatch(F, N, W, H, C, "cuda", want_abs=True)
+    out = B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], _t(off), _t(sc.extr), bg=0.1)
+    with capture_T_front() as cap:
+        out.backward(_t(gimg))
+    torch.cuda.synchronize()
+    B.check()
+    tr = B.tile_range.long()
+    ln = (tr[..., 1] - tr[..., 0]).float()
+    assert float(ln.max()) > 4.0 * float(ln.mean()) and float(ln.max()) > 600      # strongly unbalanced lists
+    assert float((cap.maps[0] - 1).abs().max()) < 2e-4
+    per, tot = oc.static_frames(oracle_mod, sc.xyz, off, sc.scale, sc.rotate, sc.opacity, sc.extr, W, H,
+                                [dict(feature=feat, bg=0.1, taps=True)], [gimg])
+    same = _same_geometry(B, per)
+    _check_images(out, per, 0, "clustered")
+    tol = GRAD_RTOL if same else 5e-3
+    assert_grad(p["xyz"].grad, tot["xyz"], "xyz", tol)
+    assert_grad(p["scales"].grad, tot["scale"], "scales", tol)
+    assert_grad(p["uquats"].grad, tot["rotate"], "uquats", tol)
+    assert_grad(p["opacity"].grad, tot["opacity"], "opacity", tol)
+    assert_grad(p["feature"].grad, tot["feats"][0], "feature", tol)
+    assert_grad(B.tap, tot["tap"], "tap", tol)
+    assert_grad(B.abs_tap, tot["abs_tap"], "abs_tap", tol)
+
+
+def _rot_z(a):
+    c, s = np.cos(a), np.sin(a)
+    R = np.eye(4, dtype=np.float32)
+    R[0, 0], R[0, 1], R[1, 0], R[1, 1] = c, -s, s, c
+    return R
+
+
+@pytest.mark.parametrize("entry", ["render", "render_sets"])
+def test_per_frame_cameras_against_oracle(oracle_mod, entry):
+    """render_batch gives every batch element its own camera (reference: dptr_ortho_enhanced.py:409-411): F orthographic
+    cameras [F,4,4] in one batch, no offsets -- batched preprocess with per-frame extr, Gaussian-side backward with the
+    projection chain per frame (frames_gauss_bwd_static_kernel CAM = 1) -- against the oracle chain frame by frame."""
+    from splatter_a_video_amd.synth import make_scene
+    N, W, H, F = 9000, 192, 128, 3
+    sc = make_scene(N, W, H, seed=17)
+    rng = np.random.default_rng(2)
+    extr = np.stack([_rot_z(0.0), _rot_z(0.07), _rot_z(-0.11)])
+    extr[1, 0, 3], extr[1, 1, 3] = 0.05, -0.02
+    extr[2, 0, 3], extr[2, 2, 3] = -0.04, 0.3
+    p = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity).items()}
+    if entry == "render":
+        C = 3
+        feat = rng.uniform(size=(N, C)).astype(np.float32)
+        gs_ = [rng.normal(size=(F, C, H, W)).astype(np.float32)]
+        ft = _t(feat, True)
+        B = FrameBatch(F, N, W, H, C, "cuda", want_abs=True)
+        outs = [B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], ft, None, _t(extr), bg=0.2)]
+        osets = [dict(feature=feat, bg=0.2, taps=True)]
+        feats_t = [ft]
+    else:
+        rgb = rng.uniform(size=(N, 3)).astype(np.float32)
+        attrs = rng.uniform(-1, 1, size=(N, 19)).astype(np.float32)
+        gs_ = [rng.normal(size=(F, c, H, W)).astype(np.float32) for c in (3, 1, 19)]
+        t_rgb, t_att = _t(rgb, True), _t(attrs, True)
+        B = FrameBatch(F, N, W, H, 23, "cuda", want_abs=True)
+        sets = [dict(feature=t_rgb, bg=0.2, taps=True), dict(feature="depth", bg=1.0), dict(feature=t_att, bg=0.0, detach_opacity=True)]
+        outs = list(B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], sets, None, _t(extr))[:3])
+        osets = [dict(feature=rgb, bg=0.2, taps=True), dict(feature="depth", bg=1.0), dict(feature=attrs, bg=0.0, detach_opacity=True)]
+        feats_t = [t_rgb, None, t_att]
+    torch.autograd.backward(outs, [_t(x) for x in gs_])
+    torch.cuda.synchronize()
+    B.check()
+    per, tot = oc.static_frames(oracle_mod, sc.xyz, None, sc.scale, sc.rotate, sc.opacity, extr, W, H, osets, gs_)
+    same = _same_geometry(B, per)
+    _check_images(torch.cat(outs, 1), per, 0, entry)
+    tol = GRAD_RTOL if same else 5e-3
+    assert_grad(p["xyz"].grad, tot["xyz"], "xyz", tol)
+    assert_grad(p["scales"].grad, tot["scale"], "scales", tol)
+    assert_grad(p["uquats"].grad, tot["rotate"], "uquats", tol)
+    assert_grad(p["opacity"].grad, tot["opacity"], "opacity", tol)
+    for ft_, want in zip(feats_t, tot["feats"]):
+        if ft_ is not None:
+            assert_grad(ft_.grad, want, "feature", tol)
+    assert_grad(B.tap, tot["tap"], "tap", tol)
+    assert_grad(B.abs_tap, tot["abs_tap"], "abs_tap", tol)
+
+
+def test_perspective_batch_against_oracle(oracle_mod):
+    """the pinhole camera of gs.rasterization / DPTRRender as a frame batch: fused perspective preprocess per frame (per-frame
+    extr AND offsets), Gaussian-side backward with the perspective chain per frame (position gradient through the projection
+    and the EWA Jacobian; CAM = 2) -- against the oracle's perspective chain"""
+    from splatter_a_video_amd.synth import make_scene
+    N, W, H, F, C = 8000, 160, 112, 2, 3
+    sc = make_scene(N, W, H, seed=29, ortho=False)
+    rng = np.random.default_rng(6)
+    extr = np.stack([sc.extr, sc.extr @ _rot_z(0.05)]).astype(np.float32)
+    off = (0.03 * rng.normal(size=(F, N, 3))).astype(np.float32)
+    off[0] = 0.0
+    feat = rng.uniform(size=(N, C)).astype(np.float32)
+    gimg = rng.normal(size=(F, C, H, W)).astype(np.float32)
+    p = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity, feature=feat).items()}
+    B = FrameBatch(F, N, W, H, C, "cuda")
+    out = B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], _t(off), _t(extr), bg=0.1, nearest=0.2,
+                   intr=_t(sc.intr))
+    with capture_T_front() as cap:
+        out.backward(_t(gimg))
+    torch.cuda.synchronize()
+    B.check()
+    assert float((cap.maps[0] - 1).abs().max()) < 2e-4
+    per, tot = oc.static_frames(oracle_mod, sc.xyz, off, sc.scale, sc.rotate, sc.opacity, extr, W, H,
+                                [dict(feature=feat, bg=0.1, taps=True)], [gimg], intr=sc.intr, nearest=0.2)
+    assert min(r["M"] for r in per) > 5000
+    same = _same_geometry(B, per)
+    _check_images(out, per, 0, "perspective")
+    tol = GRAD_RTOL if same else 5e-3
+    assert_grad(p["xyz"].grad, tot["xyz"], "xyz", tol)
+    assert_grad(p["scales"].grad, tot["scale"], "scales", tol)
+    assert_grad(p["uquats"].grad, tot["rotate"], "uquats", tol)
+    assert_grad(p["opacity"].grad, tot["opacity"], "opacity", tol)
+    assert_grad(p["feature"].grad, tot["feats"][0], "feature", tol)
+    assert_grad(B.tap, tot["tap"], "tap", tol)
+
+
+def test_fused_perspective_preprocess_equals_the_operator_chain():
+    """gs.preprocess_persp (what gs.rasterization runs now) = project_point -> compute_cov3d -> ewa_project: projection, radius and
+    tile counts bit for bit (same one-Gaussian device functions), the conic up to the FMA contraction of a cov3d that stays in
+    registers, and the gradients"""
+    import dptr.gs as gs
+    from splatter_a_video_amd.synth import make_scene
+    N, W, H = 20000, 320, 200
+    sc = make_scene(N, W, H, seed=3, ortho=False)
+    rng = np.random.default_rng(1)
+    g = [_t(rng.normal(size=s).astype(np.float32)) for s in ((N, 2), (N, 1), (N, 3))]
+    intr, extr = _t(sc.intr), _t(sc.extr)
+    a = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scale=sc.scale, rotate=sc.rotate).items()}
+    uv, depth = gs.project_point(a["xyz"], intr, extr, W, H)
+    vis = depth != 0
+    cov = gs.compute_cov3d(a["scale"], a["rotate"], vis)
+    conic, radius, tiles = gs.ewa_project(a["xyz"], cov, intr, extr, uv, W, H, vis)
+    torch.autograd.backward([uv, depth, conic], g)
+    b = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scale=sc.scale, rotate=sc.rotate).items()}
+    uv2, depth2, conic2, radius2, tiles2 = gs.preprocess_persp(b["xyz"], b["scale"], b["rotate"], intr, extr, W, H)
+    assert torch.equal(uv2, uv) and torch.equal(depth2, depth) and torch.equal(radius2, radius) and torch.equal(tiles2, tiles)
+    assert torch.allclose(conic2, conic, rtol=2e-5, atol=2e-6 * float(conic.abs().max()))
+    torch.autograd.backward([uv2, depth2, conic2], g)
+    for k in a:
+        x, y = b[k].grad, a[k].grad
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-6 * float(y.abs().max())), k
+    assert int((radius > 0).sum()) > N // 2
