@@ -89,26 +89,16 @@
 #ifndef BLEND_STATE_SKEW
 #define BLEND_STATE_SKEW 1 // strip-walk backward kernels: per-pixel replay state rows skewed by lane group (bank conflicts)
 #endif
-// power is a negative-semidefinite form: it can only exceed 0 by rounding.  The matrix-core kernels evaluate it as
-// an expanded polynomial (absolute error up to ~5e-6 in log2 units), so their "power > 0" guard of the reference
-// (src/alpha_blending.cu:93) sits just above that noise; it still rejects genuinely indefinite conics.
-#define BLEND_PW_MAX 1.5e-4f
-// BLEND_EXP_CLAMP (default): the guard is the clamp bit of v_exp_f32 -- G = min(exp2(power), 1) -- instead of a compare per
-// (pixel, splat): identical wherever power <= 0 (every pixel of a positive-definite conic up to rounding; EWA only emits
-// those: cov2d + 0.3 I), a pixel on a splat's centre gets G = 1 exactly instead of 1 + 1e-5, and a NaN power still gives
-// alpha = 0 (DX10 clamp: NaN -> 0).  Forward and every backward kernel share exp2_guard(), so decisions stay reproducible.
-#ifndef BLEND_EXP_CLAMP
-#define BLEND_EXP_CLAMP 1
-#endif
-// G = exp2(pw) under the guard; `ok` = the splat is not rejected by the guard
+// The reference skips a splat when power > 0 (src/alpha_blending.cu:93).  power is a negative-semidefinite form -- EWA only
+// emits positive-definite conics (cov2d + 0.3 I) -- so it exceeds 0 by rounding only (the expanded polynomial carries ~1e-5 of
+// absolute noise in log2 units; at a splat's centre the reference evaluates exp(0) = 1).  No compare per (pixel, splat) is spent
+// on it: the raw alpha is exp2 of the polynomial (opacity included, see power_coeffs) with the clamp bit of v_exp_f32 set --
+// alpha_raw = min(o exp(power), 1), and a NaN (o < 0, garbage conic) becomes 0 under the DX10 clamp, i.e. "skipped".  Forward
+// and every backward kernel share exp2_guard(), so decisions stay reproducible.
+// raw alpha = exp2(pw) = o * exp(power); `ok` is always true (kept for the callers' predicate chains)
 __device__ __forceinline__ float exp2_guard(float pw, bool &ok) {
-#if BLEND_EXP_CLAMP
     ok = true;
     return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(pw), 0.f, 1.f);   // folds into v_exp_f32 ... clamp
-#else
-    ok = !(pw > BLEND_PW_MAX);
-    return __builtin_amdgcn_exp2f(pw);
-#endif
 }
 
 struct BlendArgs {
@@ -202,25 +192,26 @@ __device__ __forceinline__ BlendArgs frame_args(const BlendArgs &B, int f) {
 // reproduces its forward's alpha bit for bit (the reference's two kernels share their expression as well,
 // src/alpha_blending.cu:78-87 vs :196-203; a decision alpha >= 1/255 that flips between the two passes would corrupt
 // the T /= (1 - alpha) replay of that pixel).
-//   power(x, y) * log2(e) = q0 + qx x + qy y + qxx x^2 + qxy x y + qyy y^2      x, y: pixel relative to the tile centre
+//   log2(o) + power(x, y) * log2(e) = q0 + qx x + qy y + qxx x^2 + qxy x y + qyy y^2      x, y: pixel relative to the tile centre
 // evaluated as the fused-multiply-add chain q0 -> +x qx -> +y qy -> +xx qxx -> +xy qxy -> +yy qyy.  The matrix-core
 // backward gets exactly this chain from two v_mfma_f32_16x16x4_f32 (an f32 MFMA is the ascending fma chain over k
 // starting from C: profiles/r02_mfma_fma_chain_probe.json, 2^20 of 2^20 random products bit-equal); the lane = pixel
 // kernels run it on the VALU.  The coefficients come from power_coeffs() everywhere (explicit fma, no contraction).
-// power is a negative-semidefinite form that only exceeds 0 by rounding; the expanded polynomial carries an absolute
-// error of ~1e-5 (log2 units), so the reference's "power > 0" guard (src/alpha_blending.cu:93) sits just above that
-// noise (BLEND_PW_MAX) -- at exactly 0 it would drop pixels that sit on a splat's centre.
+// exp2 of it is the raw alpha o * exp(power) itself.  The reference's "power > 0" guard: see exp2_guard().
 #define BLEND_L2E 1.4426950408889634f
 struct PowerCoef {
     float q0, qx, qy, qxx, qxy, qyy;
 };
-__device__ __forceinline__ PowerCoef power_coeffs(float u, float v, float cA, float cB, float cC, float cx, float cy) {
+// The opacity rides in the constant term: q0 = log2(o) - 0.5 log2(e) c^T Q c, so that exp2 of the polynomial IS o * exp(power)
+// (the raw alpha) -- one multiply less per (pixel, splat) evaluation in every kernel.  o <= 0 gives -inf / NaN -> alpha 0
+// (the reference: o * G < 1/255 -> skipped).
+__device__ __forceinline__ PowerCoef power_coeffs(float u, float v, float cA, float cB, float cC, float o, float cx, float cy) {
 #pragma clang fp contract(off)
     const float uc = u - cx, vc = v - cy;  // splat centre relative to the tile centre
     const float tx = __builtin_fmaf(cA, uc, cB * vc);
     const float ty = __builtin_fmaf(cB, uc, cC * vc);
     PowerCoef k;
-    k.q0 = (-0.5f * BLEND_L2E) * __builtin_fmaf(uc, tx, vc * ty);
+    k.q0 = __builtin_fmaf(-0.5f * BLEND_L2E, __builtin_fmaf(uc, tx, vc * ty), __builtin_amdgcn_logf(o));
     k.qx = BLEND_L2E * tx;
     k.qy = BLEND_L2E * ty;
     k.qxx = (-0.5f * BLEND_L2E) * cA;
@@ -510,7 +501,7 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ> &L, int
         } else {
             const float4 a0 = L.g0(e), a1 = L.g1(e);
             if (COEF && part == 0) {
-                const PowerCoef k = power_coeffs(a0.x, a0.y, a0.z, a0.w, a1.x, tx0 + 7.5f, ty0 + 7.5f);
+                const PowerCoef k = power_coeffs(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, tx0 + 7.5f, ty0 + 7.5f);
                 L.coef[2 * e] = make_float4(k.q0, k.qx, k.qy, k.qxx);
                 L.coef[2 * e + 1] = make_float4(k.qxy, k.qyy, a1.y, a1.w);
             }
@@ -664,7 +655,7 @@ blend_fwd_kernel(const BlendArgs B) {
     constexpr int RM = RB / 32;                   // record offset = RM * coefficient-block offset
     static_assert((SB + 1) * 32 <= 65536 && SB % U == 0 && RB % 32 == 0, "offsets must fit the 16-bit list entries");
     __shared__ TileLDS<CH, SB, !BIAS> L;
-    __shared__ __attribute__((aligned(8))) unsigned short s_qlist[4][4][SB];  // [wave][quarter] survivor lists (32 e: coefficient-block byte offsets)
+    __shared__ __attribute__((aligned(16))) unsigned int s_qlist[4][4][SB];  // [wave][quarter] survivor lists (32 e: coefficient-block byte offsets)
     __shared__ int s_done[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int gtile = xcd_tile(blockIdx.x, gridDim.x);
@@ -689,7 +680,7 @@ blend_fwd_kernel(const BlendArgs B) {
     const int n = range.y - range.x;
 
     if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
-    if (!BIAS && tid < 2) L.coef[2 * SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!BIAS && tid < 2) L.coef[2 * SB + tid] = make_float4(tid == 0 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);  // inert entry: q0 = log2(0)
     // list position of (entry e, super-batch b): forward walk
     auto pos = [n](int e, int b) { const int q = b * SB + e; return q < n ? q : -1; };
     Stager<CH, SB> st;
@@ -728,7 +719,7 @@ blend_fwd_kernel(const BlendArgs B) {
                     const bool keep = (bits >> q) & 1u;
                     const unsigned long long m = __ballot(keep);
                     const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (keep) s_qlist[w][q][cq[q] + before] = (unsigned short)(e * 32);
+                    if (keep) s_qlist[w][q][cq[q] + before] = (unsigned)(e * 32);
                     cq[q] += __popcll(m);
                 }
             }
@@ -737,23 +728,19 @@ blend_fwd_kernel(const BlendArgs B) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll 1
-                for (int i = cq[q] + lane; i < cntU; i += WAVE) s_qlist[w][q][i] = (unsigned short)(SB * 32);  // opacity 0 -> alpha 0
+                for (int i = cq[q] + lane; i < cntU; i += WAVE) s_qlist[w][q][i] = (unsigned)(SB * 32);  // log2(o) = -inf -> alpha 0
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int myq = ((lane >> 2) & 1) + 2 * ((lane >> 5) & 1);  // quarter of this lane's pixel
-            const unsigned short *mylist = s_qlist[w][myq];
+            const unsigned int *mylist = s_qlist[w][myq];
             const char *recb = reinterpret_cast<const char *>(L.rec);
             const char *cfb = reinterpret_cast<const char *>(L.coef);
             int lastoff = -1;  // block offset of the last splat applied in this super-batch
             for (int j0 = 0; j0 < cntU; j0 += U) {
                 unsigned off[U];
-                static_assert(U == 2 || U == 4, "a trip reads its list entries as one 4- or 8-byte word");
+                static_assert(U == 2 || U == 4, "a trip reads its list entries as one 8- or 16-byte word");
 #pragma unroll
-                for (int h = 0; h < U / 2; ++h) {
-                    const unsigned v = reinterpret_cast<const unsigned *>(mylist + j0)[h];  // adjacent words: one ds_read_b64 for U = 4
-                    off[2 * h] = v & 0xffffu;
-                    off[2 * h + 1] = v >> 16;
-                }
+                for (int u = 0; u < U; ++u) off[u] = mylist[j0 + u];  // adjacent 32-bit entries: one ds_read_b64 / b128 per trip, no unpacking
                 float4 g0[U], g1[U];
                 float alpha[U];  // 0 where the splat does not touch the pixel: no per-splat predicate registers
 #pragma unroll
@@ -772,7 +759,7 @@ blend_fwd_kernel(const BlendArgs B) {
                     } else {
                         const float pw = power_poly(g0[u], g1[u], x, y, xx, xy, yy);
                         bool pw_ok;
-                        const float a = fminf(0.99f, g1[u].z * exp2_guard(pw, pw_ok));
+                        const float a = fminf(0.99f, exp2_guard(pw, pw_ok));
                         alpha[u] = (pw_ok && !(a < (1.0f / 255.0f))) ? a : 0.f;
                     }
                     amax = fmaxf(amax, alpha[u]);
@@ -965,7 +952,7 @@ blend_bwd_pair_kernel(const BlendArgs B) {
     const int wmax = wave_max_i(last);  // this wave never needs entries q >= wmax
     if (lane == 0) s_wmax[w] = wmax;
     if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
-    if (!BIAS && tid < 2) L.coef[2 * SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!BIAS && tid < 2) L.coef[2 * SB + tid] = make_float4(tid == 0 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);  // inert entry: q0 = log2(0)
     __syncthreads();
     const int2 range = A.tile_range[tile];
     const int len = range.y - range.x;
@@ -1025,8 +1012,8 @@ blend_bwd_pair_kernel(const BlendArgs B) {
                     pw_ok = !(q < 0.f);
                 } else {
                     const float pw = power_poly(L.coef[2 * e[u]], L.coef[2 * e[u] + 1], x, y, xx, xy, yy);
-                    G[u] = exp2_guard(pw, pw_ok);
-                    araw = g1[u].y * G[u];
+                    araw = exp2_guard(pw, pw_ok);                      // = o * G (the forward's value, bit for bit)
+                    G[u] = araw * __builtin_amdgcn_rcpf(g1[u].y);      // (araw > 0 only where o > 0)
                 }
                 alpha[u] = fminf(0.99f, araw);
                 ok[u] = (j0 + u < cnt) && !done && (top - e[u] < last) && pw_ok && !(alpha[u] < (1.0f / 255.0f));
@@ -1505,7 +1492,7 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
             // B operands: this lane's K-slice of the splat's power coefficients (x log2 e) and features
             float bq1, bq2, bf[NK];
             {
-                const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, tcx, tcy);
+                const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, o, tcx, tcy);
                 bq1 = kk == 0 ? pc.q0 : kk == 1 ? pc.qx : kk == 2 ? pc.qy : pc.qxx;
                 bq2 = kk == 0 ? pc.qxy : kk == 1 ? pc.qyy : 0.f;
 #pragma unroll
@@ -1541,8 +1528,7 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                     Ts4[i] = stv.z;
                     Rs4[i] = stv.w;
                     bool pw_ok;
-                    const float Gs = exp2_guard(pw[i], pw_ok);
-                    araw[i] = o * Gs;
+                    araw[i] = exp2_guard(pw[i], pw_ok);   // o * G: the opacity is part of the polynomial's constant term
                     // (min(0.99, .) is monotone and 0.99 > 1/255: alpha < 1/255 <=> araw < 1/255 -- the forward's decision)
                     ok[i] = (qn < last) && pw_ok && !(araw[i] < (1.0f / 255.0f));
                     araw[i] = ok[i] ? araw[i] : 0.f;   // 0 for a splat this pixel does not replay: alpha = 0, dL/dpower = 0
@@ -1998,7 +1984,7 @@ blend_bwd_sets_kernel(const BlendArgs B) {
             const int qn = top - e;
             float bq1, bq2, bf[NK];
             {
-                const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, tcx, tcy);
+                const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, o, tcx, tcy);
                 bq1 = kk == 0 ? pc.q0 : kk == 1 ? pc.qx : kk == 2 ? pc.qy : pc.qxx;
                 bq2 = kk == 0 ? pc.qxy : kk == 1 ? pc.qyy : 0.f;
 #pragma unroll
@@ -2031,8 +2017,7 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                     Rs[0][i] = sb.y; Rs[1][i] = sb.z; Rs[2][i] = sb.w;
                     cg[0][i] = cv0[i]; cg[1][i] = cv1[i]; cg[2][i] = cv2[i];
                     bool pw_ok;
-                    const float Gs = exp2_guard(pw[i], pw_ok);
-                    araw[i] = o * Gs;
+                    araw[i] = exp2_guard(pw[i], pw_ok);   // o * G: the opacity is part of the polynomial's constant term
                     const float alpha = fminf(0.99f, araw[i]);
                     ok[i] = (qn < last) && pw_ok && !(alpha < (1.0f / 255.0f));
                     a[i] = ok[i] ? alpha : 0.f;
@@ -2207,7 +2192,7 @@ blend_bwd_atomic_kernel(const BlendArgs B) {
     const int wmax = wave_max_i(last);
     if (lane == 0) s_wmax[w] = wmax;
     if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
-    if (!BIAS && tid < 2) L.coef[2 * SB + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!BIAS && tid < 2) L.coef[2 * SB + tid] = make_float4(tid == 0 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);  // inert entry: q0 = log2(0)
     __syncthreads();
     const int2 range = A.tile_range[tile];
     const int n = imin_(range.y - range.x, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
@@ -2244,8 +2229,8 @@ blend_bwd_atomic_kernel(const BlendArgs B) {
                 pw_ok = !(q < 0.f);
             } else {
                 const float pw = power_poly(L.coef[2 * e], L.coef[2 * e + 1], x, y, xx, xy, yy);
-                G = exp2_guard(pw, pw_ok);
-                araw = g1.y * G;
+                araw = exp2_guard(pw, pw_ok);                          // = o * G (the forward's value, bit for bit)
+                G = araw * __builtin_amdgcn_rcpf(g1.y);
             }
             const float alpha = fminf(0.99f, araw);
             const bool ok = !done && (top - e < last) && pw_ok && !(alpha < (1.0f / 255.0f));

@@ -108,3 +108,54 @@ class OrthoEnhancedRenderer:
         if n == 0:
             return
         state.update()
+
+
+class PerspRenderer:
+    """Native counterpart of the reference's pinhole renderer ``DPTRRender`` (src/pointrix/renderer/dptr.py:42-169, :171-224):
+    same call signature and return value of ``render_iter`` / ``render_batch``, the same blend (rgb + depth (+ pixel_flow) in one
+    ``alpha_blending`` with the ``ndc`` tap), but the three per-Gaussian operators (project_point, compute_cov3d, ewa_project)
+    run as ONE fused launch per direction (``gs.preprocess_persp``).  Cameras are not differentiated here (the reference
+    renderer does not optimise them either); its own class keeps working unchanged through the ``dptr`` shim."""
+
+    def __init__(self, white_bg: bool = False):
+        self.bg_color = 1.0 if white_bg else 0.0
+
+    def render_iter(self, FovX, FovY, height, width, extrinsic_matrix: Tensor, intrinsic_matrix: Tensor, camera_center: Tensor,
+                    position: Tensor, opacity: Tensor, scaling: Tensor, rotation: Tensor, shs: Tensor,
+                    scaling_modifier: float = 1.0, render_xyz: bool = False, **kwargs) -> dict:
+        W, H = int(width), int(height)
+        direction = position - camera_center.reshape(1, 3).to(position.device)
+        direction = direction / direction.norm(dim=1, keepdim=True)
+        rgb = gs.compute_sh(shs, 3, direction)
+        uv, depth, conic, radius, tiles = gs.preprocess_persp(position, scaling, rotation, intrinsic_matrix, extrinsic_matrix, W, H,
+                                                              nearest=0.01)     # dptr.py:107-147 in one launch
+        idx_sorted, tile_range = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        names, parts = ["rgb", "depth"], [rgb, depth]
+        if "pixel_flow" in kwargs:
+            names.append("pixel_flow"); parts.append(kwargs["pixel_flow"])
+        widths = [p.shape[-1] for p in parts]
+        ndc = torch.zeros_like(uv, requires_grad=True)
+        rendered = gs.alpha_blending(uv, conic, opacity, torch.cat(parts, dim=-1), idx_sorted, tile_range, self.bg_color, W, H, ndc)
+        split, c0 = {}, 0
+        for k, c in zip(names, widths):
+            split[k] = rendered[c0:c0 + c]
+            c0 += c
+        return {"rendered_features_split": split, "viewspace_points": ndc, "visibility_filter": radius > 0, "radii": radius}
+
+    def render_batch(self, render_dict: dict, batch: Sequence[dict]) -> dict:
+        """``render_iter`` per batch element with its own camera; features stacked, visibility OR-ed, radii max-ed (:171-224)"""
+        feats: Dict[str, List[Tensor]] = {}
+        viewspace_points, vis, radii = [], [], []
+        for b_i in batch:
+            args = dict(b_i)
+            args.update(render_dict)
+            r = self.render_iter(**args)
+            for k, v in r["rendered_features_split"].items():
+                feats.setdefault(k, []).append(v)
+            viewspace_points.append(r["viewspace_points"])
+            vis.append(r["visibility_filter"].unsqueeze(0))
+            radii.append(r["radii"].unsqueeze(0))
+        return {**{k: torch.stack(v, dim=0) for k, v in feats.items()},
+                "viewspace_points": viewspace_points,
+                "visibility": torch.cat(vis).any(dim=0),
+                "radii": torch.cat(radii, 0).max(dim=0).values}
