@@ -48,6 +48,8 @@ SYMBOLS = [
     "splat_frames_gauss_backward_static_sets", "splat_frames_gauss_backward_dynamic_sets",
     "splat_preprocess_forward_batch_cam", "splat_frames_gauss_backward_static_cam", "splat_frames_gauss_backward_static_sets_cam",
     "splat_preprocess_persp_forward", "splat_preprocess_persp_backward",
+    "splat_blend_sets2_pair_stride", "splat_blend_sets2_pack_floats", "splat_alpha_blending_backward_batch_sets2",
+    "splat_frames_gauss_backward_static_sets2_cam", "splat_frames_gauss_backward_dynamic_sets2",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]
 
@@ -85,6 +87,10 @@ def lib() -> ctypes.CDLL:
         L.splat_blend_sets_pair_stride.argtypes = [ctypes.c_int]
         L.splat_blend_sets_pack_floats.restype = ctypes.c_size_t
         L.splat_blend_sets_pack_floats.argtypes = []
+        L.splat_blend_sets2_pair_stride.restype = ctypes.c_size_t
+        L.splat_blend_sets2_pair_stride.argtypes = []
+        L.splat_blend_sets2_pack_floats.restype = ctypes.c_size_t
+        L.splat_blend_sets2_pack_floats.argtypes = []
         L.splat_profile_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
         if L.splat_abi_version() != ABI_VERSION:
             raise SplatError("libsplat_hip.so ABI version mismatch; rebuild it")

@@ -493,11 +493,17 @@ class _RenderDynamicSets(torch.autograd.Function):
             dfe.append(dfeat)
             dfs[group_of[si]], strides[group_of[si]] = dfeat, int(feats[fi].shape[1])
             fi += 1
-        rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], ctx.opa_t, 0, want_abs)
+        two = _two_pass_ok(meta, widths)
+        if two:
+            rec = _blend_sets_backward_two_pass(fb, meta, ctx.blend, grads[:len(meta)], ctx.opa_t, 0)
+            want_abs = 1 if fb.want_abs else 0
+        else:
+            rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], ctx.opa_t, 0, want_abs)
         i3 = ctypes.c_int32 * 3
         p3 = (ctypes.c_void_p * 3)(*[0 if d is None else d.data_ptr() for d in dfs])
         has_tap = tap_set is not None
-        L.check(lib.splat_frames_gauss_backward_dynamic_sets(
+        gauss = lib.splat_frames_gauss_backward_dynamic_sets2 if two else lib.splat_frames_gauss_backward_dynamic_sets
+        L.check(gauss(
             L.ci(F), L.ci(P), L.ci(I), L.ci(C), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ptr(rec), L.ptr(fb.goff), L.ptr(fb.radius),
             L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(layout), L.ptr(rotation), L.ptr(rot_poly), L.ptr(rot_fourier),
             L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c), L.ptr(bufs["position"]), L.ptr(bufs["pos_cubic_node"]),
@@ -594,6 +600,53 @@ def _check_set_features(meta, feats, P):
         t = next(it)
         if t.dim() != 2 or t.shape[0] != P or t.shape[1] != w:
             raise ValueError(f"a set's feature must be [P={P}, {w}], got {tuple(t.shape)}")
+
+
+def _two_pass_ok(meta, widths) -> bool:
+    """SPLAT_SETS_TWO_PASS=1: the renderer's own configuration -- a tap set of <= 3 channels blended with the live opacity, the
+    per-frame depth, an attribute set of <= 20 channels blended with opacity.detach() -- takes the two-pass backward
+    (splat_alpha_blending_backward_batch_sets2: narrow kernel + LDS-resident dL_dout kernel, 4 + 3 waves per SIMD instead of the
+    one-pass kernel's 2).  Measured at BASELINE configs[1] (round 3): 192 + 521 us per frame against the one-pass kernel's 612 --
+    the second replay of the alpha / T chain costs more than the third wave gains -- so the one-pass kernel stays the default;
+    both are checked against the oracle (tests/test_gpu_frames_oracle.py)."""
+    if os.environ.get("SPLAT_SETS_TWO_PASS", "0") != "1" or len(meta) != 3:
+        return False
+    groups = _set_groups(meta)
+    if sorted(groups) != [0, 1, 2]:
+        return False
+    for (w, _, detach, taps), cn, g in zip(meta, widths, groups):
+        if g == 0 and (w == "depth" or cn > 3 or detach):
+            return False
+        if g == 1 and w != "depth":
+            return False
+        if g == 2 and (w == "depth" or cn > 20):
+            return False
+    return True
+
+
+def _blend_sets_backward_two_pass(fb, meta, state, grads, opacity, op_fs):
+    """the tile passes of the two-pass backward; returns the SETS2 record buffer"""
+    lib, st = L.lib(), L.stream()
+    F, P, W, H, cap = fb.F, fb.P, fb.W, fb.H, fb.capacity
+    groups = _set_groups(meta)
+    by = {}
+    for (w, bg, _, _), t, g_, cn, grp in zip(meta, state["tens"], grads, state["widths"], groups):
+        dl = L.need(g_, "dL_dout") if g_ is not None else torch.zeros(F, cn, H, W, dtype=torch.float32, device=fb.dev)
+        if tuple(dl.shape) != (F, cn, H, W):
+            raise ValueError("image gradient of a set must be [F, c, H, W]")
+        by[grp] = (t, dl, float(bg), cn)
+    (t_tap, dl_tap, bg_tap, cn_tap), (t_dep, dl_dep, bg_dep, _), (t_att, dl_att, bg_att, cn_att) = by[0], by[1], by[2]
+    from .gs.raster_ops import _debug_T_front
+    rec = fb._set_buffer(("rec", "sets2"), F * cap * int(lib.splat_blend_sets2_pair_stride()))
+    pack_a = fb._set_buffer(("pack", "sets2a"), F * P * int(lib.splat_blend_pack_floats(cn_tap)))
+    pack_b = fb._set_buffer(("pack", "sets2b"), F * P * int(lib.splat_blend_sets2_pack_floats()))
+    L.check(lib.splat_alpha_blending_backward_batch_sets2(
+        L.ci(F), L.ci(P), L.ci(cn_tap), L.ci(cn_att), (ctypes.c_float * 3)(bg_tap, bg_dep, bg_att), L.ptr(fb.uv), L.ptr(fb.conic),
+        L.ptr(opacity), ctypes.c_int64(op_fs), L.ptr(t_tap), ctypes.c_int64(0), L.ptr(t_dep), L.ptr(t_att), ctypes.c_int64(0),
+        L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib),
+        L.ptr(dl_tap), L.ptr(dl_dep), L.ptr(dl_att), L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack_a), L.ptr(pack_b),
+        L.ptr(fb.cull_flags), L.ptr(_debug_T_front(F * H, W, fb.dev)), st))
+    return rec
 
 
 def _set_groups(meta):
@@ -696,11 +749,17 @@ class _RenderSets(torch.autograd.Function):
                 dfe.append(dfeat)
                 dfs[group_of[si]], strides[group_of[si]] = dfeat, int(feats[fi].shape[1])
                 fi += 1
-            rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], opacity, op_fs, want_abs)
+            two = _two_pass_ok(meta, widths)
+            if two:
+                rec = _blend_sets_backward_two_pass(fb, meta, ctx.blend, grads[:len(meta)], opacity, op_fs)
+                want_abs = 1 if fb.want_abs else 0
+            else:
+                rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], opacity, op_fs, want_abs)
             i3 = ctypes.c_int32 * 3
             p3 = (ctypes.c_void_p * 3)(*[0 if d is None else d.data_ptr() for d in dfs])
             has_tap = tap_set is not None
-            L.check(lib.splat_frames_gauss_backward_static_sets_cam(
+            gauss = lib.splat_frames_gauss_backward_static_sets2_cam if two else lib.splat_frames_gauss_backward_static_sets_cam
+            L.check(gauss(
                 L.ci(F), L.ci(P), L.ci(C), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ptr(rec), L.ptr(fb.goff), L.ptr(fb.radius),
                 L.ptr(xyz), L.ptr(scales), L.ptr(uquats), ctypes.byref(camc), L.ci(1), L.ptr(bufs["xyz"]), L.ptr(bufs["scales"]),
                 L.ptr(bufs["uquats"]), L.ptr(bufs["opacity"]), i3(*c0s), i3(*cns), p3, i3(*strides), L.ci(depth_ch),
