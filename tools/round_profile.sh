@@ -2,7 +2,7 @@
 # GPU box: everything the round's measurement record needs, in one gpurun call.
 #   tools/round_profile.sh <tag>        (writes gpurun_out/<tag>/...)
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 export PYTHONPATH=$GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 mkdir -p $O
@@ -18,13 +18,16 @@ run bench_dynamic_a15 --dynamic --no-cpu-baseline
 run bench_render_iter --render-iter --no-cpu-baseline
 run bench_render_iter_per_frame --render-iter --per-frame --no-cpu-baseline
 run bench_render_iter_dynamic --render-iter --dynamic --no-cpu-baseline   # the reference's real training frame
+SPLAT_SETS_TWO_PASS=1 run bench_render_iter_dynamic_two_pass --render-iter --dynamic --no-cpu-baseline
+run bench_clustered --scene clustered --no-cpu-baseline --no-extra-lines   # 70 % of the Gaussians in blobs covering 10 % of the image
 # kernel trace of the default bench command (2 timed steps of 25 frames)
 export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+B="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-extra-lines"
 (cd /tmp && timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o bench -- $B > $GRAFT_REPO_ROOT/$O/prof_stdout.log 2>&1)
 find $O/prof -name '*kernel_stats*' | head -3
+python tools/trace_workload_stats.py $(find $O/prof -name '*kernel_trace.csv' | head -1) $O/kernel_stats_workload.csv
 # HBM traffic: two --pmc passes over one step of the default bench (25 frames per launch)
-B1="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+B1="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-extra-lines"
 bash tools/pmc_run.sh ${TAG}_rd "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum" $B1 < /dev/null > /dev/null
 bash tools/pmc_run.sh ${TAG}_wr "WRITE_SIZE" $B1 < /dev/null > /dev/null
 python tools/pmc_traffic.py gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr $O/pmc_traffic.json "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum (bytes = 32*n32+64*n64+128*n128) and WRITE_SIZE (KiB), separate passes, one step of the default bench.py (frame batch: 25 frames per launch), per launch" "300000x854x480x0:batch:morton" > /dev/null
