@@ -12,9 +12,9 @@
 //   K2b bin_tilescan single workgroup: exclusive scan of tile_count -> tile_range[T,2], M;
 //   K3 bin_scatter  same chunking as K1; LDS counters start at the chunk's base, ds_add_rtn
 //                   hands out the slot; writes key = (depth bits << 32 | gaussian id);
-//   K4 tile_sort    one workgroup per tile: bitonic sort of the tile's keys in LDS (all
-//                   comparators ascending -> no power-of-two padding needed), writes ids (and,
-//                   in pair-map mode, the Gaussian-major pair slot of every sorted entry).
+//   K4 tile_sort    one workgroup per tile: bitonic sort of the tile's keys in registers (<= 2048 keys; crowded
+//                   tiles: 2048-key blocks in registers + the strides of whole blocks through the tile's global
+//                   segment), writes ids (and, in pair-map mode, the Gaussian-major pair slot of every sorted entry).
 //
 // Since keys inside a tile are unique (id in the low word) the result is deterministic and equals
 // a STABLE sort of the reference keys (ties: ascending Gaussian id).  No host synchronisation.
@@ -28,7 +28,7 @@
 #define BIN_LDS_TILES 12288     // <= 48 KB of LDS counters; larger tile grids use global atomics
 #define BIN_GLOBAL_BLOCKS 2048   // grid of K1/K3 on the global-atomic path
 #define SORT_BLOCK 256
-#define SORT_LDS_KEYS 2048      // 16 KB of LDS per sort workgroup (larger tiles sort in their global segment)
+#define SORT_LDS_KEYS 2048      // 16 KB of LDS per sort workgroup: the exchange buffer of the two widest strides of a 2048-key block
 
 struct BinPlan {
     int T, gx, gy;
@@ -306,41 +306,6 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
 }
 
 // ------------------------------------------------------------------ K4: per-tile bitonic sort
-// All comparators ascending ("flip" first step of every merge), so indices >= n behave as +inf
-// without being stored: works for any n.  MEM = LDS copy (n <= SORT_LDS_KEYS) or the global
-// buffer itself (rare oversized tiles; a workgroup's global stores are visible to itself after
-// __syncthreads()).
-template <typename KeyPtr>
-__device__ __forceinline__ void bitonic_any_n(KeyPtr a, int n) {
-    int lg = 0;
-    while ((1 << lg) < n) ++lg;  // padded size 2^lg
-    const int half = (1 << lg) >> 1;
-    for (int lk = 1; lk <= lg; ++lk) {  // merge width k = 2^lk; all index math in shifts / masks
-        const int k = 1 << lk, hk = k >> 1;
-        for (int t = threadIdx.x; t < half; t += SORT_BLOCK) {  // flip step: i <-> mirror inside the block of k
-            const int blk = t >> (lk - 1), off = t & (hk - 1);
-            const int lo = (blk << lk) + off, hi = (blk << lk) + k - 1 - off;
-            if (hi < n) {
-                const unsigned long long x = a[lo], y = a[hi];
-                if (x > y) { a[lo] = y; a[hi] = x; }
-            }
-        }
-        __syncthreads();
-        for (int lj = lk - 2; lj >= 0; --lj) {  // stride j = 2^lj
-            const int j = 1 << lj;
-            for (int t = threadIdx.x; t < half; t += SORT_BLOCK) {
-                const int blk = t >> lj, off = t & (j - 1);
-                const int lo = (blk << (lj + 1)) + off, hi = lo + j;
-                if (hi < n) {
-                    const unsigned long long x = a[lo], y = a[hi];
-                    if (x > y) { a[lo] = y; a[hi] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // ---- register-blocked bitonic sort: R keys per thread (element i = t R + r), 256 threads -> up to 256 R keys.
 // Compare-exchange partners inside a thread are registers, partners up to 63 lanes away are fetched with VALU-only
 // cross-lane moves (DPP quad_perm / row shifts / row_ror, gfx950 v_permlane{16,32}_swap), only the two largest
@@ -471,6 +436,74 @@ __device__ __forceinline__ void tile_sort_regs(const u64 *g, int n, long long r0
     }
 }
 
+// ---- tiles above 8 SORT_BLOCK keys (crowded tiles: a foreground object on few tiles): blocks of NB = 8 SORT_BLOCK keys sort
+// in registers; the merges above NB take their wide strides (>= NB elements) through the tile's global segment (the segment of
+// one tile stays in L2) and finish every block's strides below NB in registers again.  All comparators of the merges ascend
+// ("flip" first step), so the +inf of the missing tail never moves and is never stored.  A tile of 5600 keys: 3 block sorts,
+// 3 global passes and 6 register cascades instead of the 91 global-memory stages of bitonic_any_n (BASELINE configs[1],
+// clustered scene: 205 us per frame of tile_sort before).
+template <int R>
+__device__ __forceinline__ void tile_sort_blocks(volatile u64 *g, int n, u64 *xbuf) {
+    constexpr int NB = R * SORT_BLOCK;
+    const int t = threadIdx.x;
+    const int nblk = (n + NB - 1) / NB;
+    u64 k[R];
+    auto load = [&](int b) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = b * NB + t * R + r;
+            k[r] = i < n ? g[i] : ~0ull;
+        }
+    };
+    auto store = [&](int b) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = b * NB + t * R + r;
+            if (i < n) g[i] = k[r];
+        }
+    };
+    for (int b = 0; b < nblk; ++b) {
+        load(b);
+        BitonicK<R, 2, NB>::run(k, t, xbuf);
+        store(b);
+    }
+    __syncthreads();
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    const int half = (1 << lg) >> 1;
+    for (int lk = 1; lk <= lg; ++lk) {
+        const int kw = 1 << lk, hk = kw >> 1;
+        if (kw <= NB) continue;                      // (merges inside a block: done)
+        for (int c = t; c < half; c += SORT_BLOCK) {  // flip step: i <-> mirror inside the block of kw
+            const int blk = c >> (lk - 1), off = c & (hk - 1);
+            const int lo = (blk << lk) + off, hi = (blk << lk) + kw - 1 - off;
+            if (hi < n) {
+                const u64 x = g[lo], y = g[hi];
+                if (x > y) { g[lo] = y; g[hi] = x; }
+            }
+        }
+        __syncthreads();
+        for (int lj = lk - 2; (1 << lj) >= NB; --lj) {   // strides of whole blocks
+            const int j = 1 << lj;
+            for (int c = t; c < half; c += SORT_BLOCK) {
+                const int blk = c >> lj, off = c & (j - 1);
+                const int lo = (blk << (lj + 1)) + off, hi = lo + j;
+                if (hi < n) {
+                    const u64 x = g[lo], y = g[hi];
+                    if (x > y) { g[lo] = y; g[hi] = x; }
+                }
+            }
+            __syncthreads();
+        }
+        for (int b = 0; b < nblk; ++b) {                 // strides NB / 2 .. 1 of every block, ascending
+            load(b);
+            BitonicJ<R, (1 << 30), NB / 2>::run(k, t, xbuf);
+            store(b);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(SORT_BLOCK)
 tile_sort_kernel(int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
                  int *__restrict__ idx_sorted, const int *__restrict__ owner, int *__restrict__ slot_sorted) {
@@ -501,9 +534,9 @@ tile_sort_kernel(int *__restrict__ tile_range, long long capacity, unsigned long
         tile_sort_regs<8>(g, n, r0, capacity, idx_sorted, owner, slot_sorted, sk);
     } else {
         __syncthreads();
-        bitonic_any_n((volatile unsigned long long *)g, n);
+        tile_sort_blocks<8>((volatile u64 *)g, n, sk);
         for (int i = threadIdx.x; i < n; i += SORT_BLOCK) {
-            const int lo = (int)(unsigned)(g[i] & 0xffffffffull);
+            const int lo = (int)(unsigned)(((volatile u64 *)g)[i] & 0xffffffffull);
             if (slot_sorted) {
                 slot_sorted[r0 + i] = (long long)lo < capacity ? lo : (int)(capacity - 1);
                 idx_sorted[r0 + i] = (long long)lo < capacity ? owner[lo] : 0;

@@ -35,6 +35,9 @@
 #ifndef BLEND_FWD_U
 #define BLEND_FWD_U 4      // survivors evaluated per trip in the forward (narrow channel counts)
 #endif
+#ifndef BLEND_FWD_TRIPTEST
+#define BLEND_FWD_TRIPTEST 0   // forward: skip a trip's compositing when no lane of the wave has a splat to apply (see the kernel)
+#endif
 #ifndef BLEND_FWD_SB
 #define BLEND_FWD_SB 128   // forward super-batch (narrow channel counts): 14 KB of LDS per workgroup
 #endif
@@ -681,8 +684,7 @@ blend_fwd_kernel(const BlendArgs B) {
     const int cn = EXACT ? CH : A.cn;
 
     const bool inside = (px < A.W) && (py < A.H);
-    bool done = !inside;
-    float T = 1.0f, F[CH];
+    float T = inside ? 1.0f : -1.0f, F[CH];   // T < 0: the pixel is finished, |T| its final transmittance
     int last = 0, layer = 0;
 #pragma unroll
     for (int k = 0; k < CH; ++k) F[k] = 0.f;
@@ -699,7 +701,7 @@ blend_fwd_kernel(const BlendArgs B) {
     st.load_ids(A, tid, range.x, pos, 1);
 
     for (int base = 0, batch = 0; base < n; base += SB, ++batch) {
-        const bool alld = __all(done);
+        const bool alld = __all(T < 0.f);
         if (lane == 0) s_done[w] = alld;
         const int nb = imin_(SB, n - base);
         st.park(L, tid);
@@ -759,7 +761,7 @@ blend_fwd_kernel(const BlendArgs B) {
                     g0[u] = *reinterpret_cast<const float4 *>(src);
                     g1[u] = *reinterpret_cast<const float4 *>(src + 16);
                 }
-                float amax = 0.f;
+                bool any = false;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (BIAS) {
@@ -772,13 +774,14 @@ blend_fwd_kernel(const BlendArgs B) {
                         const float a = fminf(0.99f, exp2_guard(pw, pw_ok));
                         alpha[u] = (pw_ok && !(a < (1.0f / 255.0f))) ? a : 0.f;
                     }
-                    amax = fmaxf(amax, alpha[u]);
+                    if (BLEND_FWD_TRIPTEST) any = any || (alpha[u] > 0.f);
                 }
-                if (__builtin_amdgcn_ballot_w64(!done && amax > 0.f) == 0ull) continue;   // (the bool form: no 0 / 1 round trip through a VGPR)
+                if (BLEND_FWD_TRIPTEST && __builtin_amdgcn_ballot_w64(any && T > 0.f) == 0ull) continue;
+                // Branch-free compositing.  A finished pixel carries its final T NEGATED: T (1 - alpha) < 0.0001 holds for it
+                // again ("saturated"), so nothing applies and no `done` predicate is kept; alpha = 0 (splat skipped on this
+                // pixel) multiplies T by 1 and adds f * 0: the pixel's values do not change by a bit.
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const bool ok = !done && alpha[u] > 0.f;  // an earlier survivor of this trip may have saturated the pixel
-                    if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
                     float f[CH];
                     const float4 *fq = reinterpret_cast<const float4 *>(recb + off[u] * RM + 32);  // 16-byte chunks of the record
 #pragma unroll
@@ -790,13 +793,12 @@ blend_fwd_kernel(const BlendArgs B) {
                         if (k + 3 < CH) f[k + 3] = v.w;
                     }
                     const float nT = T * (1.f - alpha[u]);
-                    const bool sat = ok && (nT < 0.0001f);
-                    const bool app = ok && !sat;
-                    done = done || sat;
-                    const float wgt = (app ? alpha[u] : 0.f) * T;
+                    const bool sat = nT < 0.0001f;   // reference: the splat that would take T below 1e-4 ends the pixel, unapplied
+                    const float wgt = sat ? 0.f : alpha[u] * T;
+                    const bool app = wgt > 0.f;
 #pragma unroll
                     for (int k = 0; k < CH; ++k) F[k] += f[k] * wgt;
-                    T = app ? nT : T;
+                    T = sat ? -fabsf(T) : nT;
                     lastoff = app ? (int)off[u] : lastoff;
                     if (ENH) {
                         if (app && (A.trunc || layer < A.K)) {
@@ -805,7 +807,7 @@ blend_fwd_kernel(const BlendArgs B) {
                             const size_t pix = (size_t)A.W * (size_t)py + px;
                             A.gs_idx[pix * A.K + layer] = __float_as_int(g1[u].w);
                             layer++;
-                            if (A.trunc && layer >= A.K) done = true;
+                            if (A.trunc && layer >= A.K) T = -T;
                         }
                     }
                 }
@@ -817,6 +819,7 @@ blend_fwd_kernel(const BlendArgs B) {
     if (inside) {
         const size_t HW = (size_t)A.H * A.W;
         const size_t pix = (size_t)A.W * (size_t)py + px;
+        T = fabsf(T);
         A.final_T[pix] = T;
         A.ncontrib[pix] = last;
 #pragma unroll

@@ -156,10 +156,12 @@ def test_compute_sh(gpu, oracle_mod, deg, free):
 
 # ------------------------------------------------------------------ sort
 @pytest.mark.parametrize("N,W,H,sigma", [(1, 16, 16, 2.0), (500, 33, 17, 2.0), (5000, 256, 256, 2.0),
-                                         (60000, 854, 480, 2.0), (6000, 64, 64, 12.0)])
+                                         (60000, 854, 480, 2.0), (6000, 64, 64, 12.0), (19000, 64, 64, 12.0),
+                                         (2300, 48, 48, 12.0)])
 def test_sort_gaussian_bit_exact(gpu, oracle_mod, N, W, H, sigma):
     """idx_sorted / tile_range identical to the oracle (stable order); sigma=12 px on 64x64 makes
-    tiles with > 2048 pairs, which takes the global-memory bitonic path."""
+    tiles with > 2048 pairs (2300: one block and a tail; 6000: 4096 < n < 8192; 19000: three merge levels above the
+    2048-key register blocks), the crowded-tile path of tile_sort."""
     import dptr.gs as gs
     o = oracle_mod
     sc = make_scene(N, W, H, seed=N + 1)
