@@ -1371,10 +1371,10 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
         }
 #pragma unroll
         for (int k = CH; k < PS; ++k) r[k] = 0.f;  // slot PZ: what lanes without a channel feed to the MFMAs
-        r[PS] = Tf * bgdot;
+        r[PS] = 0.f;
         r[PS + 1] = __int_as_float(last);
         r[PS + 2] = Tf;   // T_state: transmittance behind the splats replayed so far
-        r[PS + 3] = 0.f;  // R_state: colour behind them (dotted with dL_dout)
+        r[PS + 3] = Tf * bgdot;  // R_state: colour behind them (dotted with dL_dout) -- the background is the deepest layer
         wmax = wave_max_i(last);  // this wave never needs entries q >= wmax
         if (lane == 0) s_wmax[w] = wmax;
     }
@@ -1424,7 +1424,6 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     for (int q = 0; q < NA; ++q) gch[q] = 16 * q + nl < CH ? 16 * q + nl : PZ;  // channel row of the feature product
 #pragma unroll
     for (int j = 0; j < NK; ++j) kch[j] = 4 * j + kk < CH ? 4 * j + kk : PZ;    // K index of the cg product
-    const float xk = (float)(4 * (kk & 1)) - 3.5f, yk = (float)(kk >> 1) - 3.5f;  // own pixel: x = xk + i, y = yk + 2 G
 
     // wide rows: the A operands of the colour and feature-gradient products are the same in every chunk (dL_dout of the
     // wave's pixels) -- held in registers instead of re-read from LDS per chunk
@@ -1504,11 +1503,18 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
             // list position of this survivor in the tile (negative for the inert slot: harmless, alpha = 0)
             const int qn = (CARRY && e > SB) ? __float_as_int(g1.w) : top - e;
             // B operands: this lane's K-slice of the splat's power coefficients (x log2 e) and features
-            float bq1, bq2, bf[NK];
+            float bq1, bq2, blx = 0.f, bly = 0.f, bf[NK];
             {
                 const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, o, tcx, tcy);
                 bq1 = kk == 0 ? pc.q0 : kk == 1 ? pc.qx : kk == 2 ? pc.qy : pc.qxx;
                 bq2 = kk == 0 ? pc.qxy : kk == 1 ? pc.qyy : 0.f;
+                if (ABS) {
+                    // conic (centre - pixel), the factor of |d uv|, is affine in the pixel: one product with the monomials
+                    // (1, x, y, .) of phi1 per axis instead of six VALU operations per (pixel, splat)
+                    const float ut = g0.x - tcx, vt = g0.y - tcy;   // centre relative to the tile centre (phi1's origin)
+                    blx = kk == 0 ? cA * ut + cB * vt : kk == 1 ? -cA : kk == 2 ? -cB : 0.f;
+                    bly = kk == 0 ? cB * ut + cC * vt : kk == 1 ? -cB : kk == 2 ? -cC : 0.f;
+                }
 #pragma unroll
                 for (int j = 0; j < NK; ++j)  // this lane's K index of slab j: float 8 + 4 j + kk (zeros past CH: pack_kernel)
                     bf[j] = reinterpret_cast<const float *>(&L.rec[L.part(e, 2 + j)])[kk];
@@ -1531,13 +1537,12 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                 for (int j = 0; j < NK; ++j)
                     cgv = __builtin_amdgcn_mfma_f32_16x16x4f32(HOIST ? hcg[HOIST ? G : 0][HOIST ? j : 0] : pixcol[G * GS + kch[j]],
                                                                bf[j], cgv, 0, 0, 0);
-                float cg[4], araw[4], a[4], r1a[4], rp[4], Tb[4], Ts4[4], Rs4[4];
+                float cg[4], araw[4], a[4], r1a[4], rp[4], Ts4[4], Rs4[4];
                 bool ok[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float4 stv = *reinterpret_cast<const float4 *>(pixrow + G * GS + i * PW + PS);
                     cg[i] = cgv[i];  // (the colour dot product stays on the matrix cores: as per-lane FMAs it was 6 % slower)
-                    Tb[i] = stv.x;
                     const int last = __float_as_int(stv.y);
                     Ts4[i] = stv.z;
                     Rs4[i] = stv.w;
@@ -1565,10 +1570,15 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     lds_store2_lane15(pixrow + G * GS + i * PW + PS + 2, T[i], Rs4[i] + rs[i]);
+                f32x4 lx = {0.f, 0.f, 0.f, 0.f}, ly = {0.f, 0.f, 0.f, 0.f};
+                if (ABS) {
+                    lx = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], blx, lx, 0, 0, 0);
+                    ly = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bly, ly, 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int s = 4 * G + i;
-                    const float dLa = T[i] * cg[i] - (R[i] + Tb[i]) * r1a[i];
+                    const float dLa = T[i] * cg[i] - R[i] * r1a[i];   // (R includes the background term: the state starts from it)
                     const float dLp = araw[i] * dLa;  // dL/dpower (araw = 0 where the splat is not replayed)
                     d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(HOIST ? hmom[HOIST ? s : 0] : momrow[64 * s], dLp, d_mom, 0, 0, 0);
                     if (FEAT_VALU) {
@@ -1584,9 +1594,8 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
                                 HOIST ? hft[HOIST ? s : 0][HOIST ? q : 0] : pixrow[G * GS + i * PW + gch[q]], wgt[i], d_f[q], 0, 0, 0);
                     }
                     if (ABS) {
-                        const float dx = uc - (xk + (float)i), dy = vc - (yk + (float)(2 * G));
-                        s_ax += fabsf(dLp * (cA * dx + cB * dy));
-                        s_ay += fabsf(dLp * (cB * dx + cC * dy));
+                        s_ax += fabsf(dLp * lx[i]);
+                        s_ay += fabsf(dLp * ly[i]);
                     }
                 }
             }
@@ -1739,7 +1748,7 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
 struct SetsCfg {
     static constexpr int CH = 28, NK = 7, NA = 2, SB = 64;
     static constexpr int NG = 10, NCMAX = NG + CH;
-    static constexpr int PS = 8;  // state floats per pixel: [T_final bg.g of set 0 1 2, ncontrib | T, R of set 0 1 2]
+    static constexpr int PS = 8;  // state floats per pixel: [. . . ncontrib | T, R of set 0 1 2 (starting from T_final bg.g)]
 };
 
 // slot -> row channel (or -1): uniform selects on the kernel arguments
@@ -1880,10 +1889,10 @@ blend_bwd_sets_kernel(const BlendArgs B) {
             bgd[gi] += (gi == 0 ? A.s0bg : gi == 1 ? A.s1bg : A.s2bg) * g;
         }
         float *r = s_state[w] + pixoff(lane);
-        r[0] = Tf * bgd[0]; r[1] = Tf * bgd[1]; r[2] = Tf * bgd[2];
+        r[0] = 0.f; r[1] = 0.f; r[2] = 0.f;
         r[3] = __int_as_float(last);
         r[4] = Tf;    // T_state: transmittance behind the splats replayed so far
-        r[5] = 0.f; r[6] = 0.f; r[7] = 0.f;  // R_state of the three sets
+        r[5] = Tf * bgd[0]; r[6] = Tf * bgd[1]; r[7] = Tf * bgd[2];  // R_state of the three sets: starts from the background (the deepest layer)
         wmax = wave_max_i(last);
         if (lane == 0) s_wmax[w] = wmax;
     }
@@ -1957,7 +1966,6 @@ blend_bwd_sets_kernel(const BlendArgs B) {
         }
         return;
     }
-    const float xk = (float)(4 * (kk & 1)) - 3.5f, yk = (float)(kk >> 1) - 3.5f;  // own pixel: x = xk + i, y = yk + 2 G
 
     auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };
     Stager<CH, SB> st;
@@ -1996,11 +2004,16 @@ blend_bwd_sets_kernel(const BlendArgs B) {
             const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
             const float uc = g0.x - bx0 - 3.5f, vc = g0.y - by0 - 3.5f;
             const int qn = top - e;
-            float bq1, bq2, bf[NK];
+            float bq1, bq2, blx, bly, bf[NK];
             {
                 const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, o, tcx, tcy);
                 bq1 = kk == 0 ? pc.q0 : kk == 1 ? pc.qx : kk == 2 ? pc.qy : pc.qxx;
                 bq2 = kk == 0 ? pc.qxy : kk == 1 ? pc.qyy : 0.f;
+                // conic (centre - pixel), the tap gradient's factor, is affine in the pixel: one product with the monomials
+                // (1, x, y, .) of phi1 per axis instead of six VALU operations per (pixel, splat)
+                const float ut = g0.x - tcx, vt = g0.y - tcy;   // centre relative to the tile centre (phi1's origin)
+                blx = kk == 0 ? cA * ut + cB * vt : kk == 1 ? -cA : kk == 2 ? -cB : 0.f;
+                bly = kk == 0 ? cB * ut + cC * vt : kk == 1 ? -cB : kk == 2 ? -cC : 0.f;
 #pragma unroll
                 for (int j = 0; j < NK; ++j) bf[j] = reinterpret_cast<const float *>(&L.rec[L.part(e, 2 + j)])[kk];
             }
@@ -2019,14 +2032,12 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                 cv1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][1], bf[1], cv1, 0, 0, 0);
 #pragma unroll
                 for (int j = 2; j < NK; ++j) cv2 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][j], bf[j], cv2, 0, 0, 0);
-                float araw[4], a[4], r1a[4], rp[4], Ts4[4], Tb[3][4], Rs[3][4], cg[3][4];
+                float araw[4], a[4], r1a[4], rp[4], Ts4[4], Rs[3][4], cg[3][4];
                 bool ok[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float4 sa = *reinterpret_cast<const float4 *>(state + G * GS + i * PS);
+                    const int last = __float_as_int(state[G * GS + i * PS + 3]);
                     const float4 sb = *reinterpret_cast<const float4 *>(state + G * GS + i * PS + 4);
-                    Tb[0][i] = sa.x; Tb[1][i] = sa.y; Tb[2][i] = sa.z;
-                    const int last = __float_as_int(sa.w);
                     Ts4[i] = sb.x;
                     Rs[0][i] = sb.y; Rs[1][i] = sb.z; Rs[2][i] = sb.w;
                     cg[0][i] = cv0[i]; cg[1][i] = cv1[i]; cg[2][i] = cv2[i];
@@ -2057,12 +2068,15 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                     lds_store2_lane15(state + G * GS + i * PS + 4, T[i], Rs[0][i] + rs[0][i]);
                     lds_store2_lane15(state + G * GS + i * PS + 6, Rs[1][i] + rs[1][i], Rs[2][i] + rs[2][i]);
                 }
+                f32x4 lx = {0.f, 0.f, 0.f, 0.f}, ly = {0.f, 0.f, 0.f, 0.f};
+                lx = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], blx, lx, 0, 0, 0);
+                ly = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bly, ly, 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int s = 4 * G + i;
-                    const float dLa0 = T[i] * cg[0][i] - (R[0][i] + Tb[0][i]) * r1a[i];
-                    const float dLa1 = T[i] * cg[1][i] - (R[1][i] + Tb[1][i]) * r1a[i];
-                    const float dLa2 = T[i] * cg[2][i] - (R[2][i] + Tb[2][i]) * r1a[i];
+                    const float dLa0 = T[i] * cg[0][i] - R[0][i] * r1a[i];   // (R includes the set's background term)
+                    const float dLa1 = T[i] * cg[1][i] - R[1][i] * r1a[i];
+                    const float dLa2 = T[i] * cg[2][i] - R[2][i] * r1a[i];
                     const float am = ok[i] ? araw[i] : 0.f;
                     const float dLp_tap = am * dLa0;            // dL/dpower of the tap set
                     const float dLp_op = am * (dLa0 + dLa1);     // ... of the sets blended with the live opacity
@@ -2071,8 +2085,7 @@ blend_bwd_sets_kernel(const BlendArgs B) {
 #pragma unroll
                     for (int q = 0; q < NA; ++q) d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(hft[s][q], wgt[i], d_f[q], 0, 0, 0);
                     s_op += dLp_op;
-                    const float dx = uc - (xk + (float)i), dy = vc - (yk + (float)(2 * G));
-                    const float gx = dLp_tap * (cA * dx + cB * dy), gy = dLp_tap * (cB * dx + cC * dy);
+                    const float gx = dLp_tap * lx[i], gy = dLp_tap * ly[i];
                     s_tx += gx;
                     s_ty += gy;
                     if (ABS) {
@@ -2186,7 +2199,7 @@ struct AttrCfg {
     static constexpr int CH = 20, NK = 5, NA = 2, SB = 64, CAP = 32;
     static constexpr int NG = 7;                    // ux uy ca cb cc o dz
     static constexpr int NCMAX = NG + CH;
-    static constexpr int PS = 8;                    // state floats per pixel: [Tb1 Tb2 ncontrib gz | T R1 R2 .]
+    static constexpr int PS = 8;                    // state floats per pixel: [. . ncontrib gz | T R1 R2 .]  (R from T_final bg.g)
     static constexpr int RQL = 7;                   // staged parts of a packed record: geometry (2) + 20 attribute slots (5)
     static constexpr int REC_A = 12, REC_STRIDE = 40;  // the shared record: pass A's floats, total stride
 };
@@ -2285,11 +2298,11 @@ blend_bwd_attr_kernel(const BlendArgs B) {
             bg2 += A.s2bg * v;
         }
         float *r = s_state[w] + lane * PS;
-        r[0] = Tf * (A.s1bg * gz); r[1] = Tf * bg2;
+        r[0] = 0.f; r[1] = 0.f;
         r[2] = __int_as_float(last);
         r[3] = gz;
         r[4] = Tf;            // T_state
-        r[5] = 0.f; r[6] = 0.f; r[7] = 0.f;   // R_state of the depth set, of the attribute set
+        r[5] = Tf * (A.s1bg * gz); r[6] = Tf * bg2; r[7] = 0.f;   // R_state of the depth set, of the attribute set: from the background
         const int wmax = wave_max_i(last);
         if (lane == 0) s_wmax[w] = wmax;
     }
@@ -2395,15 +2408,14 @@ blend_bwd_attr_kernel(const BlendArgs B) {
                 asm volatile("" ::: "memory");   // (keeps the loads above the power product)
 #pragma unroll
                 for (int j = 0; j < NK; ++j) cv2 = __builtin_amdgcn_mfma_f32_16x16x4f32(opc[j], bf[j], cv2, 0, 0, 0);
-                float araw[4], a[4], r1a[4], rp[4], Ts4[4], Tb1[4], Tb2[4], R1s[4], R2s[4], gz[4];
+                float araw[4], a[4], r1a[4], rp[4], Ts4[4], R1s[4], R2s[4], gz[4];
                 bool ok[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float4 sa = *reinterpret_cast<const float4 *>(state + (16 * G + i) * PS);
+                    const float2 sa = *reinterpret_cast<const float2 *>(state + (16 * G + i) * PS + 2);
                     const float4 sb = *reinterpret_cast<const float4 *>(state + (16 * G + i) * PS + 4);
-                    Tb1[i] = sa.x; Tb2[i] = sa.y;
-                    const int last = __float_as_int(sa.z);
-                    gz[i] = sa.w;
+                    const int last = __float_as_int(sa.x);
+                    gz[i] = sa.y;
                     Ts4[i] = sb.x; R1s[i] = sb.y; R2s[i] = sb.z;
                     bool pw_ok;
                     araw[i] = exp2_guard(pw[i], pw_ok);
@@ -2434,8 +2446,8 @@ blend_bwd_attr_kernel(const BlendArgs B) {
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float dLa1 = T[i] * cg1[i] - (R1[i] + Tb1[i]) * r1a[i];
-                    const float dLa2 = T[i] * cv2[i] - (R2[i] + Tb2[i]) * r1a[i];
+                    const float dLa1 = T[i] * cg1[i] - R1[i] * r1a[i];   // (R includes the set's background term)
+                    const float dLa2 = T[i] * cv2[i] - R2[i] * r1a[i];
                     const float dLp_op = araw[i] * dLa1;             // the depth set is blended with the live opacity
                     const float dLp = araw[i] * (dLa1 + dLa2);
                     d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[(16 * G + i) * 9], dLp, d_mom, 0, 0, 0);
