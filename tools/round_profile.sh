@@ -36,4 +36,9 @@ bash tools/pmc_run.sh ${TAG}_b1 "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLE
 bash tools/pmc_run.sh ${TAG}_b2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES" $B1 < /dev/null > /dev/null
 bash tools/pmc_run.sh ${TAG}_b3 "SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE" $B1 < /dev/null > /dev/null
 PMC_CONFIG="300000x854x480x0:batch:morton" PMC_SOURCE="rocprofv3 --pmc, three passes over one step of the default bench.py (frame batch: 25 frames per launch), per launch, summed over the 8 XCDs; SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES in quad-cycles (guides/MI355X_MICROARCH.md)" python tools/pmc_blend_counters.py $O/pmc_blend_counters.json gpurun_out/pmc_${TAG}_b1 gpurun_out/pmc_${TAG}_b2 gpurun_out/pmc_${TAG}_b3
+# clustered scene (70 % of the Gaussians on 10 % of the image): wave residency of the compositing kernels (two passes)
+BC="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --scene clustered --no-cpu-baseline --no-kernel-timing --no-extra-lines"
+bash tools/pmc_run.sh ${TAG}_c1 "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA" $BC < /dev/null > /dev/null
+bash tools/pmc_run.sh ${TAG}_c3 "SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE" $BC < /dev/null > /dev/null
+PMC_CONFIG="300000x854x480x0:batch:morton:clustered" PMC_SOURCE="rocprofv3 --pmc, two passes over one step of bench.py --scene clustered, per launch, summed over the 8 XCDs" python tools/pmc_blend_counters.py $O/pmc_blend_counters_clustered.json gpurun_out/pmc_${TAG}_c1 gpurun_out/pmc_${TAG}_c3
 ls $O
