@@ -120,3 +120,24 @@ struct GradLayout {
 // stride of a pair record in floats: the used floats rounded up to whole 16-byte chunks (a Gaussian's records are
 // contiguous and streamed with float4 loads; padding every record to a 64-byte sector cost 30 % more traffic)
 #define PAIR_STRIDE(nc) (((nc) + 3) & ~3)
+// Workgroups are handed to the 8 XCDs round-robin by linear block id, and every XCD has its own L2.  Neighbouring
+// tiles gather largely the same packed records (a splat touches ~4 tiles), so runs of BLEND_XCD_RUN consecutive tiles
+// of the row-major order go to the same XCD (its consecutive blocks, i.e. roughly concurrently resident), and the runs
+// are dealt round-robin so that every XCD sees the whole image (a contiguous band per XCD halves the HBM reads as
+// well but leaves the XCDs that own the image borders idle early).  Block b = XCD b & 7, its (b >> 3)-th block.
+#ifndef BLEND_XCD_RUN
+#define BLEND_XCD_RUN 64   // a run is about one tile row of a 480p frame plus the start of the next (54 tiles per row)
+#endif
+__device__ __forceinline__ int xcd_tile(int b, int T) {
+#if BLEND_XCD_RUN > 1
+    constexpr int S = BLEND_XCD_RUN;
+    const int full = (T / (8 * S)) * (8 * S);  // tiles covered by complete rounds of 8 runs; the tail maps linearly
+    if (b >= full) return b;
+    const int x = b & 7, q = b >> 3;
+    return ((q / S) * 8 + x) * S + (q % S);
+#else
+    return b;
+#endif
+}
+
+
