@@ -56,7 +56,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak (guides/MI355X_MICROARCH.md); ~6300 GB
 PMC_TAG = os.environ.get("SPLAT_PMC_TAG", "r03")
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_traffic.json")
 PMC_COUNTER_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_blend_counters.json")
-PMC_KERNEL_NAMES = {"blend_bwd": "blend_bwd_mfma_kernel", "blend_fwd": "blend_fwd_kernel", "tile_sort": "tile_sort_kernel",
+PMC_KERNEL_NAMES = {"blend_bwd": ("blend_bwd_quarter_kernel", "blend_bwd_mfma_kernel"), "blend_fwd": "blend_fwd_kernel", "tile_sort": "tile_sort_kernel",
                     "gauss_bwd": "frames_gauss_bwd_static_kernel", "pair_reduce": "pair_reduce_kernel",
                     "sh_fwd": "sh_fwd_kernel", "sh_bwd": "sh_bwd_kernel", "bin_scatter": "bin_scatter_kernel"}
 
@@ -69,7 +69,10 @@ def pmc_traffic(kernel, tag_cfg):
         rec = json.load(open(PMC_TRAFFIC_FILE))
         if rec.get("config") != tag_cfg:
             return None, None
-        k = rec["kernels"].get(PMC_KERNEL_NAMES.get(kernel, ""), None)
+        names = PMC_KERNEL_NAMES.get(kernel, "")
+        k = None
+        for nm in (names if isinstance(names, tuple) else (names,)):   # (the kernel the launch actually ran: first name on record)
+            k = k or rec["kernels"].get(nm, None)
         if k is None:
             return None, None
         return k["read_bytes"] + k["write_bytes"], f"profiles/{PMC_TAG}_pmc_traffic.json ({rec.get('source', 'rocprofv3 --pmc, offline')})"

@@ -1712,6 +1712,388 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
     }
 }
 
+// ------------------------------------------------------------------ narrow matrix-core backward on QUARTER lists
+// blend_bwd_mfma_kernel replays a block-level survivor over the 64 pixels of the wave's 8x8 block; on BASELINE configs[1] a
+// (tile, splat) pair keeps 1.23 of its 4 blocks but only 3.2 of its 16 quarters (4x4 pixels), and 32 % of the evaluated
+// (pixel, splat) pairs are active against the forward's 49 %.  Here every 4x4 quarter of the wave's block walks
+// its OWN order-preserving list (the quarter bits of the forward's cull flags; pixels of different quarters are independent,
+// only the order inside a quarter matters), a step = 16 survivors of one quarter's list x its 16 pixels = the strip step of
+// blend_bwd_mfma_kernel with the strip being the quarter.  What makes a step per quarter pay (round 2's experiment with the
+// full chunk prologue / epilogue per step did not):
+//   * the power polynomial's coefficients are computed ONCE per staged entry, by the lanes that park its record (quad exchange
+//     of the two geometry parts), into the record's unused floats: part 3 = q0 qx qy qxx, part 1 .zw = qxy qyy;
+//   * a step adds RAW moments of dL/dpower about the wave's block centre (moved to the tile centre in the combine) and the feature sums
+//     into the survivor's slab row (rows by position in the wave's block-level list, float4 read-add-write by three lane
+//     groups); the map to d uv / d conic / d opacity runs once per entry in the combine, which has the entry's geometry;
+//   * no carried survivors: lists of a quarter are short, the super-batch is what fills the steps.
+// Same arithmetic as blend_bwd_mfma_kernel per (pixel, splat): exponent chain, guards, scans.  Narrow rows without |taps|.
+#ifndef BLEND_Q_SB
+#define BLEND_Q_SB 128
+#endif
+#ifndef BLEND_Q_CAP
+#define BLEND_Q_CAP 64   // slab rows per wave and round (a second round costs a list rebuild, two barriers and a combine: 145 us per frame at 48 rows, 155 at 44, 189 at 32)
+#endif
+#ifndef BLEND_Q_SWZ
+#define BLEND_Q_SWZ 1   // part p of entry e at 4 e + (p ^ ((e >> 2) & 3)): 16 survivors' reads of one part spread over the banks
+#endif
+#ifndef BLEND_Q_MINW
+#define BLEND_Q_MINW 4
+#endif
+template <int CH>
+struct QuarterCfg {
+    static_assert(CH <= 3 && Rec<CH>::RQ == 4 && Rec<CH>::CULL >= 11, "floats 11-15 of the record (cull parameters) are free for the coefficients");
+    static constexpr int SB = BLEND_Q_SB, CAP = BLEND_Q_CAP;
+    static constexpr int NG = GradLayout<false, false>::NG, NC = NG + CH, NCP = PAIR_STRIDE(NC);
+    static constexpr int RW = 16;   // slab row: [M0 Mx My Mxx | Mxy Myy . . | f0 f1 f2 . of lane groups 0 + 2 | of lane groups 1 + 3]
+    static constexpr int PW = 8;    // pixel row: [g0 g1 g2 . | . ncontrib T_state R_state]
+};
+
+template <int CH, bool EXACT>
+__global__ void __launch_bounds__(256, BLEND_Q_MINW)
+blend_bwd_quarter_kernel(const BlendArgs B) {
+    using Cfg = QuarterCfg<CH>;
+    constexpr int SB = Cfg::SB, CAP = Cfg::CAP, NCP = Cfg::NCP, RW = Cfg::RW, PW = Cfg::PW, RQ = 4;
+    static_assert(SB <= 128 && CAP < 255, "list entries are (entry | position << 8) in 16 bits");
+    __shared__ float4 s_rec[(SB + 1) * RQ];              // staged records, slot SB = inert; part p of entry e at qpart(e, p)
+    auto qpart = [](int e, int p) { return BLEND_Q_SWZ ? 4 * e + (p ^ ((e >> 2) & 3)) : 4 * e + p; };
+    __shared__ unsigned int s_keep[SB];
+    __shared__ unsigned short s_qlist[4][4][CAP + 16];   // [wave][quarter], entries of the current round: entry | (slab row) << 8
+    __shared__ unsigned int s_pos4[SB];                  // byte w: position of entry e in wave w's block-level list (255: none)
+    __shared__ __attribute__((aligned(16))) float s_acc[4][(CAP + 1) * RW];
+    constexpr int KS = 4 * PW + 8, GS = 4 * KS;          // pixel rows skewed per lane group (see blend_bwd_mfma_kernel)
+    __shared__ __attribute__((aligned(16))) float s_pix[4][4 * GS];
+    auto pixoff = [](int q) { return (q >> 4) * GS + ((q >> 2) & 3) * KS + (q & 3) * PW; };
+    __shared__ float s_mom[16 * 32];   // [step][lane group][row & 7]: rows 0-5 of the moment operand (rows 8-15 alias them: their products are not used)
+    __shared__ int s_wmax[4];
+    __shared__ int s_more[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int gtile = xcd_tile(blockIdx.x, gridDim.x);
+    const int frame = gtile / B.T, tile = gtile - frame * B.T;
+    const BlendArgs A = frame_args(B, frame);
+    const int RST = B.rec_stride ? B.rec_stride : NCP;
+    float *const pair_buf = B.pair_buf + (size_t)frame * (size_t)B.cap * RST + B.rec_off;
+    const int tx = tile % A.gx, ty = tile / A.gx;
+    const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
+    const float tcx = (float)(tx * TILE) + 7.5f, tcy = (float)(ty * TILE) + 7.5f;   // tile centre: origin of the polynomial AND of the moments
+    const float ox = (float)((w & 1) * 8) - 7.5f, oy = (float)((w >> 1) * 8) - 7.5f;
+    const int cn = EXACT ? CH : A.cn;
+    const int nl = lane & 15, kk = lane >> 4;
+    // pixel index of the strip walk: q = 16 G + 4 kk + i  <->  quarter G = (sx, sy), pixel (x, y) = (4 sx + i, 4 sy + kk)
+    auto qx = [](int q) { return 4 * ((q >> 4) & 1) + (q & 3); };
+    auto qy = [](int q) { return 4 * (q >> 5) + ((q >> 2) & 3); };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // A operand of the moment product (one table for the four waves): rows 0-3 = 1 x y xx, rows
+                                    // 4-5 = xy yy of the pixel in BLOCK-centred coordinates; the combine moves a wave's sums to the tile centre
+        const int st = 4 * w + r, Gs = st >> 2, is = st & 3;
+        const int q = 16 * Gs + 4 * kk + is;
+        const float x = (float)qx(q) - 3.5f, y = (float)qy(q) - 3.5f;
+        float v = 0.f;
+        if (nl < 4) v = nl == 0 ? 1.f : nl == 1 ? x : nl == 2 ? y : x * x;
+        else if (nl < 6) v = nl == 4 ? x * y : y * y;
+        if (nl < 8) s_mom[32 * st + 8 * kk + nl] = v;
+    }
+    float phi1[4], phi2[4];
+#pragma unroll
+    for (int Gs = 0; Gs < 4; ++Gs) {
+        const int q = 16 * Gs + nl;
+        const float x = (float)qx(q) + ox, y = (float)qy(q) + oy;
+        phi1[Gs] = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
+        phi2[Gs] = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
+    }
+    const int lx = lane & 7, ly = lane >> 3;                                       // lane <-> pixel (lx, ly) of the block
+    const int myq = 16 * ((lx >> 2) + 2 * (ly >> 2)) + 4 * (ly & 3) + (lx & 3);    // its index in the strip walk
+    {
+        const int px = bx + lx, py = by + ly;
+        const size_t HW = (size_t)A.H * A.W;
+        const bool inside = (px < A.W) && (py < A.H);
+        const size_t pix = (size_t)A.W * (size_t)py + px;
+        const float Tf = inside ? A.final_T[pix] : 0.f;
+        const int last = inside ? A.ncontrib[pix] : 0;
+        float *r = s_pix[w] + pixoff(myq);
+        float bgdot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g = (k < CH && inside && k < cn) ? A.dL_dout[(size_t)(A.c0 + k) * HW + pix] : 0.f;
+            r[k] = g;
+            bgdot += A.bg * g;
+        }
+        r[4] = 0.f;
+        r[5] = __int_as_float(last);
+        r[6] = Tf;             // T_state
+        r[7] = Tf * bgdot;     // R_state: starts from the background
+        const int wmax = wave_max_i(last);
+        if (lane == 0) s_wmax[w] = wmax;
+    }
+    if (tid < RQ) s_rec[qpart(SB, tid)] = make_float4(tid == 3 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);   // inert slot SB: q0 = log2(0)
+    if (lane < RW) s_acc[w][CAP * RW + lane] = 0.f;   // the slab's zero row
+    __syncthreads();
+    const int2 range = A.tile_range[tile];
+    const int len = range.y - range.x;
+    const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
+    const int *slots = A.slot_sorted + range.x;
+    auto store_rec = [&](int slot, const float (&v)[12]) {
+        float4 *dst = reinterpret_cast<float4 *>(pair_buf + (size_t)slot * RST);
+#pragma unroll
+        for (int c = 0; c < NCP / 4; ++c) dst[c] = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    };
+    {
+        const float z[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int ql = n + tid; ql < len; ql += 256) store_rec(slots[ql], z);   // entries nobody replays: zero record
+    }
+    if (n <= 0) {
+        if (A.dbg_T_front) {
+            const int px = bx + lx, py = by + ly;
+            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_pix[w][pixoff(myq) + 6];
+        }
+        return;
+    }
+    float *pixrow = s_pix[w] + kk * KS;            // own pixel of step (G, i): pixrow + G * GS + i * PW
+    const float *pixcol = s_pix[w] + pixoff(nl);   // pixel nl of quarter G: pixcol + G * GS
+    const float *momrow = s_mom + 8 * kk + (nl & 7);
+    const int kch = kk < CH ? kk : 4;              // K index of the cg product (slot 4 of a pixel row is zero)
+
+    auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };
+    Stager<CH, SB> st;
+    static_assert(Stager<CH, SB>::NCHUNK % 256 == 0, "every thread parks K chunks");
+    st.load_ids(A, tid, range.x, pos, 0);
+    st.load_payload(A, tid);
+    st.load_ids(A, tid, range.x, pos, 1);
+    auto load_flags = [&](int topb) -> unsigned {
+        const int q = topb - tid;
+        return (tid < SB && q >= 0) ? (unsigned)A.cull_flags[range.x + q] : 0u;
+    };
+    unsigned fl_next = load_flags(n - 1);
+
+    int batch = 0;
+    for (int top = n - 1; top >= 0; top -= SB, ++batch) {
+        const int nb = imin_(SB, top + 1);
+        {   // park the records; the lanes holding part 0 / part 1 of an entry exchange them and leave the polynomial's
+            // coefficients in the record: part 3 = q0 qx qy qxx, part 1 = C o qxy qyy
+            const int p = tid & 3;
+#pragma unroll
+            for (int k = 0; k < Stager<CH, SB>::K; ++k) {
+                const int e = (tid >> 2) + 64 * k;
+                const float4 mine = st.v[k];
+                float4 other;
+                other.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.x), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                other.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.y), 0xB1, 0xf, 0xf, true));
+                other.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.z), 0xB1, 0xf, 0xf, true));
+                other.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.w), 0xB1, 0xf, 0xf, true));
+                const float4 g0 = p == 0 ? mine : other, g1 = p == 0 ? other : mine;
+                const PowerCoef pc = power_coeffs(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, tcx, tcy);
+                if (p == 0) {
+                    s_rec[qpart(e, 0)] = mine;
+                    s_rec[qpart(e, 3)] = make_float4(pc.q0, pc.qx, pc.qy, pc.qxx);
+                } else if (p == 1) {
+                    s_rec[qpart(e, 1)] = make_float4(mine.x, mine.y, pc.qxy, pc.qyy);
+                } else if (p == 2) {
+                    s_rec[qpart(e, 2)] = make_float4(mine.x, mine.y, mine.z, 0.f);   // (.w: a cull parameter, possibly inf, would meet a zero of the cg product)
+                }
+            }
+        }
+        const unsigned fl = fl_next;
+        fl_next = load_flags(top - SB);
+        if (tid < SB) {   // keep word of entry tid: byte w = the quarter bits of the forward's cull, if wave w still needs the entry
+            unsigned kw = 0u;
+            if (tid < nb) {
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww)
+                    if (top - tid < s_wmax[ww]) kw |= fl & (0xfu << (8 * ww));
+            }
+            s_keep[tid] = kw;
+        }
+        __syncthreads();
+        float *slab = s_acc[w];
+        int slot_mine = 0;
+        for (int p0 = 0;; p0 += CAP) {   // rounds of CAP positions of the wave's block-level list (one, unless more survive)
+            // ---- this wave's lists: block-level positions (slab rows, the combine's lookup) and one list per quarter
+            // (the four quarter counts ride in the bytes of one word: one wave-wide prefix sum serves the four lists)
+            unsigned cqw = 0u;   // packed list lengths, byte q = quarter q (at most CAP entries of a round in a list)
+            int cnt = 0;
+#pragma unroll
+            for (int r = 0; r < SB / WAVE; ++r) {
+                const int e = r * WAVE + lane;
+                unsigned bits = (s_keep[e] >> (8 * w)) & 0xfu;
+                const bool kb = bits != 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(kb);
+                const int ps = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (p0 == 0) reinterpret_cast<unsigned char *>(s_pos4)[4 * e + w] = kb ? (unsigned char)imin_(ps, 254) : (unsigned char)255;
+                bits = ((unsigned)(ps - p0) < (unsigned)CAP) ? bits : 0u;       // entries of this round
+                const unsigned word = (bits * 0x00204081u) & 0x01010101u;      // bit q -> byte q
+                unsigned incl = word;
+                asm volatile("s_nop 1\n\t"
+                             "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\t"
+                             "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\t"
+                             "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\t"
+                             "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\t"
+                             "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                             "s_nop 1\n\t"
+                             "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                             : "+v"(incl));
+                const unsigned posw = cqw + incl - word;                       // packed list positions of this lane's entry
+                const unsigned short ent = (unsigned short)(e | ((ps - p0) << 8));
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((bits >> q) & 1u) s_qlist[w][q][(posw >> (8 * q)) & 0xffu] = ent;
+                cqw += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                cnt += __popcll(m);
+            }
+            int cq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cq[q] = (int)((cqw >> (8 * q)) & 0xffu);
+            if (lane < 16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s_qlist[w][q][cq[q] + lane] = (unsigned short)(SB | (CAP << 8));   // pad: inert entry, zero row
+            }
+            {   // rows of this round start from zero
+                const int rows = imin_(imax_(cnt - p0, 0), CAP);
+                float4 *z = reinterpret_cast<float4 *>(slab);
+                for (int c = lane; c < rows * (RW / 4); c += WAVE) z[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (lane == 0) s_more[w] = cnt > p0 + CAP;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {
+                for (int j0 = 0; j0 < cq[G]; j0 += 16) {
+                    const unsigned le = s_qlist[w][G][j0 + nl];
+                    const int e = le & 0xffu, row = le >> 8;
+                    const int qn = top - e;
+                    const float *er = reinterpret_cast<const float *>(s_rec) + e * (4 * RQ);
+                    const int sw = BLEND_Q_SWZ ? 4 * ((e >> 2) & 3) : 0;   // float offset of part p: 4 p ^ sw
+                    const float bq1 = er[(12 ^ sw) + kk];           // q0 qx qy qxx
+                    const float bq2 = er[(4 ^ sw) + 2 + (kk & 1)];  // qxy qyy (lane groups 2, 3: their monomial operand is zero)
+                    const float bf = er[(8 ^ sw) + kk];             // feature kk (zero past CH)
+                    f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
+                    float dfv[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) dfv[c] = 0.f;
+                    asm volatile("" ::: "memory");
+                    f32x4 pw = {0.f, 0.f, 0.f, 0.f}, cgv = {0.f, 0.f, 0.f, 0.f};
+                    pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bq1, pw, 0, 0, 0);
+                    pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi2[G], bq2, pw, 0, 0, 0);
+                    cgv = __builtin_amdgcn_mfma_f32_16x16x4f32(pixcol[G * GS + kch], bf, cgv, 0, 0, 0);
+                    float cg[4], araw[4], a[4], r1a[4], rp[4], Ts4[4], Rs4[4];
+                    float4 gq[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        gq[i] = *reinterpret_cast<const float4 *>(pixrow + G * GS + i * PW);
+                        const float4 stv = *reinterpret_cast<const float4 *>(pixrow + G * GS + i * PW + 4);
+                        cg[i] = cgv[i];
+                        const int last = __float_as_int(stv.y);
+                        Ts4[i] = stv.z;
+                        Rs4[i] = stv.w;
+                        bool pw_ok;
+                        araw[i] = exp2_guard(pw[i], pw_ok);
+                        const bool ok = (qn < last) && pw_ok && !(araw[i] < (1.0f / 255.0f));
+                        araw[i] = ok ? araw[i] : 0.f;
+                        a[i] = fminf(0.99f, araw[i]);
+                        r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
+                        rp[i] = r1a[i];
+                    }
+                    row_scan_mul4(rp[0], rp[1], rp[2], rp[3]);
+                    float T[4], wgt[4], rs[4], R[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        T[i] = Ts4[i] * rp[i];
+                        wgt[i] = a[i] * T[i];
+                        rs[i] = cg[i] * wgt[i];
+                    }
+                    row_scan_add4(rs[0], rs[1], rs[2], rs[3]);
+                    row_shr1_add4(R, rs, Rs4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lds_store2_lane15(pixrow + G * GS + i * PW + 6, T[i], Rs4[i] + rs[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float dLa = T[i] * cg[i] - R[i] * r1a[i];
+                        const float dLp = araw[i] * dLa;
+                        d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[32 * (4 * G + i)], dLp, d_mom, 0, 0, 0);
+                        dfv[0] = __builtin_fmaf(gq[i].x, wgt[i], dfv[0]);
+                        if (CH > 1) dfv[1 % CH] = __builtin_fmaf(gq[i].y, wgt[i], dfv[1 % CH]);
+                        if (CH > 2) dfv[2 % CH] = __builtin_fmaf(gq[i].z, wgt[i], dfv[2 % CH]);
+                    }
+                    // ---- step epilogue: raw sums into the survivor's row (this wave's quarters run one after the other: plain
+                    //      read-add-write; lane group kk owns floats 4 kk .. 4 kk + 3 of the row)
+                    float fs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {   // lane groups kk and kk ^ 2 together (one swap); groups 0 and 1 keep a half each
+                        const u32x2_b r = __builtin_amdgcn_permlane32_swap(__float_as_uint(dfv[c]), __float_as_uint(dfv[c]), false, false);
+                        fs[c] = dfv[c] + __uint_as_float((lane & 32) ? r[0] : r[1]);
+                    }
+                    if (kk < 2 && j0 + nl < cq[G]) {   // lane group kk: floats 4 kk .. of the moments, 8 + 4 kk .. of the features
+                        float4 *rm = reinterpret_cast<float4 *>(slab + row * RW + 4 * kk), *rf = rm + 2;
+                        float4 m4 = *rm, f4 = *rf;
+                        m4.x += d_mom[0]; m4.y += d_mom[1]; m4.z += d_mom[2]; m4.w += d_mom[3];
+                        f4.x += fs[0]; f4.y += fs[1]; f4.z += fs[2];
+                        *rm = m4;
+                        *rf = f4;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next step may add to the same rows
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (p0 == 0) {
+                slot_mine = tid < nb ? slots[top - tid] : 0;   // this thread's entry in the combine: entry tid
+                st.load_payload(A, tid);
+                st.load_ids(A, tid, range.x, pos, batch + 2);
+            }
+            __syncthreads();
+            // ---- combine: thread e sums entry e's rows of the four slabs and maps the raw moments to the record
+            if (tid < nb) {
+                const int e = tid;
+                const unsigned int p4 = s_pos4[e];
+                float s[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const unsigned int pp = umin_(((p4 >> (8 * ww)) & 0xffu) - (unsigned)p0, (unsigned)CAP);
+                    const float4 *rw = reinterpret_cast<const float4 *>(s_acc[ww] + pp * RW);
+                    const float4 m = rw[0], m2 = rw[1], fa = rw[2], fb = rw[3];
+                    // wave ww's moments are about its block centre (bxw, byw) = (-4 | 4, -4 | 4) from the tile centre:
+                    // X = x + bxw, Y = y + byw
+                    const float bxw = (ww & 1) ? 4.f : -4.f, byw = (ww >> 1) ? 4.f : -4.f;
+                    s[0] += m.x;
+                    s[1] += m.y + bxw * m.x;
+                    s[2] += m.z + byw * m.x;
+                    s[3] += m.w + 2.f * bxw * m.y + (bxw * bxw) * m.x;
+                    s[4] += m2.x + bxw * m.z + byw * m.y + (bxw * byw) * m.x;
+                    s[5] += m2.y + 2.f * byw * m.z + (byw * byw) * m.x;
+                    s[6] += fa.x + fb.x; s[7] += fa.y + fb.y; s[8] += fa.z + fb.z;
+                }
+                const float4 g0 = s_rec[qpart(e, 0)], g1 = s_rec[qpart(e, 1)];
+                const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
+                const float uc = g0.x - tcx, vc = g0.y - tcy;
+                const float M0 = s[0], Mx = s[1], My = s[2], Mxx = s[3], Mxy = s[4], Myy = s[5];
+                float rec[12];
+                rec[0] = cA * Mx + cB * My - (cA * uc + cB * vc) * M0;
+                rec[1] = cB * Mx + cC * My - (cB * uc + cC * vc) * M0;
+                rec[2] = -0.5f * (uc * uc * M0 - 2.f * uc * Mx + Mxx);
+                rec[3] = -(uc * vc * M0 - uc * My - vc * Mx + Mxy);
+                rec[4] = -0.5f * (vc * vc * M0 - 2.f * vc * My + Myy);
+                rec[5] = o > 0.f ? M0 / o : 0.f;
+                rec[6] = s[6]; rec[7] = s[7]; rec[8] = s[8];
+                rec[9] = 0.f; rec[10] = 0.f; rec[11] = 0.f;
+                if (p0 > 0) {   // a further round of the same super-batch: this thread stored the record before
+                    const float *old = pair_buf + (size_t)slot_mine * RST;
+#pragma unroll
+                    for (int c = 0; c < Cfg::NC; ++c) rec[c] += old[c];
+                }
+                store_rec(slot_mine, rec);
+            }
+            const bool more = s_more[0] | s_more[1] | s_more[2] | s_more[3];
+            __syncthreads();
+            if (!more) break;
+        }
+    }
+    if (A.dbg_T_front) {
+        const int px = bx + lx, py = by + ly;
+        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_pix[w][pixoff(myq) + 6];
+    }
+}
+
 // ------------------------------------------------------------------ backward of several feature SETS in ONE pass
 // The reference renderer composites up to three feature sets over one geometry (reference:
 // src/pointrix/renderer/dptr_ortho_enhanced.py:331-375): the TAP set (alpha_blending_enhanced: every gradient + the ndc /
@@ -2667,11 +3049,25 @@ static bool bwd_use_mfma() {
     return v != 0;
 }
 
+// SPLAT_BWD_QUARTERS=0: the block-level matrix-core kernel also where the quarter-list kernel applies (A/B measurements)
+static bool bwd_use_quarters() {
+    static const int v = [] {
+        const char *e = getenv("SPLAT_BWD_QUARTERS");
+        return (e && strcmp(e, "0") == 0) ? 0 : 1;
+    }();
+    return v != 0;
+}
+
 template <int CH, bool ABS, bool BIAS>
 static int launch_bwd_ab(const BlendArgs &A, int T, bool pair, hipStream_t s) {
     const dim3 grid((unsigned)(T * A.F)), block(256);
     const bool exact = A.cn == CH;
-    if (pair && !BIAS && bwd_use_mfma()) {
+    if (pair && !BIAS && !ABS && CH <= 3 && A.cull_flags && bwd_use_mfma() && bwd_use_quarters()) {
+        // frame batch, narrow row without |taps|: one survivor list per 4x4 quarter (the forward's quarter bits)
+        constexpr int QC = CH <= 3 ? CH : 3;
+        if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_quarter_kernel<QC, true>), grid, block, 0, s, A);
+        else SPLAT_LAUNCH("blend_bwd", (blend_bwd_quarter_kernel<QC, false>), grid, block, 0, s, A);
+    } else if (pair && !BIAS && bwd_use_mfma()) {
         if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_mfma_kernel<CH, ABS, true>), grid, block, 0, s, A);
         else SPLAT_LAUNCH("blend_bwd", (blend_bwd_mfma_kernel<CH, ABS, false>), grid, block, 0, s, A);
     } else if (pair) {
