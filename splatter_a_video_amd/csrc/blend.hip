@@ -2541,6 +2541,462 @@ blend_bwd_sets_kernel(const BlendArgs B) {
     }
 }
 
+// ------------------------------------------------------------------ three-set backward on QUARTER lists
+// blend_bwd_sets_kernel with the strip walk of blend_bwd_quarter_kernel: every 4x4 quarter of the wave's block walks its own
+// list (the forward's quarter bits), a step = 16 survivors of one quarter's list x its 16 pixels.  Per staged entry, once (the
+// lanes that park its two geometry parts): the polynomial's coefficients and the constant terms of the tap factor into the
+// record's free floats (part 9 = q0 qx qy qxx, part 10 = qxy qyy -c0x -c0y, part 11 = 0).  A step adds raw sums into the
+// survivor's slab row (rows by position in the wave's block-level list; float4 read-add-write, a lane group per float4):
+//   [M0 Mx My Mxx | Mxy Myy ay(B) . | op tx ty ax (A) | op tx ty ax (B) | ay(A) . . . | dL_dfeature of the 28 slots]
+// (block-centred moments of dL/dpower; A / B: the per-lane sums of lane groups 0 + 2 / 1 + 3); the combine moves the moments to
+// the tile centre, maps them to d uv / d conic and routes the slots to the row's channels -- once per entry.
+struct SetsQCfg {
+    static constexpr int CH = SetsCfg::CH, NK = SetsCfg::NK, NA = SetsCfg::NA, SB = SetsCfg::SB, NG = SetsCfg::NG, PS = SetsCfg::PS;
+    static constexpr int CAP = SB;          // a row per staged entry at most: no rounds
+    static constexpr int RW = 20 + CH;      // 48 floats
+    static constexpr int RQ = Rec<CH>::RQ;  // 12 parts
+};
+
+template <bool ABS>
+__global__ void __launch_bounds__(256, BLEND_SETS_MINW)
+blend_bwd_sets_quarter_kernel(const BlendArgs B) {
+    using Cfg = SetsQCfg;
+    constexpr int CH = Cfg::CH, SB = Cfg::SB, NG = Cfg::NG, NK = Cfg::NK, NA = Cfg::NA, PS = Cfg::PS, CAP = Cfg::CAP, RW = Cfg::RW, RQ = Cfg::RQ;
+    static_assert(RQ == 12 && Rec<CH>::CULL == 43 && SB == 64 && CAP * RW >= 32 * CH, "record floats 36-47 are free; the staging of 32 pixels fits a slab");
+    __shared__ float4 s_rec[(SB + 1) * RQ];             // staged records (swizzled groups of four parts), slot SB = inert
+    auto qpart = [](int e, int p) { return e * RQ + ((p & ~3) | ((p & 3) ^ ((e >> 2) & 3))); };
+    __shared__ unsigned int s_keep[SB];
+    __shared__ unsigned int s_pos4[SB];
+    __shared__ unsigned short s_qlist[4][4][SB + 16];   // [wave][quarter]: entry | (slab row) << 8
+    __shared__ __attribute__((aligned(16))) float s_acc[4][(CAP + 1) * RW];
+    constexpr int KS = 4 * PS + 8, GS = 4 * KS;
+    __shared__ __attribute__((aligned(16))) float s_state[4][4 * GS];
+    auto pixoff = [](int q) { return (q >> 4) * GS + ((q >> 2) & 3) * KS + (q & 3) * PS; };
+    __shared__ float s_mom[16 * 32];                    // [step][lane group][row & 7], see blend_bwd_quarter_kernel
+    __shared__ int s_wmax[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int gtile = xcd_tile(blockIdx.x, gridDim.x);
+    const int frame = gtile / B.T, tile = gtile - frame * B.T;
+    const BlendArgs A = frame_args(B, frame);
+    const int NC = NG + A.C, NCP = PAIR_STRIDE(NC);
+    float *const pair_buf = B.pair_buf + (size_t)frame * (size_t)B.cap * NCP;
+    const int tx = tile % A.gx, ty = tile / A.gx;
+    const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
+    const float tcx = (float)(tx * TILE) + 7.5f, tcy = (float)(ty * TILE) + 7.5f;
+    const float ox = (float)((w & 1) * 8) - 7.5f, oy = (float)((w >> 1) * 8) - 7.5f;
+    const int nl = lane & 15, kk = lane >> 4;
+    // strip walk: q = 16 G + 4 kk + i  <->  quarter G = (sx, sy), pixel (x, y) = (4 sx + i, 4 sy + kk) of the block
+    auto qx = [](int q) { return 4 * ((q >> 4) & 1) + (q & 3); };
+    auto qy = [](int q) { return 4 * (q >> 5) + ((q >> 2) & 3); };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // moment operand, block-centred: rows 0-3 = 1 x y xx, rows 4-5 = xy yy
+        const int st = 4 * w + r, Gs = st >> 2, is = st & 3;
+        const int q = 16 * Gs + 4 * kk + is;
+        const float x = (float)qx(q) - 3.5f, y = (float)qy(q) - 3.5f;
+        float v = 0.f;
+        if (nl < 4) v = nl == 0 ? 1.f : nl == 1 ? x : nl == 2 ? y : x * x;
+        else if (nl < 6) v = nl == 4 ? x * y : y * y;
+        if (nl < 8) s_mom[32 * st + 8 * kk + nl] = v;
+    }
+    float phi1[4], phi2[4];
+#pragma unroll
+    for (int Gs = 0; Gs < 4; ++Gs) {
+        const int q = 16 * Gs + nl;
+        const float x = (float)qx(q) + ox, y = (float)qy(q) + oy;
+        phi1[Gs] = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
+        phi2[Gs] = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
+    }
+    const int lx = lane & 7, ly = lane >> 3;
+    const int myq = 16 * ((lx >> 2) + 2 * (ly >> 2)) + 4 * (ly & 3) + (lx & 3);
+    float *stage = s_acc[w];  // [pixel of the half block (raster)][slot]
+    float gpix[CH];
+    {
+        const int px = bx + lx, py = by + ly;
+        const size_t HW = (size_t)A.H * A.W;
+        const bool inside = (px < A.W) && (py < A.H);
+        const size_t pix = (size_t)A.W * (size_t)py + px;
+        const float Tf = inside ? A.final_T[pix] : 0.f;
+        const int last = inside ? A.ncontrib[pix] : 0;
+        float bgd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = sets_slot_channel(A, k);
+            const int gi = k < 4 ? 0 : k < 8 ? 1 : 2;
+            float g = 0.f;
+            if (inside && c >= 0) {
+                if (A.dL_dout) {
+                    g = A.dL_dout[(size_t)c * HW + pix];
+                } else {
+                    const float *d = gi == 0 ? A.sdl0 : gi == 1 ? A.sdl1 : A.sdl2;
+                    const int o = k - (gi == 0 ? 0 : gi == 1 ? 4 : 8);
+                    g = d[(size_t)o * HW + pix];
+                }
+            }
+            gpix[k] = g;
+            bgd[gi] += (gi == 0 ? A.s0bg : gi == 1 ? A.s1bg : A.s2bg) * g;
+        }
+        float *r = s_state[w] + pixoff(myq);
+        r[0] = 0.f; r[1] = 0.f; r[2] = 0.f;
+        r[3] = __int_as_float(last);
+        r[4] = Tf;
+        r[5] = Tf * bgd[0]; r[6] = Tf * bgd[1]; r[7] = Tf * bgd[2];
+        const int wmax = wave_max_i(last);
+        if (lane == 0) s_wmax[w] = wmax;
+    }
+    if (tid < RQ) s_rec[qpart(SB, tid)] = make_float4(tid == 9 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);   // inert slot SB: q0 = log2(0)
+    // ---- dL_dout of the wave's pixels into registers in both MFMA operand layouts, 32 pixels (two quarters) at a time
+    float hcg[4][NK], hft[16][NA];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if ((lane >> 5) == h) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) stage[(lane & 31) * CH + k] = gpix[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int G = 2 * h; G < 2 * h + 2; ++G)
+#pragma unroll
+            for (int j = 0; j < NK; ++j)   // A[m = pixel nl of quarter G][k = slot]: raster index 8 (nl >> 2) + 4 (G & 1) + (nl & 3) of the half
+                hcg[G][j] = stage[(8 * (nl >> 2) + 4 * (G & 1) + (nl & 3)) * CH + 4 * j + kk];
+#pragma unroll
+        for (int st = 8 * h; st < 8 * h + 8; ++st) {
+#pragma unroll
+            for (int q = 0; q < NA; ++q)  // A[m = slot 16 q + nl][k = own pixel of step st = (G, i)]: raster 8 kk + 4 (G & 1) + i
+                hft[st][q] = 16 * q + nl < CH ? stage[(8 * kk + 4 * ((st >> 2) & 1) + (st & 3)) * CH + 16 * q + nl] : 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < RW) s_acc[w][CAP * RW + lane] = 0.f;   // the slab's zero row
+    __syncthreads();
+    const float *momrow = s_mom + 8 * kk + (nl & 7);
+    const int2 range = A.tile_range[tile];
+    const int len = range.y - range.x;
+    const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
+    const int *slots = A.slot_sorted + range.x;
+    // combine: four threads per entry -- part 0: geometry (floats 0 .. 9 of the record), parts 1 .. 3: the slots' feature gradients
+    const int ce = tid >> 2, cp = tid & 3;
+    auto zero_rec = [&](int slot) {
+        float *dst = pair_buf + (size_t)slot * NCP;
+        for (int c = cp; c < NCP / 4; c += 4) reinterpret_cast<float4 *>(dst)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    for (int ql = n + ce; ql < len; ql += 64) zero_rec(slots[ql]);   // entries nobody replays: zero record
+    float *state = s_state[w] + kk * KS;
+    if (n <= 0) {
+        if (A.dbg_T_front) {
+            const int px = bx + lx, py = by + ly;
+            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq) + 4];
+        }
+        return;
+    }
+    // per-lane float offsets inside a staged record (before the entry's swizzle): tap factor operands -c0x cA cB 0 / -c0y cB cC 0
+    const int offx = kk == 0 ? 42 : kk == 1 ? 2 : kk == 2 ? 3 : 47;
+    const int offy = kk == 0 ? 43 : kk == 1 ? 3 : kk == 2 ? 4 : 47;
+
+    auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };
+    Stager<CH, SB> st;
+    static_assert(Stager<CH, SB>::NCHUNK % 256 == 0, "every thread parks K chunks");
+    st.load_ids(A, tid, range.x, pos, 0);
+    st.load_payload(A, tid);
+    st.load_ids(A, tid, range.x, pos, 1);
+    auto load_flags = [&](int topb) -> unsigned {
+        const int q = topb - tid;
+        return (tid < SB && q >= 0) ? (unsigned)A.cull_flags[range.x + q] : 0u;
+    };
+    unsigned fl_next = load_flags(n - 1);
+
+    int batch = 0;
+    for (int top = n - 1; top >= 0; top -= SB, ++batch) {
+        const int nb = imin_(SB, top + 1);
+        {   // park; parts 0 / 1 of an entry sit in neighbouring lanes of a quad: they exchange and leave the coefficients
+#pragma unroll
+            for (int k = 0; k < Stager<CH, SB>::K; ++k) {
+                const int c = tid + 256 * k;
+                const int e = c / RQ, p = c - e * RQ;
+                const float4 mine = st.v[k];
+                float4 other;
+                other.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.x), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                other.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.y), 0xB1, 0xf, 0xf, true));
+                other.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.z), 0xB1, 0xf, 0xf, true));
+                other.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.w), 0xB1, 0xf, 0xf, true));
+                const float4 g0 = p == 0 ? mine : other, g1 = p == 0 ? other : mine;
+                const PowerCoef pc = power_coeffs(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, tcx, tcy);
+                const float ut = g0.x - tcx, vt = g0.y - tcy;
+                if (p == 0) {
+                    s_rec[qpart(e, 0)] = mine;
+                    s_rec[qpart(e, 9)] = make_float4(pc.q0, pc.qx, pc.qy, pc.qxx);
+                } else if (p == 1) {
+                    s_rec[qpart(e, 1)] = mine;
+                    s_rec[qpart(e, 10)] = make_float4(pc.qxy, pc.qyy, -(g0.z * ut + g0.w * vt), -(g0.w * ut + g1.x * vt));
+                } else if (p < 9) {
+                    s_rec[qpart(e, p)] = mine;
+                } else if (p == 11) {
+                    s_rec[qpart(e, 11)] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        const unsigned fl = fl_next;
+        fl_next = load_flags(top - SB);
+        if (tid < SB) {
+            unsigned kw = 0u;
+            if (tid < nb) {
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww)
+                    if (top - tid < s_wmax[ww]) kw |= fl & (0xfu << (8 * ww));
+            }
+            s_keep[tid] = kw;
+        }
+        __syncthreads();
+        float *slab = s_acc[w];
+        // ---- this wave's lists (SB = 64: one entry per lane)
+        unsigned cqw = 0u;
+        int cnt;
+        {
+            const int e = lane;
+            const unsigned bits = (s_keep[e] >> (8 * w)) & 0xfu;
+            const bool kb = bits != 0u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(kb);
+            const int ps = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            reinterpret_cast<unsigned char *>(s_pos4)[4 * e + w] = kb ? (unsigned char)ps : (unsigned char)255;
+            const unsigned word = (bits * 0x00204081u) & 0x01010101u;
+            unsigned incl = word;
+            asm volatile("s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                         : "+v"(incl));
+            const unsigned posw = incl - word;
+            const unsigned short ent = (unsigned short)(e | (ps << 8));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((bits >> q) & 1u) s_qlist[w][q][(posw >> (8 * q)) & 0xffu] = ent;
+            cqw = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            cnt = __popcll(m);
+        }
+        int cq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cq[q] = (int)((cqw >> (8 * q)) & 0xffu);
+        if (lane < 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_qlist[w][q][cq[q] + lane] = (unsigned short)(SB | (CAP << 8));   // pad: inert entry, zero row
+        }
+        {   // rows start from zero
+            float4 *z = reinterpret_cast<float4 *>(slab);
+            for (int c = lane; c < cnt * (RW / 4); c += WAVE) z[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            for (int j0 = 0; j0 < cq[G]; j0 += 16) {
+                const unsigned le = s_qlist[w][G][j0 + nl];
+                const int e = le & 0xffu, row = le >> 8;
+                const int qn = top - e;
+                const float *er = reinterpret_cast<const float *>(s_rec) + e * (4 * RQ);
+                const int sw = 4 * ((e >> 2) & 3);   // float offset f of a record: f ^ sw (the swizzle permutes groups of four parts)
+                const float bq1 = er[(36 + kk) ^ sw];
+                const float bq2 = er[(40 + (kk & 1)) ^ sw];   // (lane groups 2, 3: their monomial operand is zero)
+                const float blx = er[offx ^ sw], bly = er[offy ^ sw];
+                float bf[NK];
+#pragma unroll
+                for (int j = 0; j < NK; ++j) bf[j] = er[(8 + 4 * j + kk) ^ sw];
+                f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
+                f32x4 d_f[NA];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+                float s_op = 0.f, s_tx = 0.f, s_ty = 0.f, s_ax = 0.f, s_ay = 0.f;
+                asm volatile("" ::: "memory");
+                f32x4 pw = {0.f, 0.f, 0.f, 0.f}, cv0 = {0.f, 0.f, 0.f, 0.f}, cv1 = {0.f, 0.f, 0.f, 0.f}, cv2 = {0.f, 0.f, 0.f, 0.f};
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bq1, pw, 0, 0, 0);
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi2[G], bq2, pw, 0, 0, 0);
+                cv0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][0], bf[0], cv0, 0, 0, 0);
+                cv1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][1], bf[1], cv1, 0, 0, 0);
+#pragma unroll
+                for (int j = 2; j < NK; ++j) cv2 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][j], bf[j], cv2, 0, 0, 0);
+                float araw[4], a[4], r1a[4], rp[4], Ts4[4], Rs[3][4], cg[3][4];
+                bool ok[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int last = __float_as_int(state[G * GS + i * PS + 3]);
+                    const float4 sb = *reinterpret_cast<const float4 *>(state + G * GS + i * PS + 4);
+                    Ts4[i] = sb.x;
+                    Rs[0][i] = sb.y; Rs[1][i] = sb.z; Rs[2][i] = sb.w;
+                    cg[0][i] = cv0[i]; cg[1][i] = cv1[i]; cg[2][i] = cv2[i];
+                    bool pw_ok;
+                    araw[i] = exp2_guard(pw[i], pw_ok);
+                    const float alpha = fminf(0.99f, araw[i]);
+                    ok[i] = (qn < last) && pw_ok && !(alpha < (1.0f / 255.0f));
+                    a[i] = ok[i] ? alpha : 0.f;
+                    r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
+                    rp[i] = r1a[i];
+                }
+                row_scan_mul4(rp[0], rp[1], rp[2], rp[3]);
+                float T[4], wgt[4], rs[3][4], R[3][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    T[i] = Ts4[i] * rp[i];
+                    wgt[i] = a[i] * T[i];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) rs[g][i] = cg[g][i] * wgt[i];
+                }
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    row_scan_add4(rs[g][0], rs[g][1], rs[g][2], rs[g][3]);
+                    row_shr1_add4(R[g], rs[g], Rs[g]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lds_store2_lane15(state + G * GS + i * PS + 4, T[i], Rs[0][i] + rs[0][i]);
+                    lds_store2_lane15(state + G * GS + i * PS + 6, Rs[1][i] + rs[1][i], Rs[2][i] + rs[2][i]);
+                }
+                f32x4 lx4 = {0.f, 0.f, 0.f, 0.f}, ly4 = {0.f, 0.f, 0.f, 0.f};   // -conic (centre - pixel): the sign returns in the combine
+                lx4 = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], blx, lx4, 0, 0, 0);
+                ly4 = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bly, ly4, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int s = 4 * G + i;
+                    const float dLa0 = T[i] * cg[0][i] - R[0][i] * r1a[i];
+                    const float dLa1 = T[i] * cg[1][i] - R[1][i] * r1a[i];
+                    const float dLa2 = T[i] * cg[2][i] - R[2][i] * r1a[i];
+                    const float am = ok[i] ? araw[i] : 0.f;
+                    const float dLp_tap = am * dLa0;
+                    const float dLp_op = am * (dLa0 + dLa1);
+                    const float dLp = am * (dLa0 + dLa1 + dLa2);
+                    d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[32 * s], dLp, d_mom, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NA; ++q) d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(hft[s][q], wgt[i], d_f[q], 0, 0, 0);
+                    s_op += dLp_op;
+                    const float gx = dLp_tap * lx4[i], gy = dLp_tap * ly4[i];
+                    s_tx += gx;
+                    s_ty += gy;
+                    if (ABS) {
+                        s_ax += fabsf(gx);
+                        s_ay += fabsf(gy);
+                    }
+                }
+                // ---- step epilogue: lane groups kk and kk ^ 2 pool their sums (one swap each); then a float4 read-add-write per
+                //      lane group: kk 0: moments 0-3 | kk 1: Mxy Myy ay(B) | kk 2: sums A (+ ay(A)) | kk 3: sums B; and the feature quads
+                auto half = [&](float v) {
+                    const u32x2_b r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                    return v + __uint_as_float((lane & 32) ? r[0] : r[1]);
+                };
+                s_op = half(s_op); s_tx = half(s_tx); s_ty = half(s_ty);
+                if (ABS) { s_ax = half(s_ax); s_ay = half(s_ay); }
+                if (j0 + nl < cq[G]) {
+                    float *rr = slab + row * RW;
+                    float4 v1;
+                    v1.x = kk < 2 ? d_mom[0] : s_op;
+                    v1.y = kk < 2 ? d_mom[1] : s_tx;
+                    v1.z = kk == 0 ? d_mom[2] : kk == 1 ? s_ay : s_ty;
+                    v1.w = kk == 0 ? d_mom[3] : kk == 1 ? 0.f : s_ax;
+                    float4 *p1 = reinterpret_cast<float4 *>(rr + 4 * kk);
+                    float4 o1 = *p1;
+                    o1.x += v1.x; o1.y += v1.y; o1.z += v1.z; o1.w += v1.w;
+                    *p1 = o1;
+                    if (ABS && kk == 2) rr[16] += s_ay;
+                    float4 *pf = reinterpret_cast<float4 *>(rr + 20 + 4 * kk);   // slots 4 kk .. (q = 0) and 16 + 4 kk .. (q = 1)
+                    float4 f0 = pf[0];
+                    f0.x += d_f[0][0]; f0.y += d_f[0][1]; f0.z += d_f[0][2]; f0.w += d_f[0][3];
+                    pf[0] = f0;
+                    if (kk < 3) {
+                        float4 f1 = pf[4];
+                        f1.x += d_f[1][0]; f1.y += d_f[1][1]; f1.z += d_f[1][2]; f1.w += d_f[1][3];
+                        pf[4] = f1;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        const int slot_mine = ce < nb ? slots[top - ce] : 0;   // entry ce of the combine
+        st.load_payload(A, tid);
+        st.load_ids(A, tid, range.x, pos, batch + 2);
+        __syncthreads();
+        // ---- combine: entry ce, part cp
+        if (ce < nb) {
+            const int e = ce;
+            const unsigned int p4 = s_pos4[e];
+            float *dst = pair_buf + (size_t)slot_mine * NCP;
+            if (cp == 0) {
+                float s[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // M0 Mx My Mxx Mxy Myy | op tx ty ax ay
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const unsigned int pp = umin_((p4 >> (8 * ww)) & 0xffu, (unsigned)CAP);
+                    const float4 *rw = reinterpret_cast<const float4 *>(s_acc[ww] + pp * RW);
+                    const float4 m = rw[0], m2 = rw[1], sa = rw[2], sb2 = rw[3];
+                    const float ayA = s_acc[ww][pp * RW + 16];
+                    const float bxw = (ww & 1) ? 4.f : -4.f, byw = (ww >> 1) ? 4.f : -4.f;   // block centre from the tile centre
+                    s[0] += m.x;
+                    s[1] += m.y + bxw * m.x;
+                    s[2] += m.z + byw * m.x;
+                    s[3] += m.w + 2.f * bxw * m.y + (bxw * bxw) * m.x;
+                    s[4] += m2.x + bxw * m.z + byw * m.y + (bxw * byw) * m.x;
+                    s[5] += m2.y + 2.f * byw * m.z + (byw * byw) * m.x;
+                    s[6] += sa.x + sb2.x; s[7] += sa.y + sb2.y; s[8] += sa.z + sb2.z; s[9] += sa.w + sb2.w;
+                    s[10] += ayA + m2.z;
+                }
+                const float4 g0 = s_rec[qpart(e, 0)], g1 = s_rec[qpart(e, 1)];
+                const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
+                const float uc = g0.x - tcx, vc = g0.y - tcy;
+                const float M0 = s[0], Mx = s[1], My = s[2], Mxx = s[3], Mxy = s[4], Myy = s[5];
+                float4 r0, r1;
+                r0.x = cA * Mx + cB * My - (cA * uc + cB * vc) * M0;
+                r0.y = cB * Mx + cC * My - (cB * uc + cC * vc) * M0;
+                r0.z = -0.5f * (uc * uc * M0 - 2.f * uc * Mx + Mxx);
+                r0.w = -(uc * vc * M0 - uc * My - vc * Mx + Mxy);
+                r1.x = -0.5f * (vc * vc * M0 - 2.f * vc * My + Myy);
+                r1.y = o > 0.f ? s[6] / o : 0.f;
+                r1.z = ABS ? s[9] : 0.f;
+                r1.w = ABS ? s[10] : 0.f;
+                reinterpret_cast<float4 *>(dst)[0] = r0;
+                reinterpret_cast<float4 *>(dst)[1] = r1;
+                dst[8] = s[7];    // d uv of the tap set alone (the step's factor carries the minus sign)
+                dst[9] = s[8];
+            } else {
+                // slots [8 (cp - 1) .. ) of the 28 (cp 1: 0-7, cp 2: 8-19, cp 3: 20-27), summed over the waves, to their row channels
+                const int s0 = cp == 1 ? 0 : cp == 2 ? 8 : 20, ns = cp == 2 ? 12 : 8;
+                float f[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) f[k] = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const unsigned int pp = umin_((p4 >> (8 * ww)) & 0xffu, (unsigned)CAP);
+                    const float4 *rw = reinterpret_cast<const float4 *>(s_acc[ww] + pp * RW + 20 + s0);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (4 * c < ns) {
+                            const float4 v = rw[c];
+                            f[4 * c] += v.x; f[4 * c + 1] += v.y; f[4 * c + 2] += v.z; f[4 * c + 3] += v.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    if (k < ns) {
+                        const int c = sets_slot_channel(A, s0 + k);
+                        if (c >= 0) dst[NG + c] = f[k];
+                    }
+                }
+                // (floats NC .. NCP - 1 of a record are padding)
+            }
+        }
+        __syncthreads();
+    }
+    if (A.dbg_T_front) {
+        const int px = bx + lx, py = by + ly;
+        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq) + 4];
+    }
+}
+
 // ------------------------------------------------------------------ backward of the WIDE part of the renderer's row in its own pass
 // blend_bwd_sets_kernel replays the alpha / T chain once for three sets but needs 255 registers (dL_dout of 23 channels in both
 // MFMA operand layouts): two waves per SIMD, the matrix pipe and the VALU take turns instead of overlapping (615 us per frame at
@@ -3448,7 +3904,10 @@ extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, con
     SPLAT_LAUNCH("blend_pack", pack_sets_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)F), dim3(256), 0, s, A);
     SPLAT_POST_LAUNCH();
     const dim3 grid((unsigned)(T * F)), block(256);
-    if (want_abs) SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_kernel<true>, grid, block, 0, s, A);
+    if (A.cull_flags && bwd_use_quarters()) {   // quarter lists (the forward's quarter bits)
+        if (want_abs) SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_quarter_kernel<true>, grid, block, 0, s, A);
+        else SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_quarter_kernel<false>, grid, block, 0, s, A);
+    } else if (want_abs) SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_kernel<true>, grid, block, 0, s, A);
     else SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_kernel<false>, grid, block, 0, s, A);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
