@@ -2553,7 +2553,7 @@ blend_bwd_sets_kernel(const BlendArgs B) {
 struct SetsQCfg {
     static constexpr int CH = SetsCfg::CH, NK = SetsCfg::NK, NA = SetsCfg::NA, SB = SetsCfg::SB, NG = SetsCfg::NG, PS = SetsCfg::PS;
     static constexpr int CAP = SB;          // a row per staged entry at most: no rounds
-    static constexpr int RW = 20 + CH;      // 48 floats
+    static constexpr int RW = 20 + CH + 4;  // 48 floats + 4 of padding: the float4 k of 16 consecutive rows sit on 16 different bank quads
     static constexpr int RQ = Rec<CH>::RQ;  // 12 parts
 };
 
@@ -2569,9 +2569,12 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     __shared__ unsigned int s_pos4[SB];
     __shared__ unsigned short s_qlist[4][4][SB + 16];   // [wave][quarter]: entry | (slab row) << 8
     __shared__ __attribute__((aligned(16))) float s_acc[4][(CAP + 1) * RW];
-    constexpr int KS = 4 * PS + 8, GS = 4 * KS;
+    // replay state of a pixel: [T, R of set 0 1 2] (float4 rows, the four lane groups' rows of a step skewed by 4 floats) and
+    // its ncontrib (own array)
+    constexpr int KS = 4 * 4 + 4, GS = 4 * KS;
     __shared__ __attribute__((aligned(16))) float s_state[4][4 * GS];
-    auto pixoff = [](int q) { return (q >> 4) * GS + ((q >> 2) & 3) * KS + (q & 3) * PS; };
+    __shared__ int s_last[4][64];
+    auto pixoff = [](int q) { return (q >> 4) * GS + ((q >> 2) & 3) * KS + (q & 3) * 4; };
     __shared__ float s_mom[16 * 32];                    // [step][lane group][row & 7], see blend_bwd_quarter_kernel
     __shared__ int s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -2636,10 +2639,9 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
             bgd[gi] += (gi == 0 ? A.s0bg : gi == 1 ? A.s1bg : A.s2bg) * g;
         }
         float *r = s_state[w] + pixoff(myq);
-        r[0] = 0.f; r[1] = 0.f; r[2] = 0.f;
-        r[3] = __int_as_float(last);
-        r[4] = Tf;
-        r[5] = Tf * bgd[0]; r[6] = Tf * bgd[1]; r[7] = Tf * bgd[2];
+        r[0] = Tf;
+        r[1] = Tf * bgd[0]; r[2] = Tf * bgd[1]; r[3] = Tf * bgd[2];
+        s_last[w][myq] = last;
         const int wmax = wave_max_i(last);
         if (lane == 0) s_wmax[w] = wmax;
     }
@@ -2683,10 +2685,11 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     };
     for (int ql = n + ce; ql < len; ql += 64) zero_rec(slots[ql]);   // entries nobody replays: zero record
     float *state = s_state[w] + kk * KS;
+    const int *lastp = s_last[w] + 4 * kk;   // ncontrib of the own pixel of step (G, i): lastp[16 G + i]
     if (n <= 0) {
         if (A.dbg_T_front) {
             const int px = bx + lx, py = by + ly;
-            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq) + 4];
+            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq)];
         }
         return;
     }
@@ -2826,8 +2829,8 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 bool ok[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int last = __float_as_int(state[G * GS + i * PS + 3]);
-                    const float4 sb = *reinterpret_cast<const float4 *>(state + G * GS + i * PS + 4);
+                    const int last = lastp[16 * G + i];
+                    const float4 sb = *reinterpret_cast<const float4 *>(state + G * GS + i * 4);
                     Ts4[i] = sb.x;
                     Rs[0][i] = sb.y; Rs[1][i] = sb.z; Rs[2][i] = sb.w;
                     cg[0][i] = cv0[i]; cg[1][i] = cv1[i]; cg[2][i] = cv2[i];
@@ -2855,8 +2858,8 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    lds_store2_lane15(state + G * GS + i * PS + 4, T[i], Rs[0][i] + rs[0][i]);
-                    lds_store2_lane15(state + G * GS + i * PS + 6, Rs[1][i] + rs[1][i], Rs[2][i] + rs[2][i]);
+                    lds_store2_lane15(state + G * GS + i * 4, T[i], Rs[0][i] + rs[0][i]);
+                    lds_store2_lane15(state + G * GS + i * 4 + 2, Rs[1][i] + rs[1][i], Rs[2][i] + rs[2][i]);
                 }
                 f32x4 lx4 = {0.f, 0.f, 0.f, 0.f}, ly4 = {0.f, 0.f, 0.f, 0.f};   // -conic (centre - pixel): the sign returns in the combine
                 lx4 = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], blx, lx4, 0, 0, 0);
@@ -2993,7 +2996,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     }
     if (A.dbg_T_front) {
         const int px = bx + lx, py = by + ly;
-        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq) + 4];
+        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq)];
     }
 }
 
