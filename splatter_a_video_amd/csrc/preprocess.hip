@@ -411,13 +411,14 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
     constexpr int NQ = NCP / 4, NS = (NQ + 3) / 4;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 2, sub = t & 3;
-    if (i >= A.P) return;  // whole quads leave together
+    if (CAM != 0 && i >= A.P) return;  // whole quads leave together (CAM == 0: after the workgroup's barrier below)
     float4 a[NS];
 #pragma unroll
     for (int c = 0; c < NS; ++c) a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     int rmax = 0;
     bool any = false;
-    int nbeg = i > 0 ? A.goff[i - 1] : 0, nend = A.goff[i];
+    int nbeg = 0, nend = 0;
+    if (CAM != 0) { nbeg = i > 0 ? A.goff[i - 1] : 0; nend = A.goff[i]; }
     // per-frame chain (CAM > 0): position gradient and dL/dcov3d summed over the frames
     float gpf[3] = {0.f, 0.f, 0.f}, g6f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float c3s[6], ss[3], qs[4];
@@ -427,7 +428,78 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
         ss[0] = A.scales[3 * i]; ss[1] = A.scales[3 * i + 1]; ss[2] = A.scales[3 * i + 2];
         cov3d_pt(ss, qs, c3s);
     }
-    for (int f = 0; f < A.F; ++f) {
+    if (CAM == 0) {
+        // One camera: the records of all frames are only summed.  The walk is bound by bytes in flight (two records per quad and
+        // a slot range that depends on the previous frame's: 2.6-2.9 TB/s): the slot ranges of ALL frames of the workgroup's 64
+        // Gaussians are read up front into LDS (coalesced; the record loads then depend on nothing in flight), a frame's first
+        // U records are requested together, and the next frame's while this frame's are summed (two register buffers).
+        constexpr int U = NS == 1 ? 4 : 2, FMAX = 32;   // (wide records: two per buffer -- at four the registers cost more waves than the loads in flight gain)
+        __shared__ int s_goff[FMAX][65];   // [frame][Gaussian of the workgroup + 1]: inclusive prefix, entry 0 = the Gaussian before
+        const int i0 = (int)(blockIdx.x * 64);
+        const int nf = imin_(A.F, FMAX);
+        for (int c = threadIdx.x; c < nf * 65; c += 256) {
+            const int f = c / 65, g = c - f * 65;
+            const int gi = i0 + g - 1;
+            s_goff[f][g] = (gi >= 0 && gi < A.P) ? A.goff[(size_t)f * A.P + gi] : 0;
+        }
+        __syncthreads();
+        if (i >= A.P) return;
+        const int li = i - i0;
+        auto range = [&](int f, int &b, int &e) {
+            if (f < FMAX) { b = s_goff[f][li]; e = s_goff[f][li + 1]; }
+            else { const int *goff = A.goff + (size_t)f * A.P; b = i > 0 ? goff[i - 1] : 0; e = goff[i]; }
+        };
+        float4 bufA[U][NS], bufB[U][NS];
+        int radA = 0, radB = 0;
+        auto issue = [&](float4 (&v)[U][NS], int &rad, int f, int beg, int end) {
+            const float *base = A.pair + (size_t)f * (size_t)A.cap * NCP + 4 * sub;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < NS; ++c)
+                    v[u][c] = (beg + u < end && 4 * c + sub < NQ)
+                                  ? *reinterpret_cast<const float4 *>(base + (size_t)(beg + u) * NCP + 16 * c)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            rad = (A.radii_max && sub == 0) ? A.radius[(size_t)f * A.P + i] : 0;
+        };
+        auto consume = [&](const float4 (&v)[U][NS], int rad, int f, int beg, int end) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    a[c].x += v[u][c].x; a[c].y += v[u][c].y; a[c].z += v[u][c].z; a[c].w += v[u][c].w;
+                }
+            rmax = imax_(rmax, rad);
+            any = any || end > beg;
+            const float *base = A.pair + (size_t)f * (size_t)A.cap * NCP + 4 * sub;
+            for (int j = beg + U; j < end; j += 2) {   // a Gaussian on more than U tiles: two records in flight
+                const bool two = j + 1 < end;
+                float4 v0[NS], v1[NS];
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    const bool mine = 4 * c + sub < NQ;
+                    v0[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v1[c] = (mine && two) ? *reinterpret_cast<const float4 *>(base + (size_t)(j + 1) * NCP + 16 * c)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    a[c].x += v0[c].x; a[c].y += v0[c].y; a[c].z += v0[c].z; a[c].w += v0[c].w;
+                    a[c].x += v1[c].x; a[c].y += v1[c].y; a[c].z += v1[c].z; a[c].w += v1[c].w;
+                }
+            }
+        };
+        int b0, e0, b1 = 0, e1 = 0;
+        range(0, b0, e0);
+        issue(bufA, radA, 0, b0, e0);
+        for (int f = 0; f < A.F; f += 2) {
+            if (f + 1 < A.F) { range(f + 1, b1, e1); issue(bufB, radB, f + 1, b1, e1); }
+            consume(bufA, radA, f, b0, e0);
+            if (f + 2 < A.F) { range(f + 2, b0, e0); issue(bufA, radA, f + 2, b0, e0); }
+            if (f + 1 < A.F) consume(bufB, radB, f + 1, b1, e1);
+        }
+    }
+    for (int f = 0; CAM > 0 && f < A.F; ++f) {
         float4 atot[CAM > 0 ? NS : 1];
         if (CAM > 0) {   // this frame's records are summed on their own (a = this frame, atot = the frames before)
 #pragma unroll
