@@ -1726,6 +1726,10 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
 //     into the survivor's slab row (rows by position in the wave's block-level list, float4 read-add-write by three lane
 //     groups); the map to d uv / d conic / d opacity runs once per entry in the combine, which has the entry's geometry;
 //   * no carried survivors: lists of a quarter are short, the super-batch is what fills the steps.
+// (Wave w walking quarter w of each of the tile's four blocks instead -- a more even share of the tile: barrier-coupled steps
+// 1.087 -> 1.047 of the mean in the CPU model, and what blend_bwd_sets_quarter_kernel does -- doubles the rows a wave needs
+// (a splat's quarters inside one block share a row, its quarters in different blocks meet in different waves): second rounds
+// everywhere at 64 rows, 138 -> 166 us per frame; 128 rows do not fit four workgroups per CU.)
 // Same arithmetic as blend_bwd_mfma_kernel per (pixel, splat): exponent chain, guards, scans.  Narrow rows without |taps|.
 #ifndef BLEND_Q_SB
 #define BLEND_Q_SB 128
@@ -2549,7 +2553,8 @@ blend_bwd_sets_kernel(const BlendArgs B) {
 // survivor's slab row (rows by position in the wave's block-level list; float4 read-add-write, a lane group per float4):
 //   [M0 Mx My Mxx | Mxy Myy ay(B) . | op tx ty ax (A) | op tx ty ax (B) | ay(A) . . . | dL_dfeature of the 28 slots]
 // (block-centred moments of dL/dpower; A / B: the per-lane sums of lane groups 0 + 2 / 1 + 3); the combine moves the moments to
-// the tile centre, maps them to d uv / d conic and routes the slots to the row's channels -- once per entry.
+// the tile centre, maps them to d uv / d conic and routes the slots to the row's channels -- once per entry.  Wave w walks
+// quarter w of each of the tile's four blocks (see blend_bwd_quarter_kernel).
 struct SetsQCfg {
     static constexpr int CH = SetsCfg::CH, NK = SetsCfg::NK, NA = SetsCfg::NA, SB = SetsCfg::SB, NG = SetsCfg::NG, PS = SetsCfg::PS;
     static constexpr int CAP = SB;          // a row per staged entry at most: no rounds
@@ -2584,18 +2589,18 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     const int NC = NG + A.C, NCP = PAIR_STRIDE(NC);
     float *const pair_buf = B.pair_buf + (size_t)frame * (size_t)B.cap * NCP;
     const int tx = tile % A.gx, ty = tile / A.gx;
-    const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
+    const int wx = 4 * (w & 1), wy = 4 * (w >> 1);   // this wave's quarter inside every block
     const float tcx = (float)(tx * TILE) + 7.5f, tcy = (float)(ty * TILE) + 7.5f;
-    const float ox = (float)((w & 1) * 8) - 7.5f, oy = (float)((w >> 1) * 8) - 7.5f;
+    const float ox = (float)wx - 7.5f, oy = (float)wy - 7.5f;
     const int nl = lane & 15, kk = lane >> 4;
-    // strip walk: q = 16 G + 4 kk + i  <->  quarter G = (sx, sy), pixel (x, y) = (4 sx + i, 4 sy + kk) of the block
-    auto qx = [](int q) { return 4 * ((q >> 4) & 1) + (q & 3); };
-    auto qy = [](int q) { return 4 * (q >> 5) + ((q >> 2) & 3); };
+    // strip walk: q = 16 G + 4 kk + i  <->  block G = (gx, gy), pixel (8 gx + i, 8 gy + kk) + (wx, wy) of the tile
+    auto qx = [](int q) { return 8 * ((q >> 4) & 1) + (q & 3); };
+    auto qy = [](int q) { return 8 * (q >> 5) + ((q >> 2) & 3); };
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {   // moment operand, block-centred: rows 0-3 = 1 x y xx, rows 4-5 = xy yy
+    for (int r = 0; r < 4; ++r) {   // moment operand about the centre of the wave's pixel set: rows 0-3 = 1 x y xx, rows 4-5 = xy yy
         const int st = 4 * w + r, Gs = st >> 2, is = st & 3;
         const int q = 16 * Gs + 4 * kk + is;
-        const float x = (float)qx(q) - 3.5f, y = (float)qy(q) - 3.5f;
+        const float x = (float)qx(q) - 5.5f, y = (float)qy(q) - 5.5f;
         float v = 0.f;
         if (nl < 4) v = nl == 0 ? 1.f : nl == 1 ? x : nl == 2 ? y : x * x;
         else if (nl < 6) v = nl == 4 ? x * y : y * y;
@@ -2609,12 +2614,12 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         phi1[Gs] = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
         phi2[Gs] = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
     }
-    const int lx = lane & 7, ly = lane >> 3;
-    const int myq = 16 * ((lx >> 2) + 2 * (ly >> 2)) + 4 * (ly & 3) + (lx & 3);
+    const int myq = lane;                              // lane <-> pixel `lane` of the strip walk
+    const int lx = wx + qx(myq), ly = wy + qy(myq);    // its position in the tile
     float *stage = s_acc[w];  // [pixel of the half block (raster)][slot]
     float gpix[CH];
     {
-        const int px = bx + lx, py = by + ly;
+        const int px = tx * TILE + lx, py = ty * TILE + ly;
         const size_t HW = (size_t)A.H * A.W;
         const bool inside = (px < A.W) && (py < A.H);
         const size_t pix = (size_t)A.W * (size_t)py + px;
@@ -2659,13 +2664,13 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
 #pragma unroll
         for (int G = 2 * h; G < 2 * h + 2; ++G)
 #pragma unroll
-            for (int j = 0; j < NK; ++j)   // A[m = pixel nl of quarter G][k = slot]: raster index 8 (nl >> 2) + 4 (G & 1) + (nl & 3) of the half
-                hcg[G][j] = stage[(8 * (nl >> 2) + 4 * (G & 1) + (nl & 3)) * CH + 4 * j + kk];
+            for (int j = 0; j < NK; ++j)   // A[m = pixel nl of quarter G][k = slot]: pixel 16 (G & 1) + nl of the half (lanes in walk order)
+                hcg[G][j] = stage[(16 * (G & 1) + nl) * CH + 4 * j + kk];
 #pragma unroll
         for (int st = 8 * h; st < 8 * h + 8; ++st) {
 #pragma unroll
-            for (int q = 0; q < NA; ++q)  // A[m = slot 16 q + nl][k = own pixel of step st = (G, i)]: raster 8 kk + 4 (G & 1) + i
-                hft[st][q] = 16 * q + nl < CH ? stage[(8 * kk + 4 * ((st >> 2) & 1) + (st & 3)) * CH + 16 * q + nl] : 0.f;
+            for (int q = 0; q < NA; ++q)  // A[m = slot 16 q + nl][k = own pixel of step st = (G, i)]: pixel 16 (G & 1) + 4 kk + i of the half
+                hft[st][q] = 16 * q + nl < CH ? stage[(16 * ((st >> 2) & 1) + 4 * kk + (st & 3)) * CH + 16 * q + nl] : 0.f;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2688,7 +2693,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     const int *lastp = s_last[w] + 4 * kk;   // ncontrib of the own pixel of step (G, i): lastp[16 G + i]
     if (n <= 0) {
         if (A.dbg_T_front) {
-            const int px = bx + lx, py = by + ly;
+            const int px = tx * TILE + lx, py = ty * TILE + ly;
             if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq)];
         }
         return;
@@ -2741,12 +2746,15 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         }
         const unsigned fl = fl_next;
         fl_next = load_flags(top - SB);
-        if (tid < SB) {
+        if (tid < SB) {   // byte w' bit G = quarter w' of block G in the forward's cull flags (byte G bit w')
             unsigned kw = 0u;
             if (tid < nb) {
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww)
-                    if (top - tid < s_wmax[ww]) kw |= fl & (0xfu << (8 * ww));
+                for (int ww = 0; ww < 4; ++ww) {
+                    const unsigned t4 = (fl >> ww) & 0x01010101u;
+                    const unsigned nib = ((t4 * 0x01020408u) >> 24) & 0xfu;
+                    if (top - tid < s_wmax[ww]) kw |= nib << (8 * ww);
+                }
             }
             s_keep[tid] = kw;
         }
@@ -2937,7 +2945,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                     const float4 *rw = reinterpret_cast<const float4 *>(s_acc[ww] + pp * RW);
                     const float4 m = rw[0], m2 = rw[1], sa = rw[2], sb2 = rw[3];
                     const float ayA = s_acc[ww][pp * RW + 16];
-                    const float bxw = (ww & 1) ? 4.f : -4.f, byw = (ww >> 1) ? 4.f : -4.f;   // block centre from the tile centre
+                    const float bxw = (ww & 1) ? 2.f : -2.f, byw = (ww >> 1) ? 2.f : -2.f;   // centre of the wave's pixel set from the tile centre
                     s[0] += m.x;
                     s[1] += m.y + bxw * m.x;
                     s[2] += m.z + byw * m.x;
@@ -2995,7 +3003,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         __syncthreads();
     }
     if (A.dbg_T_front) {
-        const int px = bx + lx, py = by + ly;
+        const int px = tx * TILE + lx, py = ty * TILE + ly;
         if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq)];
     }
 }
