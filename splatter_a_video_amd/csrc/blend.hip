@@ -3008,6 +3008,389 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     }
 }
 
+// ------------------------------------------------------------------ wide single-set backward on QUARTER lists
+// The strip walk of blend_bwd_sets_quarter_kernel for ONE feature set of 16 .. 32 channels (the wide instantiations of
+// blend_bwd_mfma_kernel run 2 workgroups per CU on block lists, their four waves adding into one slab with LDS float atomics
+// at 32 channels): quarter lists from the forward's quarter bits, wave w on quarter w of each of the tile's four blocks,
+// dL_dout of the wave's pixels in registers in both MFMA operand layouts, the polynomial's coefficients once per staged entry,
+// raw block-set-centred moments + the feature gradients added into slab rows by position (float4 read-add-write), the map to
+// d uv / d conic / d opacity once per entry in the combine.  Record: GradLayout<false, false> = [ux uy ca cb cc o | features].
+template <int CH>
+struct WideQCfg {
+    static_assert(CH % 4 == 0 && CH >= 16 && CH <= 32, "whole K-slabs");
+    static constexpr int SB = 64, CAP = SB;
+    static constexpr int NK = CH / 4, NA = (CH + 15) / 16;
+    static constexpr int NG = GradLayout<false, false>::NG, NC = NG + CH, NCP = PAIR_STRIDE(NC);
+    static constexpr int RW = (((8 + CH) / 4) | 1) * 4;   // slab row [M0 Mx My Mxx | Mxy Myy . . | CH feature gradients], an odd number of float4
+    static constexpr int RQ = Rec<CH>::RQ;
+};
+
+template <int CH, bool EXACT>
+__global__ void __launch_bounds__(256, (CH <= 20 ? 3 : 2))   // 16 / 20 channels: 168 registers and 48 KB of LDS -- three workgroups per CU
+blend_bwd_wide_quarter_kernel(const BlendArgs B) {
+    using Cfg = WideQCfg<CH>;
+    constexpr int SB = Cfg::SB, CAP = Cfg::CAP, NK = Cfg::NK, NA = Cfg::NA, NG = Cfg::NG, NCP = Cfg::NCP, RW = Cfg::RW, RQ = Cfg::RQ;
+    static_assert(RQ % 4 == 0 && CAP * RW >= 32 * CH && Stager<CH, SB>::NCHUNK % 256 == 0, "swizzle groups; staging of 32 pixels fits a slab");
+    __shared__ float4 s_rec[(SB + 1) * RQ];
+    auto qpart = [](int e, int p) { return e * RQ + ((p & ~3) | ((p & 3) ^ ((e >> 2) & 3))); };
+    __shared__ float4 s_coef[(SB + 1) * 2];             // [q0 qx qy qxx | qxy qyy 0 0] of the staged entries, slot SB = inert
+    __shared__ unsigned int s_keep[SB];
+    __shared__ unsigned int s_pos4[SB];
+    __shared__ unsigned short s_qlist[4][4][SB + 16];
+    __shared__ __attribute__((aligned(16))) float s_acc[4][(CAP + 1) * RW];
+    constexpr int KS = 4 * 2 + 2, GS = 4 * KS;          // replay state [T, R] per pixel, lane groups' rows skewed
+    __shared__ __attribute__((aligned(8))) float s_state[4][4 * GS];
+    __shared__ int s_last[4][64];
+    auto pixoff = [](int q) { return (q >> 4) * GS + ((q >> 2) & 3) * KS + (q & 3) * 2; };
+    __shared__ float s_mom[16 * 32];
+    __shared__ int s_wmax[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int gtile = xcd_tile(blockIdx.x, gridDim.x);
+    const int frame = gtile / B.T, tile = gtile - frame * B.T;
+    const BlendArgs A = frame_args(B, frame);
+    const int RST = B.rec_stride ? B.rec_stride : NCP;
+    float *const pair_buf = B.pair_buf + (size_t)frame * (size_t)B.cap * RST + B.rec_off;
+    const int tx = tile % A.gx, ty = tile / A.gx;
+    const int wx = 4 * (w & 1), wy = 4 * (w >> 1);
+    const float tcx = (float)(tx * TILE) + 7.5f, tcy = (float)(ty * TILE) + 7.5f;
+    const float ox = (float)wx - 7.5f, oy = (float)wy - 7.5f;
+    const int cn = EXACT ? CH : A.cn;
+    const int nl = lane & 15, kk = lane >> 4;
+    auto qx = [](int q) { return 8 * ((q >> 4) & 1) + (q & 3); };
+    auto qy = [](int q) { return 8 * (q >> 5) + ((q >> 2) & 3); };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int st = 4 * w + r, Gs = st >> 2, is = st & 3;
+        const int q = 16 * Gs + 4 * kk + is;
+        const float x = (float)qx(q) - 5.5f, y = (float)qy(q) - 5.5f;
+        float v = 0.f;
+        if (nl < 4) v = nl == 0 ? 1.f : nl == 1 ? x : nl == 2 ? y : x * x;
+        else if (nl < 6) v = nl == 4 ? x * y : y * y;
+        if (nl < 8) s_mom[32 * st + 8 * kk + nl] = v;
+    }
+    float phi1[4], phi2[4];
+#pragma unroll
+    for (int Gs = 0; Gs < 4; ++Gs) {
+        const int q = 16 * Gs + nl;
+        const float x = (float)qx(q) + ox, y = (float)qy(q) + oy;
+        phi1[Gs] = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
+        phi2[Gs] = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
+    }
+    const int myq = lane;
+    const int lx = wx + qx(myq), ly = wy + qy(myq);
+    float *stage = s_acc[w];
+    float gpix[CH];
+    {
+        const int px = tx * TILE + lx, py = ty * TILE + ly;
+        const size_t HW = (size_t)A.H * A.W;
+        const bool inside = (px < A.W) && (py < A.H);
+        const size_t pix = (size_t)A.W * (size_t)py + px;
+        const float Tf = inside ? A.final_T[pix] : 0.f;
+        const int last = inside ? A.ncontrib[pix] : 0;
+        float bgdot = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const float g = (inside && k < cn) ? A.dL_dout[(size_t)(A.c0 + k) * HW + pix] : 0.f;
+            gpix[k] = g;
+            bgdot += A.bg * g;
+        }
+        float *r = s_state[w] + pixoff(myq);
+        r[0] = Tf;
+        r[1] = Tf * bgdot;
+        s_last[w][myq] = last;
+        const int wmax = wave_max_i(last);
+        if (lane == 0) s_wmax[w] = wmax;
+    }
+    if (tid < RQ) s_rec[qpart(SB, tid)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 2) s_coef[2 * SB + tid] = make_float4(tid == 0 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);   // inert slot: q0 = log2(0)
+    float hcg[4][NK], hft[16][NA];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if ((lane >> 5) == h) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) stage[(lane & 31) * CH + k] = gpix[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int G = 2 * h; G < 2 * h + 2; ++G)
+#pragma unroll
+            for (int j = 0; j < NK; ++j) hcg[G][j] = stage[(16 * (G & 1) + nl) * CH + 4 * j + kk];
+#pragma unroll
+        for (int st = 8 * h; st < 8 * h + 8; ++st) {
+#pragma unroll
+            for (int q = 0; q < NA; ++q)
+                hft[st][q] = 16 * q + nl < CH ? stage[(16 * ((st >> 2) & 1) + 4 * kk + (st & 3)) * CH + 16 * q + nl] : 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < RW) s_acc[w][CAP * RW + lane] = 0.f;   // the slab's zero row
+    __syncthreads();
+    const float *momrow = s_mom + 8 * kk + (nl & 7);
+    const int2 range = A.tile_range[tile];
+    const int len = range.y - range.x;
+    const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
+    const int *slots = A.slot_sorted + range.x;
+    const int ce = tid >> 2, cp = tid & 3;   // combine: four threads per entry (geometry | three shares of the feature chunks)
+    auto zero_rec = [&](int slot) {
+        float *dst = pair_buf + (size_t)slot * RST;
+        for (int c = cp; c < NCP / 4; c += 4) reinterpret_cast<float4 *>(dst)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    for (int ql = n + ce; ql < len; ql += 64) zero_rec(slots[ql]);
+    float *state = s_state[w] + kk * KS;
+    const int *lastp = s_last[w] + 4 * kk;
+    if (n <= 0) {
+        if (A.dbg_T_front) {
+            const int px = tx * TILE + lx, py = ty * TILE + ly;
+            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq)];
+        }
+        return;
+    }
+    auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };
+    Stager<CH, SB> st;
+    st.load_ids(A, tid, range.x, pos, 0);
+    st.load_payload(A, tid);
+    st.load_ids(A, tid, range.x, pos, 1);
+    auto load_flags = [&](int topb) -> unsigned {
+        const int q = topb - tid;
+        return (tid < SB && q >= 0) ? (unsigned)A.cull_flags[range.x + q] : 0u;
+    };
+    unsigned fl_next = load_flags(n - 1);
+
+    int batch = 0;
+    for (int top = n - 1; top >= 0; top -= SB, ++batch) {
+        const int nb = imin_(SB, top + 1);
+        {   // park; the lanes holding parts 0 / 1 of an entry exchange them and leave the polynomial's coefficients
+#pragma unroll
+            for (int k = 0; k < Stager<CH, SB>::K; ++k) {
+                const int c = tid + 256 * k;
+                const int e = c / RQ, p = c - e * RQ;
+                const float4 mine = st.v[k];
+                float4 other;
+                other.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.x), 0xB1, 0xf, 0xf, true));
+                other.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.y), 0xB1, 0xf, 0xf, true));
+                other.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.z), 0xB1, 0xf, 0xf, true));
+                other.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.w), 0xB1, 0xf, 0xf, true));
+                const float4 g0 = p == 0 ? mine : other, g1 = p == 0 ? other : mine;
+                const PowerCoef pc = power_coeffs(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, tcx, tcy);
+                s_rec[qpart(e, p)] = mine;
+                if (p == 0) s_coef[2 * e] = make_float4(pc.q0, pc.qx, pc.qy, pc.qxx);
+                else if (p == 1) s_coef[2 * e + 1] = make_float4(pc.qxy, pc.qyy, 0.f, 0.f);
+            }
+        }
+        const unsigned fl = fl_next;
+        fl_next = load_flags(top - SB);
+        if (tid < SB) {   // byte w' bit G = quarter w' of block G in the forward's cull flags (byte G bit w')
+            unsigned kw = 0u;
+            if (tid < nb) {
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const unsigned t4 = (fl >> ww) & 0x01010101u;
+                    const unsigned nib = ((t4 * 0x01020408u) >> 24) & 0xfu;
+                    if (top - tid < s_wmax[ww]) kw |= nib << (8 * ww);
+                }
+            }
+            s_keep[tid] = kw;
+        }
+        __syncthreads();
+        float *slab = s_acc[w];
+        unsigned cqw = 0u;
+        int cnt;
+        {
+            const int e = lane;
+            const unsigned bits = (s_keep[e] >> (8 * w)) & 0xfu;
+            const bool kb = bits != 0u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(kb);
+            const int ps = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            reinterpret_cast<unsigned char *>(s_pos4)[4 * e + w] = kb ? (unsigned char)ps : (unsigned char)255;
+            const unsigned word = (bits * 0x00204081u) & 0x01010101u;
+            unsigned incl = word;
+            asm volatile("s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                         : "+v"(incl));
+            const unsigned posw = incl - word;
+            const unsigned short ent = (unsigned short)(e | (ps << 8));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((bits >> q) & 1u) s_qlist[w][q][(posw >> (8 * q)) & 0xffu] = ent;
+            cqw = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            cnt = __popcll(m);
+        }
+        int cq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cq[q] = (int)((cqw >> (8 * q)) & 0xffu);
+        if (lane < 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_qlist[w][q][cq[q] + lane] = (unsigned short)(SB | (CAP << 8));
+        }
+        {
+            float4 *z = reinterpret_cast<float4 *>(slab);
+            for (int c = lane; c < cnt * (RW / 4); c += WAVE) z[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            for (int j0 = 0; j0 < cq[G]; j0 += 16) {
+                const unsigned le = s_qlist[w][G][j0 + nl];
+                const int e = le & 0xffu, row = le >> 8;
+                const int qn = top - e;
+                const float *er = reinterpret_cast<const float *>(s_rec) + e * (4 * RQ);
+                const float *ec = reinterpret_cast<const float *>(s_coef) + e * 8;
+                const int sw = 4 * ((e >> 2) & 3);
+                const float bq1 = ec[kk];
+                const float bq2 = ec[4 + (kk & 1)];
+                float bf[NK];
+#pragma unroll
+                for (int j = 0; j < NK; ++j) bf[j] = er[(8 + 4 * j + kk) ^ sw];
+                f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
+                f32x4 d_f[NA];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+                asm volatile("" ::: "memory");
+                f32x4 pw = {0.f, 0.f, 0.f, 0.f}, cva = {0.f, 0.f, 0.f, 0.f}, cvb = {0.f, 0.f, 0.f, 0.f};
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bq1, pw, 0, 0, 0);
+                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi2[G], bq2, pw, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NK; j += 2) {   // two accumulation chains
+                    cva = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][j], bf[j], cva, 0, 0, 0);
+                    if (j + 1 < NK) cvb = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][j + 1], bf[j + 1], cvb, 0, 0, 0);
+                }
+                float cg[4], araw[4], a[4], r1a[4], rp[4], Ts4[4], Rs4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int last = lastp[16 * G + i];
+                    const float2 sv = *reinterpret_cast<const float2 *>(state + G * GS + i * 2);
+                    Ts4[i] = sv.x;
+                    Rs4[i] = sv.y;
+                    cg[i] = cva[i] + cvb[i];
+                    bool pw_ok;
+                    araw[i] = exp2_guard(pw[i], pw_ok);
+                    const bool ok = (qn < last) && pw_ok && !(araw[i] < (1.0f / 255.0f));
+                    araw[i] = ok ? araw[i] : 0.f;
+                    a[i] = fminf(0.99f, araw[i]);
+                    r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
+                    rp[i] = r1a[i];
+                }
+                row_scan_mul4(rp[0], rp[1], rp[2], rp[3]);
+                float T[4], wgt[4], rs[4], R[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    T[i] = Ts4[i] * rp[i];
+                    wgt[i] = a[i] * T[i];
+                    rs[i] = cg[i] * wgt[i];
+                }
+                row_scan_add4(rs[0], rs[1], rs[2], rs[3]);
+                row_shr1_add4(R, rs, Rs4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds_store2_lane15(state + G * GS + i * 2, T[i], Rs4[i] + rs[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int s = 4 * G + i;
+                    const float dLa = T[i] * cg[i] - R[i] * r1a[i];
+                    const float dLp = araw[i] * dLa;
+                    d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[32 * s], dLp, d_mom, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NA; ++q) d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(hft[s][q], wgt[i], d_f[q], 0, 0, 0);
+                }
+                if (j0 + nl < cq[G]) {
+                    float *rr = slab + row * RW;
+                    if (kk < 2) {
+                        float4 *p1 = reinterpret_cast<float4 *>(rr + 4 * kk);
+                        float4 o1 = *p1;
+                        o1.x += d_mom[0]; o1.y += d_mom[1]; o1.z += d_mom[2]; o1.w += d_mom[3];
+                        *p1 = o1;
+                    }
+#pragma unroll
+                    for (int q = 0; q < NA; ++q) {
+                        if (16 * q + 4 * kk < CH) {
+                            float4 *pf = reinterpret_cast<float4 *>(rr + 8 + 16 * q + 4 * kk);
+                            float4 f0 = *pf;
+                            f0.x += d_f[q][0]; f0.y += d_f[q][1]; f0.z += d_f[q][2]; f0.w += d_f[q][3];
+                            *pf = f0;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        const int slot_mine = ce < nb ? slots[top - ce] : 0;
+        st.load_payload(A, tid);
+        st.load_ids(A, tid, range.x, pos, batch + 2);
+        __syncthreads();
+        if (ce < nb) {
+            const int e = ce;
+            const unsigned int p4 = s_pos4[e];
+            float *dst = pair_buf + (size_t)slot_mine * RST;
+            if (cp == 0) {
+                float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const unsigned int pp = umin_((p4 >> (8 * ww)) & 0xffu, (unsigned)CAP);
+                    const float4 *rw = reinterpret_cast<const float4 *>(s_acc[ww] + pp * RW);
+                    const float4 m = rw[0], m2 = rw[1];
+                    const float bxw = (ww & 1) ? 2.f : -2.f, byw = (ww >> 1) ? 2.f : -2.f;
+                    s[0] += m.x;
+                    s[1] += m.y + bxw * m.x;
+                    s[2] += m.z + byw * m.x;
+                    s[3] += m.w + 2.f * bxw * m.y + (bxw * bxw) * m.x;
+                    s[4] += m2.x + bxw * m.z + byw * m.y + (bxw * byw) * m.x;
+                    s[5] += m2.y + 2.f * byw * m.z + (byw * byw) * m.x;
+                }
+                const float4 g0 = s_rec[qpart(e, 0)], g1 = s_rec[qpart(e, 1)];
+                const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
+                const float uc = g0.x - tcx, vc = g0.y - tcy;
+                const float M0 = s[0], Mx = s[1], My = s[2], Mxx = s[3], Mxy = s[4], Myy = s[5];
+                float4 r0;
+                r0.x = cA * Mx + cB * My - (cA * uc + cB * vc) * M0;
+                r0.y = cB * Mx + cC * My - (cB * uc + cC * vc) * M0;
+                r0.z = -0.5f * (uc * uc * M0 - 2.f * uc * Mx + Mxx);
+                r0.w = -(uc * vc * M0 - uc * My - vc * Mx + Mxy);
+                reinterpret_cast<float4 *>(dst)[0] = r0;
+                float2 r1;
+                r1.x = -0.5f * (vc * vc * M0 - 2.f * vc * My + Myy);
+                r1.y = o > 0.f ? M0 / o : 0.f;
+                reinterpret_cast<float2 *>(dst)[2] = r1;
+            } else {
+                constexpr int NQF = CH / 4, PER = (NQF + 2) / 3;   // feature float4 chunks, shared by three threads
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int c = (cp - 1) * PER + k;
+                    if (c < NQF) {
+                        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int ww = 0; ww < 4; ++ww) {
+                            const unsigned int pp = umin_((p4 >> (8 * ww)) & 0xffu, (unsigned)CAP);
+                            const float4 v = *reinterpret_cast<const float4 *>(s_acc[ww] + pp * RW + 8 + 4 * c);
+                            f.x += v.x; f.y += v.y; f.z += v.z; f.w += v.w;
+                        }
+                        float2 *d2 = reinterpret_cast<float2 *>(dst + NG + 4 * c);   // (NG = 6: 8-byte aligned)
+                        d2[0] = make_float2(f.x, f.y);
+                        d2[1] = make_float2(f.z, f.w);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (A.dbg_T_front) {
+        const int px = tx * TILE + lx, py = ty * TILE + ly;
+        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq)];
+    }
+}
+
 // ------------------------------------------------------------------ backward of the WIDE part of the renderer's row in its own pass
 // blend_bwd_sets_kernel replays the alpha / T chain once for three sets but needs 255 registers (dL_dout of 23 channels in both
 // MFMA operand layouts): two waves per SIMD, the matrix pipe and the VALU take turns instead of overlapping (615 us per frame at
@@ -3534,6 +3917,11 @@ static int launch_bwd_ab(const BlendArgs &A, int T, bool pair, hipStream_t s) {
         constexpr int QC = CH <= 3 ? CH : 3;
         if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_quarter_kernel<QC, true>), grid, block, 0, s, A);
         else SPLAT_LAUNCH("blend_bwd", (blend_bwd_quarter_kernel<QC, false>), grid, block, 0, s, A);
+    } else if (pair && !BIAS && !ABS && CH >= 16 && A.cull_flags && !A.rec_stride && bwd_use_mfma() && bwd_use_quarters()) {
+        // frame batch, wide row without |taps|: quarter lists
+        constexpr int WC = CH >= 16 ? CH : 16;
+        if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_wide_quarter_kernel<WC, true>), grid, block, 0, s, A);
+        else SPLAT_LAUNCH("blend_bwd", (blend_bwd_wide_quarter_kernel<WC, false>), grid, block, 0, s, A);
     } else if (pair && !BIAS && bwd_use_mfma()) {
         if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_mfma_kernel<CH, ABS, true>), grid, block, 0, s, A);
         else SPLAT_LAUNCH("blend_bwd", (blend_bwd_mfma_kernel<CH, ABS, false>), grid, block, 0, s, A);
