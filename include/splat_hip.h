@@ -161,6 +161,27 @@ int splat_alpha_blending_backward(int P, int C, const float *uv, const float *co
                                     inclusion decision of the forward (a flipped decision is off by >= 1/255)*/,
                                   splat_stream_t stream);
 
+/* The same two calls with the forward's cull decisions handed to the backward (ABI 17): cull_flags[M] receives one word per
+ * sorted entry (byte b = the 4x4 quarters of the tile's 8x8 block b the splat can reach); a backward that gets them walks one
+ * survivor list per quarter instead of culling again (narrow rows without |taps|, rows of 16 .. 32 channels).  NULL: as above.
+ * Reference: the same operators, src/submodules/dptr/dptr/gs/src/alpha_blending.cu:16-110 (forward), :150-249 (backward). */
+int splat_alpha_blending_forward_flags(int P, int C, const float *uv, const float *conic, const float *opacity,
+                                       const float *feature, const float *opacity_bias,
+                                       const int32_t *idx_sorted, const int32_t *tile_range, float bg,
+                                       const float *bg_channels, int W, int H, int K, int enable_truncation,
+                                       float *out, float *final_T, int32_t *ncontrib, int32_t *gs_idx,
+                                       float *pack_scratch, uint32_t *cull_flags, splat_stream_t stream);
+int splat_alpha_blending_backward_flags(int P, int C, const float *uv, const float *conic, const float *opacity,
+                                        const float *feature, const float *opacity_bias,
+                                        const int32_t *idx_sorted, const int32_t *tile_range, float bg, int W,
+                                        int H, const float *final_T, const int32_t *ncontrib,
+                                        const float *dL_dout, float *dL_duv, float *dL_dabs_uv, float *dL_dconic,
+                                        float *dL_dopacity, float *dL_dfeature, float *dL_dopacity_bias,
+                                        float *dL_dndc, float *dL_dabs_ndc, const int32_t *goff_incl,
+                                        const int32_t *slot_sorted, float *pair_scratch, float *pack_scratch,
+                                        int pack_is_valid, float *dbg_T_front, const uint32_t *cull_flags,
+                                        splat_stream_t stream);
+
 /* ---- per-frame evaluation of the dynamic Gaussians --------------------------------------
  * Replaces the eager torch of src/dynamic_gaussian_with_base_point_cloud.py:
  *   get_position :236-250  pos_t = position + c3 + c2 d + c1 d^2 + c0 d^3, c = cubic[N,4,I,3][:, :, seg]

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -28,7 +28,8 @@ SYMBOLS = [
     "splat_compute_sh_forward", "splat_compute_sh_backward",
     "splat_bin_scratch_bytes", "splat_bin_count", "splat_bin_sort",
     "splat_compute_gaussian_key", "splat_compute_tile_gaussian_range",
-    "splat_alpha_blending_forward", "splat_alpha_blending_backward", "splat_blend_pair_floats", "splat_blend_pack_floats",
+    "splat_alpha_blending_forward", "splat_alpha_blending_backward", "splat_alpha_blending_forward_flags",
+    "splat_alpha_blending_backward_flags", "splat_blend_pair_floats", "splat_blend_pack_floats",
     "splat_dynamic_eval_forward", "splat_dynamic_eval_backward",
     "splat_position_poly_fourier_forward", "splat_position_poly_fourier_backward",
     "splat_preprocess_ortho_forward", "splat_preprocess_ortho_backward",

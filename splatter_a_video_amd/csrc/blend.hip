@@ -3990,12 +3990,12 @@ extern "C" size_t splat_blend_pair_floats(int C, int has_bias) {
 }
 
 // ================================================================== C ABI
-extern "C" int splat_alpha_blending_forward(int P, int C, const float *uv, const float *conic, const float *opacity,
-                                            const float *feature, const float *opacity_bias,
-                                            const int32_t *idx_sorted, const int32_t *tile_range, float bg,
-                                            const float *bg_channels, int W, int H, int K, int enable_truncation,
-                                            float *out, float *final_T, int32_t *ncontrib, int32_t *gs_idx,
-                                            float *pack_scratch, splat_stream_t stream) {
+static int blend_forward_impl(int P, int C, const float *uv, const float *conic, const float *opacity,
+                              const float *feature, const float *opacity_bias,
+                              const int32_t *idx_sorted, const int32_t *tile_range, float bg,
+                              const float *bg_channels, int W, int H, int K, int enable_truncation,
+                              float *out, float *final_T, int32_t *ncontrib, int32_t *gs_idx,
+                              float *pack_scratch, uint32_t *cull_flags, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && C >= 1 && W > 0 && H > 0, "bad sizes");
     SPLAT_CHECK_ARG(tile_range && out && final_T && ncontrib, "null pointer");
     SPLAT_CHECK_ARG(P == 0 || (uv && conic && opacity && feature && pack_scratch), "null pointer");
@@ -4009,6 +4009,7 @@ extern "C" int splat_alpha_blending_forward(int P, int C, const float *uv, const
     A.K = enh ? K : 0; A.trunc = enable_truncation ? 1 : 0;
     A.out = out; A.final_T = final_T; A.ncontrib = ncontrib; A.gs_idx = gs_idx;
     A.pack = pack_scratch;
+    A.cull_flags = cull_flags;   // optional: the cull's keep words of every sorted entry, for the backward
     const int T = A.gx * ((H + TILE - 1) / TILE);
     A.F = 1; A.T = T;
     for (int c0 = 0; c0 < C; c0 += 32) {  // reference chunking: src/alpha_blending.cu:287-394
@@ -4020,15 +4021,35 @@ extern "C" int splat_alpha_blending_forward(int P, int C, const float *uv, const
     return SPLAT_OK;
 }
 
-extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, const float *conic, const float *opacity,
-                                             const float *feature, const float *opacity_bias,
-                                             const int32_t *idx_sorted, const int32_t *tile_range, float bg, int W,
-                                             int H, const float *final_T, const int32_t *ncontrib,
-                                             const float *dL_dout, float *dL_duv, float *dL_dabs_uv, float *dL_dconic,
-                                             float *dL_dopacity, float *dL_dfeature, float *dL_dopacity_bias,
-                                             float *dL_dndc, float *dL_dabs_ndc, const int32_t *goff_incl,
-                                             const int32_t *slot_sorted, float *pair_scratch, float *pack_scratch,
-                                             int pack_is_valid, float *dbg_T_front, splat_stream_t stream) {
+extern "C" int splat_alpha_blending_forward(int P, int C, const float *uv, const float *conic, const float *opacity,
+                                            const float *feature, const float *opacity_bias,
+                                            const int32_t *idx_sorted, const int32_t *tile_range, float bg,
+                                            const float *bg_channels, int W, int H, int K, int enable_truncation,
+                                            float *out, float *final_T, int32_t *ncontrib, int32_t *gs_idx,
+                                            float *pack_scratch, splat_stream_t stream) {
+    return blend_forward_impl(P, C, uv, conic, opacity, feature, opacity_bias, idx_sorted, tile_range, bg, bg_channels, W, H, K,
+                              enable_truncation, out, final_T, ncontrib, gs_idx, pack_scratch, nullptr, stream);
+}
+
+extern "C" int splat_alpha_blending_forward_flags(int P, int C, const float *uv, const float *conic, const float *opacity,
+                                                  const float *feature, const float *opacity_bias,
+                                                  const int32_t *idx_sorted, const int32_t *tile_range, float bg,
+                                                  const float *bg_channels, int W, int H, int K, int enable_truncation,
+                                                  float *out, float *final_T, int32_t *ncontrib, int32_t *gs_idx,
+                                                  float *pack_scratch, uint32_t *cull_flags, splat_stream_t stream) {
+    return blend_forward_impl(P, C, uv, conic, opacity, feature, opacity_bias, idx_sorted, tile_range, bg, bg_channels, W, H, K,
+                              enable_truncation, out, final_T, ncontrib, gs_idx, pack_scratch, cull_flags, stream);
+}
+
+static int blend_backward_impl(int P, int C, const float *uv, const float *conic, const float *opacity,
+                               const float *feature, const float *opacity_bias,
+                               const int32_t *idx_sorted, const int32_t *tile_range, float bg, int W,
+                               int H, const float *final_T, const int32_t *ncontrib,
+                               const float *dL_dout, float *dL_duv, float *dL_dabs_uv, float *dL_dconic,
+                               float *dL_dopacity, float *dL_dfeature, float *dL_dopacity_bias,
+                               float *dL_dndc, float *dL_dabs_ndc, const int32_t *goff_incl,
+                               const int32_t *slot_sorted, float *pair_scratch, float *pack_scratch,
+                               int pack_is_valid, float *dbg_T_front, const uint32_t *cull_flags, splat_stream_t stream) {
     SPLAT_CHECK_ARG(P >= 0 && C >= 1 && W > 0 && H > 0, "bad sizes");
     if (P == 0) return SPLAT_OK;
     // idx_sorted may be NULL when no Gaussian touches any tile (M = 0: every tile range is empty, nothing dereferences it)
@@ -4055,6 +4076,7 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
     A.goff_incl = goff_incl; A.slot_sorted = slot_sorted; A.pair_buf = pair_scratch;
     A.pack = pack_scratch;
     A.dbg_T_front = dbg_T_front;
+    A.cull_flags = pair_mode ? const_cast<uint32_t *>(cull_flags) : nullptr;   // (the forward's keep words: quarter-list kernels)
     A.pack_valid = (pack_is_valid && C <= 32) ? 1 : 0;  // one chunk only: later chunks overwrite the scratch
     const int T = A.gx * ((H + TILE - 1) / TILE);
     A.F = 1; A.T = T;
@@ -4066,6 +4088,37 @@ extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, cons
         if (rc != SPLAT_OK) return rc;
     }
     return SPLAT_OK;
+}
+
+extern "C" int splat_alpha_blending_backward(int P, int C, const float *uv, const float *conic, const float *opacity,
+                                             const float *feature, const float *opacity_bias,
+                                             const int32_t *idx_sorted, const int32_t *tile_range, float bg, int W,
+                                             int H, const float *final_T, const int32_t *ncontrib,
+                                             const float *dL_dout, float *dL_duv, float *dL_dabs_uv, float *dL_dconic,
+                                             float *dL_dopacity, float *dL_dfeature, float *dL_dopacity_bias,
+                                             float *dL_dndc, float *dL_dabs_ndc, const int32_t *goff_incl,
+                                             const int32_t *slot_sorted, float *pair_scratch, float *pack_scratch,
+                                             int pack_is_valid, float *dbg_T_front, splat_stream_t stream) {
+    return blend_backward_impl(P, C, uv, conic, opacity, feature, opacity_bias, idx_sorted, tile_range, bg, W, H, final_T, ncontrib,
+                               dL_dout, dL_duv, dL_dabs_uv, dL_dconic, dL_dopacity, dL_dfeature, dL_dopacity_bias, dL_dndc,
+                               dL_dabs_ndc, goff_incl, slot_sorted, pair_scratch, pack_scratch, pack_is_valid, dbg_T_front, nullptr,
+                               stream);
+}
+
+extern "C" int splat_alpha_blending_backward_flags(int P, int C, const float *uv, const float *conic, const float *opacity,
+                                                   const float *feature, const float *opacity_bias,
+                                                   const int32_t *idx_sorted, const int32_t *tile_range, float bg, int W,
+                                                   int H, const float *final_T, const int32_t *ncontrib,
+                                                   const float *dL_dout, float *dL_duv, float *dL_dabs_uv, float *dL_dconic,
+                                                   float *dL_dopacity, float *dL_dfeature, float *dL_dopacity_bias,
+                                                   float *dL_dndc, float *dL_dabs_ndc, const int32_t *goff_incl,
+                                                   const int32_t *slot_sorted, float *pair_scratch, float *pack_scratch,
+                                                   int pack_is_valid, float *dbg_T_front, const uint32_t *cull_flags,
+                                                   splat_stream_t stream) {
+    return blend_backward_impl(P, C, uv, conic, opacity, feature, opacity_bias, idx_sorted, tile_range, bg, W, H, final_T, ncontrib,
+                               dL_dout, dL_duv, dL_dabs_uv, dL_dconic, dL_dopacity, dL_dfeature, dL_dopacity_bias, dL_dndc,
+                               dL_dabs_ndc, goff_incl, slot_sorted, pair_scratch, pack_scratch, pack_is_valid, dbg_T_front,
+                               cull_flags, stream);
 }
 
 

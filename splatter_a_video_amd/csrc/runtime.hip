@@ -18,7 +18,7 @@ void splat_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *splat_last_error(void) { return g_err; }
-extern "C" int splat_abi_version(void) { return 16; }
+extern "C" int splat_abi_version(void) { return 17; }
 
 namespace {
 struct Pending {

@@ -238,12 +238,19 @@ class _AlphaBlend(torch.autograd.Function):
         ncontrib = torch.empty(H, W, dtype=torch.int32, device=dev)
         gs_idx = torch.empty(H, W, K, dtype=torch.int32, device=dev) if K > 0 else None  # kernel pads with -1
         pack = torch.empty(max(P, 1) * L.lib().splat_blend_pack_floats(C), dtype=torch.float32, device=dev)
-        L.check(L.lib().splat_alpha_blending_forward(
+        ctx.pairmap = _find_pairmap(idx_sorted, tile_range, P)
+        # the cull's keep words of every sorted entry: with them the pair-mode backward walks quarter lists instead of
+        # culling again (kept only when a backward can follow)
+        flags = None
+        if ctx.pairmap is not None and idx_sorted.numel() > 0 and any(ctx.needs_input_grad[:5]):
+            flags = torch.empty(idx_sorted.numel(), dtype=torch.int32, device=dev)
+        L.check(L.lib().splat_alpha_blending_forward_flags(
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias_c),
             L.ptr(idx_sorted), L.ptr(tile_range), L.cf(bg), L.ptr(None), L.ci(W), L.ci(H), L.ci(K),
-            L.ci(1 if trunc else 0), L.ptr(out), L.ptr(final_T), L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.stream()))
+            L.ci(1 if trunc else 0), L.ptr(out), L.ptr(final_T), L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.ptr(flags),
+            L.stream()))
+        ctx.flags = flags
         ctx.meta = (float(bg), int(W), int(H), bias is not None, ndc is not None, abs_ndc is not None)
-        ctx.pairmap = _find_pairmap(idx_sorted, tile_range, P)
         ctx.pack = pack          # packed records: reused by the backward when C <= 32 (one channel chunk)
         saved = [uv, conic, opacity, feature, idx_sorted, tile_range, final_T, ncontrib]
         if bias_c is not None:
@@ -291,11 +298,12 @@ class _AlphaBlend(torch.autograd.Function):
         in_kernel = scratch is not None
         dndc = alloc(P, 2, dtype=torch.float32, device=dev) if (has_ndc and in_kernel) else None
         dabs_ndc = alloc(P, 2, dtype=torch.float32, device=dev) if (has_abs and in_kernel) else None
-        L.check(L.lib().splat_alpha_blending_backward(
+        L.check(L.lib().splat_alpha_blending_backward_flags(
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(feature), L.ptr(bias), L.ptr(idx_sorted),
             L.ptr(tile_range), L.cf(bg), L.ci(W), L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(g), L.ptr(duv),
             L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(dbias), L.ptr(dndc), L.ptr(dabs_ndc), L.ptr(goff),
-            L.ptr(slot_sorted), L.ptr(scratch), L.ptr(pack), L.ci(1), L.ptr(_debug_T_front(H, W, dev)), L.stream()))
+            L.ptr(slot_sorted), L.ptr(scratch), L.ptr(pack), L.ci(1), L.ptr(_debug_T_front(H, W, dev)),
+            L.ptr(ctx.flags if pm is not None else None), L.stream()))
         if (has_ndc or has_abs) and not in_kernel:
             half = _half_wh(W, H, dev)
             if has_ndc:
@@ -360,11 +368,15 @@ class _BlendShared(torch.autograd.Function):
         ncontrib = torch.empty(H, W, dtype=torch.int32, device=dev)
         gs_idx = torch.empty(H, W, K, dtype=torch.int32, device=dev) if K > 0 else None
         pack = torch.empty(max(P, 1) * L.lib().splat_blend_pack_floats(C), dtype=torch.float32, device=dev)
-        L.check(L.lib().splat_alpha_blending_forward(
+        ctx.pairmap = _find_pairmap(idx_sorted, tile_range, P)
+        flags = None   # the cull's keep words for the sets' backward passes (see _AlphaBlend)
+        if ctx.pairmap is not None and idx_sorted.numel() > 0 and any(ctx.needs_input_grad):
+            flags = torch.empty(idx_sorted.numel(), dtype=torch.int32, device=dev)
+        L.check(L.lib().splat_alpha_blending_forward_flags(
             L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(allf), L.ptr(None), L.ptr(idx_sorted),
             L.ptr(tile_range), L.cf(0.0), L.ptr(bgc), L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(final_T),
-            L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.stream()))
-        ctx.pairmap = _find_pairmap(idx_sorted, tile_range, P)
+            L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.ptr(flags), L.stream()))
+        ctx.flags = flags
         ctx.meta = (int(W), int(H), tuple(float(b) for b in bgs), tuple(bool(d) for d in detach_opacity),
                     tuple(bool(t) for t in taps), ndc is not None, abs_ndc is not None, widths)
         ctx.save_for_backward(uv, conic, opacity, idx_sorted, tile_range, final_T, ncontrib, *feats)
@@ -407,11 +419,12 @@ class _BlendShared(torch.autograd.Function):
             dop = alloc(opacity.shape, dtype=torch.float32, device=dev)
             dfeat = alloc(P, C, dtype=torch.float32, device=dev)
             pack = torch.empty(max(P, 1) * lib.splat_blend_pack_floats(C), dtype=torch.float32, device=dev)
-            L.check(lib.splat_alpha_blending_backward(
+            L.check(lib.splat_alpha_blending_backward_flags(
                 L.ci(P), L.ci(C), L.ptr(uv), L.ptr(conic), L.ptr(opacity), L.ptr(f), L.ptr(None), L.ptr(idx_sorted),
                 L.ptr(tile_range), L.cf(bgs[s]), L.ci(W), L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(g), L.ptr(duv),
                 L.ptr(dabs), L.ptr(dconic), L.ptr(dop), L.ptr(dfeat), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(goff),
-                L.ptr(slot_sorted), L.ptr(scratch), L.ptr(pack), L.ci(0), L.ptr(_debug_T_front(H, W, dev)), L.stream()))
+                L.ptr(slot_sorted), L.ptr(scratch), L.ptr(pack), L.ci(0), L.ptr(_debug_T_front(H, W, dev)),
+                L.ptr(ctx.flags if pm is not None else None), L.stream()))
             dfeats[s] = dfeat
             duv_t = duv if duv_t is None else duv_t + duv
             dconic_t = dconic if dconic_t is None else dconic_t + dconic
