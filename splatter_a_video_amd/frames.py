@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import warnings
 from typing import Dict, Optional
 
 import torch
@@ -102,7 +103,8 @@ class FrameBatch:
     """Buffers and launch sequence of a batch of ``F`` frames of ``P`` Gaussians at ``W`` x ``H`` with ``C`` composited
     feature channels (C <= 32).  ``capacity`` = tile-Gaussian pairs reserved per frame; None: measured on the first call
     (one host sync), afterwards the batch runs without any host synchronisation and ``check()`` (call it whenever the
-    host synchronises anyway, e.g. once per optimiser step) raises if a frame outgrew it."""
+    host synchronises anyway, e.g. once per optimiser step) raises if a frame outgrew it; without ``check()`` the next
+    forward raises, one step late (the flag travels to pinned host memory behind the binning kernels)."""
 
     def __init__(self, F: int, P: int, W: int, H: int, C: int, device, capacity: Optional[int] = None,
                  want_abs: bool = False, slack: float = 1.25):
@@ -173,8 +175,29 @@ class FrameBatch:
         return m
 
     def _begin_forward(self) -> int:
+        self._poll_overflow()
         self.generation += 1
         return self.generation
+
+    def _note_overflow(self) -> None:
+        """behind the binning kernels of a forward: the overflow flag travels to pinned host memory asynchronously"""
+        if getattr(self, "_ovf_host", None) is None:
+            self._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._ovf_host.copy_(self.overflow, non_blocking=True)
+        self._ovf_event = torch.cuda.Event()
+        self._ovf_event.record()
+
+    def _poll_overflow(self) -> None:
+        """at the next forward, without a host synchronisation: raises if an earlier batch outgrew the capacity (its surplus
+        pairs were dropped: that batch's images and gradients were incomplete) -- a caller that never calls check() still learns
+        of it one step late instead of never"""
+        ev = getattr(self, "_ovf_event", None)
+        if ev is not None and ev.query():
+            self._ovf_event = None
+            if int(self._ovf_host[0]) != 0:
+                raise L.SplatError(f"FrameBatch: an earlier batch held more tile-Gaussian pairs in one frame than the capacity "
+                                   f"{self.capacity} (its surplus pairs were dropped); build the batch with a larger `capacity` / "
+                                   "`slack`")
 
     def _check_generation(self, gen: int) -> None:
         if gen != self.generation:
@@ -209,6 +232,7 @@ class FrameBatch:
             L.ci(F_), L.ci(P_), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.radius), L.ci(W), L.ci(H),
             L.ptr(self.bin_scratch), L.ptr(self.tile_range), ctypes.c_int64(cap), L.ptr(self.keys), L.ptr(self.idx_sorted),
             L.ptr(self.overflow), L.ptr(self.goff), L.ptr(self.owner), L.ptr(self.slot_sorted), st))
+        self._note_overflow()
 
     def _struct(self, xyz, scales, uquats, opacity, feature, offsets, cam, bg, nearest=0.01, extent=1.3) -> _SplatFrames:
         b = _SplatFrames()
@@ -244,6 +268,7 @@ class FrameBatch:
         b = self._struct(xyz, scales, uquats, opacity, feature, offsets, cam, bg, nearest, extent)
         b.out = out.data_ptr()
         L.check(lib.splat_frames_forward(ctypes.byref(b)))
+        self._note_overflow()
         return out
 
     def _backward_onecall(self, dL_dout, xyz, scales, uquats, offsets, cam, bg, bufs, accumulate, dbg=None):
@@ -521,7 +546,13 @@ def _blend_sets_forward(fb, meta, feats, opacity, op_fs, K):
     lib, st = L.lib(), L.stream()
     F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
     widths = [1 if m[0] == "depth" else m[0] for m in meta]
-    plan = _one_pass_plan(meta, widths, C) if os.environ.get("SPLAT_SETS_ONE_PASS", "1") != "0" else None
+    one_pass_wanted = os.environ.get("SPLAT_SETS_ONE_PASS", "1") != "0"
+    plan = _one_pass_plan(meta, widths, C) if one_pass_wanted else None
+    if plan is None and one_pass_wanted and not fb.__dict__.get("_warned_per_set"):
+        fb.__dict__["_warned_per_set"] = True   # (once per batch object)
+        warnings.warn("FrameBatch.render_sets: these feature sets do not fit the one-pass backward (one set per routing group -- "
+                      "taps / live opacity / detached opacity -- of at most 4 / 4 / 20 channels): the backward runs one pass of "
+                      "the tile kernels per set", RuntimeWarning, stacklevel=3)
     tens, it = [], iter(feats)
     for w, _, _, _ in meta:
         tens.append(fb.depth if w == "depth" else _points(next(it), "feature", w))

@@ -164,6 +164,9 @@ def test_batch_capacity_overflow_is_flagged_and_safe():
     assert torch.isfinite(out).all() and torch.isfinite(p["xyz"].grad).all()
     with pytest.raises(SplatError):
         B.check()
+    # ... and a caller that never calls check() learns of it at the next forward (no host synchronisation of its own)
+    with pytest.raises(SplatError):
+        B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], off, _t(sc.extr))
 
 
 @pytest.mark.parametrize("one_pass", ["1", "0"])
