@@ -45,7 +45,8 @@ def _per_frame(sc, p, off, feat, g, W, H, bg, abs_tap=False):
 
 @pytest.mark.parametrize("N,W,H,F,C,abs_tap", [(3000, 100, 60, 3, 3, False), (20000, 256, 192, 4, 3, True),
                                                (5000, 96, 64, 2, 19, False), (1, 16, 16, 2, 1, False),
-                                               (60000, 854, 480, 2, 3, False)])
+                                               (60000, 854, 480, 2, 3, False),
+                                               (700, 64, 48, 35, 3, False)])   # (more frames than the Gaussian-side walk keeps slot ranges for in LDS)
 def test_batch_equals_per_frame_operators(N, W, H, F, C, abs_tap):
     sc = make_scene(N, W, H, seed=N + C)
     rng = np.random.default_rng(N)
