@@ -1199,28 +1199,6 @@ __device__ __forceinline__ void row_scan_add4(float &a, float &b, float &c, floa
                      SCAN4("v_add_f32_dpp", "8")
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
-// lds_store2_lane15 at a compile-time float offset OFF (< 255) from p: the offset rides in the instruction (no address add)
-template <int OFF>
-__device__ __forceinline__ void lds_store2_lane15_at(float *p, float a, float b) {
-    static_assert(OFF >= 0 && OFF + 1 <= 255, "ds_write2_b32 offsets are 8 bits, in dwords");
-    const unsigned addr = (unsigned)(size_t)p;
-    asm volatile(
-        "s_mov_b64 exec, %3\n\t"
-        "ds_write2_b32 %0, %1, %2 offset0:%4 offset1:%5\n\t"
-        "s_mov_b64 exec, -1"
-        :
-        : "v"(addr), "v"(a), "v"(b), "s"(0x8000800080008000ull), "n"(OFF), "n"(OFF + 1)
-        : "memory");
-}
-// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
-template <int... Is, typename F>
-__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, Is...>, F &&f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
-}
 // two floats to LDS from the last lane of every 16-lane row (EXEC is all ones in the callers: full waves, uniform flow)
 __device__ __forceinline__ void lds_store2_lane15(float *p, float a, float b) {
     const unsigned addr = (unsigned)(size_t)p;  // LDS byte address = low 32 bits of the generic shared pointer

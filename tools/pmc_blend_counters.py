@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 out, dirs = sys.argv[1], sys.argv[2:]
-KERNELS = {"blend_fwd_kernel": "blend_fwd", "blend_bwd_mfma_kernel": "blend_bwd", "blend_bwd_quarter_kernel": "blend_bwd", "blend_bwd_sets_kernel": "blend_bwd_sets", "blend_bwd_sets_quarter_kernel": "blend_bwd_sets"}
+KERNELS = {"blend_fwd_kernel": "blend_fwd", "blend_bwd_mfma_kernel": "blend_bwd", "blend_bwd_quarter_kernel": "blend_bwd", "blend_bwd_wide_quarter_kernel": "blend_bwd", "blend_bwd_sets_kernel": "blend_bwd_sets", "blend_bwd_sets_quarter_kernel": "blend_bwd_sets"}
 rows = []
 for d in dirs:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
