@@ -1708,7 +1708,8 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
 // 1.087 -> 1.047 of the mean in the CPU model, and what blend_bwd_sets_quarter_kernel does -- doubles the rows a wave needs
 // (a splat's quarters inside one block share a row, its quarters in different blocks meet in different waves): second rounds
 // everywhere at 64 rows, 138 -> 166 us per frame; 128 rows do not fit four workgroups per CU.)
-// Same arithmetic as blend_bwd_mfma_kernel per (pixel, splat): exponent chain, guards, scans.  Narrow rows without |taps|.
+// Same arithmetic as blend_bwd_mfma_kernel per (pixel, splat): exponent chain, guards, scans.  Narrow rows; ABS: with the |d uv|
+// sums of the abs taps (two more products per step for conic (centre - pixel), as in blend_bwd_sets_quarter_kernel).
 #ifndef BLEND_Q_SB
 #define BLEND_Q_SB 128
 #endif
@@ -1721,19 +1722,19 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
 #ifndef BLEND_Q_MINW
 #define BLEND_Q_MINW 4
 #endif
-template <int CH>
+template <int CH, bool ABS = false>
 struct QuarterCfg {
     static_assert(CH <= 3 && Rec<CH>::RQ == 4 && Rec<CH>::CULL >= 11, "floats 11-15 of the record (cull parameters) are free for the coefficients");
     static constexpr int SB = BLEND_Q_SB, CAP = BLEND_Q_CAP;
-    static constexpr int NG = GradLayout<false, false>::NG, NC = NG + CH, NCP = PAIR_STRIDE(NC);
-    static constexpr int RW = 16;   // slab row: [M0 Mx My Mxx | Mxy Myy . . | f0 f1 f2 . of lane groups 0 + 2 | of lane groups 1 + 3]
+    static constexpr int NG = GradLayout<ABS, false>::NG, NC = NG + CH, NCP = PAIR_STRIDE(NC);
+    static constexpr int RW = 16;   // slab row: [M0 Mx My Mxx | Mxy Myy ax ay | f0 f1 f2 . of lane groups 0 + 2 | of lane groups 1 + 3]
     static constexpr int PW = 8;    // pixel row: [g0 g1 g2 . | . ncontrib T_state R_state]
 };
 
-template <int CH, bool EXACT>
+template <int CH, bool ABS, bool EXACT>
 __global__ void __launch_bounds__(256, BLEND_Q_MINW)
 blend_bwd_quarter_kernel(const BlendArgs B) {
-    using Cfg = QuarterCfg<CH>;
+    using Cfg = QuarterCfg<CH, ABS>;
     constexpr int SB = Cfg::SB, CAP = Cfg::CAP, NCP = Cfg::NCP, RW = Cfg::RW, PW = Cfg::PW, RQ = 4;
     static_assert(SB <= 128 && CAP < 255, "list entries are (entry | position << 8) in 16 bits");
     __shared__ float4 s_rec[(SB + 1) * RQ];              // staged records, slot SB = inert; part p of entry e at qpart(e, p)
@@ -1950,6 +1951,15 @@ blend_bwd_quarter_kernel(const BlendArgs B) {
                     const float bq1 = er[(12 ^ sw) + kk];           // q0 qx qy qxx
                     const float bq2 = er[(4 ^ sw) + 2 + (kk & 1)];  // qxy qyy (lane groups 2, 3: their monomial operand is zero)
                     const float bf = er[(8 ^ sw) + kk];             // feature kk (zero past CH)
+                    float blx = 0.f, bly = 0.f;
+                    if (ABS) {   // -conic (centre - pixel) as a product with the monomials (1, x, y, .): operands -c0x cA cB 0 / -c0y cB cC 0
+                        const float4 ge = *reinterpret_cast<const float4 *>(er + (0 ^ sw));   // u v cA cB
+                        const float cCe = er[(4 ^ sw)];
+                        const float ut = ge.x - tcx, vt = ge.y - tcy;
+                        blx = kk == 0 ? -(ge.z * ut + ge.w * vt) : kk == 1 ? ge.z : kk == 2 ? ge.w : 0.f;
+                        bly = kk == 0 ? -(ge.w * ut + cCe * vt) : kk == 1 ? ge.w : kk == 2 ? cCe : 0.f;
+                    }
+                    float s_ax = 0.f, s_ay = 0.f;
                     f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
                     float dfv[CH];
 #pragma unroll
@@ -1989,17 +1999,30 @@ blend_bwd_quarter_kernel(const BlendArgs B) {
                     row_shr1_add4(R, rs, Rs4);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) lds_store2_lane15(pixrow + G * GS + i * PW + 6, T[i], Rs4[i] + rs[i]);
+                    f32x4 lx4 = {0.f, 0.f, 0.f, 0.f}, ly4 = {0.f, 0.f, 0.f, 0.f};
+                    if (ABS) {
+                        lx4 = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], blx, lx4, 0, 0, 0);
+                        ly4 = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bly, ly4, 0, 0, 0);
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float dLa = T[i] * cg[i] - R[i] * r1a[i];
                         const float dLp = araw[i] * dLa;
                         d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[32 * (4 * G + i)], dLp, d_mom, 0, 0, 0);
+                        if (ABS) {
+                            s_ax += fabsf(dLp * lx4[i]);
+                            s_ay += fabsf(dLp * ly4[i]);
+                        }
                         dfv[0] = __builtin_fmaf(gq[i].x, wgt[i], dfv[0]);
                         if (CH > 1) dfv[1 % CH] = __builtin_fmaf(gq[i].y, wgt[i], dfv[1 % CH]);
                         if (CH > 2) dfv[2 % CH] = __builtin_fmaf(gq[i].z, wgt[i], dfv[2 % CH]);
                     }
                     // ---- step epilogue: raw sums into the survivor's row (this wave's quarters run one after the other: plain
                     //      read-add-write; lane group kk owns floats 4 kk .. 4 kk + 3 of the row)
+                    if (ABS) {
+                        s_ax = rows_sum(s_ax, lane);
+                        s_ay = rows_sum(s_ay, lane);
+                    }
                     float fs[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {   // lane groups kk and kk ^ 2 together (one swap); groups 0 and 1 keep a half each
@@ -2009,7 +2032,9 @@ blend_bwd_quarter_kernel(const BlendArgs B) {
                     if (kk < 2 && j0 + nl < cq[G]) {   // lane group kk: floats 4 kk .. of the moments, 8 + 4 kk .. of the features
                         float4 *rm = reinterpret_cast<float4 *>(slab + row * RW + 4 * kk), *rf = rm + 2;
                         float4 m4 = *rm, f4 = *rf;
-                        m4.x += d_mom[0]; m4.y += d_mom[1]; m4.z += d_mom[2]; m4.w += d_mom[3];
+                        m4.x += d_mom[0]; m4.y += d_mom[1];
+                        m4.z += d_mom[2] + ((ABS && kk == 1) ? s_ax : 0.f);   // (lane group 1: rows 6, 7 of the moment product are zero)
+                        m4.w += d_mom[3] + ((ABS && kk == 1) ? s_ay : 0.f);
                         f4.x += fs[0]; f4.y += fs[1]; f4.z += fs[2];
                         *rm = m4;
                         *rf = f4;
@@ -2044,6 +2069,7 @@ blend_bwd_quarter_kernel(const BlendArgs B) {
                     s[4] += m2.x + bxw * m.z + byw * m.y + (bxw * byw) * m.x;
                     s[5] += m2.y + 2.f * byw * m.z + (byw * byw) * m.x;
                     s[6] += fa.x + fb.x; s[7] += fa.y + fb.y; s[8] += fa.z + fb.z;
+                    s[9] += m2.z; s[10] += m2.w;
                 }
                 const float4 g0 = s_rec[qpart(e, 0)], g1 = s_rec[qpart(e, 1)];
                 const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
@@ -2056,8 +2082,11 @@ blend_bwd_quarter_kernel(const BlendArgs B) {
                 rec[3] = -(uc * vc * M0 - uc * My - vc * Mx + Mxy);
                 rec[4] = -0.5f * (vc * vc * M0 - 2.f * vc * My + Myy);
                 rec[5] = o > 0.f ? M0 / o : 0.f;
-                rec[6] = s[6]; rec[7] = s[7]; rec[8] = s[8];
-                rec[9] = 0.f; rec[10] = 0.f; rec[11] = 0.f;
+                rec[6] = 0.f; rec[7] = 0.f; rec[8] = 0.f; rec[9] = 0.f; rec[10] = 0.f; rec[11] = 0.f;
+                if (ABS) { rec[6] = s[9]; rec[7] = s[10]; }
+                rec[Cfg::NG] = s[6];
+                if (CH > 1) rec[Cfg::NG + 1 % CH] = s[7];
+                if (CH > 2) rec[Cfg::NG + 2 % CH] = s[8];
                 if (p0 > 0) {   // a further round of the same super-batch: this thread stored the record before
                     const float *old = pair_buf + (size_t)slot_mine * RST;
 #pragma unroll
@@ -3890,11 +3919,11 @@ template <int CH, bool ABS, bool BIAS>
 static int launch_bwd_ab(const BlendArgs &A, int T, bool pair, hipStream_t s) {
     const dim3 grid((unsigned)(T * A.F)), block(256);
     const bool exact = A.cn == CH;
-    if (pair && !BIAS && !ABS && CH <= 3 && A.cull_flags && bwd_use_mfma() && bwd_use_quarters()) {
-        // frame batch, narrow row without |taps|: one survivor list per 4x4 quarter (the forward's quarter bits)
+    if (pair && !BIAS && CH <= 3 && A.cull_flags && bwd_use_mfma() && bwd_use_quarters()) {
+        // narrow row with the forward's cull words: one survivor list per 4x4 quarter
         constexpr int QC = CH <= 3 ? CH : 3;
-        if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_quarter_kernel<QC, true>), grid, block, 0, s, A);
-        else SPLAT_LAUNCH("blend_bwd", (blend_bwd_quarter_kernel<QC, false>), grid, block, 0, s, A);
+        if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_quarter_kernel<QC, ABS, true>), grid, block, 0, s, A);
+        else SPLAT_LAUNCH("blend_bwd", (blend_bwd_quarter_kernel<QC, ABS, false>), grid, block, 0, s, A);
     } else if (pair && !BIAS && !ABS && CH >= 16 && A.cull_flags && !A.rec_stride && bwd_use_mfma() && bwd_use_quarters()) {
         // frame batch, wide row without |taps|: quarter lists
         constexpr int WC = CH >= 16 ? CH : 16;
