@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak (guides/MI355X_MICROARCH.md); ~6300 GB
 # same command line (tools/round_profile.sh: separate rocprofv3 --pmc passes; read requests sized by
 # TCC_EA0_RDREQ_{32B,64B,128B}, WRITE_SIZE in KiB); stamped with the profile they come from and only reported when the
 # bench runs the configuration they were taken at.
-PMC_TAG = os.environ.get("SPLAT_PMC_TAG", "r03")
+PMC_TAG = os.environ.get("SPLAT_PMC_TAG", "r04")
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_traffic.json")
 PMC_COUNTER_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_blend_counters.json")
 PMC_KERNEL_NAMES = {"blend_bwd": ("blend_bwd_quarter_kernel", "blend_bwd_mfma_kernel"), "blend_fwd": "blend_fwd_kernel", "tile_sort": "tile_sort_kernel",
@@ -61,21 +61,32 @@ PMC_KERNEL_NAMES = {"blend_bwd": ("blend_bwd_quarter_kernel", "blend_bwd_mfma_ke
                     "sh_fwd": "sh_fwd_kernel", "sh_bwd": "sh_bwd_kernel", "bin_scatter": "bin_scatter_kernel"}
 
 
+def pmc_stamp_ok(rec):
+    """an offline PMC record may only be quoted by the build it was taken from: its `build_id` (tools/pmc_*.py stamp it with
+    splat_build_id() of the library that ran, next to `git_head`) must be the running library's"""
+    return rec.get("build_id") is not None and rec.get("build_id") == L.build_id()
+
+
 def pmc_traffic(kernel, tag_cfg):
-    """(bytes per launch, source note) of a kernel from the offline PMC record, if it was taken at this configuration"""
+    """(bytes per launch, source note) of a kernel from the offline PMC record, if it was taken at this configuration BY THIS
+    BUILD of the library"""
     if not os.path.exists(PMC_TRAFFIC_FILE):
         return None, None
     try:
         rec = json.load(open(PMC_TRAFFIC_FILE))
         if rec.get("config") != tag_cfg:
             return None, None
+        if not pmc_stamp_ok(rec):
+            return None, (f"profiles/{PMC_TAG}_pmc_traffic.json is from build {rec.get('build_id')}, the running library is "
+                          f"{L.build_id()}: not quoted")
         names = PMC_KERNEL_NAMES.get(kernel, "")
         k = None
         for nm in (names if isinstance(names, tuple) else (names,)):   # (the kernel the launch actually ran: first name on record)
             k = k or rec["kernels"].get(nm, None)
         if k is None:
             return None, None
-        return k["read_bytes"] + k["write_bytes"], f"profiles/{PMC_TAG}_pmc_traffic.json ({rec.get('source', 'rocprofv3 --pmc, offline')})"
+        return k["read_bytes"] + k["write_bytes"], (f"profiles/{PMC_TAG}_pmc_traffic.json (build {rec.get('build_id')}, git "
+                                                    f"{str(rec.get('git_head'))[:12]}; {rec.get('source', 'rocprofv3 --pmc, offline')})")
     except Exception:
         return None, None
 
@@ -85,10 +96,12 @@ def pmc_issue(kernel, tag_cfg):
         return None
     try:
         rec = json.load(open(PMC_COUNTER_FILE))
-        if rec.get("config") not in (None, tag_cfg):
+        if rec.get("config") not in (None, tag_cfg) or not pmc_stamp_ok(rec):
             return None
         k = rec["kernels"].get(kernel, None)
-        return None if k is None else dict(k["derived"], source=f"profiles/{PMC_TAG}_pmc_blend_counters.json (rocprofv3 --pmc, offline)")
+        return None if k is None else dict(k["derived"], kernel_name=k.get("kernel_name"),
+                                           source=f"profiles/{PMC_TAG}_pmc_blend_counters.json (build {rec.get('build_id')}, git "
+                                                  f"{str(rec.get('git_head'))[:12]}; rocprofv3 --pmc, offline)")
     except Exception:
         return None
 
@@ -116,6 +129,16 @@ def parse():
     ap.add_argument("--stale-overlap", action="store_true",
                     help="stale-1 mode: double-buffered gradient bucket, the all-reduce of step s overlaps step s+1's frames "
                          "and no optimiser runs (NOT synchronous data parallelism; for comparison only)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="EXACT overlap: the rank's frames run as two half-batches with a gradient buffer each; the first half's "
+                         "all-reduce runs under the second half's forward + backward, the sums are added, one Adam step "
+                         "(parallel.overlapped_halves_step: same parameters as the synchronous step to fp32 summation order)")
+    ap.add_argument("--no-comm-analysis", action="store_true",
+                    help="N > 1: skip the extra measurements of the line (all-reduce alone, step without the collective, the "
+                         "--overlap variant)")
+    ap.add_argument("--ref-flow", action="store_true",
+                    help="the reference's LITERAL per-frame call sequence (dptr_ortho_enhanced.py:272-376): eager-torch orthographic "
+                         "projection + EWA on the GPU, the synchronising sort_gaussian, three separate blends through autograd")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the Adam step (forward+backward+all-reduce only)")
     ap.add_argument("--no-spatial-order", action="store_true",
                     help="keep the synthetic scene's random Gaussian order (default: Morton order of the screen positions, as "
@@ -155,7 +178,8 @@ class FrameRenderer:
     """Frame-sharded DP unit: parameters replicated, gradients of all local frames accumulate into
     one flat bucket (views), one all-reduce + one Adam step per gradient step."""
 
-    def __init__(self, sc, device, frames, C_extra=0, mode="batch", dynamic=False, stale_overlap=False, optimizer=True):
+    def __init__(self, sc, device, frames, C_extra=0, mode="batch", dynamic=False, stale_overlap=False, optimizer=True,
+                 halves=False):
         self.sc = sc
         self.mode = mode
         self.dynamic = dynamic
@@ -190,8 +214,10 @@ class FrameRenderer:
             src["attrs"] = np.random.default_rng(7).uniform(-1, 1, size=(N, 19)).astype(np.float32)
         # stale-1 mode only: two gradient buffers, the all-reduce of step s runs on RCCL's stream while step s+1 fills the other
         self.overlap = bool(stale_overlap) and dist.is_available() and dist.is_initialized()
+        # --overlap (exact): two half-batches, a gradient buffer each (parallel.overlapped_halves_step)
+        self.halves = bool(halves) and mode in ("batch", "render_iter") and len(frames) >= 2 and not self.overlap
         self.bucket = FlatGradBucket({k: torch.as_tensor(v, device=device) for k, v in src.items()},
-                                     buffers=2 if self.overlap else 1)
+                                     buffers=2 if (self.overlap or self.halves) else 1)
         self.p = self.bucket.params
         self.flat_grad = self.bucket.flat_grad
         # Adam on the flat buffer (the reference's optimiser, eps 1e-15).  The learning rate is kept small so that the
@@ -215,18 +241,34 @@ class FrameRenderer:
             self.renderer = OrthoEnhancedRenderer(densify_abs_grad_enable=True)
             self.dL_depth = torch.randn(1, self.H, self.W, generator=g).to(device)
             self.dL_attr = torch.randn(19, self.H, self.W, generator=g).to(device)
-        if self.mode == "render_iter":
-            self.batch = FrameBatch(self.F, N, self.W, self.H, 3 + 1 + 19, device, want_abs=True)
-            self.off_all = None if dynamic else torch.stack(self.offs).contiguous()
-            rep = lambda t: t.unsqueeze(0).repeat(self.F, 1, 1, 1).contiguous()
-            self.dL_sets = [rep(self.dL_dout), rep(self.dL_depth), rep(self.dL_attr)]
-        if self.mode == "batch":
-            if self.C > 32:
+        # the step's frames as ONE frame batch, or (--overlap) as two half-batches
+        self.parts = []
+        if self.mode in ("batch", "render_iter"):
+            if self.mode == "batch" and self.C > 32:
                 raise SystemExit("the frame batch composites at most 32 channels per call")
-            self.batch = FrameBatch(self.F, N, self.W, self.H, self.C, device)
-            self.off_all = None if dynamic else torch.stack(self.offs).contiguous()
-            self.dL_all = self.dL_dout.unsqueeze(0).repeat(self.F, 1, 1, 1).contiguous()
+            cut = (self.F + 1) // 2 if self.halves else self.F
+            for lo, hi in ((0, cut), (cut, self.F)):
+                if hi > lo:
+                    self.parts.append(self._part(lo, hi, N, device, g))
+            self.batch = self.parts[0].batch
         self.last = {}
+
+    def _part(self, lo, hi, N, device, g):
+        """frames [lo, hi) of the step as one FrameBatch with its offsets and image gradients"""
+        class Part:
+            pass
+        pt = Part()
+        pt.frames = self.frames[lo:hi]
+        n = hi - lo
+        rep = lambda t: t.unsqueeze(0).repeat(n, 1, 1, 1).contiguous()
+        pt.off_all = None if self.dynamic else torch.stack(self.offs[lo:hi]).contiguous()
+        if self.mode == "render_iter":
+            pt.batch = FrameBatch(n, N, self.W, self.H, 3 + 1 + 19, device, want_abs=True)
+            pt.dL_sets = [rep(self.dL_dout), rep(self.dL_depth), rep(self.dL_attr)]
+        else:
+            pt.batch = FrameBatch(n, N, self.W, self.H, self.C, device)
+            pt.dL_all = rep(self.dL_dout)
+        return pt
 
     def offsets(self, f):
         d = 0.05 * torch.sin(2.0 * np.pi * (f / float(self.sc.F)) + self.phase)
@@ -236,7 +278,8 @@ class FrameRenderer:
         return off
 
     # ------------------------------------------------------------------ all local frames of a step, one launch sequence
-    def frames_batched(self):
+    def frames_batched(self, part=None):
+        part = part or self.parts[0]
         p = self.p
         g = {k: self.bucket.grad(k) for k in p}
         feat = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"]) if self.use_sh else p["feature"]
@@ -245,24 +288,25 @@ class FrameRenderer:
             sink = {k: g[k] for k in ("pos_cubic_node", "rotation", "opacity", "scaling")}
             if not self.use_sh:
                 sink["feature"] = g["feature"]
-            out = self.batch.render_dynamic(self.clock, self.frames, self.extr, feat, position=self.position,
+            out = part.batch.render_dynamic(self.clock, part.frames, self.extr, feat, position=self.position,
                                             pos_cubic_node=p["pos_cubic_node"], rotation=p["rotation"],
                                             rot_poly_feat=self.rot_poly, rot_fourier_feat=self.rot_fourier, opacity=p["opacity"],
                                             scaling=p["scaling"], cubic_layout=SEGMENT_MAJOR, bg=self.sc.bg, nearest=0.01,
                                             grad_sink=sink)
-            out.backward(self.dL_all)
+            out.backward(part.dL_all)
             self.last = dict(M=self.last.get("M", 0), T=self.batch.T)
             return
         sink = {"xyz": g["xyz"], "scales": g["scale"], "uquats": g["rotate"], "opacity": g["opacity"]}
         if not self.use_sh:
             sink["feature"] = g["feature"]
-        out = self.batch.render(p["xyz"], p["scale"], p["rotate"], p["opacity"], feat, self.off_all, self.extr,
+        out = part.batch.render(p["xyz"], p["scale"], p["rotate"], p["opacity"], feat, part.off_all, self.extr,
                                 bg=self.sc.bg, nearest=0.01, grad_sink=sink)
-        out.backward(self.dL_all)
+        out.backward(part.dL_all)
         self.last = dict(M=self.last.get("M", 0), T=self.batch.T)
 
     # ------------------------------------------------------------------ the reference's real frame (row a1), frame batch
-    def frames_render_iter_batched(self):
+    def frames_render_iter_batched(self, part=None):
+        part = part or self.parts[0]
         p = self.p
         g = {k: self.bucket.grad(k) for k in p}
         rgb = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"])      # once per step (constant view direction)
@@ -270,17 +314,17 @@ class FrameRenderer:
                 dict(feature=p["attrs"], bg=0.0, detach_opacity=True)]
         if self.dynamic:   # the reference's real training frame: its dynamic Gaussians through the three blends
             from splatter_a_video_amd.dynamics import SEGMENT_MAJOR
-            out = self.batch.render_dynamic_sets(
-                self.clock, self.frames, self.extr, sets, position=self.position, pos_cubic_node=p["pos_cubic_node"],
+            out = part.batch.render_dynamic_sets(
+                self.clock, part.frames, self.extr, sets, position=self.position, pos_cubic_node=p["pos_cubic_node"],
                 rotation=p["rotation"], rot_poly_feat=self.rot_poly, rot_fourier_feat=self.rot_fourier, opacity=p["opacity"],
                 scaling=p["scaling"], cubic_layout=SEGMENT_MAJOR, K=20,
                 grad_sink={k: g[k] for k in ("pos_cubic_node", "rotation", "opacity", "scaling")})
-            torch.autograd.backward(list(out[:3]), self.dL_sets)
+            torch.autograd.backward(list(out[:3]), part.dL_sets)
             self.last = dict(M=self.last.get("M", 0), T=self.batch.T)
             return
-        out = self.batch.render_sets(p["xyz"], p["scale"], p["rotate"], p["opacity"], sets, self.off_all, self.extr, K=20,
+        out = part.batch.render_sets(p["xyz"], p["scale"], p["rotate"], p["opacity"], sets, part.off_all, self.extr, K=20,
                                      grad_sink={"xyz": g["xyz"], "scales": g["scale"], "uquats": g["rotate"], "opacity": g["opacity"]})
-        torch.autograd.backward(list(out[:3]), self.dL_sets)
+        torch.autograd.backward(list(out[:3]), part.dL_sets)
         self.last = dict(M=self.last.get("M", 0), T=self.batch.T)
 
     # ------------------------------------------------------------------ the reference's real frame (row a1), frame by frame
@@ -349,16 +393,23 @@ class FrameRenderer:
         """the forward pass of all local frames alone (SH colours -> preprocess -> binning -> sort -> compositing), no graph"""
         p = self.p
         with torch.no_grad():
+            if self.halves:      # (the two half-batches one after the other)
+                return [self._forward_only_part(pt) for pt in self.parts]
+            return self._forward_only_part(self.parts[0]) if self.parts else None
+
+    def _forward_only_part(self, part):
+        p = self.p
+        with torch.no_grad():
             if self.mode == "batch":
                 feat = gs.compute_sh(p["shs"], 3, self.dirs) if self.use_sh else p["feature"]
                 if self.dynamic:
                     from splatter_a_video_amd.dynamics import SEGMENT_MAJOR
-                    return self.batch.render_dynamic(self.clock, self.frames, self.extr, feat, position=self.position,
+                    return part.batch.render_dynamic(self.clock, part.frames, self.extr, feat, position=self.position,
                                                      pos_cubic_node=p["pos_cubic_node"], rotation=p["rotation"],
                                                      rot_poly_feat=self.rot_poly, rot_fourier_feat=self.rot_fourier,
                                                      opacity=p["opacity"], scaling=p["scaling"], cubic_layout=SEGMENT_MAJOR,
                                                      bg=self.sc.bg, nearest=0.01)
-                return self.batch.render(p["xyz"], p["scale"], p["rotate"], p["opacity"], feat, self.off_all, self.extr,
+                return part.batch.render(p["xyz"], p["scale"], p["rotate"], p["opacity"], feat, part.off_all, self.extr,
                                          bg=self.sc.bg, nearest=0.01)
             if self.mode == "render_iter":
                 rgb = gs.compute_sh(p["shs"], 3, self.dirs)
@@ -366,11 +417,11 @@ class FrameRenderer:
                         dict(feature=p["attrs"], bg=0.0, detach_opacity=True)]
                 if self.dynamic:
                     from splatter_a_video_amd.dynamics import SEGMENT_MAJOR
-                    return self.batch.render_dynamic_sets(
-                        self.clock, self.frames, self.extr, sets, position=self.position, pos_cubic_node=p["pos_cubic_node"],
+                    return part.batch.render_dynamic_sets(
+                        self.clock, part.frames, self.extr, sets, position=self.position, pos_cubic_node=p["pos_cubic_node"],
                         rotation=p["rotation"], rot_poly_feat=self.rot_poly, rot_fourier_feat=self.rot_fourier,
                         opacity=p["opacity"], scaling=p["scaling"], cubic_layout=SEGMENT_MAJOR, K=20)
-                return self.batch.render_sets(p["xyz"], p["scale"], p["rotate"], p["opacity"], sets, self.off_all, self.extr, K=20)
+                return part.batch.render_sets(p["xyz"], p["scale"], p["rotate"], p["opacity"], sets, part.off_all, self.extr, K=20)
         return None
 
     def scene_stats(self):
@@ -392,6 +443,20 @@ class FrameRenderer:
     def step(self, collective=True):
         """one gradient step: local frames forward+backward, ONE all-reduce of the flat bucket (skipped when no process
         group exists, and in rank 0's private kernel-timing pass), one Adam step; returns when everything is enqueued"""
+        if self.halves:
+            from splatter_a_video_amd.parallel import overlapped_halves_step
+            run = self.frames_batched if self.mode == "batch" else self.frames_render_iter_batched
+            if collective:
+                overlapped_halves_step(self.bucket, lambda: run(self.parts[0]), lambda: run(self.parts[1]), self.opt)
+            else:                 # rank 0's private kernel-timing pass: same launches, no collective
+                for k, pt in enumerate(self.parts):
+                    self.bucket.activate(k)
+                    self.bucket.zero_grad()
+                    run(pt)
+                self.bucket.fold(0, 1)
+                if self.opt is not None:
+                    self.opt.step()
+            return
         self.bucket.swap()        # stale-1 mode: waits for the collective that last used the buffer we switch to
         self.bucket.zero_grad()
         if self.mode == "batch":
@@ -415,8 +480,8 @@ class FrameRenderer:
     def check_sorts(self):
         """after the timed region: every capacity-bounded sort of the run fitted (host sync)"""
         m = 0
-        if self.mode in ("batch", "render_iter"):
-            m = self.batch.check()
+        for pt in self.parts:
+            m = max(m, pt.batch.check())
         for st in self.sort_status:
             m = max(m, st.check())
         self.sort_status.clear()
@@ -431,19 +496,22 @@ class FrameRenderer:
             self.last["M"] = m
 
 
-def kernel_bytes(name, N, M, HW, C, T, use_sh, fpl=1.0, sets=False):
+def kernel_bytes(name, N, M, HW, C, T, use_sh, fpl=1.0, sets=False, nparam=None, sh_acc=True, dyn=False):
     """Algorithmic HBM bytes of ONE LAUNCH that covers ``fpl`` frames (SURVEY.md 8d bookkeeping, per kernel): what the frames
     share (parameters, SH coefficients, gradient accumulators, Adam state) is counted ONCE per launch, per-frame arrays
     (screen-space geometry, pair lists, records, images) once per frame.  ``sets``: the renderer's three feature sets
     (3 + 1 + 19 channels) in one pass."""
     F_in = 192 if use_sh else 0
-    nparam = N * (3 + 3 + 4 + 1 + (48 if use_sh else C))
+    if nparam is None:       # floats of the flat parameter buffer the optimiser streams (callers pass the bucket's real size)
+        nparam = N * (3 + 3 + 4 + 1 + (48 if use_sh else C))
     if sets:
         C = 23
     rec_g = 10 if sets else 8                # gradient floats of a pair record in front of the feature gradients
     shared = {
         "sh_fwd": N * (F_in + 12 + 1 + 12 + 3),
-        "sh_bwd": N * (F_in + 12 + 1 + 3 + 12 + F_in + 12),   # (+F_in read when it accumulates into the bucket)
+        # dirs, visible, clamped, dL_dcolors in; dL_dshs out (+ read when it accumulates into the bucket).  The coefficients
+        # themselves are only read for a direction gradient, which no caller on the path requests.
+        "sh_bwd": N * (12 + 1 + 3 + 12 + F_in * (2 if sh_acc else 1)),
         # static parameters in: xyz, scale, quat
         "preprocess_fwd": N * (12 + 12 + 16),
         # dynamic parameters in (position, rotation + 192 B of tables, opacity, scaling), activated opacity out
@@ -475,7 +543,8 @@ def kernel_bytes(name, N, M, HW, C, T, use_sh, fpl=1.0, sets=False):
         "blend_bwd": M * (28 + 4 * C) + M * (4 * rec_g + 4 * C) + HW * (4 * C + 8),
         # reads the records through the inverse pair map, writes the per-Gaussian gradients
         "pair_reduce": M * (4 + 4 * rec_g + 4 * C) + N * (4 + 4 * rec_g + 4 * C),
-        "gauss_bwd": M * (4 * rec_g + 4 * C) + N * 8,
+        # the records of the frame (+ dynamic Gaussians: the frame's 48-byte spline segment in, its gradient out: DESIGN 4)
+        "gauss_bwd": M * (4 * rec_g + 4 * C) + N * 8 + (N * 88 if dyn else 0),
     }
     return shared.get(name, 0) + fpl * per_frame.get(name, 0)
 
@@ -651,9 +720,53 @@ def main():
         return d
 
     R = FrameRenderer(sc, dev, frames, a.channels, mode=mode, dynamic=a.dynamic, stale_overlap=a.stale_overlap,
-                      optimizer=not a.no_optimizer)
+                      optimizer=not a.no_optimizer, halves=a.overlap)
     dt = timed(R.step, R.finish)
     R.check_sorts()   # the sync-free sorts of the timed steps all fitted their capacity (raises otherwise)
+
+    # N > 1: what the collective costs (every rank takes part; rank 0 reports).  The step is synchronous, so the all-reduce of
+    # the flat bucket is exposed by construction; these figures say how much of the step it is, and what the exact half-batch
+    # overlap (--overlap) makes of it.  Failures here must not cost the line its headline: they are reported in `comm.error`.
+    comm = None
+    if launched and world > 1 and not a.no_comm_analysis and not a.stale_overlap:
+        comm = {"bucket_MB": round(R.flat_grad.numel() * 4 / 1e6, 1), "backend": backend}
+        try:
+            buf = torch.zeros_like(R.flat_grad)
+            for _ in range(2):
+                dist.all_reduce(buf)
+            reps = 10
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dist.all_reduce(buf)
+            sync()
+            tt = torch.tensor([(time.perf_counter() - t0) / reps], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ar = float(tt.item())
+            del buf
+            dt_nc = timed(lambda: R.step(collective=False))
+            step_ms, nc_ms = dt / a.steps * 1e3, dt_nc / a.steps * 1e3
+            nbytes = R.flat_grad.numel() * 4
+            comm.update({"allreduce_ms": round(ar * 1e3, 4), "allreduce_reps": reps,
+                         "allreduce_algbw_GBps": round(nbytes / ar / 1e9, 1),
+                         "allreduce_busbw_GBps": round(nbytes / ar / 1e9 * 2 * (world - 1) / world, 1),
+                         "step_ms": round(step_ms, 3), "step_ms_without_collective": round(nc_ms, 3),
+                         "exposed_comm_frac": round(max(0.0, step_ms - nc_ms) / step_ms, 4),
+                         "mode": "exact half-batch overlap" if R.halves else "synchronous"})
+        except Exception as e:   # noqa: BLE001
+            comm["error"] = repr(e)[:300]
+        if not a.overlap and mode in ("batch", "render_iter") and a.frames >= 2:
+            try:
+                R3 = FrameRenderer(sc, dev, frames, a.channels, mode=mode, dynamic=a.dynamic, optimizer=not a.no_optimizer, halves=True)
+                dt3 = timed(R3.step, R3.finish)
+                R3.check_sorts()
+                comm["overlap_exact"] = {"value": round(a.frames * a.steps * world / dt3, 2), "unit": "frames/s",
+                                         "ms_per_step": round(dt3 / a.steps * 1e3, 3),
+                                         "what": "same step with --overlap: two half-batches, the first half's all-reduce under "
+                                                 "the second half's forward + backward, sums added, one Adam step (exact)"}
+                del R3
+            except Exception as e:   # noqa: BLE001
+                comm["overlap_exact"] = {"error": repr(e)[:300]}
     frames_total = a.frames * a.steps * world
     fps = frames_total / dt
     M, T = R.last["M"], R.last["T"]
@@ -684,7 +797,8 @@ def main():
                     b = sum(kernel_bytes(n, a.gaussians, M, HW, c, T, False, a.frames * 3.0 / cnt) for c in (3, 1, 19)) / 3.0
                 else:
                     b = kernel_bytes(n, a.gaussians, M, HW, R.C, T, R.use_sh, fpl,
-                                     sets=mode.startswith("render_iter") and n.startswith(("blend", "gauss_bwd", "pair_reduce")))
+                                     sets=mode.startswith("render_iter") and n.startswith(("blend", "gauss_bwd", "pair_reduce")),
+                                     nparam=R.flat_grad.numel(), sh_acc=mode in ("batch", "frame", "render_iter"), dyn=R.dynamic)
                 kernels[n] = {"avg_us": round(avg * 1e3, 2), "launches": cnt, "frames_per_launch": round(fpl, 2),
                               "us_per_frame": round(ms * 1e3 / a.frames, 2), "alg_MB_per_launch": round(b / 1e6, 2),
                               "GBps": round(b / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
@@ -692,12 +806,10 @@ def main():
             dom = max(kernels, key=lambda k: kernels[k]["us_per_frame"])
             ach = kernels[dom]["GBps"]
             traffic, tsrc = pmc_traffic(dom, tag_cfg)
-            roofline = {"kernel": dom,
-                        # `achieved` / `peak` / `frac` price the kernel's ALGORITHMIC bytes against HBM as the measurement
-                        # contract asks ("bound" names that pricing basis); what actually limits the compositing kernels is
-                        # instruction issue (`limited_by`, `issue`, and `compute` below), not bandwidth
-                        "bound": "hbm", "limited_by": "valu+mfma issue" if dom.startswith("blend") else "hbm",
-                        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # HBM pricing of the dominant kernel (SURVEY 8d's algorithmic bytes); for a compositing kernel -- bound by FP32
+            # issue, not by bandwidth -- the line's primary roofline becomes the FP32 pipe once the scene statistics are known
+            # (below), and this pricing stays beside it as `hbm`
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                         "issue": pmc_issue(dom, tag_cfg),
                         "avg_us": kernels[dom]["avg_us"], "frames_per_launch": kernels[dom]["frames_per_launch"],
@@ -721,7 +833,22 @@ def main():
     if stats is not None:
         stats["scene"] = a.scene
     if roofline is not None and stats is not None:
-        roofline["compute"] = compute_rates(stats, kernels)
+        comp = compute_rates(stats, kernels)
+        roofline["compute"] = comp
+        dom = roofline["kernel"]
+        if dom in comp:
+            # The compositing kernels are bound by FP32 instruction issue: their f32 MFMAs run on the same FP32 lanes as the
+            # VALU (157.3 TFLOP/s is both the dense f32 MFMA peak and the packed-FP32 vector peak), HBM sits at a
+            # tenth of its peak.  `achieved` = the reference's arithmetic over the list entries the pixels walk (a LOWER bound
+            # of the useful flops: 16 per visited (pixel, entry) pair forward, 14 backward) per launch / the launch's duration.
+            roofline["hbm"] = {k: roofline[k] for k in ("achieved", "peak", "unit", "frac", "alg_bytes_per_launch")}
+            roofline.update({"bound": "mfma", "achieved": comp[dom]["TFLOPs_lower_bound"], "peak": comp["peak_TFLOPs"],
+                             "unit": "TFLOP/s", "frac": comp[dom]["frac_of_fp32_peak"],
+                             "alg_flops_per_launch": int(comp["evaluations_per_frame"] * (16.0 if dom == "blend_fwd" else 14.0)
+                                                         * roofline["frames_per_launch"]),
+                             "what": "FP32 pipe (f32 MFMA + VALU share it): walked (pixel, list entry) pairs x the reference's "
+                                     "flops per visit, per launch / launch duration, against the dense f32 MFMA peak; `hbm` = the "
+                                     "same launch's algorithmic bytes against the HBM peak"})
 
     # second workload of the line (N = 1, default configuration only): the reference's REAL training frame -- its dynamic
     # Gaussians (time-varying position and rotation) through render_iter's three blends (rgb enhanced K = 20 + depth + 19
@@ -752,6 +879,8 @@ def main():
 
     if rank == 0:
         par = f"frame-sharded dp{world}, " + ("stale-1: all-reduce overlapped with the next step, no optimiser" if R.overlap else
+                                              "exact overlap: two half-batches, all-reduce of half 1 under half 2, sum -> Adam -> next forward"
+                                              if R.halves else
                                               "synchronous: all-reduce -> Adam -> next forward" if R.opt is not None else
                                               "synchronous all-reduce, no optimiser")
         line = {
@@ -759,7 +888,10 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "ranks_seen": ranks_seen,
+            "ranks_seen": ranks_seen, "build_id": L.build_id(),
+            "allreduce_ms": None if not comm else comm.get("allreduce_ms"),
+            "exposed_comm_frac": None if not comm else comm.get("exposed_comm_frac"),
+            "comm": comm,
             "config": {"workload": (f"{a.gaussians} dynamic Gaussians of the reference's model (spline position, time-varying rotation)"
                                     if R.dynamic else
                                     f"{a.gaussians} Gaussians moving by per-frame position offsets (SURVEY 8d generator: static "

@@ -42,6 +42,20 @@ typedef void *splat_stream_t; /* hipStream_t */
 const char *splat_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int splat_abi_version(void);
+/* Hash (16 hex digits) of the sources this binary was built from (csrc/Makefile); "unstamped" for a build outside the
+   Makefile.  Measurement records under profiles/ carry it; bench.py only quotes PMC constants taken from the same build. */
+const char *splat_build_id(void);
+/* Deterministic mode (process-wide; the reference has none -- its backward is all float atomics, src/alpha_blending.cu:
+   229-246): when on, no backward this library launches uses float atomics, so identical inputs give bit-identical
+   gradients run to run.  The frame-batch entry points and the per-frame operators on this library's own sort (pair
+   records) are deterministic with the flag off as well (tests/test_gpu_determinism.py); the flag makes the block-level
+   matrix-core kernel (carried survivors: <= 15 atomic record adds per wave and super-batch) give way to the DPP pair
+   kernel and makes splat_alpha_blending_backward without a pair map (foreign idx_sorted: atomic kernel) return
+   SPLAT_E_ARG.  Camera gradients of project_point (one atomic per wave) stay outside the guarantee. */
+void splat_set_deterministic(int on);
+int splat_get_deterministic(void);
+/* dst[0 .. n) = value on `stream` (gradient-bucket zeroing without a framework fill kernel). */
+int splat_fill_f32(float *dst, size_t n, float value, splat_stream_t stream);
 
 /* ---- project_point : replaces projectPointsForward/Backward (src/project_point.cu:147-227) ---- */
 /* uv, depth: fully written. */

@@ -17,11 +17,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "splat_last_error", "splat_abi_version",
+    "splat_last_error", "splat_abi_version", "splat_build_id", "splat_set_deterministic", "splat_get_deterministic",
+    "splat_fill_f32",
     "splat_project_point_forward", "splat_project_point_backward",
     "splat_compute_cov3d_forward", "splat_compute_cov3d_backward",
     "splat_ewa_project_forward", "splat_ewa_project_backward",
@@ -73,6 +74,11 @@ def lib() -> ctypes.CDLL:
         L = ctypes.CDLL(LIB_PATH)
         L.splat_last_error.restype = ctypes.c_char_p
         L.splat_abi_version.restype = ctypes.c_int
+        L.splat_build_id.restype = ctypes.c_char_p
+        L.splat_set_deterministic.argtypes = [ctypes.c_int]
+        L.splat_set_deterministic.restype = None
+        L.splat_get_deterministic.restype = ctypes.c_int
+        L.splat_fill_f32.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_float, ctypes.c_void_p]
         L.splat_bin_scratch_bytes.restype = ctypes.c_size_t
         L.splat_bin_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.splat_knn_plan_bytes.restype = ctypes.c_size_t
@@ -140,6 +146,21 @@ def need(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
         else:
             raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
     return t.contiguous()
+
+
+def build_id() -> str:
+    """hash of the sources the loaded library was built from (csrc/Makefile); measurement records carry it"""
+    return lib().splat_build_id().decode()
+
+
+def set_deterministic(on: bool) -> None:
+    """process-wide deterministic mode (include/splat_hip.h: splat_set_deterministic): no backward launches a kernel with
+    float atomics; a foreign idx_sorted (atomic backward) raises"""
+    lib().splat_set_deterministic(1 if on else 0)
+
+
+def deterministic() -> bool:
+    return bool(lib().splat_get_deterministic())
 
 
 def profile_enable(on: bool) -> None:

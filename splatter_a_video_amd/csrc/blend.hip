@@ -3929,13 +3929,18 @@ static int launch_bwd_ab(const BlendArgs &A, int T, bool pair, hipStream_t s) {
         constexpr int WC = CH >= 16 ? CH : 16;
         if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_wide_quarter_kernel<WC, true>), grid, block, 0, s, A);
         else SPLAT_LAUNCH("blend_bwd", (blend_bwd_wide_quarter_kernel<WC, false>), grid, block, 0, s, A);
-    } else if (pair && !BIAS && bwd_use_mfma()) {
+    } else if (pair && !BIAS && bwd_use_mfma() && !(BLEND_CARRY && splat_deterministic())) {
         if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_mfma_kernel<CH, ABS, true>), grid, block, 0, s, A);
         else SPLAT_LAUNCH("blend_bwd", (blend_bwd_mfma_kernel<CH, ABS, false>), grid, block, 0, s, A);
     } else if (pair) {
         if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_pair_kernel<CH, ABS, BIAS, true>), grid, block, 0, s, A);
         else SPLAT_LAUNCH("blend_bwd", (blend_bwd_pair_kernel<CH, ABS, BIAS, false>), grid, block, 0, s, A);
     } else {
+        if (splat_deterministic()) {
+            splat_set_error("deterministic mode: the backward needs this library's pair map (goff_incl, slot_sorted, pair_scratch); "
+                            "a foreign idx_sorted would take the float-atomic kernel");
+            return SPLAT_E_ARG;
+        }
         if (exact) SPLAT_LAUNCH("blend_bwd", (blend_bwd_atomic_kernel<CH, ABS, BIAS, true>), grid, block, 0, s, A);
         else SPLAT_LAUNCH("blend_bwd", (blend_bwd_atomic_kernel<CH, ABS, BIAS, false>), grid, block, 0, s, A);
     }

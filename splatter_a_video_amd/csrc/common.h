@@ -31,6 +31,8 @@ void splat_set_error(const char *fmt, ...);
         }                                                                              \
     } while (0)
 
+bool splat_deterministic();   // splat_set_deterministic (runtime.hip)
+
 // ---------------------------------------------------------------- profiled launches
 // When splat_profile_enable(1) was called, every kernel launch is bracketed by two hipEvents
 // recorded on the launch stream; splat_profile_read() sums them per kernel-name prefix.

@@ -43,11 +43,17 @@ extern "C" int splat_frames_count(const splat_frames_t *b) {
 extern "C" int splat_frames_backward(const splat_frames_t *b) {
     SPLAT_CHECK_ARG(b != nullptr && b->struct_bytes == sizeof(splat_frames_t), "splat_frames_t of another ABI version");
     SPLAT_CHECK_ARG(b->dL_dout && b->pair_records, "null pointer");
+    // everything the second launch sequence validates is checked BEFORE the tile kernels run: a bad struct must not leave
+    // half a backward behind (pair records overwritten, no gradients)
+    SPLAT_CHECK_ARG(b->d_opacity && b->d_feature, "null gradient pointer");
+    SPLAT_CHECK_ARG(b->d_xyz && b->d_scales && b->d_uquats, "null gradient pointer");
+    SPLAT_CHECK_ARG(b->xyz && b->scales && b->uquats && b->extr && b->goff_incl && b->radius, "null pointer");
+    SPLAT_CHECK_ARG(!b->perspective || b->intr, "the pinhole camera needs intr");
+    SPLAT_CHECK_ARG(b->F == 1 || b->offsets || b->extr_frame_stride != 0, "several frames need per-frame offsets or cameras");
     int rc = splat_alpha_blending_backward_batch(b->F, b->P, b->C, b->idx_sorted, b->tile_range, b->capacity, b->bg, b->W, b->H,
                                                  b->final_T, b->ncontrib, b->dL_dout, b->want_abs, b->slot_sorted,
                                                  b->pair_records, b->pack, b->cull_flags, b->dbg_T_front, b->stream);
     if (rc != SPLAT_OK) return rc;
-    SPLAT_CHECK_ARG(b->d_opacity && b->d_feature, "null gradient pointer");
     const splat_camera_t cam = batch_camera(b);
     return splat_frames_gauss_backward_static_cam(b->F, b->P, b->C, b->W, b->H, b->capacity, b->want_abs, b->pair_records,
                                                   b->goff_incl, b->radius, b->xyz, b->scales, b->uquats, &cam, b->accumulate,

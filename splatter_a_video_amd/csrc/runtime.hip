@@ -18,7 +18,24 @@ void splat_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *splat_last_error(void) { return g_err; }
-extern "C" int splat_abi_version(void) { return 17; }
+extern "C" int splat_abi_version(void) { return 18; }
+
+#ifndef SPLAT_BUILD_ID
+#define SPLAT_BUILD_ID "unstamped"
+#endif
+// hash of the sources this binary was built from (csrc/Makefile): measurement records carry it, bench.py refuses PMC
+// constants taken from another build
+extern "C" const char *splat_build_id(void) { return SPLAT_BUILD_ID; }
+
+// Deterministic mode: every kernel this library launches for a backward is free of float atomics, so two runs
+// on the same inputs give bit-identical gradients.  The frame-batch path and the per-frame operators on this package's own
+// sort (pair records + quarter lists from the forward's cull words) are deterministic already; the flag closes the
+// remaining doors: the block-level matrix-core kernel (its carried survivors add with atomics) gives way to the DPP pair
+// kernel, and a foreign idx_sorted (atomic backward) is refused.
+static int g_deterministic = 0;
+extern "C" void splat_set_deterministic(int on) { g_deterministic = on != 0; }
+extern "C" int splat_get_deterministic(void) { return g_deterministic; }
+bool splat_deterministic() { return g_deterministic != 0; }
 
 namespace {
 struct Pending {

@@ -53,6 +53,19 @@ class _SplatCamera(ctypes.Structure):
                 ("extr", ctypes.c_void_p), ("extr_frame_stride", ctypes.c_int64), ("offsets", ctypes.c_void_p)]
 
 
+def _versions(*tensors):
+    """(tensor, autograd version) of the camera / offset tensors a backward re-reads WITHOUT save_for_backward (they are
+    passed as raw pointers): an in-place edit between forward and backward would silently change the gradients"""
+    return tuple((t, t._version) for t in tensors if t is not None)
+
+
+def _check_versions(saved, what: str) -> None:
+    for t, v in saved:
+        if t._version != v:
+            raise RuntimeError(f"FrameBatch: {what} was modified in place between the forward and its backward (the backward "
+                               "re-projects under the forward's cameras / offsets); clone it before editing")
+
+
 class _Camera:
     """Camera of a batch: ``extr`` one world-to-camera matrix ([4,4] / [3,4]) or one per frame ([F,4,4] / [F,3,4] -- the
     reference's render_batch gives every batch element its own, dptr_ortho_enhanced.py:409-411); ``intr`` None: the
@@ -104,7 +117,8 @@ class FrameBatch:
     feature channels (C <= 32).  ``capacity`` = tile-Gaussian pairs reserved per frame; None: measured on the first call
     (one host sync), afterwards the batch runs without any host synchronisation and ``check()`` (call it whenever the
     host synchronises anyway, e.g. once per optimiser step) raises if a frame outgrew it; without ``check()`` the next
-    forward raises, one step late (the flag travels to pinned host memory behind the binning kernels)."""
+    forward raises, a step or a few late (the flag travels to pinned host memory behind the binning kernels; the error is
+    raised once and the flag cleared, so batches that fit keep running afterwards)."""
 
     def __init__(self, F: int, P: int, W: int, H: int, C: int, device, capacity: Optional[int] = None,
                  want_abs: bool = False, slack: float = 1.25):
@@ -171,6 +185,8 @@ class FrameBatch:
         largest per-frame pair count"""
         m = int(self.pairs.max().item())
         if self.capacity is not None and m > self.capacity:
+            self.overflow.zero_()                   # reported here: the sticky flag must not fail the next batch again
+            self._ovf_event = None
             raise L.SplatError(f"FrameBatch: {m} tile-Gaussian pairs in one frame exceed the capacity {self.capacity}")
         return m
 
@@ -180,24 +196,38 @@ class FrameBatch:
         return self.generation
 
     def _note_overflow(self) -> None:
-        """behind the binning kernels of a forward: the overflow flag travels to pinned host memory asynchronously"""
+        """behind the binning kernels of a forward: the overflow flag travels to pinned host memory asynchronously.  The
+        device flag is sticky (bin_scatter only ever sets it), so ONE copy in flight is enough: while an earlier copy has not
+        completed no new one is enqueued -- a host that runs ahead of the GPU still polls an event that WILL complete (replacing
+        the pending event on every forward left it polling events that never had)."""
+        ev = getattr(self, "_ovf_event", None)
+        if ev is not None and not ev.query():
+            return                                  # the copy in flight is older than this batch; the next one sees its flag
+        if ev is not None:
+            self._read_overflow()                   # a completed copy nobody polled yet
         if getattr(self, "_ovf_host", None) is None:
             self._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._ovf_host.copy_(self.overflow, non_blocking=True)
         self._ovf_event = torch.cuda.Event()
         self._ovf_event.record()
 
+    def _read_overflow(self) -> None:
+        """the completed host copy of the flag: raise once, then clear the device flag so that later batches that fit run
+        again (a caller may catch the error, e.g. to rebuild with more slack)"""
+        self._ovf_event = None
+        if int(self._ovf_host[0]) != 0:
+            self._ovf_host[0] = 0
+            self.overflow.zero_()                   # stream-ordered behind the kernels that set it
+            raise L.SplatError(f"FrameBatch: an earlier batch held more tile-Gaussian pairs in one frame than the capacity "
+                               f"{self.capacity} (its surplus pairs were dropped: that batch's images and gradients were "
+                               "incomplete); build the batch with a larger `capacity` / `slack`")
+
     def _poll_overflow(self) -> None:
-        """at the next forward, without a host synchronisation: raises if an earlier batch outgrew the capacity (its surplus
-        pairs were dropped: that batch's images and gradients were incomplete) -- a caller that never calls check() still learns
-        of it one step late instead of never"""
+        """at the next forward, without a host synchronisation: raises if an earlier batch outgrew the capacity -- a caller
+        that never calls check() still learns of it a few steps late instead of never"""
         ev = getattr(self, "_ovf_event", None)
         if ev is not None and ev.query():
-            self._ovf_event = None
-            if int(self._ovf_host[0]) != 0:
-                raise L.SplatError(f"FrameBatch: an earlier batch held more tile-Gaussian pairs in one frame than the capacity "
-                                   f"{self.capacity} (its surplus pairs were dropped); build the batch with a larger `capacity` / "
-                                   "`slack`")
+            self._read_overflow()
 
     def _check_generation(self, gen: int) -> None:
         if gen != self.generation:
@@ -735,6 +765,7 @@ class _RenderSets(torch.autograd.Function):
         out, gs_idx, ctx.blend = _blend_sets_forward(fb, meta, feats, opacity, op_fs, K)
         ctx.fb, ctx.meta, ctx.sink, ctx.K = fb, meta, sink, K
         ctx.cam, ctx.off = cam, off
+        ctx.cam_versions = _versions(cam.extr, cam.intr, off)
         ctx.save_for_backward(xyz, scales, uquats, opacity, *feats)
         ctx.set_materialize_grads(False)
         imgs, c0 = [], 0
@@ -753,6 +784,7 @@ class _RenderSets(torch.autograd.Function):
         fb._check_generation(ctx.gen)
         xyz, scales, uquats, opacity = ctx.saved_tensors[:4]
         feats = ctx.saved_tensors[4:]
+        _check_versions(ctx.cam_versions, "a camera / offset tensor")
         camc = ctx.cam.struct(ctx.off)
         meta, sink = ctx.meta, (ctx.sink or {})
         lib, st = L.lib(), L.stream()
@@ -854,6 +886,7 @@ class _RenderFrames(torch.autograd.Function):
         out = fb._forward_onecall(xyz, scales, uquats, opacity, feature, off, cam, bg, nearest, extent)
         ctx.fb, ctx.bg, ctx.sink = fb, bg, sink
         ctx.cam, ctx.off = cam, off
+        ctx.cam_versions = _versions(cam.extr, cam.intr, off)
         ctx.save_for_backward(xyz, scales, uquats, opacity, feature)
         return out
 
@@ -862,6 +895,7 @@ class _RenderFrames(torch.autograd.Function):
         fb: FrameBatch = ctx.fb
         fb._check_generation(ctx.gen)
         xyz, scales, uquats, opacity, feature = ctx.saved_tensors
+        _check_versions(ctx.cam_versions, "a camera / offset tensor")
         g = L.need(dL_dout, "dL_dout")
         sink = ctx.sink or {}
         like = {"xyz": xyz, "scales": scales, "uquats": uquats, "opacity": opacity, "feature": feature}

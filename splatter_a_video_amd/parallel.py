@@ -78,7 +78,22 @@ class FlatGradBucket:
         self._point_grads()
 
     def zero_grad(self) -> None:
-        self.flat_grad.zero_()
+        """the active gradient buffer := 0.  On the GPU one float4 fill launch of the library (splat_fill_f32) on the current
+        stream; the CPU buffers of the gloo tests use the framework's."""
+        g = self.flat_grad
+        if g.is_cuda:
+            import ctypes
+
+            from . import _lib as L
+            L.check(L.lib().splat_fill_f32(L.ptr(g), ctypes.c_size_t(g.numel()), L.cf(0.0), L.stream()))
+        else:
+            g.zero_()
+
+    def activate(self, buffer: int) -> None:
+        """make ``buffer`` the active gradient buffer (after its last collective has finished)"""
+        self.wait(buffer)
+        self.active = buffer
+        self._point_grads()
 
     def all_reduce(self, average: bool = False, async_op: bool = False) -> None:
         """One collective per step over the active buffer; a no-op for a single process.  ``async_op``: return at once,
@@ -90,6 +105,12 @@ class FlatGradBucket:
                 self.pending[self.active] = (work, average)
             elif average:
                 flat.div_(dist.get_world_size())
+
+    def fold(self, src: int, dst: int) -> None:
+        """flat_grads[dst] += flat_grads[src] (both reductions finished): the two half-batch sums of overlapped_halves_step"""
+        self.wait(src)
+        self.wait(dst)
+        self.flat_grads[dst].add_(self.flat_grads[src])
 
     def wait(self, buffer: int = None) -> None:
         """finish the outstanding collective of ``buffer`` (default: all buffers)"""
@@ -132,6 +153,32 @@ def reduce_densify_batch(viewspace_grad: torch.Tensor, visibility: torch.Tensor,
     dist.all_reduce(v, op=dist.ReduceOp.MAX)
     visibility.copy_(v.to(visibility.dtype))
     dist.all_reduce(radii, op=dist.ReduceOp.MAX)
+
+
+def overlapped_halves_step(bucket: FlatGradBucket, first_half, second_half, optimizer=None, average: bool = False) -> None:
+    """One gradient step with HALF of the all-reduce hidden and the SAME result as ``sharded_step`` (to fp32 summation
+    order): the rank's frames are split into two half-batches with a gradient buffer each (``FlatGradBucket(buffers=2)``);
+    the first half's buffer is all-reduced asynchronously (RCCL's own stream) UNDER the second half's forward + backward,
+    the second half's buffer synchronously behind it, the two sums are added and the optimiser steps once.  Nothing is
+    stale: the parameters change only after both halves' gradients have been reduced.  ``first_half`` / ``second_half``
+    render their frames forward + backward into the bucket's ACTIVE buffer (``bucket.grad(name)`` / ``.grad`` of the
+    parameters at call time).  What stays exposed is the second half's collective (half of the bytes when the link is
+    bandwidth bound) -- every gradient of a frame-sharded step completes in its last kernels, so a full-size bucket
+    cannot be hidden without staleness."""
+    if len(bucket.flat_grads) < 2:
+        raise ValueError("overlapped_halves_step needs FlatGradBucket(buffers=2)")
+    bucket.activate(0)
+    bucket.zero_grad()
+    first_half()
+    bucket.all_reduce(async_op=True)
+    bucket.activate(1)
+    bucket.zero_grad()
+    second_half()
+    bucket.all_reduce(async_op=False)
+    bucket.fold(0, 1)                     # waits for the first half's collective; the sum sits in the active buffer
+    if optimizer is not None:
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        optimizer.step(grad_scale=(1.0 / world) if average else 1.0)
 
 
 def sharded_step(bucket: FlatGradBucket, frames: Iterable[int], render_and_backward, optimizer=None,

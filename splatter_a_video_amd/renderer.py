@@ -117,8 +117,23 @@ class PerspRenderer:
     run as ONE fused launch per direction (``gs.preprocess_persp``).  Cameras are not differentiated here (the reference
     renderer does not optimise them either); its own class keeps working unchanged through the ``dptr`` shim."""
 
-    def __init__(self, white_bg: bool = False):
+    def __init__(self, white_bg: bool = False, max_sh_degree: int = 3, update_sh_iter: int = 1000):
         self.bg_color = 1.0 if white_bg else 0.0
+        # the trainer's hooks on a renderer (default_trainer: renderer.update_sh_degree(iteration) every step,
+        # renderer.state_dict() / load_state_dict() in checkpoints; dptr.py:42-56, :218-228)
+        self.max_sh_degree, self.update_sh_iter = int(max_sh_degree), int(update_sh_iter)
+        self.active_sh_degree = 0
+
+    def update_sh_degree(self, step: int) -> None:
+        """one more SH band every ``update_sh_iter`` steps up to ``max_sh_degree`` (dptr.py:218-221)"""
+        if step % self.update_sh_iter == 0 and self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    def state_dict(self) -> dict:
+        return {"active_sh_degree": self.active_sh_degree}
+
+    def load_state_dict(self, state_dict: dict) -> None:
+        self.active_sh_degree = int(state_dict["active_sh_degree"])
 
     def render_iter(self, FovX, FovY, height, width, extrinsic_matrix: Tensor, intrinsic_matrix: Tensor, camera_center: Tensor,
                     position: Tensor, opacity: Tensor, scaling: Tensor, rotation: Tensor, shs: Tensor,
@@ -126,7 +141,7 @@ class PerspRenderer:
         W, H = int(width), int(height)
         direction = position - camera_center.reshape(1, 3).to(position.device)
         direction = direction / direction.norm(dim=1, keepdim=True)
-        rgb = gs.compute_sh(shs, 3, direction)
+        rgb = gs.compute_sh(shs, 3, direction)      # dptr.py:107 evaluates degree 3 whatever active_sh_degree says; kept
         uv, depth, conic, radius, tiles = gs.preprocess_persp(position, scaling, rotation, intrinsic_matrix, extrinsic_matrix, W, H,
                                                               nearest=0.01)     # dptr.py:107-147 in one launch
         idx_sorted, tile_range = gs.sort_gaussian(uv, depth, W, H, radius, tiles)

@@ -23,11 +23,12 @@ def _free_port():
     return p
 
 
-def _run(frames, steps=2):
+def _run(frames, steps=2, halves=False):
     import bench
     from splatter_a_video_amd.synth import make_scene
     sc = make_scene(N, W, H, F=12, seed=77)
-    R = bench.FrameRenderer(sc, torch.device("cuda:0"), frames, mode="batch")
+    R = bench.FrameRenderer(sc, torch.device("cuda:0"), frames, mode="batch", halves=halves)
+    assert R.halves == halves
     R.opt.set_lr(1e-3)              # a visible update: step 2's forward must see step 1's parameters
     grads = []
     for _ in range(steps):
@@ -38,14 +39,14 @@ def _run(frames, steps=2):
     return grads, R.bucket.flat_param.detach().clone()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, halves=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        grads, param = _run([f for f in range(FRAMES) if f % world == rank])
+        grads, param = _run([f for f in range(FRAMES) if f % world == rank], halves=halves)
         torch.save({"grads": [g.cpu() for g in grads], "param": param.cpu()}, out + f".{rank}")
     finally:
         dist.destroy_process_group()
@@ -72,6 +73,24 @@ def test_two_ranks_on_one_device_match_single_process(tmp_path):
     assert float(g1.abs().max()) > 0
 
 
+@pytest.mark.timeout(600)
+def test_two_ranks_exact_overlap_equals_the_synchronous_step(tmp_path):
+    """--overlap (parallel.overlapped_halves_step through the bench's step): each rank's 3 frames as half-batches of 2 + 1,
+    half 1's all-reduce (async, second buffer) under half 2's forward + backward -- same reduced gradient and parameters as
+    the single-process synchronous step, replicas bit-identical"""
+    out = str(tmp_path / "ov")
+    mp.spawn(_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["param"], r1["param"])
+    grads, param = _run(list(range(FRAMES)))
+    for s, (g2, g1) in enumerate(zip(r0["grads"], grads)):
+        g1 = g1.cpu()
+        assert torch.allclose(g2, g1, rtol=2e-4, atol=2e-6 * float(g1.abs().max())), f"step {s}"
+    d = (r0["param"] - param.cpu()).abs()
+    assert float(d.max()) <= 2.1 * 1e-3 * 2          # (Adam: sign of rounding-noise gradients, see above)
+    assert float(d.median()) < 1e-6 and float((d > 1e-5).float().mean()) < 0.02
+
+
 @pytest.mark.timeout(900)
 def test_bench_gpus_2_launches_and_reports_two_ranks():
     """`python bench.py --gpus 2` with no torchrun environment starts two ranks itself (gloo: both share this box's GPU;
@@ -93,4 +112,13 @@ def test_bench_gpus_2_launches_and_reports_two_ranks():
         lines[n] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert lines[2]["n_gpus"] == 2 and lines[2]["ranks_seen"] == 2
     assert lines[1]["n_gpus"] == 1 and lines[1]["ranks_seen"] == 1
+    # the collective's cost is in the line: the bucket's all-reduce alone, the step without it, the
+    # exposed fraction, and the exact half-batch overlap variant measured beside the synchronous step
+    c = lines[2]["comm"]
+    assert "error" not in c, c
+    assert lines[2]["allreduce_ms"] == c["allreduce_ms"] > 0 and c["step_ms_without_collective"] > 0
+    assert 0.0 <= lines[2]["exposed_comm_frac"] <= 1.0
+    assert c["overlap_exact"]["value"] > 0, c
+    assert lines[1]["comm"] is None and lines[1]["allreduce_ms"] is None
+    assert len(lines[1]["build_id"]) == 16
     assert lines[2]["config"]["frames_per_rank_per_step"] == 3 and lines[2]["value"] > 0

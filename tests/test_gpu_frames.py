@@ -165,9 +165,49 @@ def test_batch_capacity_overflow_is_flagged_and_safe():
     assert torch.isfinite(out).all() and torch.isfinite(p["xyz"].grad).all()
     with pytest.raises(SplatError):
         B.check()
-    # ... and a caller that never calls check() learns of it at the next forward (no host synchronisation of its own)
-    with pytest.raises(SplatError):
-        B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], off, _t(sc.extr))
+    # check() reported it and cleared the sticky flag.  A caller that never calls check() learns of an overflow at a later
+    # forward without a host synchronisation of its own -- also when the host runs ahead of the GPU (the pending
+    # event used to be replaced on every forward, so a loop without host syncs polled events that had never completed)
+    render = lambda q=p: B.render(q["xyz"], q["scales"], q["uquats"], q["opacity"], q["feature"], off, _t(sc.extr))
+    with torch.no_grad():
+        for _ in range(3):
+            render()                 # overflows again, three times, no host sync in between
+        torch.cuda.synchronize()
+        with pytest.raises(SplatError):
+            render()
+        # ... raised once; the flag is cleared: a batch that fits runs again on the same object
+        few = p["xyz"].detach().clone()
+        few[300:, 2] = -1.0          # behind the near plane: 300 Gaussians (~1200 pairs) stay
+        small = dict(p, xyz=few)
+        out = render(small)
+        torch.cuda.synchronize()
+        render(small)                # (the forward that polls the copy taken behind the fitting batch)
+        torch.cuda.synchronize()
+        render(small)
+        assert B.check() <= 2000 and torch.isfinite(out).all()
+
+
+def test_backward_refuses_cameras_or_offsets_edited_in_place():
+    """the Gaussian-side backward re-projects xyz + offsets[f] under extr[f] from raw pointers -- an in-place edit
+    between forward and backward must raise like autograd's own version check, not silently change the gradients"""
+    N, W, H, F, C = 3000, 96, 64, 2, 3
+    sc = make_scene(N, W, H, seed=4)
+    off = _t(_offsets(sc, F))
+    p = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity,
+                                         feature=np.ones((N, C), np.float32)).items()}
+    B = FrameBatch(F, N, W, H, C, "cuda")
+    extr = _t(sc.extr).unsqueeze(0).repeat(F, 1, 1).contiguous()
+    out = B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], off, extr)
+    off.mul_(1.5)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        out.sum().backward()
+    out = B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], off, extr)
+    extr[1, 0, 3] += 0.01
+    with pytest.raises(RuntimeError, match="modified in place"):
+        out.sum().backward()
+    out = B.render(p["xyz"], p["scales"], p["uquats"], p["opacity"], p["feature"], off, extr)
+    out.sum().backward()
+    assert torch.isfinite(p["xyz"].grad).all()
 
 
 @pytest.mark.parametrize("one_pass", ["1", "0"])

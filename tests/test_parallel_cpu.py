@@ -11,8 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from splatter_a_video_amd.parallel import (FlatGradBucket, frames_of_rank, reduce_densify_batch, reduce_visibility,
-                                            sharded_step)
+from splatter_a_video_amd.parallel import (FlatGradBucket, frames_of_rank, overlapped_halves_step, reduce_densify_batch,
+                                            reduce_visibility, sharded_step)
 
 
 def _free_port():
@@ -183,6 +183,57 @@ def test_two_rank_synchronous_steps_match_single_process(tmp_path):
     for step in range(3):
         sharded_step(ref, list(range(6 * step, 6 * step + 6)), lambda f: _toy_render(ref.params, f).backward(), optimizer=opt)
     torch.testing.assert_close(p0, ref.flat_param.detach(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ exact overlap: two half-batches, all-reduce of half 1 under half 2
+def _worker_halves(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = FlatGradBucket(_params(), buffers=2)
+        opt = _TorchFlatAdam(b, 1e-2)
+        grads = []
+        for step in range(3):
+            mine = frames_of_rank(list(range(6 * step, 6 * step + 6)), rank, world)      # 3 frames: halves of 2 + 1
+            render = lambda fs: [_toy_render(b.params, f).backward() for f in fs]
+            overlapped_halves_step(b, lambda: render(mine[:2]), lambda: render(mine[2:]), optimizer=opt)
+            assert b.pending == [None, None]            # nothing outstanding when the optimiser has stepped
+            grads.append(b.flat_grad.clone())
+        torch.save({"param": b.flat_param.detach().clone(), "grads": grads}, out + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_overlapped_halves_equal_the_synchronous_step(tmp_path):
+    """the exact overlap mode -- half 1's gradients are all-reduced (async, second flat buffer) under half
+    2's forward + backward, the sums are added, Adam steps once -- leaves the parameters of the synchronous step (to fp32
+    summation order: 2e-6 of the maximum), on both ranks bit-identically, over several steps"""
+    out = str(tmp_path / "h")
+    mp.spawn(_worker_halves, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["param"], r1["param"])
+    ref = FlatGradBucket(_params())
+    opt = _TorchFlatAdam(ref, 1e-2)
+    for step in range(3):
+        sharded_step(ref, list(range(6 * step, 6 * step + 6)), lambda f: _toy_render(ref.params, f).backward(), optimizer=opt)
+        g = ref.flat_grad
+        assert float((r0["grads"][step] - g).abs().max()) <= 2e-6 * float(g.abs().max())
+    p = ref.flat_param.detach()
+    assert float((r0["param"] - p).abs().max()) <= 2e-6 * float(p.abs().max())
+
+
+def test_overlapped_halves_need_two_buffers_and_work_without_a_process_group():
+    b1 = FlatGradBucket(_params())
+    with pytest.raises(ValueError, match="buffers=2"):
+        overlapped_halves_step(b1, lambda: None, lambda: None)
+    b = FlatGradBucket(_params(), buffers=2)
+    overlapped_halves_step(b, lambda: _toy_render(b.params, 0).backward(), lambda: _toy_render(b.params, 1).backward())
+    ref = FlatGradBucket(_params())
+    sharded_step(ref, [0, 1], lambda f: _toy_render(ref.params, f).backward())
+    torch.testing.assert_close(b.flat_grad, ref.flat_grad)
+    assert b.active == 1
 
 
 # ------------------------------------------------------------------ densification decisions are rank-deterministic

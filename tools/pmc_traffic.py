@@ -7,9 +7,15 @@ usage: python tools/pmc_traffic.py <read_pass_dir> <write_pass_dir> <out.json> "
 import csv
 import glob
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from stamp import stamp  # noqa: E402
+
+FULL = {}   # short kernel name -> the full (template) name of its largest launches
 
 
 def load(d):
@@ -21,6 +27,9 @@ def load(d):
             m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
             if m:
                 rows.append((m.group(1), int(r.get("Grid_Size", 0) or 0), r["Counter_Name"], float(r["Counter_Value"])))
+                g = int(r.get("Grid_Size", 0) or 0)
+                if g >= FULL.get(m.group(1), (0, ""))[0]:
+                    FULL[m.group(1)] = (g, re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")))
     big = defaultdict(int)
     for k, g, _, _ in rows:
         big[k] = max(big[k], g)
@@ -33,12 +42,13 @@ def load(d):
 
 
 rd, wr = load(sys.argv[1]), load(sys.argv[2])
-out = {"source": sys.argv[4], "config": sys.argv[5] if len(sys.argv) > 5 else None, "kernels": {}}
+out = dict(stamp(), source=sys.argv[4], config=sys.argv[5] if len(sys.argv) > 5 else None, kernels={})
 for k in sorted(set(rd) | set(wr)):
     c = rd.get(k, {})
     n32, n64, n128 = c.get("TCC_EA0_RDREQ_32B_sum", 0.0), c.get("TCC_EA0_RDREQ_64B_sum", 0.0), c.get("TCC_EA0_RDREQ_128B_sum", 0.0)
     rb = 32 * n32 + 64 * n64 + 128 * n128
     wb = wr.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
-    out["kernels"][k] = {"read_bytes": int(rb), "write_bytes": int(wb), "total_MB": round((rb + wb) / 1e6, 1)}
+    out["kernels"][k] = {"read_bytes": int(rb), "write_bytes": int(wb), "total_MB": round((rb + wb) / 1e6, 1),
+                         "kernel_name": FULL.get(k, (0, None))[1]}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))
