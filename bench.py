@@ -219,7 +219,6 @@ class FrameRenderer:
         self.bucket = FlatGradBucket({k: torch.as_tensor(v, device=device) for k, v in src.items()},
                                      buffers=2 if (self.overlap or self.halves) else 1)
         self.p = self.bucket.params
-        self.flat_grad = self.bucket.flat_grad
         # Adam on the flat buffer (the reference's optimiser, eps 1e-15).  The learning rate is kept small so that the
         # synthetic scene's statistics (pairs per frame, list lengths) stay put over the run's steps: the cost of the
         # update does not depend on it.
@@ -252,6 +251,11 @@ class FrameRenderer:
                     self.parts.append(self._part(lo, hi, N, device, g))
             self.batch = self.parts[0].batch
         self.last = {}
+
+    @property
+    def flat_grad(self):
+        """the bucket's ACTIVE gradient buffer (after a step: the one the optimiser consumed)"""
+        return self.bucket.flat_grad
 
     def _part(self, lo, hi, N, device, g):
         """frames [lo, hi) of the step as one FrameBatch with its offsets and image gradients"""
