@@ -80,6 +80,9 @@
 #ifndef BLEND_SETS_CAP
 #define BLEND_SETS_CAP 32  // slab rows per wave of the three-set backward (list positions per round)
 #endif
+#ifndef BLEND_SETS_LE_AHEAD
+#define BLEND_SETS_LE_AHEAD 1  // three-set quarter kernel: read a step's list entry one step ahead (0: at the top of the step)
+#endif
 #ifndef BLEND_LATE_STAGE
 #define BLEND_LATE_STAGE 1 // matrix-core backward: gather the next super-batch's records behind the chunk loop (1) or in front of it (0)
 #endif
@@ -2117,10 +2120,10 @@ blend_bwd_quarter_kernel(const BlendArgs B) {
 // Channel slots: [0,4) tap set | [4,8) second set | [8,28) detached set, zero padded (whole K-slabs of the cg product).
 // dL_dout of the wave's pixels lives in REGISTERS in both MFMA operand layouts (staged once through the slab memory); LDS
 // keeps the 8-float replay state of a pixel.  Pair record:
-//       [ux uy ca cb | cc o ax ay | tx ty | dL_dfeature of the row's channels 0 .. C-1]      (NG = 10, NC = 10 + C)
+//       [ux uy ca cb | cc o ax ay | tx ty 0 0 | dL_dfeature of the row's channels 0 .. C-1]      (NG = SETS_NG = 12, NC = 12 + C)
 struct SetsCfg {
     static constexpr int CH = 28, NK = 7, NA = 2, SB = 64;
-    static constexpr int NG = 10, NCMAX = NG + CH;
+    static constexpr int NG = SETS_NG, NCMAX = NG + CH;
     static constexpr int PS = 8;  // state floats per pixel: [. . . ncontrib | T, R of set 0 1 2 (starting from T_final bg.g)]
 };
 
@@ -2495,6 +2498,8 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                 } else {
                     rec[8] = -s_tx;   // d uv of the tap set alone: sum dLp (conic (pixel - centre))
                     rec[9] = -s_ty;
+                    rec[10] = 0.f;    // (padding of the geometry part: whole 16-byte chunks)
+                    rec[11] = 0.f;
                 }
 #pragma unroll
                 for (int q = 0; q < NA; ++q)
@@ -2569,7 +2574,10 @@ struct SetsQCfg {
     static constexpr int RQ = Rec<CH>::RQ;  // 12 parts
 };
 
-template <bool ABS>
+// STD: the renderer's own plan -- rgb (3 channels, taps) at row channels 0-2, the depth at channel 3, 19 detached attributes
+// at channels 4-22 -- whose channel gradients the combine stores as whole float4 (record chunk 3 = slots 0 1 2 4, chunks 4 .. 8 =
+// slots 8 .. 27); other plans route every slot to its channel with scalar stores.
+template <bool ABS, bool STD>
 __global__ void __launch_bounds__(256, BLEND_SETS_MINW)
 blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     using Cfg = SetsQCfg;
@@ -2579,7 +2587,9 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     auto qpart = [](int e, int p) { return e * RQ + ((p & ~3) | ((p & 3) ^ ((e >> 2) & 3))); };
     __shared__ unsigned int s_keep[SB];
     __shared__ unsigned int s_pos4[SB];
-    __shared__ unsigned short s_qlist[4][4][SB + 16];   // [wave][quarter]: entry | (slab row) << 8
+    constexpr int QL = SB + 16;                         // a list and its padding (the inert entry, 16 times)
+    __shared__ unsigned short s_qlist[(4 * 4 + 1) * QL];   // [wave][quarter][QL]: entry | (slab row) << 8 (+ one list of slack: the
+                                                           // step loop reads the NEXT step's entry one step ahead, also past the last list)
     __shared__ __attribute__((aligned(16))) float s_acc[4][(CAP + 1) * RW];
     // replay state of a pixel: [T, R of set 0 1 2] (float4 rows, the four lane groups' rows of a step skewed by 4 floats) and
     // its ncontrib (own array)
@@ -2689,8 +2699,8 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     const int len = range.y - range.x;
     const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
     const int *slots = A.slot_sorted + range.x;
-    // combine: four threads per entry -- part 0: geometry (floats 0 .. 9 of the record), parts 1 .. 3: the slots' feature gradients
-    const int ce = tid >> 2, cp = tid & 3;
+    // combine: entry = lane, role = wave -- wave 0: geometry (floats 0 .. 11 of the record), waves 1 .. 3: the slots' channel gradients
+    const int ce = lane, cp = w;
     auto zero_rec = [&](int slot) {
         float *dst = pair_buf + (size_t)slot * NCP;
         for (int c = cp; c < NCP / 4; c += 4) reinterpret_cast<float4 *>(dst)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2710,11 +2720,31 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     const int offy = kk == 0 ? 43 : kk == 1 ? 3 : kk == 2 ? 4 : 47;
 
     auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };
-    Stager<CH, SB> st;
-    static_assert(Stager<CH, SB>::NCHUNK % 256 == 0, "every thread parks K chunks");
-    st.load_ids(A, tid, range.x, pos, 0);
-    st.load_payload(A, tid);
-    st.load_ids(A, tid, range.x, pos, 1);
+    // staging: a QUAD per entry -- thread t <-> entry se = t >> 2, 16-byte part sp = t & 3 of each of the record's three 64-byte
+    // sectors (four lanes per sector: coalesced).  One index load and three payload loads per thread and super-batch (of the
+    // third sector only part 8, the last four feature slots, is used; parts 9-11 of the staged record are written here), no
+    // division, and the coefficient block runs ONCE per wave (the generic Stager -- chunk c = t + 256 k, entry c / 12 -- made every
+    // wave run it for each of its three chunks: 230 of the 830 VALU instructions a wave spent per super-batch outside the steps).
+    static_assert(SB == 64 && RQ == 12, "256 threads = 64 entries x 4 parts; three sectors per record");
+    const int se = tid >> 2, sp = tid & 3;
+    int sid_next;              // Gaussian of entry se, two super-batches ahead (-1: past the list)
+    float4 sv0, sv1, sv2 = make_float4(0.f, 0.f, 0.f, 0.f);   // parts sp, 4 + sp, 8 (sp == 0) of entry se, one super-batch ahead
+#define SETSQ_STAGE_IDS(b)                                                        \
+    do {                                                                          \
+        const int q_ = pos(se, (b));                                              \
+        sid_next = q_ >= 0 ? A.idx_sorted[range.x + q_] : -1;                     \
+    } while (0)
+    // (past the list the quad loads Gaussian 0's record: staged entries >= nb are in no list and the combine skips them)
+#define SETSQ_STAGE_PAYLOAD()                                                                                                   \
+    do {                                                                                                                        \
+        const float4 *src_ = reinterpret_cast<const float4 *>(A.pack + (size_t)imax_(sid_next, 0) * Rec<CH>::RS) + sp;          \
+        sv0 = src_[0];                                                                                                          \
+        sv1 = src_[4];                                                                                                          \
+        if (sp == 0) sv2 = src_[8];                                                                                             \
+    } while (0)
+    SETSQ_STAGE_IDS(0);
+    SETSQ_STAGE_PAYLOAD();
+    SETSQ_STAGE_IDS(1);
     auto load_flags = [&](int topb) -> unsigned {
         const int q = topb - tid;
         return (tid < SB && q >= 0) ? (unsigned)A.cull_flags[range.x + q] : 0u;
@@ -2724,31 +2754,28 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     int batch = 0;
     for (int top = n - 1; top >= 0; top -= SB, ++batch) {
         const int nb = imin_(SB, top + 1);
-        {   // park; parts 0 / 1 of an entry sit in neighbouring lanes of a quad: they exchange and leave the coefficients
-#pragma unroll
-            for (int k = 0; k < Stager<CH, SB>::K; ++k) {
-                const int c = tid + 256 * k;
-                const int e = c / RQ, p = c - e * RQ;
-                const float4 mine = st.v[k];
-                float4 other;
-                other.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.x), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-                other.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.y), 0xB1, 0xf, 0xf, true));
-                other.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.z), 0xB1, 0xf, 0xf, true));
-                other.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.w), 0xB1, 0xf, 0xf, true));
-                const float4 g0 = p == 0 ? mine : other, g1 = p == 0 ? other : mine;
-                const PowerCoef pc = power_coeffs(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, tcx, tcy);
-                const float ut = g0.x - tcx, vt = g0.y - tcy;
-                if (p == 0) {
-                    s_rec[qpart(e, 0)] = mine;
-                    s_rec[qpart(e, 9)] = make_float4(pc.q0, pc.qx, pc.qy, pc.qxx);
-                } else if (p == 1) {
-                    s_rec[qpart(e, 1)] = mine;
-                    s_rec[qpart(e, 10)] = make_float4(pc.qxy, pc.qyy, -(g0.z * ut + g0.w * vt), -(g0.w * ut + g1.x * vt));
-                } else if (p < 9) {
-                    s_rec[qpart(e, p)] = mine;
-                } else if (p == 11) {
-                    s_rec[qpart(e, 11)] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+        {   // park; parts 0 / 1 of an entry sit in neighbouring lanes of its quad: they exchange and leave the coefficients
+            const float4 mine = sv0;
+            float4 other;
+            other.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.x), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+            other.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.y), 0xB1, 0xf, 0xf, true));
+            other.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.z), 0xB1, 0xf, 0xf, true));
+            other.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.w), 0xB1, 0xf, 0xf, true));
+            const float4 g0 = (sp & 1) == 0 ? mine : other, g1 = (sp & 1) == 0 ? other : mine;   // (lanes 2, 3 of a quad: unused)
+            const PowerCoef pc = power_coeffs(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, tcx, tcy);
+            const float ut = g0.x - tcx, vt = g0.y - tcy;
+            const int sz = (se >> 2) & 3;                 // the entry's swizzle: part p of a group of four at p ^ sz
+            float4 *rb = s_rec + se * RQ;
+            rb[sp ^ sz] = mine;                           // parts 0 .. 3
+            rb[4 + (sp ^ sz)] = sv1;                      // parts 4 .. 7
+            // parts 8 .. 11: the last feature slots | q0 qx qy qxx | qxy qyy -c0x -c0y | 0
+            if (sp == 0) {
+                rb[8 + sz] = sv2;
+                rb[8 + (1 ^ sz)] = make_float4(pc.q0, pc.qx, pc.qy, pc.qxx);
+            } else if (sp == 1) {
+                rb[8 + (2 ^ sz)] = make_float4(pc.qxy, pc.qyy, -(g0.z * ut + g0.w * vt), -(g0.w * ut + g1.x * vt));
+            } else if (sp == 3) {
+                rb[8 + (3 ^ sz)] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         const unsigned fl = fl_next;
@@ -2796,7 +2823,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
             const unsigned short ent = (unsigned short)(e | (ps << 8));
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if ((bits >> q) & 1u) s_qlist[w][q][(posw >> (8 * q)) & 0xffu] = ent;
+                if ((bits >> q) & 1u) s_qlist[(4 * w + q) * QL + ((posw >> (8 * q)) & 0xffu)] = ent;
             cqw = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
             cnt = __popcll(m);
         }
@@ -2805,7 +2832,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         for (int q = 0; q < 4; ++q) cq[q] = (int)((cqw >> (8 * q)) & 0xffu);
         if (lane < 16) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s_qlist[w][q][cq[q] + lane] = (unsigned short)(SB | (CAP << 8));   // pad: inert entry, zero row
+            for (int q = 0; q < 4; ++q) s_qlist[(4 * w + q) * QL + cq[q] + lane] = (unsigned short)(SB | (CAP << 8));   // pad: inert entry, zero row
         }
         {   // rows start from zero
             float4 *z = reinterpret_cast<float4 *>(slab);
@@ -2813,10 +2840,30 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // the list entry of a step is read ONE STEP AHEAD (the step's operand reads hang on it: one LDS round trip less on the
+        // step's critical path).  Steps in walk order: quarter 0's, then quarter 1's ...; the entry behind the last step of a
+        // quarter is the first of the next quarter that has any (read past the last list: slack, unused).
+#if BLEND_SETS_LE_AHEAD
+        int gfirst = 0;
+#pragma unroll
+        for (int q = 3; q >= 0; --q) gfirst = cq[q] > 0 ? q : gfirst;
+        unsigned le_next = s_qlist[(4 * w + gfirst) * QL + nl];
+#endif
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
             for (int j0 = 0; j0 < cq[G]; j0 += 16) {
-                const unsigned le = s_qlist[w][G][j0 + nl];
+#if BLEND_SETS_LE_AHEAD
+                const unsigned le = le_next;
+                {
+                    int gn = 4;       // the next quarter with a list (4: none -- the slack list, or the next wave's first)
+#pragma unroll
+                    for (int q = 3; q > G; --q) gn = cq[q] > 0 ? q : gn;
+                    const bool lastq = j0 + 16 >= cq[G];
+                    le_next = s_qlist[(lastq ? (4 * w + gn) * QL : (4 * w + G) * QL + j0 + 16) + nl];
+                }
+#else
+                const unsigned le = s_qlist[(4 * w + G) * QL + j0 + nl];
+#endif
                 const int e = le & 0xffu, row = le >> 8;
                 const int qn = top - e;
                 const float *er = reinterpret_cast<const float *>(s_rec) + e * (4 * RQ);
@@ -2936,10 +2983,12 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
             }
         }
         const int slot_mine = ce < nb ? slots[top - ce] : 0;   // entry ce of the combine
-        st.load_payload(A, tid);
-        st.load_ids(A, tid, range.x, pos, batch + 2);
+        SETSQ_STAGE_PAYLOAD();
+        SETSQ_STAGE_IDS(batch + 2);
         __syncthreads();
-        // ---- combine: entry ce, part cp
+        // ---- combine: entry ce = lane, role cp = wave -- wave 0: the geometry part of the record, waves 1 .. 3: the channel
+        //      gradients.  Wave-uniform roles: a wave runs ONE of the two paths (four parts per entry in neighbouring lanes made
+        //      every wave run both).
         if (ce < nb) {
             const int e = ce;
             const unsigned int p4 = s_pos4[e];
@@ -2977,8 +3026,30 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 r1.w = ABS ? s[10] : 0.f;
                 reinterpret_cast<float4 *>(dst)[0] = r0;
                 reinterpret_cast<float4 *>(dst)[1] = r1;
-                dst[8] = s[7];    // d uv of the tap set alone (the step's factor carries the minus sign)
-                dst[9] = s[8];
+                // d uv of the tap set alone (the step's factor carries the minus sign), and the chunk's padding
+                reinterpret_cast<float4 *>(dst)[2] = make_float4(s[7], s[8], 0.f, 0.f);
+            } else if (STD) {
+                // record chunks 3 + 2 (cp - 1) and the next one: chunk 3 = slots 0 1 2 4 (r g b | depth), chunk j >= 4 = slots
+                // 4 j - 8 .. 4 j - 5, i.e. float4 j + 3 of a slab row (slot s at row float 20 + s)
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const unsigned int pp = umin_((p4 >> (8 * ww)) & 0xffu, (unsigned)CAP);
+                    const float4 *rw = reinterpret_cast<const float4 *>(s_acc[ww] + pp * RW);
+                    float4 va, vb;
+                    if (cp == 1) {
+                        const float4 v5 = rw[5];
+                        va = make_float4(v5.x, v5.y, v5.z, s_acc[ww][pp * RW + 24]);
+                        vb = rw[7];
+                    } else {
+                        va = rw[2 * cp + 4];
+                        vb = rw[2 * cp + 5];
+                    }
+                    a.x += va.x; a.y += va.y; a.z += va.z; a.w += va.w;
+                    b.x += vb.x; b.y += vb.y; b.z += vb.z; b.w += vb.w;
+                }
+                reinterpret_cast<float4 *>(dst)[2 * cp + 1] = a;
+                reinterpret_cast<float4 *>(dst)[2 * cp + 2] = b;   // (cp 3: channels 20 21 22 and the record's last padding float)
             } else {
                 // slots [8 (cp - 1) .. ) of the 28 (cp 1: 0-7, cp 2: 8-19, cp 3: 20-27), summed over the waves, to their row channels
                 const int s0 = cp == 1 ? 0 : cp == 2 ? 8 : 20, ns = cp == 2 ? 12 : 8;
@@ -3014,6 +3085,9 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq)];
     }
 }
+
+#undef SETSQ_STAGE_IDS
+#undef SETSQ_STAGE_PAYLOAD
 
 // ------------------------------------------------------------------ wide single-set backward on QUARTER lists
 // The strip walk of blend_bwd_sets_quarter_kernel for ONE feature set of 16 .. 32 channels (the wide instantiations of
@@ -3915,6 +3989,15 @@ static bool bwd_use_quarters() {
     return v != 0;
 }
 
+// SPLAT_SETS_STD=0: the generic slot -> channel routing also for the renderer's own plan (tests compare the two)
+static bool sets_std_plan_enabled() {
+    static const int v = [] {
+        const char *e = getenv("SPLAT_SETS_STD");
+        return (e && strcmp(e, "0") == 0) ? 0 : 1;
+    }();
+    return v != 0;
+}
+
 template <int CH, bool ABS, bool BIAS>
 static int launch_bwd_ab(const BlendArgs &A, int T, bool pair, hipStream_t s) {
     const dim3 grid((unsigned)(T * A.F)), block(256);
@@ -4298,7 +4381,7 @@ extern "C" int splat_alpha_blending_backward_batch_set(int F, int P, int C, int 
 // (<= 4 channels: full gradients + the densification taps), set 1 = a second set blended with the live opacity (<= 4
 // channels), set 2 = the set blended with opacity.detach() (<= 20 channels); set_cn[g] = 0: no such set.  The sets must tile
 // the row's C channels exactly.  set_c0 / set_cn / set_bg are HOST arrays of three entries.  Records: stride
-// splat_blend_sets_pair_stride(C), layout [ux uy ca cb | cc o ax ay | tx ty | dL_dfeature[0..C-1]] (reduce them with
+// splat_blend_sets_pair_stride(C), layout [ux uy ca cb | cc o ax ay | tx ty 0 0 | dL_dfeature[0..C-1]] (reduce them with
 // splat_frames_gauss_backward_static_sets); pack_scratch: F * P * splat_blend_sets_pack_floats() floats.
 extern "C" size_t splat_blend_sets_pair_stride(int C) { return (size_t)PAIR_STRIDE(SetsCfg::NG + C); }
 extern "C" size_t splat_blend_sets_pack_floats(void) { return (size_t)Rec<SetsCfg::CH>::RS; }
@@ -4369,8 +4452,16 @@ extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, con
     SPLAT_POST_LAUNCH();
     const dim3 grid((unsigned)(T * F)), block(256);
     if (A.cull_flags && bwd_use_quarters()) {   // quarter lists (the forward's quarter bits)
-        if (want_abs) SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_quarter_kernel<true>, grid, block, 0, s, A);
-        else SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_quarter_kernel<false>, grid, block, 0, s, A);
+        // the renderer's own plan (rgb 0-2 | depth 3 | 19 attributes 4-22): channel gradients stored as whole float4
+        const bool std_plan = C == 23 && set_c0[0] == 0 && set_cn[0] == 3 && set_c0[1] == 3 && set_cn[1] == 1 && set_c0[2] == 4 &&
+                              set_cn[2] == 19 && sets_std_plan_enabled();
+        if (want_abs) {
+            if (std_plan) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, true>), grid, block, 0, s, A);
+            else SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, false>), grid, block, 0, s, A);
+        } else {
+            if (std_plan) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<false, true>), grid, block, 0, s, A);
+            else SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<false, false>), grid, block, 0, s, A);
+        }
     } else if (want_abs) SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_kernel<true>, grid, block, 0, s, A);
     else SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_kernel<false>, grid, block, 0, s, A);
     SPLAT_POST_LAUNCH();

@@ -122,6 +122,11 @@ struct GradLayout {
 // stride of a pair record in floats: the used floats rounded up to whole 16-byte chunks (a Gaussian's records are
 // contiguous and streamed with float4 loads; padding every record to a 64-byte sector cost 30 % more traffic)
 #define PAIR_STRIDE(nc) (((nc) + 3) & ~3)
+// SETS records (the renderer's three feature sets in one backward pass, blend.hip): [ux uy ca cb | cc o ax ay | tx ty 0 0 |
+// dL_dfeature of the row's channels 0 .. C-1] -- the geometry part fills three whole 16-byte chunks, so the channel gradients
+// start on a chunk boundary (the tile kernel stores them as float4, the Gaussian-side walk reads whole chunks anyway; for the
+// renderer's 23 channels the stride stays PAIR_STRIDE(12 + 23) = 36 floats)
+constexpr int SETS_NG = 12;
 // Workgroups are handed to the 8 XCDs round-robin by linear block id, and every XCD has its own L2.  Neighbouring
 // tiles gather largely the same packed records (a splat touches ~4 tiles), so runs of BLEND_XCD_RUN consecutive tiles
 // of the row-major order go to the same XCD (its consecutive blocks, i.e. roughly concurrently resident), and the runs

@@ -348,7 +348,7 @@ struct GaussBwdArgs {
     int skip_opacity;       // this feature set was blended with opacity.detach(): no opacity gradient
     int depth_channel;      // >= 0: that channel of the set is the per-frame depth feature -- its summed gradient is
                             // dL/ddepth of the projection (-> position), not a feature gradient
-    // SETS records (blend_bwd_sets_kernel: [ux uy ca cb | cc o ax ay | tx ty | row channels]): per set the first row
+    // SETS records (blend_bwd_sets_kernel: [ux uy ca cb | cc o ax ay | tx ty 0 0 | row channels], common.h SETS_NG): per set the first row
     // channel, the width, the gradient rows (NULL: not wanted) and their stride
     int sc0[3], scn[3], sstride[3];
     float *sdf[3];
@@ -410,7 +410,7 @@ template <bool ABS, int NCP, bool SETS = false, int CAM = 0, bool S2 = false>
 __global__ void __launch_bounds__(256)
 frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
     static_assert(!S2 || (NCP == 40 && SETS && ABS), "SETS2 records: 40 floats, abs sums present");
-    constexpr int NG = SETS ? 10 : GradLayout<ABS, false>::NG;
+    constexpr int NG = SETS ? SETS_NG : GradLayout<ABS, false>::NG;
     constexpr int NQ = NCP / 4, NS = (NQ + 3) / 4;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 2, sub = t & 3;
@@ -762,7 +762,7 @@ template <bool ABS, int NCP, bool SETS = false, bool S2 = false>
 __global__ void __launch_bounds__(256, GAUSS_DYN_MINW)
 frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
     static_assert(!S2 || (NCP == 40 && SETS && ABS), "SETS2 records: 40 floats, abs sums present");
-    constexpr int NG = SETS ? 10 : GradLayout<ABS, false>::NG;
+    constexpr int NG = SETS ? SETS_NG : GradLayout<ABS, false>::NG;
     constexpr int NQ = NCP / 4, NS = (NQ + 3) / 4;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int n = t >> 2, j = t & 3;
