@@ -81,7 +81,9 @@
 #define BLEND_SETS_CAP 32  // slab rows per wave of the three-set backward (list positions per round)
 #endif
 #ifndef BLEND_SETS_LE_AHEAD
-#define BLEND_SETS_LE_AHEAD 1  // three-set quarter kernel: read a step's list entry one step ahead (0: at the top of the step)
+#define BLEND_SETS_LE_AHEAD 0  // three-set quarter kernel: read a step's list entry one step ahead (1) or at the top of the step (0).
+                               // Measured (round 4, c2 training frame): 438 vs 434 us per frame -- the round trip it saves is hidden
+                               // by the second wave of the SIMD, the address arithmetic it adds is not
 #endif
 #ifndef BLEND_LATE_STAGE
 #define BLEND_LATE_STAGE 1 // matrix-core backward: gather the next super-batch's records behind the chunk loop (1) or in front of it (0)
@@ -327,12 +329,14 @@ __device__ __forceinline__ bool cull_test(float u, float v, float a, float b, fl
 // rows [i0, i0 + nrec) of a set's [P, cn] feature tensor into the staged records (LDS rows of LS floats, float offset `at`):
 // the 256 threads read the nrec * cn consecutive floats coalesced (a thread reading its own 76-byte row of the attribute set
 // touched 64 lines per load instruction: 2.4 TB/s for the whole packing kernel)
+// SETS: `at` is the set's first SLOT and channel ch goes to float sets_fpos(at + ch) of the row (transposed slots, see there)
+template <bool SETS = false>
 __device__ __forceinline__ void stage_feature_rows(float *s_rec, int LS, int at, const float *src, int cn, int i0, int nrec) {
     if (!src || cn <= 0) return;
     const float *p = src + (size_t)i0 * cn;
     for (int e = threadIdx.x; e < nrec * cn; e += 256) {
         const int row = e / cn, ch = e - row * cn;
-        s_rec[row * LS + at + ch] = p[e];
+        s_rec[row * LS + (SETS ? 8 + 8 * ((at + ch) & 3) + ((at + ch) >> 2) : at + ch)] = p[e];
     }
 }
 
@@ -2127,6 +2131,12 @@ struct SetsCfg {
     static constexpr int PS = 8;  // state floats per pixel: [. . . ncontrib | T, R of set 0 1 2 (starting from T_final bg.g)]
 };
 
+// Float of feature slot s inside the packed SETS record (and its staged copy): the 28 slots are stored TRANSPOSED -- slot
+// 4 j + kk at 8 + 8 kk + j -- so that the B operand rows a lane group kk feeds to the colour products (slots kk, 4 + kk, ..,
+// 24 + kk) are 7 consecutive floats: two ds_read_b128 per step instead of seven ds_read_b32 whose 16 lanes hit 8 bank pairs
+// (record stride 48 floats = 16 mod 32).  Floats 8 kk + 15 are padding (zero).
+__device__ __forceinline__ constexpr int sets_fpos(int slot) { return 8 + 8 * (slot & 3) + (slot >> 2); }
+
 // slot -> row channel (or -1): uniform selects on the kernel arguments
 __device__ __forceinline__ int sets_slot_channel(const BlendArgs &A, int slot) {
     const int g = slot < 4 ? 0 : slot < 8 ? 1 : 2;
@@ -2158,7 +2168,7 @@ pack_sets_kernel(const BlendArgs B) {
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 const int c = sets_slot_channel(A, k);
-                if (c >= 0) r[8 + k] = f[c];
+                if (c >= 0) r[sets_fpos(k)] = f[c];
             }
         }   // (else: the sets' own tensors, staged cooperatively below)
         const CullP cp = cull_params(r[2], r[3], r[4], r[5]);
@@ -2172,9 +2182,9 @@ pack_sets_kernel(const BlendArgs B) {
     __syncthreads();
     const int nrec = imin_(256, A.P - i0);
     if (!A.feature) {  // slots [0,4) | [4,8) | [8,28) of the three sets
-        stage_feature_rows(s_rec, LS, 8, A.sf0, A.s0cn, i0, nrec);
-        stage_feature_rows(s_rec, LS, 12, A.sf1, A.s1cn, i0, nrec);
-        stage_feature_rows(s_rec, LS, 16, A.sf2, A.s2cn, i0, nrec);
+        stage_feature_rows<true>(s_rec, LS, 0, A.sf0, A.s0cn, i0, nrec);
+        stage_feature_rows<true>(s_rec, LS, 4, A.sf1, A.s1cn, i0, nrec);
+        stage_feature_rows<true>(s_rec, LS, 8, A.sf2, A.s2cn, i0, nrec);
         __syncthreads();
     }
     float4 *dst = reinterpret_cast<float4 *>(A.pack + (size_t)i0 * RS);
@@ -2391,7 +2401,7 @@ blend_bwd_sets_kernel(const BlendArgs B) {
                 blx = kk == 0 ? cA * ut + cB * vt : kk == 1 ? -cA : kk == 2 ? -cB : 0.f;
                 bly = kk == 0 ? cB * ut + cC * vt : kk == 1 ? -cB : kk == 2 ? -cC : 0.f;
 #pragma unroll
-                for (int j = 0; j < NK; ++j) bf[j] = reinterpret_cast<const float *>(&L.rec[L.part(e, 2 + j)])[kk];
+                for (int j = 0; j < NK; ++j) bf[j] = L.f(e, 8 + 8 * kk + j);   // slot 4 j + kk (transposed slots: sets_fpos)
             }
             f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
             f32x4 d_f[NA];
@@ -2571,7 +2581,12 @@ struct SetsQCfg {
     static constexpr int CH = SetsCfg::CH, NK = SetsCfg::NK, NA = SetsCfg::NA, SB = SetsCfg::SB, NG = SetsCfg::NG, PS = SetsCfg::PS;
     static constexpr int CAP = SB;          // a row per staged entry at most: no rounds
     static constexpr int RW = 20 + CH + 4;  // 48 floats + 4 of padding: the float4 k of 16 consecutive rows sit on 16 different bank quads
-    static constexpr int RQ = Rec<CH>::RQ;  // 12 parts
+    static constexpr int RQ = Rec<CH>::RQ;  // 12 parts of the packed record
+    // staged record (LDS): parts 0-1 geometry | parts 2-9 the transposed feature slots (sets_fpos) | parts 10-13 the step's
+    // other B operands by lane group, Q[kk] = (q1 q2 lx ly)[kk] with q1 = q0 qx qy qxx, q2 = qxy qyy 0 0 (the polynomial),
+    // lx = -c0x cA cB 0, ly = -c0y cB cC 0 (the tap factor) | part 14 padding: 15 parts, an ODD number of 16-byte slots, so
+    // consecutive entries start on different slots of the 256-byte bank row and no swizzle is needed
+    static constexpr int RQL = 15;
 };
 
 // STD: the renderer's own plan -- rgb (3 channels, taps) at row channels 0-2, the depth at channel 3, 19 detached attributes
@@ -2582,9 +2597,10 @@ __global__ void __launch_bounds__(256, BLEND_SETS_MINW)
 blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     using Cfg = SetsQCfg;
     constexpr int CH = Cfg::CH, SB = Cfg::SB, NG = Cfg::NG, NK = Cfg::NK, NA = Cfg::NA, PS = Cfg::PS, CAP = Cfg::CAP, RW = Cfg::RW, RQ = Cfg::RQ;
-    static_assert(RQ == 12 && Rec<CH>::CULL == 43 && SB == 64 && CAP * RW >= 32 * CH, "record floats 36-47 are free; the staging of 32 pixels fits a slab");
-    __shared__ float4 s_rec[(SB + 1) * RQ];             // staged records (swizzled groups of four parts), slot SB = inert
-    auto qpart = [](int e, int p) { return e * RQ + ((p & ~3) | ((p & 3) ^ ((e >> 2) & 3))); };
+    constexpr int RQL = Cfg::RQL;
+    static_assert(RQ == 12 && Rec<CH>::CULL == 43 && SB == 64 && CAP * RW >= 32 * CH, "record floats 40-42 are free; the staging of 32 pixels fits a slab");
+    __shared__ float4 s_rec[(SB + 1) * RQL];            // staged records (SetsQCfg::RQL parts each), slot SB = inert
+    auto qpart = [](int e, int p) { return e * RQL + p; };
     __shared__ unsigned int s_keep[SB];
     __shared__ unsigned int s_pos4[SB];
     constexpr int QL = SB + 16;                         // a list and its padding (the inert entry, 16 times)
@@ -2667,7 +2683,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         const int wmax = wave_max_i(last);
         if (lane == 0) s_wmax[w] = wmax;
     }
-    if (tid < RQ) s_rec[qpart(SB, tid)] = make_float4(tid == 9 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);   // inert slot SB: q0 = log2(0)
+    if (tid < RQL) s_rec[qpart(SB, tid)] = make_float4(tid == 10 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);   // inert slot SB: q0 = log2(0)
     // ---- dL_dout of the wave's pixels into registers in both MFMA operand layouts, 32 pixels (two quarters) at a time
     float hcg[4][NK], hft[16][NA];
 #pragma unroll
@@ -2715,20 +2731,17 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         }
         return;
     }
-    // per-lane float offsets inside a staged record (before the entry's swizzle): tap factor operands -c0x cA cB 0 / -c0y cB cC 0
-    const int offx = kk == 0 ? 42 : kk == 1 ? 2 : kk == 2 ? 3 : 47;
-    const int offy = kk == 0 ? 43 : kk == 1 ? 3 : kk == 2 ? 4 : 47;
 
     auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };
     // staging: a QUAD per entry -- thread t <-> entry se = t >> 2, 16-byte part sp = t & 3 of each of the record's three 64-byte
     // sectors (four lanes per sector: coalesced).  One index load and three payload loads per thread and super-batch (of the
-    // third sector only part 8, the last four feature slots, is used; parts 9-11 of the staged record are written here), no
+    // third sector only parts 8 and 9, the last feature slots, are used; the cull parameters behind them are not), no
     // division, and the coefficient block runs ONCE per wave (the generic Stager -- chunk c = t + 256 k, entry c / 12 -- made every
     // wave run it for each of its three chunks: 230 of the 830 VALU instructions a wave spent per super-batch outside the steps).
     static_assert(SB == 64 && RQ == 12, "256 threads = 64 entries x 4 parts; three sectors per record");
     const int se = tid >> 2, sp = tid & 3;
     int sid_next;              // Gaussian of entry se, two super-batches ahead (-1: past the list)
-    float4 sv0, sv1, sv2 = make_float4(0.f, 0.f, 0.f, 0.f);   // parts sp, 4 + sp, 8 (sp == 0) of entry se, one super-batch ahead
+    float4 sv0, sv1, sv2 = make_float4(0.f, 0.f, 0.f, 0.f);   // parts sp, 4 + sp, 8 + sp (sp < 2) of entry se, one super-batch ahead
 #define SETSQ_STAGE_IDS(b)                                                        \
     do {                                                                          \
         const int q_ = pos(se, (b));                                              \
@@ -2740,7 +2753,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         const float4 *src_ = reinterpret_cast<const float4 *>(A.pack + (size_t)imax_(sid_next, 0) * Rec<CH>::RS) + sp;          \
         sv0 = src_[0];                                                                                                          \
         sv1 = src_[4];                                                                                                          \
-        if (sp == 0) sv2 = src_[8];                                                                                             \
+        if (sp < 2) sv2 = src_[8];                                                                                              \
     } while (0)
     SETSQ_STAGE_IDS(0);
     SETSQ_STAGE_PAYLOAD();
@@ -2754,29 +2767,26 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     int batch = 0;
     for (int top = n - 1; top >= 0; top -= SB, ++batch) {
         const int nb = imin_(SB, top + 1);
-        {   // park; parts 0 / 1 of an entry sit in neighbouring lanes of its quad: they exchange and leave the coefficients
+        {   // park: the quad's lanes copy their parts and each leaves ONE of the four operand rows Q[sp] (the two geometry parts
+            // sit in lanes 0 / 1 of the quad: broadcast)
             const float4 mine = sv0;
-            float4 other;
-            other.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.x), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-            other.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.y), 0xB1, 0xf, 0xf, true));
-            other.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.z), 0xB1, 0xf, 0xf, true));
-            other.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.w), 0xB1, 0xf, 0xf, true));
-            const float4 g0 = (sp & 1) == 0 ? mine : other, g1 = (sp & 1) == 0 ? other : mine;   // (lanes 2, 3 of a quad: unused)
+            float4 g0, g1;
+#define QB_(v, c) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), c, 0xf, 0xf, true))
+            g0.x = QB_(mine.x, 0x00); g0.y = QB_(mine.y, 0x00); g0.z = QB_(mine.z, 0x00); g0.w = QB_(mine.w, 0x00);   // quad_perm [0,0,0,0]
+            g1.x = QB_(mine.x, 0x55); g1.y = QB_(mine.y, 0x55);                                                       // quad_perm [1,1,1,1]
+#undef QB_
             const PowerCoef pc = power_coeffs(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, tcx, tcy);
             const float ut = g0.x - tcx, vt = g0.y - tcy;
-            const int sz = (se >> 2) & 3;                 // the entry's swizzle: part p of a group of four at p ^ sz
-            float4 *rb = s_rec + se * RQ;
-            rb[sp ^ sz] = mine;                           // parts 0 .. 3
-            rb[4 + (sp ^ sz)] = sv1;                      // parts 4 .. 7
-            // parts 8 .. 11: the last feature slots | q0 qx qy qxx | qxy qyy -c0x -c0y | 0
-            if (sp == 0) {
-                rb[8 + sz] = sv2;
-                rb[8 + (1 ^ sz)] = make_float4(pc.q0, pc.qx, pc.qy, pc.qxx);
-            } else if (sp == 1) {
-                rb[8 + (2 ^ sz)] = make_float4(pc.qxy, pc.qyy, -(g0.z * ut + g0.w * vt), -(g0.w * ut + g1.x * vt));
-            } else if (sp == 3) {
-                rb[8 + (3 ^ sz)] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            float4 *rb = s_rec + se * RQL;
+            rb[sp] = mine;                                // parts 0 .. 3
+            rb[4 + sp] = sv1;                             // parts 4 .. 7
+            if (sp < 2) rb[8 + sp] = sv2;                 // parts 8, 9
+            float4 qv;                                    // Q[sp] = (q1 q2 lx ly)[sp]
+            qv.x = sp == 0 ? pc.q0 : sp == 1 ? pc.qx : sp == 2 ? pc.qy : pc.qxx;
+            qv.y = sp == 0 ? pc.qxy : sp == 1 ? pc.qyy : 0.f;
+            qv.z = sp == 0 ? -(g0.z * ut + g0.w * vt) : sp == 1 ? g0.z : sp == 2 ? g0.w : 0.f;
+            qv.w = sp == 0 ? -(g0.w * ut + g1.x * vt) : sp == 1 ? g0.w : sp == 2 ? g1.x : 0.f;
+            rb[10 + sp] = qv;
         }
         const unsigned fl = fl_next;
         fl_next = load_flags(top - SB);
@@ -2866,14 +2876,13 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
 #endif
                 const int e = le & 0xffu, row = le >> 8;
                 const int qn = top - e;
-                const float *er = reinterpret_cast<const float *>(s_rec) + e * (4 * RQ);
-                const int sw = 4 * ((e >> 2) & 3);   // float offset f of a record: f ^ sw (the swizzle permutes groups of four parts)
-                const float bq1 = er[(36 + kk) ^ sw];
-                const float bq2 = er[(40 + (kk & 1)) ^ sw];   // (lane groups 2, 3: their monomial operand is zero)
-                const float blx = er[offx ^ sw], bly = er[offy ^ sw];
+                // the step's B operands of this lane group: three 16-byte reads (Q[kk], slots kk 4+kk 8+kk 12+kk, slots 16+kk 20+kk 24+kk)
+                const float4 *er = s_rec + e * RQL;
+                const float4 qv = er[10 + kk], t0 = er[2 + 2 * kk], t1 = er[3 + 2 * kk];
+                const float bq1 = qv.x, bq2 = qv.y, blx = qv.z, bly = qv.w;
                 float bf[NK];
-#pragma unroll
-                for (int j = 0; j < NK; ++j) bf[j] = er[(8 + 4 * j + kk) ^ sw];
+                bf[0] = t0.x; bf[1] = t0.y; bf[2] = t0.z; bf[3] = t0.w; bf[4] = t1.x; bf[5] = t1.y; bf[6] = t1.z;
+                static_assert(NK == 7, "slots 4 j + kk, j = 0 .. 6");
                 f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
                 f32x4 d_f[NA];
 #pragma unroll
@@ -2993,7 +3002,36 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
             const int e = ce;
             const unsigned int p4 = s_pos4[e];
             float *dst = pair_buf + (size_t)slot_mine * NCP;
-            if (cp == 0) {
+            if (STD && cp == 0) {
+                // the moments (about the centre of each wave's pixel set) to the tile centre, then to d uv / d conic: floats 0 .. 4
+                float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // M0 Mx My Mxx Mxy Myy
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const unsigned int pp = umin_((p4 >> (8 * ww)) & 0xffu, (unsigned)CAP);
+                    const float4 *rw = reinterpret_cast<const float4 *>(s_acc[ww] + pp * RW);
+                    const float4 m = rw[0];
+                    const float2 m2 = *reinterpret_cast<const float2 *>(rw + 1);
+                    const float bxw = (ww & 1) ? 2.f : -2.f, byw = (ww >> 1) ? 2.f : -2.f;   // centre of the wave's pixel set from the tile centre
+                    s[0] += m.x;
+                    s[1] += m.y + bxw * m.x;
+                    s[2] += m.z + byw * m.x;
+                    s[3] += m.w + 2.f * bxw * m.y + (bxw * bxw) * m.x;
+                    s[4] += m2.x + bxw * m.z + byw * m.y + (bxw * byw) * m.x;
+                    s[5] += m2.y + 2.f * byw * m.z + (byw * byw) * m.x;
+                }
+                const float4 g0 = s_rec[qpart(e, 0)];
+                const float cC = s_rec[qpart(e, 1)].x;
+                const float cA = g0.z, cB = g0.w;
+                const float uc = g0.x - tcx, vc = g0.y - tcy;
+                const float M0 = s[0], Mx = s[1], My = s[2], Mxx = s[3], Mxy = s[4], Myy = s[5];
+                float4 r0;
+                r0.x = cA * Mx + cB * My - (cA * uc + cB * vc) * M0;
+                r0.y = cB * Mx + cC * My - (cB * uc + cC * vc) * M0;
+                r0.z = -0.5f * (uc * uc * M0 - 2.f * uc * Mx + Mxx);
+                r0.w = -(uc * vc * M0 - uc * My - vc * Mx + Mxy);
+                reinterpret_cast<float4 *>(dst)[0] = r0;
+                dst[4] = -0.5f * (vc * vc * M0 - 2.f * vc * My + Myy);
+            } else if (cp == 0) {
                 float s[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // M0 Mx My Mxx Mxy Myy | op tx ty ax ay
 #pragma unroll
                 for (int ww = 0; ww < 4; ++ww) {
@@ -3029,27 +3067,51 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 // d uv of the tap set alone (the step's factor carries the minus sign), and the chunk's padding
                 reinterpret_cast<float4 *>(dst)[2] = make_float4(s[7], s[8], 0.f, 0.f);
             } else if (STD) {
-                // record chunks 3 + 2 (cp - 1) and the next one: chunk 3 = slots 0 1 2 4 (r g b | depth), chunk j >= 4 = slots
-                // 4 j - 8 .. 4 j - 5, i.e. float4 j + 3 of a slab row (slot s at row float 20 + s)
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+                // record chunk 3 = slots 0 1 2 4 (r g b | depth), chunk j >= 4 = slots 4 j - 8 .. 4 j - 5, i.e. float4 j + 3 of a
+                // slab row (slot s at row float 20 + s)
+                // Roles (the moments' move to the tile centre makes wave 0's part the longest; the waves meet at the barrier
+                // behind the combine): wave 1 = the per-lane sums (d opacity, taps, |taps|: floats 5 .. 9) + chunk 3, wave 2 =
+                // chunks 4 5 6, wave 3 = chunks 7 8.
+                if (cp == 1) {
+                    float op = 0.f, tx_ = 0.f, ty_ = 0.f, ax = 0.f, ay = 0.f;
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) {
-                    const unsigned int pp = umin_((p4 >> (8 * ww)) & 0xffu, (unsigned)CAP);
-                    const float4 *rw = reinterpret_cast<const float4 *>(s_acc[ww] + pp * RW);
-                    float4 va, vb;
-                    if (cp == 1) {
-                        const float4 v5 = rw[5];
-                        va = make_float4(v5.x, v5.y, v5.z, s_acc[ww][pp * RW + 24]);
-                        vb = rw[7];
-                    } else {
-                        va = rw[2 * cp + 4];
-                        vb = rw[2 * cp + 5];
+                    for (int ww = 0; ww < 4; ++ww) {
+                        const unsigned int pp = umin_((p4 >> (8 * ww)) & 0xffu, (unsigned)CAP);
+                        const float *rf = s_acc[ww] + pp * RW;
+                        const float4 *rw = reinterpret_cast<const float4 *>(rf);
+                        const float4 sa = rw[2], sb2 = rw[3], v5 = rw[5];
+                        op += sa.x + sb2.x; tx_ += sa.y + sb2.y; ty_ += sa.z + sb2.z; ax += sa.w + sb2.w;
+                        ay += rf[16] + rf[6];
+                        a.x += v5.x; a.y += v5.y; a.z += v5.z; a.w += rf[24];
                     }
-                    a.x += va.x; a.y += va.y; a.z += va.z; a.w += va.w;
-                    b.x += vb.x; b.y += vb.y; b.z += vb.z; b.w += vb.w;
+                    const float o = s_rec[qpart(e, 1)].y;
+                    dst[5] = o > 0.f ? op / o : 0.f;
+                    dst[6] = ABS ? ax : 0.f;
+                    dst[7] = ABS ? ay : 0.f;
+                    reinterpret_cast<float4 *>(dst)[2] = make_float4(tx_, ty_, 0.f, 0.f);   // d uv of the tap set alone | padding
+                    reinterpret_cast<float4 *>(dst)[3] = a;                                 // r g b | depth
+                } else {
+                    // record chunks 4 5 6 (wave 2) / 7 8 (wave 3) = float4 7 8 9 / 10 11 of a slab row
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
+                    const int r0_ = cp == 2 ? 7 : 10;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) {
+                        const unsigned int pp = umin_((p4 >> (8 * ww)) & 0xffu, (unsigned)CAP);
+                        const float4 *rw = reinterpret_cast<const float4 *>(s_acc[ww] + pp * RW) + r0_;
+                        const float4 va = rw[0], vb = rw[1];
+                        a.x += va.x; a.y += va.y; a.z += va.z; a.w += va.w;
+                        b.x += vb.x; b.y += vb.y; b.z += vb.z; b.w += vb.w;
+                        if (cp == 2) {
+                            const float4 vc_ = rw[2];
+                            c.x += vc_.x; c.y += vc_.y; c.z += vc_.z; c.w += vc_.w;
+                        }
+                    }
+                    float4 *d4 = reinterpret_cast<float4 *>(dst) + (cp == 2 ? 4 : 7);
+                    d4[0] = a;
+                    d4[1] = b;   // (wave 3: channels 20 21 22 and the record's last padding float)
+                    if (cp == 2) d4[2] = c;
                 }
-                reinterpret_cast<float4 *>(dst)[2 * cp + 1] = a;
-                reinterpret_cast<float4 *>(dst)[2 * cp + 2] = b;   // (cp 3: channels 20 21 22 and the record's last padding float)
             } else {
                 // slots [8 (cp - 1) .. ) of the 28 (cp 1: 0-7, cp 2: 8-19, cp 3: 20-27), summed over the waves, to their row channels
                 const int s0 = cp == 1 ? 0 : cp == 2 ? 8 : 20, ns = cp == 2 ? 12 : 8;
