@@ -85,6 +85,10 @@
                                // Measured (round 4, c2 training frame): 438 vs 434 us per frame -- the round trip it saves is hidden
                                // by the second wave of the SIMD, the address arithmetic it adds is not
 #endif
+#ifndef BLEND_SETS_EARLY_ROWS
+#define BLEND_SETS_EARLY_ROWS 1  // three-set quarter kernel: request the survivor's slab row at the top of the step (13 registers
+                                 // across the step) instead of in front of the epilogue's adds
+#endif
 #ifndef BLEND_LATE_STAGE
 #define BLEND_LATE_STAGE 1 // matrix-core backward: gather the next super-batch's records behind the chunk loop (1) or in front of it (0)
 #endif
@@ -2883,6 +2887,15 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 float bf[NK];
                 bf[0] = t0.x; bf[1] = t0.y; bf[2] = t0.z; bf[3] = t0.w; bf[4] = t1.x; bf[5] = t1.y; bf[6] = t1.z;
                 static_assert(NK == 7, "slots 4 j + kk, j = 0 .. 6");
+#if BLEND_SETS_EARLY_ROWS
+                // the survivor's slab row -- what the step's epilogue adds into -- is requested NOW (a padded list slot reads the
+                // zero row), so that its LDS round trip runs under the step instead of in front of the epilogue's adds
+                float *const rr = slab + row * RW;
+                float4 *const p1 = reinterpret_cast<float4 *>(rr + 4 * kk);
+                float4 *const pf = reinterpret_cast<float4 *>(rr + 20 + 4 * kk);   // slots 4 kk .. (q = 0) and 16 + 4 kk .. (q = 1)
+                const float4 o1_in = *p1, f0_in = pf[0], f1_in = pf[4];            // (lane group 3: pf[4] is the row's padding)
+                const float ay_in = rr[16];
+#endif
                 f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
                 f32x4 d_f[NA];
 #pragma unroll
@@ -2965,6 +2978,25 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 };
                 s_op = half(s_op); s_tx = half(s_tx); s_ty = half(s_ty);
                 if (ABS) { s_ax = half(s_ax); s_ay = half(s_ay); }
+#if BLEND_SETS_EARLY_ROWS
+                if (j0 + nl < cq[G]) {
+                    float4 o1 = o1_in;
+                    o1.x += kk < 2 ? d_mom[0] : s_op;
+                    o1.y += kk < 2 ? d_mom[1] : s_tx;
+                    o1.z += kk == 0 ? d_mom[2] : kk == 1 ? s_ay : s_ty;
+                    o1.w += kk == 0 ? d_mom[3] : kk == 1 ? 0.f : s_ax;
+                    *p1 = o1;
+                    if (ABS && kk == 2) rr[16] = ay_in + s_ay;
+                    float4 f0 = f0_in;
+                    f0.x += d_f[0][0]; f0.y += d_f[0][1]; f0.z += d_f[0][2]; f0.w += d_f[0][3];
+                    pf[0] = f0;
+                    if (kk < 3) {
+                        float4 f1 = f1_in;
+                        f1.x += d_f[1][0]; f1.y += d_f[1][1]; f1.z += d_f[1][2]; f1.w += d_f[1][3];
+                        pf[4] = f1;
+                    }
+                }
+#else
                 if (j0 + nl < cq[G]) {
                     float *rr = slab + row * RW;
                     float4 v1;
@@ -2987,6 +3019,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                         pf[4] = f1;
                     }
                 }
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
