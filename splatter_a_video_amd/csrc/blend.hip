@@ -85,6 +85,9 @@
                                // Measured (round 4, c2 training frame): 438 vs 434 us per frame -- the round trip it saves is hidden
                                // by the second wave of the SIMD, the address arithmetic it adds is not
 #endif
+#ifndef BLEND_SETS_TWO_BARRIERS
+#define BLEND_SETS_TWO_BARRIERS 1  // three-set quarter kernel: no barrier behind the combine (it reads the staged geometry in front of its barrier)
+#endif
 #ifndef BLEND_SETS_EARLY_ROWS
 #define BLEND_SETS_EARLY_ROWS 1  // three-set quarter kernel: request the survivor's slab row at the top of the step (13 registers
                                  // across the step) instead of in front of the epilogue's adds
@@ -3027,7 +3030,28 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         const int slot_mine = ce < nb ? slots[top - ce] : 0;   // entry ce of the combine
         SETSQ_STAGE_PAYLOAD();
         SETSQ_STAGE_IDS(batch + 2);
+#if BLEND_SETS_TWO_BARRIERS
+        // the combine's only reads of the staged records, taken BEFORE the barrier: behind it a fast wave may already park the next
+        // super-batch over them while a slow one still combines (the combine otherwise reads the slabs and position bytes, which
+        // nobody writes before the next super-batch's barrier) -- two barriers per super-batch instead of three
+        float4 cg0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float cgC = 0.f, cgo = 0.f;
+        if (cp <= 1) {
+            cg0 = s_rec[qpart(ce, 0)];
+            const float4 t_ = s_rec[qpart(ce, 1)];
+            cgC = t_.x; cgo = t_.y;
+        }
+#endif
         __syncthreads();
+#if !BLEND_SETS_TWO_BARRIERS
+        float4 cg0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float cgC = 0.f, cgo = 0.f;
+        if (cp <= 1) {
+            cg0 = s_rec[qpart(ce, 0)];
+            const float4 t_ = s_rec[qpart(ce, 1)];
+            cgC = t_.x; cgo = t_.y;
+        }
+#endif
         // ---- combine: entry ce = lane, role cp = wave -- wave 0: the geometry part of the record, waves 1 .. 3: the channel
         //      gradients.  Wave-uniform roles: a wave runs ONE of the two paths (four parts per entry in neighbouring lanes made
         //      every wave run both).
@@ -3052,8 +3076,8 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                     s[4] += m2.x + bxw * m.z + byw * m.y + (bxw * byw) * m.x;
                     s[5] += m2.y + 2.f * byw * m.z + (byw * byw) * m.x;
                 }
-                const float4 g0 = s_rec[qpart(e, 0)];
-                const float cC = s_rec[qpart(e, 1)].x;
+                const float4 g0 = cg0;
+                const float cC = cgC;
                 const float cA = g0.z, cB = g0.w;
                 const float uc = g0.x - tcx, vc = g0.y - tcy;
                 const float M0 = s[0], Mx = s[1], My = s[2], Mxx = s[3], Mxy = s[4], Myy = s[5];
@@ -3082,8 +3106,8 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                     s[6] += sa.x + sb2.x; s[7] += sa.y + sb2.y; s[8] += sa.z + sb2.z; s[9] += sa.w + sb2.w;
                     s[10] += ayA + m2.z;
                 }
-                const float4 g0 = s_rec[qpart(e, 0)], g1 = s_rec[qpart(e, 1)];
-                const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
+                const float4 g0 = cg0;
+                const float cA = g0.z, cB = g0.w, cC = cgC, o = cgo;
                 const float uc = g0.x - tcx, vc = g0.y - tcy;
                 const float M0 = s[0], Mx = s[1], My = s[2], Mxx = s[3], Mxy = s[4], Myy = s[5];
                 float4 r0, r1;
@@ -3118,7 +3142,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                         ay += rf[16] + rf[6];
                         a.x += v5.x; a.y += v5.y; a.z += v5.z; a.w += rf[24];
                     }
-                    const float o = s_rec[qpart(e, 1)].y;
+                    const float o = cgo;
                     dst[5] = o > 0.f ? op / o : 0.f;
                     dst[6] = ABS ? ax : 0.f;
                     dst[7] = ABS ? ay : 0.f;
@@ -3173,7 +3197,9 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 // (floats NC .. NCP - 1 of a record are padding)
             }
         }
+#if !BLEND_SETS_TWO_BARRIERS
         __syncthreads();
+#endif
     }
     if (A.dbg_T_front) {
         const int px = tx * TILE + lx, py = ty * TILE + ly;
