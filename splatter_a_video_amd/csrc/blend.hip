@@ -3232,7 +3232,7 @@ __global__ void __launch_bounds__(256, (CH <= 20 ? 3 : 2))   // 16 / 20 channels
 blend_bwd_wide_quarter_kernel(const BlendArgs B) {
     using Cfg = WideQCfg<CH>;
     constexpr int SB = Cfg::SB, CAP = Cfg::CAP, NK = Cfg::NK, NA = Cfg::NA, NG = Cfg::NG, NCP = Cfg::NCP, RW = Cfg::RW, RQ = Cfg::RQ;
-    static_assert(RQ % 4 == 0 && CAP * RW >= 32 * CH && Stager<CH, SB>::NCHUNK % 256 == 0, "swizzle groups; staging of 32 pixels fits a slab");
+    static_assert(RQ % 4 == 0 && CAP * RW >= 32 * CH && SB == 64, "swizzle groups; staging of 32 pixels fits a slab; a quad per staged entry");
     __shared__ float4 s_rec[(SB + 1) * RQ];
     auto qpart = [](int e, int p) { return e * RQ + ((p & ~3) | ((p & 3) ^ ((e >> 2) & 3))); };
     __shared__ float4 s_coef[(SB + 1) * 2];             // [q0 qx qy qxx | qxy qyy 0 0] of the staged entries, slot SB = inert
@@ -3334,7 +3334,7 @@ blend_bwd_wide_quarter_kernel(const BlendArgs B) {
     const int len = range.y - range.x;
     const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
     const int *slots = A.slot_sorted + range.x;
-    const int ce = tid >> 2, cp = tid & 3;   // combine: four threads per entry (geometry | three shares of the feature chunks)
+    const int ce = lane, cp = w;   // combine: entry = lane, role = wave (geometry | three shares of the feature chunks): wave-uniform paths
     auto zero_rec = [&](int slot) {
         float *dst = pair_buf + (size_t)slot * RST;
         for (int c = cp; c < NCP / 4; c += 4) reinterpret_cast<float4 *>(dst)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -3350,10 +3350,26 @@ blend_bwd_wide_quarter_kernel(const BlendArgs B) {
         return;
     }
     auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };
-    Stager<CH, SB> st;
-    st.load_ids(A, tid, range.x, pos, 0);
-    st.load_payload(A, tid);
-    st.load_ids(A, tid, range.x, pos, 1);
+    // staging: a quad per entry (see blend_bwd_sets_quarter_kernel) -- thread t <-> entry se = t >> 2, part sp = t & 3 of each of the
+    // record's NSEC 64-byte sectors: one index load per thread and super-batch, no division, the coefficient block once per wave
+    constexpr int NSEC = RQ / 4;
+    const int se = tid >> 2, sp = tid & 3;
+    int sid_next;
+    float4 sv[NSEC];
+#define WIDEQ_STAGE_IDS(b)                                                        \
+    do {                                                                          \
+        const int q_ = pos(se, (b));                                              \
+        sid_next = q_ >= 0 ? A.idx_sorted[range.x + q_] : -1;                     \
+    } while (0)
+    // (past the list the quad loads Gaussian 0's record: staged entries >= nb are in no list and the combine skips them)
+#define WIDEQ_STAGE_PAYLOAD()                                                                                                   \
+    do {                                                                                                                        \
+        const float4 *src_ = reinterpret_cast<const float4 *>(A.pack + (size_t)imax_(sid_next, 0) * Rec<CH>::RS) + sp;          \
+        _Pragma("unroll") for (int k_ = 0; k_ < NSEC; ++k_) sv[k_] = src_[4 * k_];                                              \
+    } while (0)
+    WIDEQ_STAGE_IDS(0);
+    WIDEQ_STAGE_PAYLOAD();
+    WIDEQ_STAGE_IDS(1);
     auto load_flags = [&](int topb) -> unsigned {
         const int q = topb - tid;
         return (tid < SB && q >= 0) ? (unsigned)A.cull_flags[range.x + q] : 0u;
@@ -3364,22 +3380,19 @@ blend_bwd_wide_quarter_kernel(const BlendArgs B) {
     for (int top = n - 1; top >= 0; top -= SB, ++batch) {
         const int nb = imin_(SB, top + 1);
         {   // park; the lanes holding parts 0 / 1 of an entry exchange them and leave the polynomial's coefficients
+            const float4 mine = sv[0];
+            float4 other;
+            other.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.x), 0xB1, 0xf, 0xf, true));
+            other.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.y), 0xB1, 0xf, 0xf, true));
+            other.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.z), 0xB1, 0xf, 0xf, true));
+            other.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.w), 0xB1, 0xf, 0xf, true));
+            const float4 g0 = (sp & 1) == 0 ? mine : other, g1 = (sp & 1) == 0 ? other : mine;   // (lanes 2, 3 of a quad: unused)
+            const PowerCoef pc = power_coeffs(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, tcx, tcy);
+            float4 *rb = s_rec + se * RQ + (sp ^ ((se >> 2) & 3));   // part 4 k + sp at 4 k + (sp ^ swizzle)
 #pragma unroll
-            for (int k = 0; k < Stager<CH, SB>::K; ++k) {
-                const int c = tid + 256 * k;
-                const int e = c / RQ, p = c - e * RQ;
-                const float4 mine = st.v[k];
-                float4 other;
-                other.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.x), 0xB1, 0xf, 0xf, true));
-                other.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.y), 0xB1, 0xf, 0xf, true));
-                other.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.z), 0xB1, 0xf, 0xf, true));
-                other.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.w), 0xB1, 0xf, 0xf, true));
-                const float4 g0 = p == 0 ? mine : other, g1 = p == 0 ? other : mine;
-                const PowerCoef pc = power_coeffs(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, tcx, tcy);
-                s_rec[qpart(e, p)] = mine;
-                if (p == 0) s_coef[2 * e] = make_float4(pc.q0, pc.qx, pc.qy, pc.qxx);
-                else if (p == 1) s_coef[2 * e + 1] = make_float4(pc.qxy, pc.qyy, 0.f, 0.f);
-            }
+            for (int k = 0; k < NSEC; ++k) rb[4 * k] = sv[k];
+            if (sp == 0) s_coef[2 * se] = make_float4(pc.q0, pc.qx, pc.qy, pc.qxx);
+            else if (sp == 1) s_coef[2 * se + 1] = make_float4(pc.qxy, pc.qyy, 0.f, 0.f);
         }
         const unsigned fl = fl_next;
         fl_next = load_flags(top - SB);
@@ -3456,6 +3469,18 @@ blend_bwd_wide_quarter_kernel(const BlendArgs B) {
                 float bf[NK];
 #pragma unroll
                 for (int j = 0; j < NK; ++j) bf[j] = er[(8 + 4 * j + kk) ^ sw];
+                // the survivor's slab row is requested now (a padded list slot reads the zero row): its round trip runs under the step
+                // (not at 20 channels: the 168-register budget of three waves per SIMD has no room for the 12 registers)
+                constexpr bool EARLY = CH != 20;
+                float *const rr = slab + row * RW;
+                float4 *const p1 = reinterpret_cast<float4 *>(rr + 4 * (kk & 1));
+                float4 o1_in, fq_in[NA];
+                if (EARLY) {
+                    o1_in = *p1;
+#pragma unroll
+                    for (int q = 0; q < NA; ++q)
+                        fq_in[q] = *reinterpret_cast<const float4 *>(rr + 8 + ((16 * q + 4 * kk < CH) ? 16 * q + 4 * kk : 0));
+                }
                 f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
                 f32x4 d_f[NA];
 #pragma unroll
@@ -3507,20 +3532,17 @@ blend_bwd_wide_quarter_kernel(const BlendArgs B) {
                     for (int q = 0; q < NA; ++q) d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(hft[s][q], wgt[i], d_f[q], 0, 0, 0);
                 }
                 if (j0 + nl < cq[G]) {
-                    float *rr = slab + row * RW;
                     if (kk < 2) {
-                        float4 *p1 = reinterpret_cast<float4 *>(rr + 4 * kk);
-                        float4 o1 = *p1;
+                        float4 o1 = EARLY ? o1_in : *p1;
                         o1.x += d_mom[0]; o1.y += d_mom[1]; o1.z += d_mom[2]; o1.w += d_mom[3];
                         *p1 = o1;
                     }
 #pragma unroll
                     for (int q = 0; q < NA; ++q) {
                         if (16 * q + 4 * kk < CH) {
-                            float4 *pf = reinterpret_cast<float4 *>(rr + 8 + 16 * q + 4 * kk);
-                            float4 f0 = *pf;
+                            float4 f0 = EARLY ? fq_in[q] : *reinterpret_cast<const float4 *>(rr + 8 + 16 * q + 4 * kk);
                             f0.x += d_f[q][0]; f0.y += d_f[q][1]; f0.z += d_f[q][2]; f0.w += d_f[q][3];
-                            *pf = f0;
+                            *reinterpret_cast<float4 *>(rr + 8 + 16 * q + 4 * kk) = f0;
                         }
                     }
                 }
@@ -3529,8 +3551,17 @@ blend_bwd_wide_quarter_kernel(const BlendArgs B) {
             }
         }
         const int slot_mine = ce < nb ? slots[top - ce] : 0;
-        st.load_payload(A, tid);
-        st.load_ids(A, tid, range.x, pos, batch + 2);
+        WIDEQ_STAGE_PAYLOAD();
+        WIDEQ_STAGE_IDS(batch + 2);
+        // the combine's reads of the staged records, in front of its barrier: behind it a fast wave may already park the next
+        // super-batch (two barriers per super-batch, see blend_bwd_sets_quarter_kernel)
+        float4 cg0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float cgC = 0.f, cgo = 0.f;
+        if (cp == 0) {
+            cg0 = s_rec[qpart(ce, 0)];
+            const float4 t_ = s_rec[qpart(ce, 1)];
+            cgC = t_.x; cgo = t_.y;
+        }
         __syncthreads();
         if (ce < nb) {
             const int e = ce;
@@ -3551,8 +3582,8 @@ blend_bwd_wide_quarter_kernel(const BlendArgs B) {
                     s[4] += m2.x + bxw * m.z + byw * m.y + (bxw * byw) * m.x;
                     s[5] += m2.y + 2.f * byw * m.z + (byw * byw) * m.x;
                 }
-                const float4 g0 = s_rec[qpart(e, 0)], g1 = s_rec[qpart(e, 1)];
-                const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y;
+                const float4 g0 = cg0;
+                const float cA = g0.z, cB = g0.w, cC = cgC, o = cgo;
                 const float uc = g0.x - tcx, vc = g0.y - tcy;
                 const float M0 = s[0], Mx = s[1], My = s[2], Mxx = s[3], Mxy = s[4], Myy = s[5];
                 float4 r0;
@@ -3585,13 +3616,14 @@ blend_bwd_wide_quarter_kernel(const BlendArgs B) {
                 }
             }
         }
-        __syncthreads();
     }
     if (A.dbg_T_front) {
         const int px = tx * TILE + lx, py = ty * TILE + ly;
         if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][pixoff(myq)];
     }
 }
+#undef WIDEQ_STAGE_IDS
+#undef WIDEQ_STAGE_PAYLOAD
 
 // ------------------------------------------------------------------ backward of the WIDE part of the renderer's row in its own pass
 // blend_bwd_sets_kernel replays the alpha / T chain once for three sets but needs 255 registers (dL_dout of 23 channels in both
