@@ -210,7 +210,7 @@ class FrameRenderer:
             src["shs"] = sc.shs
         else:
             src["feature"] = sc.feature
-        if mode in ("render_iter", "render_iter_frame"):
+        if mode in ("render_iter", "render_iter_frame", "ref_flow"):
             src["attrs"] = np.random.default_rng(7).uniform(-1, 1, size=(N, 19)).astype(np.float32)
         # stale-1 mode only: two gradient buffers, the all-reduce of step s runs on RCCL's stream while step s+1 fills the other
         self.overlap = bool(stale_overlap) and dist.is_available() and dist.is_initialized()
@@ -235,7 +235,7 @@ class FrameRenderer:
             self.offs = self.frames
         else:
             self.offs = [self.offsets(f) for f in self.frames]
-        if self.mode in ("render_iter", "render_iter_frame"):
+        if self.mode in ("render_iter", "render_iter_frame", "ref_flow"):
             from splatter_a_video_amd.renderer import OrthoEnhancedRenderer
             self.renderer = OrthoEnhancedRenderer(densify_abs_grad_enable=True)
             self.dL_depth = torch.randn(1, self.H, self.W, generator=g).to(device)
@@ -251,6 +251,7 @@ class FrameRenderer:
                     self.parts.append(self._part(lo, hi, N, device, g))
             self.batch = self.parts[0].batch
         self.last = {}
+        self._feat_in = None
 
     @property
     def flat_grad(self):
@@ -347,6 +348,48 @@ class FrameRenderer:
         rgb.backward(rgb_in.grad)
         self.last = dict(M=self.last.get("M", 0), T=((self.W + 15) // 16) * ((self.H + 15) // 16))
 
+    # ------------------------------------------------------------------ the reference's literal call sequence, frame by frame
+    def frames_ref_flow(self):
+        """render_iter exactly as src/pointrix/renderer/dptr_ortho_enhanced.py:270-376 issues it, frame by frame: SH colours per
+        frame, EAGER torch orthographic projection and EWA (tools/eager_ortho.py -- the reference keeps these two steps in
+        torch), gs.compute_cov3d, the SYNCHRONISING gs.sort_gaussian, then three separate blends through autograd
+        (alpha_blending_enhanced K = 20 with the ndc / abs_ndc taps, the depth with bg = 1, the attributes with
+        opacity.detach()).  What an unmodified copy of the reference's renderer file gets from this library."""
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import eager_ortho as eo
+        p = self.p
+        W, H = self.W, self.H
+        for off in self.offs:
+            pos = p["xyz"] + off
+            rgb = gs.compute_sh(p["shs"], 3, self.dirs)
+            uv, depth = eo.project_point_ortho(pos, self.extr, W, H, nearest=0.01)
+            visible = depth != 0
+            cov3d = gs.compute_cov3d(p["scale"], p["rotate"], visible)
+            conic, radius, tiles = eo.ewa_project_ortho(pos, cov3d, self.extr, uv, W, H, visible.squeeze(-1))
+            idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+            ndc = torch.zeros_like(uv, requires_grad=True)
+            abs_ndc = torch.zeros_like(uv, requires_grad=True)
+            img, ncontrib, gs_idx = gs.alpha_blending_enhanced(uv, conic, p["opacity"], rgb, idx, tr, self.sc.bg, W, H, ndc, abs_ndc, K=20)
+            dep = gs.alpha_blending(uv, conic, p["opacity"], depth, idx, tr, 1.0, W, H, ndc.detach())
+            att = gs.alpha_blending(uv, conic, p["opacity"].detach(), p["attrs"], idx, tr, 0.0, W, H, ndc.detach())
+            torch.autograd.backward([img, dep, att], [self.dL_dout, self.dL_depth, self.dL_attr])
+            self.last = dict(M=idx.numel(), T=tr.shape[0])
+
+    def eager_steps_only(self):
+        """the two eager-torch steps of the literal flow alone (projection, cov3d, EWA forward + backward through autograd) for
+        all local frames: what of the --ref-flow frame is framework time rather than this library's kernels"""
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import eager_ortho as eo
+        p = self.p
+        W, H = self.W, self.H
+        for off in self.offs:
+            pos = p["xyz"] + off
+            uv, depth = eo.project_point_ortho(pos, self.extr, W, H, nearest=0.01)
+            visible = depth != 0
+            cov3d = gs.compute_cov3d(p["scale"], p["rotate"], visible)
+            conic, radius, tiles = eo.ewa_project_ortho(pos, cov3d, self.extr, uv, W, H, visible.squeeze(-1))
+            (uv.sum() + depth.sum() + conic.sum()).backward()
+
     # ------------------------------------------------------------------ one frame (round-1 paths)
     def frame(self, off):
         """one frame, forward + backward.  ``frame`` mode: fused per-frame operators whose backward adds the parameter
@@ -359,7 +402,8 @@ class FrameRenderer:
         if self.dynamic:
             from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, frame_preprocess
             g = {k: self.bucket.grad(k) for k in self.p}
-            feat = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"]) if self.use_sh else p["feature"]
+            feat = (self._feat_in if self._feat_in is not None else
+                    gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"]) if self.use_sh else p["feature"])
             uv, depth, conic, radius, tiles, opacity = frame_preprocess(
                 self.clock, off, self.extr, W, H, position=self.position, pos_cubic_node=p["pos_cubic_node"],
                 rotation=p["rotation"], rot_poly_feat=self.rot_poly, rot_fourier_feat=self.rot_fourier,
@@ -367,7 +411,8 @@ class FrameRenderer:
                 grad_sink={k: g[k] for k in ("pos_cubic_node", "rotation", "opacity", "scaling")})
         elif fused:
             g = {k: self.bucket.grad(k) for k in self.p}
-            feat = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"]) if self.use_sh else p["feature"]
+            feat = (self._feat_in if self._feat_in is not None else
+                    gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"]) if self.use_sh else p["feature"])
             uv, depth, conic, radius, tiles = gs.preprocess_ortho(
                 p["xyz"], p["scale"], p["rotate"], self.extr, W, H, nearest=0.01, offset=off,
                 grad_sink={"xyz": g["xyz"], "scales": g["scale"], "uquats": g["rotate"]})
@@ -469,9 +514,21 @@ class FrameRenderer:
             self.frames_render_iter_batched()
         elif self.mode == "render_iter_frame":
             self.frames_render_iter()
+        elif self.mode == "ref_flow":
+            self.frames_ref_flow()
         else:
+            # fused per-frame operators: the SH colours once per step (the view direction is constant, as in the frame batch and
+            # in the native renderer), the frames' colour gradients summed before the one SH backward; the reference's operator
+            # chain (--ops) evaluates them per frame as its renderer does
+            feat = None
+            if self.mode == "frame" and self.use_sh:
+                feat = gs.compute_sh_into(self.p["shs"], 3, self.dirs, None, self.bucket.grad("shs"))
+                self._feat_in = feat.detach().requires_grad_(True)
             for off in self.offs:
                 self.frame(off)
+            if feat is not None:
+                feat.backward(self._feat_in.grad)
+                self._feat_in = None
         if collective and dist.is_available() and dist.is_initialized():
             self.bucket.all_reduce(async_op=self.overlap)     # synchronous unless --stale-overlap
         if self.opt is not None:
@@ -666,7 +723,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    mode = ("render_iter_frame" if a.per_frame else "render_iter") if a.render_iter else "ops" if a.ops else "frame" if a.per_frame else "batch"
+    mode = ("ref_flow" if a.ref_flow else ("render_iter_frame" if a.per_frame else "render_iter") if a.render_iter else "ops" if a.ops
+            else "frame" if a.per_frame else "batch")
     clip = max(a.clip, 25 * world)
     sc = make_scene(a.gaussians, a.width, a.height, F=clip, C=a.channels, seed=1234,
                     clustered=0.7 if a.scene == "clustered" else 0.0)
@@ -796,7 +854,7 @@ def main():
             if cnt:
                 avg = ms / cnt
                 fpl = a.frames / cnt       # frames one launch covers (1 on the per-frame paths, F in the batch)
-                if mode == "render_iter_frame" and n in ("blend_bwd", "blend_pack", "pair_reduce"):
+                if mode in ("render_iter_frame", "ref_flow") and n in ("blend_bwd", "blend_pack", "pair_reduce"):
                     # per-frame renderer: one backward launch per set -> the per-launch figure is the mean over the sets
                     b = sum(kernel_bytes(n, a.gaussians, M, HW, c, T, False, a.frames * 3.0 / cnt) for c in (3, 1, 19)) / 3.0
                 else:
@@ -833,6 +891,12 @@ def main():
                         "ms_per_frame": round(dtf / (a.frames * a.steps) * 1e3, 4),
                         "what": "forward pass alone (SH -> preprocess -> binning -> sort -> compositing), same frames, timed like `value`"}
     stats = R.scene_stats() if rank == 0 else None
+    eager_only = None
+    if mode == "ref_flow":
+        dte = timed(R.eager_steps_only)
+        eager_only = {"ms_per_frame": round(dte / (a.frames * a.steps) * 1e3, 4),
+                      "what": "the flow's two eager-torch steps alone (orthographic projection + EWA, with gs.compute_cov3d between "
+                              "them), forward + backward, timed like `value`: framework kernels, not this library's"}
 
     if stats is not None:
         stats["scene"] = a.scene
@@ -888,7 +952,8 @@ def main():
                                               "synchronous: all-reduce -> Adam -> next forward" if R.opt is not None else
                                               "synchronous all-reduce, no optimiser")
         line = {
-            "metric": "rendered frames/sec fwd+bwd @480p, 300k Gaussians" + (" (render_iter: three blends, 23 channels)" if mode.startswith("render_iter") else ""),
+            "metric": "rendered frames/sec fwd+bwd @480p, 300k Gaussians" + (" (render_iter: three blends, 23 channels)"
+                                                                             if mode.startswith("render_iter") or mode == "ref_flow" else ""),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -917,6 +982,9 @@ def main():
                                 "dynamic-Gaussian evaluation fused into the per-frame preprocess + gradient sinks" if R.dynamic else
                                 "render_iter of the reference's renderer (rgb enhanced K=20 + depth + 19 attribute channels per "
                                 "frame), native OrthoEnhancedRenderer, per-frame operators" if mode == "render_iter_frame" else
+                                "the reference's LITERAL render_iter call sequence (dptr_ortho_enhanced.py:270-376): eager-torch "
+                                "projection + EWA, compute_cov3d, synchronising sort_gaussian, three separate blends through "
+                                "autograd, frame by frame" if mode == "ref_flow" else
                                 "render_iter of the reference's renderer (rgb enhanced K=20 + depth + 19 attribute channels per frame) "
                                 "as a frame batch: one forward over the 23-channel row, one backward pass for the three feature sets"
                                 if mode == "render_iter" else
@@ -929,7 +997,7 @@ def main():
             "gpu_kernel_ms_per_frame": {"forward": None if fwd_ms is None else round(fwd_ms, 4),
                                         "backward": None if bwd_ms is None else round(bwd_ms, 4),
                                         "optimizer": None if opt_ms is None else round(opt_ms, 4)},
-            "forward_only": forward_only, "scene_stats": stats,
+            "forward_only": forward_only, "eager_steps_only": eager_only, "scene_stats": stats,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c_oracle": cpu_c, "kernels": kernels,
             "extra_lines": extra_lines,
         }
