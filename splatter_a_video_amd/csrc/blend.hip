@@ -1228,14 +1228,17 @@ __device__ __forceinline__ void lds_store2_lane15(float *p, float a, float b) {
 // sum over the four 16-lane rows of a wave (lanes n, n + 16, n + 32, n + 48): two VALU-only swaps (gfx950 v_permlane16_swap /
 // v_permlane32_swap), every lane ends up with the total
 typedef unsigned u32x2_b __attribute__((ext_vector_type(2)));
+// (a swap of (v, v) leaves the even rows' / lower half's values in every lane of the first result and the odd rows' / upper
+// half's in the second: their sum is v + the partner's v in EVERY lane -- no select, and the same two operands as before)
 __device__ __forceinline__ float rows_sum(float v, int lane) {
+    (void)lane;
     {
         const u32x2_b r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        v += __uint_as_float((lane & 16) ? r[0] : r[1]);   // value of lane ^ 16
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);   // + value of lane ^ 16
     }
     {
         const u32x2_b r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        v += __uint_as_float((lane & 32) ? r[0] : r[1]);   // value of lane ^ 32
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);   // + value of lane ^ 32
     }
     return v;
 }
@@ -2041,14 +2044,14 @@ blend_bwd_quarter_kernel(const BlendArgs B) {
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {   // lane groups kk and kk ^ 2 together (one swap); groups 0 and 1 keep a half each
                         const u32x2_b r = __builtin_amdgcn_permlane32_swap(__float_as_uint(dfv[c]), __float_as_uint(dfv[c]), false, false);
-                        fs[c] = dfv[c] + __uint_as_float((lane & 32) ? r[0] : r[1]);
+                        fs[c] = __uint_as_float(r[0]) + __uint_as_float(r[1]);   // own + the value of lane ^ 32, in every lane
                     }
                     if (kk < 2 && j0 + nl < cq[G]) {   // lane group kk: floats 4 kk .. of the moments, 8 + 4 kk .. of the features
                         float4 *rm = reinterpret_cast<float4 *>(slab + row * RW + 4 * kk), *rf = rm + 2;
                         float4 m4 = *rm, f4 = *rf;
                         m4.x += d_mom[0]; m4.y += d_mom[1];
-                        m4.z += d_mom[2] + ((ABS && kk == 1) ? s_ax : 0.f);   // (lane group 1: rows 6, 7 of the moment product are zero)
-                        m4.w += d_mom[3] + ((ABS && kk == 1) ? s_ay : 0.f);
+                        m4.z += ABS ? d_mom[2] + (kk == 1 ? s_ax : 0.f) : d_mom[2];   // (lane group 1: rows 6, 7 of the moment product are zero)
+                        m4.w += ABS ? d_mom[3] + (kk == 1 ? s_ay : 0.f) : d_mom[3];
                         f4.x += fs[0]; f4.y += fs[1]; f4.z += fs[2];
                         *rm = m4;
                         *rf = f4;
@@ -2977,7 +2980,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 //      lane group: kk 0: moments 0-3 | kk 1: Mxy Myy ay(B) | kk 2: sums A (+ ay(A)) | kk 3: sums B; and the feature quads
                 auto half = [&](float v) {
                     const u32x2_b r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-                    return v + __uint_as_float((lane & 32) ? r[0] : r[1]);
+                    return __uint_as_float(r[0]) + __uint_as_float(r[1]);   // own + the value of lane ^ 32, in every lane
                 };
                 s_op = half(s_op); s_tx = half(s_tx); s_ty = half(s_ty);
                 if (ABS) { s_ax = half(s_ax); s_ay = half(s_ay); }
