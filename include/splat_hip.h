@@ -580,6 +580,14 @@ int splat_alpha_blending_backward_batch_sets(int F, int P, int C, const int32_t 
                                              const int32_t *slot_sorted, float *pair_records,
                                              float *pack_scratch, const uint32_t *cull_flags /*NULL or the forward's*/,
                                              float *dbg_T_front, splat_stream_t stream);
+
+/* out[i, 0 .. ncp) = sum of the pair records (stride ncp floats, a multiple of 4; 16-byte aligned) in Gaussian i's slots
+   [goff_incl[i-1], goff_incl[i]) -- any record layout.  With splat_alpha_blending_backward_batch_sets at F = 1 this is the
+   reduction of the single-frame operator gs.alpha_blending_shared (the reference's three blends of render_iter,
+   dptr_ortho_enhanced.py:331-375, as separate operators: gradients w.r.t. uv / conic / opacity / features go back to autograd);
+   the caller slices the summed SETS record.  out [P, ncp] fully written; no atomics. */
+int splat_pair_records_segment_sum(int P, int ncp, const float *pair_records, const int32_t *goff_incl, float *out,
+                                   splat_stream_t stream);
 int splat_frames_gauss_backward_static_sets(int F, int P, int C, int W, int H, int64_t capacity, const float *pair_records,
                                             const int32_t *goff_incl, const int32_t *radius, const float *xyz,
                                             const float *scales, const float *uquats, const float *extr, int accumulate,

@@ -4624,6 +4624,48 @@ extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, con
     return SPLAT_OK;
 }
 
+// Per-Gaussian sums of pair records of ANY layout: out[i, :] = sum of the records in Gaussian i's slots [goff_incl[i-1],
+// goff_incl[i]) (stride `ncp` floats, a multiple of 4).  The SINGLE-FRAME use of splat_alpha_blending_backward_batch_sets
+// (F = 1: the per-frame operator gs.alpha_blending_shared, where the three blends are separate from the projection and the
+// gradients go back to autograd as d uv / d conic / d opacity / d feature): the caller slices the summed SETS record
+// [ux uy ca cb | cc o ax ay | tx ty 0 0 | row channels].  A thread per (Gaussian, 16-byte chunk): the threads of a record read
+// it contiguously.  out is fully written ([P, ncp]); deterministic (slot order).
+namespace {
+__global__ void __launch_bounds__(256)
+records_segment_sum_kernel(int P, int nq, const float4 *__restrict__ rec, const int *__restrict__ goff, float4 *__restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(t / nq), c = (int)(t - (long long)i * nq);
+    if (i >= P) return;
+    const int beg = i > 0 ? goff[i - 1] : 0, end = goff[i];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    int j = beg;
+    for (; j + 1 < end; j += 2) {   // two records in flight
+        const float4 v0 = rec[(size_t)j * nq + c], v1 = rec[(size_t)(j + 1) * nq + c];
+        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+        b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
+    }
+    if (j < end) {
+        const float4 v0 = rec[(size_t)j * nq + c];
+        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    }
+    out[(size_t)i * nq + c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+}  // namespace
+
+extern "C" int splat_pair_records_segment_sum(int P, int ncp, const float *pair_records, const int32_t *goff_incl, float *out,
+                                              splat_stream_t stream) {
+    SPLAT_CHECK_ARG(P >= 0 && ncp >= 4 && ncp % 4 == 0, "bad sizes (the record stride is a multiple of 4 floats)");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(pair_records && goff_incl && out, "null pointer");
+    SPLAT_CHECK_ARG(((uintptr_t)pair_records | (uintptr_t)out) % 16 == 0, "records and out must be 16-byte aligned");
+    const int nq = ncp / 4;
+    const long long threads = (long long)P * nq;
+    SPLAT_LAUNCH("pair_reduce", records_segment_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                 P, nq, (const float4 *)pair_records, goff_incl, (float4 *)out);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
 // The renderer's three blends backward in TWO tile passes that share one pair record (see blend_bwd_attr_kernel): the tap set
 // (<= 3 channels; taps and |taps| always produced) through the narrow matrix-core kernel, then the depth set (the per-frame depth
 // feature [F,P], live opacity) + the detached attribute set (<= 20 channels) through blend_bwd_attr_kernel.  set_bg: HOST

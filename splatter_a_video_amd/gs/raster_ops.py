@@ -8,6 +8,7 @@ alpha_blending_enhanced.py:7-160, alpha_blending_with_bias.py, __init__.py:28-10
 from __future__ import annotations
 
 import ctypes
+import os
 import warnings
 import weakref
 from typing import Optional, Tuple
@@ -397,6 +398,9 @@ class _BlendShared(torch.autograd.Function):
         lib = L.lib()
         duv_t = dconic_t = dop_t = dndc = dabs_t = None
         dfeats = [None] * len(feats)
+        one = _BlendShared._one_pass(ctx, grads)
+        if one is not None:
+            return one
         for s, (f, g) in enumerate(zip(feats, grads[:len(feats)])):
             if g is None:
                 continue
@@ -445,6 +449,71 @@ class _BlendShared(torch.autograd.Function):
             dndc = z(P, 2, device=dev) if has_ndc else None
             dabs_t = z(P, 2, device=dev) if has_abs else None
         return (duv_t, dconic_t, dop_t, None, None, None, None, None, dndc, dabs_t, None, None, None) + tuple(dfeats)
+
+
+def _blend_shared_one_pass(ctx, grads):
+    """The sets' backward in ONE pass of the tile kernels (splat_alpha_blending_backward_batch_sets at F = 1: one replay of the
+    alpha / transmittance chain for the renderer's three blends, dL/dalpha routed per set) + one per-Gaussian sum of the SETS
+    records (splat_pair_records_segment_sum), when the sets fit the one-pass plan (one set per routing group -- taps / live
+    opacity / detached opacity -- of at most 4 / 4 / 20 channels), every set has a gradient and the sort is this package's
+    (pair map + the forward's cull words).  Returns the backward's result tuple, or None: one native backward per set."""
+    import ctypes
+
+    from ..frames import _one_pass_plan, _set_groups
+    W, H, bgs, detach, taps, has_ndc, has_abs, widths = ctx.meta
+    uv, conic, opacity, idx_sorted, tile_range, final_T, ncontrib = ctx.saved_tensors[:7]
+    feats = ctx.saved_tensors[7:]
+    n = len(feats)
+    M = idx_sorted.numel()
+    if ctx.pairmap is None or ctx.flags is None or M == 0 or any(g is None for g in grads[:n]):
+        return None
+    if os.environ.get("SPLAT_SHARED_ONE_PASS", "1") == "0":
+        return None
+    C = sum(widths)
+    meta = tuple((w, bg, d, t) for w, bg, d, t in zip(widths, bgs, detach, taps))
+    plan = _one_pass_plan(meta, list(widths), C)
+    if plan is None:
+        return None
+    c0s, cns, pbg, _, tap_set = plan
+    P, dev = uv.shape[0], uv.device
+    lib = L.lib()
+    groups = _set_groups(meta)
+    fptr, dptr = [0, 0, 0], [0, 0, 0]
+    keep = []
+    for f, g, grp, w in zip(feats, grads[:n], groups, widths):
+        g = L.need(g, "dL_dout")
+        if tuple(g.shape) != (w, H, W):
+            raise ValueError("image gradient of a set must be [c, H, W]")
+        keep.append(g)
+        fptr[grp], dptr[grp] = f.data_ptr(), g.data_ptr()
+    want_abs = 1 if (has_abs and tap_set is not None) else 0
+    ncp = int(lib.splat_blend_sets_pair_stride(C))
+    NG = 12                                        # csrc/common.h SETS_NG: [ux uy ca cb | cc o ax ay | tx ty 0 0 | row channels]
+    assert ncp == (NG + C + 3) // 4 * 4
+    rec = torch.empty(M * ncp, dtype=torch.float32, device=dev)
+    pack = torch.empty(max(P, 1) * int(lib.splat_blend_sets_pack_floats()), dtype=torch.float32, device=dev)
+    i3, f3, p3, l3 = ctypes.c_int32 * 3, ctypes.c_float * 3, ctypes.c_void_p * 3, ctypes.c_int64 * 3
+    pm = ctx.pairmap
+    L.check(lib.splat_alpha_blending_backward_batch_sets(
+        L.ci(1), L.ci(P), L.ci(C), i3(*c0s), i3(*cns), f3(*pbg), L.ptr(uv), L.ptr(conic), L.ptr(opacity), ctypes.c_int64(0),
+        L.ptr(None), ctypes.c_int64(0), p3(*fptr), l3(0, 0, 0), L.ptr(idx_sorted), L.ptr(tile_range), ctypes.c_int64(M), L.ci(W),
+        L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(None), p3(*dptr), L.ci(want_abs), L.ptr(pm.slot_sorted), L.ptr(rec),
+        L.ptr(pack), L.ptr(ctx.flags), L.ptr(_debug_T_front(H, W, dev)), L.stream()))
+    red = torch.empty(P, ncp, dtype=torch.float32, device=dev)
+    L.check(lib.splat_pair_records_segment_sum(L.ci(P), L.ci(ncp), L.ptr(rec), L.ptr(pm.goff), L.ptr(red), L.stream()))
+    half = _half_wh(W, H, dev)
+    duv, dconic = red[:, 0:2].contiguous(), red[:, 2:5].contiguous()
+    dop = red[:, 5].contiguous().reshape(opacity.shape)
+    dndc = (red[:, 8:10] * half[None, :]) if (has_ndc and tap_set is not None) else (torch.zeros(P, 2, device=dev) if has_ndc else None)
+    dabs = (red[:, 6:8] * half[None, :]) if want_abs else (torch.zeros(P, 2, device=dev) if has_abs else None)
+    dfeats = []
+    for grp, w in zip(groups, widths):
+        c0 = NG + c0s[grp]
+        dfeats.append(red[:, c0:c0 + w].contiguous())
+    return (duv, dconic, dop, None, None, None, None, None, dndc, dabs, None, None, None) + tuple(dfeats)
+
+
+_BlendShared._one_pass = staticmethod(_blend_shared_one_pass)
 
 
 def _offsets(widths):

@@ -154,3 +154,45 @@ def test_perspective_renderer_equals_the_reference_sequence():
     for k in pa:
         a, b = pb[k].grad, pa[k].grad
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-5 * float(b.abs().max())), k
+
+
+@pytest.mark.parametrize("abs_tap", [True, False])
+def test_shared_blend_one_pass_backward_equals_one_backward_per_set(abs_tap, monkeypatch):
+    """gs.alpha_blending_shared's backward: ONE pass of the three-set tile kernel at F = 1 + splat_pair_records_segment_sum
+    (the default when the sets fit the one-pass plan) against one native backward per set (SPLAT_SHARED_ONE_PASS=0) -- the
+    reference's three autograd nodes (dptr_ortho_enhanced.py:331-375): same images, every gradient and both taps to summation
+    order"""
+    N, W, H, K = 9000, 192, 128, 20
+    sc = make_scene(N, W, H, seed=25)
+    rng = np.random.default_rng(4)
+    base = dict(position=sc.positions(1), opacity=sc.opacity, scaling=sc.scale, rotation=sc.rotate,
+                rgb=rng.uniform(size=(N, 3)).astype(np.float32), attrs=rng.uniform(-1, 1, size=(N, 19)).astype(np.float32))
+    g = [_t(rng.normal(size=(c, H, W)).astype(np.float32)) for c in (3, 1, 19)]
+    res = []
+    for one_pass in ("1", "0"):
+        monkeypatch.setenv("SPLAT_SHARED_ONE_PASS", one_pass)
+        p = {k: _t(v, True) for k, v in base.items()}
+        uv, depth, conic, radius, tiles = gs.preprocess_ortho(p["position"], p["scaling"], p["rotation"], _t(sc.extr), W, H, nearest=0.01)
+        idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        ndc = torch.zeros_like(uv, requires_grad=True)
+        andc = torch.zeros_like(uv, requires_grad=True) if abs_tap else None
+        out = gs.alpha_blending_shared(uv, conic, p["opacity"], [p["rgb"], depth, p["attrs"]], idx, tr, [0.2, 1.0, 0.0], W, H, ndc, andc,
+                                       K=K, detach_opacity=[False, False, True], taps=[True, False, False])
+        torch.autograd.backward(list(out[:3]), g)
+        torch.cuda.synchronize()
+        r = {k: v.grad.clone() for k, v in p.items()}
+        r.update(tap=ndc.grad.clone(), imgs=[o.detach().clone() for o in out[:3]])
+        if abs_tap:
+            r["abs_tap"] = andc.grad.clone()
+        res.append(r)
+    a, b = res
+    for x, y in zip(a["imgs"], b["imgs"]):
+        assert torch.equal(x, y)
+    for k in b:
+        if k == "imgs":
+            continue
+        d = (a[k] - b[k]).abs()
+        tol = 2e-4 * b[k].abs() + 2e-6 * float(b[k].abs().max()) + 1e-12
+        assert int((d > tol).sum()) <= max(2, d.numel() // 50000), (k, int((d > tol).sum()), float(d.max()))
+        assert bool((d <= 10 * tol).all()), k
+    assert float(a["position"].abs().max()) > 0
