@@ -581,6 +581,25 @@ int splat_alpha_blending_backward_batch_sets(int F, int P, int C, const int32_t 
                                              float *pack_scratch, const uint32_t *cull_flags /*NULL or the forward's*/,
                                              float *dbg_T_front, splat_stream_t stream);
 
+/* splat_alpha_blending_backward_batch_sets with the packed records the FORWARD left for this row (forward_pack: the
+   pack_scratch of splat_alpha_blending_forward_batch_sets -- or of splat_alpha_blending_forward[_flags] at F = 1 -- called
+   with the same C channels, untouched since; F * P * splat_blend_pack_floats(C) floats).  For the reference renderer's own
+   plan (rgb at row channels 0-2 with the taps, depth at channel 3, 19 attributes blended with opacity.detach() at channels
+   4-22: dptr_ortho_enhanced.py:331-375) with the forward's cull words the tile kernel stages those records directly and no
+   packing launch runs; any other plan, or forward_pack = NULL, behaves like splat_alpha_blending_backward_batch_sets
+   (pack_scratch is still required then). */
+int splat_alpha_blending_backward_batch_sets_packed(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
+                                                    const float *set_bg, const float *uv, const float *conic,
+                                                    const float *opacity, int64_t opacity_frame_stride,
+                                                    const float *feature, int64_t feature_frame_stride,
+                                                    const float *const *set_feature, const int64_t *set_feature_fs,
+                                                    const int32_t *idx_sorted, const int32_t *tile_range, int64_t capacity,
+                                                    int W, int H, const float *final_T, const int32_t *ncontrib,
+                                                    const float *dL_dout, const float *const *set_dL, int want_abs,
+                                                    const int32_t *slot_sorted, float *pair_records, float *pack_scratch,
+                                                    const uint32_t *cull_flags, float *dbg_T_front, const float *forward_pack,
+                                                    splat_stream_t stream);
+
 /* out[i, 0 .. ncp) = sum of the pair records (stride ncp floats, a multiple of 4; 16-byte aligned) in Gaussian i's slots
    [goff_incl[i-1], goff_incl[i]) -- any record layout.  With splat_alpha_blending_backward_batch_sets at F = 1 this is the
    reduction of the single-frame operator gs.alpha_blending_shared (the reference's three blends of render_iter,

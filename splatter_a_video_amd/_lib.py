@@ -46,7 +46,7 @@ SYMBOLS = [
     "splat_frames_count", "splat_frames_forward", "splat_frames_backward",
     "splat_frames_gauss_backward_static", "splat_alpha_blending_backward_batch_set", "splat_frames_gauss_backward_static_set",
     "splat_blend_sets_pair_stride", "splat_blend_sets_pack_floats", "splat_alpha_blending_backward_batch_sets",
-    "splat_alpha_blending_forward_batch_sets", "splat_pair_records_segment_sum",
+    "splat_alpha_blending_forward_batch_sets", "splat_pair_records_segment_sum", "splat_alpha_blending_backward_batch_sets_packed",
     "splat_frames_gauss_backward_static_sets", "splat_frames_gauss_backward_dynamic_sets",
     "splat_preprocess_forward_batch_cam", "splat_frames_gauss_backward_static_cam", "splat_frames_gauss_backward_static_sets_cam",
     "splat_preprocess_persp_forward", "splat_preprocess_persp_backward",

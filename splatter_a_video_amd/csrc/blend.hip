@@ -2602,9 +2602,13 @@ struct SetsQCfg {
 // STD: the renderer's own plan -- rgb (3 channels, taps) at row channels 0-2, the depth at channel 3, 19 detached attributes
 // at channels 4-22 -- whose channel gradients the combine stores as whole float4 (record chunk 3 = slots 0 1 2 4, chunks 4 .. 8 =
 // slots 8 .. 27); other plans route every slot to its channel with scalar stores.
-template <bool ABS, bool STD>
+// FWDREC (with STD): the records the FORWARD packed for this row (Rec<24>: [u v A B | C o . id | channels 0 .. 22 .], 32 floats)
+// are staged directly -- the park scatters a record's channels to their transposed slot positions -- so the backward needs no
+// packing launch of its own (17 us per frame at c2) and gathers 128 instead of 192 bytes per entry.
+template <bool ABS, bool STD, bool FWDREC = false>
 __global__ void __launch_bounds__(256, BLEND_SETS_MINW)
 blend_bwd_sets_quarter_kernel(const BlendArgs B) {
+    static_assert(!FWDREC || STD, "the forward's records are only understood for the renderer's own plan");
     using Cfg = SetsQCfg;
     constexpr int CH = Cfg::CH, SB = Cfg::SB, NG = Cfg::NG, NK = Cfg::NK, NA = Cfg::NA, PS = Cfg::PS, CAP = Cfg::CAP, RW = Cfg::RW, RQ = Cfg::RQ;
     constexpr int RQL = Cfg::RQL;
@@ -2693,6 +2697,9 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         const int wmax = wave_max_i(last);
         if (lane == 0) s_wmax[w] = wmax;
     }
+    if (FWDREC) {   // the park writes a record's channels float by float: the slots no channel maps to and the padding stay zero
+        for (int c = tid; c < SB * RQL; c += 256) s_rec[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (tid < RQL) s_rec[qpart(SB, tid)] = make_float4(tid == 10 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);   // inert slot SB: q0 = log2(0)
     // ---- dL_dout of the wave's pixels into registers in both MFMA operand layouts, 32 pixels (two quarters) at a time
     float hcg[4][NK], hft[16][NA];
@@ -2760,10 +2767,10 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     // (past the list the quad loads Gaussian 0's record: staged entries >= nb are in no list and the combine skips them)
 #define SETSQ_STAGE_PAYLOAD()                                                                                                   \
     do {                                                                                                                        \
-        const float4 *src_ = reinterpret_cast<const float4 *>(A.pack + (size_t)imax_(sid_next, 0) * Rec<CH>::RS) + sp;          \
+        const float4 *src_ = reinterpret_cast<const float4 *>(A.pack + (size_t)imax_(sid_next, 0) * (FWDREC ? 32 : Rec<CH>::RS)) + sp; \
         sv0 = src_[0];                                                                                                          \
         sv1 = src_[4];                                                                                                          \
-        if (sp < 2) sv2 = src_[8];                                                                                              \
+        if (!FWDREC && sp < 2) sv2 = src_[8];                                                                                   \
     } while (0)
     SETSQ_STAGE_IDS(0);
     SETSQ_STAGE_PAYLOAD();
@@ -2788,9 +2795,20 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
             const PowerCoef pc = power_coeffs(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, tcx, tcy);
             const float ut = g0.x - tcx, vt = g0.y - tcy;
             float4 *rb = s_rec + se * RQL;
-            rb[sp] = mine;                                // parts 0 .. 3
-            rb[4 + sp] = sv1;                             // parts 4 .. 7
-            if (sp < 2) rb[8 + sp] = sv2;                 // parts 8, 9
+            if (FWDREC) {
+                // forward record: parts 0 1 = geometry, part 2 = r g b depth, part 3 = attributes 0-3, parts 4 + sp = attributes
+                // 4 + 4 sp ..; channel -> slot (rgb 0-2 | depth 4 | attribute a 8 + a) -> float sets_fpos(slot)
+                float *rf = reinterpret_cast<float *>(rb);
+                if (sp < 2) rb[sp] = mine;
+                else if (sp == 2) { rf[8] = mine.x; rf[16] = mine.y; rf[24] = mine.z; rf[9] = mine.w; }
+                else { rf[10] = mine.x; rf[18] = mine.y; rf[26] = mine.z; rf[34] = mine.w; }
+                rf[11 + sp] = sv1.x; rf[19 + sp] = sv1.y; rf[27 + sp] = sv1.z;   // slots 12 + 4 sp + i at 11 + sp + 8 i
+                if (sp < 3) rf[35 + sp] = sv1.w;                                   // (sp 3: channel 23 is the record's padding -> slot 27 stays zero)
+            } else {
+                rb[sp] = mine;                                // parts 0 .. 3
+                rb[4 + sp] = sv1;                             // parts 4 .. 7
+                if (sp < 2) rb[8 + sp] = sv2;                 // parts 8, 9
+            }
             float4 qv;                                    // Q[sp] = (q1 q2 lx ly)[sp]
             qv.x = sp == 0 ? pc.q0 : sp == 1 ? pc.qx : sp == 2 ? pc.qy : pc.qxx;
             qv.y = sp == 0 ? pc.qxy : sp == 1 ? pc.qyy : 0.f;
@@ -4542,22 +4560,22 @@ extern "C" int splat_alpha_blending_backward_batch_set(int F, int P, int C, int 
 extern "C" size_t splat_blend_sets_pair_stride(int C) { return (size_t)PAIR_STRIDE(SetsCfg::NG + C); }
 extern "C" size_t splat_blend_sets_pack_floats(void) { return (size_t)Rec<SetsCfg::CH>::RS; }
 
-extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
-                                                        const float *set_bg, const float *uv, const float *conic,
-                                                        const float *opacity, int64_t opacity_frame_stride,
-                                                        const float *feature, int64_t feature_frame_stride,
-                                                        const float *const *set_feature, const int64_t *set_feature_fs,
-                                                        const int32_t *idx_sorted, const int32_t *tile_range,
-                                                        int64_t capacity, int W, int H, const float *final_T,
-                                                        const int32_t *ncontrib, const float *dL_dout,
-                                                        const float *const *set_dL, int want_abs,
-                                                        const int32_t *slot_sorted, float *pair_records,
-                                                        float *pack_scratch, const uint32_t *cull_flags,
-                                                        float *dbg_T_front, splat_stream_t stream) {
+static int backward_batch_sets_impl(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
+                                    const float *set_bg, const float *uv, const float *conic,
+                                    const float *opacity, int64_t opacity_frame_stride,
+                                    const float *feature, int64_t feature_frame_stride,
+                                    const float *const *set_feature, const int64_t *set_feature_fs,
+                                    const int32_t *idx_sorted, const int32_t *tile_range,
+                                    int64_t capacity, int W, int H, const float *final_T,
+                                    const int32_t *ncontrib, const float *dL_dout,
+                                    const float *const *set_dL, int want_abs,
+                                    const int32_t *slot_sorted, float *pair_records,
+                                    float *pack_scratch, const uint32_t *cull_flags,
+                                    float *dbg_T_front, const float *forward_pack, splat_stream_t stream) {
     SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= SetsCfg::CH && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 28)");
     SPLAT_CHECK_ARG(set_c0 && set_cn && set_bg, "null set table");
     SPLAT_CHECK_ARG(uv && conic && opacity && idx_sorted && tile_range && final_T && ncontrib && slot_sorted && pair_records &&
-                        pack_scratch,
+                        (pack_scratch || forward_pack),
                     "null pointer");
     SPLAT_CHECK_ARG(feature || (set_feature && set_feature_fs), "features: the row [F,P,C] or the sets' own tensors");
     SPLAT_CHECK_ARG(dL_dout || set_dL, "image gradient: the row [F,C,H,W] or the sets' own tensors");
@@ -4604,13 +4622,24 @@ extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, con
         SPLAT_CHECK_ARG((!set_cn[0] || A.sdl0) && (!set_cn[1] || A.sdl1) && (!set_cn[2] || A.sdl2), "null set gradient pointer");
     }
     hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(T * F)), block(256);
+    // the renderer's own plan (rgb 0-2 | depth 3 | 19 attributes 4-22): channel gradients stored as whole float4
+    const bool std_plan = C == 23 && set_c0[0] == 0 && set_cn[0] == 3 && set_c0[1] == 3 && set_cn[1] == 1 && set_c0[2] == 4 &&
+                          set_cn[2] == 19 && sets_std_plan_enabled();
+    if (forward_pack && std_plan && A.cull_flags && bwd_use_quarters()) {
+        // the forward's packed records of this row (splat_alpha_blending_forward_batch_sets / _forward with C = 23: 32 floats per
+        // Gaussian and frame) are staged directly: no packing launch
+        A.pack = const_cast<float *>(forward_pack);
+        A.pack_fs = (long long)P * 32;
+        if (want_abs) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, true, true>), grid, block, 0, s, A);
+        else SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<false, true, true>), grid, block, 0, s, A);
+        SPLAT_POST_LAUNCH();
+        return SPLAT_OK;
+    }
+    SPLAT_CHECK_ARG(pack_scratch, "pack_scratch is needed: the forward's records do not serve this plan / these kernels");
     SPLAT_LAUNCH("blend_pack", pack_sets_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)F), dim3(256), 0, s, A);
     SPLAT_POST_LAUNCH();
-    const dim3 grid((unsigned)(T * F)), block(256);
     if (A.cull_flags && bwd_use_quarters()) {   // quarter lists (the forward's quarter bits)
-        // the renderer's own plan (rgb 0-2 | depth 3 | 19 attributes 4-22): channel gradients stored as whole float4
-        const bool std_plan = C == 23 && set_c0[0] == 0 && set_cn[0] == 3 && set_c0[1] == 3 && set_cn[1] == 1 && set_c0[2] == 4 &&
-                              set_cn[2] == 19 && sets_std_plan_enabled();
         if (want_abs) {
             if (std_plan) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, true>), grid, block, 0, s, A);
             else SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, false>), grid, block, 0, s, A);
@@ -4622,6 +4651,48 @@ extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, con
     else SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_kernel<false>, grid, block, 0, s, A);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
+}
+
+extern "C" int splat_alpha_blending_backward_batch_sets(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
+                                                        const float *set_bg, const float *uv, const float *conic,
+                                                        const float *opacity, int64_t opacity_frame_stride,
+                                                        const float *feature, int64_t feature_frame_stride,
+                                                        const float *const *set_feature, const int64_t *set_feature_fs,
+                                                        const int32_t *idx_sorted, const int32_t *tile_range,
+                                                        int64_t capacity, int W, int H, const float *final_T,
+                                                        const int32_t *ncontrib, const float *dL_dout,
+                                                        const float *const *set_dL, int want_abs,
+                                                        const int32_t *slot_sorted, float *pair_records,
+                                                        float *pack_scratch, const uint32_t *cull_flags,
+                                                        float *dbg_T_front, splat_stream_t stream) {
+    return backward_batch_sets_impl(F, P, C, set_c0, set_cn, set_bg, uv, conic, opacity, opacity_frame_stride, feature,
+                                    feature_frame_stride, set_feature, set_feature_fs, idx_sorted, tile_range, capacity, W, H,
+                                    final_T, ncontrib, dL_dout, set_dL, want_abs, slot_sorted, pair_records, pack_scratch,
+                                    cull_flags, dbg_T_front, nullptr, stream);
+}
+
+// The same with the packed records the FORWARD left for this row (`forward_pack`: the pack_scratch of
+// splat_alpha_blending_forward_batch_sets / splat_alpha_blending_forward[_flags] called with the same C = 23 channels, F * P * 32
+// floats, untouched since): for the renderer's own plan (rgb at channels 0-2 with the taps, the depth at channel 3, 19 detached
+// attributes at channels 4-22) with the forward's cull words the tile kernel stages them directly and no packing launch runs;
+// any other plan (or forward_pack = NULL) behaves like splat_alpha_blending_backward_batch_sets.
+extern "C" int splat_alpha_blending_backward_batch_sets_packed(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
+                                                               const float *set_bg, const float *uv, const float *conic,
+                                                               const float *opacity, int64_t opacity_frame_stride,
+                                                               const float *feature, int64_t feature_frame_stride,
+                                                               const float *const *set_feature, const int64_t *set_feature_fs,
+                                                               const int32_t *idx_sorted, const int32_t *tile_range,
+                                                               int64_t capacity, int W, int H, const float *final_T,
+                                                               const int32_t *ncontrib, const float *dL_dout,
+                                                               const float *const *set_dL, int want_abs,
+                                                               const int32_t *slot_sorted, float *pair_records,
+                                                               float *pack_scratch, const uint32_t *cull_flags,
+                                                               float *dbg_T_front, const float *forward_pack,
+                                                               splat_stream_t stream) {
+    return backward_batch_sets_impl(F, P, C, set_c0, set_cn, set_bg, uv, conic, opacity, opacity_frame_stride, feature,
+                                    feature_frame_stride, set_feature, set_feature_fs, idx_sorted, tile_range, capacity, W, H,
+                                    final_T, ncontrib, dL_dout, set_dL, want_abs, slot_sorted, pair_records, pack_scratch,
+                                    cull_flags, dbg_T_front, forward_pack, stream);
 }
 
 // Per-Gaussian sums of pair records of ANY layout: out[i, :] = sum of the records in Gaussian i's slots [goff_incl[i-1],

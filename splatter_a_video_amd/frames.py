@@ -642,13 +642,18 @@ def _blend_sets_backward_one_pass(fb, meta, state, grads, opacity, op_fs, want_a
         dl[grp] = t.data_ptr()
     from .gs.raster_ops import _debug_T_front
     rec = fb._set_buffer(("rec", "sets"), F * cap * int(lib.splat_blend_sets_pair_stride(C)))
-    pack = fb._set_buffer(("pack", "sets"), F * P * int(lib.splat_blend_sets_pack_floats()))
-    L.check(lib.splat_alpha_blending_backward_batch_sets(
+    # the renderer's own plan (rgb 0-2 with the taps | depth 3 | 19 detached attributes 4-22): the tile kernel stages the records
+    # the FORWARD packed (fb.pack) -- no packing launch, no second record array; other plans pack their own
+    c0s, cns = plan[0], plan[1]
+    std = (C == 23 and list(c0s) == [0, 3, 4] and list(cns) == [3, 1, 19] and os.environ.get("SPLAT_SETS_STD", "1") != "0"
+           and os.environ.get("SPLAT_BWD_QUARTERS", "1") != "0" and os.environ.get("SPLAT_SETS_FWDREC", "1") != "0")
+    pack = None if std else fb._set_buffer(("pack", "sets"), F * P * int(lib.splat_blend_sets_pack_floats()))
+    L.check(lib.splat_alpha_blending_backward_batch_sets_packed(
         L.ci(F), L.ci(P), L.ci(C), tabs["c0"], tabs["cn"], tabs["bg"], L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity),
         ctypes.c_int64(op_fs), L.ptr(None), ctypes.c_int64(0), tabs["feat"], tabs["fs"], L.ptr(fb.idx_sorted),
         L.ptr(fb.tile_range), ctypes.c_int64(cap), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(None),
         (ctypes.c_void_p * 3)(*dl), L.ci(want_abs), L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(fb.cull_flags),
-        L.ptr(_debug_T_front(F * H, W, fb.dev)), st))
+        L.ptr(_debug_T_front(F * H, W, fb.dev)), L.ptr(fb.pack if std else None), st))
     return rec
 
 

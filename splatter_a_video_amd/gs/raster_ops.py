@@ -378,6 +378,7 @@ class _BlendShared(torch.autograd.Function):
             L.ptr(tile_range), L.cf(0.0), L.ptr(bgc), L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(final_T),
             L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.ptr(flags), L.stream()))
         ctx.flags = flags
+        ctx.fwd_pack = pack if flags is not None else None   # the forward's packed records: the one-pass backward stages them
         ctx.meta = (int(W), int(H), tuple(float(b) for b in bgs), tuple(bool(d) for d in detach_opacity),
                     tuple(bool(t) for t in taps), ndc is not None, abs_ndc is not None, widths)
         ctx.save_for_backward(uv, conic, opacity, idx_sorted, tile_range, final_T, ncontrib, *feats)
@@ -491,14 +492,17 @@ def _blend_shared_one_pass(ctx, grads):
     NG = 12                                        # csrc/common.h SETS_NG: [ux uy ca cb | cc o ax ay | tx ty 0 0 | row channels]
     assert ncp == (NG + C + 3) // 4 * 4
     rec = torch.empty(M * ncp, dtype=torch.float32, device=dev)
-    pack = torch.empty(max(P, 1) * int(lib.splat_blend_sets_pack_floats()), dtype=torch.float32, device=dev)
+    std = (C == 23 and list(c0s) == [0, 3, 4] and list(cns) == [3, 1, 19] and ctx.fwd_pack is not None
+           and os.environ.get("SPLAT_SETS_STD", "1") != "0" and os.environ.get("SPLAT_BWD_QUARTERS", "1") != "0"
+           and os.environ.get("SPLAT_SETS_FWDREC", "1") != "0")
+    pack = None if std else torch.empty(max(P, 1) * int(lib.splat_blend_sets_pack_floats()), dtype=torch.float32, device=dev)
     i3, f3, p3, l3 = ctypes.c_int32 * 3, ctypes.c_float * 3, ctypes.c_void_p * 3, ctypes.c_int64 * 3
     pm = ctx.pairmap
-    L.check(lib.splat_alpha_blending_backward_batch_sets(
+    L.check(lib.splat_alpha_blending_backward_batch_sets_packed(
         L.ci(1), L.ci(P), L.ci(C), i3(*c0s), i3(*cns), f3(*pbg), L.ptr(uv), L.ptr(conic), L.ptr(opacity), ctypes.c_int64(0),
         L.ptr(None), ctypes.c_int64(0), p3(*fptr), l3(0, 0, 0), L.ptr(idx_sorted), L.ptr(tile_range), ctypes.c_int64(M), L.ci(W),
         L.ci(H), L.ptr(final_T), L.ptr(ncontrib), L.ptr(None), p3(*dptr), L.ci(want_abs), L.ptr(pm.slot_sorted), L.ptr(rec),
-        L.ptr(pack), L.ptr(ctx.flags), L.ptr(_debug_T_front(H, W, dev)), L.stream()))
+        L.ptr(pack), L.ptr(ctx.flags), L.ptr(_debug_T_front(H, W, dev)), L.ptr(ctx.fwd_pack if std else None), L.stream()))
     red = torch.empty(P, ncp, dtype=torch.float32, device=dev)
     L.check(lib.splat_pair_records_segment_sum(L.ci(P), L.ci(ncp), L.ptr(rec), L.ptr(pm.goff), L.ptr(red), L.stream()))
     half = _half_wh(W, H, dev)

@@ -216,3 +216,32 @@ def test_operators_run_on_a_non_default_stream():
         img = gs.alpha_blending(uv, conic, q["opacity"], q["feature"], idx, tr, 0.1, W, H)
         s.synchronize()
         assert torch.equal(img, ref["out"][0])
+
+
+def test_three_set_backward_from_the_forwards_records_is_bit_identical(monkeypatch):
+    """the three-set tile kernel staging the records the FORWARD packed (default for the renderer's own plan: no packing launch
+    in the backward) against the same kernel on its own packed records (SPLAT_SETS_FWDREC=0): the same staged values, the same
+    arithmetic -- bit-identical gradients and taps"""
+    N, W, H, F, K = 30000, 320, 240, 3, 20
+    sc = make_scene(N, W, H, seed=23)
+    rng = np.random.default_rng(6)
+    off = _t(_offsets(sc, F))
+    base = dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity, rgb=rng.uniform(size=(N, 3)).astype(np.float32),
+                attrs=rng.uniform(-1, 1, size=(N, 19)).astype(np.float32))
+    gr = [_t(rng.normal(size=(F, c, H, W)).astype(np.float32)) for c in (3, 1, 19)]
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SPLAT_SETS_FWDREC", flag)
+        p = {k: _t(v, True) for k, v in base.items()}
+        B = FrameBatch(F, N, W, H, 23, "cuda", want_abs=True)
+        sets = [dict(feature=p["rgb"], bg=0.1, taps=True), dict(feature="depth", bg=1.0),
+                dict(feature=p["attrs"], bg=0.0, detach_opacity=True)]
+        o = B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], sets, off, _t(sc.extr), K=K)
+        torch.autograd.backward(list(o[:3]), gr)
+        torch.cuda.synchronize()
+        r = {k: v.grad.clone() for k, v in p.items()}
+        r.update(tap=B.tap.clone(), abs_tap=B.abs_tap.clone())
+        res.append(r)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+    assert float(res[0]["attrs"].abs().max()) > 0
