@@ -736,7 +736,8 @@ frame_preprocess_fwd_batch_kernel(int F, int P, int I, int layout, const DynTab 
 // sigmoid, position = base + cubic segment.  Everything accumulates in registers; the spline segment's four coefficient
 // rows are flushed when the walk leaves the segment (frames of a batch are time-ordered: a handful of flushes).
 #ifndef GAUSS_DYN_MINW
-#define GAUSS_DYN_MINW 4
+#define GAUSS_DYN_MINW 3   // 168 registers, no scratch (4: 128 registers and 156 bytes of scratch per lane -- 62 vs 54 us per frame for the
+                           // three-set records at c2, round 4)
 #endif
 struct GaussDynArgs {
     int F, P, W, H, I, layout;
