@@ -2,10 +2,17 @@
 # GPU box: everything the round's measurement record needs, in one gpurun call.
 #   tools/round_profile.sh <tag>        (writes gpurun_out/<tag>/...)
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r03}
+TAG=${1:-r04}
 export PYTHONPATH=$GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 mkdir -p $O
+python - <<PY > $O/stamp.json
+import json, sys
+sys.path.insert(0, "tools")
+from stamp import stamp
+print(json.dumps(stamp(), indent=1))
+PY
+cat $O/stamp.json
 run() { name=$1; shift; timeout 400 python bench.py "$@" < /dev/null 2> $O/$name.err | tail -1 > $O/$name.json; cut -c1-160 $O/$name.json; }
 timeout 900 python -m pytest tests -m gpu -q < /dev/null > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 run bench_line                                   # default: frame batch, synchronous step with Adam, CPU baselines
@@ -20,6 +27,7 @@ run bench_render_iter_per_frame --render-iter --per-frame --no-cpu-baseline
 run bench_render_iter_dynamic --render-iter --dynamic --no-cpu-baseline   # the reference's real training frame
 SPLAT_SETS_TWO_PASS=1 run bench_render_iter_dynamic_two_pass --render-iter --dynamic --no-cpu-baseline
 run bench_clustered --scene clustered --no-cpu-baseline --no-extra-lines   # 70 % of the Gaussians in blobs covering 10 % of the image
+run bench_ref_flow --ref-flow --steps 3 --warmup 1 --no-cpu-baseline      # the reference's literal render_iter call sequence (eager projection + EWA)
 # kernel trace of the default bench command (2 timed steps of 25 frames)
 export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-extra-lines"
@@ -41,4 +49,5 @@ BC="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --scene clustered --no
 bash tools/pmc_run.sh ${TAG}_c1 "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA" $BC < /dev/null > /dev/null
 bash tools/pmc_run.sh ${TAG}_c3 "SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE" $BC < /dev/null > /dev/null
 PMC_CONFIG="300000x854x480x0:batch:morton:clustered" PMC_SOURCE="rocprofv3 --pmc, two passes over one step of bench.py --scene clustered, per launch, summed over the 8 XCDs" python tools/pmc_blend_counters.py $O/pmc_blend_counters_clustered.json gpurun_out/pmc_${TAG}_c1 gpurun_out/pmc_${TAG}_c3
+bash tools/round_profile_render_iter.sh $TAG > $O/render_iter_profile.log 2>&1; tail -4 $O/render_iter_profile.log
 ls $O
