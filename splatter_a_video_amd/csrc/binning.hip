@@ -25,6 +25,10 @@
 #ifndef BIN_CHUNK
 #define BIN_CHUNK 512           // Gaussians per row (chunk) before BIN_MAX_NB caps the row count
 #endif
+#ifndef BIN_CHUNK_BATCH
+#define BIN_CHUNK_BATCH 2048    // ... in a frame batch of at least BIN_BATCH_FRAMES frames (see make_plan)
+#endif
+#define BIN_BATCH_FRAMES 4
 #define BIN_LDS_TILES 12288     // <= 48 KB of LDS counters; larger tile grids use global atomics
 #define BIN_GLOBAL_BLOCKS 2048   // grid of K1/K3 on the global-atomic path
 #define SORT_BLOCK 256
@@ -43,7 +47,12 @@ struct BinPlan {
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
-static BinPlan make_plan(int P, int W, int H) {
+// F: frames of the launch.  The scratch LAYOUT (offsets, bytes per frame: what splat_bin_scratch_bytes reports) is that of the
+// single-frame plan whatever F is; a frame batch (F >= BIN_BATCH_FRAMES) only uses FEWER, larger chunks of it: with grid.y = F
+// there are workgroups enough, and every row less is 2 T counters less for bin_count to write, bin_colscan to scan and
+// bin_scatter's workgroups to load (c2, 25 frames: count + scans + scatter 14.0 -> 11.8 us per frame; a single frame needs the
+// small chunks: 512 workgroups are all it has).
+static BinPlan make_plan(int P, int W, int H, int F = 1) {
     BinPlan p;
     p.gx = (W + TILE - 1) / TILE;
     p.gy = (H + TILE - 1) / TILE;
@@ -53,17 +62,24 @@ static BinPlan make_plan(int P, int W, int H) {
     if (nb < 1) nb = 1;
     if (nb > BIN_MAX_NB) nb = BIN_MAX_NB;
     if (!p.lds) nb = 1;  // global-atomic path keeps a single row
+    const int nb_layout = nb;
+    if (p.lds && F >= BIN_BATCH_FRAMES) {
+        int nbb = (P + BIN_CHUNK_BATCH - 1) / BIN_CHUNK_BATCH;
+        if (nbb < 1) nbb = 1;
+        if (nbb < nb) nb = nbb;
+    }
     p.NB = nb;
     p.chunk = (P + nb - 1) / nb;
     if (p.chunk < 1) p.chunk = 1;
     size_t o = 0;
-    p.off_matrix = o; o += (size_t)(p.NB < 2 ? 2 : p.NB) * p.T * sizeof(int);  // global path: [counts, fill]
+    p.off_matrix = o; o += (size_t)(nb_layout < 2 ? 2 : nb_layout) * p.T * sizeof(int);  // global path: [counts, fill]
     o = (o + 255) & ~(size_t)255;
     p.off_tilecount = o; o += (size_t)p.T * sizeof(int);
     o = (o + 255) & ~(size_t)255;
     p.off_total = o; o += 256;
     p.nchunk = p.lds ? p.NB : imax(1, imin((P + BIN_BLOCK - 1) / BIN_BLOCK, BIN_GLOBAL_BLOCKS));
-    p.off_chunksum = o; o += (size_t)(p.nchunk + 1) * sizeof(int);  // pairs per chunk -> exclusive chunk offsets
+    const int nchunk_layout = p.lds ? nb_layout : p.nchunk;
+    p.off_chunksum = o; o += (size_t)(nchunk_layout + 1) * sizeof(int);  // pairs per chunk -> exclusive chunk offsets
     o = (o + 255) & ~(size_t)255;
     p.bytes = o;
     return p;
@@ -559,7 +575,7 @@ extern "C" size_t splat_bin_scratch_bytes(int P, int W, int H) {
 
 static int bin_count_impl(int F, int P, const float *uv, const int32_t *radius, int W, int H, void *scratch,
                           int32_t *tile_range, int32_t *M_out, int32_t *gcount, hipStream_t s) {
-    const BinPlan p = make_plan(P, W, H);
+    const BinPlan p = make_plan(P, W, H, F);
     const long long S = (long long)(p.bytes / sizeof(int));
     char *base = (char *)scratch;
     int *matrix = (int *)(base + p.off_matrix);
@@ -598,7 +614,7 @@ static int bin_sort_impl(int F, int P, const float *uv, const float *depth, cons
                          void *scratch, int32_t *tile_range, int64_t capacity, uint64_t *keys, int32_t *idx_sorted,
                          int32_t *overflow_out, int32_t *goff_incl, int32_t *owner_scratch, int32_t *slot_sorted,
                          hipStream_t s) {
-    const BinPlan p = make_plan(P, W, H);
+    const BinPlan p = make_plan(P, W, H, F);
     const long long S = (long long)(p.bytes / sizeof(int));
     char *base = (char *)scratch;
     int *matrix = (int *)(base + p.off_matrix);
