@@ -361,7 +361,21 @@ __device__ __forceinline__ u64 lane_xor_key(u64 k, int lane) {
 template <int R, int D>
 __device__ __forceinline__ void xthread_stage(u64 (&k)[R], int t, bool up, u64 *xbuf) {
     const bool take_min = ((t & D) == 0) == up;
-    if (D < 64) {
+    if (D == 16 || D == 32) {
+        // a swap of (k, k) leaves the pair's LOWER thread's key in the first result and the upper thread's in the second, in
+        // both threads: the pair's minimum / maximum needs one compare of the two results and no partner select (the generic
+        // form below selects the partner's words first: two selects and two register copies more per key)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned lo = (unsigned)k[r], hi = (unsigned)(k[r] >> 32);
+            const u32x2_t sl = D == 16 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false)
+                                       : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+            const u32x2_t sh = D == 16 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false)
+                                       : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+            const u64 a = ((u64)sh[0] << 32) | sl[0], b = ((u64)sh[1] << 32) | sl[1];   // lower / upper thread of the pair
+            k[r] = ((a < b) == take_min) ? a : b;   // take_min ? min(a, b) : max(a, b)
+        }
+    } else if (D < 64) {
         const int lane = t & 63;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
