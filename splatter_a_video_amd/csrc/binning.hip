@@ -32,6 +32,12 @@
 #define BIN_LDS_TILES 12288     // <= 48 KB of LDS counters; larger tile grids use global atomics
 #define BIN_GLOBAL_BLOCKS 2048   // grid of K1/K3 on the global-atomic path
 #define SORT_BLOCK 256
+#ifndef SORT_SWIZZLE_ALL
+#define SORT_SWIZZLE_ALL 0
+#endif
+#ifndef SORT_SWIZZLE4
+#define SORT_SWIZZLE4 1         // thread distance 4: ds_swizzle (one LDS-crossbar instruction per word) instead of two DPP moves + a select
+#endif
 #define SORT_LDS_KEYS 2048      // 16 KB of LDS per sort workgroup: the exchange buffer of the two widest strides of a 2048-key block
 
 struct BinPlan {
@@ -336,11 +342,18 @@ __device__ __forceinline__ unsigned dpp_u(unsigned v) {
 
 template <int D>
 __device__ __forceinline__ unsigned lane_xor_u(unsigned v, int lane) {
+#if SORT_SWIZZLE_ALL
+    if (D <= 16) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x001F | (D << 10));   // bit mode: xor D inside 32 lanes
+#endif
     if (D == 1) return dpp_u<0xB1>(v);   // quad_perm:[1,0,3,2]
     if (D == 2) return dpp_u<0x4E>(v);   // quad_perm:[2,3,0,1]
     if (D == 4) {                        // inside a row of 16: lanes with bit 2 clear read lane+4, the others lane-4
+#if SORT_SWIZZLE4
+        return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);   // bit mode: and 0x1f, or 0, xor 4 -- the LDS crossbar, no VALU
+#else
         const unsigned up = dpp_u<0x104>(v), dn = dpp_u<0x114>(v);  // row_shl:4 / row_shr:4
         return (lane & 4) ? dn : up;
+#endif
     }
     if (D == 8) return dpp_u<0x128>(v);  // row_ror:8
     if (D == 16) {
@@ -361,7 +374,7 @@ __device__ __forceinline__ u64 lane_xor_key(u64 k, int lane) {
 template <int R, int D>
 __device__ __forceinline__ void xthread_stage(u64 (&k)[R], int t, bool up, u64 *xbuf) {
     const bool take_min = ((t & D) == 0) == up;
-    if (D == 16 || D == 32) {
+    if ((D == 16 && !SORT_SWIZZLE_ALL) || D == 32) {
         // a swap of (k, k) leaves the pair's LOWER thread's key in the first result and the upper thread's in the second, in
         // both threads: the pair's minimum / maximum needs one compare of the two results and no partner select (the generic
         // form below selects the partner's words first: two selects and two register copies more per key)
