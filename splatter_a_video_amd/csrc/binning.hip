@@ -58,6 +58,27 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 // there are workgroups enough, and every row less is 2 T counters less for bin_count to write, bin_colscan to scan and
 // bin_scatter's workgroups to load (c2, 25 frames: count + scans + scatter 14.0 -> 11.8 us per frame; a single frame needs the
 // small chunks: 512 workgroups are all it has).
+static int bits_for(long long n) {  // bits that hold 0 .. n - 1
+    int b = 1;
+    while ((1ll << b) < n) ++b;
+    return b;
+}
+
+// Pair-map keys.  The low key word has to order a tile's equal depths by ascending Gaussian id and to lead the sort to both
+// the Gaussian and its pair slot.  BIN_PACKED_KEYS: the word is (id << kbits) | k, k = index of the tile inside the splat's
+// rectangle (k < T): the sort reads the slot as goff_excl[id] + k from the per-Gaussian prefix the scatter writes anyway
+// (4 P bytes per frame, L2-resident) -- no `owner` array written per pair by the scatter and gathered per pair, at sector
+// granularity, by the sort.  When id and k do not fit 32 bits (1M Gaussians on more than 4096 tiles) the word is the pair
+// slot and `owner` resolves the id as before.  Both forms sort identically (slots grow with (id, k)).
+#ifndef BIN_PACKED_KEYS
+#define BIN_PACKED_KEYS 1
+#endif
+static int pair_key_kbits(int P, int T) {
+    if (!BIN_PACKED_KEYS) return 0;
+    const int kb = bits_for(T), ib = bits_for(P);
+    return kb + ib <= 32 ? kb : 0;
+}
+
 static BinPlan make_plan(int P, int W, int H, int F = 1) {
     BinPlan p;
     p.gx = (W + TILE - 1) / TILE;
@@ -259,7 +280,7 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
                    const int *__restrict__ radius, int gx, int gy, int T, int chunk, int *__restrict__ matrix,
                    const int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
                    int *__restrict__ overflow, int *__restrict__ goff_incl, int *__restrict__ owner,
-                   const int *__restrict__ chunk_off, long long S) {
+                   const int *__restrict__ chunk_off, long long S, int kbits) {
     // Pair-map mode (goff_incl != null): the kernel also produces goff_incl, the inclusive prefix of tiles per
     // Gaussian (chunk offset from K2b + a workgroup scan of the rectangle areas), and the low key word is the pair
     // slot j = goff_excl[i] + k (k-th tile of the splat's rectangle) instead of the Gaussian id: slots grow with
@@ -310,6 +331,20 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
         }
         if (r <= 0) continue;
         const unsigned long long dkey = (unsigned long long)__float_as_uint(depth[i]) << 32;
+        if (goff_incl && kbits) {  // packed pair-map keys: (id << kbits) | k
+            unsigned lo = (unsigned)i << kbits;
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) {
+                    const int t = ty * gx + tx;
+                    int slot;
+                    if (LDS) slot = atomicAdd(&cnt[t], 1);
+                    else slot = tile_range[2 * t] + atomicAdd(&matrix[T + t], 1);
+                    if ((long long)slot < capacity) keys[slot] = dkey | lo;
+                    else *overflow = 1;
+                    ++lo;
+                }
+            continue;
+        }
         for (int ty = y0; ty < y1; ++ty)
             for (int tx = x0; tx < x1; ++tx) {
                 const int t = ty * gx + tx;
@@ -453,9 +488,27 @@ struct BitonicK<R, NP * 2, NP> {
     static __device__ __forceinline__ void run(u64 (&)[R], int, u64 *) {}
 };
 
+// low key word -> (Gaussian id, pair slot) of a sorted entry (pair-map mode; see pair_key_kbits)
+struct PairKey {
+    const int *owner;   // slot keys: Gaussian of every slot
+    const int *goff;    // packed keys: inclusive prefix of tiles per Gaussian
+    int kbits;
+    long long capacity;
+    __device__ __forceinline__ void resolve(unsigned lo, int &id, int &slot) const {
+        if (kbits) {
+            id = (int)(lo >> kbits);
+            const long long j = (long long)(id > 0 ? goff[id - 1] : 0) + (lo & ((1u << kbits) - 1u));
+            slot = (int)(j < capacity ? j : capacity - 1);   // (only after a flagged overflow)
+        } else {
+            slot = (long long)lo < capacity ? (int)lo : (int)(capacity - 1);
+            id = (long long)lo < capacity ? owner[lo] : 0;
+        }
+    }
+};
+
 template <int R>
-__device__ __forceinline__ void tile_sort_regs(const u64 *g, int n, long long r0, long long capacity, int *idx_sorted,
-                                               const int *owner, int *slot_sorted, u64 *xbuf) {
+__device__ __forceinline__ void tile_sort_regs(const u64 *g, int n, long long r0, const PairKey &pk, int *idx_sorted,
+                                               int *slot_sorted, u64 *xbuf) {
     const int t = threadIdx.x;
     u64 k[R];
 #pragma unroll
@@ -468,12 +521,14 @@ __device__ __forceinline__ void tile_sort_regs(const u64 *g, int n, long long r0
     for (int r = 0; r < R; ++r) {
         const int i = t * R + r;
         if (i < n) {
-            const int lo = (int)(unsigned)(k[r] & 0xffffffffull);
+            const unsigned lo = (unsigned)(k[r] & 0xffffffffull);
             if (slot_sorted) {
-                slot_sorted[r0 + i] = (long long)lo < capacity ? lo : (int)(capacity - 1);
-                idx_sorted[r0 + i] = (long long)lo < capacity ? owner[lo] : 0;
+                int id, slot;
+                pk.resolve(lo, id, slot);
+                slot_sorted[r0 + i] = slot;
+                idx_sorted[r0 + i] = id;
             } else {
-                idx_sorted[r0 + i] = lo;
+                idx_sorted[r0 + i] = (int)lo;
             }
         }
     }
@@ -549,7 +604,8 @@ __device__ __forceinline__ void tile_sort_blocks(volatile u64 *g, int n, u64 *xb
 
 __global__ void __launch_bounds__(SORT_BLOCK)
 tile_sort_kernel(int T, int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
-                 int *__restrict__ idx_sorted, const int *__restrict__ owner, int *__restrict__ slot_sorted) {
+                 int *__restrict__ idx_sorted, const int *__restrict__ owner, int *__restrict__ slot_sorted,
+                 const int *__restrict__ goff_incl, int P, int kbits) {
     __shared__ __attribute__((aligned(16))) unsigned long long sk[SORT_LDS_KEYS];
     // one workgroup per (frame, tile), XCD-aware (xcd_tile: runs of neighbouring tiles on one XCD): neighbouring tiles look
     // up largely the same sectors of `owner` (pair slots are Gaussian-major, a splat touches ~4 tiles); dealt round-robin by
@@ -559,8 +615,9 @@ tile_sort_kernel(int T, int *__restrict__ tile_range, long long capacity, unsign
     {   // frame batch: T tiles per frame
         const size_t f = gtile / T;
         tile_range += f * 2 * T; keys += f * capacity; idx_sorted += f * capacity;
-        if (slot_sorted) { owner += f * capacity; slot_sorted += f * capacity; }
+        if (slot_sorted) { owner += f * capacity; slot_sorted += f * capacity; goff_incl += f * P; }
     }
+    const PairKey pk{owner, goff_incl, kbits, capacity};
     long long r0 = tile_range[2 * t];
     long long r1 = tile_range[2 * t + 1];
     if (r1 > capacity) {  // overflow (already flagged by K3): the range the blend kernels will read never leaves the buffers
@@ -576,19 +633,21 @@ tile_sort_kernel(int T, int *__restrict__ tile_range, long long capacity, unsign
     unsigned long long *g = keys + r0;
     // low key word: Gaussian id, or (pair-map mode) the pair slot whose owner is the Gaussian id
     if (n <= 4 * SORT_BLOCK) {
-        tile_sort_regs<4>(g, n, r0, capacity, idx_sorted, owner, slot_sorted, sk);
+        tile_sort_regs<4>(g, n, r0, pk, idx_sorted, slot_sorted, sk);
     } else if (n <= 8 * SORT_BLOCK) {
-        tile_sort_regs<8>(g, n, r0, capacity, idx_sorted, owner, slot_sorted, sk);
+        tile_sort_regs<8>(g, n, r0, pk, idx_sorted, slot_sorted, sk);
     } else {
         __syncthreads();
         tile_sort_blocks<8>((volatile u64 *)g, n, sk);
         for (int i = threadIdx.x; i < n; i += SORT_BLOCK) {
-            const int lo = (int)(unsigned)(((volatile u64 *)g)[i] & 0xffffffffull);
+            const unsigned lo = (unsigned)(((volatile u64 *)g)[i] & 0xffffffffull);
             if (slot_sorted) {
-                slot_sorted[r0 + i] = (long long)lo < capacity ? lo : (int)(capacity - 1);
-                idx_sorted[r0 + i] = (long long)lo < capacity ? owner[lo] : 0;
+                int id, slot;
+                pk.resolve(lo, id, slot);
+                slot_sorted[r0 + i] = slot;
+                idx_sorted[r0 + i] = id;
             } else {
-                idx_sorted[r0 + i] = lo;
+                idx_sorted[r0 + i] = (int)lo;
             }
         }
     }
@@ -646,10 +705,11 @@ static int bin_sort_impl(int F, int P, const float *uv, const float *depth, cons
     char *base = (char *)scratch;
     int *matrix = (int *)(base + p.off_matrix);
     const int *chunk_off = (const int *)(base + p.off_chunksum);
+    const int kbits = goff_incl ? pair_key_kbits(P, p.T) : 0;
     if (p.lds) {
         SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<true>, dim3(p.NB, F), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
                      P, (const float2 *)uv, depth, radius, p.gx, p.gy, p.T, p.chunk, matrix, tile_range,
-                     (long long)capacity, (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off, S);
+                     (long long)capacity, (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off, S, kbits);
     } else {
         // fill counters live in tile_count's neighbour: reuse matrix row "1" = matrix + T (allocated: NB=1 -> need 2 rows)
         for (int f = 0; f < F; ++f)
@@ -658,11 +718,11 @@ static int bin_sort_impl(int F, int P, const float *uv, const float *depth, cons
         const int chunk = (P + nblk - 1) / nblk;
         SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<false>, dim3(nblk, F), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
                      depth, radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, tile_range, (long long)capacity,
-                     (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off, S);
+                     (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off, S, kbits);
     }
     SPLAT_POST_LAUNCH();
     SPLAT_LAUNCH("tile_sort", tile_sort_kernel, dim3((unsigned)((size_t)p.T * F)), dim3(SORT_BLOCK), 0, s, p.T, tile_range, (long long)capacity,
-                 (unsigned long long *)keys, idx_sorted, owner_scratch, slot_sorted);
+                 (unsigned long long *)keys, idx_sorted, owner_scratch, slot_sorted, goff_incl, P, kbits);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }
