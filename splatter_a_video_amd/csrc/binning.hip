@@ -445,47 +445,108 @@ __device__ __forceinline__ void xthread_stage(u64 (&k)[R], int t, bool up, u64 *
     }
 }
 
-template <int R, int K, int J>
-__device__ __forceinline__ void bitonic_stage(u64 (&k)[R], int t, u64 *xbuf) {
-    // merge width K, stride J (elements); direction of element i: ascending iff (i & K) == 0
+// ---- the network: every comparator ASCENDS.  A merge of width K starts with the "flip" step (element i against its mirror
+// inside the block of K) and goes on with the strides K/4 .. 1; the lower element keeps the minimum everywhere.  The +inf of the
+// missing tail therefore never moves, and a wave whose 64 R elements all lie past the list (`live` false, wave-uniform) has
+// nothing to do outside the LDS exchanges: a tile of c2 (711 keys of the 1024 a workgroup sorts) runs three waves' worth of
+// compare-exchanges instead of four.
+template <int M>
+__device__ __forceinline__ unsigned lane_mirror_u(unsigned v, int mirror_addr) {   // lane ^ M, M = 2^s - 1
+    if (M == 1) return dpp_u<0xB1>(v);    // quad_perm:[1,0,3,2]
+    if (M == 3) return dpp_u<0x1B>(v);    // quad_perm:[3,2,1,0]
+    if (M == 7) return dpp_u<0x141>(v);   // row_half_mirror
+    if (M == 15) return dpp_u<0x140>(v);  // row_mirror
+    if (M == 31) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x7C1F);   // bit mode: xor 31 inside 32 lanes
+    return (unsigned)__builtin_amdgcn_ds_bpermute(mirror_addr, (int)v);          // the whole wave reversed
+}
+
+// flip step of the merge of width K = D R elements (thread t against thread t ^ (D - 1), register r against R - 1 - r)
+template <int R, int D>
+__device__ __forceinline__ void xthread_flip(u64 (&k)[R], int t, bool live, u64 *xbuf) {
+    const bool lower = (t & (D >> 1)) == 0;
+    if (D <= 64) {
+        if (!live) return;
+        const int mirror_addr = ((t & 63) ^ 63) << 2;
+        u64 p[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const u64 q = k[R - 1 - r];
+            p[r] = ((u64)lane_mirror_u<D - 1>((unsigned)(q >> 32), mirror_addr) << 32) | lane_mirror_u<D - 1>((unsigned)q, mirror_addr);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) k[r] = ((p[r] < k[r]) == lower) ? p[r] : k[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) xbuf[r * SORT_BLOCK + t] = k[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const u64 p = xbuf[(R - 1 - r) * SORT_BLOCK + (t ^ (D - 1))];
+            k[r] = ((p < k[r]) == lower) ? p : k[r];
+        }
+        __syncthreads();
+    }
+}
+
+template <int R, int K>
+__device__ __forceinline__ void flip_stage(u64 (&k)[R], int t, bool live, u64 *xbuf) {
+    if (K <= R) {
+        if (!live) return;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if ((r & (K >> 1)) == 0) {
+                const u64 a = k[r], b = k[r ^ (K - 1)];
+                const bool sw = a > b;
+                k[r] = sw ? b : a;
+                k[r ^ (K - 1)] = sw ? a : b;
+            }
+        }
+    } else {
+        xthread_flip<R, K / R>(k, t, live, xbuf);
+    }
+}
+
+template <int R, int J>
+__device__ __forceinline__ void asc_stage(u64 (&k)[R], int t, bool live, u64 *xbuf) {   // stride J (elements), ascending
     if (J < R) {
+        if (!live) return;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if ((r & J) == 0) {
-                const bool up = (K < R) ? ((r & K) == 0) : (((t * R) & K) == 0);
                 const u64 a = k[r], b = k[r | J];
-                const bool sw = (a > b) == up;
+                const bool sw = a > b;
                 k[r] = sw ? b : a;
                 k[r | J] = sw ? a : b;
             }
         }
     } else {
-        const bool up = ((t * R) & K) == 0;
-        xthread_stage<R, J / R>(k, t, up, xbuf);
+        if (J / R < 64 && !live) return;
+        xthread_stage<R, J / R>(k, t, true, xbuf);
     }
 }
 
-template <int R, int K, int J>
-struct BitonicJ {
-    static __device__ __forceinline__ void run(u64 (&k)[R], int t, u64 *xbuf) {
-        bitonic_stage<R, K, J>(k, t, xbuf);
-        BitonicJ<R, K, J / 2>::run(k, t, xbuf);
+template <int R, int J>
+struct BitonicJ {   // strides J, J / 2 .. 1
+    static __device__ __forceinline__ void run(u64 (&k)[R], int t, bool live, u64 *xbuf) {
+        asc_stage<R, J>(k, t, live, xbuf);
+        BitonicJ<R, J / 2>::run(k, t, live, xbuf);
     }
 };
-template <int R, int K>
-struct BitonicJ<R, K, 0> {
-    static __device__ __forceinline__ void run(u64 (&)[R], int, u64 *) {}
+template <int R>
+struct BitonicJ<R, 0> {
+    static __device__ __forceinline__ void run(u64 (&)[R], int, bool, u64 *) {}
 };
 template <int R, int K, int NP>
-struct BitonicK {
-    static __device__ __forceinline__ void run(u64 (&k)[R], int t, u64 *xbuf) {
-        BitonicJ<R, K, K / 2>::run(k, t, xbuf);
-        BitonicK<R, K * 2, NP>::run(k, t, xbuf);
+struct BitonicK {   // merges of width K, 2 K .. NP
+    static __device__ __forceinline__ void run(u64 (&k)[R], int t, bool live, u64 *xbuf) {
+        flip_stage<R, K>(k, t, live, xbuf);
+        BitonicJ<R, K / 4>::run(k, t, live, xbuf);
+        BitonicK<R, K * 2, NP>::run(k, t, live, xbuf);
     }
 };
 template <int R, int NP>
 struct BitonicK<R, NP * 2, NP> {
-    static __device__ __forceinline__ void run(u64 (&)[R], int, u64 *) {}
+    static __device__ __forceinline__ void run(u64 (&)[R], int, bool, u64 *) {}
 };
 
 // low key word -> (Gaussian id, pair slot) of a sorted entry (pair-map mode; see pair_key_kbits)
@@ -516,7 +577,7 @@ __device__ __forceinline__ void tile_sort_regs(const u64 *g, int n, long long r0
         const int i = t * R + r;
         k[r] = i < n ? g[i] : ~0ull;
     }
-    BitonicK<R, 2, R * SORT_BLOCK>::run(k, t, xbuf);
+    BitonicK<R, 2, R * SORT_BLOCK>::run(k, t, (t & ~63) * R < n, xbuf);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = t * R + r;
@@ -562,7 +623,7 @@ __device__ __forceinline__ void tile_sort_blocks(volatile u64 *g, int n, u64 *xb
     };
     for (int b = 0; b < nblk; ++b) {
         load(b);
-        BitonicK<R, 2, NB>::run(k, t, xbuf);
+        BitonicK<R, 2, NB>::run(k, t, b * NB + (t & ~63) * R < n, xbuf);
         store(b);
     }
     __syncthreads();
@@ -595,7 +656,7 @@ __device__ __forceinline__ void tile_sort_blocks(volatile u64 *g, int n, u64 *xb
         }
         for (int b = 0; b < nblk; ++b) {                 // strides NB / 2 .. 1 of every block, ascending
             load(b);
-            BitonicJ<R, (1 << 30), NB / 2>::run(k, t, xbuf);
+            BitonicJ<R, NB / 2>::run(k, t, b * NB + (t & ~63) * R < n, xbuf);
             store(b);
         }
         __syncthreads();
