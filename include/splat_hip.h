@@ -115,7 +115,8 @@ int splat_bin_count(int P, const float *uv, const int32_t *radius, int W, int H,
  * INCLUSIVE prefix sum of the tiles each Gaussian touches (the scan is fused into the count / scatter kernels: chunk
  * totals in splat_bin_count, chunk offsets + a workgroup scan in the scatter).  Every (Gaussian, tile) pair owns the
  * slot goff_excl[id] + k (k-th tile, row-major inside the splat's tile rectangle); the sort also emits
- * slot_sorted[M] = slot of each sorted entry (owner[M] is workspace: Gaussian id of each slot).  The atomic-free
+ * slot_sorted[M] = slot of each sorted entry (owner[M] is workspace: Gaussian id of each slot -- left untouched when the
+ * Gaussian id and k fit one 32-bit key word together, bits(P) + bits(T) <= 32, which needs no such array).  The atomic-free
  * blend backward consumes goff_incl and slot_sorted. */
 int splat_bin_sort(int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
                    void *scratch, int32_t *tile_range /*in; clamped to the capacity on overflow*/, int64_t capacity, uint64_t *keys,

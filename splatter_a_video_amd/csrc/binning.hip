@@ -11,10 +11,12 @@
 //                   workgroup, rows held in registers), column total -> tile_count[T];
 //   K2b bin_tilescan single workgroup: exclusive scan of tile_count -> tile_range[T,2], M;
 //   K3 bin_scatter  same chunking as K1; LDS counters start at the chunk's base, ds_add_rtn
-//                   hands out the slot; writes key = (depth bits << 32 | gaussian id);
-//   K4 tile_sort    one workgroup per tile: bitonic sort of the tile's keys in registers (<= 2048 keys; crowded
-//                   tiles: 2048-key blocks in registers + the strides of whole blocks through the tile's global
-//                   segment), writes ids (and, in pair-map mode, the Gaussian-major pair slot of every sorted entry).
+//                   hands out the slot; writes key = (depth bits << 32 | gaussian id) -- pair-map mode: the low word
+//                   is (id << kbits | index of the tile in the splat's rectangle), or the pair slot (pair_key_kbits);
+//   K4 tile_sort    one workgroup per tile: all-ascending bitonic network over the tile's keys in registers (<= 2048
+//                   keys; waves whose elements all lie past the list idle; crowded tiles: 2048-key blocks in registers +
+//                   the strides of whole blocks through the tile's global segment), writes ids (and, in pair-map mode,
+//                   the Gaussian-major pair slot of every sorted entry).
 //
 // Since keys inside a tile are unique (id in the low word) the result is deterministic and equals
 // a STABLE sort of the reference keys (ties: ascending Gaussian id).  No host synchronisation.

@@ -1256,7 +1256,7 @@ __device__ __forceinline__ void row_shr1_add4(float (&R)[4], const float (&rs)[4
 }
 
 template <int CH, bool ABS, bool EXACT>
-__global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_MFMA_MINW : (CH <= 20 ? BLEND_WIDE_MINW : 1)))
+__global__ void __launch_bounds__(256, (CH <= 3 ? BLEND_MFMA_MINW : CH <= 8 ? 2 : (CH <= 20 ? BLEND_WIDE_MINW : 1)))   // (8 channels: the registers of two waves per SIMD)
 blend_bwd_mfma_kernel(const BlendArgs B) {
     using Cfg = MfmaCfg<CH, ABS>;
     constexpr int SB = Cfg::SB, NG = Cfg::NG, NC = Cfg::NC, NCP = Cfg::NCP, PW = Cfg::PW, NA = Cfg::NA, NK = Cfg::NK;
@@ -2610,7 +2610,7 @@ __global__ void __launch_bounds__(256, BLEND_SETS_MINW)
 blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     static_assert(!FWDREC || STD, "the forward's records are only understood for the renderer's own plan");
     using Cfg = SetsQCfg;
-    constexpr int CH = Cfg::CH, SB = Cfg::SB, NG = Cfg::NG, NK = Cfg::NK, NA = Cfg::NA, PS = Cfg::PS, CAP = Cfg::CAP, RW = Cfg::RW, RQ = Cfg::RQ;
+    constexpr int CH = Cfg::CH, SB = Cfg::SB, NG = Cfg::NG, NK = Cfg::NK, NA = Cfg::NA, CAP = Cfg::CAP, RW = Cfg::RW, RQ = Cfg::RQ;
     constexpr int RQL = Cfg::RQL;
     static_assert(RQ == 12 && Rec<CH>::CULL == 43 && SB == 64 && CAP * RW >= 32 * CH, "record floats 40-42 are free; the staging of 32 pixels fits a slab");
     __shared__ float4 s_rec[(SB + 1) * RQL];            // staged records (SetsQCfg::RQL parts each), slot SB = inert

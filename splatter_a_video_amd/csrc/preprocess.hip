@@ -365,14 +365,15 @@ struct S2Geo {
 template <int NS>
 __device__ __forceinline__ S2Geo s2_geometry(const float4 (&a)[NS]) {
     S2Geo g;
+    constexpr int I1 = NS > 1 ? 1 : 0;   // (SETS2 records have NS = 3; other instantiations never run this)
     g.tu = quad_bcast<0>(a[0].x); g.tv = quad_bcast<0>(a[0].y);
     g.ux = g.tu + quad_bcast<3>(a[0].x); g.uy = g.tv + quad_bcast<3>(a[0].y);
     g.ca = quad_bcast<0>(a[0].z) + quad_bcast<3>(a[0].z);
     g.cb = quad_bcast<0>(a[0].w) + quad_bcast<3>(a[0].w);
-    g.cc = quad_bcast<1>(a[0].x) + quad_bcast<0>(a[1].x);
-    g.dop = quad_bcast<1>(a[0].y) + quad_bcast<0>(a[1].y);
+    g.cc = quad_bcast<1>(a[0].x) + quad_bcast<0>(a[I1].x);
+    g.dop = quad_bcast<1>(a[0].y) + quad_bcast<0>(a[I1].y);
     g.ax = quad_bcast<1>(a[0].z); g.ay = quad_bcast<1>(a[0].w);
-    g.gdep = quad_bcast<0>(a[1].z);
+    g.gdep = quad_bcast<0>(a[I1].z);
     return g;
 }
 // feature gradients of a SETS2 record: component k -> (set 0 channel k - 8 | set 2 channel k - 19), added into the sets' rows
