@@ -648,16 +648,36 @@ __device__ __forceinline__ void carry_out(TileLDS<CH, SB, COEF, XR, SWZ> &L, Car
 }
 
 // ------------------------------------------------------------------ forward
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int CH>
 struct FwdCfg {
     static constexpr int SB = CH <= 8 ? BLEND_FWD_SB : 128;
 };
 
+// Wide rows (16 .. 32 channels), BLEND_FWD_MFMA: the channel sums F[p, c] += w[p, s] f[s, c] are a product over (pixels x
+// splats x channels) and run on the matrix pipe.  Lane = pixel as before for the alpha / transmittance chain, but the 16 lanes of
+// a DPP row ARE one 4x4 quarter (lane -> pixel map below), a trip evaluates four survivors of the quarter's list, and a 4x4
+// transpose of the four weight registers across the rows (two v_permlane32_swap + two v_permlane16_swap) yields the A operand
+// of every quarter at once: A_g[m = pixel i of quarter g][k = trip] in lane 16 k + i.  B_g[k][n] = channel n of quarter g's
+// k-th survivor is one ds_read_b32 per lane from the staged record; D_g (16 pixels x 16 channels) accumulates over the trips.
+// An f32 MFMA is the ascending fma chain over k starting from C (profiles/r02_mfma_fma_chain_probe.json), i.e. bit for bit the
+// F += f * w chain of the lane = pixel loop in the same splat order.  Per four survivors: 8 MFMAs (256 FP32-pipe cycles; 4 with
+// 16 channels) + 4 swaps instead of 4 x CH FMAs (384 cycles at 24 channels, 512 at 32) and CH / 4 broadcast ds_read_b128 each.
+#ifndef BLEND_FWD_MFMA
+#define BLEND_FWD_MFMA 1
+#endif
+
+#ifndef BLEND_FWD_MF_MINW
+#define BLEND_FWD_MF_MINW 3
+#endif
 template <int CH, bool ENH, bool BIAS, bool EXACT>
-__global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_FWD_MINW : CH <= 16 ? 4 : 3))
+__global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_FWD_MINW : CH <= 16 ? 4 : (BLEND_FWD_MFMA && !BIAS) ? BLEND_FWD_MF_MINW : 3))
 blend_fwd_kernel(const BlendArgs B) {
     constexpr int SB = FwdCfg<CH>::SB;
-    constexpr int U = CH <= 8 ? BLEND_FWD_U : 2;  // survivors evaluated per trip
+    constexpr bool MF = BLEND_FWD_MFMA && CH >= 16 && !BIAS;
+    constexpr int NCB = (CH + 15) / 16;           // MF: 16-channel blocks of the product
+    constexpr int U = MF ? 4 : CH <= 8 ? BLEND_FWD_U : 2;  // survivors evaluated per trip
     constexpr int RB = Rec<CH>::RS * 4;           // bytes per record
     constexpr int RM = RB / 32;                   // record offset = RM * coefficient-block offset
     static_assert((SB + 1) * 32 <= 65536 && SB % U == 0 && RB % 32 == 0, "offsets must fit the 16-bit list entries");
@@ -670,12 +690,23 @@ blend_fwd_kernel(const BlendArgs B) {
     const BlendArgs A = frame_args(B, frame);
     const int tx = tile % A.gx, ty = tile / A.gx;
     const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
-    const int px = bx + (lane & 7), py = by + (lane >> 3);
+    // pixel of the lane inside the wave's 8x8 block: row-major, or (MF) quarter-major -- DPP row q = lanes 16 q .. 16 q + 15 = the
+    // 4x4 quarter q (x half = q & 1, y half = q >> 1), row-major inside it
+    const int lx = MF ? ((lane >> 4) & 1) * 4 + (lane & 3) : (lane & 7);
+    const int ly = MF ? (lane >> 5) * 4 + ((lane >> 2) & 3) : (lane >> 3);
+    const int px = bx + lx, py = by + ly;
     const float pxf = (float)px, pyf = (float)py;
     // pixel relative to the tile centre and its monomials (exact in f32)
-    const float x = (float)((w & 1) * 8 + (lane & 7)) - 7.5f, y = (float)((w >> 1) * 8 + (lane >> 3)) - 7.5f;
+    const float x = (float)((w & 1) * 8 + lx) - 7.5f, y = (float)((w >> 1) * 8 + ly) - 7.5f;
     const float xx = x * x, xy = x * y, yy = y * y;
     const int cn = EXACT ? CH : A.cn;
+    f32x4 D[MF ? 4 : 1][MF ? NCB : 1];   // MF: D[g][c][j] = sum of pixel 4 (lane >> 4) + j of quarter g, channel 16 c + (lane & 15)
+    if (MF) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) D[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     const bool inside = (px < A.W) && (py < A.H);
     float T = inside ? 1.0f : -1.0f, F[CH];   // T < 0: the pixel is finished, |T| its final transmittance
@@ -737,16 +768,30 @@ blend_fwd_kernel(const BlendArgs B) {
                 for (int i = cq[q] + lane; i < cntU; i += WAVE) s_qlist[w][q][i] = (unsigned)(SB * 32);  // log2(o) = -inf -> alpha 0
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int myq = ((lane >> 2) & 1) + 2 * ((lane >> 5) & 1);  // quarter of this lane's pixel
+            const int myq = MF ? (lane >> 4) : ((lane >> 2) & 1) + 2 * ((lane >> 5) & 1);  // quarter of this lane's pixel
             const unsigned int *mylist = s_qlist[w][myq];
             const char *recb = reinterpret_cast<const char *>(L.rec);
             const char *cfb = reinterpret_cast<const char *>(L.coef);
             int lastoff = -1;  // block offset of the last splat applied in this super-batch
+            // MF: byte offsets of this lane's column (channel) in the B operands of block 0 and, relative to it, of block 1
+            const int chan_off = 4 * (lane & 15);
+            const int chan_off1 = (16 + (lane & 15) < CH) ? 64 : -chan_off;
             for (int j0 = 0; j0 < cntU; j0 += U) {
                 unsigned off[U];
                 static_assert(U == 2 || U == 4, "a trip reads its list entries as one 8- or 16-byte word");
 #pragma unroll
                 for (int u = 0; u < U; ++u) off[u] = mylist[j0 + u];  // adjacent 32-bit entries: one ds_read_b64 / b128 per trip, no unpacking
+                float bq[MF ? 4 : 1][MF ? NCB : 1];   // MF: B operands, requested before the trip's arithmetic (two LDS round trips)
+                if constexpr (MF) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned og = s_qlist[w][g][j0 + (lane >> 4)];   // quarter g's survivor of trip lane >> 4
+                        const char *fb = recb + og * RM + 32 + chan_off;
+                        // (block 1 of a 20 / 24-channel row: columns past the row read channel 0 again -- finite, never stored)
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) bq[g][c] = *reinterpret_cast<const float *>(fb + (c == 0 ? 0 : chan_off1));
+                    }
+                }
                 float4 g0[U], g1[U];
                 float alpha[U];  // 0 where the splat does not touch the pixel: no per-splat predicate registers
 #pragma unroll
@@ -774,24 +819,31 @@ blend_fwd_kernel(const BlendArgs B) {
                 // Branch-free compositing.  A finished pixel carries its final T NEGATED: T (1 - alpha) < 0.0001 holds for it
                 // again ("saturated"), so nothing applies and no `done` predicate is kept; alpha = 0 (splat skipped on this
                 // pixel) multiplies T by 1 and adds f * 0: the pixel's values do not change by a bit.
+                float wq[MF ? U : 1];   // MF: the trip's weights, then (transposed) the quarters' A operands
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    float f[CH];
-                    const float4 *fq = reinterpret_cast<const float4 *>(recb + off[u] * RM + 32);  // 16-byte chunks of the record
+                    float f[MF ? 1 : CH];
+                    if (!MF) {
+                        const float4 *fq = reinterpret_cast<const float4 *>(recb + off[u] * RM + 32);  // 16-byte chunks of the record
 #pragma unroll
-                    for (int k = 0; k < CH; k += 4) {
-                        const float4 v = fq[k / 4];
-                        if (k + 0 < CH) f[k + 0] = v.x;
-                        if (k + 1 < CH) f[k + 1] = v.y;
-                        if (k + 2 < CH) f[k + 2] = v.z;
-                        if (k + 3 < CH) f[k + 3] = v.w;
+                        for (int k = 0; k < CH; k += 4) {
+                            const float4 v = fq[k / 4];
+                            if (k + 0 < CH) f[k + 0] = v.x;
+                            if (k + 1 < CH) f[k + 1] = v.y;
+                            if (k + 2 < CH) f[k + 2] = v.z;
+                            if (k + 3 < CH) f[k + 3] = v.w;
+                        }
                     }
                     const float nT = T * (1.f - alpha[u]);
                     const bool sat = nT < 0.0001f;   // reference: the splat that would take T below 1e-4 ends the pixel, unapplied
                     const float wgt = sat ? 0.f : alpha[u] * T;
                     const bool app = wgt > 0.f;
+                    if (MF) {
+                        wq[u] = wgt;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < CH; ++k) F[k] += f[k] * wgt;
+                        for (int k = 0; k < CH; ++k) F[k] += f[k] * wgt;
+                    }
                     T = sat ? -fabsf(T) : nT;
                     lastoff = app ? (int)off[u] : lastoff;
                     if (ENH) {
@@ -805,10 +857,51 @@ blend_fwd_kernel(const BlendArgs B) {
                         }
                     }
                 }
+                if constexpr (MF) {
+                    // rows <-> registers: wq[g] becomes (w_0 | w_1 | w_2 | w_3)[row g] = quarter g's A operand
+                    typedef unsigned u32x2_f __attribute__((ext_vector_type(2)));
+                    const u32x2_f s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(wq[0]), __float_as_uint(wq[2]), false, false);
+                    const u32x2_f s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(wq[1]), __float_as_uint(wq[3]), false, false);
+                    const u32x2_f a01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+                    const u32x2_f a23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+                    const float Aq[4] = {__uint_as_float(a01[0]), __uint_as_float(a01[1]), __uint_as_float(a23[0]), __uint_as_float(a23[1])};
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) D[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aq[g], bq[g][c], D[g][c], 0, 0, 0);
+                }
             }
             last = lastoff >= 0 ? base + lastoff / 32 + 1 : last;
         }
         __syncthreads();
+    }
+    if constexpr (MF) {
+        // D -> the lane's own F[]: a quarter at a time through the wave's 16 x 36 floats of the (dead) staging area.  (Every
+        // thread left the loop behind a barrier: nobody reads the records any more.)
+        constexpr int ST = 36;
+        static_assert(4 * 16 * ST * 4 <= (int)sizeof(L.rec), "four waves' quarter buffers fit the staged records");
+        float *so = reinterpret_cast<float *>(L.rec) + w * (16 * ST);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) so[(4 * (lane >> 4) + j) * ST + 16 * c + (lane & 15)] = D[g][c][j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float4 *src = reinterpret_cast<const float4 *>(so + (lane & 15) * ST);
+            const bool mine = (lane >> 4) == g;
+#pragma unroll
+            for (int k = 0; k < CH; k += 4) {
+                const float4 v = src[k / 4];
+                if (k + 0 < CH) F[k + 0] = mine ? v.x : F[k + 0];
+                if (k + 1 < CH) F[k + 1] = mine ? v.y : F[k + 1];
+                if (k + 2 < CH) F[k + 2] = mine ? v.z : F[k + 2];
+                if (k + 3 < CH) F[k + 3] = mine ? v.w : F[k + 3];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     if (inside) {
         const size_t HW = (size_t)A.H * A.W;
@@ -1173,7 +1266,6 @@ pair_reduce_kernel(const BlendArgs A) {
 //     R_n   = R_state + sum_{q<n} a_q T_q cg_q                (colour behind splat n, already dotted with dL_dout)
 //     dL/da = T_n cg_n - (R_n + T_final bg.g) / (1-a_n)
 // The records written to the slabs / pair_buf are the same as blend_bwd_pair_kernel's (pair_reduce is shared).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int CH, bool ABS>
 struct MfmaCfg {
