@@ -82,3 +82,18 @@ def test_single_frame_backward_with_and_without_the_forwards_cull_words(C, with_
         tol = 2e-4 * y.abs() + 2e-6 * float(y.abs().max()) + 1e-12
         assert int((d > tol).sum()) <= max(2, x.numel() // 50000), (k, int((d > tol).sum()), float(d.max()))
         assert bool((d <= 10 * tol).all()), k
+
+
+@pytest.mark.gpu
+def test_sort_and_pair_map_with_slot_keys():
+    """The pair map's low key word is (Gaussian id, tile index inside the splat's rectangle) whenever the two fit 32 bits --
+    every size under test.  SPLAT_BIN_SLOT_KEYS=1 (read once per process) selects the other form (pair slot in the key, ids
+    through the `owner` workspace: what 1M Gaussians on more than 4096 tiles get): the sort's bit-exactness tests, the pair-map
+    test and the batch's oracle test run again in a child process on that form."""
+    env = dict(os.environ, SPLAT_BIN_SLOT_KEYS="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_frames_oracle.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "sort or pair_map or render_against", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
