@@ -1208,33 +1208,27 @@ pair_reduce_kernel(const BlendArgs A) {
     const int beg = i > 0 ? A.goff_incl[i - 1] : 0, end = A.goff_incl[i];
     constexpr int NQ = NCP / 4;         // 16-byte chunks per record; lane `sub` owns chunks sub, sub + 4, ...
     constexpr int NS = (NQ + 3) / 4;
+    // records requested together: a splat's records are one dependent round trip per TU of them (94 % of the splats of the
+    // bench scene touch at most six tiles; two at a time was 2 .. 3 round trips for the average splat)
+    constexpr int TU = NS == 1 ? 6 : NS == 2 ? 3 : 2;
     float4 a[NS];
 #pragma unroll
     for (int c = 0; c < NS; ++c) a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float *base = A.pair_buf + 4 * sub;
-    int j = beg;
-    for (; j + 1 < end; j += 2) {  // two records in flight
-        float4 v0[NS], v1[NS];
+    for (int j = beg; j < end; j += TU) {
+        float4 v[TU][NS];
 #pragma unroll
-        for (int c = 0; c < NS; ++c) {
-            const bool mine = 4 * c + sub < NQ;
-            v0[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            v1[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)(j + 1) * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int u = 0; u < TU; ++u)
 #pragma unroll
-        for (int c = 0; c < NS; ++c) {
-            a[c].x += v0[c].x; a[c].y += v0[c].y; a[c].z += v0[c].z; a[c].w += v0[c].w;
-            a[c].x += v1[c].x; a[c].y += v1[c].y; a[c].z += v1[c].z; a[c].w += v1[c].w;
-        }
-    }
-    if (j < end) {
+            for (int c = 0; c < NS; ++c)
+                v[u][c] = (j + u < end && 4 * c + sub < NQ) ? *reinterpret_cast<const float4 *>(base + (size_t)(j + u) * NCP + 16 * c)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int c = 0; c < NS; ++c) {
-            if (4 * c + sub < NQ) {
-                const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c);
-                a[c].x += v.x; a[c].y += v.y; a[c].z += v.z; a[c].w += v.w;
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                a[c].x += v[u][c].x; a[c].y += v[u][c].y; a[c].z += v[u][c].z; a[c].w += v[u][c].w;
             }
-        }
     }
 #pragma unroll
     for (int c = 0; c < NS; ++c) {

@@ -324,6 +324,9 @@ inline dim3 dyn_grid(int P) { return dim3((unsigned)(((size_t)P * 4 + DYN_BLOCK 
 // Static parameters + per-frame offsets under the orthographic camera: conic, radius and the projection Jacobian do not
 // depend on the frame (the offsets only move the centre), and the whole backward chain is linear in (dL_duv,
 // dL_dconic): the records of all frames are summed first and the chain runs ONCE per Gaussian.
+#ifndef GAUSS_BWD_TAIL
+#define GAUSS_BWD_TAIL 6
+#endif
 #ifndef GAUSS_BWD_U
 #define GAUSS_BWD_U 6   // records of a frame requested together by the static Gaussian-side backward (narrow records: 17.4 us per frame at 4, 16.5 at 6, 16.2 at 8)
 #endif
@@ -437,7 +440,8 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
         // a slot range that depends on the previous frame's: 2.6-2.9 TB/s): the slot ranges of ALL frames of the workgroup's 64
         // Gaussians are read up front into LDS (coalesced; the record loads then depend on nothing in flight), a frame's first
         // U records are requested together, and the next frame's while this frame's are summed (two register buffers).
-        constexpr int U = NS == 1 ? GAUSS_BWD_U : 2, FMAX = 32;   // (wide records: two per buffer -- at four the registers cost more waves than the loads in flight gain)
+        constexpr int U = NS == 1 ? GAUSS_BWD_U : 2, FMAX = 32;
+        constexpr int TU = NS == 1 ? GAUSS_BWD_TAIL : 2;   // records a tail round requests together   // (wide records: two per buffer -- at four the registers cost more waves than the loads in flight gain)
         __shared__ int s_goff[FMAX][65];   // [frame][Gaussian of the workgroup + 1]: inclusive prefix, entry 0 = the Gaussian before
         const int i0 = (int)(blockIdx.x * 64);
         const int nf = imin_(A.F, FMAX);
@@ -476,21 +480,21 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
             rmax = imax_(rmax, rad);
             any = any || end > beg;
             const float *base = A.pair + (size_t)f * (size_t)A.cap * NCP + 4 * sub;
-            for (int j = beg + U; j < end; j += 2) {   // a Gaussian on more than U tiles: two records in flight
-                const bool two = j + 1 < end;
-                float4 v0[NS], v1[NS];
+            for (int j = beg + U; j < end; j += TU) {   // a Gaussian on more than U tiles: TU more records in flight
+                float4 vt[TU][NS];
 #pragma unroll
-                for (int c = 0; c < NS; ++c) {
-                    const bool mine = 4 * c + sub < NQ;
-                    v0[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)j * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    v1[c] = (mine && two) ? *reinterpret_cast<const float4 *>(base + (size_t)(j + 1) * NCP + 16 * c)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                for (int u = 0; u < TU; ++u)
 #pragma unroll
-                for (int c = 0; c < NS; ++c) {
-                    a[c].x += v0[c].x; a[c].y += v0[c].y; a[c].z += v0[c].z; a[c].w += v0[c].w;
-                    a[c].x += v1[c].x; a[c].y += v1[c].y; a[c].z += v1[c].z; a[c].w += v1[c].w;
-                }
+                    for (int c = 0; c < NS; ++c)
+                        vt[u][c] = (j + u < end && 4 * c + sub < NQ)
+                                       ? *reinterpret_cast<const float4 *>(base + (size_t)(j + u) * NCP + 16 * c)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < TU; ++u)
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) {
+                        a[c].x += vt[u][c].x; a[c].y += vt[u][c].y; a[c].z += vt[u][c].z; a[c].w += vt[u][c].w;
+                    }
             }
         };
         int b0, e0, b1 = 0, e1 = 0;
@@ -817,27 +821,40 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
 #pragma unroll
             for (int c = 0; c < NS; ++c) af[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             const float *base = A.pair + (size_t)ff * (size_t)A.cap * NCP + 4 * j;
-            int r = beg;
-            for (; r + 1 < end; r += 2) {  // two records in flight
-                float4 v0[NS], v1[NS];
+            if constexpr (NS == 1) {
+                // narrow records: six requested together (one dependent round trip for 94 % of the splats; two at a time was 2 .. 3)
+                constexpr int TD = 6;
+                for (int r = beg; r < end; r += TD) {
+                    float4 v[TD];
 #pragma unroll
-                for (int c = 0; c < NS; ++c) {
-                    const bool mine = 4 * c + j < NQ;
-                    v0[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)r * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    v1[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)(r + 1) * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int u = 0; u < TD; ++u)
+                        v[u] = (r + u < end && j < NQ) ? *reinterpret_cast<const float4 *>(base + (size_t)(r + u) * NCP) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int u = 0; u < TD; ++u) { af[0].x += v[u].x; af[0].y += v[u].y; af[0].z += v[u].z; af[0].w += v[u].w; }
                 }
+            } else {   // wide records: two in flight (the registers of a third or fourth cost more than the round trips they save)
+                int r = beg;
+                for (; r + 1 < end; r += 2) {
+                    float4 v0[NS], v1[NS];
 #pragma unroll
-                for (int c = 0; c < NS; ++c) {
-                    af[c].x += v0[c].x; af[c].y += v0[c].y; af[c].z += v0[c].z; af[c].w += v0[c].w;
-                    af[c].x += v1[c].x; af[c].y += v1[c].y; af[c].z += v1[c].z; af[c].w += v1[c].w;
+                    for (int c = 0; c < NS; ++c) {
+                        const bool mine = 4 * c + j < NQ;
+                        v0[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)r * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v1[c] = mine ? *reinterpret_cast<const float4 *>(base + (size_t)(r + 1) * NCP + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) {
+                        af[c].x += v0[c].x; af[c].y += v0[c].y; af[c].z += v0[c].z; af[c].w += v0[c].w;
+                        af[c].x += v1[c].x; af[c].y += v1[c].y; af[c].z += v1[c].z; af[c].w += v1[c].w;
+                    }
                 }
-            }
-            if (r < end) {
+                if (r < end) {
 #pragma unroll
-                for (int c = 0; c < NS; ++c) {
-                    if (4 * c + j < NQ) {
-                        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)r * NCP + 16 * c);
-                        af[c].x += v.x; af[c].y += v.y; af[c].z += v.z; af[c].w += v.w;
+                    for (int c = 0; c < NS; ++c) {
+                        if (4 * c + j < NQ) {
+                            const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)r * NCP + 16 * c);
+                            af[c].x += v.x; af[c].y += v.y; af[c].z += v.z; af[c].w += v.w;
+                        }
                     }
                 }
             }
