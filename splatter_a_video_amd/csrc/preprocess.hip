@@ -324,11 +324,22 @@ inline dim3 dyn_grid(int P) { return dim3((unsigned)(((size_t)P * 4 + DYN_BLOCK 
 // Static parameters + per-frame offsets under the orthographic camera: conic, radius and the projection Jacobian do not
 // depend on the frame (the offsets only move the centre), and the whole backward chain is linear in (dL_duv,
 // dL_dconic): the records of all frames are summed first and the chain runs ONCE per Gaussian.
+// One-camera walk: a frame's first U records of a Gaussian are requested together (two register buffers: the next frame's while
+// this frame's are summed), the records past them TAIL at a time -- every round of them is a dependent memory round trip, and 6 %
+// of the bench scene's splats touch more than six tiles (most waves hold one).  Narrow (one-chunk-per-lane) records: U = 6
+// (17.4 us per frame at 4, 16.5 at 6, 16.2 at 8 with the tail two at a time), TAIL = 6 (17.2 -> 14.4); wide records: U = 2 (at
+// four the registers cost more waves than the loads in flight gain), TAIL = 4 (c5: 43.6 -> 40.9 us per frame).
+#ifndef GAUSS_BWD_U
+#define GAUSS_BWD_U 6
+#endif
 #ifndef GAUSS_BWD_TAIL
 #define GAUSS_BWD_TAIL 6
 #endif
-#ifndef GAUSS_BWD_U
-#define GAUSS_BWD_U 6   // records of a frame requested together by the static Gaussian-side backward (narrow records: 17.4 us per frame at 4, 16.5 at 6, 16.2 at 8)
+#ifndef GAUSS_BWD_U_WIDE
+#define GAUSS_BWD_U_WIDE 2
+#endif
+#ifndef GAUSS_BWD_TAIL_WIDE
+#define GAUSS_BWD_TAIL_WIDE 4
 #endif
 struct GaussBwdArgs {
     int F, P, W, H;
@@ -440,8 +451,8 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
         // a slot range that depends on the previous frame's: 2.6-2.9 TB/s): the slot ranges of ALL frames of the workgroup's 64
         // Gaussians are read up front into LDS (coalesced; the record loads then depend on nothing in flight), a frame's first
         // U records are requested together, and the next frame's while this frame's are summed (two register buffers).
-        constexpr int U = NS == 1 ? GAUSS_BWD_U : 2, FMAX = 32;
-        constexpr int TU = NS == 1 ? GAUSS_BWD_TAIL : 2;   // records a tail round requests together   // (wide records: two per buffer -- at four the registers cost more waves than the loads in flight gain)
+        constexpr int U = NS == 1 ? GAUSS_BWD_U : GAUSS_BWD_U_WIDE, FMAX = 32;
+        constexpr int TU = NS == 1 ? GAUSS_BWD_TAIL : GAUSS_BWD_TAIL_WIDE;   // records a tail round requests together
         __shared__ int s_goff[FMAX][65];   // [frame][Gaussian of the workgroup + 1]: inclusive prefix, entry 0 = the Gaussian before
         const int i0 = (int)(blockIdx.x * 64);
         const int nf = imin_(A.F, FMAX);
