@@ -819,14 +819,24 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
         float m_nrm = 1.f, m_d = 0.f, m_gdep = 0.f;
         bool m_valid = false;
         int took = 0;
+        // the slot ranges (and radii) of the group's four frames are requested together: one memory round trip in front of the
+        // records' instead of one per frame
+        int rb[4], re[4], rr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ff = imin_(f + k, A.F - 1);
+            const int *goff = A.goff + (size_t)ff * A.P;
+            rb[k] = n > 0 ? goff[n - 1] : 0;
+            re[k] = goff[n];
+            rr[k] = (A.radii_max && j == 0) ? A.radius[(size_t)ff * A.P + n] : 0;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int ff = f + k;
             if (ff >= A.F || A.tab[ff].seg != seg) break;  // grid-uniform
             took = k + 1;
-            const int *goff = A.goff + (size_t)ff * A.P;
-            const int beg = n > 0 ? goff[n - 1] : 0, end = goff[n];
-            if (A.radii_max && j == 0) rmax = imax_(rmax, A.radius[(size_t)ff * A.P + n]);
+            const int beg = rb[k], end = re[k];
+            rmax = imax_(rmax, rr[k]);
             if (end <= beg) continue;  // quad-uniform: no record of this Gaussian in frame ff
             float4 af[NS];
 #pragma unroll
