@@ -211,7 +211,14 @@ class FrameRenderer:
         else:
             src["feature"] = sc.feature
         if mode in ("render_iter", "render_iter_frame", "ref_flow"):
-            src["attrs"] = np.random.default_rng(7).uniform(-1, 1, size=(N, 19)).astype(np.float32)
+            attrs = np.random.default_rng(7).uniform(-1, 1, size=(N, 19)).astype(np.float32)
+            if mode == "render_iter_frame":
+                # the per-frame renderer takes its attributes by name, as the reference's model holds them: one parameter
+                # tensor each (views of ONE [N, 19] parameter made autograd copy both slices per frame in either direction)
+                src["mask_attribute"] = np.ascontiguousarray(attrs[:, :1])
+                src["dino_attribute"] = np.ascontiguousarray(attrs[:, 1:])
+            else:
+                src["attrs"] = attrs
         # stale-1 mode only: two gradient buffers, the all-reduce of step s runs on RCCL's stream while step s+1 fills the other
         self.overlap = bool(stale_overlap) and dist.is_available() and dist.is_initialized()
         # --overlap (exact): two half-batches, a gradient buffer each (parallel.overlapped_halves_step)
@@ -337,15 +344,18 @@ class FrameRenderer:
         p = self.p
         rgb = self.renderer.colors(p["shs"])          # once per batch: the view direction is constant (render_batch)
         rgb_in = rgb.detach().requires_grad_(True)    # the frames' colour gradients are summed before the one SH backward
+        attrs = {"mask_attribute": p["mask_attribute"], "dino_attribute": p["dino_attribute"]}
+        row = torch.cat(list(attrs.values()), dim=-1)  # likewise the attribute row (render_batch: one concatenation per batch)
+        row_in = row.detach().requires_grad_(True)
         for off in self.offs:
             r = self.renderer.render_iter(self.H, self.W, self.extr, p["xyz"] + off, p["opacity"], p["scale"], p["rotate"], None,
-                                          num_idx=20, rgb=rgb_in,
-                                          render_attributes={"mask_attribute": p["attrs"][:, :1], "dino_attribute": p["attrs"][:, 1:]})
+                                          num_idx=20, rgb=rgb_in, render_attributes=attrs, attribute_row=row_in)
             f = r["rendered_features_split"]
             torch.autograd.backward([f["rgb"], f["depth"], f["mask_attribute"], f["dino_attribute"]],
                                     [self.dL_dout, self.dL_depth, self.dL_attr[:1], self.dL_attr[1:]])
             self._radii = r["radii"]
         rgb.backward(rgb_in.grad)
+        row.backward(row_in.grad)
         self.last = dict(M=self.last.get("M", 0), T=((self.W + 15) // 16) * ((self.H + 15) // 16))
 
     # ------------------------------------------------------------------ the reference's literal call sequence, frame by frame

@@ -344,6 +344,21 @@ def alpha_blending_with_bias(uv: Tensor, conic: Tensor, opacity: Tensor, feature
                              abs_ndc, 0, False)
 
 
+_BG_CHANNELS = {}
+
+
+def _bg_channels(widths, bgs, device) -> Tensor:
+    """per-channel background of a row of feature sets (read-only, cached: three fill kernels and a cat per call otherwise)"""
+    key = (widths, bgs, str(device))
+    t = _BG_CHANNELS.get(key)
+    if t is None:
+        if len(_BG_CHANNELS) > 64:
+            _BG_CHANNELS.clear()
+        t = torch.cat([torch.full((w,), b, dtype=torch.float32, device=device) for w, b in zip(widths, bgs)])
+        _BG_CHANNELS[key] = t
+    return t
+
+
 # ------------------------------------------------------------------ several feature sets, one forward pass
 class _BlendShared(torch.autograd.Function):
     """inputs: uv, conic, opacity, idx_sorted, tile_range, W, H, K, ndc, abs_ndc, bgs, detach_opacity, taps, *features"""
@@ -363,7 +378,7 @@ class _BlendShared(torch.autograd.Function):
         C = sum(widths)
         dev = uv.device
         allf = torch.cat(feats, dim=1) if len(feats) > 1 else feats[0]
-        bgc = torch.cat([torch.full((w,), float(b), dtype=torch.float32, device=dev) for w, b in zip(widths, bgs)])
+        bgc = _bg_channels(tuple(widths), tuple(float(b) for b in bgs), dev)
         out = torch.empty(C, H, W, dtype=torch.float32, device=dev)
         final_T = torch.empty(H, W, dtype=torch.float32, device=dev)
         ncontrib = torch.empty(H, W, dtype=torch.int32, device=dev)

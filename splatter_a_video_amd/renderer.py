@@ -27,10 +27,13 @@ class OrthoEnhancedRenderer:
 
     def render_iter(self, height: int, width: int, extrinsic_matrix: Tensor, position: Tensor, opacity: Tensor,
                     scaling: Tensor, rotation: Tensor, shs: Tensor, bg_color: Optional[float] = None, num_idx: int = 10,
-                    render_attributes: Optional[Dict[str, Tensor]] = None, rgb: Optional[Tensor] = None, **_unused) -> dict:
+                    render_attributes: Optional[Dict[str, Tensor]] = None, rgb: Optional[Tensor] = None,
+                    attribute_row: Optional[Tensor] = None, **_unused) -> dict:
         """One frame.  ``render_attributes`` maps names to per-Gaussian tensors [N, c] (the reference passes them as
         keyword arguments listed in ``render_attributes_list``).  ``rgb``: colours already evaluated from ``shs``
-        (``render_batch`` evaluates them once per batch: the view direction is the same constant for every frame)."""
+        (``render_batch`` evaluates them once per batch: the view direction is the same constant for every frame);
+        ``attribute_row``: the attributes already concatenated [N, sum c] in the order of ``render_attributes`` (they do
+        not depend on the frame either: one concatenation and one split of its gradient per batch instead of per frame)."""
         W, H = int(width), int(height)
         if rgb is None:
             rgb = self.colors(shs)
@@ -45,7 +48,7 @@ class OrthoEnhancedRenderer:
         sets, bgs, detach, taps = [rgb, depth], [bg, 1.0], [False, False], [True, False]
         names = list(render_attributes) if render_attributes else []
         if names:
-            sets.append(torch.cat([render_attributes[k] for k in names], dim=-1))
+            sets.append(attribute_row if attribute_row is not None else torch.cat([render_attributes[k] for k in names], dim=-1))
             bgs.append(0.0); detach.append(True); taps.append(False)
         res = gs.alpha_blending_shared(uv, conic, opacity, sets, idx_sorted, tile_range, bgs, W, H, ndc, abs_ndc, K=num_idx,
                                        detach_opacity=detach, taps=taps)
@@ -77,11 +80,15 @@ class OrthoEnhancedRenderer:
         feats: Dict[str, List[Tensor]] = {}
         viewspace_points, vis, radii, gs_idx = [], [], [], []
         shared_rgb = self.colors(render_dict["shs"]) if "shs" in render_dict else None
+        attrs = render_dict.get("render_attributes")
+        shared_row = torch.cat([attrs[k] for k in attrs], dim=-1) if attrs else None
         for b_i in batch:
             args = dict(b_i)
             args.update(render_dict)
             if shared_rgb is not None:
                 args["rgb"] = shared_rgb
+            if shared_row is not None and "render_attributes" not in b_i:
+                args["attribute_row"] = shared_row
             r = self.render_iter(**args)
             for k, v in r["rendered_features_split"].items():
                 feats.setdefault(k, []).append(v)

@@ -108,6 +108,33 @@ def test_render_batch_shared_colours_give_the_same_gradients():
     assert torch.allclose(grads[0][1], grads[1][1], rtol=1e-5, atol=1e-6 * float(grads[1][1].abs().max()))
 
 
+def test_render_batch_shared_attribute_row_gives_the_same_images_and_gradients():
+    """attributes handed to render_batch in the shared dictionary are concatenated ONCE per batch (render_iter's
+    ``attribute_row``); handed per frame, every frame concatenates them itself: same images, same gradients"""
+    N, W, H = 2500, 96, 64
+    sc = make_scene(N, W, H, seed=13)
+    R = OrthoEnhancedRenderer()
+    rng = np.random.default_rng(3)
+    ga, gb = _t(rng.normal(size=(3, 1, H, W)).astype(np.float32)), _t(rng.normal(size=(3, 4, H, W)).astype(np.float32))
+    mask0, feat0 = rng.uniform(-1, 1, size=(N, 1)).astype(np.float32), rng.uniform(-1, 1, size=(N, 4)).astype(np.float32)
+    res = []
+    for shared in (True, False):
+        mask, feat = _t(mask0, True), _t(feat0, True)
+        attrs = {"mask_attribute": mask, "dino_attribute": feat}
+        common = dict(opacity=_t(sc.opacity), scaling=_t(sc.scale), rotation=_t(sc.rotate), shs=_t(sc.shs), height=H, width=W,
+                      extrinsic_matrix=_t(sc.extr))
+        frames = [dict(position=_t(sc.positions(f))) for f in (0, 2, 5)]
+        if shared:
+            out = R.render_batch({**common, "render_attributes": attrs}, frames)
+        else:
+            out = R.render_batch(common, [{**f, "render_attributes": attrs} for f in frames])
+        ((out["mask_attribute"] * ga).sum() + (out["dino_attribute"] * gb).sum()).backward()
+        res.append((out["mask_attribute"].detach(), out["dino_attribute"].detach(), mask.grad.clone(), feat.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in (2, 3):
+        assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-6 * float(res[1][k].abs().max()))
+
+
 def test_perspective_renderer_equals_the_reference_sequence():
     """PerspRenderer.render_iter / render_batch (fused gs.preprocess_persp) against the operator sequence of the reference's
     DPTRRender.render_iter (src/pointrix/renderer/dptr.py:107-169: compute_sh with per-point directions, project_point
