@@ -273,6 +273,15 @@ def test_alpha_blending_variants(gpu, oracle_mod, variant, N, W, H, mode):
     _blend_case(gpu, oracle_mod, N, W, H, 3, 1.0 if variant == "plain" else 0.0, variant, seed=5, mode=mode)
 
 
+@pytest.mark.parametrize("variant", ["plain", "enh", "trunc"])
+@pytest.mark.parametrize("C", [16, 20, 24, 32])
+def test_alpha_blending_wide_rows_on_the_matrix_pipe(gpu, oracle_mod, C, variant):
+    """rows of 16 .. 32 channels: the forward's channel sums run as MFMAs (quarter-major lanes, four survivors per trip, DESIGN
+    4i) -- every width of that path with the id lists and the truncation of the enhanced variants, on an image that is no
+    multiple of the tile"""
+    _blend_case(gpu, oracle_mod, 5000, 150, 90, C, 0.37, variant, seed=40 + C, K=7, mode="pair")
+
+
 def test_alpha_blending_pair_mode_big_splats(gpu, oracle_mod):
     """sigma = 12 px: long per-Gaussian pair lists and > 4096-entry tiles through the pair-mode backward."""
     sc_kw = dict()
