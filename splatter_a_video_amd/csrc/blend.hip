@@ -793,7 +793,8 @@ blend_fwd_kernel(const BlendArgs B) {
                     }
                 }
                 float4 g0[U], g1[U];
-                float alpha[U];  // 0 where the splat does not touch the pixel: no per-splat predicate registers
+                float alpha[U];  // 0 where the splat does not touch the pixel
+                bool aok[U];     // alpha[u] != 0 (a wave mask in scalar registers: the compare that zeroed alpha[u])
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const char *src = BIAS ? recb + off[u] * RM : cfb + off[u];
@@ -806,12 +807,14 @@ blend_fwd_kernel(const BlendArgs B) {
                     if (BIAS) {
                         const float q = neg_power_factored(g0[u].x - pxf, g0[u].y - pyf, g0[u].z, g0[u].w, g1[u].x);
                         const float a = fminf(0.99f, __builtin_fmaf(g1[u].y, exp_neg(q), g1[u].z));
-                        alpha[u] = (!(q < 0.f) && !(a < (1.0f / 255.0f))) ? a : 0.f;
+                        aok[u] = !(q < 0.f) && !(a < (1.0f / 255.0f));
+                        alpha[u] = aok[u] ? a : 0.f;
                     } else {
                         const float pw = power_poly(g0[u], g1[u], x, y, xx, xy, yy);
                         bool pw_ok;
                         const float a = fminf(0.99f, exp2_guard(pw, pw_ok));
-                        alpha[u] = (pw_ok && !(a < (1.0f / 255.0f))) ? a : 0.f;
+                        aok[u] = pw_ok && !(a < (1.0f / 255.0f));
+                        alpha[u] = aok[u] ? a : 0.f;
                     }
                     if (BLEND_FWD_TRIPTEST) any = any || (alpha[u] > 0.f);
                 }
@@ -837,7 +840,10 @@ blend_fwd_kernel(const BlendArgs B) {
                     const float nT = T * (1.f - alpha[u]);
                     const bool sat = nT < 0.0001f;   // reference: the splat that would take T below 1e-4 ends the pixel, unapplied
                     const float wgt = sat ? 0.f : alpha[u] * T;
-                    const bool app = wgt > 0.f;
+                    // applied: alpha >= 1/255 and not saturating -- then T (1 - alpha) >= 1e-4, so T > 0 and alpha T > 0: the
+                    // same predicate as wgt > 0, from the two masks already in scalar registers (no third compare)
+                    // (narrow rows; the wide kernels keep the compare: their scalar unit is the busier one)
+                    const bool app = CH <= 8 ? (aok[u] && !sat) : wgt > 0.f;
                     if (MF) {
                         wq[u] = wgt;
                     } else {
