@@ -409,13 +409,16 @@ pack_kernel(const BlendArgs B) {
 // of 16 different survivors at once (ds_read_b128, 64 banks: 4-way conflict) and a K-slice of the features (ds_read_b32,
 // 32 banks: 8-way).  With the swizzle 16 consecutive entries hit 16 different quads.
 // RQL: the leading 16-byte parts of a record that are staged (default: all) -- rows of RQL parts
-template <int CH, int SB, bool COEF = false, int XR = 0, bool SWZ = false, int RQL = Rec<CH>::RQ>
+// CS: float4 per coefficient block -- 2, or 3 when the block also carries the entry's (at most four) channels behind the
+// coefficients (the narrow forward: one base address per evaluated survivor instead of two)
+template <int CH, int SB, bool COEF = false, int XR = 0, bool SWZ = false, int RQL = Rec<CH>::RQ, int CS = 2>
 struct TileLDS {
     static constexpr int RQ = RQL;
     static constexpr bool SWIZZLED = SWZ;
     static_assert(!SWZ || RQL % 4 == 0, "the swizzle permutes groups of four parts");
     float4 rec[(SB + 1 + XR) * RQ];
-    float4 coef[COEF ? 2 * (SB + 1) : 1];
+    static constexpr int CSTRIDE = CS;
+    float4 coef[COEF ? CS * (SB + 1) : 1];
     unsigned int keep[SB];  // byte w of entry e: wave w's 8x8 block can be reached by the splat (and passes its predicate)
     unsigned short list[4][SB + 16 + XR / 4];
     static __device__ __forceinline__ int part(int e, int p) {  // float4 index of part p of entry e
@@ -470,8 +473,8 @@ struct Stager {
                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    template <bool COEF, int XR, bool SWZ, int RQL>
-    __device__ __forceinline__ void park(TileLDS<CH, SB, COEF, XR, SWZ, RQL> &L, int tid) const {
+    template <bool COEF, int XR, bool SWZ, int RQL, int CS>
+    __device__ __forceinline__ void park(TileLDS<CH, SB, COEF, XR, SWZ, RQL, CS> &L, int tid) const {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = tid + 256 * k;
@@ -490,8 +493,8 @@ struct Stager {
 // SUB: the flag byte of a kept block carries one bit per 4x4 quarter (bit sx + 2 sy) from a bounding-box test of the
 // quarter's pixel centres, for kernels that keep a survivor list per quarter; otherwise the byte is 0 / 1.
 // gflags: optional global copy of the staged entries' keep words (BlendArgs::cull_flags + the super-batch's first position).
-template <int CH, int SB, bool BIAS, bool SUB, bool COEF, int XR, bool SWZ, int RQL, typename Pred>
-__device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ, RQL> &L, int tid, int nb, float tx0, float ty0, Pred pred,
+template <int CH, int SB, bool BIAS, bool SUB, bool COEF, int XR, bool SWZ, int RQL, int CS, typename Pred>
+__device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ, RQL, CS> &L, int tid, int nb, float tx0, float ty0, Pred pred,
                                           unsigned int *gflags = nullptr) {
     constexpr int TPE = 256 / SB;  // threads per entry (1, 2 or 4): each tests 4 / TPE of the blocks
     constexpr int BPT = 4 / TPE;
@@ -509,8 +512,9 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ, RQL> &L
             const float4 a0 = L.g0(e), a1 = L.g1(e);
             if (COEF && part == 0) {
                 const PowerCoef k = power_coeffs(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, tx0 + 7.5f, ty0 + 7.5f);
-                L.coef[2 * e] = make_float4(k.q0, k.qx, k.qy, k.qxx);
-                L.coef[2 * e + 1] = make_float4(k.qxy, k.qyy, a1.y, a1.w);
+                L.coef[CS * e] = make_float4(k.q0, k.qx, k.qy, k.qxx);
+                L.coef[CS * e + 1] = make_float4(k.qxy, k.qyy, a1.y, a1.w);
+                if (CS == 3) L.coef[CS * e + 2] = L.rec[L.part(e, 2)];   // channels 0 .. 3 of the record
             }
             CullP cp;
             if (Rec<CH>::CULL >= 0 && RQL == Rec<CH>::RQ) {
@@ -680,8 +684,13 @@ blend_fwd_kernel(const BlendArgs B) {
     constexpr int U = MF ? 4 : CH <= 8 ? BLEND_FWD_U : 2;  // survivors evaluated per trip
     constexpr int RB = Rec<CH>::RS * 4;           // bytes per record
     constexpr int RM = RB / 32;                   // record offset = RM * coefficient-block offset
-    static_assert((SB + 1) * 32 <= 65536 && SB % U == 0 && RB % 32 == 0, "offsets must fit the 16-bit list entries");
-    __shared__ TileLDS<CH, SB, !BIAS> L;
+    // rows of at most four channels carry them in the coefficient block (48 bytes): the survivor's block offset is the only
+    // address of an evaluation (no record offset to derive from it: one VALU instruction per evaluated (pixel, splat) less)
+    constexpr int CS = (!BIAS && CH <= 4) ? 3 : 2;
+    constexpr int CSB = 16 * CS;                  // bytes per coefficient block = unit of the list entries
+    static_assert((SB + 1) * CSB <= 65536 && SB % U == 0 && RB % 32 == 0, "offsets must fit the 16-bit list entries");
+    static_assert(BIAS ? CSB == 32 : true, "with a bias the list entries address the records (32-byte unit)");
+    __shared__ TileLDS<CH, SB, !BIAS, 0, false, Rec<CH>::RQ, CS> L;
     __shared__ __attribute__((aligned(16))) unsigned int s_qlist[4][4][SB];  // [wave][quarter] survivor lists (32 e: coefficient-block byte offsets)
     __shared__ int s_done[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -717,7 +726,7 @@ blend_fwd_kernel(const BlendArgs B) {
     const int n = range.y - range.x;
 
     if (tid < Rec<CH>::RQ) L.rec[SB * Rec<CH>::RQ + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB
-    if (!BIAS && tid < 2) L.coef[2 * SB + tid] = make_float4(tid == 0 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);  // inert entry: q0 = log2(0)
+    if (!BIAS && tid < CS) L.coef[CS * SB + tid] = make_float4(tid == 0 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);  // inert entry: q0 = log2(0)
     // list position of (entry e, super-batch b): forward walk
     auto pos = [n](int e, int b) { const int q = b * SB + e; return q < n ? q : -1; };
     Stager<CH, SB> st;
@@ -756,7 +765,7 @@ blend_fwd_kernel(const BlendArgs B) {
                     const bool keep = (bits >> q) & 1u;
                     const unsigned long long m = __ballot(keep);
                     const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (keep) s_qlist[w][q][cq[q] + before] = (unsigned)(e * 32);
+                    if (keep) s_qlist[w][q][cq[q] + before] = (unsigned)(e * CSB);
                     cq[q] += __popcll(m);
                 }
             }
@@ -765,7 +774,7 @@ blend_fwd_kernel(const BlendArgs B) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll 1
-                for (int i = cq[q] + lane; i < cntU; i += WAVE) s_qlist[w][q][i] = (unsigned)(SB * 32);  // log2(o) = -inf -> alpha 0
+                for (int i = cq[q] + lane; i < cntU; i += WAVE) s_qlist[w][q][i] = (unsigned)(SB * CSB);  // log2(o) = -inf -> alpha 0
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int myq = MF ? (lane >> 4) : ((lane >> 2) & 1) + 2 * ((lane >> 5) & 1);  // quarter of this lane's pixel
@@ -827,7 +836,11 @@ blend_fwd_kernel(const BlendArgs B) {
                 for (int u = 0; u < U; ++u) {
                     float f[MF ? 1 : CH];
                     if (!MF) {
-                        const float4 *fq = reinterpret_cast<const float4 *>(recb + off[u] * RM + 32);  // 16-byte chunks of the record
+                        // (CS == 3: the address is ready with the list entry -- without this tie to alpha[u] the scheduler requests
+                        // the channels of all U survivors up front and the twelve registers they hold spill elsewhere)
+                        if (CS == 3) asm volatile("" : "+v"(off[u]) : "v"(alpha[u]));
+                        const float4 *fq = CS == 3 ? reinterpret_cast<const float4 *>(cfb + off[u] + 32)             // behind the coefficients
+                                                   : reinterpret_cast<const float4 *>(recb + off[u] * RM + 32);  // 16-byte chunks of the record
 #pragma unroll
                         for (int k = 0; k < CH; k += 4) {
                             const float4 v = fq[k / 4];
@@ -877,7 +890,7 @@ blend_fwd_kernel(const BlendArgs B) {
                         for (int c = 0; c < NCB; ++c) D[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aq[g], bq[g][c], D[g][c], 0, 0, 0);
                 }
             }
-            last = lastoff >= 0 ? base + lastoff / 32 + 1 : last;
+            last = lastoff >= 0 ? base + lastoff / CSB + 1 : last;
         }
         __syncthreads();
     }
