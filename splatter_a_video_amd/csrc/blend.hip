@@ -1330,6 +1330,27 @@ __device__ __forceinline__ void lds_store2_lane15(float *p, float a, float b) {
         : "memory");
 }
 
+// four such pairs behind ONE exec switch, the pairs' places given as constant dword offsets from `base` (the instruction's own
+// offset fields: no address arithmetic per pair).  Per step of the strip-walk kernels: 4 VALU and 6 SALU instructions less than
+// four lds_store2_lane15 calls.
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void lds_store2x4_lane15(float *base, float a0, float b0, float a1, float b1, float a2, float b2, float a3,
+                                                    float b3) {
+    static_assert(O0 >= 0 && O1 >= 0 && O2 >= 0 && O3 >= 0 && O0 < 255 && O1 < 255 && O2 < 255 && O3 < 255, "ds_write2_b32 offsets are 8-bit dword counts");
+    const unsigned addr = (unsigned)(size_t)base;
+    asm volatile(
+        "s_mov_b64 exec, %9\n\t"
+        "ds_write2_b32 %0, %1, %2 offset0:%c10 offset1:%c11\n\t"
+        "ds_write2_b32 %0, %3, %4 offset0:%c12 offset1:%c13\n\t"
+        "ds_write2_b32 %0, %5, %6 offset0:%c14 offset1:%c15\n\t"
+        "ds_write2_b32 %0, %7, %8 offset0:%c16 offset1:%c17\n\t"
+        "s_mov_b64 exec, -1"
+        :
+        : "v"(addr), "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "s"(0x8000800080008000ull), "n"(O0),
+          "n"(O0 + 1), "n"(O1), "n"(O1 + 1), "n"(O2), "n"(O2 + 1), "n"(O3), "n"(O3 + 1)
+        : "memory");
+}
+
 // sum over the four 16-lane rows of a wave (lanes n, n + 16, n + 32, n + 48): two VALU-only swaps (gfx950 v_permlane16_swap /
 // v_permlane32_swap), every lane ends up with the total
 typedef unsigned u32x2_b __attribute__((ext_vector_type(2)));
@@ -2119,8 +2140,8 @@ blend_bwd_quarter_kernel(const BlendArgs B) {
                     }
                     row_scan_add4(rs[0], rs[1], rs[2], rs[3]);
                     row_shr1_add4(R, rs, Rs4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) lds_store2_lane15(pixrow + G * GS + i * PW + 6, T[i], Rs4[i] + rs[i]);
+                    lds_store2x4_lane15<6, PW + 6, 2 * PW + 6, 3 * PW + 6>(pixrow + G * GS, T[0], Rs4[0] + rs[0], T[1], Rs4[1] + rs[1], T[2],
+                                                                           Rs4[2] + rs[2], T[3], Rs4[3] + rs[3]);
                     f32x4 lx4 = {0.f, 0.f, 0.f, 0.f}, ly4 = {0.f, 0.f, 0.f, 0.f};
                     if (ABS) {
                         lx4 = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], blx, lx4, 0, 0, 0);
@@ -3070,10 +3091,10 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                     row_shr1_add4(R[g], rs[g], Rs[g]);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    lds_store2_lane15(state + G * GS + i * 4, T[i], Rs[0][i] + rs[0][i]);
-                    lds_store2_lane15(state + G * GS + i * 4 + 2, Rs[1][i] + rs[1][i], Rs[2][i] + rs[2][i]);
-                }
+                for (int i = 0; i < 4; i += 2)   // two pixels (four pairs) per exec switch
+                    lds_store2x4_lane15<0, 2, 4, 6>(state + G * GS + i * 4, T[i], Rs[0][i] + rs[0][i], Rs[1][i] + rs[1][i],
+                                                    Rs[2][i] + rs[2][i], T[i + 1], Rs[0][i + 1] + rs[0][i + 1], Rs[1][i + 1] + rs[1][i + 1],
+                                                    Rs[2][i + 1] + rs[2][i + 1]);
                 f32x4 lx4 = {0.f, 0.f, 0.f, 0.f}, ly4 = {0.f, 0.f, 0.f, 0.f};   // -conic (centre - pixel): the sign returns in the combine
                 lx4 = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], blx, lx4, 0, 0, 0);
                 ly4 = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bly, ly4, 0, 0, 0);
@@ -3646,8 +3667,8 @@ blend_bwd_wide_quarter_kernel(const BlendArgs B) {
                 }
                 row_scan_add4(rs[0], rs[1], rs[2], rs[3]);
                 row_shr1_add4(R, rs, Rs4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) lds_store2_lane15(state + G * GS + i * 2, T[i], Rs4[i] + rs[i]);
+                lds_store2x4_lane15<0, 2, 4, 6>(state + G * GS, T[0], Rs4[0] + rs[0], T[1], Rs4[1] + rs[1], T[2], Rs4[2] + rs[2], T[3],
+                                                Rs4[3] + rs[3]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int s = 4 * G + i;
