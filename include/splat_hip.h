@@ -56,6 +56,31 @@ void splat_set_deterministic(int on);
 int splat_get_deterministic(void);
 /* dst[0 .. n) = value on `stream` (gradient-bucket zeroing without a framework fill kernel). */
 int splat_fill_f32(float *dst, size_t n, float value, splat_stream_t stream);
+/* Process-wide options, set THROUGH THE ABI (the library reads no environment variable).  Keys (default):
+     "bwd_quarters"   (1)  backward tile kernels walk one survivor list per 4x4 quarter when the forward's cull words are given;
+                           0: the block-level matrix-core kernels everywhere (what a caller without cull words gets)
+     "bwd_kernel_dpp" (0)  1: the DPP-reduction pair kernel instead of the matrix-core kernels (A/B measurements)
+     "sets_std"       (1)  the three-set backward's float4 record stores + the forward's packed records for the renderer's own
+                           plan (rgb 0-2 | depth 3 | 19 attributes 4-22); 0: the generic slot -> channel routing for every plan
+     "bin_slot_keys"  (0)  1: pair-slot sort keys + owner array also where the packed (id, k) keys fit (tests: small sizes)
+     "deterministic"  (0)  = splat_set_deterministic
+   Unknown key: SPLAT_E_ARG.  Set them before the first launch that depends on them (they are read at launch time). */
+int splat_set_option(const char *key, int value);
+int splat_get_option(const char *key, int *value);
+
+/* A feature SOURCE of a composited row: row channels [c0, c0 + cn) come from dense rows feature[P, cn]; frame f of a batch
+   reads feature + f * frame_stride floats (0: one tensor shared by the frames).  d_feature (Gaussian-side backward only; NULL:
+   no gradient wanted) has the same layout: a shared source receives the SUM over the frames, a per-frame source every frame's
+   own gradient (both ADDED).  A set of the reference's renderer is the concatenation of its sources
+   (RenderFeatures.combine, src/pointrix/utils/renderer/renderer_utils.py:31-72; e.g. ["track_gs"] + render_attributes,
+   src/trainer_fragGS.py:511 -- track_gs = position(ids2) differs per frame, the attributes do not). */
+typedef struct splat_feature_source_t {
+    int32_t c0, cn;
+    const float *feature;
+    float *d_feature;
+    int64_t frame_stride;
+} splat_feature_source_t;
+#define SPLAT_MAX_SOURCES 8
 
 /* ---- project_point : replaces projectPointsForward/Backward (src/project_point.cu:147-227) ---- */
 /* uv, depth: fully written. */
@@ -520,6 +545,13 @@ int splat_frames_gauss_backward_static_set(int F, int P, int cn, int W, int H, i
  * pack_scratch: F * P * splat_blend_sets_pack_floats() floats.  Other widths / routings: the per-set calls above. */
 /* forward of a row whose feature sets live in their own tensors (no concatenated [F,P,C] row; same tables as below, in any
  * routing: set g = row channels [set_c0[g], + set_cn[g]) from set_feature[g]); otherwise splat_alpha_blending_forward_batch */
+int splat_alpha_blending_forward_batch_sources(int F, int P, int C, int nsrc, const splat_feature_source_t *src,
+                                               const float *uv, const float *conic, const float *opacity,
+                                               int64_t opacity_frame_stride, const int32_t *idx_sorted,
+                                               const int32_t *tile_range, int64_t capacity, const float *bg_channels, int W,
+                                               int H, int K, int enable_truncation, float *out, float *final_T,
+                                               int32_t *ncontrib, int32_t *gs_idx, float *pack_scratch, uint32_t *cull_flags,
+                                               splat_stream_t stream);
 int splat_alpha_blending_forward_batch_sets(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
                                             const float *const *set_feature, const int64_t *set_feature_fs,
                                             const float *uv, const float *conic, const float *opacity,
@@ -529,6 +561,9 @@ int splat_alpha_blending_forward_batch_sets(int F, int P, int C, const int32_t *
                                             int32_t *ncontrib, int32_t *gs_idx, float *pack_scratch, uint32_t *cull_flags,
                                             splat_stream_t stream);
 size_t splat_blend_sets_pair_stride(int C);
+/* 1 when splat_alpha_blending_backward_batch_sets_packed stages the forward's packed records for this plan (the renderer's own:
+   rgb 0-2 | depth 3 | 19 attributes 4-22, with cull words, options "sets_std" and "bwd_quarters" on): no pack_scratch needed */
+int splat_blend_sets_uses_forward_pack(int C, const int32_t *set_c0, const int32_t *set_cn, int has_cull_flags);
 size_t splat_blend_sets_pack_floats(void);
 /* The same three blends backward in TWO tile passes sharing one pair record (the renderer's configuration: a tap set of <= 3
  * channels, the per-frame depth [F,P] blended with the live opacity, an attribute set of <= 20 channels blended with
@@ -658,6 +693,44 @@ int splat_frames_gauss_backward_dynamic_sets(int F, int P, int I, int C, int W, 
  *      seg_end_host[nseg] (host, ascending, last == n) and seg_lr_host[nseg] (host): learning rate of each contiguous
  *      segment (parameter group); grad_scale multiplies the gradient first (1 / world size for a mean); step >= 1 is
  *      the 1-based step count t of the bias corrections.  All device buffers 16-byte aligned. ---- */
+/* splat_frames_gauss_backward_dynamic_sets with the row described by SOURCES (nsrc <= SPLAT_MAX_SOURCES): the gradient of a shared
+ * source (frame_stride 0) is the sum over the frames, ADDED to d_feature[P, cn]; a per-frame source (frame_stride != 0) gets
+ * every frame's own gradient ADDED at d_feature + f * frame_stride (track_gs: the gradient then reaches the spline through
+ * splat_dynamic_positions_batch_backward).  Channels no source with a d_feature covers (the depth channel) are skipped. */
+int splat_frames_gauss_backward_dynamic_sources(int F, int P, int I, int C, int W, int H, int64_t capacity,
+                                                const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
+                                                const void *tab, const float *position, const float *cubic, int cubic_layout,
+                                                const float *rotation, const float *rot_poly, const float *rot_fourier,
+                                                const float *opacity, const float *scaling, const float *extr,
+                                                float *d_position, float *d_cubic, float *d_rotation, float *d_opacity,
+                                                float *d_scaling, int nsrc, const splat_feature_source_t *src,
+                                                int depth_channel, float *tap, float *abs_tap, int32_t *radii_max,
+                                                splat_stream_t stream);
+/* the static-Gaussian counterpart (shared sources only: a per-frame source with a d_feature is SPLAT_E_ARG) */
+int splat_frames_gauss_backward_static_sources_cam(int F, int P, int C, int W, int H, int64_t capacity,
+                                                   const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
+                                                   const float *xyz, const float *scales, const float *uquats,
+                                                   const splat_camera_t *cam, int accumulate, float *d_xyz, float *d_scales,
+                                                   float *d_uquats, float *d_opacity, int nsrc,
+                                                   const splat_feature_source_t *src, int depth_channel, float *tap,
+                                                   float *abs_tap, int32_t *radii_max, splat_stream_t stream);
+
+/* position(t_f) of every Gaussian (spline model, dynamic_gaussian_with_base_point_cloud.py:236-250) at the F frame times of
+ * `tab` (the device table of splat_frame_preprocess_forward_batch): out[f * out_frame_stride + 3 n + j] -- the pair frames of a
+ * training batch (track_gs = position(ids2), src/trainer_fragGS.py:486-507; the node sequence of its ARAP term, :671-675) in
+ * one launch.  Backward: g (same indexing) is ADDED into d_position [P,3] and into the coefficient rows of every frame's
+ * segment of d_cubic (either may be NULL); no atomics. */
+int splat_dynamic_positions_batch_forward(int F, int P, int I, const void *tab, const float *position, const float *cubic,
+                                          int cubic_layout, float *out, int64_t out_frame_stride, splat_stream_t stream);
+int splat_dynamic_positions_batch_backward(int F, int P, int I, const void *tab, const float *g, int64_t g_frame_stride,
+                                           int cubic_layout, float *d_position, float *d_cubic, splat_stream_t stream);
+
+/* L1 image loss and its gradient in one pass (l1_loss of the reference's training step, src/trainer_fragGS.py:573-600):
+ * grad[f, i] = scale * sign(pred[f * pred_frame_stride + i] - target[f, i]) for i < inner (pred may be a channel slice of a wider
+ * image row), *loss_sum (zero-init, optional) += sum |pred - target| (float atomics: the sum is not bit-reproducible, the gradient is). */
+int splat_l1_loss_grad(int F, int64_t inner, const float *pred, int64_t pred_frame_stride, const float *target, float scale,
+                       float *grad, float *loss_sum, splat_stream_t stream);
+
 #define SPLAT_ADAM_MAX_SEGMENTS 16
 int splat_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int nseg,
                     const int64_t *seg_end_host, const float *seg_lr_host, float beta1, float beta2, float eps,
@@ -672,6 +745,21 @@ int splat_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, 
  *      [Nt-1,S,3,3]) = the rotation of every (frame, sample). ---- */
 int splat_arap_energy(int Nt, int Nv, int K, int S, const float *nodes, const int32_t *nbr, const float *weight,
                       const int64_t *sample_idx, float *energy, float *d_nodes, float *rotations, splat_stream_t stream);
+
+/* B node sequences in one launch (the (ids1, ids2) pairs of a training batch, src/trainer_fragGS.py:671-675): sequence b =
+ * nodes + b * node_batch_stride ([Nt, Nv, 3]); sample_idx [B, S]; neighbour rows BY SAMPLE nbr [B, S, K] (vertex ids, -1 = no
+ * edge), weight likewise or NULL (1 per edge); energy [B] and d_nodes (strides of nodes; NULL: none) zero-init, ADDED to. */
+int splat_arap_energy_batch(int B, int Nt, int Nv, int K, int S, const float *nodes, int64_t node_batch_stride,
+                            const int32_t *nbr, const float *weight, const int64_t *sample_idx, float *energy, float *d_nodes,
+                            float grad_scale /* d_nodes += grad_scale * gradient; the energy is not scaled */,
+                            splat_stream_t stream);
+/* K <= 8 nearest points of S query VERTICES (query_idx [B, S]: indices into the set itself) among the N points of each of B
+ * point sets (set b at points + b * points_batch_stride), brute force in two launches: dists / idx [B, S, K] ascending, ties ->
+ * smaller index, the query itself included -- knn_points(points, points)[sample] for the 512 sampled vertices of the ARAP term
+ * (src/geometry_utils.py:17-19,98-101) without a grid build per point set.  scratch: splat_knn_brute_scratch_bytes(B, N, S). */
+size_t splat_knn_brute_scratch_bytes(int B, int N, int S);
+int splat_knn_brute_batch(int B, int N, int S, int K, const float *points, int64_t points_batch_stride,
+                          const int64_t *query_idx, float *dists, int32_t *idx, void *scratch, splat_stream_t stream);
 
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ---- */
 void splat_profile_enable(int on);

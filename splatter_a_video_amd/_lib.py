@@ -17,12 +17,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "splat_last_error", "splat_abi_version", "splat_build_id", "splat_set_deterministic", "splat_get_deterministic",
-    "splat_fill_f32",
+    "splat_fill_f32", "splat_set_option", "splat_get_option",
     "splat_project_point_forward", "splat_project_point_backward",
     "splat_compute_cov3d_forward", "splat_compute_cov3d_backward",
     "splat_ewa_project_forward", "splat_ewa_project_backward",
@@ -52,8 +52,17 @@ SYMBOLS = [
     "splat_preprocess_persp_forward", "splat_preprocess_persp_backward",
     "splat_blend_sets2_pair_stride", "splat_blend_sets2_pack_floats", "splat_alpha_blending_backward_batch_sets2",
     "splat_frames_gauss_backward_static_sets2_cam", "splat_frames_gauss_backward_dynamic_sets2",
+    "splat_alpha_blending_forward_batch_sources", "splat_frames_gauss_backward_dynamic_sources",
+    "splat_frames_gauss_backward_static_sources_cam", "splat_blend_sets_uses_forward_pack",
+    "splat_dynamic_positions_batch_forward", "splat_dynamic_positions_batch_backward",
+    "splat_arap_energy_batch", "splat_knn_brute_scratch_bytes", "splat_knn_brute_batch", "splat_l1_loss_grad",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]
+
+# environment switches of earlier rounds, applied ONCE at load THROUGH the ABI (splat_set_option): the library itself reads no
+# environment variable.  {variable: (option key, value that turns the non-default on, option value)}
+_ENV_OPTIONS = {"SPLAT_BWD_QUARTERS": ("bwd_quarters", "0", 0), "SPLAT_BWD_KERNEL": ("bwd_kernel_dpp", "dpp", 1),
+                "SPLAT_SETS_STD": ("sets_std", "0", 0), "SPLAT_BIN_SLOT_KEYS": ("bin_slot_keys", "1", 1)}
 
 
 class SplatError(RuntimeError):
@@ -99,9 +108,16 @@ def lib() -> ctypes.CDLL:
         L.splat_blend_sets2_pack_floats.restype = ctypes.c_size_t
         L.splat_blend_sets2_pack_floats.argtypes = []
         L.splat_profile_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+        L.splat_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        L.splat_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+        L.splat_knn_brute_scratch_bytes.restype = ctypes.c_size_t
+        L.splat_knn_brute_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         if L.splat_abi_version() != ABI_VERSION:
             raise SplatError("libsplat_hip.so ABI version mismatch; rebuild it")
         _lib = L
+        for var, (key, on, value) in _ENV_OPTIONS.items():
+            if os.environ.get(var) == on:
+                check(L.splat_set_option(key.encode(), ctypes.c_int(value)))
     return _lib
 
 
@@ -151,6 +167,43 @@ def need(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
 def build_id() -> str:
     """hash of the sources the loaded library was built from (csrc/Makefile); measurement records carry it"""
     return lib().splat_build_id().decode()
+
+
+def set_option(key: str, value: int) -> None:
+    """process-wide option of the library (include/splat_hip.h: splat_set_option): "bwd_quarters", "bwd_kernel_dpp", "sets_std",
+    "bin_slot_keys", "deterministic"; read at launch time"""
+    check(lib().splat_set_option(key.encode(), ctypes.c_int(int(value))))
+
+
+def get_option(key: str) -> int:
+    v = ctypes.c_int(0)
+    check(lib().splat_get_option(key.encode(), ctypes.byref(v)))
+    return v.value
+
+
+class option:
+    """``with L.option("bwd_quarters", 0): ...`` -- an option for the duration of a block (tests)"""
+
+    def __init__(self, key: str, value: int):
+        self.key, self.value = key, int(value)
+
+    def __enter__(self):
+        self.old = get_option(self.key)
+        set_option(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.key, self.old)
+        return False
+
+
+class FeatureSource(ctypes.Structure):
+    """mirror of splat_feature_source_t (include/splat_hip.h)"""
+    _fields_ = [("c0", ctypes.c_int32), ("cn", ctypes.c_int32), ("feature", ctypes.c_void_p), ("d_feature", ctypes.c_void_p),
+                ("frame_stride", ctypes.c_int64)]
+
+
+MAX_SOURCES = 8
 
 
 def set_deterministic(on: bool) -> None:

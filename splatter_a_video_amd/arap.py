@@ -9,7 +9,8 @@ per (vertex, frame), 3x3 SVD by Jacobi rotations), forward and gradient together
 """
 from __future__ import annotations
 
-from typing import Optional
+import ctypes
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
@@ -82,3 +83,41 @@ def arap_rotations(nodes_sequence: Tensor, nbr: Tensor, weight: Optional[Tensor]
                                       L.ptr(L.need(sample_idx.long(), "sample_idx", torch.int64)), L.ptr(energy), L.ptr(None),
                                       L.ptr(rot), L.stream()))
     return rot
+
+
+def pair_connectivity(nodes: Tensor, sample_idx: Tensor, K: int = 5, radius: float = 0.1, least_edge_num: int = 3) -> Tensor:
+    """Neighbour rows of the SAMPLED vertices only: what ``cal_connectivity_from_points(points, K=K)`` (reference:
+    src/geometry_utils.py:7-38 -- K + 1 nearest neighbours, the vertex itself dropped, neighbours past ``least_edge_num`` cut
+    at ``radius``) gives for the rows ``sample_idx`` -- the only rows ``cal_arap_error`` reads.  ``nodes`` [B, Nv, 3] (the
+    pairs' first frames), ``sample_idx`` [B, S]; returns nbr [B, S, K] int32 (vertex ids, -1 = no edge)."""
+    from .knn import knn_brute_batch
+    d, i = knn_brute_batch(nodes, sample_idx, K + 1)
+    d, i = d[:, :, 1:], i[:, :, 1:]
+    cut = d >= radius * radius
+    cut[:, :, :least_edge_num] = False
+    return torch.where(cut, torch.full_like(i, -1), i).contiguous()
+
+
+def pair_arap(pairs: Tensor, sample_idx: Tensor, nbr: Tensor, K_table: int = 10, d_pairs: Optional[Tensor] = None,
+              grad_scale: float = 1.0) -> Tensor:
+    """``cal_arap_error`` of B node PAIRS in one launch: ``pairs`` [B, 2, Nv, 3] (position(ids1), position(ids2) of every pair,
+    contiguous), ``sample_idx`` [B, S], ``nbr`` [B, S, K] from ``pair_connectivity`` (edge weights 1, the edge table padded to
+    ``K_table`` slots like the reference's default ``K = 10`` -- empty slots contribute nothing).  Returns the B energies
+    (each divided by Nt = 2, as the reference does); ``d_pairs`` (zero-init buffer of ``pairs``' shape) receives
+    ``grad_scale`` x the gradient of the UNDIVIDED energy / Nt by ADDITION (raw operator: no autograd)."""
+    if pairs.dim() != 4 or pairs.shape[1] != 2 or pairs.shape[3] != 3 or not pairs.is_contiguous():
+        raise ValueError("pairs must be a contiguous [B, 2, Nv, 3] tensor")
+    pairs = L.need(pairs, "pairs")
+    B, _, Nv, _ = pairs.shape
+    S, K = nbr.shape[1], nbr.shape[2]
+    nbr = L.need(nbr, "nbr", torch.int32)
+    sample_idx = L.need(sample_idx, "sample_idx", torch.int64)
+    if tuple(sample_idx.shape) != (B, S) or nbr.shape[0] != B:
+        raise ValueError("sample_idx must be [B, S] and nbr [B, S, K]")
+    if d_pairs is not None and (tuple(d_pairs.shape) != tuple(pairs.shape) or not d_pairs.is_contiguous()):
+        raise ValueError("d_pairs must be a contiguous buffer of pairs' shape")
+    energy = torch.zeros(B, dtype=torch.float32, device=pairs.device)
+    L.check(L.lib().splat_arap_energy_batch(L.ci(B), L.ci(2), L.ci(Nv), L.ci(K), L.ci(S), L.ptr(pairs), ctypes.c_int64(2 * Nv * 3),
+                                            L.ptr(nbr), L.ptr(None), L.ptr(sample_idx), L.ptr(energy), L.ptr(d_pairs),
+                                            L.cf(grad_scale / 2.0), L.stream()))
+    return energy / 2.0

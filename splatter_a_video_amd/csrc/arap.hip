@@ -98,14 +98,35 @@ __device__ void kabsch_rotation(const float S[3][3], float R[3][3]) {
         for (int c = 0; c < 3; ++c) R[r][c] = W[r][0] * U[c][0] + W[r][1] * U[c][1] + d3 * W[r][2] * U[c][2];
 }
 
+// Batch of node sequences (grid.y = sequence b; the pairs (ids1, ids2) of a training batch, src/trainer_fragGS.py:671-675):
+// sequence b's nodes / gradients at + b * node_bs floats, its sampled vertices at sample_idx + b * sample_bs, its energy at
+// energy[b].  nbr_compact: the neighbour table (and `weight`) is [S, K] per sequence (row = SAMPLE s, + b * S * K) instead of
+// [Nv, K] (row = vertex) -- only the sampled vertices' neighbours are ever read.
+struct ArapBatch {
+    long long node_bs, sample_bs;
+    int nbr_compact;
+    float grad_scale;   // d_nodes += grad_scale * d energy / d nodes (the loss weight of the term; the energy itself is not scaled)
+};
+
 __global__ void __launch_bounds__(128)
 arap_kernel(int Nt, int Nv, int K, int S_, const float *__restrict__ nodes, const int *__restrict__ nbr,
             const float *__restrict__ weight, const long long *__restrict__ sample_idx, float *__restrict__ energy,
-            float *__restrict__ d_nodes, float *__restrict__ rot_out) {
+            float *__restrict__ d_nodes, float *__restrict__ rot_out, const ArapBatch bt) {
     const int g = blockIdx.x * 128 + threadIdx.x;
     if (g >= S_ * (Nt - 1)) return;
     const int s = g % S_, t = 1 + g / S_;
+    const int b = blockIdx.y;
+    nodes += (size_t)b * bt.node_bs;
+    if (d_nodes) d_nodes += (size_t)b * bt.node_bs;
+    sample_idx += (size_t)b * bt.sample_bs;
+    energy += b;
+    if (rot_out) rot_out += (size_t)b * (size_t)S_ * (Nt - 1) * 9;
     const int i = (int)sample_idx[s];
+    if (bt.nbr_compact) {   // rows by sample: shift the tables so that row i below is sample s of sequence b
+        const long long off = ((long long)b * S_ + s - i) * K;
+        nbr += off;
+        if (weight) weight += off;
+    }
     const float *src = nodes, *tgt = nodes + (size_t)t * Nv * 3;
     const float pi0[3] = {src[3 * i], src[3 * i + 1], src[3 * i + 2]}, pit[3] = {tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2]};
     float es[ARAP_MAXK][3], et[ARAP_MAXK][3], w[ARAP_MAXK];
@@ -153,8 +174,8 @@ arap_kernel(int Nt, int Nv, int K, int S_, const float *__restrict__ nodes, cons
             float gt[3], gs[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                gt[c] = 2.f * w[k] * st[c];
-                gs[c] = -2.f * w[k] * (R[0][c] * st[0] + R[1][c] * st[1] + R[2][c] * st[2]);
+                gt[c] = bt.grad_scale * (2.f * w[k] * st[c]);
+                gs[c] = bt.grad_scale * (-2.f * w[k] * (R[0][c] * st[0] + R[1][c] * st[1] + R[2][c] * st[2]));
                 git[c] += gt[c]; gi0[c] += gs[c];
                 atomic_add_f32(d_nodes + (size_t)t * Nv * 3 + 3 * j + c, -gt[c]);
                 atomic_add_f32(d_nodes + 3 * j + c, -gs[c]);
@@ -178,8 +199,31 @@ extern "C" int splat_arap_energy(int Nt, int Nv, int K, int S, const float *node
     SPLAT_CHECK_ARG(nodes && nbr && energy && (S == 0 || sample_idx), "null pointer");
     if (S == 0 || Nt < 2) return SPLAT_OK;
     const int total = S * (Nt - 1);
+    ArapBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    bt.grad_scale = 1.f;
     SPLAT_LAUNCH("arap_energy", arap_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream, Nt, Nv, K, S,
-                 nodes, nbr, weight, (const long long *)sample_idx, energy, d_nodes, rotations);
+                 nodes, nbr, weight, (const long long *)sample_idx, energy, d_nodes, rotations, bt);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+// B node sequences in one launch: sequence b = nodes + b * node_batch_stride ([Nt, Nv, 3]), sampled vertices sample_idx + b * S,
+// neighbour rows BY SAMPLE nbr[b, s, 0..K) (vertex ids; -1: no edge; what a K-nearest-neighbour query of the sampled vertices
+// alone returns), weight likewise or NULL (1 per edge); energy[b] += that sequence's energy (zero-init), d_nodes (zero-init,
+// same strides as nodes) += grad_scale * its gradient (the term's loss weight; the energy is not scaled).  The (ids1, ids2) pairs of a training batch, src/trainer_fragGS.py:671-675.
+extern "C" int splat_arap_energy_batch(int B, int Nt, int Nv, int K, int S, const float *nodes, int64_t node_batch_stride,
+                                       const int32_t *nbr, const float *weight, const int64_t *sample_idx, float *energy,
+                                       float *d_nodes, float grad_scale, void *stream) {
+    SPLAT_CHECK_ARG(B >= 1 && B <= 65535 && Nt >= 1 && Nv >= 1 && K >= 1 && K <= ARAP_MAXK && S >= 0, "bad sizes (K <= 16)");
+    SPLAT_CHECK_ARG(nodes && nbr && energy && (S == 0 || sample_idx), "null pointer");
+    SPLAT_CHECK_ARG(node_batch_stride >= (int64_t)Nt * Nv * 3, "node_batch_stride below Nt * Nv * 3");
+    if (S == 0 || Nt < 2) return SPLAT_OK;
+    const int total = S * (Nt - 1);
+    ArapBatch bt;
+    bt.node_bs = node_batch_stride; bt.sample_bs = S; bt.nbr_compact = 1; bt.grad_scale = grad_scale;
+    SPLAT_LAUNCH("arap_energy", arap_kernel, dim3((unsigned)((total + 127) / 128), (unsigned)B), dim3(128), 0, (hipStream_t)stream,
+                 Nt, Nv, K, S, nodes, nbr, weight, (const long long *)sample_idx, energy, d_nodes, (float *)nullptr, bt);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }

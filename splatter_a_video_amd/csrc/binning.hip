@@ -78,10 +78,7 @@ static int bits_for(long long n) {  // bits that hold 0 .. n - 1
 #endif
 static int pair_key_kbits(int P, int T) {
     if (!BIN_PACKED_KEYS) return 0;
-    static const bool slot_keys = [] {   // SPLAT_BIN_SLOT_KEYS=1 (read once): the slot form everywhere -- how the tests reach it at small sizes
-        const char *e = getenv("SPLAT_BIN_SLOT_KEYS");
-        return e && e[0] == '1';
-    }();
+    const bool slot_keys = splat_option(SPLAT_OPT_BIN_SLOT_KEYS) != 0;   // the slot form everywhere -- how the tests reach it at small sizes
     if (slot_keys) return 0;
     const int kb = bits_for(T), ib = bits_for(P);
     return kb + ib <= 32 ? kb : 0;

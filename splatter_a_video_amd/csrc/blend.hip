@@ -163,6 +163,12 @@ struct BlendArgs {
     // tensor (the caller does not concatenate a row / a gradient image); NULL: `feature` / `dL_dout` hold the whole row
     const float *sf0, *sf1, *sf2, *sdl0, *sdl1, *sdl2;
     long long sfs0, sfs1, sfs2;
+    // forward packing of a row whose channels come from several SOURCES (splat_alpha_blending_forward_batch_sources): source s =
+    // row channels [src_c0[s], + src_cn[s]) from dense rows src_f[s][P, cn] (+ frame * src_fs[s]); nsrc = 0: sf0 .. sf2 above
+    int nsrc;
+    int src_c0[SPLAT_MAX_SOURCES], src_cn[SPLAT_MAX_SOURCES];
+    const float *src_f[SPLAT_MAX_SOURCES];
+    long long src_fs[SPLAT_MAX_SOURCES];
     // optional [F, cap] words, one per sorted tile entry: byte w != 0 = the forward's cull kept the entry for the tile's
     // block w (the keep word of tile_cull).  The forward writes them, the strip-walk backward kernels read them instead
     // of repeating the cull (13 % of their VALU instructions); NULL: every kernel culls for itself.
@@ -385,10 +391,11 @@ pack_kernel(const BlendArgs B) {
         for (int k = 0; k < RS; k += 4) row[k / 4] = make_float4(r[k], r[k + 1], r[k + 2], r[k + 3]);
         __syncthreads();
         const int nrec = imin_(256, A.P - i0);
-        if (!A.feature) {  // row channel c of set g sits at float 8 + c - c0 of the record (chunk [c0, c0 + cn) = the whole row)
-            stage_feature_rows(s_rec, LS, 8 + A.s0c0 - A.c0, A.sf0, A.s0cn, i0, nrec);
-            stage_feature_rows(s_rec, LS, 8 + A.s1c0 - A.c0, A.sf1, A.s1cn, i0, nrec);
-            stage_feature_rows(s_rec, LS, 8 + A.s2c0 - A.c0, A.sf2, A.s2cn, i0, nrec);
+        if (!A.feature) {  // row channel c of source s sits at float 8 + c - c0 of the record (chunk [c0, c0 + cn) = the whole row)
+            // (the table is read from the kernel argument block B itself: indexing a modified copy would put it in scratch)
+            for (int sidx = 0; sidx < B.nsrc; ++sidx)
+                stage_feature_rows(s_rec, LS, 8 + B.src_c0[sidx] - B.c0, B.src_f[sidx] + (size_t)blockIdx.y * B.src_fs[sidx],
+                                   B.src_cn[sidx], i0, nrec);
             __syncthreads();
         }
         float4 *dst = reinterpret_cast<float4 *>(A.pack + (size_t)i0 * RS);
@@ -4271,32 +4278,10 @@ static int launch_fwd(const BlendArgs &A, int T, bool enh, bool bias, hipStream_
     return SPLAT_OK;
 }
 
-// SPLAT_BWD_KERNEL=dpp selects the DPP-reduction pair kernel (A/B measurements); default: MFMA reductions
-static bool bwd_use_mfma() {
-    static const int v = [] {
-        const char *e = getenv("SPLAT_BWD_KERNEL");
-        return (e && strcmp(e, "dpp") == 0) ? 0 : 1;
-    }();
-    return v != 0;
-}
-
-// SPLAT_BWD_QUARTERS=0: the block-level matrix-core kernel also where the quarter-list kernel applies (A/B measurements)
-static bool bwd_use_quarters() {
-    static const int v = [] {
-        const char *e = getenv("SPLAT_BWD_QUARTERS");
-        return (e && strcmp(e, "0") == 0) ? 0 : 1;
-    }();
-    return v != 0;
-}
-
-// SPLAT_SETS_STD=0: the generic slot -> channel routing also for the renderer's own plan (tests compare the two)
-static bool sets_std_plan_enabled() {
-    static const int v = [] {
-        const char *e = getenv("SPLAT_SETS_STD");
-        return (e && strcmp(e, "0") == 0) ? 0 : 1;
-    }();
-    return v != 0;
-}
+// kernel selection: options of the ABI (splat_set_option), read at launch time
+static bool bwd_use_mfma() { return splat_option(SPLAT_OPT_BWD_KERNEL_DPP) == 0; }        // 1: the DPP-reduction pair kernel (A/B)
+static bool bwd_use_quarters() { return splat_option(SPLAT_OPT_BWD_QUARTERS) != 0; }      // 0: block-level kernels everywhere
+static bool sets_std_plan_enabled() { return splat_option(SPLAT_OPT_SETS_STD) != 0; }     // 0: generic slot -> channel routing
 
 template <int CH, bool ABS, bool BIAS>
 static int launch_bwd_ab(const BlendArgs &A, int T, bool pair, hipStream_t s) {
@@ -4559,35 +4544,37 @@ extern "C" int splat_alpha_blending_forward_batch(int F, int P, int C, const flo
     return fwd_chunk(A, T, enh, false, (hipStream_t)stream);
 }
 
-// splat_alpha_blending_forward_batch over a row whose feature sets live in their own tensors (no concatenated [F,P,C] row):
-// set g = row channels [set_c0[g], + set_cn[g]) from set_feature[g] ([P, cn] rows; frame stride set_feature_fs[g] floats, 0 =
-// shared by the frames).  HOST arrays of three entries; set_cn[g] = 0: no such set; the sets must tile the row.
-extern "C" int splat_alpha_blending_forward_batch_sets(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
-                                                       const float *const *set_feature, const int64_t *set_feature_fs,
-                                                       const float *uv, const float *conic, const float *opacity,
-                                                       int64_t opacity_frame_stride, const int32_t *idx_sorted,
-                                                       const int32_t *tile_range, int64_t capacity,
-                                                       const float *bg_channels, int W, int H, int K, int enable_truncation,
-                                                       float *out, float *final_T, int32_t *ncontrib, int32_t *gs_idx,
-                                                       float *pack_scratch, uint32_t *cull_flags, splat_stream_t stream) {
+// splat_alpha_blending_forward_batch over a row whose channels come from several SOURCES (no concatenated [F,P,C] row):
+// source s = row channels [c0, c0 + cn) from dense rows feature[P, cn] (frame f at feature + f * frame_stride floats; 0 = shared
+// by the frames -- a per-frame source is e.g. the depth [F,P,1] or track_gs = position(ids2) [F,P,3],
+// src/trainer_fragGS.py:506-511).  The sources must tile the row; d_feature is not used by the forward.
+extern "C" int splat_alpha_blending_forward_batch_sources(int F, int P, int C, int nsrc, const splat_feature_source_t *src,
+                                                          const float *uv, const float *conic, const float *opacity,
+                                                          int64_t opacity_frame_stride, const int32_t *idx_sorted,
+                                                          const int32_t *tile_range, int64_t capacity,
+                                                          const float *bg_channels, int W, int H, int K, int enable_truncation,
+                                                          float *out, float *final_T, int32_t *ncontrib, int32_t *gs_idx,
+                                                          float *pack_scratch, uint32_t *cull_flags, splat_stream_t stream) {
     SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 32 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 32)");
-    SPLAT_CHECK_ARG(set_c0 && set_cn && set_feature && set_feature_fs && bg_channels, "null set table");
+    SPLAT_CHECK_ARG(src && nsrc >= 1 && nsrc <= SPLAT_MAX_SOURCES && bg_channels, "null / oversized source table");
     SPLAT_CHECK_ARG(uv && conic && opacity && idx_sorted && tile_range && out && final_T && ncontrib && pack_scratch, "null pointer");
-    {
-        unsigned long long covered = 0ull;
-        for (int g = 0; g < 3; ++g) {
-            SPLAT_CHECK_ARG(set_cn[g] >= 0 && (set_cn[g] == 0 || (set_c0[g] >= 0 && set_c0[g] + set_cn[g] <= C && set_feature[g])),
-                            "set outside the row / null set feature pointer");
-            for (int k = 0; k < set_cn[g]; ++k) {
-                SPLAT_CHECK_ARG(!(covered & (1ull << (set_c0[g] + k))), "the sets overlap");
-                covered |= 1ull << (set_c0[g] + k);
-            }
-        }
-        SPLAT_CHECK_ARG(covered == (1ull << C) - 1ull, "the sets do not cover the row's channels");
-    }
-    const bool enh = (gs_idx != nullptr) && K > 0;
     BlendArgs A;
     memset(&A, 0, sizeof(A));
+    {
+        unsigned long long covered = 0ull;
+        for (int g = 0; g < nsrc; ++g) {
+            SPLAT_CHECK_ARG(src[g].cn >= 0 && (src[g].cn == 0 || (src[g].c0 >= 0 && src[g].c0 + src[g].cn <= C && src[g].feature)),
+                            "source outside the row / null source pointer");
+            for (int k = 0; k < src[g].cn; ++k) {
+                SPLAT_CHECK_ARG(!(covered & (1ull << (src[g].c0 + k))), "the sources overlap");
+                covered |= 1ull << (src[g].c0 + k);
+            }
+            A.src_c0[g] = src[g].c0; A.src_cn[g] = src[g].cn; A.src_f[g] = src[g].feature; A.src_fs[g] = src[g].frame_stride;
+        }
+        SPLAT_CHECK_ARG(covered == (1ull << C) - 1ull, "the sources do not cover the row's channels");
+    }
+    A.nsrc = nsrc;
+    const bool enh = (gs_idx != nullptr) && K > 0;
     A.P = P; A.C = C;
     A.uv = (const float2 *)uv; A.conic = conic; A.opacity = opacity;
     A.idx_sorted = idx_sorted; A.tile_range = (const int2 *)tile_range;
@@ -4602,10 +4589,27 @@ extern "C" int splat_alpha_blending_forward_batch_sets(int F, int P, int C, cons
     A.pack_fs = (long long)P * (long long)splat_blend_pack_floats(C);
     A.opacity_fs = opacity_frame_stride;
     A.c0 = 0; A.cn = C;
-    A.s0c0 = set_c0[0]; A.s0cn = set_cn[0]; A.s1c0 = set_c0[1]; A.s1cn = set_cn[1]; A.s2c0 = set_c0[2]; A.s2cn = set_cn[2];
-    A.sf0 = set_feature[0]; A.sf1 = set_feature[1]; A.sf2 = set_feature[2];
-    A.sfs0 = set_feature_fs[0]; A.sfs1 = set_feature_fs[1]; A.sfs2 = set_feature_fs[2];
     return fwd_chunk(A, T, enh, false, (hipStream_t)stream);
+}
+
+// The same with (at most) three sets given as parallel HOST arrays of three entries (set_cn[g] = 0: no such set).
+extern "C" int splat_alpha_blending_forward_batch_sets(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
+                                                       const float *const *set_feature, const int64_t *set_feature_fs,
+                                                       const float *uv, const float *conic, const float *opacity,
+                                                       int64_t opacity_frame_stride, const int32_t *idx_sorted,
+                                                       const int32_t *tile_range, int64_t capacity,
+                                                       const float *bg_channels, int W, int H, int K, int enable_truncation,
+                                                       float *out, float *final_T, int32_t *ncontrib, int32_t *gs_idx,
+                                                       float *pack_scratch, uint32_t *cull_flags, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(set_c0 && set_cn && set_feature && set_feature_fs, "null set table");
+    splat_feature_source_t src[3];
+    memset(src, 0, sizeof(src));
+    for (int g = 0; g < 3; ++g) {
+        src[g].c0 = set_c0[g]; src[g].cn = set_cn[g]; src[g].feature = set_feature[g]; src[g].frame_stride = set_feature_fs[g];
+    }
+    return splat_alpha_blending_forward_batch_sources(F, P, C, 3, src, uv, conic, opacity, opacity_frame_stride, idx_sorted,
+                                                      tile_range, capacity, bg_channels, W, H, K, enable_truncation, out, final_T,
+                                                      ncontrib, gs_idx, pack_scratch, cull_flags, stream);
 }
 
 extern "C" int splat_alpha_blending_backward_batch(int F, int P, int C, const int32_t *idx_sorted,
@@ -4686,6 +4690,15 @@ extern "C" int splat_alpha_blending_backward_batch_set(int F, int P, int C, int 
 extern "C" size_t splat_blend_sets_pair_stride(int C) { return (size_t)PAIR_STRIDE(SetsCfg::NG + C); }
 extern "C" size_t splat_blend_sets_pack_floats(void) { return (size_t)Rec<SetsCfg::CH>::RS; }
 
+// Does splat_alpha_blending_backward_batch_sets_packed stage the FORWARD's packed records for this plan (no packing launch, no
+// pack_scratch needed)?  The one place the condition lives: callers ask instead of re-deriving it.
+extern "C" int splat_blend_sets_uses_forward_pack(int C, const int32_t *set_c0, const int32_t *set_cn, int has_cull_flags) {
+    if (!set_c0 || !set_cn) return 0;
+    const bool std_plan = C == 23 && set_c0[0] == 0 && set_cn[0] == 3 && set_c0[1] == 3 && set_cn[1] == 1 && set_c0[2] == 4 &&
+                          set_cn[2] == 19 && sets_std_plan_enabled();
+    return (std_plan && has_cull_flags && bwd_use_quarters()) ? 1 : 0;
+}
+
 static int backward_batch_sets_impl(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
                                     const float *set_bg, const float *uv, const float *conic,
                                     const float *opacity, int64_t opacity_frame_stride,
@@ -4738,10 +4751,13 @@ static int backward_batch_sets_impl(int F, int P, int C, const int32_t *set_c0, 
     A.s0c0 = set_c0[0]; A.s0cn = set_cn[0]; A.s0bg = set_bg[0];
     A.s1c0 = set_c0[1]; A.s1cn = set_cn[1]; A.s1bg = set_bg[1];
     A.s2c0 = set_c0[2]; A.s2cn = set_cn[2]; A.s2bg = set_bg[2];
+    const bool from_forward = forward_pack && splat_blend_sets_uses_forward_pack(C, set_c0, set_cn, cull_flags != nullptr);
     if (!feature) {
         A.sf0 = set_feature[0]; A.sf1 = set_feature[1]; A.sf2 = set_feature[2];
         A.sfs0 = set_feature_fs[0]; A.sfs1 = set_feature_fs[1]; A.sfs2 = set_feature_fs[2];
-        SPLAT_CHECK_ARG((!set_cn[0] || A.sf0) && (!set_cn[1] || A.sf1) && (!set_cn[2] || A.sf2), "null set feature pointer");
+        // (the forward's packed records carry the row: the sets' own tensors are not read, e.g. a row described by sources)
+        SPLAT_CHECK_ARG(from_forward || ((!set_cn[0] || A.sf0) && (!set_cn[1] || A.sf1) && (!set_cn[2] || A.sf2)),
+                        "null set feature pointer");
     }
     if (!dL_dout) {
         A.sdl0 = set_dL[0]; A.sdl1 = set_dL[1]; A.sdl2 = set_dL[2];
@@ -4752,7 +4768,7 @@ static int backward_batch_sets_impl(int F, int P, int C, const int32_t *set_c0, 
     // the renderer's own plan (rgb 0-2 | depth 3 | 19 attributes 4-22): channel gradients stored as whole float4
     const bool std_plan = C == 23 && set_c0[0] == 0 && set_cn[0] == 3 && set_c0[1] == 3 && set_cn[1] == 1 && set_c0[2] == 4 &&
                           set_cn[2] == 19 && sets_std_plan_enabled();
-    if (forward_pack && std_plan && A.cull_flags && bwd_use_quarters()) {
+    if (from_forward) {
         // the forward's packed records of this row (splat_alpha_blending_forward_batch_sets / _forward with C = 23: 32 floats per
         // Gaussian and frame) are staged directly: no packing launch
         A.pack = const_cast<float *>(forward_pack);

@@ -32,6 +32,9 @@ void splat_set_error(const char *fmt, ...);
     } while (0)
 
 bool splat_deterministic();   // splat_set_deterministic (runtime.hip)
+// splat_set_option keys (runtime.hip): kernel selection through the ABI, read at launch time
+enum { SPLAT_OPT_BWD_QUARTERS = 0, SPLAT_OPT_BWD_KERNEL_DPP, SPLAT_OPT_SETS_STD, SPLAT_OPT_BIN_SLOT_KEYS, SPLAT_OPT_COUNT };
+int splat_option(int id);
 
 // ---------------------------------------------------------------- profiled launches
 // When splat_profile_enable(1) was called, every kernel launch is bracketed by two hipEvents

@@ -135,6 +135,71 @@ __global__ __launch_bounds__(DYN_BLOCK) void position_pf_bwd_kernel(int P, DynBa
     }
 }
 
+
+// ---- position(t) of every Gaussian at ALL frame times of a table (the pair frames of a training batch: track_gs =
+// position(ids2), src/trainer_fragGS.py:486-507; the node sequence of the ARAP term, :671-675).  One thread per (Gaussian,
+// axis) walks the frames: base position read once, the frame's 48-byte spline segment per frame, the arithmetic of
+// dynamic_eval_fwd_kernel.  out[f * out_fs + 3 n + j]; grid.y slices the frames.
+__global__ __launch_bounds__(DYN_BLOCK) void dynamic_positions_fwd_kernel(int F, int P, int I, int layout,
+                                                                         const DynTab *__restrict__ tab,
+                                                                         const float *__restrict__ position,
+                                                                         const float *__restrict__ cubic, float *__restrict__ out,
+                                                                         long long out_fs) {
+    const size_t t = (size_t)blockIdx.x * DYN_BLOCK + threadIdx.x;
+    if (t >= (size_t)P * 3) return;
+    const size_t n = t / 3, j = t - 3 * n;
+    const float base = position[t];
+    const int per = (F + gridDim.y - 1) / gridDim.y;
+    const int f0 = blockIdx.y * per, f1 = imin_(F, f0 + per);
+    for (int f = f0; f < f1; ++f) {
+        const CubicAddr ca = cubic_addr(layout, P, I, tab[f].seg);
+        const float d = tab[f].d;
+        const float *c = cubic + ca.seg_off + n * ca.stride_n + j;
+        const size_t row = ca.stride_k;
+        const float c0 = c[0], c1 = c[row], c2 = c[2 * row], c3 = c[3 * row];
+        float p = c3 + c2 * d;
+        p = p + c1 * (d * d);
+        p = p + c0 * (d * d * d);
+        out[(size_t)f * out_fs + t] = p + base;
+    }
+}
+
+// Backward: g[f * g_fs + 3 n + j] = dL/dposition(t_f) -> d_position += sum_f g, the four coefficient rows of frame f's segment
+// += g * (d^3, d^2, d, 1).  One thread per (Gaussian, axis) walks ALL frames (no atomics: it owns its rows); frames of one
+// segment that follow each other accumulate in registers and are flushed when the walk leaves the segment.
+__global__ __launch_bounds__(DYN_BLOCK) void dynamic_positions_bwd_kernel(int F, int P, int I, int layout,
+                                                                         const DynTab *__restrict__ tab,
+                                                                         const float *__restrict__ g, long long g_fs,
+                                                                         float *__restrict__ d_position,
+                                                                         float *__restrict__ d_cubic) {
+    const size_t t = (size_t)blockIdx.x * DYN_BLOCK + threadIdx.x;
+    if (t >= (size_t)P * 3) return;
+    const size_t n = t / 3, j = t - 3 * n;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, dpos = 0.f;
+    int cur = -1;
+    auto flush = [&](int seg) {
+        if (seg < 0 || !d_cubic) return;
+        const CubicAddr ca = cubic_addr(layout, P, I, seg);
+        float *c = d_cubic + ca.seg_off + n * ca.stride_n + j;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k * ca.stride_k] += acc[k];
+    };
+    for (int f = 0; f < F; ++f) {
+        const int seg = tab[f].seg;
+        if (seg != cur) {
+            flush(cur);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = 0.f;
+            cur = seg;
+        }
+        const float d = tab[f].d, v = g[(size_t)f * g_fs + t];
+        dpos += v;
+        acc[0] += v * (d * d * d); acc[1] += v * (d * d); acc[2] += v * d; acc[3] += v;
+    }
+    flush(cur);
+    if (d_position) d_position[t] += dpos;
+}
+
 }  // namespace
 
 extern "C" int splat_position_poly_fourier_forward(int P, const float *basis_host, const float *position,
@@ -217,6 +282,45 @@ extern "C" int splat_dynamic_eval_backward(int P, int I, int seg, float d, const
         SPLAT_LAUNCH("dynamic_eval_bwd", dynamic_eval_bwd_kernel<false>, dyn_grid(P), dim3(DYN_BLOCK), 0, s, P,
                      cubic_addr(cubic_layout, P, I, seg), d, load_basis(basis_host), rotation, (const float4 *)rot_poly, (const float4 *)rot_fourier, opacity,
                      scaling, g_pos, g_rot, g_opa, g_scl, d_position, d_cubic, d_rotation, d_opacity, d_scaling);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+// position(t_f) of every Gaussian for the F frame times of `tab` (device table of F 64-byte entries {int seg; float d; float
+// basis[12]; pad}: the table of splat_frame_preprocess_forward_batch): out[f * out_frame_stride + 3 n + j].  The pair frames of
+// a training batch (track_gs = position(ids2), src/trainer_fragGS.py:486-507) and the node sequence of its ARAP term.
+extern "C" int splat_dynamic_positions_batch_forward(int F, int P, int I, const void *tab, const float *position,
+                                                     const float *cubic, int cubic_layout, float *out,
+                                                     int64_t out_frame_stride, void *stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 0 && I >= 1, "F >= 1, P >= 0 and I >= 1 required");
+    SPLAT_CHECK_ARG(cubic_layout == SPLAT_CUBIC_GAUSSIAN_MAJOR || cubic_layout == SPLAT_CUBIC_SEGMENT_MAJOR, "unknown cubic_layout");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(tab && position && cubic && out, "null pointer");
+    SPLAT_CHECK_ARG(out_frame_stride >= (int64_t)P * 3, "out_frame_stride below P * 3");
+    const unsigned blocks = (unsigned)(((size_t)P * 3 + DYN_BLOCK - 1) / DYN_BLOCK);
+    unsigned slices = 1;   // enough workgroups to fill the chip: slice the frames when the Gaussians alone do not
+    while (blocks * slices < 2048u && slices < (unsigned)F) slices *= 2;
+    if (slices > (unsigned)F) slices = (unsigned)F;
+    SPLAT_LAUNCH("dynamic_positions_fwd", dynamic_positions_fwd_kernel, dim3(blocks, slices), dim3(DYN_BLOCK), 0, (hipStream_t)stream,
+                 F, P, I, cubic_layout, (const DynTab *)tab, position, cubic, out, (long long)out_frame_stride);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+// Backward of the above: g[f * g_frame_stride + 3 n + j] is ADDED into d_position [P,3] (optional) and into the coefficient
+// rows of every frame's segment of d_cubic (layout `cubic_layout`, optional).  Deterministic (no atomics).
+extern "C" int splat_dynamic_positions_batch_backward(int F, int P, int I, const void *tab, const float *g,
+                                                      int64_t g_frame_stride, int cubic_layout, float *d_position,
+                                                      float *d_cubic, void *stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 0 && I >= 1, "F >= 1, P >= 0 and I >= 1 required");
+    SPLAT_CHECK_ARG(cubic_layout == SPLAT_CUBIC_GAUSSIAN_MAJOR || cubic_layout == SPLAT_CUBIC_SEGMENT_MAJOR, "unknown cubic_layout");
+    if (P == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(tab && g, "null pointer");
+    SPLAT_CHECK_ARG(g_frame_stride >= (int64_t)P * 3, "g_frame_stride below P * 3");
+    if (!d_position && !d_cubic) return SPLAT_OK;
+    const unsigned blocks = (unsigned)(((size_t)P * 3 + DYN_BLOCK - 1) / DYN_BLOCK);
+    SPLAT_LAUNCH("dynamic_positions_bwd", dynamic_positions_bwd_kernel, dim3(blocks), dim3(DYN_BLOCK), 0, (hipStream_t)stream, F, P, I,
+                 cubic_layout, (const DynTab *)tab, g, (long long)g_frame_stride, d_position, d_cubic);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }

@@ -258,6 +258,80 @@ knn_search_kernel(int N, const float *__restrict__ query, const int *__restrict_
     }
 }
 
+
+// ---- K nearest neighbours of a FEW query vertices in each of B point sets, brute force (the ARAP term of a training batch
+// needs the neighbours of its 512 sampled vertices only, src/geometry_utils.py:90-123 with :17-19; a grid build per point set
+// costs more than scanning the set for 512 queries).  Block = 256 queries x one chunk of the points, staged through LDS in
+// tiles of KNB_TILE (every lane reads the same point: a broadcast); partial top-KT lists per chunk, merged by knn_brute_merge.
+// Exact; ties -> smaller index (knn_insert), the arithmetic of knn_search_kernel.
+constexpr int KNB_TILE = 1024, KNB_TILES = 4, KNB_CHUNK = KNB_TILE * KNB_TILES;
+
+template <int KT>
+__global__ void __launch_bounds__(KB)
+knn_brute_partial_kernel(int N, int S, int G, const float *__restrict__ pts, long long pts_bs, const long long *__restrict__ qidx,
+                         float *__restrict__ pd, int *__restrict__ pi) {
+    __shared__ float4 sp[KNB_TILE];
+    const int c = blockIdx.x, b = blockIdx.z;
+    const int q = blockIdx.y * KB + threadIdx.x;
+    const float *P = pts + (size_t)b * pts_bs;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (q < S) {
+        const long long v = qidx[(size_t)b * S + q];
+        qx = P[3 * v]; qy = P[3 * v + 1]; qz = P[3 * v + 2];
+    }
+    float bd[KT];
+    int bi[KT];
+#pragma unroll
+    for (int p = 0; p < KT; ++p) { bd[p] = __builtin_inff(); bi[p] = 0x7fffffff; }
+    for (int tl = 0; tl < KNB_TILES; ++tl) {
+        const int base = c * KNB_CHUNK + tl * KNB_TILE;
+        if (base >= N) break;   // block-uniform
+        __syncthreads();
+        for (int e = threadIdx.x; e < KNB_TILE; e += KB) {
+            const int id = base + e;
+            sp[e] = id < N ? make_float4(P[3 * (size_t)id], P[3 * (size_t)id + 1], P[3 * (size_t)id + 2], __int_as_float(id))
+                           : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        }
+        __syncthreads();
+        const int n = imin_(KNB_TILE, N - base);
+        for (int e = 0; e < n; ++e) {
+            const float4 p = sp[e];
+            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+            knn_insert<KT>(bd, bi, dx * dx + dy * dy + dz * dz, __float_as_int(p.w));
+        }
+    }
+    if (q < S) {
+        const size_t o = (((size_t)b * G + c) * S + q) * KT;
+#pragma unroll
+        for (int p = 0; p < KT; ++p) { pd[o + p] = bd[p]; pi[o + p] = bi[p]; }
+    }
+}
+
+template <int KT>
+__global__ void __launch_bounds__(KB)
+knn_brute_merge_kernel(int S, int G, int K, const float *__restrict__ pd, const int *__restrict__ pi, float *__restrict__ dists,
+                       int *__restrict__ idx) {
+    const int q = blockIdx.x * KB + threadIdx.x, b = blockIdx.y;
+    if (q >= S) return;
+    float bd[KT];
+    int bi[KT];
+#pragma unroll
+    for (int p = 0; p < KT; ++p) { bd[p] = __builtin_inff(); bi[p] = 0x7fffffff; }
+    for (int c = 0; c < G; ++c) {
+        const size_t o = (((size_t)b * G + c) * S + q) * KT;
+#pragma unroll
+        for (int p = 0; p < KT; ++p)
+            if (pi[o + p] != 0x7fffffff) knn_insert<KT>(bd, bi, pd[o + p], pi[o + p]);
+    }
+#pragma unroll
+    for (int p = 0; p < KT; ++p) {
+        if (p < K) {
+            const bool have = bi[p] != 0x7fffffff;
+            dists[((size_t)b * S + q) * K + p] = have ? bd[p] : 0.f;
+            idx[((size_t)b * S + q) * K + p] = have ? bi[p] : -1;
+        }
+    }
+}
 }  // namespace
 
 extern "C" int splat_knn_grid_cells(int M) {
@@ -320,6 +394,34 @@ extern "C" int splat_knn_search(int N, const float *query, const int32_t *query_
     else
         SPLAT_LAUNCH("knn_search", knn_search_kernel<16>, kgrid(N), dim3(KB), 0, s, N, query, query_order, M,
                      (const float4 *)sorted, cell_start, (const KnnPlan *)plan, K, rcap, dists, idx);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
+
+// K nearest points of S query VERTICES (query_idx [B, S] int64: indices into the set itself) among the N points of each of B
+// point sets (set b at points + b * points_batch_stride floats), brute force: dists / idx [B, S, K] ascending, ties -> smaller
+// index, the query itself included (distance 0) like knn_points(points, points).  scratch: splat_knn_brute_scratch_bytes().
+extern "C" size_t splat_knn_brute_scratch_bytes(int B, int N, int S) {
+    const size_t G = ((size_t)(N > 0 ? N : 1) + KNB_CHUNK - 1) / KNB_CHUNK;
+    return (size_t)(B > 0 ? B : 1) * G * (size_t)(S > 0 ? S : 1) * 8 * (sizeof(float) + sizeof(int));
+}
+
+extern "C" int splat_knn_brute_batch(int B, int N, int S, int K, const float *points, int64_t points_batch_stride,
+                                     const int64_t *query_idx, float *dists, int32_t *idx, void *scratch, void *stream) {
+    SPLAT_CHECK_ARG(B >= 1 && B <= 65535 && N >= 1 && S >= 0, "bad sizes");
+    SPLAT_CHECK_ARG(K >= 1 && K <= 8, "K must be 1..8");
+    if (S == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(points && query_idx && dists && idx && scratch, "null pointer");
+    SPLAT_CHECK_ARG(points_batch_stride >= (int64_t)N * 3 || B == 1, "points_batch_stride below N * 3");
+    hipStream_t s = (hipStream_t)stream;
+    const int G = (N + KNB_CHUNK - 1) / KNB_CHUNK;
+    float *pd = (float *)scratch;
+    int *pi = (int *)(pd + (size_t)B * G * S * 8);
+    SPLAT_LAUNCH("knn_brute", knn_brute_partial_kernel<8>, dim3((unsigned)G, (unsigned)((S + KB - 1) / KB), (unsigned)B), dim3(KB), 0, s,
+                 N, S, G, points, (long long)points_batch_stride, (const long long *)query_idx, pd, pi);
+    SPLAT_POST_LAUNCH();
+    SPLAT_LAUNCH("knn_brute_merge", knn_brute_merge_kernel<8>, dim3((unsigned)((S + KB - 1) / KB), (unsigned)B), dim3(KB), 0, s, S, G, K,
+                 pd, pi, dists, idx);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }

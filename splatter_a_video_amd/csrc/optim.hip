@@ -86,7 +86,57 @@ fill_kernel(float *__restrict__ dst, long long n, float value) {
         if (tail0 + threadIdx.x < n && threadIdx.x < 4) dst[tail0 + threadIdx.x] = value;
     }
 }
+
+// L1 image loss and its gradient in one pass (the photometric / depth / attribute terms of a training step,
+// src/trainer_fragGS.py:573-600 -- l1_loss on the rendered frames): grad = scale * sign(pred - target), loss_sum += sum |pred -
+// target|.  pred may be a channel slice of a wider image row: F blocks of `inner` contiguous floats, `pred_fs` floats apart;
+// target and grad are dense [F, inner].  grid.y = frame.
+__global__ void __launch_bounds__(256)
+l1_loss_grad_kernel(long long inner, const float *__restrict__ pred, long long pred_fs, const float *__restrict__ target,
+                    float scale, float *__restrict__ grad, float *__restrict__ loss_sum) {
+    const long long f = blockIdx.y;
+    const float *p = pred + f * pred_fs, *t = target + f * inner;
+    float *g = grad + f * inner;
+    float acc = 0.f;
+    const bool vec = (((uintptr_t)p | (uintptr_t)t | (uintptr_t)g) & 15) == 0;
+    const long long n4 = vec ? inner >> 2 : 0;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4 *>(p)[q], b = reinterpret_cast<const float4 *>(t)[q];
+        const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+        acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+        auto sg = [scale](float d) { return d > 0.f ? scale : (d < 0.f ? -scale : 0.f); };
+        reinterpret_cast<float4 *>(g)[q] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < inner; i += (long long)gridDim.x * 256) {
+        const float d = p[i] - t[i];
+        acc += fabsf(d);
+        g[i] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+    }
+    acc = wave_sum_to_lane63(acc);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_sum) atomic_add_f32(loss_sum, (part[0] + part[1]) + (part[2] + part[3]));
+}
 }  // namespace
+
+// grad[f, i] = scale * sign(pred[f * pred_frame_stride + i] - target[f, i]), *loss_sum += sum |pred - target| (zero-init; float
+// atomics: the reported sum is not bit-reproducible, the gradient is).  The mean-reduced L1 loss of the reference
+// (l1_loss, src/trainer_fragGS.py:573) and its backward: scale = weight / (F * inner).
+extern "C" int splat_l1_loss_grad(int F, int64_t inner, const float *pred, int64_t pred_frame_stride, const float *target,
+                                  float scale, float *grad, float *loss_sum, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(F >= 0 && F <= 65535 && inner >= 0, "bad sizes");
+    if (F == 0 || inner == 0) return SPLAT_OK;
+    SPLAT_CHECK_ARG(pred && target && grad, "null pointer");
+    SPLAT_CHECK_ARG(pred_frame_stride >= inner, "pred_frame_stride below the block size");
+    long long blocks = ((inner >> 2) + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    SPLAT_LAUNCH("l1_loss_grad", l1_loss_grad_kernel, dim3((unsigned)blocks, (unsigned)F), dim3(256), 0, (hipStream_t)stream,
+                 (long long)inner, pred, (long long)pred_frame_stride, target, scale, grad, loss_sum);
+    SPLAT_POST_LAUNCH();
+    return SPLAT_OK;
+}
 
 extern "C" int splat_fill_f32(float *dst, size_t n, float value, splat_stream_t stream) {
     if (n == 0) return SPLAT_OK;

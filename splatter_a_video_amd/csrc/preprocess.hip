@@ -364,8 +364,12 @@ struct GaussBwdArgs {
                             // dL/ddepth of the projection (-> position), not a feature gradient
     // SETS records (blend_bwd_sets_kernel: [ux uy ca cb | cc o ax ay | tx ty 0 0 | row channels], common.h SETS_NG): per set the first row
     // channel, the width, the gradient rows (NULL: not wanted) and their stride
-    int sc0[3], scn[3], sstride[3];
-    float *sdf[3];
+    // ... generalised to SOURCES (splat_feature_source_t): nsrc entries; sfs[g] != 0 marks a per-frame source (static kernels:
+    // refused by the host side)
+    int nsrc;
+    int sc0[SPLAT_MAX_SOURCES], scn[SPLAT_MAX_SOURCES], sstride[SPLAT_MAX_SOURCES];
+    float *sdf[SPLAT_MAX_SOURCES];
+    long long sfs[SPLAT_MAX_SOURCES];
 };
 
 // SETS2 records (splat_alpha_blending_backward_batch_sets2, 40 floats):
@@ -391,8 +395,9 @@ __device__ __forceinline__ S2Geo s2_geometry(const float4 (&a)[NS]) {
     return g;
 }
 // feature gradients of a SETS2 record: component k -> (set 0 channel k - 8 | set 2 channel k - 19), added into the sets' rows
-__device__ __forceinline__ void s2_put_feature(int k, float v, size_t n, const int (&scn)[3], float *const (&sdf)[3],
-                                               const int (&sstride)[3], bool acc) {
+__device__ __forceinline__ void s2_put_feature(int k, float v, size_t n, const int (&scn)[SPLAT_MAX_SOURCES],
+                                               float *const (&sdf)[SPLAT_MAX_SOURCES], const int (&sstride)[SPLAT_MAX_SOURCES],
+                                               bool acc) {
     if (k >= 8 && k < 8 + scn[0] && sdf[0]) {
         float *p = sdf[0] + n * sstride[0] + (k - 8);
         *p = acc ? *p + v : v;
@@ -665,6 +670,25 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
         }
     }
     // features: component k of the record lives in chunk k / 4 = lane (k / 4) & 3, register a[k / 16]
+    if (SETS && !S2) {   // routed by source (a uniform loop over the table; the component tests are per lane)
+        for (int g = 0; g < A.nsrc; ++g) {
+            float *df = A.sdf[g];
+            if (!df) continue;
+            const int c0 = A.sc0[g], cn = A.scn[g], st = A.sstride[g];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                if (4 * c + sub < NQ) {
+                    const float v[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ch = 16 * c + 4 * sub + e - NG;
+                        if (ch >= c0 && ch < c0 + cn && ch != A.depth_channel) put1(df + (size_t)i * st + (ch - c0), v[e]);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < NS; ++c) {
         if (4 * c + sub < NQ) {
@@ -675,11 +699,6 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
                 const int ch = k0 + e - NG;
                 if (S2) {
                     s2_put_feature(k0 + e, v[e], (size_t)i, A.scn, A.sdf, A.sstride, acc);
-                } else if (SETS) {
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-                        if (ch >= A.sc0[g] && ch < A.sc0[g] + A.scn[g] && ch != A.depth_channel && A.sdf[g])
-                            put1(A.sdf[g] + (size_t)i * A.sstride[g] + (ch - A.sc0[g]), v[e]);
                 } else if (ch >= 0 && ch < A.cn && ch != A.depth_channel && A.d_feature) {
                     put1(A.d_feature + (size_t)i * A.C + ch, v[e]);
                 }
@@ -770,12 +789,16 @@ struct GaussDynArgs {
     float *tap, *abs_tap;
     int *radii_max;
     // SETS records (blend_bwd_sets_kernel): see GaussBwdArgs
-    int sc0[3], scn[3], sstride[3];
-    float *sdf[3];
+    // (sources: nsrc entries; sfs[g] != 0 = per-frame source whose gradient is ADDED per frame at sdf[g] + f * sfs[g]; npf = their count)
+    int nsrc, npf;
+    int sc0[SPLAT_MAX_SOURCES], scn[SPLAT_MAX_SOURCES], sstride[SPLAT_MAX_SOURCES];
+    float *sdf[SPLAT_MAX_SOURCES];
+    long long sfs[SPLAT_MAX_SOURCES];
     int depth_channel;
 };
 
-template <bool ABS, int NCP, bool SETS = false, bool S2 = false>
+// PF: the row has per-frame sources (A.npf > 0) -- its own instantiation: their block costs the walk ten registers
+template <bool ABS, int NCP, bool SETS = false, bool S2 = false, bool PF = false>
 __global__ void __launch_bounds__(256, GAUSS_DYN_MINW)
 frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
     static_assert(!S2 || (NCP == 40 && SETS && ABS), "SETS2 records: 40 floats, abs sums present");
@@ -883,6 +906,26 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
             for (int c = 0; c < NS; ++c) {
                 atot[c].x += af[c].x; atot[c].y += af[c].y; atot[c].z += af[c].z; atot[c].w += af[c].w;
             }
+            if (SETS && !S2 && PF) {
+                // per-frame sources (track_gs = position(ids2), src/trainer_fragGS.py:506-511): THIS frame's gradient of their
+                // channels goes to the frame's own rows; the lane that holds a component adds it (a quad owns its Gaussian)
+                for (int g = 0; g < A.nsrc; ++g) {
+                    if (A.sfs[g] == 0 || !A.sdf[g]) continue;
+                    const int c0 = A.sc0[g], cn = A.scn[g];
+                    float *dst = A.sdf[g] + (size_t)ff * (size_t)A.sfs[g] + (size_t)n * A.sstride[g];
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) {
+                        if (4 * c + j < NQ) {
+                            const float v[4] = {af[c].x, af[c].y, af[c].z, af[c].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int ch = 16 * c + 4 * j + e - NG;
+                                if (ch >= c0 && ch < c0 + cn) dst[ch - c0] += v[e];
+                            }
+                        }
+                    }
+                }
+            }
             float ux = quad_bcast<0>(af[0].x), uy = quad_bcast<0>(af[0].y);
             float ga = quad_bcast<0>(af[0].z), gb = quad_bcast<0>(af[0].w), gc = quad_bcast<1>(af[0].x);
             float gdep = 0.f;  // SETS: the frame's gradient of the depth channel = dL/ddepth of the projection
@@ -985,6 +1028,25 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
         }
     }
     if (j == 0 && A.radii_max) A.radii_max[n] = rmax;
+    if (SETS && !S2) {   // shared sources: the sum over the frames (per-frame sources were written frame by frame)
+        for (int g = 0; g < A.nsrc; ++g) {
+            float *df = A.sdf[g];
+            if (!df || A.sfs[g] != 0) continue;
+            const int c0 = A.sc0[g], cn = A.scn[g], st = A.sstride[g];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                if (4 * c + j < NQ) {
+                    const float v[4] = {atot[c].x, atot[c].y, atot[c].z, atot[c].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ch = 16 * c + 4 * j + e - NG;
+                        if (ch >= c0 && ch < c0 + cn && ch != A.depth_channel) df[(size_t)n * st + (ch - c0)] += v[e];
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < NS; ++c) {
         if (4 * c + j < NQ) {
@@ -995,11 +1057,6 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
                 const int ch = k0 + e - NG;
                 if (S2) {
                     s2_put_feature(k0 + e, v[e], (size_t)n, A.scn, A.sdf, A.sstride, true);
-                } else if (SETS) {
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-                        if (ch >= A.sc0[g] && ch < A.sc0[g] + A.scn[g] && ch != A.depth_channel && A.sdf[g])
-                            A.sdf[g][(size_t)n * A.sstride[g] + (ch - A.sc0[g])] += v[e];
                 } else if (ch >= 0 && ch < A.cn && A.d_feature) {
                     A.d_feature[(size_t)n * A.C + ch] += v[e];
                 }
@@ -1041,7 +1098,8 @@ int launch_gauss_bwd_dynamic_sets(const GaussDynArgs &A, int ncp, hipStream_t s)
         SPLAT_POST_LAUNCH();
         return SPLAT_OK;
     }
-#define GDS(N) case N: SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_dynamic_kernel<true, N, true>), grid, block, 0, s, A); break
+#define GDS(N) case N: if (A.npf > 0) SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_dynamic_kernel<true, N, true, false, true>), grid, block, 0, s, A); \
+                    else SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_dynamic_kernel<true, N, true>), grid, block, 0, s, A); break
     switch (ncp) {
         GDS(12); GDS(16); GDS(20); GDS(24); GDS(28); GDS(32); GDS(36); GDS(40);
         default: splat_set_error("gauss_bwd: unsupported record stride %d", ncp); return SPLAT_E_ARG;
@@ -1141,11 +1199,49 @@ static int gauss_backward_static_sets_impl(int sets2, STAT_SETS_PARAMS) {
     SPLAT_CHECK_ARG(mode >= 0, "camera: extr (and intr for the perspective camera) must be set");
     A.d_xyz = d_xyz; A.d_scales = d_scales; A.d_uquats = d_uquats; A.d_opacity = d_opacity;
     A.tap = tap; A.abs_tap = abs_tap; A.radii_max = radii_max; A.accumulate = accumulate;
+    A.nsrc = 3;
     for (int g = 0; g < 3; ++g) {
         A.sc0[g] = set_c0[g]; A.scn[g] = set_cn[g]; A.sstride[g] = set_stride[g]; A.sdf[g] = set_dfeature[g];
         SPLAT_CHECK_ARG(set_cn[g] == 0 || !set_dfeature[g] || set_stride[g] >= set_cn[g], "feature stride below the set width");
     }
     const int ncp = sets2 ? -40 : (int)splat_blend_sets_pair_stride(C);
+    return mode == 0 ? launch_gauss_bwd_static_sets<0>(A, ncp, (hipStream_t)stream)
+         : mode == 1 ? launch_gauss_bwd_static_sets<1>(A, ncp, (hipStream_t)stream)
+                     : launch_gauss_bwd_static_sets<2>(A, ncp, (hipStream_t)stream);
+}
+
+// the same with the row described by feature SOURCES (include/splat_hip.h: splat_feature_source_t); shared sources only
+extern "C" int splat_frames_gauss_backward_static_sources_cam(int F, int P, int C, int W, int H, int64_t capacity,
+                                                              const float *pair_records, const int32_t *goff_incl,
+                                                              const int32_t *radius, const float *xyz, const float *scales,
+                                                              const float *uquats, const splat_camera_t *cam, int accumulate,
+                                                              float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
+                                                              int nsrc, const splat_feature_source_t *src, int depth_channel,
+                                                              float *tap, float *abs_tap, int32_t *radii_max, void *stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 28 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 28)");
+    SPLAT_CHECK_ARG(pair_records && goff_incl && xyz && scales && uquats && cam, "null input pointer");
+    SPLAT_CHECK_ARG(d_xyz && d_scales && d_uquats && d_opacity, "null gradient pointer");
+    SPLAT_CHECK_ARG(src && nsrc >= 0 && nsrc <= SPLAT_MAX_SOURCES, "null / oversized source table");
+    SPLAT_CHECK_ARG(depth_channel < C, "depth_channel outside the row");
+    SPLAT_CHECK_ARG(!radii_max || radius, "radii_max needs the per-frame radius");
+    GaussBwdArgs A;
+    memset(&A, 0, sizeof(A));
+    A.F = F; A.P = P; A.W = W; A.H = H; A.C = C; A.cn = C; A.cap = capacity;
+    A.skip_opacity = 0; A.depth_channel = depth_channel;
+    A.pair = pair_records; A.goff = goff_incl; A.radius = radius;
+    A.xyz = xyz; A.scales = scales; A.uquats = (const float4 *)uquats;
+    const int mode = set_camera(A, cam, F);
+    SPLAT_CHECK_ARG(mode >= 0, "camera: extr (and intr for the perspective camera) must be set");
+    A.d_xyz = d_xyz; A.d_scales = d_scales; A.d_uquats = d_uquats; A.d_opacity = d_opacity;
+    A.tap = tap; A.abs_tap = abs_tap; A.radii_max = radii_max; A.accumulate = accumulate;
+    A.nsrc = nsrc;
+    for (int g = 0; g < nsrc; ++g) {
+        SPLAT_CHECK_ARG(src[g].cn >= 0 && src[g].c0 >= 0 && src[g].c0 + src[g].cn <= C, "source outside the row");
+        SPLAT_CHECK_ARG(!(src[g].d_feature && src[g].frame_stride != 0 && F > 1),
+                        "a per-frame source's gradient needs the dynamic entry point (static Gaussians: the records of all frames are summed)");
+        A.sc0[g] = src[g].c0; A.scn[g] = src[g].cn; A.sstride[g] = src[g].cn; A.sdf[g] = src[g].d_feature;
+    }
+    const int ncp = (int)splat_blend_sets_pair_stride(C);
     return mode == 0 ? launch_gauss_bwd_static_sets<0>(A, ncp, (hipStream_t)stream)
          : mode == 1 ? launch_gauss_bwd_static_sets<1>(A, ncp, (hipStream_t)stream)
                      : launch_gauss_bwd_static_sets<2>(A, ncp, (hipStream_t)stream);
@@ -1493,11 +1589,51 @@ static int gauss_backward_dynamic_sets_impl(int sets2, int F, int P, int I, int 
     A.rot_fourier = (const float4 *)rot_fourier; A.opacity = opacity; A.scaling = scaling; A.extr = extr;
     A.d_position = d_position; A.d_cubic = d_cubic; A.d_rotation = d_rotation; A.d_opacity = d_opacity; A.d_scaling = d_scaling;
     A.tap = tap; A.abs_tap = abs_tap; A.radii_max = radii_max; A.depth_channel = depth_channel;
+    A.nsrc = 3;
     for (int g = 0; g < 3; ++g) {
         A.sc0[g] = set_c0[g]; A.scn[g] = set_cn[g]; A.sstride[g] = set_stride[g]; A.sdf[g] = set_dfeature[g];
         SPLAT_CHECK_ARG(set_cn[g] == 0 || !set_dfeature[g] || set_stride[g] >= set_cn[g], "feature stride below the set width");
     }
     return launch_gauss_bwd_dynamic_sets(A, sets2 ? -40 : (int)splat_blend_sets_pair_stride(C), (hipStream_t)stream);
+}
+
+// the same with the row described by feature SOURCES (include/splat_hip.h: splat_feature_source_t): shared sources receive the
+// sum over the frames, per-frame sources every frame's own gradient
+extern "C" int splat_frames_gauss_backward_dynamic_sources(int F, int P, int I, int C, int W, int H, int64_t capacity,
+                                                           const float *pair_records, const int32_t *goff_incl,
+                                                           const int32_t *radius, const void *tab, const float *position,
+                                                           const float *cubic, int cubic_layout, const float *rotation,
+                                                           const float *rot_poly, const float *rot_fourier, const float *opacity,
+                                                           const float *scaling, const float *extr, float *d_position,
+                                                           float *d_cubic, float *d_rotation, float *d_opacity, float *d_scaling,
+                                                           int nsrc, const splat_feature_source_t *src, int depth_channel,
+                                                           float *tap, float *abs_tap, int32_t *radii_max, void *stream) {
+    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && I >= 1 && C >= 1 && C <= 28 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 28)");
+    SPLAT_CHECK_ARG(cubic_layout == SPLAT_CUBIC_GAUSSIAN_MAJOR || cubic_layout == SPLAT_CUBIC_SEGMENT_MAJOR, "unknown cubic_layout");
+    SPLAT_CHECK_ARG(pair_records && goff_incl && tab && position && cubic && rotation && rot_poly && rot_fourier && opacity &&
+                        scaling && extr,
+                    "null input pointer");
+    SPLAT_CHECK_ARG(src && nsrc >= 0 && nsrc <= SPLAT_MAX_SOURCES, "null / oversized source table");
+    SPLAT_CHECK_ARG(depth_channel < C, "depth_channel outside the row");
+    SPLAT_CHECK_ARG(!radii_max || radius, "radii_max needs the per-frame radius");
+    GaussDynArgs A;
+    memset(&A, 0, sizeof(A));
+    A.F = F; A.P = P; A.W = W; A.H = H; A.I = I; A.layout = cubic_layout; A.C = C; A.cn = C; A.cap = capacity;
+    A.pair = pair_records; A.goff = goff_incl; A.radius = radius; A.tab = (const DynTab *)tab;
+    A.position = position; A.cubic = cubic; A.rotation = rotation; A.rot_poly = (const float4 *)rot_poly;
+    A.rot_fourier = (const float4 *)rot_fourier; A.opacity = opacity; A.scaling = scaling; A.extr = extr;
+    A.d_position = d_position; A.d_cubic = d_cubic; A.d_rotation = d_rotation; A.d_opacity = d_opacity; A.d_scaling = d_scaling;
+    A.tap = tap; A.abs_tap = abs_tap; A.radii_max = radii_max; A.depth_channel = depth_channel;
+    A.nsrc = nsrc;
+    for (int g = 0; g < nsrc; ++g) {
+        SPLAT_CHECK_ARG(src[g].cn >= 0 && src[g].c0 >= 0 && src[g].c0 + src[g].cn <= C, "source outside the row");
+        SPLAT_CHECK_ARG(src[g].frame_stride == 0 || !src[g].d_feature || src[g].frame_stride >= (int64_t)P * src[g].cn,
+                        "frame stride of a per-frame source below P * cn");
+        A.sc0[g] = src[g].c0; A.scn[g] = src[g].cn; A.sstride[g] = src[g].cn; A.sdf[g] = src[g].d_feature;
+        A.sfs[g] = src[g].d_feature ? src[g].frame_stride : 0;
+        if (A.sfs[g] != 0) ++A.npf;
+    }
+    return launch_gauss_bwd_dynamic_sets(A, (int)splat_blend_sets_pair_stride(C), (hipStream_t)stream);
 }
 
 #define DYN_SETS_PARAMS int F, int P, int I, int C, int W, int H, int64_t capacity, const float *pair_records, const int32_t *goff_incl, \

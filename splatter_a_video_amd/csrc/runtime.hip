@@ -1,6 +1,7 @@
 // Error reporting and the optional per-kernel hipEvent timing of libsplat_hip.so.
 #include <stdarg.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -18,7 +19,7 @@ void splat_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *splat_last_error(void) { return g_err; }
-extern "C" int splat_abi_version(void) { return 18; }
+extern "C" int splat_abi_version(void) { return 19; }
 
 #ifndef SPLAT_BUILD_ID
 #define SPLAT_BUILD_ID "unstamped"
@@ -32,10 +33,32 @@ extern "C" const char *splat_build_id(void) { return SPLAT_BUILD_ID; }
 // sort (pair records + quarter lists from the forward's cull words) are deterministic already; the flag closes the
 // remaining doors: the block-level matrix-core kernel (its carried survivors add with atomics) gives way to the DPP pair
 // kernel, and a foreign idx_sorted (atomic backward) is refused.
-static int g_deterministic = 0;
-extern "C" void splat_set_deterministic(int on) { g_deterministic = on != 0; }
-extern "C" int splat_get_deterministic(void) { return g_deterministic; }
-bool splat_deterministic() { return g_deterministic != 0; }
+// (std::atomic: the flag may be flipped by one thread while another launches; set it before use for a defined kernel choice)
+static std::atomic<int> g_deterministic{0};
+extern "C" void splat_set_deterministic(int on) { g_deterministic.store(on != 0, std::memory_order_relaxed); }
+extern "C" int splat_get_deterministic(void) { return g_deterministic.load(std::memory_order_relaxed); }
+bool splat_deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
+
+// Options: kernel selection through the ABI (splat_set_option) instead of getenv() inside the library.
+static const char *const g_opt_key[SPLAT_OPT_COUNT] = {"bwd_quarters", "bwd_kernel_dpp", "sets_std", "bin_slot_keys"};
+static std::atomic<int> g_opt[SPLAT_OPT_COUNT] = {{1}, {0}, {1}, {0}};
+int splat_option(int id) { return g_opt[id].load(std::memory_order_relaxed); }
+extern "C" int splat_set_option(const char *key, int value) {
+    SPLAT_CHECK_ARG(key != nullptr, "null key");
+    if (strcmp(key, "deterministic") == 0) { splat_set_deterministic(value); return SPLAT_OK; }
+    for (int i = 0; i < SPLAT_OPT_COUNT; ++i)
+        if (strcmp(key, g_opt_key[i]) == 0) { g_opt[i].store(value, std::memory_order_relaxed); return SPLAT_OK; }
+    splat_set_error("splat_set_option: unknown key '%s'", key);
+    return SPLAT_E_ARG;
+}
+extern "C" int splat_get_option(const char *key, int *value) {
+    SPLAT_CHECK_ARG(key != nullptr && value != nullptr, "null pointer");
+    if (strcmp(key, "deterministic") == 0) { *value = splat_get_deterministic(); return SPLAT_OK; }
+    for (int i = 0; i < SPLAT_OPT_COUNT; ++i)
+        if (strcmp(key, g_opt_key[i]) == 0) { *value = splat_option(i); return SPLAT_OK; }
+    splat_set_error("splat_get_option: unknown key '%s'", key);
+    return SPLAT_E_ARG;
+}
 
 namespace {
 struct Pending {

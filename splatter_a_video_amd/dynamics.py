@@ -333,6 +333,86 @@ def frame_preprocess(clock: FrameClock, time, extr: Tensor, W: int, H: int, *, p
                                   extr, seg, d, basis, clock.interval_num, W, H, nearest, extent, grad_sink, cubic_layout)
 
 
+def frame_table(clock: FrameClock, times, device) -> Tensor:
+    """device table of per-frame scalars (segment, offset inside it, the 12 time-basis values; 64 bytes per frame) of the frame
+    times ``times`` -- the table of the batched entry points (splat_frame_preprocess_forward_batch, splat_dynamic_positions_*)"""
+    host = np.zeros((len(times), 16), np.float32)
+    for f, t in enumerate(times):
+        seg, d, basis = clock.scalars(t)
+        host[f, 0] = np.array([seg], np.int32).view(np.float32)[0]
+        host[f, 1] = d
+        host[f, 2:14] = np.frombuffer(basis, dtype=np.float32, count=12)
+    return torch.from_numpy(host).to(device)
+
+
+def positions_batch_forward(tab: Tensor, position: Tensor, pos_cubic_node: Tensor, interval_num: int,
+                            cubic_layout: int = GAUSSIAN_MAJOR, out: Optional[Tensor] = None) -> Tensor:
+    """``get_position(t)`` of every Gaussian for ALL frame times of ``tab`` (``frame_table``) in one launch: [F, N, 3].  The pair
+    frames of a training batch -- track_gs = position(ids2) and the node sequence of the ARAP term
+    (src/trainer_fragGS.py:486-507,671-675).  Raw operator (no autograd; ``positions_batch`` is the autograd form)."""
+    position = L.need(position, "position")
+    cubic = L.need(pos_cubic_node, "pos_cubic_node")
+    N, F = position.shape[0], tab.shape[0]
+    if cubic.numel() != N * 4 * interval_num * 3:
+        raise ValueError("pos_cubic_node must hold N * 4 * interval_num * 3 floats")
+    if out is None:
+        out = torch.empty(F, N, 3, dtype=torch.float32, device=position.device)
+    elif tuple(out.shape) != (F, N, 3) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError(f"out must be a contiguous float32 [F={F}, N={N}, 3] buffer")
+    L.check(L.lib().splat_dynamic_positions_batch_forward(
+        L.ci(F), L.ci(N), L.ci(interval_num), L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(cubic_layout), L.ptr(out),
+        ctypes.c_int64(N * 3), L.stream()))
+    return out
+
+
+def positions_batch_backward(tab: Tensor, g: Tensor, interval_num: int, cubic_layout: int, d_position: Optional[Tensor],
+                             d_pos_cubic_node: Optional[Tensor]) -> None:
+    """``g`` [F, N, 3] = dL/dposition(t_f) is ADDED into ``d_position`` [N, 3] and into the coefficient rows of every frame's
+    segment of ``d_pos_cubic_node`` (either may be None); one launch, no atomics"""
+    g = L.need(g, "g")
+    F, N = g.shape[0], g.shape[1]
+    if tab.shape[0] != F:
+        raise ValueError("one table entry per frame of g")
+    L.check(L.lib().splat_dynamic_positions_batch_backward(
+        L.ci(F), L.ci(N), L.ci(interval_num), L.ptr(tab), L.ptr(g), ctypes.c_int64(N * 3), L.ci(cubic_layout),
+        L.ptr(d_position), L.ptr(d_pos_cubic_node), L.stream()))
+
+
+class _PositionsBatch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, position, cubic, tab, I, layout, sink):
+        out = positions_batch_forward(tab, position, cubic, I, layout)
+        ctx.meta, ctx.sink, ctx.shapes = (int(I), int(layout)), sink, (position.shape, cubic.shape)
+        ctx.save_for_backward(tab)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (tab,) = ctx.saved_tensors
+        I, layout = ctx.meta
+        sink = ctx.sink or {}
+        need_p, need_c = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dev = g.device
+        b_pos = sink.get("position") if need_p else None
+        b_cub = sink.get("pos_cubic_node") if need_c else None
+        r_pos = r_cub = None
+        if need_p and b_pos is None:
+            b_pos = r_pos = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
+        if need_c and b_cub is None:
+            b_cub = r_cub = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dev)
+        positions_batch_backward(tab, g, I, layout, b_pos, b_cub)
+        return r_pos, r_cub, None, None, None, None
+
+
+def positions_batch(clock: FrameClock, times, position: Tensor, pos_cubic_node: Tensor, cubic_layout: int = GAUSSIAN_MAJOR,
+                    grad_sink: Optional[Dict[str, Tensor]] = None, tab: Optional[Tensor] = None) -> Tensor:
+    """[F, N, 3]: ``get_position(time)`` (reference: src/dynamic_gaussian_with_base_point_cloud.py:236-250) for every time of
+    ``times`` in ONE launch each way; differentiable w.r.t. ``position`` and ``pos_cubic_node`` (``grad_sink`` as in ``evaluate``)."""
+    if tab is None:
+        tab = frame_table(clock, times, position.device)
+    return _PositionsBatch.apply(position, pos_cubic_node, tab, clock.interval_num, int(cubic_layout), grad_sink)
+
+
 class DynamicGaussians(torch.nn.Module):
     """Parameter holder with the reference's attribute / getter names (position, pos_cubic_node, rotation,
     rot_poly_feat, rot_fourier_feat, opacity, scaling; get_position(time), get_rotation(time), get_opacity,

@@ -108,6 +108,11 @@ class _Camera:
         return (self.extr,) if self.intr is None else (self.extr, self.intr)
 
 
+# python-level switches of the multi-set paths (tests flip them; the library's own options: L.set_option)
+OPTIONS = {"sets_one_pass": os.environ.get("SPLAT_SETS_ONE_PASS", "1") != "0",
+           "sets_two_pass": os.environ.get("SPLAT_SETS_TWO_PASS", "0") == "1"}
+
+
 def _tiles(W: int, H: int) -> int:
     return ((W + 15) // 16) * ((H + 15) // 16)
 
@@ -369,22 +374,39 @@ class FrameBatch:
                             grad_sink: Optional[Dict[str, Tensor]] = None):
         """The reference's real training frame, for all frames of the batch: its dynamic Gaussians (``render_dynamic``)
         through the three blends of ``render_iter`` (``render_sets``: same ``sets`` list, same return value).  The sets must
-        fit the one-pass backward (one set per routing group, <= 4 / 4 / 20 channels)."""
+        fit the one-pass backward (one set per routing group, <= 4 / 4 / 20 channels).
+
+        A set's ``feature`` may also be a LIST of tensors -- the set is their concatenation along the channels, as the
+        reference's renderer concatenates its attributes (RenderFeatures.combine; ``["track_gs"] + render_attributes``,
+        src/trainer_fragGS.py:511) -- and a tensor of a list may be per frame, ``[F, P, c]`` (track_gs = position(ids2) differs
+        from frame to frame; a strided view with dense rows is read in place): no ``[F, P, C]`` row is materialised, a shared
+        tensor's gradient is the sum over the frames, a per-frame tensor gets every frame's own.  ``grad_sink["feature:k"]``
+        (k = position of the tensor in the flattened list of all sets' tensors) receives that gradient by ADDITION instead of
+        autograd.  Lists / per-frame tensors need the renderer's own plan (rgb 3 | depth 1 | 19 attribute channels)."""
         tab = self.frame_table(clock, times)
-        feats = [s_["feature"] for s_ in sets if not isinstance(s_["feature"], str)]
-        meta = tuple((("depth" if isinstance(s_["feature"], str) else int(s_["feature"].shape[1])), float(s_.get("bg", 0.0)),
-                      bool(s_.get("detach_opacity", False)), bool(s_.get("taps", False))) for s_ in sets)
+        meta, parts, feats = _parse_sets(sets, self.F, self.P)
         widths = [1 if m[0] == "depth" else m[0] for m in meta]
         if sum(widths) != self.C:
             raise ValueError(f"the sets hold {sum(widths)} channels, the batch was built for C = {self.C}")
-        if _one_pass_plan(meta, widths, self.C) is None:
+        plan = _one_pass_plan(meta, widths, self.C)
+        if plan is None:
             raise ValueError("render_dynamic_sets needs sets that fit the one-pass backward: one set per routing group "
                              "(taps / live opacity / detached opacity) of at most 4 / 4 / 20 channels")
-        sink = check_sink(grad_sink, {"position": position, "pos_cubic_node": pos_cubic_node, "rotation": rotation,
-                                      "opacity": opacity, "scaling": scaling})
+        if _has_sources(parts) and not _uses_forward_pack(plan, self.C):
+            raise ValueError("feature lists / per-frame feature tensors need the renderer's own plan: a tap set of 3 channels, the "
+                             "depth, 19 channels blended with opacity.detach() (the plan whose backward stages the forward's records)")
+        fsink = {k: v for k, v in (grad_sink or {}).items() if k.startswith("feature:")}
+        psink = {k: v for k, v in (grad_sink or {}).items() if not k.startswith("feature:")}
+        sink = check_sink(psink, {"position": position, "pos_cubic_node": pos_cubic_node, "rotation": rotation,
+                                  "opacity": opacity, "scaling": scaling})
+        for k, buf in fsink.items():
+            i = int(k.split(":")[1])
+            if not (0 <= i < len(feats)) or tuple(buf.shape) != tuple(feats[i].shape) or buf.dtype != torch.float32 \
+                    or not buf.is_cuda or buf.stride(-1) != 1 or buf.stride(-2) != buf.shape[-1]:
+                raise ValueError(f"grad_sink[{k!r}] must be a float32 GPU buffer of the feature tensor's shape with dense rows")
         return _RenderDynamicSets.apply(position, pos_cubic_node, rotation, opacity, scaling, rot_poly_feat, rot_fourier_feat, extr,
                                         tab, self, int(clock.interval_num), int(cubic_layout), meta, int(K), float(nearest),
-                                        float(extent), sink, *feats)
+                                        float(extent), sink, parts, fsink or None, *feats)
 
     # ------------------------------------------------------------------ several feature sets of one geometry (row a1)
     def render_sets(self, xyz: Tensor, scales: Tensor, uquats: Tensor, opacity: Tensor, sets, offsets: Optional[Tensor],
@@ -478,11 +500,11 @@ class _RenderDynamic(torch.autograd.Function):
 
 
 class _RenderDynamicSets(torch.autograd.Function):
-    N_FIXED = 17      # arguments in front of the feature tensors
+    N_FIXED = 19      # arguments in front of the feature tensors
 
     @staticmethod
     def forward(ctx, position, cubic, rotation, opacity, scaling, rot_poly, rot_fourier, extr, tab, fb, I, layout, meta, K,
-                nearest, extent, sink, *feats):
+                nearest, extent, sink, parts, fsink, *feats):
         P, F = fb.P, fb.F
         position = _points(position, "position", 3)
         rotation = _points(rotation, "rotation", 4)
@@ -494,7 +516,9 @@ class _RenderDynamicSets(torch.autograd.Function):
             raise ValueError("parameter shapes do not match the batch (P Gaussians, I spline segments)")
         if position.shape[0] != P or rotation.shape[0] != P or scaling.shape[0] != P:
             raise ValueError(f"the batch was built for {P} Gaussians")
-        _check_set_features(meta, feats, P)
+        sources = _has_sources(parts)
+        if not sources:
+            _check_set_features(meta, feats, P)
         extr_c = _extr12(extr)
         lib, st = L.lib(), L.stream()
         W, H, C = fb.W, fb.H, fb.C
@@ -505,10 +529,15 @@ class _RenderDynamicSets(torch.autograd.Function):
             L.ptr(rot_fourier), L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c), L.ci(W), L.ci(H), L.cf(nearest), L.cf(extent),
             L.ptr(fb.uv), L.ptr(fb.depth), L.ptr(fb.conic), L.ptr(fb.radius), L.ptr(opa_t), st))
         fb._bin_and_sort()
-        out, gs_idx, ctx.blend = _blend_sets_forward(fb, meta, feats, opa_t, 0, K)
+        if sources:
+            feats = tuple(_source_tensor(t, pf, F, P) for t, (_, pf) in zip(feats, [p_ for pp in parts for p_ in pp]))
+            out, gs_idx, ctx.blend = _blend_sources_forward(fb, meta, parts, feats, opa_t, K)
+        else:
+            out, gs_idx, ctx.blend = _blend_sets_forward(fb, meta, feats, opa_t, 0, K)
         if ctx.blend["plan"] is None:
             raise ValueError("render_dynamic_sets needs sets that fit the one-pass backward")
         ctx.fb, ctx.meta, ctx.sink, ctx.geo = fb, meta, sink, (I, layout)
+        ctx.parts, ctx.fsink, ctx.sources = parts, (fsink or {}), sources
         ctx.opa_t = opa_t
         ctx.save_for_backward(position, cubic, rotation, opacity, scaling, rot_poly, rot_fourier, extr_c, tab, *feats)
         ctx.set_materialize_grads(False)
@@ -537,9 +566,44 @@ class _RenderDynamicSets(torch.autograd.Function):
         bufs = {k: (sink[k] if k in sink else torch.zeros_like(v)) for k, v in like.items()}
         c0s, cns, bgs, depth_ch, tap_set = _one_pass_plan(meta, widths, C)
         want_abs = 1 if (tap_set is not None and fb.want_abs) else 0
+        NF = _RenderDynamicSets.N_FIXED
+        has_tap = tap_set is not None
+        if ctx.sources:
+            # the row by SOURCES: a shared tensor's gradient is the sum over the frames, a per-frame tensor gets every frame's own
+            rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], ctx.opa_t, 0, want_abs)
+            table = (L.FeatureSource * L.MAX_SOURCES)()
+            dfe, n, fi, c0 = [], 0, 0, 0
+            for si, ((w, _, _, _), pp) in enumerate(zip(meta, ctx.parts)):
+                if w == "depth":
+                    c0 += 1
+                    continue
+                for cn, per_frame in pp:
+                    t = feats[fi]
+                    key = f"feature:{fi}"
+                    need = grads[si] is not None and (ctx.needs_input_grad[NF + fi] or key in ctx.fsink)
+                    buf = ctx.fsink.get(key)
+                    ret = None
+                    if need and buf is None:
+                        buf = ret = torch.zeros(t.shape, dtype=torch.float32, device=dev)
+                    dfe.append(ret)
+                    if need:
+                        table[n].c0, table[n].cn, table[n].feature = c0, cn, t.data_ptr()
+                        table[n].d_feature = buf.data_ptr()
+                        table[n].frame_stride = int(buf.stride(0)) if per_frame else 0
+                        n += 1
+                    c0 += cn
+                    fi += 1
+            L.check(lib.splat_frames_gauss_backward_dynamic_sources(
+                L.ci(F), L.ci(P), L.ci(I), L.ci(C), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ptr(rec), L.ptr(fb.goff),
+                L.ptr(fb.radius), L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(layout), L.ptr(rotation), L.ptr(rot_poly),
+                L.ptr(rot_fourier), L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c), L.ptr(bufs["position"]),
+                L.ptr(bufs["pos_cubic_node"]), L.ptr(bufs["rotation"]), L.ptr(bufs["opacity"]), L.ptr(bufs["scaling"]), L.ci(n),
+                table, L.ci(depth_ch), L.ptr(fb.tap if has_tap else None),
+                L.ptr(fb.abs_tap if (has_tap and want_abs) else None), L.ptr(fb.radii_max if has_tap else None), st))
+            ret = tuple(None if k in sink else bufs[k] for k in like)
+            return ret + (None,) * (NF - 5) + tuple(dfe)
         group_of = _set_groups(meta)
         fi, dfe, dfs, strides = 0, [], [None, None, None], [0, 0, 0]
-        NF = _RenderDynamicSets.N_FIXED
         for si, (w, _, _, _) in enumerate(meta):
             if w == "depth":
                 continue
@@ -556,7 +620,6 @@ class _RenderDynamicSets(torch.autograd.Function):
             rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], ctx.opa_t, 0, want_abs)
         i3 = ctypes.c_int32 * 3
         p3 = (ctypes.c_void_p * 3)(*[0 if d is None else d.data_ptr() for d in dfs])
-        has_tap = tap_set is not None
         gauss = lib.splat_frames_gauss_backward_dynamic_sets2 if two else lib.splat_frames_gauss_backward_dynamic_sets
         L.check(gauss(
             L.ci(F), L.ci(P), L.ci(I), L.ci(C), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ptr(rec), L.ptr(fb.goff), L.ptr(fb.radius),
@@ -569,6 +632,88 @@ class _RenderDynamicSets(torch.autograd.Function):
         return ret + (None,) * (NF - 5) + tuple(dfe)
 
 
+def _parse_sets(sets, F, P):
+    """``sets`` -> (meta: per set (width | "depth", bg, detach_opacity, taps); parts: per set the (channels, per_frame) of every
+    tensor its feature is made of -- () for the depth; the flat list of those tensors)"""
+    meta, parts, feats = [], [], []
+    for s_ in sets:
+        f = s_["feature"]
+        common = (float(s_.get("bg", 0.0)), bool(s_.get("detach_opacity", False)), bool(s_.get("taps", False)))
+        if isinstance(f, str):
+            if f != "depth":
+                raise ValueError('a set\'s feature is a tensor, a list of tensors or the string "depth"')
+            meta.append(("depth",) + common)
+            parts.append(())
+            continue
+        pp = []
+        for t in (list(f) if isinstance(f, (list, tuple)) else [f]):
+            if not isinstance(t, Tensor) or t.dim() not in (2, 3):
+                raise ValueError("a feature tensor is [P, c] (shared by the frames) or [F, P, c] (one row set per frame)")
+            if t.dim() == 3 and (t.shape[0] != F or t.shape[1] != P):
+                raise ValueError(f"a per-frame feature tensor must be [F={F}, P={P}, c], got {tuple(t.shape)}")
+            if t.dim() == 2 and t.shape[0] != P:
+                raise ValueError(f"a feature tensor must be [P={P}, c], got {tuple(t.shape)}")
+            pp.append((int(t.shape[-1]), t.dim() == 3))
+            feats.append(t)
+        meta.append((sum(c for c, _ in pp),) + common)
+        parts.append(tuple(pp))
+    return tuple(meta), tuple(parts), feats
+
+
+def _has_sources(parts) -> bool:
+    """does any set consist of several tensors or of a per-frame tensor? (then the row is described by sources)"""
+    return any(len(pp) > 1 or (len(pp) == 1 and pp[0][1]) for pp in parts)
+
+
+def _source_tensor(t: Tensor, per_frame: bool, F: int, P: int) -> Tensor:
+    """a source the kernels read in place: float32 on the device, dense rows; a per-frame tensor may be a strided view
+    (frame stride >= P * c), anything else is made contiguous"""
+    if not per_frame:
+        return L.need(t, "feature")
+    cn = t.shape[2]
+    if t.is_cuda and t.dtype == torch.float32 and t.stride(2) == 1 and t.stride(1) == cn and t.stride(0) >= P * cn:
+        L.need(t[0], "feature")      # (device gate; a frame's rows are contiguous)
+        return t
+    return L.need(t, "feature")
+
+
+def _blend_sources_forward(fb, meta, parts, feats, opacity, K):
+    """Forward compositing of a row described by SOURCES (splat_alpha_blending_forward_batch_sources): every tensor of every set
+    is read in place -- shared rows [P, c], per-frame rows [F, P, c] (any frame stride), the per-frame depth."""
+    lib, st = L.lib(), L.stream()
+    F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
+    widths = [1 if m[0] == "depth" else m[0] for m in meta]
+    plan = _one_pass_plan(meta, widths, C)
+    cache = fb.__dict__.setdefault("_bgc", {})
+    bgc = cache.get(meta)
+    if bgc is None:
+        bgc = torch.tensor([bg for (w, bg, _, _), n in zip(meta, widths) for _ in range(n)], dtype=torch.float32, device=fb.dev)
+        cache[meta] = bgc
+    table = (L.FeatureSource * L.MAX_SOURCES)()
+    n, c0, it = 0, 0, iter(feats)
+    for (w, _, _, _), pp in zip(meta, parts):
+        if w == "depth":
+            table[n].c0, table[n].cn, table[n].feature, table[n].frame_stride = c0, 1, fb.depth.data_ptr(), P
+            n += 1
+            c0 += 1
+            continue
+        for cn, per_frame in pp:
+            t = next(it)
+            if n >= L.MAX_SOURCES:
+                raise ValueError(f"at most {L.MAX_SOURCES} feature tensors per row")
+            table[n].c0, table[n].cn, table[n].feature = c0, cn, t.data_ptr()
+            table[n].frame_stride = int(t.stride(0)) if per_frame else 0
+            n += 1
+            c0 += cn
+    out = torch.empty(F, C, H, W, dtype=torch.float32, device=fb.dev)
+    gs_idx = torch.empty(F, H, W, K, dtype=torch.int32, device=fb.dev) if K > 0 else None
+    L.check(lib.splat_alpha_blending_forward_batch_sources(
+        L.ci(F), L.ci(P), L.ci(C), L.ci(n), table, L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity), ctypes.c_int64(0),
+        L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.ptr(bgc), L.ci(W), L.ci(H), L.ci(K), L.ci(0),
+        L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx), L.ptr(fb.pack), L.ptr(fb.cull_flags), st))
+    return out, gs_idx, dict(plan=plan, tens=None, row=None, widths=widths)
+
+
 def _blend_sets_forward(fb, meta, feats, opacity, op_fs, K):
     """Forward compositing of the sets' row for all frames.  When the sets fit the one-pass backward every set is read from its
     own tensor (shared features [P,c], the per-frame depth [F,P,1]) -- no [F,P,C] row is materialised; otherwise the row is
@@ -576,7 +721,7 @@ def _blend_sets_forward(fb, meta, feats, opacity, op_fs, K):
     lib, st = L.lib(), L.stream()
     F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
     widths = [1 if m[0] == "depth" else m[0] for m in meta]
-    one_pass_wanted = os.environ.get("SPLAT_SETS_ONE_PASS", "1") != "0"
+    one_pass_wanted = OPTIONS["sets_one_pass"]
     plan = _one_pass_plan(meta, widths, C) if one_pass_wanted else None
     if plan is None and one_pass_wanted and not fb.__dict__.get("_warned_per_set"):
         fb.__dict__["_warned_per_set"] = True   # (once per batch object)
@@ -617,8 +762,8 @@ def _set_tables(meta, plan, tens, P):
     c0s, cns, bgs, _, _ = plan
     groups = _set_groups(meta)
     ptr, fs = [0, 0, 0], [0, 0, 0]
-    for (w, _, _, _), t, g in zip(meta, tens, groups):
-        ptr[g] = t.data_ptr()
+    for (w, _, _, _), t, g in zip(meta, tens or [None] * len(meta), groups):
+        ptr[g] = 0 if t is None else t.data_ptr()   # (None: a row by sources -- its backward stages the forward's records)
         fs[g] = P if w == "depth" else 0        # the depth [F,P,1] is per frame, feature rows are shared
     i3, f3 = ctypes.c_int32 * 3, ctypes.c_float * 3
     return dict(c0=i3(*c0s), cn=i3(*cns), bg=f3(*bgs), feat=(ctypes.c_void_p * 3)(*ptr), fs=(ctypes.c_int64 * 3)(*fs))
@@ -644,9 +789,7 @@ def _blend_sets_backward_one_pass(fb, meta, state, grads, opacity, op_fs, want_a
     rec = fb._set_buffer(("rec", "sets"), F * cap * int(lib.splat_blend_sets_pair_stride(C)))
     # the renderer's own plan (rgb 0-2 with the taps | depth 3 | 19 detached attributes 4-22): the tile kernel stages the records
     # the FORWARD packed (fb.pack) -- no packing launch, no second record array; other plans pack their own
-    c0s, cns = plan[0], plan[1]
-    std = (C == 23 and list(c0s) == [0, 3, 4] and list(cns) == [3, 1, 19] and os.environ.get("SPLAT_SETS_STD", "1") != "0"
-           and os.environ.get("SPLAT_BWD_QUARTERS", "1") != "0" and os.environ.get("SPLAT_SETS_FWDREC", "1") != "0")
+    std = _uses_forward_pack(plan, C)
     pack = None if std else fb._set_buffer(("pack", "sets"), F * P * int(lib.splat_blend_sets_pack_floats()))
     L.check(lib.splat_alpha_blending_backward_batch_sets_packed(
         L.ci(F), L.ci(P), L.ci(C), tabs["c0"], tabs["cn"], tabs["bg"], L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity),
@@ -655,6 +798,16 @@ def _blend_sets_backward_one_pass(fb, meta, state, grads, opacity, op_fs, want_a
         (ctypes.c_void_p * 3)(*dl), L.ci(want_abs), L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(fb.cull_flags),
         L.ptr(_debug_T_front(F * H, W, fb.dev)), L.ptr(fb.pack if std else None), st))
     return rec
+
+
+def _uses_forward_pack(plan, C) -> bool:
+    """does the one-pass backward of this plan stage the records the FORWARD packed (no packing launch, no pack scratch)?  The C
+    library owns the condition (splat_blend_sets_uses_forward_pack: the renderer's own plan with the cull words)."""
+    from .gs.raster_ops import OPTIONS as RO
+    if plan is None or not RO["sets_fwdrec"]:
+        return False
+    i3 = ctypes.c_int32 * 3
+    return bool(L.lib().splat_blend_sets_uses_forward_pack(L.ci(C), i3(*plan[0]), i3(*plan[1]), L.ci(1)))
 
 
 def _check_set_features(meta, feats, P):
@@ -675,7 +828,7 @@ def _two_pass_ok(meta, widths) -> bool:
     one-pass kernel's 2).  Measured at BASELINE configs[1] (round 3): 192 + 521 us per frame against the one-pass kernel's 612 --
     the second replay of the alpha / T chain costs more than the third wave gains -- so the one-pass kernel stays the default;
     both are checked against the oracle (tests/test_gpu_frames_oracle.py)."""
-    if os.environ.get("SPLAT_SETS_TWO_PASS", "0") != "1" or len(meta) != 3:
+    if not OPTIONS["sets_two_pass"] or len(meta) != 3:
         return False
     groups = _set_groups(meta)
     if sorted(groups) != [0, 1, 2]:

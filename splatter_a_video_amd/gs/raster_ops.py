@@ -393,7 +393,9 @@ class _BlendShared(torch.autograd.Function):
             L.ptr(tile_range), L.cf(0.0), L.ptr(bgc), L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(final_T),
             L.ptr(ncontrib), L.ptr(gs_idx), L.ptr(pack), L.ptr(flags), L.stream()))
         ctx.flags = flags
-        ctx.fwd_pack = pack if flags is not None else None   # the forward's packed records: the one-pass backward stages them
+        # the forward's packed records stay alive until the backward only when the one-pass backward will stage them (the
+        # renderer's own plan: splat_blend_sets_uses_forward_pack); 128 B per Gaussian otherwise freed right here
+        ctx.fwd_pack = pack if (flags is not None and _uses_forward_pack(widths, detach_opacity, taps)) else None
         ctx.meta = (int(W), int(H), tuple(float(b) for b in bgs), tuple(bool(d) for d in detach_opacity),
                     tuple(bool(t) for t in taps), ndc is not None, abs_ndc is not None, widths)
         ctx.save_for_backward(uv, conic, opacity, idx_sorted, tile_range, final_T, ncontrib, *feats)
@@ -483,7 +485,7 @@ def _blend_shared_one_pass(ctx, grads):
     M = idx_sorted.numel()
     if ctx.pairmap is None or ctx.flags is None or M == 0 or any(g is None for g in grads[:n]):
         return None
-    if os.environ.get("SPLAT_SHARED_ONE_PASS", "1") == "0":
+    if not OPTIONS["shared_one_pass"]:
         return None
     C = sum(widths)
     meta = tuple((w, bg, d, t) for w, bg, d, t in zip(widths, bgs, detach, taps))
@@ -507,9 +509,8 @@ def _blend_shared_one_pass(ctx, grads):
     NG = 12                                        # csrc/common.h SETS_NG: [ux uy ca cb | cc o ax ay | tx ty 0 0 | row channels]
     assert ncp == (NG + C + 3) // 4 * 4
     rec = torch.empty(M * ncp, dtype=torch.float32, device=dev)
-    std = (C == 23 and list(c0s) == [0, 3, 4] and list(cns) == [3, 1, 19] and ctx.fwd_pack is not None
-           and os.environ.get("SPLAT_SETS_STD", "1") != "0" and os.environ.get("SPLAT_BWD_QUARTERS", "1") != "0"
-           and os.environ.get("SPLAT_SETS_FWDREC", "1") != "0")
+    i3_ = ctypes.c_int32 * 3
+    std = ctx.fwd_pack is not None and bool(lib.splat_blend_sets_uses_forward_pack(L.ci(C), i3_(*c0s), i3_(*cns), L.ci(1)))
     pack = None if std else torch.empty(max(P, 1) * int(lib.splat_blend_sets_pack_floats()), dtype=torch.float32, device=dev)
     i3, f3, p3, l3 = ctypes.c_int32 * 3, ctypes.c_float * 3, ctypes.c_void_p * 3, ctypes.c_int64 * 3
     pm = ctx.pairmap
@@ -533,6 +534,26 @@ def _blend_shared_one_pass(ctx, grads):
 
 
 _BlendShared._one_pass = staticmethod(_blend_shared_one_pass)
+
+# python-level switches of the shared blend (tests flip them; the library's own options: L.set_option)
+OPTIONS = {"shared_one_pass": os.environ.get("SPLAT_SHARED_ONE_PASS", "1") != "0",
+           "sets_fwdrec": os.environ.get("SPLAT_SETS_FWDREC", "1") != "0"}
+
+
+def _uses_forward_pack(widths, detach, taps) -> bool:
+    """will the one-pass backward of these sets stage the forward's packed records?  (the C library owns the condition)"""
+    import ctypes
+
+    from ..frames import _one_pass_plan
+    if not (OPTIONS["shared_one_pass"] and OPTIONS["sets_fwdrec"]):
+        return False
+    C = sum(widths)
+    meta = tuple((w, 0.0, bool(d), bool(t)) for w, d, t in zip(widths, detach, taps))
+    plan = _one_pass_plan(meta, list(widths), C)
+    if plan is None:
+        return False
+    i3 = ctypes.c_int32 * 3
+    return bool(L.lib().splat_blend_sets_uses_forward_pack(L.ci(C), i3(*plan[0]), i3(*plan[1]), L.ci(1)))
 
 
 def _offsets(widths):

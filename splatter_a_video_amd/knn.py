@@ -77,6 +77,34 @@ def knn_points(p1: Tensor, p2: Tensor, lengths1: Optional[Tensor] = None, length
     return KNN(dists=dists, idx=idx, knn=nn)
 
 
+def knn_brute_batch(points: Tensor, query_idx: Tensor, K: int):
+    """K <= 8 nearest points of a FEW query vertices in each of B point sets, brute force in two launches: ``points`` [B, N, 3]
+    (any batch stride, dense rows), ``query_idx`` [B, S] int64 = indices of the query vertices in their own set; returns
+    (dists [B, S, K], idx [B, S, K] int32) ascending, ties -> smaller index, the query itself included (distance 0) -- rows
+    ``query_idx`` of ``knn_points(points, points, K=K)``.  What the ARAP term of a training batch needs: the neighbours of its
+    512 sampled vertices (src/geometry_utils.py:17-19,98-101), for which a grid build per point set would cost more than the
+    scan.  No gradient (the reference's ARAP takes none through the neighbour choice)."""
+    if points.dim() != 3 or points.shape[2] != 3 or query_idx.dim() != 2 or query_idx.shape[0] != points.shape[0]:
+        raise ValueError("points must be [B, N, 3] and query_idx [B, S]")
+    if not 1 <= K <= 8:
+        raise ValueError("K must be in 1..8")
+    p = points.detach()
+    if not (p.is_cuda and p.dtype == torch.float32 and p.stride(2) == 1 and p.stride(1) == 3):
+        p = L.need(p, "points")
+    else:
+        L.need(p[0], "points")
+    q = L.need(query_idx, "query_idx", torch.int64)
+    B, N, S = p.shape[0], p.shape[1], q.shape[1]
+    lib = L.lib()
+    dev = p.device
+    dists = torch.empty(B, S, K, dtype=torch.float32, device=dev)
+    idx = torch.empty(B, S, K, dtype=torch.int32, device=dev)
+    scratch = torch.empty(max(int(lib.splat_knn_brute_scratch_bytes(B, N, S)), 4), dtype=torch.uint8, device=dev)
+    L.check(lib.splat_knn_brute_batch(L.ci(B), L.ci(N), L.ci(S), L.ci(K), L.ptr(p), ctypes.c_int64(p.stride(0) if B > 1 else N * 3),
+                                      L.ptr(q), L.ptr(dists), L.ptr(idx), L.ptr(scratch), L.stream()))
+    return dists, idx
+
+
 def distCUDA2(points: Tensor) -> Tensor:
     """Mean squared distance of every point to its three nearest neighbours, the quantity ``simple_knn._C.distCUDA2``
     returns (reference use: src/pointrix/utils/gaussian_points/gaussian_utils.py:5,68-73, initial Gaussian scales;

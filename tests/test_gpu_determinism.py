@@ -12,6 +12,7 @@ import torch
 import dptr.gs as gs
 from splatter_a_video_amd import _lib as L
 from splatter_a_video_amd.frames import FrameBatch
+from splatter_a_video_amd.gs import raster_ops as RO
 from splatter_a_video_amd.synth import make_scene
 
 pytestmark = pytest.mark.gpu
@@ -231,7 +232,7 @@ def test_three_set_backward_from_the_forwards_records_is_bit_identical(monkeypat
     gr = [_t(rng.normal(size=(F, c, H, W)).astype(np.float32)) for c in (3, 1, 19)]
     res = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("SPLAT_SETS_FWDREC", flag)
+        monkeypatch.setitem(RO.OPTIONS, "sets_fwdrec", flag == "1")
         p = {k: _t(v, True) for k, v in base.items()}
         B = FrameBatch(F, N, W, H, 23, "cuda", want_abs=True)
         sets = [dict(feature=p["rgb"], bg=0.1, taps=True), dict(feature="depth", bg=1.0),

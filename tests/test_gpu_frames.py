@@ -6,6 +6,7 @@ import torch
 
 import dptr.gs as gs
 from splatter_a_video_amd._lib import SplatError
+from splatter_a_video_amd import frames as FR
 from splatter_a_video_amd.frames import FrameBatch
 from splatter_a_video_amd.gs.raster_ops import capture_T_front
 from splatter_a_video_amd.synth import make_scene
@@ -222,7 +223,7 @@ def test_render_sets_equals_the_native_renderer_frame_by_frame(one_pass, monkeyp
     (opacity detached) of every frame in one set of launches, against OrthoEnhancedRenderer.render_iter frame by frame
     (which tests/test_gpu_renderer_native.py / test_gpu_renderer_flow.py tie to the reference's call sequence)."""
     from splatter_a_video_amd.renderer import OrthoEnhancedRenderer
-    monkeypatch.setenv("SPLAT_SETS_ONE_PASS", one_pass)
+    monkeypatch.setitem(FR.OPTIONS, "sets_one_pass", one_pass == "1")
     N, W, H, F, K = 9000, 192, 128, 3, 20
     sc = make_scene(N, W, H, seed=15)
     rng = np.random.default_rng(3)
@@ -285,7 +286,7 @@ def test_render_sets_one_pass_equals_the_per_set_passes(case, monkeypatch):
     gs_ = [_t(rng.normal(size=(F, w, H, W)).astype(np.float32)) for w in gw]
 
     def run(flag):
-        monkeypatch.setenv("SPLAT_SETS_ONE_PASS", flag)
+        monkeypatch.setitem(FR.OPTIONS, "sets_one_pass", flag == "1")
         p = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity).items()}
         fe = [_t(f, True) for f in feats_np]
         if case == "detached_first":

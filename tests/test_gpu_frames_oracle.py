@@ -11,6 +11,7 @@ import pytest
 import torch
 
 import oracle_chain as oc
+from splatter_a_video_amd import frames as FR
 from splatter_a_video_amd.frames import FrameBatch
 from splatter_a_video_amd.gs.raster_ops import capture_T_front
 from test_gpu_parity import GRAD_RTOL, IMG_ATOL, IMG_RTOL, assert_grad
@@ -101,7 +102,7 @@ def test_render_sets_against_oracle(oracle_mod, two_pass, monkeypatch):
     19 attribute channels with opacity.detach() -- one forward over the 23-channel row, then the TWO-pass backward (tap set:
     blend_bwd_mfma_kernel<3>; depth + attributes: blend_bwd_attr_kernel; one shared record) or the ONE-pass three-set
     backward (blend_bwd_sets_kernel), and frames_gauss_bwd_static_sets(2) -- against three oracle blends per frame."""
-    monkeypatch.setenv("SPLAT_SETS_TWO_PASS", two_pass)
+    monkeypatch.setitem(FR.OPTIONS, "sets_two_pass", two_pass == "1")
     F, K = 3, 20
     g, opacity, off, rng = _c1_scene(F, seed=3)
     N, W, H = g["xyz"].shape[0], int(g["W"]), int(g["H"])
@@ -198,7 +199,7 @@ def test_render_dynamic_sets_against_oracle_with_reference_parameters(oracle_mod
     (400 Gaussians x 50 frames, tests/golden/make_golden_dynamic.py; its activations are pinned in test_gpu_dynamic.py) tiled
     to fill a 96 x 64 view: dynamic evaluation -> three blends -> one-pass backward -> frames_gauss_bwd_dynamic_sets."""
     from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, FrameClock, to_gaussian_major, to_segment_major
-    monkeypatch.setenv("SPLAT_SETS_TWO_PASS", two_pass)
+    monkeypatch.setitem(FR.OPTIONS, "sets_two_pass", two_pass == "1")
     g = dict(np.load(os.path.join(GOLD, "dynamic_400x50.npz")))
     clock = FrameClock(int(g["T"]), g["intervals"], int(g["start_frame_id"]), int(g["time_len"]))
     I = clock.interval_num

@@ -6,6 +6,7 @@ import torch
 
 import dptr.gs as gs
 from splatter_a_video_amd.densify import DensifyState
+from splatter_a_video_amd.gs import raster_ops as RO
 from splatter_a_video_amd.renderer import OrthoEnhancedRenderer
 from splatter_a_video_amd.synth import make_scene
 
@@ -197,7 +198,7 @@ def test_shared_blend_one_pass_backward_equals_one_backward_per_set(abs_tap, mon
     g = [_t(rng.normal(size=(c, H, W)).astype(np.float32)) for c in (3, 1, 19)]
     res = []
     for one_pass in ("1", "0"):
-        monkeypatch.setenv("SPLAT_SHARED_ONE_PASS", one_pass)
+        monkeypatch.setitem(RO.OPTIONS, "shared_one_pass", one_pass == "1")
         p = {k: _t(v, True) for k, v in base.items()}
         uv, depth, conic, radius, tiles = gs.preprocess_ortho(p["position"], p["scaling"], p["rotation"], _t(sc.extr), W, H, nearest=0.01)
         idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
