@@ -266,18 +266,49 @@ knn_search_kernel(int N, const float *__restrict__ query, const int *__restrict_
 // Exact; ties -> smaller index (knn_insert), the arithmetic of knn_search_kernel.
 constexpr int KNB_TILE = 1024, KNB_TILES = 4, KNB_CHUNK = KNB_TILE * KNB_TILES;
 
+// Bound pass: an upper bound of the query's K-th neighbour distance from the KNB_WIN points around its own index (the Gaussians
+// are kept in Morton order of their screen positions, densify.spatial_order: index neighbours are mostly space neighbours; any K
+// points give a valid bound).  The scan then inserts only candidates within the bound -- a fresh list per (query, chunk) would
+// take ~8 ln(chunk / 8) insertions per thread, and a wave runs the insertion whenever ANY of its 64 queries inserts: three
+// times the work of the distance loop itself.
+constexpr int KNB_WIN = 128;
+template <int KT>
+__global__ void __launch_bounds__(KB)
+knn_brute_bound_kernel(int N, int S, int K, const float *__restrict__ pts, long long pts_bs, const long long *__restrict__ qidx,
+                       float *__restrict__ tau) {
+    const int q = blockIdx.x * KB + threadIdx.x, b = blockIdx.y;
+    if (q >= S) return;
+    const float *P = pts + (size_t)b * pts_bs;
+    const int v = (int)qidx[(size_t)b * S + q];
+    const float qx = P[3 * (size_t)v], qy = P[3 * (size_t)v + 1], qz = P[3 * (size_t)v + 2];
+    float bd[KT];
+    int bi[KT];
+#pragma unroll
+    for (int p = 0; p < KT; ++p) { bd[p] = __builtin_inff(); bi[p] = 0x7fffffff; }
+    const int lo = imax_(0, imin_(v - KNB_WIN / 2, N - KNB_WIN)), hi = imin_(N, lo + KNB_WIN);
+    for (int id = lo; id < hi; ++id) {
+        const float dx = qx - P[3 * (size_t)id], dy = qy - P[3 * (size_t)id + 1], dz = qz - P[3 * (size_t)id + 2];
+        knn_insert<KT>(bd, bi, dx * dx + dy * dy + dz * dz, id);
+    }
+    float t = __builtin_inff();   // fewer than K points in the window (tiny sets): no bound
+#pragma unroll
+    for (int p = 0; p < KT; ++p) t = (p == K - 1) ? bd[p] : t;
+    tau[(size_t)b * S + q] = t * 1.000002f;   // (the scan may round the same distance an ulp differently: keep the bound's own points)
+}
+
 template <int KT>
 __global__ void __launch_bounds__(KB)
 knn_brute_partial_kernel(int N, int S, int G, const float *__restrict__ pts, long long pts_bs, const long long *__restrict__ qidx,
-                         float *__restrict__ pd, int *__restrict__ pi) {
+                         const float *__restrict__ tau, float *__restrict__ pd, int *__restrict__ pi) {
     __shared__ float4 sp[KNB_TILE];
     const int c = blockIdx.x, b = blockIdx.z;
     const int q = blockIdx.y * KB + threadIdx.x;
     const float *P = pts + (size_t)b * pts_bs;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
+    float qx = 0.f, qy = 0.f, qz = 0.f, bound = -1.f;   // (a lane past the queries takes no candidate)
     if (q < S) {
         const long long v = qidx[(size_t)b * S + q];
         qx = P[3 * v]; qy = P[3 * v + 1]; qz = P[3 * v + 2];
+        bound = tau[(size_t)b * S + q];
     }
     float bd[KT];
     int bi[KT];
@@ -297,7 +328,8 @@ knn_brute_partial_kernel(int N, int S, int G, const float *__restrict__ pts, lon
         for (int e = 0; e < n; ++e) {
             const float4 p = sp[e];
             const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-            knn_insert<KT>(bd, bi, dx * dx + dy * dy + dz * dz, __float_as_int(p.w));
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d <= bound) knn_insert<KT>(bd, bi, d, __float_as_int(p.w));   // the K nearest all lie within the bound
         }
     }
     if (q < S) {
@@ -403,7 +435,8 @@ extern "C" int splat_knn_search(int N, const float *query, const int32_t *query_
 // index, the query itself included (distance 0) like knn_points(points, points).  scratch: splat_knn_brute_scratch_bytes().
 extern "C" size_t splat_knn_brute_scratch_bytes(int B, int N, int S) {
     const size_t G = ((size_t)(N > 0 ? N : 1) + KNB_CHUNK - 1) / KNB_CHUNK;
-    return (size_t)(B > 0 ? B : 1) * G * (size_t)(S > 0 ? S : 1) * 8 * (sizeof(float) + sizeof(int));
+    const size_t bs = (size_t)(B > 0 ? B : 1) * (size_t)(S > 0 ? S : 1);
+    return bs * G * 8 * (sizeof(float) + sizeof(int)) + bs * sizeof(float);   // partial lists + the bound of every query
 }
 
 extern "C" int splat_knn_brute_batch(int B, int N, int S, int K, const float *points, int64_t points_batch_stride,
@@ -417,8 +450,12 @@ extern "C" int splat_knn_brute_batch(int B, int N, int S, int K, const float *po
     const int G = (N + KNB_CHUNK - 1) / KNB_CHUNK;
     float *pd = (float *)scratch;
     int *pi = (int *)(pd + (size_t)B * G * S * 8);
+    float *tau = (float *)(pi + (size_t)B * G * S * 8);
+    SPLAT_LAUNCH("knn_brute_bound", knn_brute_bound_kernel<8>, dim3((unsigned)((S + KB - 1) / KB), (unsigned)B), dim3(KB), 0, s, N, S, K,
+                 points, (long long)points_batch_stride, (const long long *)query_idx, tau);
+    SPLAT_POST_LAUNCH();
     SPLAT_LAUNCH("knn_brute", knn_brute_partial_kernel<8>, dim3((unsigned)G, (unsigned)((S + KB - 1) / KB), (unsigned)B), dim3(KB), 0, s,
-                 N, S, G, points, (long long)points_batch_stride, (const long long *)query_idx, pd, pi);
+                 N, S, G, points, (long long)points_batch_stride, (const long long *)query_idx, tau, pd, pi);
     SPLAT_POST_LAUNCH();
     SPLAT_LAUNCH("knn_brute_merge", knn_brute_merge_kernel<8>, dim3((unsigned)((S + KB - 1) / KB), (unsigned)B), dim3(KB), 0, s, S, G, K,
                  pd, pi, dists, idx);

@@ -122,3 +122,81 @@ def test_bench_gpus_2_launches_and_reports_two_ranks():
     assert lines[1]["comm"] is None and lines[1]["allreduce_ms"] is None
     assert len(lines[1]["build_id"]) == 16
     assert lines[2]["config"]["frames_per_rank_per_step"] == 3 and lines[2]["value"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the composed training step (train_step.py) under data parallelism
+def _train_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from splatter_a_video_amd import train_step as TS
+        from test_gpu_train_step import _clip, _perturbed, _t
+        Nn, Ww, Hh, T, F = 3000, 128, 96, 20, 3
+        sc, clock, truth = _clip(Nn, Ww, Hh, T, seed=5)
+        extr = _t(sc.extr)
+        cfg = TS.DensifyConfig(interval=15, start_iter=10, stop_iter=40, grad_threshold=5e-4, cameras_extent=60.0, min_opacity=0.02, seed=9)
+        lr = dict(TS.REFERENCE_LR, pos_cubic_node=2e-3, shs=2e-2, attrs=2e-2, scaling=1e-2, rotation=5e-3)
+        st = TS.TrainingStep(_perturbed(truth, 1), clock, Ww, Hh, F, extr, lr=lr, densify=cfg, K=8, arap_samples=128, sample_seed=rank)
+        rng = np.random.default_rng(100 + rank)                     # every rank draws ITS OWN frame pairs
+        counts, losses = [st.N], []
+        for _ in range(45):
+            t1 = [int(t) for t in rng.choice(T, F, replace=False)]
+            t2 = [int((t + 1 + rng.integers(T - 1)) % T) for t in t1]
+            st.step(t1, t2, TS.render_ground_truth(truth, clock, Ww, Hh, extr, t1, t2))
+            losses.append(st.loss())
+            if st.maybe_densify():
+                counts.append(st.N)
+        torch.cuda.synchronize()
+        torch.save({"param": st.bucket.flat_param.detach().cpu(), "m": st.opt.exp_avg.cpu(), "counts": counts, "losses": losses,
+                    "frozen": st.frozen["position"].cpu()}, out + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_training_step_replicas_stay_bit_identical_through_densification(tmp_path):
+    """the composed training step on two ranks with DIFFERENT frame pairs: one all-reduce of the flat bucket per step, Adam with
+    1 / world, densification statistics reduced over the ranks (SUM of the taps, MAX of radii / visibility) -- the replicas take
+    the same clone / split / prune decisions (children from the counter-based generator), rebuild at the same count and end
+    bit-identical: parameters, Adam moments, positions"""
+    out = str(tmp_path / "ts")
+    mp.spawn(_train_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["counts"] == r1["counts"] and len(set(r0["counts"])) >= 3, (r0["counts"], r1["counts"])
+    assert torch.equal(r0["param"], r1["param"]) and torch.equal(r0["m"], r1["m"]) and torch.equal(r0["frozen"], r1["frozen"])
+    assert np.isfinite(r0["losses"]).all() and np.mean(r0["losses"][-5:]) < np.mean(r0["losses"][:3])
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("n", [8, 4])
+def test_bench_gpus_8_and_4_rehearsal_over_gloo(n):
+    """what the driver's first multi-GPU run executes, rehearsed on one device: `python bench.py --gpus 8` (and 4) starts its ranks,
+    the clip grows to 25 frames per rank (200 at 8 ranks: BASELINE configs[2]), the line says n_gpus / ranks_seen = N, carries
+    the collective's figures and the exact-overlap variant, and the extra lines -- the reference's training frame and the
+    composed training step -- run at N > 1 with their own bucket / all-reduce fields"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, SPLAT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    small = ["--gaussians", "4000", "--width", "128", "--height", "96", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+             "--no-kernel-timing"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)] + small, env=env, capture_output=True,
+                       text=True, timeout=1400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == n and line["ranks_seen"] == n
+    assert line["config"]["frames_per_rank_per_step"] == 25 and f"of a {25 * n}-frame" in line["config"]["workload"]
+    c = line["comm"]
+    assert "error" not in c and c["allreduce_ms"] > 0 and c["overlap_exact"]["value"] > 0, c
+    frame, step = line["extra_lines"]
+    assert "error" not in frame and frame["n_gpus"] == n and frame["value"] > 0
+    assert frame["comm"]["allreduce_ms"] > 0 and frame["grad_bucket_MB"] == frame["comm"]["bucket_MB"]
+    assert "error" not in step, step
+    assert step["n_gpus"] == n and step["train_step_ms"] > 0 and set(step["phases_ms"]) >= {"render_forward", "render_backward", "knn_arap"}
