@@ -952,7 +952,7 @@ def main():
         torch.cuda.synchronize()
         L.profile_enable(False)
         names = ["sh_fwd", "frame_preprocess_fwd", "frame_preprocess_bwd", "preprocess_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
-                 "bin_scatter", "tile_sort", "blend_pack", "attr_pack", "blend_fwd", "blend_bwd", "attr_bwd", "pair_reduce", "gauss_bwd", "preprocess_bwd", "ewa_bwd", "project_point_bwd",
+                 "bin_scatter", "tile_sort", "blend_pack", "blend_fwd", "blend_bwd", "pair_reduce", "gauss_bwd", "preprocess_bwd", "ewa_bwd", "project_point_bwd",
                  "cov3d_bwd", "sh_bwd", "adam_step"]
         for n in names:
             ms, cnt = L.profile_read(n)

@@ -565,44 +565,6 @@ size_t splat_blend_sets_pair_stride(int C);
    rgb 0-2 | depth 3 | 19 attributes 4-22, with cull words, options "sets_std" and "bwd_quarters" on): no pack_scratch needed */
 int splat_blend_sets_uses_forward_pack(int C, const int32_t *set_c0, const int32_t *set_cn, int has_cull_flags);
 size_t splat_blend_sets_pack_floats(void);
-/* The same three blends backward in TWO tile passes sharing one pair record (the renderer's configuration: a tap set of <= 3
- * channels, the per-frame depth [F,P] blended with the live opacity, an attribute set of <= 20 channels blended with
- * opacity.detach()): the tap set through the narrow matrix-core kernel (four waves per SIMD), depth + attributes through a
- * kernel that keeps dL_dout in LDS (three waves per SIMD) -- the one-pass kernel above needs 255 registers (two waves).
- * set_bg: HOST array (tap, depth, attribute).  Records: splat_blend_sets2_pair_stride() (= 40) floats
- *   [ux uy ca cb | cc o ax ay | f0 f1 f2 . || ux uy ca cb | cc o dz a0 | a1 .. a19 ..]
- * reduced by splat_frames_gauss_backward_{static_sets2_cam, dynamic_sets2} (arguments of the _sets forms; set 0 = tap, set 1 =
- * depth, set 2 = attributes; set_c0 / depth_channel unused).  pack_a: F * P * splat_blend_pack_floats(tap_cn) floats,
- * pack_b: F * P * splat_blend_sets2_pack_floats() floats. */
-size_t splat_blend_sets2_pair_stride(void);
-size_t splat_blend_sets2_pack_floats(void);
-int splat_alpha_blending_backward_batch_sets2(int F, int P, int tap_cn, int attr_cn, const float *set_bg, const float *uv,
-                                              const float *conic, const float *opacity, int64_t opacity_frame_stride,
-                                              const float *tap_feature, int64_t tap_feature_fs, const float *depth_feature,
-                                              const float *attr_feature, int64_t attr_feature_fs,
-                                              const int32_t *idx_sorted, const int32_t *tile_range, int64_t capacity, int W,
-                                              int H, const float *final_T, const int32_t *ncontrib, const float *dL_tap,
-                                              const float *dL_depth, const float *dL_attr, const int32_t *slot_sorted,
-                                              float *pair_records, float *pack_a, float *pack_b, const uint32_t *cull_flags,
-                                              float *dbg_T_front, splat_stream_t stream);
-int splat_frames_gauss_backward_static_sets2_cam(int F, int P, int C, int W, int H, int64_t capacity,
-                                                 const float *pair_records, const int32_t *goff_incl,
-                                                 const int32_t *radius, const float *xyz, const float *scales,
-                                                 const float *uquats, const splat_camera_t *cam, int accumulate,
-                                                 float *d_xyz, float *d_scales, float *d_uquats, float *d_opacity,
-                                                 const int32_t *set_c0, const int32_t *set_cn, float *const *set_dfeature,
-                                                 const int32_t *set_stride, int depth_channel, float *tap, float *abs_tap,
-                                                 int32_t *radii_max, splat_stream_t stream);
-int splat_frames_gauss_backward_dynamic_sets2(int F, int P, int I, int C, int W, int H, int64_t capacity,
-                                              const float *pair_records, const int32_t *goff_incl, const int32_t *radius,
-                                              const void *frame_table, const float *position, const float *pos_cubic_node,
-                                              int cubic_layout, const float *rotation, const float *rot_poly_feat,
-                                              const float *rot_fourier_feat, const float *opacity, const float *scaling,
-                                              const float *extr, float *d_position, float *d_pos_cubic_node,
-                                              float *d_rotation, float *d_opacity, float *d_scaling, const int32_t *set_c0,
-                                              const int32_t *set_cn, float *const *set_dfeature, const int32_t *set_stride,
-                                              int depth_channel, float *tap, float *abs_tap, int32_t *radii_max,
-                                              splat_stream_t stream);
 int splat_alpha_blending_backward_batch_sets(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
                                              const float *set_bg, const float *uv, const float *conic,
                                              const float *opacity, int64_t opacity_frame_stride,

@@ -50,8 +50,6 @@ SYMBOLS = [
     "splat_frames_gauss_backward_static_sets", "splat_frames_gauss_backward_dynamic_sets",
     "splat_preprocess_forward_batch_cam", "splat_frames_gauss_backward_static_cam", "splat_frames_gauss_backward_static_sets_cam",
     "splat_preprocess_persp_forward", "splat_preprocess_persp_backward",
-    "splat_blend_sets2_pair_stride", "splat_blend_sets2_pack_floats", "splat_alpha_blending_backward_batch_sets2",
-    "splat_frames_gauss_backward_static_sets2_cam", "splat_frames_gauss_backward_dynamic_sets2",
     "splat_alpha_blending_forward_batch_sources", "splat_frames_gauss_backward_dynamic_sources",
     "splat_frames_gauss_backward_static_sources_cam", "splat_blend_sets_uses_forward_pack",
     "splat_dynamic_positions_batch_forward", "splat_dynamic_positions_batch_backward",
@@ -103,10 +101,6 @@ def lib() -> ctypes.CDLL:
         L.splat_blend_sets_pair_stride.argtypes = [ctypes.c_int]
         L.splat_blend_sets_pack_floats.restype = ctypes.c_size_t
         L.splat_blend_sets_pack_floats.argtypes = []
-        L.splat_blend_sets2_pair_stride.restype = ctypes.c_size_t
-        L.splat_blend_sets2_pair_stride.argtypes = []
-        L.splat_blend_sets2_pack_floats.restype = ctypes.c_size_t
-        L.splat_blend_sets2_pack_floats.argtypes = []
         L.splat_profile_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
         L.splat_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
         L.splat_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]

@@ -3779,358 +3779,6 @@ blend_bwd_wide_quarter_kernel(const BlendArgs B) {
 #undef WIDEQ_STAGE_IDS
 #undef WIDEQ_STAGE_PAYLOAD
 
-// ------------------------------------------------------------------ backward of the WIDE part of the renderer's row in its own pass
-// blend_bwd_sets_kernel replays the alpha / T chain once for three sets but needs 255 registers (dL_dout of 23 channels in both
-// MFMA operand layouts): two waves per SIMD, the matrix pipe and the VALU take turns instead of overlapping (615 us per frame at
-// BASELINE configs[1]).  The row splits where the register pressure comes from:
-//   pass A  the tap set (rgb: taps, |taps|, every gradient) through the narrow matrix-core kernel (blend_bwd_mfma_kernel<3>,
-//           four waves per SIMD);
-//   pass B  this kernel: the depth set (live opacity, one channel: its colour dot product is one multiply per element) and the
-//           detached attribute set (<= 20 channels), dL_dout of the wave's pixels in LDS (20 KB) instead of 52 registers,
-//           slabs by list position -- 53 KB of LDS and <= 168 registers: three waves per SIMD.
-// Measured (round 3, BASELINE configs[1], 25-frame batch): pass A 192 us + pass B 521 us per frame against 612 us of the one-pass
-// kernel: a second replay of the alpha / T chain costs more than the third wave gains.  The one-pass kernel stays the default
-// (frames.py: SPLAT_SETS_TWO_PASS=1 selects this path); both are checked against the oracle.
-// Both passes write into ONE pair record (BlendArgs::rec_stride / rec_off):
-//   [A: ux uy ca cb | cc o ax ay | f0 f1 f2 .  |  B: ux uy ca cb | cc o dz a0 | a1 ..]      A at float 0 (12), B at float 12 (<= 27)
-// which the Gaussian-side backward sums component-wise (d uv = A + B, taps = A alone, d opacity = A.o + B.o where B.o carries
-// the depth set only, dz = dL/ddepth of the projection).
-struct AttrCfg {
-    static constexpr int CH = 20, NK = 5, NA = 2, SB = 64, CAP = 32;
-    static constexpr int NG = 7;                    // ux uy ca cb cc o dz
-    static constexpr int NCMAX = NG + CH;
-    static constexpr int PS = 8;                    // state floats per pixel: [. . ncontrib gz | T R1 R2 .]  (R from T_final bg.g)
-    static constexpr int RQL = 7;                   // staged parts of a packed record: geometry (2) + 20 attribute slots (5)
-    static constexpr int REC_A = 12, REC_STRIDE = 40;  // the shared record: pass A's floats, total stride
-};
-
-__global__ void __launch_bounds__(256)
-pack_attr_kernel(const BlendArgs B) {
-    // packed records of pass B: [u v A B | C o depth id | a0 .. a19 | .]  (the depth FEATURE of the frame rides in the unused
-    // opacity-bias slot; no cull parameters: the backward reads the forward's cull flags or derives them from the conic)
-    const BlendArgs A = frame_args(B, blockIdx.y);
-    constexpr int CH = AttrCfg::CH, RS = Rec<CH>::RS, RQ = Rec<CH>::RQ, LS = RS + 4;
-    __shared__ __attribute__((aligned(16))) float s_rec[256 * LS];
-    const int i0 = blockIdx.x * 256;
-    const int i = i0 + threadIdx.x;
-    float r[RS];
-#pragma unroll
-    for (int k = 0; k < RS; ++k) r[k] = 0.f;
-    if (i < A.P) {
-        const float2 q = A.uv[i];
-        r[0] = q.x; r[1] = q.y;
-        r[2] = A.conic[3 * i]; r[3] = A.conic[3 * i + 1]; r[4] = A.conic[3 * i + 2];
-        r[5] = A.opacity[i];
-        r[6] = A.sf1 ? A.sf1[i] : 0.f;          // the depth set's feature: one float per Gaussian and frame
-        r[7] = __int_as_float(i);
-    }
-    float4 *row = reinterpret_cast<float4 *>(s_rec + threadIdx.x * LS);
-#pragma unroll
-    for (int k = 0; k < RS; k += 4) row[k / 4] = make_float4(r[k], r[k + 1], r[k + 2], r[k + 3]);
-    __syncthreads();
-    const int nrec = imin_(256, A.P - i0);
-    stage_feature_rows(s_rec, LS, 8, A.sf2, A.s2cn, i0, nrec);
-    __syncthreads();
-    float4 *dst = reinterpret_cast<float4 *>(A.pack + (size_t)i0 * RS);
-    for (int c = threadIdx.x; c < nrec * RQ; c += 256) {
-        const int g = c / RQ, part = c - g * RQ;
-        dst[c] = *reinterpret_cast<const float4 *>(s_rec + g * LS + 4 * part);
-    }
-}
-
-__global__ void __launch_bounds__(256, 3)
-blend_bwd_attr_kernel(const BlendArgs B) {
-    using Cfg = AttrCfg;
-    constexpr int CH = Cfg::CH, SB = Cfg::SB, NG = Cfg::NG, NK = Cfg::NK, NA = Cfg::NA, PS = Cfg::PS, CAP = Cfg::CAP;
-    constexpr int GST = CH;                        // floats per pixel of the staged dL_dout (attribute slots)
-    __shared__ TileLDS<CH, SB, false, 0, false, Cfg::RQL> L;
-    __shared__ CarryLDS<SB, true> CL;              // (position bytes of the entries; nothing is carried here)
-    __shared__ float s_acc[4][(CAP + 1) * Cfg::NCMAX];
-    __shared__ float s_g[4][64 * GST];             // dL_dout of the attribute set: [pixel of the wave's block][slot]
-    __shared__ __attribute__((aligned(16))) float s_state[4][64 * PS];
-    __shared__ float s_mom[64 * 9];                // moment monomials [pixel of a block][1 x y xx xy yy 0 . .] (the same for the 4 waves)
-    __shared__ int s_wmax[4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int gtile = xcd_tile(blockIdx.x, gridDim.x);
-    const int frame = gtile / B.T, tile = gtile - frame * B.T;
-    const BlendArgs A = frame_args(B, frame);
-    const int cn = A.s2cn;                          // attribute channels (<= 20)
-    const int NC = NG + cn;                         // floats of this pass's part of the record
-    const int RST = B.rec_stride;
-    float *const pair_buf = B.pair_buf + (size_t)frame * (size_t)B.cap * RST + B.rec_off;
-    const int tx = tile % A.gx, ty = tile / A.gx;
-    const int bx = tx * TILE + (w & 1) * 8, by = ty * TILE + (w >> 1) * 8;
-    const float bx0 = (float)bx, by0 = (float)by;
-    const float tcx = (float)(tx * TILE) + 7.5f, tcy = (float)(ty * TILE) + 7.5f;
-    const float ox = (float)((w & 1) * 8) - 7.5f, oy = (float)((w >> 1) * 8) - 7.5f;
-    const int nl = lane & 15, kk = lane >> 4;
-    if (tid < 64) {   // moment table: block-centred coordinates of pixel q
-        const float x = (float)(tid & 7) - 3.5f, y = (float)(tid >> 3) - 3.5f;
-        float *m = s_mom + tid * 9;
-        m[0] = 1.f; m[1] = x; m[2] = y; m[3] = x * x; m[4] = x * y; m[5] = y * y; m[6] = 0.f; m[7] = 0.f; m[8] = 0.f;
-    }
-    // row type of this lane in the moment product's A operand (see blend_bwd_mfma_kernel): rows 0-3: 1 x y xx | 4-7: 1 x y xy |
-    // 8-11: 1 y yy 0 | 12-15: 0
-    const int mtype = nl == 0 || nl == 4 || nl == 8 ? 0 : nl == 1 || nl == 5 ? 1 : nl == 2 || nl == 6 || nl == 9 ? 2
-                    : nl == 3 ? 3 : nl == 7 ? 4 : nl == 10 ? 5 : 6;
-    float phi1[4], phi2[4];
-#pragma unroll
-    for (int Gs = 0; Gs < 4; ++Gs) {
-        const int q = 16 * Gs + nl;
-        const float x = (float)(q & 7) + ox, y = (float)(q >> 3) + oy;
-        phi1[Gs] = kk == 0 ? 1.f : kk == 1 ? x : kk == 2 ? y : x * x;
-        phi2[Gs] = kk == 0 ? x * y : kk == 1 ? y * y : 0.f;
-    }
-    {   // per-pixel constants: lane q <-> pixel (q & 7, q >> 3) of the wave's block
-        const int px = bx + (lane & 7), py = by + (lane >> 3);
-        const size_t HW = (size_t)A.H * A.W;
-        const bool inside = (px < A.W) && (py < A.H);
-        const size_t pix = (size_t)A.W * (size_t)py + px;
-        const float Tf = inside ? A.final_T[pix] : 0.f;
-        const int last = inside ? A.ncontrib[pix] : 0;
-        const float gz = (inside && A.sdl1) ? A.sdl1[pix] : 0.f;      // dL_dout of the depth set (one channel)
-        float bg2 = 0.f;
-        float *g = s_g[w] + lane * GST;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const float v = (inside && k < cn) ? A.sdl2[(size_t)k * HW + pix] : 0.f;
-            g[k] = v;
-            bg2 += A.s2bg * v;
-        }
-        float *r = s_state[w] + lane * PS;
-        r[0] = 0.f; r[1] = 0.f;
-        r[2] = __int_as_float(last);
-        r[3] = gz;
-        r[4] = Tf;            // T_state
-        r[5] = Tf * (A.s1bg * gz); r[6] = Tf * bg2; r[7] = 0.f;   // R_state of the depth set, of the attribute set: from the background
-        const int wmax = wave_max_i(last);
-        if (lane == 0) s_wmax[w] = wmax;
-    }
-    if (tid < Cfg::RQL) L.rec[SB * Cfg::RQL + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert slot SB (opacity 0: alpha 0)
-    if (lane < NC) s_acc[w][CAP * NC + lane] = 0.f;   // the slab's zero row
-    __syncthreads();
-    const int2 range = A.tile_range[tile];
-    const int len = range.y - range.x;
-    const int n = imin_(len, imax_(imax_(s_wmax[0], s_wmax[1]), imax_(s_wmax[2], s_wmax[3])));
-    const int *slots = A.slot_sorted + range.x;
-    const int TPR = (NC + 2) / 3, EPI = 256 / TPR;   // combine: TPR threads per record, three floats each
-    const int ce = tid / TPR, cc = tid - ce * TPR;
-    auto store_part = [&](int slot, float v0, float v1, float v2) {
-        float *dst = pair_buf + (size_t)slot * RST + 3 * cc;
-        if (3 * cc + 2 < NC) {
-            F3 t; t.x = v0; t.y = v1; t.z = v2;
-            *reinterpret_cast<F3 *>(dst) = t;
-        } else {
-            if (3 * cc < NC) dst[0] = v0;
-            if (3 * cc + 1 < NC) dst[1] = v1;
-        }
-    };
-    if (ce < EPI)
-        for (int ql = n + ce; ql < len; ql += EPI)   // entries nobody replays: zero record (this pass's part)
-            store_part(slots[ql], 0.f, 0.f, 0.f);
-    float *state = s_state[w] + 4 * kk * PS;         // own pixel of step (G, i): state + (16 G + i) * PS
-    const float *gown = s_g[w] + 4 * kk * GST + nl;   // own pixel of step (G, i), slot 16 q + nl: gown + (16 G + i) * GST + 16 q
-    const float *gcol = s_g[w] + nl * GST + kk;       // pixel nl of strip G, slot 4 j + kk: gcol + 16 G * GST + 4 j
-    const float *momrow = s_mom + 4 * kk * 9 + mtype; // own pixel of step (G, i): momrow + (16 G + i) * 9
-    if (n <= 0) {
-        if (A.dbg_T_front) {
-            const int px = bx + (lane & 7), py = by + (lane >> 3);
-            if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][lane * PS + 4];
-        }
-        return;
-    }
-    const int fcnt[NA] = {cn - 4 * kk, cn - 16 - 4 * kk};   // real channels among this lane's feature-gradient rows 16 q + 4 kk + i
-
-    auto pos = [n](int e, int b) { return n - 1 - b * SB - e; };
-    Stager<CH, SB> st;
-    st.load_ids(A, tid, range.x, pos, 0);
-    st.load_payload(A, tid);
-    st.load_ids(A, tid, range.x, pos, 1);
-    auto load_flags = [&](int topb) -> unsigned {
-        const int q = topb - tid;
-        return (A.cull_flags && tid < SB && q >= 0) ? (unsigned)A.cull_flags[range.x + q] : 0u;
-    };
-    unsigned fl_next = load_flags(n - 1);
-
-    int batch = 0;
-    for (int top = n - 1; top >= 0; top -= SB, ++batch) {
-        const int nb = imin_(SB, top + 1);
-        st.park(L, tid);
-        const unsigned fl = fl_next;
-        fl_next = load_flags(top - SB);
-        if (A.cull_flags) {
-            keep_from_flags(L, tid, nb, fl, [&](int e, int ww) { return top - e < s_wmax[ww]; });
-        } else {
-            __syncthreads();
-            tile_cull<CH, SB, false, false, false>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE),
-                                                   [&](int e, int ww) { return top - e < s_wmax[ww]; });
-        }
-        __syncthreads();
-        const int cnt = build_list_at(L, CL, w, lane, 0);
-        float *slab = s_acc[w];
-        int sl[3];
-        for (int p0 = 0;; p0 += CAP) {
-        const int p1 = imin_(cnt, p0 + CAP);
-        for (int j0 = p0; j0 < p1; j0 += 16) {
-            const int e = L.list[w][j0 + nl];
-            const float4 g0 = L.g0(e), g1 = L.g1(e);
-            const float cA = g0.z, cB = g0.w, cC = g1.x, o = g1.y, dz = g1.z;   // dz: the splat's depth feature
-            const float uc = g0.x - bx0 - 3.5f, vc = g0.y - by0 - 3.5f;
-            const int qn = top - e;
-            float bq1, bq2, bf[NK];
-            {
-                const PowerCoef pc = power_coeffs(g0.x, g0.y, cA, cB, cC, o, tcx, tcy);
-                bq1 = kk == 0 ? pc.q0 : kk == 1 ? pc.qx : kk == 2 ? pc.qy : pc.qxx;
-                bq2 = kk == 0 ? pc.qxy : kk == 1 ? pc.qyy : 0.f;
-#pragma unroll
-                for (int j = 0; j < NK; ++j) bf[j] = reinterpret_cast<const float *>(&L.rec[L.part(e, 2 + j)])[kk];
-            }
-            f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
-            f32x4 d_f[NA];
-#pragma unroll
-            for (int a = 0; a < NA; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-            float s_op = 0.f, s_dz = 0.f;
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int G = 0; G < 4; ++G) {
-                // the strip's matrix operands of dL_dout out of LDS up front (13 loads in flight while the power product runs): a
-                // load right in front of every MFMA left the wave waiting for LDS 52 times per chunk
-                float opc[NK], opf[4][NA];
-#pragma unroll
-                for (int j = 0; j < NK; ++j) opc[j] = gcol[16 * G * GST + 4 * j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int q = 0; q < NA; ++q) opf[i][q] = gown[(16 * G + i) * GST + 16 * q];
-                f32x4 pw = {0.f, 0.f, 0.f, 0.f}, cv2 = {0.f, 0.f, 0.f, 0.f};
-                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi1[G], bq1, pw, 0, 0, 0);
-                pw = __builtin_amdgcn_mfma_f32_16x16x4f32(phi2[G], bq2, pw, 0, 0, 0);
-                asm volatile("" ::: "memory");   // (keeps the loads above the power product)
-#pragma unroll
-                for (int j = 0; j < NK; ++j) cv2 = __builtin_amdgcn_mfma_f32_16x16x4f32(opc[j], bf[j], cv2, 0, 0, 0);
-                float araw[4], a[4], r1a[4], rp[4], Ts4[4], R1s[4], R2s[4], gz[4];
-                bool ok[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float2 sa = *reinterpret_cast<const float2 *>(state + (16 * G + i) * PS + 2);
-                    const float4 sb = *reinterpret_cast<const float4 *>(state + (16 * G + i) * PS + 4);
-                    const int last = __float_as_int(sa.x);
-                    gz[i] = sa.y;
-                    Ts4[i] = sb.x; R1s[i] = sb.y; R2s[i] = sb.z;
-                    bool pw_ok;
-                    araw[i] = exp2_guard(pw[i], pw_ok);
-                    ok[i] = (qn < last) && pw_ok && !(araw[i] < (1.0f / 255.0f));
-                    araw[i] = ok[i] ? araw[i] : 0.f;
-                    a[i] = fminf(0.99f, araw[i]);
-                    r1a[i] = __builtin_amdgcn_rcpf(1.f - a[i]);
-                    rp[i] = r1a[i];
-                }
-                row_scan_mul4(rp[0], rp[1], rp[2], rp[3]);
-                float T[4], wgt[4], rs1[4], rs2[4], R1[4], R2[4], cg1[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    T[i] = Ts4[i] * rp[i];
-                    wgt[i] = a[i] * T[i];
-                    cg1[i] = gz[i] * dz;            // colour dot product of the one-channel depth set
-                    rs1[i] = cg1[i] * wgt[i];
-                    rs2[i] = cv2[i] * wgt[i];
-                }
-                row_scan_add4(rs1[0], rs1[1], rs1[2], rs1[3]);
-                row_shr1_add4(R1, rs1, R1s);
-                row_scan_add4(rs2[0], rs2[1], rs2[2], rs2[3]);
-                row_shr1_add4(R2, rs2, R2s);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    lds_store2_lane15(state + (16 * G + i) * PS + 4, T[i], R1s[i] + rs1[i]);
-                    lds_store2_lane15(state + (16 * G + i) * PS + 6, R2s[i] + rs2[i], 0.f);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float dLa1 = T[i] * cg1[i] - R1[i] * r1a[i];   // (R includes the set's background term)
-                    const float dLa2 = T[i] * cv2[i] - R2[i] * r1a[i];
-                    const float dLp_op = araw[i] * dLa1;             // the depth set is blended with the live opacity
-                    const float dLp = araw[i] * (dLa1 + dLa2);
-                    d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[(16 * G + i) * 9], dLp, d_mom, 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < NA; ++q)   // A[m = slot 16 q + nl][k = own pixel]: slots >= 20 read the next pixel's row: their
-                        d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(opf[i][q], wgt[i], d_f[q], 0, 0, 0);   // rows are never stored
-                    s_op += dLp_op;
-                    s_dz = __builtin_fmaf(gz[i], wgt[i], s_dz);      // dL/d(depth feature) = sum_p g[p] w[p]
-                }
-            }
-            s_op = rows_sum(s_op, lane);
-            s_dz = rows_sum(s_dz, lane);
-            if (j0 + nl < cnt) {
-                float *rec = slab + (j0 + nl - p0) * NC;
-                const float D0 = d_mom[0];
-                if (kk == 0) {
-                    const float Dx = d_mom[1], Dy = d_mom[2], Dxx = d_mom[3];
-                    rec[0] = cA * Dx + cB * Dy - (cA * uc + cB * vc) * D0;
-                    rec[1] = cB * Dx + cC * Dy - (cB * uc + cC * vc) * D0;
-                    rec[2] = -0.5f * (uc * uc * D0 - 2.f * uc * Dx + Dxx);
-                    rec[5] = o > 0.f ? s_op / o : 0.f;
-                } else if (kk == 1) {
-                    const float Dx = d_mom[1], Dy = d_mom[2], Dxy = d_mom[3];
-                    rec[3] = -(uc * vc * D0 - uc * Dy - vc * Dx + Dxy);
-                } else if (kk == 2) {
-                    const float Dy = d_mom[1], Dyy = d_mom[2];
-                    rec[4] = -0.5f * (vc * vc * D0 - 2.f * vc * Dy + Dyy);
-                } else {
-                    rec[6] = s_dz;
-                }
-#pragma unroll
-                for (int q = 0; q < NA; ++q)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (i < fcnt[q]) rec[NG + 16 * q + 4 * kk + i] = d_f[q][i];
-            }
-        }
-        if (lane == 0) CL.more[w] = cnt > p0 + CAP;
-        if (p0 == 0) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int ql = ce + r * EPI;
-                sl[r] = (ce < EPI && ql < nb) ? slots[top - nb + 1 + ql] : 0;
-            }
-            st.load_payload(A, tid);
-            st.load_ids(A, tid, range.x, pos, batch + 2);
-        }
-        __syncthreads();
-        if (ce < EPI) {
-            const int lo = top - nb + 1;
-            int r = 0;
-            for (int ql = ce; ql < nb; ql += EPI, ++r) {
-                const unsigned int p4 = CL.pos4[nb - 1 - ql];
-                float v[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ww = 0; ww < 4; ++ww) {
-                    const unsigned int pp = umin_(((p4 >> (8 * ww)) & 0xffu) - (unsigned)p0, (unsigned)CAP);
-                    const float *row = s_acc[ww] + pp * NC + 3 * cc;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (3 * cc + j < NC) v[j] += row[j];
-                }
-                const int slot = r == 0 ? sl[0] : r == 1 ? sl[1] : r == 2 ? sl[2] : slots[lo + ql];
-                if (p0 > 0) {
-                    const float *old = pair_buf + (size_t)slot * RST + 3 * cc;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (3 * cc + j < NC) v[j] += old[j];
-                }
-                store_part(slot, v[0], v[1], v[2]);
-            }
-        }
-        const bool more = CL.more[0] | CL.more[1] | CL.more[2] | CL.more[3];
-        __syncthreads();
-        if (!more) break;
-        }
-    }
-    if (A.dbg_T_front) {
-        const int px = bx + (lane & 7), py = by + (lane >> 3);
-        if (px < A.W && py < A.H) A.dbg_T_front[(size_t)A.W * py + px] = s_state[w][lane * PS + 4];
-    }
-}
-
 // ------------------------------------------------------------------ backward, atomic mode (foreign idx_sorted)
 // Same tile structure; every wave reduces its partials and lane 63 issues one hardware float atomic
 // per (wave, splat, component).  Gradient outputs must be zero-initialised.
@@ -4440,6 +4088,11 @@ static int blend_backward_impl(int P, int C, const float *uv, const float *conic
     const int npm = (goff_incl != nullptr) + (slot_sorted != nullptr) + (pair_scratch != nullptr);
     SPLAT_CHECK_ARG(npm == 0 || npm == 3, "goff_incl, slot_sorted and pair_scratch go together");
     const bool pair_mode = npm == 3;
+    if (!pair_mode && splat_deterministic()) {   // refused BEFORE any launch (the packing kernel used to run first)
+        splat_set_error("deterministic mode: the backward needs this library's pair map (goff_incl, slot_sorted, pair_scratch); "
+                        "a foreign idx_sorted would take the float-atomic kernel");
+        return SPLAT_E_ARG;
+    }
     SPLAT_CHECK_ARG(pair_mode || (!dL_dndc && !dL_dabs_ndc), "the tap outputs need the pair-mode backward");
     SPLAT_CHECK_ARG(!dL_dabs_ndc || dL_dabs_uv, "dL_dabs_ndc needs dL_dabs_uv");
     BlendArgs A;
@@ -4876,83 +4529,5 @@ extern "C" int splat_pair_records_segment_sum(int P, int ncp, const float *pair_
     SPLAT_LAUNCH("pair_reduce", records_segment_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                  P, nq, (const float4 *)pair_records, goff_incl, (float4 *)out);
     SPLAT_POST_LAUNCH();
-    return SPLAT_OK;
-}
-
-// The renderer's three blends backward in TWO tile passes that share one pair record (see blend_bwd_attr_kernel): the tap set
-// (<= 3 channels; taps and |taps| always produced) through the narrow matrix-core kernel, then the depth set (the per-frame depth
-// feature [F,P], live opacity) + the detached attribute set (<= 20 channels) through blend_bwd_attr_kernel.  set_bg: HOST
-// array (tap, depth, attribute backgrounds).  pair_records: F * capacity * splat_blend_sets2_pair_stride() floats, layout
-//   [ux uy ca cb | cc o ax ay | f0 f1 f2 . || ux uy ca cb | cc o dz a0 | a1 .. a19 ..]
-// (reduce them with splat_frames_gauss_backward_*_sets2); pack_a: F * P * splat_blend_pack_floats(tap_cn) floats,
-// pack_b: F * P * splat_blend_sets2_pack_floats() floats.
-extern "C" size_t splat_blend_sets2_pair_stride(void) { return (size_t)AttrCfg::REC_STRIDE; }
-extern "C" size_t splat_blend_sets2_pack_floats(void) { return (size_t)Rec<AttrCfg::CH>::RS; }
-
-extern "C" int splat_alpha_blending_backward_batch_sets2(int F, int P, int tap_cn, int attr_cn, const float *set_bg,
-                                                         const float *uv, const float *conic, const float *opacity,
-                                                         int64_t opacity_frame_stride, const float *tap_feature,
-                                                         int64_t tap_feature_fs, const float *depth_feature,
-                                                         const float *attr_feature, int64_t attr_feature_fs,
-                                                         const int32_t *idx_sorted, const int32_t *tile_range,
-                                                         int64_t capacity, int W, int H, const float *final_T,
-                                                         const int32_t *ncontrib, const float *dL_tap, const float *dL_depth,
-                                                         const float *dL_attr, const int32_t *slot_sorted,
-                                                         float *pair_records, float *pack_a, float *pack_b,
-                                                         const uint32_t *cull_flags, float *dbg_T_front,
-                                                         splat_stream_t stream) {
-    SPLAT_CHECK_ARG(F >= 1 && P >= 1 && W > 0 && H > 0 && capacity >= 1, "bad sizes");
-    SPLAT_CHECK_ARG(tap_cn >= 1 && tap_cn <= 3 && attr_cn >= 1 && attr_cn <= AttrCfg::CH, "tap set: 1..3 channels, attribute set: 1..20");
-    SPLAT_CHECK_ARG(set_bg && uv && conic && opacity && tap_feature && depth_feature && attr_feature, "null input pointer");
-    SPLAT_CHECK_ARG(idx_sorted && tile_range && final_T && ncontrib && dL_tap && dL_depth && dL_attr && slot_sorted, "null pointer");
-    SPLAT_CHECK_ARG(pair_records && pack_a && pack_b, "null scratch pointer");
-    hipStream_t s = (hipStream_t)stream;
-    const int gx = (W + TILE - 1) / TILE, T = gx * ((H + TILE - 1) / TILE);
-    SPLAT_CHECK_ARG((long long)F * T < (1ll << 31), "too many tiles");
-    {   // ---- pass A: the tap set, narrow matrix-core kernel (abs sums on), floats [0, 12) of the shared record
-        BlendArgs A;
-        memset(&A, 0, sizeof(A));
-        A.P = P; A.C = tap_cn;
-        A.uv = (const float2 *)uv; A.conic = conic; A.opacity = opacity; A.feature = tap_feature;
-        A.idx_sorted = idx_sorted; A.tile_range = (const int2 *)tile_range;
-        A.bg = set_bg[0]; A.W = W; A.H = H; A.gx = gx;
-        A.final_T = const_cast<float *>(final_T); A.ncontrib = const_cast<int *>(ncontrib);
-        A.dL_dout = dL_tap;
-        A.slot_sorted = slot_sorted; A.pair_buf = pair_records;
-        A.pack = pack_a; A.pack_valid = 0;
-        A.dbg_T_front = dbg_T_front;
-        A.cull_flags = const_cast<uint32_t *>(cull_flags);
-        A.F = F; A.T = T; A.cap = capacity; A.tile_only = 1;
-        A.pack_fs = (long long)P * (long long)splat_blend_pack_floats(tap_cn);
-        A.opacity_fs = opacity_frame_stride; A.feature_fs = tap_feature_fs;
-        A.c0 = 0; A.cn = tap_cn;
-        A.dL_dabs_uv = pair_records;   // marker: abs sums wanted
-        A.rec_stride = AttrCfg::REC_STRIDE; A.rec_off = 0;
-        const int rc = bwd_chunk(A, T, false, true, s);
-        if (rc != SPLAT_OK) return rc;
-    }
-    {   // ---- pass B: depth + attributes, floats [12, 12 + 7 + attr_cn)
-        BlendArgs A;
-        memset(&A, 0, sizeof(A));
-        A.P = P; A.C = attr_cn;
-        A.uv = (const float2 *)uv; A.conic = conic; A.opacity = opacity;
-        A.idx_sorted = idx_sorted; A.tile_range = (const int2 *)tile_range;
-        A.W = W; A.H = H; A.gx = gx;
-        A.final_T = const_cast<float *>(final_T); A.ncontrib = const_cast<int *>(ncontrib);
-        A.slot_sorted = slot_sorted; A.pair_buf = pair_records;
-        A.pack = pack_b;
-        A.dbg_T_front = dbg_T_front;
-        A.cull_flags = const_cast<uint32_t *>(cull_flags);
-        A.F = F; A.T = T; A.cap = capacity; A.tile_only = 1;
-        A.pack_fs = (long long)P * (long long)Rec<AttrCfg::CH>::RS;
-        A.opacity_fs = opacity_frame_stride;
-        A.s1cn = 1; A.s1bg = set_bg[1]; A.sf1 = depth_feature; A.sfs1 = P; A.sdl1 = dL_depth;
-        A.s2cn = attr_cn; A.s2bg = set_bg[2]; A.sf2 = attr_feature; A.sfs2 = attr_feature_fs; A.sdl2 = dL_attr;
-        A.rec_stride = AttrCfg::REC_STRIDE; A.rec_off = AttrCfg::REC_A;
-        SPLAT_LAUNCH("attr_pack", pack_attr_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)F), dim3(256), 0, s, A);
-        SPLAT_POST_LAUNCH();
-        SPLAT_LAUNCH("attr_bwd", blend_bwd_attr_kernel, dim3((unsigned)(T * F)), dim3(256), 0, s, A);
-        SPLAT_POST_LAUNCH();
-    }
     return SPLAT_OK;
 }

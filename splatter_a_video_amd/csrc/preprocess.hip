@@ -372,41 +372,6 @@ struct GaussBwdArgs {
     long long sfs[SPLAT_MAX_SOURCES];
 };
 
-// SETS2 records (splat_alpha_blending_backward_batch_sets2, 40 floats):
-//   [A: ux uy ca cb | cc o ax ay | f0 f1 f2 . || B: ux uy ca cb | cc o dz a0 | a1 .. a19 ..]     A = tap set, B = depth + attributes
-// chunk c (4 floats) of the quad's sum sits in lane c & 3, register a[c >> 2]: A = chunks 0-2 (lanes 0-2, a[0]), B's geometry =
-// chunks 3, 4 (lane 3 a[0], lane 0 a[1]).  d uv / d conic = A + B, d opacity = A.o + B.o (B.o: the depth set only), taps /
-// |taps| = A alone, dz = dL/ddepth of the projection.
-struct S2Geo {
-    float ux, uy, ca, cb, cc, dop, tu, tv, ax, ay, gdep;
-};
-template <int NS>
-__device__ __forceinline__ S2Geo s2_geometry(const float4 (&a)[NS]) {
-    S2Geo g;
-    constexpr int I1 = NS > 1 ? 1 : 0;   // (SETS2 records have NS = 3; other instantiations never run this)
-    g.tu = quad_bcast<0>(a[0].x); g.tv = quad_bcast<0>(a[0].y);
-    g.ux = g.tu + quad_bcast<3>(a[0].x); g.uy = g.tv + quad_bcast<3>(a[0].y);
-    g.ca = quad_bcast<0>(a[0].z) + quad_bcast<3>(a[0].z);
-    g.cb = quad_bcast<0>(a[0].w) + quad_bcast<3>(a[0].w);
-    g.cc = quad_bcast<1>(a[0].x) + quad_bcast<0>(a[I1].x);
-    g.dop = quad_bcast<1>(a[0].y) + quad_bcast<0>(a[I1].y);
-    g.ax = quad_bcast<1>(a[0].z); g.ay = quad_bcast<1>(a[0].w);
-    g.gdep = quad_bcast<0>(a[I1].z);
-    return g;
-}
-// feature gradients of a SETS2 record: component k -> (set 0 channel k - 8 | set 2 channel k - 19), added into the sets' rows
-__device__ __forceinline__ void s2_put_feature(int k, float v, size_t n, const int (&scn)[SPLAT_MAX_SOURCES],
-                                               float *const (&sdf)[SPLAT_MAX_SOURCES], const int (&sstride)[SPLAT_MAX_SOURCES],
-                                               bool acc) {
-    if (k >= 8 && k < 8 + scn[0] && sdf[0]) {
-        float *p = sdf[0] + n * sstride[0] + (k - 8);
-        *p = acc ? *p + v : v;
-    } else if (k >= 19 && k < 19 + scn[2] && sdf[2]) {
-        float *p = sdf[2] + n * sstride[2] + (k - 19);
-        *p = acc ? *p + v : v;
-    }
-}
-
 // component k of the quad's record sum (chunk k / 4 = lane (k / 4) & 3, register a[k / 16], element k & 3) on every lane
 template <int NS>
 __device__ __forceinline__ float record_component(const float4 (&a)[NS], int k, int sub) {
@@ -426,10 +391,9 @@ __device__ __forceinline__ float record_component(const float4 (&a)[NS], int k, 
 // differ from frame to frame, 2 = perspective (its Jacobian depends on the point, hence on the frame's offset): the records
 // of every frame go through that frame's projection / EWA backward; only dL/dcov3d (linear into scale / rotation) is summed
 // over the frames first.
-template <bool ABS, int NCP, bool SETS = false, int CAM = 0, bool S2 = false>
+template <bool ABS, int NCP, bool SETS = false, int CAM = 0>
 __global__ void __launch_bounds__(256)
 frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
-    static_assert(!S2 || (NCP == 40 && SETS && ABS), "SETS2 records: 40 floats, abs sums present");
     constexpr int NG = SETS ? SETS_NG : GradLayout<ABS, false>::NG;
     constexpr int NQ = NCP / 4, NS = (NQ + 3) / 4;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -569,11 +533,7 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
             if (end > beg) {  // a record exists: visible with radius > 0 in this frame (the chain's preconditions)
                 float ux = quad_bcast<0>(a[0].x), uy = quad_bcast<0>(a[0].y);
                 float g3[3] = {quad_bcast<0>(a[0].z), quad_bcast<0>(a[0].w), quad_bcast<1>(a[0].x)};
-                float gdep = (!S2 && A.depth_channel >= 0) ? record_component<NS>(a, NG + A.depth_channel, sub) : 0.f;
-                if (S2) {
-                    const S2Geo sg = s2_geometry<NS>(a);
-                    ux = sg.ux; uy = sg.uy; g3[0] = sg.ca; g3[1] = sg.cb; g3[2] = sg.cc; gdep = sg.gdep;
-                }
+                const float gdep = A.depth_channel >= 0 ? record_component<NS>(a, NG + A.depth_channel, sub) : 0.f;
                 Cam c;
                 load_cam(CAM == 2 ? A.intr + (size_t)f * A.intr_fs : nullptr, A.extr + (size_t)f * A.extr_fs, c);
                 float p[3] = {A.xyz[3 * i], A.xyz[3 * i + 1], A.xyz[3 * i + 2]};
@@ -612,12 +572,7 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
     float g3[3] = {quad_bcast<0>(a[0].z), quad_bcast<0>(a[0].w), quad_bcast<1>(a[0].x)};
     float dop = quad_bcast<1>(a[0].y);
     // dL/ddepth (a set whose channel `depth_channel` is the depth feature): component NG + channel
-    float gdep = (!S2 && CAM == 0 && A.depth_channel >= 0) ? record_component<NS>(a, NG + A.depth_channel, sub) : 0.f;
-    S2Geo sg;
-    if (S2) {
-        sg = s2_geometry<NS>(a);
-        ux = sg.ux; uy = sg.uy; g3[0] = sg.ca; g3[1] = sg.cb; g3[2] = sg.cc; dop = sg.dop; gdep = sg.gdep;
-    }
+    const float gdep = (CAM == 0 && A.depth_channel >= 0) ? record_component<NS>(a, NG + A.depth_channel, sub) : 0.f;
     float gp[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
     if (CAM > 0) {
         gp[0] = gpf[0]; gp[1] = gpf[1]; gp[2] = gpf[2];
@@ -656,7 +611,7 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
         for (int k = 0; k < 4; ++k) put1(A.d_uquats + 4 * i + k, dq[k]);
     }
     {   // densification tap: d uv of the whole blend -- SETS records: of the tap set alone (components 8, 9 = chunk 2)
-        const float tu = S2 ? sg.tu : SETS ? quad_bcast<2>(a[0].x) : ux, tv = S2 ? sg.tv : SETS ? quad_bcast<2>(a[0].y) : uy;
+        const float tu = SETS ? quad_bcast<2>(a[0].x) : ux, tv = SETS ? quad_bcast<2>(a[0].y) : uy;
         if (sub == 3 && A.tap) {
             A.tap[2 * i] = tu * (0.5f * (float)A.W);
             A.tap[2 * i + 1] = tv * (0.5f * (float)A.H);
@@ -670,7 +625,7 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
         }
     }
     // features: component k of the record lives in chunk k / 4 = lane (k / 4) & 3, register a[k / 16]
-    if (SETS && !S2) {   // routed by source (a uniform loop over the table; the component tests are per lane)
+    if (SETS) {   // routed by source (a uniform loop over the table; the component tests are per lane)
         for (int g = 0; g < A.nsrc; ++g) {
             float *df = A.sdf[g];
             if (!df) continue;
@@ -697,9 +652,7 @@ frames_gauss_bwd_static_kernel(const GaussBwdArgs A) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ch = k0 + e - NG;
-                if (S2) {
-                    s2_put_feature(k0 + e, v[e], (size_t)i, A.scn, A.sdf, A.sstride, acc);
-                } else if (ch >= 0 && ch < A.cn && ch != A.depth_channel && A.d_feature) {
+                if (ch >= 0 && ch < A.cn && ch != A.depth_channel && A.d_feature) {
                     put1(A.d_feature + (size_t)i * A.C + ch, v[e]);
                 }
             }
@@ -798,10 +751,9 @@ struct GaussDynArgs {
 };
 
 // PF: the row has per-frame sources (A.npf > 0) -- its own instantiation: their block costs the walk ten registers
-template <bool ABS, int NCP, bool SETS = false, bool S2 = false, bool PF = false>
+template <bool ABS, int NCP, bool SETS = false, bool PF = false>
 __global__ void __launch_bounds__(256, GAUSS_DYN_MINW)
 frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
-    static_assert(!S2 || (NCP == 40 && SETS && ABS), "SETS2 records: 40 floats, abs sums present");
     constexpr int NG = SETS ? SETS_NG : GradLayout<ABS, false>::NG;
     constexpr int NQ = NCP / 4, NS = (NQ + 3) / 4;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -906,7 +858,7 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
             for (int c = 0; c < NS; ++c) {
                 atot[c].x += af[c].x; atot[c].y += af[c].y; atot[c].z += af[c].z; atot[c].w += af[c].w;
             }
-            if (SETS && !S2 && PF) {
+            if (SETS && PF) {
                 // per-frame sources (track_gs = position(ids2), src/trainer_fragGS.py:506-511): THIS frame's gradient of their
                 // channels goes to the frame's own rows; the lane that holds a component adds it (a quad owns its Gaussian)
                 for (int g = 0; g < A.nsrc; ++g) {
@@ -929,20 +881,13 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
             float ux = quad_bcast<0>(af[0].x), uy = quad_bcast<0>(af[0].y);
             float ga = quad_bcast<0>(af[0].z), gb = quad_bcast<0>(af[0].w), gc = quad_bcast<1>(af[0].x);
             float gdep = 0.f;  // SETS: the frame's gradient of the depth channel = dL/ddepth of the projection
-            if (S2) {
-                const S2Geo sg = s2_geometry<NS>(af);
-                ux = sg.ux; uy = sg.uy; ga = sg.ca; gb = sg.cb; gc = sg.cc; gdep = sg.gdep;
-                tap_u += sg.tu; tap_v += sg.tv;
-                atap_u += sg.ax; atap_v += sg.ay;
-            } else {
             // densification taps: d uv of the whole blend -- SETS records: of the tap set alone (components 8, 9 = chunk 2)
             tap_u += SETS ? quad_bcast<2>(af[0].x) : ux;
             tap_v += SETS ? quad_bcast<2>(af[0].y) : uy;
             if (ABS) {
                 atap_u += quad_bcast<1>(af[0].z); atap_v += quad_bcast<1>(af[0].w);
             }
-            }
-            if (!S2 && SETS && A.depth_channel >= 0) {
+            if (SETS && A.depth_channel >= 0) {
                 const int kd = NG + A.depth_channel;  // chunk kd / 4 -> lane (kd / 4) & 3, register af[kd / 16], element kd & 3
                 float v = 0.f;
 #pragma unroll
@@ -1012,7 +957,7 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
         if (A.d_scaling) A.d_scaling[(size_t)n * 3 + j] += d_scl;
     }
     if (A.d_rotation) A.d_rotation[(size_t)n * 4 + j] += d_rot;
-    const float dop = S2 ? quad_bcast<1>(atot[0].y) + quad_bcast<0>(atot[1].y) : quad_bcast<1>(atot[0].y);
+    const float dop = quad_bcast<1>(atot[0].y);
     if (j == 3) {
         if (A.d_opacity) {
             const float s = 1.0f / (1.0f + expf(-A.opacity[n]));
@@ -1028,7 +973,7 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
         }
     }
     if (j == 0 && A.radii_max) A.radii_max[n] = rmax;
-    if (SETS && !S2) {   // shared sources: the sum over the frames (per-frame sources were written frame by frame)
+    if (SETS) {   // shared sources: the sum over the frames (per-frame sources were written frame by frame)
         for (int g = 0; g < A.nsrc; ++g) {
             float *df = A.sdf[g];
             if (!df || A.sfs[g] != 0) continue;
@@ -1055,9 +1000,7 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ch = k0 + e - NG;
-                if (S2) {
-                    s2_put_feature(k0 + e, v[e], (size_t)n, A.scn, A.sdf, A.sstride, true);
-                } else if (ch >= 0 && ch < A.cn && A.d_feature) {
+                if (ch >= 0 && ch < A.cn && A.d_feature) {
                     A.d_feature[(size_t)n * A.C + ch] += v[e];
                 }
             }
@@ -1093,12 +1036,7 @@ int launch_gauss_bwd_static(const GaussBwdArgs &A, int ncp, hipStream_t s) {
 
 int launch_gauss_bwd_dynamic_sets(const GaussDynArgs &A, int ncp, hipStream_t s) {
     const dim3 grid((unsigned)(((size_t)A.P * 4 + 255) / 256)), block(256);
-    if (ncp == -40) {   // SETS2 records
-        SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_dynamic_kernel<true, 40, true, true>), grid, block, 0, s, A);
-        SPLAT_POST_LAUNCH();
-        return SPLAT_OK;
-    }
-#define GDS(N) case N: if (A.npf > 0) SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_dynamic_kernel<true, N, true, false, true>), grid, block, 0, s, A); \
+#define GDS(N) case N: if (A.npf > 0) SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_dynamic_kernel<true, N, true, true>), grid, block, 0, s, A); \
                     else SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_dynamic_kernel<true, N, true>), grid, block, 0, s, A); break
     switch (ncp) {
         GDS(12); GDS(16); GDS(20); GDS(24); GDS(28); GDS(32); GDS(36); GDS(40);
@@ -1112,11 +1050,6 @@ int launch_gauss_bwd_dynamic_sets(const GaussDynArgs &A, int ncp, hipStream_t s)
 template <int CAM = 0>
 int launch_gauss_bwd_static_sets(const GaussBwdArgs &A, int ncp, hipStream_t s) {
     const dim3 grid((unsigned)(((size_t)A.P * 4 + 255) / 256)), block(256);
-    if (ncp == -40) {   // SETS2 records
-        SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_static_kernel<true, 40, true, CAM, true>), grid, block, 0, s, A);
-        SPLAT_POST_LAUNCH();
-        return SPLAT_OK;
-    }
 #define GS(N) case N: SPLAT_LAUNCH("gauss_bwd", (frames_gauss_bwd_static_kernel<true, N, true, CAM>), grid, block, 0, s, A); break
     switch (ncp) {
         GS(12); GS(16); GS(20); GS(24); GS(28); GS(32); GS(36); GS(40);
@@ -1177,12 +1110,7 @@ extern "C" int splat_frames_gauss_backward_static_sets(int F, int P, int C, int 
     float *const *set_dfeature, const int32_t *set_stride, int depth_channel, float *tap, float *abs_tap, int32_t *radii_max, void *stream
 #define STAT_SETS_ARGS F, P, C, W, H, capacity, pair_records, goff_incl, radius, xyz, scales, uquats, cam, accumulate, d_xyz, d_scales, \
     d_uquats, d_opacity, set_c0, set_cn, set_dfeature, set_stride, depth_channel, tap, abs_tap, radii_max, stream
-static int gauss_backward_static_sets_impl(int sets2, STAT_SETS_PARAMS);
-extern "C" int splat_frames_gauss_backward_static_sets_cam(STAT_SETS_PARAMS) { return gauss_backward_static_sets_impl(0, STAT_SETS_ARGS); }
-// the same over the SETS2 records of splat_alpha_blending_backward_batch_sets2 (fixed layout: set 0 = tap, 1 = depth, 2 = attributes)
-extern "C" int splat_frames_gauss_backward_static_sets2_cam(STAT_SETS_PARAMS) { return gauss_backward_static_sets_impl(1, STAT_SETS_ARGS); }
-
-static int gauss_backward_static_sets_impl(int sets2, STAT_SETS_PARAMS) {
+extern "C" int splat_frames_gauss_backward_static_sets_cam(STAT_SETS_PARAMS) {
     SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= 28 && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 28)");
     SPLAT_CHECK_ARG(pair_records && goff_incl && xyz && scales && uquats && cam, "null input pointer");
     SPLAT_CHECK_ARG(d_xyz && d_scales && d_uquats && d_opacity, "null gradient pointer");
@@ -1204,7 +1132,7 @@ static int gauss_backward_static_sets_impl(int sets2, STAT_SETS_PARAMS) {
         A.sc0[g] = set_c0[g]; A.scn[g] = set_cn[g]; A.sstride[g] = set_stride[g]; A.sdf[g] = set_dfeature[g];
         SPLAT_CHECK_ARG(set_cn[g] == 0 || !set_dfeature[g] || set_stride[g] >= set_cn[g], "feature stride below the set width");
     }
-    const int ncp = sets2 ? -40 : (int)splat_blend_sets_pair_stride(C);
+    const int ncp = (int)splat_blend_sets_pair_stride(C);
     return mode == 0 ? launch_gauss_bwd_static_sets<0>(A, ncp, (hipStream_t)stream)
          : mode == 1 ? launch_gauss_bwd_static_sets<1>(A, ncp, (hipStream_t)stream)
                      : launch_gauss_bwd_static_sets<2>(A, ncp, (hipStream_t)stream);
@@ -1562,7 +1490,7 @@ extern "C" int splat_frames_gauss_backward_dynamic(int F, int P, int I, int C, i
 // dynamic_gaussian_with_base_point_cloud.py getters + render_iter's three blends): splat_frames_gauss_backward_dynamic with
 // the SETS records -- taps from the tap set, per-set feature gradients (ADDED to set_dfeature[g], HOST array of three device
 // pointers), the row channel `depth_channel` (>= 0) is the per-frame depth and feeds the position through the projection.
-static int gauss_backward_dynamic_sets_impl(int sets2, int F, int P, int I, int C, int W, int H, int64_t capacity,
+static int gauss_backward_dynamic_sets_impl(int F, int P, int I, int C, int W, int H, int64_t capacity,
                                                         const float *pair_records, const int32_t *goff_incl,
                                                         const int32_t *radius, const void *tab, const float *position,
                                                         const float *cubic, int cubic_layout, const float *rotation,
@@ -1594,7 +1522,7 @@ static int gauss_backward_dynamic_sets_impl(int sets2, int F, int P, int I, int 
         A.sc0[g] = set_c0[g]; A.scn[g] = set_cn[g]; A.sstride[g] = set_stride[g]; A.sdf[g] = set_dfeature[g];
         SPLAT_CHECK_ARG(set_cn[g] == 0 || !set_dfeature[g] || set_stride[g] >= set_cn[g], "feature stride below the set width");
     }
-    return launch_gauss_bwd_dynamic_sets(A, sets2 ? -40 : (int)splat_blend_sets_pair_stride(C), (hipStream_t)stream);
+    return launch_gauss_bwd_dynamic_sets(A, (int)splat_blend_sets_pair_stride(C), (hipStream_t)stream);
 }
 
 // the same with the row described by feature SOURCES (include/splat_hip.h: splat_feature_source_t): shared sources receive the
@@ -1644,7 +1572,4 @@ extern "C" int splat_frames_gauss_backward_dynamic_sources(int F, int P, int I, 
 #define DYN_SETS_ARGS F, P, I, C, W, H, capacity, pair_records, goff_incl, radius, tab, position, cubic, cubic_layout, rotation, rot_poly, \
     rot_fourier, opacity, scaling, extr, d_position, d_cubic, d_rotation, d_opacity, d_scaling, set_c0, set_cn, set_dfeature, set_stride, \
     depth_channel, tap, abs_tap, radii_max, stream
-extern "C" int splat_frames_gauss_backward_dynamic_sets(DYN_SETS_PARAMS) { return gauss_backward_dynamic_sets_impl(0, DYN_SETS_ARGS); }
-// the same over the SETS2 records of splat_alpha_blending_backward_batch_sets2 (set 0 = the tap set, set 1 = the depth set --
-// its gradient feeds the position --, set 2 = the attribute set; set_c0 / depth_channel are not used: the layout is fixed)
-extern "C" int splat_frames_gauss_backward_dynamic_sets2(DYN_SETS_PARAMS) { return gauss_backward_dynamic_sets_impl(1, DYN_SETS_ARGS); }
+extern "C" int splat_frames_gauss_backward_dynamic_sets(DYN_SETS_PARAMS) { return gauss_backward_dynamic_sets_impl(DYN_SETS_ARGS); }

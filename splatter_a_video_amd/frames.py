@@ -109,8 +109,7 @@ class _Camera:
 
 
 # python-level switches of the multi-set paths (tests flip them; the library's own options: L.set_option)
-OPTIONS = {"sets_one_pass": os.environ.get("SPLAT_SETS_ONE_PASS", "1") != "0",
-           "sets_two_pass": os.environ.get("SPLAT_SETS_TWO_PASS", "0") == "1"}
+OPTIONS = {"sets_one_pass": os.environ.get("SPLAT_SETS_ONE_PASS", "1") != "0"}
 
 
 def _tiles(W: int, H: int) -> int:
@@ -123,7 +122,8 @@ class FrameBatch:
     (one host sync), afterwards the batch runs without any host synchronisation and ``check()`` (call it whenever the
     host synchronises anyway, e.g. once per optimiser step) raises if a frame outgrew it; without ``check()`` the next
     forward raises, a step or a few late (the flag travels to pinned host memory behind the binning kernels; the error is
-    raised once and the flag cleared, so batches that fit keep running afterwards)."""
+    raised once and the flag cleared, so batches that fit keep running afterwards).  An overflow of the LAST batches of a run
+    is only seen by ``check()``: call it after the final step."""
 
     def __init__(self, F: int, P: int, W: int, H: int, C: int, device, capacity: Optional[int] = None,
                  want_abs: bool = False, slack: float = 1.25):
@@ -223,9 +223,10 @@ class FrameBatch:
         if int(self._ovf_host[0]) != 0:
             self._ovf_host[0] = 0
             self.overflow.zero_()                   # stream-ordered behind the kernels that set it
-            raise L.SplatError(f"FrameBatch: an earlier batch held more tile-Gaussian pairs in one frame than the capacity "
-                               f"{self.capacity} (its surplus pairs were dropped: that batch's images and gradients were "
-                               "incomplete); build the batch with a larger `capacity` / `slack`")
+            raise L.SplatError(f"FrameBatch: a batch held more tile-Gaussian pairs in one frame than the capacity "
+                               f"{self.capacity} (its surplus pairs were dropped: images and gradients of that batch -- an earlier "
+                               "one, possibly also the one just enqueued: the flag is sticky -- were incomplete); build the batch "
+                               "with a larger `capacity` / `slack`")
 
     def _poll_overflow(self) -> None:
         """at the next forward, without a host synchronisation: raises if an earlier batch outgrew the capacity -- a caller
@@ -612,16 +613,10 @@ class _RenderDynamicSets(torch.autograd.Function):
             dfe.append(dfeat)
             dfs[group_of[si]], strides[group_of[si]] = dfeat, int(feats[fi].shape[1])
             fi += 1
-        two = _two_pass_ok(meta, widths)
-        if two:
-            rec = _blend_sets_backward_two_pass(fb, meta, ctx.blend, grads[:len(meta)], ctx.opa_t, 0)
-            want_abs = 1 if fb.want_abs else 0
-        else:
-            rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], ctx.opa_t, 0, want_abs)
+        rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], ctx.opa_t, 0, want_abs)
         i3 = ctypes.c_int32 * 3
         p3 = (ctypes.c_void_p * 3)(*[0 if d is None else d.data_ptr() for d in dfs])
-        gauss = lib.splat_frames_gauss_backward_dynamic_sets2 if two else lib.splat_frames_gauss_backward_dynamic_sets
-        L.check(gauss(
+        L.check(lib.splat_frames_gauss_backward_dynamic_sets(
             L.ci(F), L.ci(P), L.ci(I), L.ci(C), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ptr(rec), L.ptr(fb.goff), L.ptr(fb.radius),
             L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(layout), L.ptr(rotation), L.ptr(rot_poly), L.ptr(rot_fourier),
             L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c), L.ptr(bufs["position"]), L.ptr(bufs["pos_cubic_node"]),
@@ -821,53 +816,6 @@ def _check_set_features(meta, feats, P):
             raise ValueError(f"a set's feature must be [P={P}, {w}], got {tuple(t.shape)}")
 
 
-def _two_pass_ok(meta, widths) -> bool:
-    """SPLAT_SETS_TWO_PASS=1: the renderer's own configuration -- a tap set of <= 3 channels blended with the live opacity, the
-    per-frame depth, an attribute set of <= 20 channels blended with opacity.detach() -- takes the two-pass backward
-    (splat_alpha_blending_backward_batch_sets2: narrow kernel + LDS-resident dL_dout kernel, 4 + 3 waves per SIMD instead of the
-    one-pass kernel's 2).  Measured at BASELINE configs[1] (round 3): 192 + 521 us per frame against the one-pass kernel's 612 --
-    the second replay of the alpha / T chain costs more than the third wave gains -- so the one-pass kernel stays the default;
-    both are checked against the oracle (tests/test_gpu_frames_oracle.py)."""
-    if not OPTIONS["sets_two_pass"] or len(meta) != 3:
-        return False
-    groups = _set_groups(meta)
-    if sorted(groups) != [0, 1, 2]:
-        return False
-    for (w, _, detach, taps), cn, g in zip(meta, widths, groups):
-        if g == 0 and (w == "depth" or cn > 3 or detach):
-            return False
-        if g == 1 and w != "depth":
-            return False
-        if g == 2 and (w == "depth" or cn > 20):
-            return False
-    return True
-
-
-def _blend_sets_backward_two_pass(fb, meta, state, grads, opacity, op_fs):
-    """the tile passes of the two-pass backward; returns the SETS2 record buffer"""
-    lib, st = L.lib(), L.stream()
-    F, P, W, H, cap = fb.F, fb.P, fb.W, fb.H, fb.capacity
-    groups = _set_groups(meta)
-    by = {}
-    for (w, bg, _, _), t, g_, cn, grp in zip(meta, state["tens"], grads, state["widths"], groups):
-        dl = L.need(g_, "dL_dout") if g_ is not None else torch.zeros(F, cn, H, W, dtype=torch.float32, device=fb.dev)
-        if tuple(dl.shape) != (F, cn, H, W):
-            raise ValueError("image gradient of a set must be [F, c, H, W]")
-        by[grp] = (t, dl, float(bg), cn)
-    (t_tap, dl_tap, bg_tap, cn_tap), (t_dep, dl_dep, bg_dep, _), (t_att, dl_att, bg_att, cn_att) = by[0], by[1], by[2]
-    from .gs.raster_ops import _debug_T_front
-    rec = fb._set_buffer(("rec", "sets2"), F * cap * int(lib.splat_blend_sets2_pair_stride()))
-    pack_a = fb._set_buffer(("pack", "sets2a"), F * P * int(lib.splat_blend_pack_floats(cn_tap)))
-    pack_b = fb._set_buffer(("pack", "sets2b"), F * P * int(lib.splat_blend_sets2_pack_floats()))
-    L.check(lib.splat_alpha_blending_backward_batch_sets2(
-        L.ci(F), L.ci(P), L.ci(cn_tap), L.ci(cn_att), (ctypes.c_float * 3)(bg_tap, bg_dep, bg_att), L.ptr(fb.uv), L.ptr(fb.conic),
-        L.ptr(opacity), ctypes.c_int64(op_fs), L.ptr(t_tap), ctypes.c_int64(0), L.ptr(t_dep), L.ptr(t_att), ctypes.c_int64(0),
-        L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib),
-        L.ptr(dl_tap), L.ptr(dl_dep), L.ptr(dl_att), L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack_a), L.ptr(pack_b),
-        L.ptr(fb.cull_flags), L.ptr(_debug_T_front(F * H, W, fb.dev)), st))
-    return rec
-
-
 def _set_groups(meta):
     """Routing group of every set: 0 = feeds the taps, 1 = live opacity without taps, 2 = opacity.detach()."""
     return [0 if taps else (2 if detach else 1) for (_, _, detach, taps) in meta]
@@ -970,17 +918,11 @@ class _RenderSets(torch.autograd.Function):
                 dfe.append(dfeat)
                 dfs[group_of[si]], strides[group_of[si]] = dfeat, int(feats[fi].shape[1])
                 fi += 1
-            two = _two_pass_ok(meta, widths)
-            if two:
-                rec = _blend_sets_backward_two_pass(fb, meta, ctx.blend, grads[:len(meta)], opacity, op_fs)
-                want_abs = 1 if fb.want_abs else 0
-            else:
-                rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], opacity, op_fs, want_abs)
+            rec = _blend_sets_backward_one_pass(fb, meta, ctx.blend, grads[:len(meta)], opacity, op_fs, want_abs)
             i3 = ctypes.c_int32 * 3
             p3 = (ctypes.c_void_p * 3)(*[0 if d is None else d.data_ptr() for d in dfs])
             has_tap = tap_set is not None
-            gauss = lib.splat_frames_gauss_backward_static_sets2_cam if two else lib.splat_frames_gauss_backward_static_sets_cam
-            L.check(gauss(
+            L.check(lib.splat_frames_gauss_backward_static_sets_cam(
                 L.ci(F), L.ci(P), L.ci(C), L.ci(W), L.ci(H), ctypes.c_int64(cap), L.ptr(rec), L.ptr(fb.goff), L.ptr(fb.radius),
                 L.ptr(xyz), L.ptr(scales), L.ptr(uquats), ctypes.byref(camc), L.ci(1), L.ptr(bufs["xyz"]), L.ptr(bufs["scales"]),
                 L.ptr(bufs["uquats"]), L.ptr(bufs["opacity"]), i3(*c0s), i3(*cns), p3, i3(*strides), L.ci(depth_ch),

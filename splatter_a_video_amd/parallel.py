@@ -176,9 +176,11 @@ def overlapped_halves_step(bucket: FlatGradBucket, first_half, second_half, opti
     second_half()
     bucket.all_reduce(async_op=False)
     bucket.fold(0, 1)                     # waits for the first half's collective; the sum sits in the active buffer
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     if optimizer is not None:
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         optimizer.step(grad_scale=(1.0 / world) if average else 1.0)
+    elif average and world > 1:
+        bucket.flat_grad.mul_(1.0 / world)    # a caller with its own optimiser gets the MEAN it asked for, not the sum
 
 
 def sharded_step(bucket: FlatGradBucket, frames: Iterable[int], render_and_backward, optimizer=None,
@@ -190,6 +192,8 @@ def sharded_step(bucket: FlatGradBucket, frames: Iterable[int], render_and_backw
     for f in frames:
         render_and_backward(f)
     bucket.all_reduce()
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     if optimizer is not None:
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         optimizer.step(grad_scale=(1.0 / world) if average else 1.0)
+    elif average and world > 1:
+        bucket.flat_grad.mul_(1.0 / world)    # (no optimiser: the averaged gradient stays in the bucket)

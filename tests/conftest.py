@@ -29,3 +29,18 @@ def gpu():
     import splatter_a_video_amd._lib as L
     L.lib()  # fails loudly when the HIP library was not built
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def lib_option():
+    """set options of the library through its ABI (splat_set_option) for the duration of one test"""
+    import splatter_a_video_amd._lib as L
+    old = {}
+
+    def set_(key, value):
+        old.setdefault(key, L.get_option(key))
+        L.set_option(key, value)
+
+    yield set_
+    for k, v in old.items():
+        L.set_option(k, v)

@@ -96,13 +96,14 @@ def test_frame_batch_render_against_oracle_and_reference_geometry(oracle_mod):
     assert (B.radii_max.cpu().numpy() == np.max([r["radius"] for r in per], 0)).mean() > 0.9999
 
 
-@pytest.mark.parametrize("two_pass", ["1", "0"])
-def test_render_sets_against_oracle(oracle_mod, two_pass, monkeypatch):
+@pytest.mark.parametrize("std", [1, 0])
+def test_render_sets_against_oracle(oracle_mod, std, lib_option):
     """render_sets = the reference's render_iter over a batch: rgb enhanced (K = 20 ids, ndc + abs_ndc taps), depth (bg 1),
-    19 attribute channels with opacity.detach() -- one forward over the 23-channel row, then the TWO-pass backward (tap set:
-    blend_bwd_mfma_kernel<3>; depth + attributes: blend_bwd_attr_kernel; one shared record) or the ONE-pass three-set
-    backward (blend_bwd_sets_kernel), and frames_gauss_bwd_static_sets(2) -- against three oracle blends per frame."""
-    monkeypatch.setitem(FR.OPTIONS, "sets_two_pass", two_pass == "1")
+    19 attribute channels with opacity.detach() -- one forward over the 23-channel row, then the ONE-pass three-set backward
+    (blend_bwd_sets_quarter_kernel: the renderer's plan staging the forward's records, option "sets_std" = 1, or the generic slot
+    -> channel routing on its own packed records, "sets_std" = 0) and frames_gauss_bwd_static_sets -- against three oracle
+    blends per frame."""
+    lib_option("sets_std", std)
     F, K = 3, 20
     g, opacity, off, rng = _c1_scene(F, seed=3)
     N, W, H = g["xyz"].shape[0], int(g["W"]), int(g["H"])
@@ -193,13 +194,13 @@ def test_render_dynamic_against_oracle(oracle_mod):
     assert_grad(B.tap, tot["tap"], "tap", tol)
 
 
-@pytest.mark.parametrize("two_pass", ["1", "0"])
-def test_render_dynamic_sets_against_oracle_with_reference_parameters(oracle_mod, two_pass, monkeypatch):
+@pytest.mark.parametrize("std", [1, 0])
+def test_render_dynamic_sets_against_oracle_with_reference_parameters(oracle_mod, std, lib_option):
     """render_dynamic_sets = the reference's training frame over a batch, on the parameters of the reference-made dynamic fixture
     (400 Gaussians x 50 frames, tests/golden/make_golden_dynamic.py; its activations are pinned in test_gpu_dynamic.py) tiled
     to fill a 96 x 64 view: dynamic evaluation -> three blends -> one-pass backward -> frames_gauss_bwd_dynamic_sets."""
     from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, FrameClock, to_gaussian_major, to_segment_major
-    monkeypatch.setitem(FR.OPTIONS, "sets_two_pass", two_pass == "1")
+    lib_option("sets_std", std)
     g = dict(np.load(os.path.join(GOLD, "dynamic_400x50.npz")))
     clock = FrameClock(int(g["T"]), g["intervals"], int(g["start_frame_id"]), int(g["time_len"]))
     I = clock.interval_num

@@ -25,7 +25,7 @@ run bench_dynamic_a15 --dynamic --no-cpu-baseline
 run bench_render_iter --render-iter --no-cpu-baseline
 run bench_render_iter_per_frame --render-iter --per-frame --no-cpu-baseline
 run bench_render_iter_dynamic --render-iter --dynamic --no-cpu-baseline   # the reference's real training frame
-SPLAT_SETS_TWO_PASS=1 run bench_render_iter_dynamic_two_pass --render-iter --dynamic --no-cpu-baseline
+run bench_train_step --train-step --no-cpu-baseline                         # the composed training step (train_step.py)
 run bench_clustered --scene clustered --no-cpu-baseline --no-extra-lines   # 70 % of the Gaussians in blobs covering 10 % of the image
 run bench_ref_flow --ref-flow --steps 3 --warmup 1 --no-cpu-baseline      # the reference's literal render_iter call sequence (eager projection + EWA)
 # kernel trace of the default bench command (2 timed steps of 25 frames)
