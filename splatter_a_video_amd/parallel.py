@@ -197,3 +197,78 @@ def sharded_step(bucket: FlatGradBucket, frames: Iterable[int], render_and_backw
         optimizer.step(grad_scale=(1.0 / world) if average else 1.0)
     elif average and world > 1:
         bucket.flat_grad.mul_(1.0 / world)    # (no optimiser: the averaged gradient stays in the bucket)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Owner-sharded step: the spline table of the reference's model is 87 % of its parameters (4 * I * 3 floats per Gaussian against
+# 72 for everything else at 200 frames, src/dynamic_gaussian_with_base_point_cloud.py:73-75) and is addressed BY TIME: segment s
+# serves the frames of its five-frame interval.  With the clip's frames dealt to the ranks in contiguous time blocks, rank r
+# OWNS the segments of its block: their gradient is reduced TO the owner only (reduce-scatter), the owner alone keeps their Adam
+# moments and steps them, and the updated blocks are all-gathered, so that every replica still evaluates position(ids2) of any
+# pair frame.  Same bytes on the wire as the ring all-reduce (2 (W-1)/W B per rank), but the optimiser streams 1/W of the
+# table's 28 bytes per parameter, its state takes 1/W of the memory, and the two halves are separate collectives: the
+# reduce-scatter can start as soon as the backward's last kernel is done while the replicated part is still in flight.
+class OwnerShards:
+    """The flat buffer split into a REPLICATED part and an OWNED parameter (``name``: leading dimension = the units that are
+    dealt out, e.g. the spline table stored segment-major [I, N, 4, 3]) cut into ``world`` contiguous blocks of whole units:
+    rank r owns units [units * r // world, units * (r + 1) // world).  The owned parameter must come FIRST in the bucket (its
+    blocks then start 16-byte aligned for the streaming Adam kernel)."""
+
+    def __init__(self, bucket: FlatGradBucket, name: str, world: int, rank: int):
+        a, b = bucket.slices[name]
+        if a != 0:
+            raise ValueError(f"the owned parameter {name!r} must be the first tensor of the bucket")
+        units = int(bucket.params[name].shape[0])
+        per = (b - a) // units
+        if units < world:
+            raise ValueError(f"{units} units cannot be dealt to {world} ranks")
+        self.name, self.world, self.rank = name, int(world), int(rank)
+        self.unit_bounds = [units * r // world for r in range(world + 1)]
+        self.bounds = [a + u * per for u in self.unit_bounds]
+        self.a, self.b, self.total = a, b, bucket.flat_param.numel()
+        self.equal = len({self.bounds[r + 1] - self.bounds[r] for r in range(world)}) == 1
+
+    @property
+    def own(self) -> Tuple[int, int]:
+        return self.bounds[self.rank], self.bounds[self.rank + 1]
+
+    def frames_of_rank(self, unit_of_frame: Sequence[int]) -> List[int]:
+        """the clip's frames in contiguous TIME BLOCKS: rank r renders the frames whose unit (``unit_of_frame[f]``: the spline
+        segment of frame f, ``FrameClock.scalars(f)[0]``) it owns -- their render-path gradient of the table is then already
+        complete on its owner"""
+        u0, u1 = self.unit_bounds[self.rank], self.unit_bounds[self.rank + 1]
+        return [f for f, u in enumerate(unit_of_frame) if u0 <= u < u1]
+
+
+def owner_sharded_step(bucket: FlatGradBucket, shards: OwnerShards, frames: Iterable[int], render_and_backward, optimizer,
+                       average: bool = False) -> None:
+    """One SYNCHRONOUS step with the owned parameter's gradient reduced to its owners only: zero -> local frames forward +
+    backward -> all-reduce of the replicated part || reduce-scatter of the owned part -> ``optimizer.step`` (replicated part on
+    every rank, own block on its owner: ``optim.OwnerShardedAdam``) -> all-gather of the updated blocks.  Parameters after the
+    step = ``sharded_step``'s (to fp32 summation order), replicas bit-identical."""
+    bucket.zero_grad()
+    for f in frames:
+        render_and_backward(f)
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    world = dist.get_world_size() if on else 1
+    g, p = bucket.flat_grad, bucket.flat_param
+    lo, hi = shards.own
+    if on:
+        work = dist.all_reduce(g[shards.b:shards.total], op=dist.ReduceOp.SUM, async_op=True)   # replicated part
+        nccl = dist.get_backend() == "nccl"
+        if nccl and shards.equal:
+            own = torch.empty(hi - lo, dtype=g.dtype, device=g.device)
+            dist.reduce_scatter_tensor(own, g[shards.a:shards.b], op=dist.ReduceOp.SUM)
+            g[lo:hi].copy_(own)
+        else:   # uneven blocks / backends without reduce-scatter (gloo): one reduce per owner -- the same bytes
+            for r in range(world):
+                dist.reduce(g[shards.bounds[r]:shards.bounds[r + 1]], dst=r, op=dist.ReduceOp.SUM)
+        work.wait()
+    optimizer.step(grad_scale=(1.0 / world) if average else 1.0)
+    if on:
+        with torch.no_grad():
+            if dist.get_backend() == "nccl" and shards.equal:
+                dist.all_gather_into_tensor(p[shards.a:shards.b], p[lo:hi].clone())
+            else:
+                for r in range(world):
+                    dist.broadcast(p[shards.bounds[r]:shards.bounds[r + 1]], src=r)

@@ -76,3 +76,31 @@ def test_flat_adam_follows_a_learning_rate_schedule():
             torch.testing.assert_close(bucket.params[n].detach(), p.detach(), rtol=2e-5, atol=1e-7)
     with pytest.raises(KeyError):
         opt.set_lr({"nope": 1.0})
+
+
+def test_owner_sharded_adam_steps_its_block_and_the_replicated_slice_like_flat_adam():
+    """optim.OwnerShardedAdam (parallel.owner_sharded_step): rank 1 of 3 steps ITS block of the owned table and the whole
+    replicated slice with the update rule of FlatAdam -- bit-identical there -- and leaves the other ranks' blocks alone"""
+    from splatter_a_video_amd.optim import FlatAdam, OwnerShardedAdam
+    from splatter_a_video_amd.parallel import FlatGradBucket, OwnerShards
+    g = torch.Generator(device="cuda").manual_seed(3)
+    I, N = 7, 1000
+    mk = lambda: {"cubic": 0.1 * torch.randn(I, N, 4, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)),
+                  "rotation": torch.randn(N, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)),
+                  "opacity": torch.randn(N, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))}
+    lr = {"cubic": 1e-3, "rotation": 2e-3, "opacity": 5e-2}
+    a, b = FlatGradBucket(mk()), FlatGradBucket(mk())
+    sh = OwnerShards(b, "cubic", 3, 1)
+    lo, hi = sh.own
+    assert (lo, hi) == (2 * N * 12, 4 * N * 12)                    # segments 2, 3 of 7 (7 * r // 3)
+    oa, ob = FlatAdam(a, lr), OwnerShardedAdam(b, sh, lr)
+    assert ob.m_own.numel() == hi - lo and ob.m_rep.numel() == 5 * N
+    before = b.flat_param.detach().clone()
+    for _ in range(3):
+        gr = torch.randn(a.flat_grad.numel(), device="cuda", generator=g)
+        a.flat_grad.copy_(gr); b.flat_grad.copy_(gr)
+        oa.step(grad_scale=0.5); ob.step(grad_scale=0.5)
+    pa, pb = a.flat_param.detach(), b.flat_param.detach()
+    assert torch.equal(pb[lo:hi], pa[lo:hi]) and torch.equal(pb[sh.b:], pa[sh.b:])
+    assert torch.equal(pb[:lo], before[:lo]) and torch.equal(pb[hi:sh.b], before[hi:sh.b])
+    assert not torch.equal(pb[lo:hi], before[lo:hi])

@@ -312,3 +312,94 @@ def test_split_needs_a_round_dependent_seed():
         D.split_children(z, z, torch.zeros(4, 4), torch.ones(4, dtype=torch.bool))
     with pytest.raises(ValueError, match="seed"):
         D.densify_split({"position": z, "scaling": z, "rotation": torch.zeros(4, 4)}, None, torch.ones(4, dtype=torch.bool))
+
+
+# ------------------------------------------------------------------ owner-sharded step: reduce-scatter + sharded Adam + all-gather
+class _TorchOwnerAdam:
+    """torch restatement of optim.OwnerShardedAdam: the replicated slice everywhere, of the owned parameter only this rank's
+    block -- moments for nothing else"""
+
+    def __init__(self, bucket, shards, lr):
+        self.b, self.s, self.lr, self.t = bucket, shards, lr, 0
+        lo, hi = shards.own
+        self.parts = [(lo, hi), (shards.b, shards.total)]
+        self.m = [torch.zeros(h - l) for l, h in self.parts]
+        self.v = [torch.zeros(h - l) for l, h in self.parts]
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        with torch.no_grad():
+            for (l, h), m, v in zip(self.parts, self.m, self.v):
+                g = self.b.flat_grad[l:h] * grad_scale
+                m.mul_(0.9).add_(g, alpha=0.1)
+                v.mul_(0.999).addcmul_(g, g, value=0.001)
+                self.b.flat_param[l:h] -= (self.lr / (1 - 0.9 ** self.t)) * m / (v.sqrt() / (1 - 0.999 ** self.t) ** 0.5 + 1e-15)
+
+
+def _seg_params(seed=0, I=5, N=30):
+    g = torch.Generator().manual_seed(seed)
+    # the owned parameter FIRST: a spline table stored segment-major [I, N, 4, 3]
+    return {"cubic": 0.1 * torch.randn(I, N, 4, 3, generator=g), "xyz": torch.randn(N, 3, generator=g), "opacity": torch.rand(N, 1, generator=g)}
+
+
+def _seg_render(p, f, I=5):
+    """a frame reads ITS segment of the table (f // 5 ... here f % I) and, like track_gs, the segment of a pair frame"""
+    s1, s2 = f % I, (3 * f + 1) % I
+    pos = p["xyz"] + p["cubic"][s1, :, 3] + 0.3 * p["cubic"][s1, :, 2]
+    pair = p["xyz"] + p["cubic"][s2, :, 3]
+    return (torch.sin(pos).sum(1, keepdim=True) * p["opacity"]).sum() + 0.1 * (pair * pos).sum()
+
+
+def _worker_owner(rank, world, port, out):
+    from splatter_a_video_amd.parallel import OwnerShards, owner_sharded_step
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = FlatGradBucket(_seg_params())
+        sh = OwnerShards(b, "cubic", world, rank)
+        opt = _TorchOwnerAdam(b, sh, 1e-2)
+        assert sh.bounds[0] == 0 and sh.bounds[-1] == b.slices["cubic"][1] and not sh.equal      # 5 segments on 2 ranks: 2 + 3
+        unit_of_frame = [f % 5 for f in range(10)]
+        mine_blocks = sh.frames_of_rank(unit_of_frame)
+        for step in range(3):
+            frames = frames_of_rank(list(range(6 * step, 6 * step + 6)), rank, world)
+            owner_sharded_step(b, sh, frames, lambda f: _seg_render(b.params, f).backward(), opt)
+        torch.save({"param": b.flat_param.detach().clone(), "blocks": mine_blocks, "own": sh.own}, out + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_owner_sharded_step_equals_the_synchronous_step(tmp_path):
+    """the spline table's gradient reduced to its owners only, Adam moments kept by the owner alone,
+    updated blocks gathered -- the parameters of sharded_step (dense all-reduce + replicated Adam) to fp32 summation order,
+    replicas bit-identical, over several steps with frames that touch OTHER ranks' segments (the pair frames)"""
+    out = str(tmp_path / "o")
+    mp.spawn(_worker_owner, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["param"], r1["param"])
+    assert r0["own"][1] == r1["own"][0] and sorted(r0["blocks"] + r1["blocks"]) == list(range(10))
+    assert r0["blocks"] == [0, 1, 5, 6] and r1["blocks"] == [2, 3, 4, 7, 8, 9]          # time blocks: segments 0-1 | 2-4
+    ref = FlatGradBucket(_seg_params())
+    opt = _TorchFlatAdam(ref, 1e-2)
+    for step in range(3):
+        sharded_step(ref, list(range(6 * step, 6 * step + 6)), lambda f: _seg_render(ref.params, f).backward(), optimizer=opt)
+    p = ref.flat_param.detach()
+    assert float((r0["param"] - p).abs().max()) <= 2e-6 * float(p.abs().max())
+
+
+def test_owner_shards_need_the_owned_parameter_first():
+    from splatter_a_video_amd.parallel import OwnerShards, owner_sharded_step
+    b = FlatGradBucket(_params())
+    with pytest.raises(ValueError, match="first tensor"):
+        OwnerShards(b, "shs", 2, 0)
+    # without a process group the step is the plain local step
+    b2 = FlatGradBucket(_seg_params())
+    sh = OwnerShards(b2, "cubic", 1, 0)
+    opt = _TorchOwnerAdam(b2, sh, 1e-2)
+    owner_sharded_step(b2, sh, [0, 1], lambda f: _seg_render(b2.params, f).backward(), opt)
+    ref = FlatGradBucket(_seg_params())
+    o2 = _TorchFlatAdam(ref, 1e-2)
+    sharded_step(ref, [0, 1], lambda f: _seg_render(ref.params, f).backward(), optimizer=o2)
+    torch.testing.assert_close(b2.flat_param.detach(), ref.flat_param.detach())
