@@ -54,7 +54,7 @@ HBM_ACHIEVABLE_GBS = 6300.0
 # same command line (tools/round_profile.sh: separate rocprofv3 --pmc passes; read requests sized by
 # TCC_EA0_RDREQ_{32B,64B,128B}, WRITE_SIZE in KiB); stamped with the profile they come from and only reported when the
 # bench runs the configuration they were taken at.
-PMC_TAG = os.environ.get("SPLAT_PMC_TAG", "r04")
+PMC_TAG = os.environ.get("SPLAT_PMC_TAG", "r05")
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_traffic.json")
 PMC_COUNTER_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_blend_counters.json")
 PMC_KERNEL_NAMES = {"blend_bwd": ("blend_bwd_quarter_kernel", "blend_bwd_mfma_kernel"), "blend_fwd": "blend_fwd_kernel", "tile_sort": "tile_sort_kernel",

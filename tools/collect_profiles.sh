@@ -1,6 +1,6 @@
 #!/bin/bash
 # copies the round's measurement record from gpurun_out/<tag>/ (scratch) into profiles/<tag>_* (tracked)
-TAG=${1:-r04}
+TAG=${1:-r05}
 S=gpurun_out/$TAG; R=gpurun_out/${TAG}_ri
 for f in $S/bench_*.json; do b=$(basename $f); cp $f profiles/${TAG}_$b; done
 cp $S/pmc_traffic.json profiles/${TAG}_pmc_traffic.json

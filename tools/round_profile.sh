@@ -2,7 +2,7 @@
 # GPU box: everything the round's measurement record needs, in one gpurun call.
 #   tools/round_profile.sh <tag>        (writes gpurun_out/<tag>/...)
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r04}
+TAG=${1:-r05}
 export PYTHONPATH=$GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 mkdir -p $O

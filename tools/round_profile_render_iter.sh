@@ -2,7 +2,7 @@
 # GPU box: kernel trace and issue counters of the reference's training frame (bench.py --render-iter --dynamic)
 #   tools/round_profile_render_iter.sh <tag>
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r04}
+TAG=${1:-r05}
 export PYTHONPATH=$GRAFT_REPO_ROOT TMPDIR=/tmp
 O=gpurun_out/${TAG}_ri
 mkdir -p $O
