@@ -734,6 +734,29 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
     st.step(t1, t2, gt)
     phases = {k: round(v, 3) for k, v in st.phases().items()}
     st.timing = False
+    # per-kernel HIP-event times of one more step (rank 0's own pass at N > 1 would enter collectives: N = 1 only)
+    kern = None
+    if world == 1 and not a.no_kernel_timing:
+        torch.cuda.synchronize()
+        L.profile_reset()
+        L.profile_enable(True)
+        st.step(t1, t2, gt)
+        torch.cuda.synchronize()
+        L.profile_enable(False)
+        kern = {}
+        for n in ("sh_fwd", "dynamic_positions_fwd", "knn_brute_bound", "knn_brute_merge", "knn_brute", "arap_energy", "frame_preprocess_fwd",
+                  "bin_count", "bin_colscan", "bin_tilescan", "bin_scatter", "tile_sort", "blend_pack", "blend_fwd", "l1_loss_grad",
+                  "blend_bwd", "gauss_bwd", "sh_bwd", "dynamic_positions_bwd", "fill", "adam_step", "densify"):
+            ms, cnt = L.profile_read(n)
+            if cnt:
+                kern[n] = {"us_per_step": round(ms * 1e3, 1), "launches": cnt}
+        for n in ("knn_brute",):      # (prefix match: the bound and merge launches are listed on their own)
+            if n in kern:
+                for sub in ("knn_brute_bound", "knn_brute_merge"):
+                    if sub in kern:
+                        kern[n]["us_per_step"] = round(kern[n]["us_per_step"] - kern[sub]["us_per_step"], 1)
+                        kern[n]["launches"] -= kern[sub]["launches"]
+        L.profile_reset()
     # densification once (every rank: the statistics were reduced, the decisions are identical), timed on its own
     n0 = st.N
     torch.cuda.synchronize()
@@ -753,7 +776,7 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
         "value": round(F * a.steps * world / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "train_step_ms": round(ms_step, 3), "ms_per_pair": round(ms_step / F, 4),
         "train_step_ms_with_densification_amortised": round(ms_step + amort, 3),
-        "phases_ms": phases,
+        "phases_ms": phases, "kernels_us_per_step": kern,
         "densify": {"ms_once": round(dens_ms, 2), "interval_steps": cfg.interval, "ms_per_step_amortised": round(amort, 3),
                     "gaussians_before": n0, **ch,
                     "what": "masks, clone, split (counter-based children), prune -- parameters and Adam moments --, Morton reorder, "

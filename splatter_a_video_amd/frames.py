@@ -420,6 +420,15 @@ class FrameBatch:
         The widths must add up to the batch's ``C``.  One forward pass composites the concatenated row; per set one
         backward pass of the tile kernels and one Gaussian-side reduction.  Returns ``(images per set ..., gs_idx)`` with
         images [F,c,H,W] and gs_idx [F,H,W,K] (None for K = 0).  Cameras (``extr`` per frame, ``intr``) as in ``render``."""
+        def one(f):
+            # a list of shared tensors = their concatenation along the channels, as the reference's renderer concatenates its
+            # attributes (RenderFeatures.combine); per-frame tensors belong to the dynamic renderer (render_dynamic_sets)
+            if isinstance(f, (list, tuple)):
+                if any(t.dim() != 2 for t in f):
+                    raise ValueError("render_sets: the tensors of a feature list are [P, c] (per-frame tensors: render_dynamic_sets)")
+                return f[0] if len(f) == 1 else torch.cat(list(f), dim=1)
+            return f
+        sets = [dict(s_, feature=one(s_["feature"])) for s_ in sets]
         feats = [s_["feature"] for s_ in sets if not isinstance(s_["feature"], str)]
         meta = tuple((("depth" if isinstance(s_["feature"], str) else int(s_["feature"].shape[1])), float(s_.get("bg", 0.0)),
                       bool(s_.get("detach_opacity", False)), bool(s_.get("taps", False))) for s_ in sets)

@@ -278,6 +278,23 @@ class TrainingStep:
             m[k] = (ea, es)
         return p, m
 
+    def set_lr(self, lr: Dict[str, float]) -> None:
+        """new learning rate(s) from the next step on (the reference's ExponLRScheduler on the spline table,
+        src/configs/frag_gs_v10.yaml:68-76: call it before each step); they survive a rebuild"""
+        self.lr.update({k: float(v) for k, v in lr.items()})
+        self.opt.set_lr(lr)
+
+    def reset_opacity(self, ceiling: float = 0.01) -> None:
+        """``reset_opacity`` of the reference (atlas_gs_optimizer.py:178-190, every ``opacity_reset_interval`` steps): opacities
+        above ``ceiling`` fall back to it (logit space), and -- as ``replace_tensor_to_optimizer`` does -- the Adam moments of the
+        opacity group start from zero"""
+        with torch.no_grad():
+            p = self.p["opacity"]
+            p.copy_(torch.minimum(p, torch.full_like(p, math.log(ceiling / (1.0 - ceiling)))))
+            a, b = self.bucket.slices["opacity"]
+            self.opt.exp_avg[a:b].zero_()
+            self.opt.exp_avg_sq[a:b].zero_()
+
     def maybe_densify(self) -> bool:
         """clone / split / prune at the reference's cadence (atlas_gs_optimizer.py:120-121,166-176); True when N changed"""
         c = self.cfg

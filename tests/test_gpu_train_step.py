@@ -329,3 +329,23 @@ def test_training_step_phases_are_timed():
     ph = st.phases()
     assert set(ph) == {"model_eval", "knn_arap", "render_forward", "loss", "render_backward", "allreduce_adam", "densify_stats"}
     assert all(v > 0 for v in ph.values())
+
+
+def test_opacity_reset_and_learning_rate_schedule_survive_a_rebuild():
+    N, W, H, T, F = 2000, 96, 64, 20, 3
+    sc, clock, truth = _clip(N, W, H, T, seed=3)
+    extr = _t(sc.extr)
+    st = TS.TrainingStep(_perturbed(truth, 4), clock, W, H, F, extr, K=4, arap_samples=64,
+                         densify=TS.DensifyConfig(interval=2, start_iter=0, grad_threshold=1e-6, cameras_extent=60.0, min_opacity=0.02, seed=1))
+    t1, t2 = [0, 5, 9], [3, 1, 17]
+    gt = TS.render_ground_truth(truth, clock, W, H, extr, t1, t2)
+    st.step(t1, t2, gt)
+    st.set_lr({"pos_cubic_node": 1.5e-5})
+    st.reset_opacity()
+    a, b = st.bucket.slices["opacity"]
+    assert float(torch.sigmoid(st.p["opacity"]).max()) <= 0.01 + 1e-6 and float(st.opt.exp_avg[a:b].abs().max()) == 0.0
+    st.step(t1, t2, gt)
+    assert st.maybe_densify() and st.N != N
+    assert st.opt.lr["pos_cubic_node"] == 1.5e-5 and st.lr["pos_cubic_node"] == 1.5e-5      # the schedule's rate at the new count
+    st.step(t1, t2, gt)
+    assert torch.isfinite(st.bucket.flat_param).all() and np.isfinite(st.loss())
