@@ -697,6 +697,14 @@ int splat_l1_loss_grad(int F, int64_t inner, const float *pred, int64_t pred_fra
 int splat_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int nseg,
                     const int64_t *seg_end_host, const float *seg_lr_host, float beta1, float beta2, float eps,
                     int step, float grad_scale, splat_stream_t stream);
+/* ... with a learning-rate pattern inside segments: of every seg_period[k] consecutive elements of segment k (from its start) the
+ * first seg_head[k] take seg_lr_head[k] instead of seg_lr[k] (period 0: none) -- two parameter groups interleaved in one tensor:
+ * the reference's features (DC) / features_rest inside the [N, 16, 3] SH block, period 48, head 3
+ * (src/configs/frag_gs_v10.yaml:44-47). */
+int splat_adam_step_pattern(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int nseg,
+                            const int64_t *seg_end_host, const float *seg_lr_host, const int32_t *seg_period_host,
+                            const int32_t *seg_head_host, const float *seg_lr_head_host, float beta1, float beta2, float eps,
+                            int step, float grad_scale, splat_stream_t stream);
 
 /* ---- as-rigid-as-possible energy: replaces estimate_rotation + cal_arap_error of
  *      src/geometry_utils.py:50-123 (~50 eager launches per frame pair incl. torch.svd) by one launch.
@@ -718,7 +726,10 @@ int splat_arap_energy_batch(int B, int Nt, int Nv, int K, int S, const float *no
 /* K <= 8 nearest points of S query VERTICES (query_idx [B, S]: indices into the set itself) among the N points of each of B
  * point sets (set b at points + b * points_batch_stride), brute force in two launches: dists / idx [B, S, K] ascending, ties ->
  * smaller index, the query itself included -- knn_points(points, points)[sample] for the 512 sampled vertices of the ARAP term
- * (src/geometry_utils.py:17-19,98-101) without a grid build per point set.  scratch: splat_knn_brute_scratch_bytes(B, N, S). */
+ * (src/geometry_utils.py:17-19,98-101) without a grid build per point set.  Four launches: tile boxes, a distance bound per query
+ * from its index neighbourhood, the scan (a wave skips the tiles whose box lies beyond all of its queries' bounds: hand the
+ * queries in ascending index order when the points are spatially ordered), the merge.  Exact whatever the order.
+ * scratch: splat_knn_brute_scratch_bytes(B, N, S). */
 size_t splat_knn_brute_scratch_bytes(int B, int N, int S);
 int splat_knn_brute_batch(int B, int N, int S, int K, const float *points, int64_t points_batch_stride,
                           const int64_t *query_idx, float *dists, int32_t *idx, void *scratch, splat_stream_t stream);

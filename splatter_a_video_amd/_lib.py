@@ -39,7 +39,7 @@ SYMBOLS = [
     "splat_compact_scratch_bytes", "splat_compact_scan", "splat_compact_rows",
     "splat_gather_rows_repeat", "splat_densify_split_sample", "splat_morton_keys",
     "splat_knn_grid_cells", "splat_knn_plan_bytes", "splat_knn_build", "splat_knn_scatter", "splat_knn_search",
-    "splat_adam_step", "splat_arap_energy",
+    "splat_adam_step", "splat_adam_step_pattern", "splat_arap_energy",
     "splat_preprocess_ortho_forward_batch", "splat_bin_count_batch", "splat_bin_sort_batch",
     "splat_alpha_blending_forward_batch", "splat_blend_pair_stride", "splat_alpha_blending_backward_batch",
     "splat_frame_preprocess_forward_batch", "splat_frames_gauss_backward_dynamic",

@@ -296,10 +296,52 @@ knn_brute_bound_kernel(int N, int S, int K, const float *__restrict__ pts, long 
     tau[(size_t)b * S + q] = t * 1.000002f;   // (the scan may round the same distance an ulp differently: keep the bound's own points)
 }
 
+// bounding box of every tile of KNB_TILE consecutive points (Morton order: compact boxes): box[(b * NT + t) * 6 + {lo xyz, hi xyz}]
+__global__ void __launch_bounds__(KB)
+knn_tile_box_kernel(int N, int NT, const float *__restrict__ pts, long long pts_bs, float *__restrict__ box) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const float *P = pts + (size_t)b * pts_bs;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int e = threadIdx.x; e < KNB_TILE; e += KB) {
+        const int id = t * KNB_TILE + e;
+        if (id < N) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = P[3 * (size_t)id + a];
+                lo[a] = fminf(lo[a], v);
+                hi[a] = fmaxf(hi[a], v);
+            }
+        }
+    }
+    __shared__ float s_lo[KB / WAVE][3], s_hi[KB / WAVE][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+        }
+        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6][a] = lo[a]; s_hi[threadIdx.x >> 6][a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float l = s_lo[0][a], h = s_hi[0][a];
+        for (int w = 1; w < KB / WAVE; ++w) { l = fminf(l, s_lo[w][a]); h = fmaxf(h, s_hi[w][a]); }
+        box[((size_t)b * NT + t) * 6 + a] = l;
+        box[((size_t)b * NT + t) * 6 + 3 + a] = h;
+    }
+}
+
+// Partial lists: block = 256 queries x one chunk (KNB_TILES tiles staged through LDS one after the other); a WAVE scans a tile only
+// if one of its 64 queries can have a candidate in the tile's box (the callers hand the queries in ascending index = Morton
+// order, so a wave's queries are neighbours and most tiles are far from all of them).  Only non-empty lists are written:
+// cnt[(b * G + c) * S + q] = entries of the list at pd / pi[((b * G + c) * S + q) * KT ..].
 template <int KT>
 __global__ void __launch_bounds__(KB)
-knn_brute_partial_kernel(int N, int S, int G, const float *__restrict__ pts, long long pts_bs, const long long *__restrict__ qidx,
-                         const float *__restrict__ tau, float *__restrict__ pd, int *__restrict__ pi) {
+knn_brute_partial_kernel(int N, int S, int G, int NT, const float *__restrict__ pts, long long pts_bs, const long long *__restrict__ qidx,
+                         const float *__restrict__ tau, const float *__restrict__ box, float *__restrict__ pd, int *__restrict__ pi,
+                         unsigned char *__restrict__ cnt) {
     __shared__ float4 sp[KNB_TILE];
     const int c = blockIdx.x, b = blockIdx.z;
     const int q = blockIdx.y * KB + threadIdx.x;
@@ -315,7 +357,8 @@ knn_brute_partial_kernel(int N, int S, int G, const float *__restrict__ pts, lon
 #pragma unroll
     for (int p = 0; p < KT; ++p) { bd[p] = __builtin_inff(); bi[p] = 0x7fffffff; }
     for (int tl = 0; tl < KNB_TILES; ++tl) {
-        const int base = c * KNB_CHUNK + tl * KNB_TILE;
+        const int tile = c * KNB_TILES + tl;
+        const int base = tile * KNB_TILE;
         if (base >= N) break;   // block-uniform
         __syncthreads();
         for (int e = threadIdx.x; e < KNB_TILE; e += KB) {
@@ -324,6 +367,11 @@ knn_brute_partial_kernel(int N, int S, int G, const float *__restrict__ pts, lon
                            : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         }
         __syncthreads();
+        const float *bx = box + ((size_t)b * NT + tile) * 6;
+        const float ex = fmaxf(fmaxf(bx[0] - qx, qx - bx[3]), 0.f), ey = fmaxf(fmaxf(bx[1] - qy, qy - bx[4]), 0.f),
+                    ez = fmaxf(fmaxf(bx[2] - qz, qz - bx[5]), 0.f);
+        // (the box distance is a lower bound of every point's distance up to rounding: compare against an inflated bound)
+        if (__builtin_amdgcn_ballot_w64((ex * ex + ey * ey + ez * ez) * 0.999998f <= bound) == 0ull) continue;   // wave-uniform
         const int n = imin_(KNB_TILE, N - base);
         for (int e = 0; e < n; ++e) {
             const float4 p = sp[e];
@@ -333,16 +381,21 @@ knn_brute_partial_kernel(int N, int S, int G, const float *__restrict__ pts, lon
         }
     }
     if (q < S) {
-        const size_t o = (((size_t)b * G + c) * S + q) * KT;
+        const size_t o = ((size_t)b * G + c) * S + q;
+        int nv = 0;
 #pragma unroll
-        for (int p = 0; p < KT; ++p) { pd[o + p] = bd[p]; pi[o + p] = bi[p]; }
+        for (int p = 0; p < KT; ++p) nv += bi[p] != 0x7fffffff ? 1 : 0;
+        cnt[o] = (unsigned char)nv;
+#pragma unroll
+        for (int p = 0; p < KT; ++p)
+            if (p < nv) { pd[o * KT + p] = bd[p]; pi[o * KT + p] = bi[p]; }
     }
 }
 
 template <int KT>
 __global__ void __launch_bounds__(KB)
-knn_brute_merge_kernel(int S, int G, int K, const float *__restrict__ pd, const int *__restrict__ pi, float *__restrict__ dists,
-                       int *__restrict__ idx) {
+knn_brute_merge_kernel(int S, int G, int K, const float *__restrict__ pd, const int *__restrict__ pi,
+                       const unsigned char *__restrict__ cnt, float *__restrict__ dists, int *__restrict__ idx) {
     const int q = blockIdx.x * KB + threadIdx.x, b = blockIdx.y;
     if (q >= S) return;
     float bd[KT];
@@ -350,10 +403,9 @@ knn_brute_merge_kernel(int S, int G, int K, const float *__restrict__ pd, const 
 #pragma unroll
     for (int p = 0; p < KT; ++p) { bd[p] = __builtin_inff(); bi[p] = 0x7fffffff; }
     for (int c = 0; c < G; ++c) {
-        const size_t o = (((size_t)b * G + c) * S + q) * KT;
-#pragma unroll
-        for (int p = 0; p < KT; ++p)
-            if (pi[o + p] != 0x7fffffff) knn_insert<KT>(bd, bi, pd[o + p], pi[o + p]);
+        const size_t o = ((size_t)b * G + c) * S + q;
+        const int nv = cnt[o];          // (coalesced over the queries; most chunks hold nothing for a query)
+        for (int p = 0; p < nv; ++p) knn_insert<KT>(bd, bi, pd[o * KT + p], pi[o * KT + p]);
     }
 #pragma unroll
     for (int p = 0; p < KT; ++p) {
@@ -434,9 +486,11 @@ extern "C" int splat_knn_search(int N, const float *query, const int32_t *query_
 // point sets (set b at points + b * points_batch_stride floats), brute force: dists / idx [B, S, K] ascending, ties -> smaller
 // index, the query itself included (distance 0) like knn_points(points, points).  scratch: splat_knn_brute_scratch_bytes().
 extern "C" size_t splat_knn_brute_scratch_bytes(int B, int N, int S) {
-    const size_t G = ((size_t)(N > 0 ? N : 1) + KNB_CHUNK - 1) / KNB_CHUNK;
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    const size_t G = (n + KNB_CHUNK - 1) / KNB_CHUNK, NT = (n + KNB_TILE - 1) / KNB_TILE;
     const size_t bs = (size_t)(B > 0 ? B : 1) * (size_t)(S > 0 ? S : 1);
-    return bs * G * 8 * (sizeof(float) + sizeof(int)) + bs * sizeof(float);   // partial lists + the bound of every query
+    // partial lists + the bound of every query + the tiles' boxes + the lists' lengths
+    return bs * G * 8 * (sizeof(float) + sizeof(int)) + bs * sizeof(float) + (size_t)(B > 0 ? B : 1) * NT * 6 * sizeof(float) + bs * G + 16;
 }
 
 extern "C" int splat_knn_brute_batch(int B, int N, int S, int K, const float *points, int64_t points_batch_stride,
@@ -451,14 +505,20 @@ extern "C" int splat_knn_brute_batch(int B, int N, int S, int K, const float *po
     float *pd = (float *)scratch;
     int *pi = (int *)(pd + (size_t)B * G * S * 8);
     float *tau = (float *)(pi + (size_t)B * G * S * 8);
+    const int NT = (N + KNB_TILE - 1) / KNB_TILE;
+    float *box = tau + (size_t)B * S;
+    unsigned char *cnt = (unsigned char *)(box + (size_t)B * NT * 6);
+    SPLAT_LAUNCH("knn_brute_box", knn_tile_box_kernel, dim3((unsigned)NT, (unsigned)B), dim3(KB), 0, s, N, NT, points,
+                 (long long)points_batch_stride, box);
+    SPLAT_POST_LAUNCH();
     SPLAT_LAUNCH("knn_brute_bound", knn_brute_bound_kernel<8>, dim3((unsigned)((S + KB - 1) / KB), (unsigned)B), dim3(KB), 0, s, N, S, K,
                  points, (long long)points_batch_stride, (const long long *)query_idx, tau);
     SPLAT_POST_LAUNCH();
     SPLAT_LAUNCH("knn_brute", knn_brute_partial_kernel<8>, dim3((unsigned)G, (unsigned)((S + KB - 1) / KB), (unsigned)B), dim3(KB), 0, s,
-                 N, S, G, points, (long long)points_batch_stride, (const long long *)query_idx, tau, pd, pi);
+                 N, S, G, NT, points, (long long)points_batch_stride, (const long long *)query_idx, tau, box, pd, pi, cnt);
     SPLAT_POST_LAUNCH();
     SPLAT_LAUNCH("knn_brute_merge", knn_brute_merge_kernel<8>, dim3((unsigned)((S + KB - 1) / KB), (unsigned)B), dim3(KB), 0, s, S, G, K,
-                 pd, pi, dists, idx);
+                 pd, pi, cnt, dists, idx);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }

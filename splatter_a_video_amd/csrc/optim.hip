@@ -19,13 +19,21 @@ struct AdamSegs {
     int n;
     long long end[ADAM_MAX_SEG];  // exclusive end of segment k (elements); segment k uses step size ss[k]
     float ss[ADAM_MAX_SEG];       // lr_k / (1 - b1^t)
+    // optional pattern INSIDE a segment: of every `period[k]` consecutive elements (from the segment's start) the first `head[k]`
+    // use ss_head[k] instead -- the SH block [N, 16, 3] of the reference holds two parameter groups interleaved per Gaussian
+    // (features: the 3 DC floats, lr 0.0025; features_rest: the 45 others, lr 0.000125; src/configs/frag_gs_v10.yaml:44-47)
+    int period[ADAM_MAX_SEG], head[ADAM_MAX_SEG];
+    float ss_head[ADAM_MAX_SEG];
 };
 
 __device__ __forceinline__ float seg_step(const AdamSegs &S, long long i) {
-    float s = S.ss[0];
+    float s = S.ss[0], sh = S.ss_head[0];
+    long long start = 0;
+    int per = S.period[0], hd = S.head[0];
 #pragma unroll
     for (int k = 1; k < ADAM_MAX_SEG; ++k)
-        if (k < S.n && i >= S.end[k - 1]) s = S.ss[k];
+        if (k < S.n && i >= S.end[k - 1]) { s = S.ss[k]; sh = S.ss_head[k]; start = S.end[k - 1]; per = S.period[k]; hd = S.head[k]; }
+    if (per > 0 && (int)((unsigned long long)(i - start) % (unsigned)per) < hd) s = sh;
     return s;
 }
 
@@ -100,12 +108,14 @@ l1_loss_grad_kernel(long long inner, const float *__restrict__ pred, long long p
     float acc = 0.f;
     const bool vec = (((uintptr_t)p | (uintptr_t)t | (uintptr_t)g) & 15) == 0;
     const long long n4 = vec ? inner >> 2 : 0;
+    typedef float nt4 __attribute__((ext_vector_type(4)));
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
-        const float4 a = reinterpret_cast<const float4 *>(p)[q], b = reinterpret_cast<const float4 *>(t)[q];
+        // three streams touched once each (a step's images: ~1 GB each at 25 frames of 480p x 23 channels): streaming accesses
+        const nt4 a = __builtin_nontemporal_load(reinterpret_cast<const nt4 *>(p) + q), b = __builtin_nontemporal_load(reinterpret_cast<const nt4 *>(t) + q);
         const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
         acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
         auto sg = [scale](float d) { return d > 0.f ? scale : (d < 0.f ? -scale : 0.f); };
-        reinterpret_cast<float4 *>(g)[q] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
+        __builtin_nontemporal_store((nt4){sg(d0), sg(d1), sg(d2), sg(d3)}, reinterpret_cast<nt4 *>(g) + q);
     }
     for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < inner; i += (long long)gridDim.x * 256) {
         const float d = p[i] - t[i];
@@ -149,9 +159,10 @@ extern "C" int splat_fill_f32(float *dst, size_t n, float value, splat_stream_t 
     return SPLAT_OK;
 }
 
-extern "C" int splat_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int nseg,
-                               const int64_t *seg_end_host, const float *seg_lr_host, float beta1, float beta2, float eps,
-                               int step, float grad_scale, splat_stream_t stream) {
+static int adam_step_impl(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int nseg,
+                          const int64_t *seg_end_host, const float *seg_lr_host, const int32_t *seg_period_host,
+                          const int32_t *seg_head_host, const float *seg_lr_head_host, float beta1, float beta2, float eps, int step,
+                          float grad_scale, splat_stream_t stream) {
     SPLAT_CHECK_ARG(n >= 0 && step >= 1, "bad sizes");
     SPLAT_CHECK_ARG(nseg >= 1 && nseg <= ADAM_MAX_SEG && seg_end_host && seg_lr_host, "1..SPLAT_ADAM_MAX_SEGMENTS segments");
     SPLAT_CHECK_ARG(seg_end_host[nseg - 1] == n, "the last segment must end at n");
@@ -165,6 +176,10 @@ extern "C" int splat_adam_step(int64_t n, float *param, const float *grad, float
     for (int k = 0; k < ADAM_MAX_SEG; ++k) {
         S.end[k] = k < nseg ? seg_end_host[k] : n;
         S.ss[k] = k < nseg ? (float)((double)seg_lr_host[k] / bc1) : 0.f;
+        S.period[k] = (k < nseg && seg_period_host) ? seg_period_host[k] : 0;
+        S.head[k] = (k < nseg && seg_head_host) ? seg_head_host[k] : 0;
+        S.ss_head[k] = (k < nseg && seg_lr_head_host) ? (float)((double)seg_lr_head_host[k] / bc1) : 0.f;
+        SPLAT_CHECK_ARG(S.period[k] >= 0 && S.head[k] >= 0 && S.head[k] <= S.period[k], "pattern: 0 <= head <= period");
         SPLAT_CHECK_ARG(k == 0 || k >= nseg || seg_end_host[k] >= seg_end_host[k - 1], "segments must be ascending");
     }
     const long long n4 = n >> 2;
@@ -175,4 +190,23 @@ extern "C" int splat_adam_step(int64_t n, float *param, const float *grad, float
                  grad, exp_avg, exp_avg_sq, S, beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, grad_scale);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
+}
+
+extern "C" int splat_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int nseg,
+                               const int64_t *seg_end_host, const float *seg_lr_host, float beta1, float beta2, float eps,
+                               int step, float grad_scale, splat_stream_t stream) {
+    return adam_step_impl(n, param, grad, exp_avg, exp_avg_sq, nseg, seg_end_host, seg_lr_host, nullptr, nullptr, nullptr, beta1,
+                          beta2, eps, step, grad_scale, stream);
+}
+
+// The same with a learning-rate PATTERN inside segments: of every seg_period[k] consecutive elements of segment k the first
+// seg_head[k] take seg_lr_head[k] (period 0: none) -- two parameter groups interleaved in one tensor, e.g. the reference's
+// features / features_rest inside the [N, 16, 3] SH block (period 48, head 3).
+extern "C" int splat_adam_step_pattern(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int nseg,
+                                       const int64_t *seg_end_host, const float *seg_lr_host, const int32_t *seg_period_host,
+                                       const int32_t *seg_head_host, const float *seg_lr_head_host, float beta1, float beta2,
+                                       float eps, int step, float grad_scale, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(seg_period_host && seg_head_host && seg_lr_head_host, "null pattern table");
+    return adam_step_impl(n, param, grad, exp_avg, exp_avg_sq, nseg, seg_end_host, seg_lr_host, seg_period_host, seg_head_host,
+                          seg_lr_head_host, beta1, beta2, eps, step, grad_scale, stream);
 }

@@ -744,6 +744,7 @@ struct GaussDynArgs {
     // SETS records (blend_bwd_sets_kernel): see GaussBwdArgs
     // (sources: nsrc entries; sfs[g] != 0 = per-frame source whose gradient is ADDED per frame at sdf[g] + f * sfs[g]; npf = their count)
     int nsrc, npf;
+    int spfq[SPLAT_MAX_SOURCES];   // per-frame source inside one 16-byte chunk of the record: that chunk's index, else -1
     int sc0[SPLAT_MAX_SOURCES], scn[SPLAT_MAX_SOURCES], sstride[SPLAT_MAX_SOURCES];
     float *sdf[SPLAT_MAX_SOURCES];
     long long sfs[SPLAT_MAX_SOURCES];
@@ -865,6 +866,21 @@ frames_gauss_bwd_dynamic_kernel(const GaussDynArgs A) {
                     if (A.sfs[g] == 0 || !A.sdf[g]) continue;
                     const int c0 = A.sc0[g], cn = A.scn[g];
                     float *dst = A.sdf[g] + (size_t)ff * (size_t)A.sfs[g] + (size_t)n * A.sstride[g];
+                    const int qc = A.spfq[g];
+                    if (qc >= 0) {   // at most four channels inside ONE 16-byte chunk of the record (track_gs: chunk 4): one lane adds them
+                        float4 v = af[0];
+#pragma unroll
+                        for (int c = 1; c < NS; ++c)
+                            if ((qc >> 2) == c) v = af[c];
+                        if (j == (qc & 3)) {
+                            const float e4[4] = {v.x, v.y, v.z, v.w};
+                            const int e0 = (NG + c0) & 3;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (e >= e0 && e - e0 < cn) dst[e - e0] += e4[e];
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int c = 0; c < NS; ++c) {
                         if (4 * c + j < NQ) {
@@ -1560,6 +1576,8 @@ extern "C" int splat_frames_gauss_backward_dynamic_sources(int F, int P, int I, 
         A.sc0[g] = src[g].c0; A.scn[g] = src[g].cn; A.sstride[g] = src[g].cn; A.sdf[g] = src[g].d_feature;
         A.sfs[g] = src[g].d_feature ? src[g].frame_stride : 0;
         if (A.sfs[g] != 0) ++A.npf;
+        const int k0 = SETS_NG + src[g].c0, k1 = k0 + src[g].cn - 1;
+        A.spfq[g] = (src[g].cn >= 1 && k0 / 4 == k1 / 4) ? k0 / 4 : -1;
     }
     return launch_gauss_bwd_dynamic_sets(A, (int)splat_blend_sets_pair_stride(C), (hipStream_t)stream);
 }

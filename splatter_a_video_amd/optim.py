@@ -18,18 +18,45 @@ from .parallel import FlatGradBucket
 MAX_SEGMENTS = 16
 
 
-def lr_segments(slices: Dict[str, tuple], lrs: Dict[str, float]):
+class PatternLR:
+    """Two parameter groups interleaved inside ONE tensor: of every ``period`` consecutive elements the first ``head`` take
+    ``head_lr``, the others ``lr``.  The reference keeps the SH coefficients as two parameters -- ``features`` (the DC triplet,
+    lr 0.0025) and ``features_rest`` (lr 0.000125; src/configs/frag_gs_v10.yaml:44-47) -- and concatenates them per forward; here
+    the block stays one [N, 16, 3] tensor: ``PatternLR(1.25e-4, head_lr=2.5e-3, period=48, head=3)``."""
+
+    def __init__(self, lr: float, head_lr: float, period: int, head: int):
+        if not (0 < head <= period):
+            raise ValueError("0 < head <= period")
+        self.lr, self.head_lr, self.period, self.head = float(lr), float(head_lr), int(period), int(head)
+
+    def __eq__(self, o):
+        return isinstance(o, PatternLR) and (self.lr, self.head_lr, self.period, self.head) == (o.lr, o.head_lr, o.period, o.head)
+
+    def __repr__(self):
+        return f"PatternLR({self.lr}, head_lr={self.head_lr}, period={self.period}, head={self.head})"
+
+
+def lr_segments(slices: Dict[str, tuple], lrs: Dict[str, float], patterns: bool = False):
     """(segment ends, segment learning rates) of the flat buffer: neighbouring groups with equal rates share a segment (the
-    kernel looks a segment up per element).  Pure host logic."""
-    ends, seg_lr = [], []
+    kernel looks a segment up per element).  With ``patterns``: also (period, head, head rate) per segment -- a ``PatternLR``
+    group keeps a segment of its own.  Pure host logic."""
+    ends, seg_lr, pat = [], [], []
     for n, (_, e) in slices.items():
-        r = float(lrs[n])
-        if seg_lr and seg_lr[-1] == r:
+        r = lrs[n]
+        if isinstance(r, PatternLR):
+            ends.append(e); seg_lr.append(r.lr); pat.append((r.period, r.head, r.head_lr))
+            continue
+        r = float(r)
+        if seg_lr and seg_lr[-1] == r and pat[-1] is None:
             ends[-1] = e
         else:
-            ends.append(e); seg_lr.append(r)
+            ends.append(e); seg_lr.append(r); pat.append(None)
     if len(ends) > MAX_SEGMENTS:
         raise ValueError(f"at most {MAX_SEGMENTS} learning-rate segments")
+    if patterns:
+        return ends, seg_lr, [p or (0, 0, 0.0) for p in pat]
+    if any(p is not None for p in pat):
+        raise ValueError("a PatternLR group needs the pattern-aware caller (FlatAdam)")
     return ends, seg_lr
 
 
@@ -38,7 +65,8 @@ class FlatAdam:
         if not bucket.flat_param.is_cuda:
             raise ValueError("FlatAdam steps GPU buffers (there is no CPU path)")
         self.bucket = bucket
-        self.lr = {n: (float(lr[n]) if isinstance(lr, dict) else float(lr)) for n in bucket.slices}
+        rate = lambda r: r if isinstance(r, PatternLR) else float(r)
+        self.lr = {n: rate(lr[n] if isinstance(lr, dict) else lr) for n in bucket.slices}
         self._build_segments()
         self.beta1, self.beta2, self.eps = float(betas[0]), float(betas[1]), float(eps)
         self.exp_avg = torch.zeros_like(bucket.flat_param)
@@ -46,10 +74,14 @@ class FlatAdam:
         self.t = 0
 
     def _build_segments(self) -> None:
-        ends, seg_lr = lr_segments(self.bucket.slices, self.lr)
+        ends, seg_lr, pat = lr_segments(self.bucket.slices, self.lr, patterns=True)
         self.nseg = len(ends)
         self.seg_end = (ctypes.c_int64 * self.nseg)(*ends)
         self.seg_lr = (ctypes.c_float * self.nseg)(*seg_lr)
+        self.has_pattern = any(p[0] for p in pat)
+        self.seg_period = (ctypes.c_int32 * self.nseg)(*[p[0] for p in pat])
+        self.seg_head = (ctypes.c_int32 * self.nseg)(*[p[1] for p in pat])
+        self.seg_head_lr = (ctypes.c_float * self.nseg)(*[p[2] for p in pat])
 
     def set_lr(self, lr: Union[float, Dict[str, float]]) -> None:
         """New learning rate(s) -- one number for every group or ``{group name: rate}`` for some of them -- from the next
@@ -61,7 +93,7 @@ class FlatAdam:
             if unknown:
                 raise KeyError(f"no parameter group(s) {unknown}; groups: {list(self.lr)}")
             for n, r in lr.items():
-                self.lr[n] = float(r)
+                self.lr[n] = r if isinstance(r, PatternLR) else float(r)
         else:
             for n in self.lr:
                 self.lr[n] = float(lr)
@@ -75,10 +107,16 @@ class FlatAdam:
             raise ValueError("grad must be a float32 GPU tensor with one entry per parameter")
         self.t += 1
         with torch.no_grad():
-            L.check(L.lib().splat_adam_step(
-                ctypes.c_int64(p.numel()), L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
-                L.ci(self.nseg), self.seg_end, self.seg_lr, L.cf(self.beta1), L.cf(self.beta2), L.cf(self.eps),
-                L.ci(self.t), L.cf(grad_scale), L.stream()))
+            if self.has_pattern:
+                L.check(L.lib().splat_adam_step_pattern(
+                    ctypes.c_int64(p.numel()), L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                    L.ci(self.nseg), self.seg_end, self.seg_lr, self.seg_period, self.seg_head, self.seg_head_lr,
+                    L.cf(self.beta1), L.cf(self.beta2), L.cf(self.eps), L.ci(self.t), L.cf(grad_scale), L.stream()))
+            else:
+                L.check(L.lib().splat_adam_step(
+                    ctypes.c_int64(p.numel()), L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                    L.ci(self.nseg), self.seg_end, self.seg_lr, L.cf(self.beta1), L.cf(self.beta2), L.cf(self.eps),
+                    L.ci(self.t), L.cf(grad_scale), L.stream()))
 
 
 class OwnerShardedAdam:
@@ -91,7 +129,7 @@ class OwnerShardedAdam:
         if not bucket.flat_param.is_cuda:
             raise ValueError("OwnerShardedAdam steps GPU buffers (there is no CPU path)")
         self.bucket, self.shards = bucket, shards
-        self.lr = {n: (float(lr[n]) if isinstance(lr, dict) else float(lr)) for n in bucket.slices}
+        self.lr = {n: (float(lr[n]) if isinstance(lr, dict) else float(lr)) for n in bucket.slices}   # (plain rates: no PatternLR here)
         self.beta1, self.beta2, self.eps = float(betas[0]), float(betas[1]), float(eps)
         lo, hi = shards.own
         if lo % 4 or hi % 4 or shards.b % 4:

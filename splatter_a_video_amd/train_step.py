@@ -42,14 +42,16 @@ from .dynamics import (GAUSSIAN_MAJOR, SEGMENT_MAJOR, FrameClock, frame_table, p
 from .frames import FrameBatch
 from .gs.fused_ops import compute_sh_into
 from .gs.point_ops import project_point_ortho
-from .optim import FlatAdam
+from .optim import FlatAdam, PatternLR
 from .parallel import FlatGradBucket, reduce_densify_batch
 
 TRAINABLE = ("pos_cubic_node", "rotation", "opacity", "scaling", "shs", "attrs")
 FROZEN = ("position", "rot_poly_feat", "rot_fourier_feat")          # :90 position is not optimised; :195-197 detached tables
-# learning rates of the reference's configuration (src/configs/frag_gs_v10.yaml:40-66; one rate for the SH block: the
-# coefficient-major [N,16,3] tensor is one parameter group here)
-REFERENCE_LR = {"pos_cubic_node": 6e-5, "rotation": 1e-3, "opacity": 5e-2, "scaling": 5e-3, "shs": 2.5e-3, "attrs": 1e-3}
+# learning rates of the reference's configuration (src/configs/frag_gs_v10.yaml:40-66).  The SH block is ONE [N,16,3] tensor here;
+# its two parameter groups -- features (the DC triplet of every Gaussian) and features_rest -- keep their own rates through a
+# pattern inside the Adam kernel's segment (optim.PatternLR: of every 48 floats the first 3)
+REFERENCE_LR = {"pos_cubic_node": 6e-5, "rotation": 1e-3, "opacity": 5e-2, "scaling": 5e-3,
+                "shs": PatternLR(1.25e-4, head_lr=2.5e-3, period=48, head=3), "attrs": 1e-3}
 
 
 @dataclass
@@ -206,7 +208,9 @@ class TrainingStep:
         ph.mark("model_eval")
         # ---- rigidity of the pair: neighbours of the sampled vertices in frame ids1, ARAP energy + gradient of both frames
         S = min(self.S, N)
-        sample = torch.from_numpy(np.stack([self.rng.choice(N, S) if N > S else np.arange(N) for _ in range(F)])).to(self.dev)
+        # (ascending: the Gaussians are in Morton order, so a wave of the neighbour search holds space neighbours; the energy is
+        #  a sum over the samples, their order does not matter)
+        sample = torch.from_numpy(np.stack([np.sort(self.rng.choice(N, S)) if N > S else np.arange(N) for _ in range(F)])).to(self.dev)
         nbr = pair_connectivity(self.pairs[:, 0], sample, K=self.knn_K)
         arap = pair_arap(self.pairs, sample, nbr, d_pairs=self.g_pairs, grad_scale=self.w.arap / F)
         ph.mark("knn_arap")
@@ -281,7 +285,7 @@ class TrainingStep:
     def set_lr(self, lr: Dict[str, float]) -> None:
         """new learning rate(s) from the next step on (the reference's ExponLRScheduler on the spline table,
         src/configs/frag_gs_v10.yaml:68-76: call it before each step); they survive a rebuild"""
-        self.lr.update({k: float(v) for k, v in lr.items()})
+        self.lr.update({k: (v if isinstance(v, PatternLR) else float(v)) for k, v in lr.items()})
         self.opt.set_lr(lr)
 
     def reset_opacity(self, ceiling: float = 0.01) -> None:

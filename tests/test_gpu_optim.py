@@ -104,3 +104,32 @@ def test_owner_sharded_adam_steps_its_block_and_the_replicated_slice_like_flat_a
     assert torch.equal(pb[lo:hi], pa[lo:hi]) and torch.equal(pb[sh.b:], pa[sh.b:])
     assert torch.equal(pb[:lo], before[:lo]) and torch.equal(pb[hi:sh.b], before[hi:sh.b])
     assert not torch.equal(pb[lo:hi], before[lo:hi])
+
+
+def test_pattern_learning_rates_are_two_parameter_groups_inside_one_tensor():
+    """optim.PatternLR: the SH block [N,16,3] as ONE tensor of the flat buffer whose DC triplets step with the rate of the
+    reference's `features` group and the other 45 floats with `features_rest`'s (src/configs/frag_gs_v10.yaml:44-47) -- against
+    torch.optim.Adam on the two tensors the reference keeps"""
+    from splatter_a_video_amd.optim import FlatAdam, PatternLR
+    from splatter_a_video_amd.parallel import FlatGradBucket
+    g = torch.Generator(device="cpu").manual_seed(5)
+    N = 3001
+    shs0, op0 = torch.randn(N, 16, 3, generator=g), torch.randn(N, 1, generator=g)
+    bucket = FlatGradBucket({"opacity": op0.cuda(), "shs": shs0.cuda(), "rotation": torch.randn(N, 4, generator=g).cuda()})
+    opt = FlatAdam(bucket, {"opacity": 5e-2, "shs": PatternLR(1.25e-4, head_lr=2.5e-3, period=48, head=3), "rotation": 1e-3}, eps=1e-15)
+    assert opt.has_pattern and opt.nseg == 3
+    dc = shs0[:, :1].clone().cuda().requires_grad_(True)
+    rest = shs0[:, 1:].clone().cuda().requires_grad_(True)
+    op = op0.clone().cuda().requires_grad_(True)
+    ref = torch.optim.Adam([{"params": [dc], "lr": 2.5e-3}, {"params": [rest], "lr": 1.25e-4}, {"params": [op], "lr": 5e-2}], eps=1e-15)
+    for _ in range(4):
+        gs_, go = torch.randn(N, 16, 3, generator=g).cuda(), torch.randn(N, 1, generator=g).cuda()
+        dc.grad, rest.grad, op.grad = gs_[:, :1].clone(), gs_[:, 1:].clone(), go
+        bucket.flat_grad.zero_()
+        bucket.grad("shs").copy_(gs_); bucket.grad("opacity").copy_(go)
+        ref.step()
+        opt.step()
+    got = bucket.params["shs"].detach()
+    torch.testing.assert_close(got[:, :1], dc.detach(), rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(got[:, 1:], rest.detach(), rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(bucket.params["opacity"].detach(), op.detach(), rtol=2e-5, atol=1e-7)

@@ -336,7 +336,8 @@ def test_opacity_reset_and_learning_rate_schedule_survive_a_rebuild():
     sc, clock, truth = _clip(N, W, H, T, seed=3)
     extr = _t(sc.extr)
     st = TS.TrainingStep(_perturbed(truth, 4), clock, W, H, F, extr, K=4, arap_samples=64,
-                         densify=TS.DensifyConfig(interval=2, start_iter=0, grad_threshold=1e-6, cameras_extent=60.0, min_opacity=0.02, seed=1))
+                         densify=TS.DensifyConfig(interval=2, start_iter=0, grad_threshold=1e-6, cameras_extent=60.0, min_opacity=0.005, seed=1))
+    # (min_opacity below the reset ceiling: the reference relies on the opacities' recovery between a reset and the next prune)
     t1, t2 = [0, 5, 9], [3, 1, 17]
     gt = TS.render_ground_truth(truth, clock, W, H, extr, t1, t2)
     st.step(t1, t2, gt)
