@@ -333,19 +333,21 @@ knn_tile_box_kernel(int N, int NT, const float *__restrict__ pts, long long pts_
     }
 }
 
-// Partial lists: block = 256 queries x one chunk (KNB_TILES tiles staged through LDS one after the other); a WAVE scans a tile only
-// if one of its 64 queries can have a candidate in the tile's box (the callers hand the queries in ascending index = Morton
-// order, so a wave's queries are neighbours and most tiles are far from all of them).  Only non-empty lists are written:
-// cnt[(b * G + c) * S + q] = entries of the list at pd / pi[((b * G + c) * S + q) * KT ..].
+// Partial lists: a WAVE = 64 queries x one chunk of KNB_TILES tiles; a wave scans a tile only if one of its queries can have a
+// candidate in the tile's box -- the callers hand the queries in ascending index = Morton order, so a wave's queries are
+// neighbours and four tiles of five are far from all of them.  The waves of a workgroup share nothing: the tile's points are
+// read through the SCALAR cache (their address is wave-uniform), eight points per trip -- no LDS staging, no barrier (with a
+// tile staged in LDS by the workgroup a tile was scanned whenever ANY of its 256 queries needed it, and the skipping waves
+// waited at the barriers; a wave staging for itself ran at a third of the occupancy).  Only non-empty lists are written:
+// cnt[(b * G + c) * S + q] = entries of the list at pd / pi[.. * KT].
 template <int KT>
 __global__ void __launch_bounds__(KB)
 knn_brute_partial_kernel(int N, int S, int G, int NT, const float *__restrict__ pts, long long pts_bs, const long long *__restrict__ qidx,
                          const float *__restrict__ tau, const float *__restrict__ box, float *__restrict__ pd, int *__restrict__ pi,
                          unsigned char *__restrict__ cnt) {
-    __shared__ float4 sp[KNB_TILE];
     const int c = blockIdx.x, b = blockIdx.z;
     const int q = blockIdx.y * KB + threadIdx.x;
-    const float *P = pts + (size_t)b * pts_bs;
+    const float *__restrict__ P = pts + (size_t)b * pts_bs;
     float qx = 0.f, qy = 0.f, qz = 0.f, bound = -1.f;   // (a lane past the queries takes no candidate)
     if (q < S) {
         const long long v = qidx[(size_t)b * S + q];
@@ -359,25 +361,30 @@ knn_brute_partial_kernel(int N, int S, int G, int NT, const float *__restrict__ 
     for (int tl = 0; tl < KNB_TILES; ++tl) {
         const int tile = c * KNB_TILES + tl;
         const int base = tile * KNB_TILE;
-        if (base >= N) break;   // block-uniform
-        __syncthreads();
-        for (int e = threadIdx.x; e < KNB_TILE; e += KB) {
-            const int id = base + e;
-            sp[e] = id < N ? make_float4(P[3 * (size_t)id], P[3 * (size_t)id + 1], P[3 * (size_t)id + 2], __int_as_float(id))
-                           : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        }
-        __syncthreads();
+        if (base >= N) break;   // uniform
         const float *bx = box + ((size_t)b * NT + tile) * 6;
         const float ex = fmaxf(fmaxf(bx[0] - qx, qx - bx[3]), 0.f), ey = fmaxf(fmaxf(bx[1] - qy, qy - bx[4]), 0.f),
                     ez = fmaxf(fmaxf(bx[2] - qz, qz - bx[5]), 0.f);
         // (the box distance is a lower bound of every point's distance up to rounding: compare against an inflated bound)
         if (__builtin_amdgcn_ballot_w64((ex * ex + ey * ey + ez * ez) * 0.999998f <= bound) == 0ull) continue;   // wave-uniform
         const int n = imin_(KNB_TILE, N - base);
-        for (int e = 0; e < n; ++e) {
-            const float4 p = sp[e];
-            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        const float *__restrict__ T = P + 3 * (size_t)base;
+        int e = 0;
+        for (; e + 8 <= n; e += 8) {   // 24 consecutive floats per trip: scalar loads
+            float v[24];
+#pragma unroll
+            for (int k = 0; k < 24; ++k) v[k] = T[3 * e + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float dx = qx - v[3 * k], dy = qy - v[3 * k + 1], dz = qz - v[3 * k + 2];
+                const float d = dx * dx + dy * dy + dz * dz;
+                if (d <= bound) knn_insert<KT>(bd, bi, d, base + e + k);   // the K nearest all lie within the bound
+            }
+        }
+        for (; e < n; ++e) {
+            const float dx = qx - T[3 * e], dy = qy - T[3 * e + 1], dz = qz - T[3 * e + 2];
             const float d = dx * dx + dy * dy + dz * dz;
-            if (d <= bound) knn_insert<KT>(bd, bi, d, __float_as_int(p.w));   // the K nearest all lie within the bound
+            if (d <= bound) knn_insert<KT>(bd, bi, d, base + e);
         }
     }
     if (q < S) {

@@ -139,8 +139,11 @@ extern "C" int splat_l1_loss_grad(int F, int64_t inner, const float *pred, int64
     if (F == 0 || inner == 0) return SPLAT_OK;
     SPLAT_CHECK_ARG(pred && target && grad, "null pointer");
     SPLAT_CHECK_ARG(pred_frame_stride >= inner, "pred_frame_stride below the block size");
+    // few, fat workgroups: every workgroup ends with ONE atomic on the same address (25 600 of them serialised were half of the
+    // kernel's time at 25 frames x 1024 workgroups)
     long long blocks = ((inner >> 2) + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    const long long cap = F >= 16 ? 96 : (F >= 4 ? 384 : 1536);
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     SPLAT_LAUNCH("l1_loss_grad", l1_loss_grad_kernel, dim3((unsigned)blocks, (unsigned)F), dim3(256), 0, (hipStream_t)stream,
                  (long long)inner, pred, (long long)pred_frame_stride, target, scale, grad, loss_sum);
