@@ -28,6 +28,7 @@ The oracle (oracle/) is only used for the `cpu_baseline` leg (rank 0, N=1, bound
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import statistics
@@ -217,8 +218,12 @@ class FrameRenderer:
             src["shs"] = sc.shs
         else:
             src["feature"] = sc.feature
+        # the reference's training frame (render_iter of its dynamic Gaussians): the first three of the 19 attribute channels are
+        # track_gs = position(ids2) of a pair frame (src/trainer_fragGS.py:506-511), read per frame as a feature source; the
+        # other 16 are the model's attributes (mask 1 + pos_poly_feat 12 + dino 3, src/configs/frag_gs_v10.yaml:115-118)
+        self.track = dynamic and mode == "render_iter"
         if mode in ("render_iter", "render_iter_frame", "ref_flow"):
-            attrs = np.random.default_rng(7).uniform(-1, 1, size=(N, 19)).astype(np.float32)
+            attrs = np.random.default_rng(7).uniform(-1, 1, size=(N, 16 if self.track else 19)).astype(np.float32)
             if mode == "render_iter_frame":
                 # the per-frame renderer takes its attributes by name, as the reference's model holds them: one parameter
                 # tensor each (views of ONE [N, 19] parameter made autograd copy both slices per frame in either direction)
@@ -284,6 +289,12 @@ class FrameRenderer:
         if self.mode == "render_iter":
             pt.batch = FrameBatch(n, N, self.W, self.H, 3 + 1 + 19, device, want_abs=True)
             pt.dL_sets = [rep(self.dL_dout), rep(self.dL_depth), rep(self.dL_attr)]
+            if self.track:   # pair frames of the part's frames, their positions and the gradient those receive
+                from splatter_a_video_amd.dynamics import frame_table
+                pair = [int((17 * t + 11) % self.sc.F) for t in pt.frames]
+                pt.tab2 = frame_table(self.clock, [t if t != u else (t + 1) % self.sc.F for t, u in zip(pair, pt.frames)], device)
+                pt.pos2 = torch.empty(n, N, 3, device=device)
+                pt.g_pos2 = torch.empty(n, N, 3, device=device)
         else:
             pt.batch = FrameBatch(n, N, self.W, self.H, self.C, device)
             pt.dL_all = rep(self.dL_dout)
@@ -331,14 +342,20 @@ class FrameRenderer:
         rgb = gs.compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"])      # once per step (constant view direction)
         sets = [dict(feature=rgb, bg=self.sc.bg, taps=True), dict(feature="depth", bg=1.0),
                 dict(feature=p["attrs"], bg=0.0, detach_opacity=True)]
-        if self.dynamic:   # the reference's real training frame: its dynamic Gaussians through the three blends
-            from splatter_a_video_amd.dynamics import SEGMENT_MAJOR
+        if self.dynamic:   # the reference's real training frame: its dynamic Gaussians through the three blends, track_gs included
+            from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, positions_batch_backward, positions_batch_forward
+            I = self.clock.interval_num
+            positions_batch_forward(part.tab2, self.position, p["pos_cubic_node"], I, SEGMENT_MAJOR, out=part.pos2)
+            L.check(L.lib().splat_fill_f32(L.ptr(part.g_pos2), ctypes.c_size_t(part.g_pos2.numel()), L.cf(0.0), L.stream()))
+            sets[2] = dict(feature=[part.pos2, p["attrs"]], bg=0.0, detach_opacity=True)
+            sink = {k: g[k] for k in ("pos_cubic_node", "rotation", "opacity", "scaling")}
+            sink.update({"feature:1": part.g_pos2, "feature:2": g["attrs"]})
             out = part.batch.render_dynamic_sets(
                 self.clock, part.frames, self.extr, sets, position=self.position, pos_cubic_node=p["pos_cubic_node"],
                 rotation=p["rotation"], rot_poly_feat=self.rot_poly, rot_fourier_feat=self.rot_fourier, opacity=p["opacity"],
-                scaling=p["scaling"], cubic_layout=SEGMENT_MAJOR, K=20,
-                grad_sink={k: g[k] for k in ("pos_cubic_node", "rotation", "opacity", "scaling")})
+                scaling=p["scaling"], cubic_layout=SEGMENT_MAJOR, K=20, grad_sink=sink)
             torch.autograd.backward(list(out[:3]), part.dL_sets)
+            positions_batch_backward(part.tab2, part.g_pos2, I, SEGMENT_MAJOR, None, g["pos_cubic_node"])
             self.last = dict(M=self.last.get("M", 0), T=self.batch.T)
             return
         out = part.batch.render_sets(p["xyz"], p["scale"], p["rotate"], p["opacity"], sets, part.off_all, self.extr, K=20,
@@ -486,7 +503,9 @@ class FrameRenderer:
                 sets = [dict(feature=rgb, bg=self.sc.bg, taps=True), dict(feature="depth", bg=1.0),
                         dict(feature=p["attrs"], bg=0.0, detach_opacity=True)]
                 if self.dynamic:
-                    from splatter_a_video_amd.dynamics import SEGMENT_MAJOR
+                    from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, positions_batch_forward
+                    positions_batch_forward(part.tab2, self.position, p["pos_cubic_node"], self.clock.interval_num, SEGMENT_MAJOR, out=part.pos2)
+                    sets[2] = dict(feature=[part.pos2, p["attrs"]], bg=0.0, detach_opacity=True)
                     return part.batch.render_dynamic_sets(
                         self.clock, part.frames, self.extr, sets, position=self.position, pos_cubic_node=p["pos_cubic_node"],
                         rotation=p["rotation"], rot_poly_feat=self.rot_poly, rot_fourier_feat=self.rot_fourier,
@@ -1078,8 +1097,10 @@ def main():
             "exposed_comm_frac": None if not comm2 else comm2.get("exposed_comm_frac"), "comm": comm2,
             "config": {"workload": f"{a.gaussians} dynamic Gaussians of the reference's model (spline position, time-varying "
                                    f"rotation; dynamic_gaussian_with_base_point_cloud.py:171-250), {a.frames} frames/step, "
-                                   f"{a.width}x{a.height}, rgb (SH deg 3, enhanced K=20, taps) + depth + 19 attribute channels, "
-                                   "fwd+bwd + Adam", "equivalent_flags": "--render-iter --dynamic",
+                                   f"{a.width}x{a.height}, rgb (SH deg 3, enhanced K=20, taps) + depth + 19 attribute channels "
+                                   "= track_gs (position of a pair frame, per frame; src/trainer_fragGS.py:506-511) + 16 model "
+                                   "attributes, fwd+bwd (incl. track_gs' gradient back into the pair frames' spline segments) + Adam",
+                       "equivalent_flags": "--render-iter --dynamic",
                        "tile_pairs_M": R2.last.get("M")}})
         del R2
         # third workload: the reference's WHOLE training step composed from the native pieces (train_step.py)
