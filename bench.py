@@ -128,6 +128,9 @@ def parse():
                     help="the reference's real frame (row a1, dptr_ortho_enhanced.py:205-383): rgb through alpha_blending_enhanced "
                          "(K = 20, ndc + abs_ndc taps), depth (bg = 1) and 19 attribute channels (opacity detached) per frame, "
                          "through the native OrthoEnhancedRenderer (per-frame operators, shared forward pass)")
+    ap.add_argument("--attr-channels", type=int, default=19,
+                    help="--render-iter (frame batch): width of the attribute set (the trainer's plans: 19 = track_gs + its render "
+                         "attributes; 1 / 3 / 4 = ['mask_attribute'] / ['dino_attribute'] / both, src/trainer_fragGS.py:657,1214,1272)")
     ap.add_argument("--train-step", action="store_true",
                     help="the reference's whole training step composed from the native pieces (splatter_a_video_amd/train_step.py; "
                          "src/trainer_fragGS.py:736-790): two dynamic evaluations, the training frame with track_gs = "
@@ -187,7 +190,7 @@ class FrameRenderer:
     one flat bucket (views), one all-reduce + one Adam step per gradient step."""
 
     def __init__(self, sc, device, frames, C_extra=0, mode="batch", dynamic=False, stale_overlap=False, optimizer=True,
-                 halves=False):
+                 halves=False, attr_channels=19):
         self.sc = sc
         self.mode = mode
         self.dynamic = dynamic
@@ -223,7 +226,8 @@ class FrameRenderer:
         # other 16 are the model's attributes (mask 1 + pos_poly_feat 12 + dino 3, src/configs/frag_gs_v10.yaml:115-118)
         self.track = dynamic and mode == "render_iter"
         if mode in ("render_iter", "render_iter_frame", "ref_flow"):
-            attrs = np.random.default_rng(7).uniform(-1, 1, size=(N, 16 if self.track else 19)).astype(np.float32)
+            self.A = 19 if (self.track or mode != "render_iter") else int(attr_channels)
+            attrs = np.random.default_rng(7).uniform(-1, 1, size=(N, 16 if self.track else self.A)).astype(np.float32)
             if mode == "render_iter_frame":
                 # the per-frame renderer takes its attributes by name, as the reference's model holds them: one parameter
                 # tensor each (views of ONE [N, 19] parameter made autograd copy both slices per frame in either direction)
@@ -258,7 +262,7 @@ class FrameRenderer:
             from splatter_a_video_amd.renderer import OrthoEnhancedRenderer
             self.renderer = OrthoEnhancedRenderer(densify_abs_grad_enable=True)
             self.dL_depth = torch.randn(1, self.H, self.W, generator=g).to(device)
-            self.dL_attr = torch.randn(19, self.H, self.W, generator=g).to(device)
+            self.dL_attr = torch.randn(self.A, self.H, self.W, generator=g).to(device)
         # the step's frames as ONE frame batch, or (--overlap) as two half-batches
         self.parts = []
         if self.mode in ("batch", "render_iter"):
@@ -287,7 +291,7 @@ class FrameRenderer:
         rep = lambda t: t.unsqueeze(0).repeat(n, 1, 1, 1).contiguous()
         pt.off_all = None if self.dynamic else torch.stack(self.offs[lo:hi]).contiguous()
         if self.mode == "render_iter":
-            pt.batch = FrameBatch(n, N, self.W, self.H, 3 + 1 + 19, device, want_abs=True)
+            pt.batch = FrameBatch(n, N, self.W, self.H, 3 + 1 + self.A, device, want_abs=True)
             pt.dL_sets = [rep(self.dL_dout), rep(self.dL_depth), rep(self.dL_attr)]
             if self.track:   # pair frames of the part's frames, their positions and the gradient those receive
                 from splatter_a_video_amd.dynamics import frame_table
@@ -886,7 +890,7 @@ def main():
     # setup, not workload: one step of a 512-Gaussian 64x64 scene through the same operators loads the library's code
     # objects and initialises the allocator, so that `--warmup 0` does not time HIP module loading
     tiny = make_scene(512, 64, 64, F=clip, C=a.channels, seed=1)
-    Rt = FrameRenderer(tiny, dev, frames[:2], a.channels, mode=mode, dynamic=a.dynamic, optimizer=not a.no_optimizer)
+    Rt = FrameRenderer(tiny, dev, frames[:2], a.channels, mode=mode, dynamic=a.dynamic, optimizer=not a.no_optimizer, attr_channels=a.attr_channels)
     Rt.step(collective=False)
     torch.cuda.synchronize()
     del Rt, tiny
@@ -928,7 +932,7 @@ def main():
         return
 
     R = FrameRenderer(sc, dev, frames, a.channels, mode=mode, dynamic=a.dynamic, stale_overlap=a.stale_overlap,
-                      optimizer=not a.no_optimizer, halves=a.overlap)
+                      optimizer=not a.no_optimizer, halves=a.overlap, attr_channels=a.attr_channels)
     dt = timed(R.step, R.finish)
     R.check_sorts()   # the sync-free sorts of the timed steps all fitted their capacity (raises otherwise)
 
@@ -1125,7 +1129,7 @@ def main():
                                               "synchronous: all-reduce -> Adam -> next forward" if R.opt is not None else
                                               "synchronous all-reduce, no optimiser")
         line = {
-            "metric": "rendered frames/sec fwd+bwd @480p, 300k Gaussians" + (" (render_iter: three blends, 23 channels)"
+            "metric": "rendered frames/sec fwd+bwd @480p, 300k Gaussians" + (f" (render_iter: three blends, {4 + getattr(R, 'A', 19)} channels)"
                                                                              if mode.startswith("render_iter") or mode == "ref_flow" else ""),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
