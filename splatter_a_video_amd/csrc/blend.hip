@@ -32,6 +32,10 @@
 #include "common.h"
 
 // tuning knobs (compile time; tools/build_variants.sh builds alternatives for A/B runs)
+#ifndef BLEND_FWD8_MINW
+#define BLEND_FWD8_MINW 4  // 5 .. 8 channels (the trainer's small plans: rgb + depth + 1 .. 4 attributes, with the K = 20 id lists): at the
+                           // narrow rows' 80 registers the enhanced instantiation spills 172 bytes per lane (128 us per frame at c2)
+#endif
 #ifndef BLEND_FWD_U
 #define BLEND_FWD_U 4      // survivors evaluated per trip in the forward (narrow channel counts)
 #endif
@@ -683,7 +687,7 @@ struct FwdCfg {
 #define BLEND_FWD_MF_MINW 3
 #endif
 template <int CH, bool ENH, bool BIAS, bool EXACT>
-__global__ void __launch_bounds__(256, (CH <= 8 ? BLEND_FWD_MINW : CH <= 16 ? 4 : (BLEND_FWD_MFMA && !BIAS) ? BLEND_FWD_MF_MINW : 3))
+__global__ void __launch_bounds__(256, (CH <= 4 ? BLEND_FWD_MINW : CH <= 8 ? BLEND_FWD8_MINW : CH <= 16 ? 4 : (BLEND_FWD_MFMA && !BIAS) ? BLEND_FWD_MF_MINW : 3))
 blend_fwd_kernel(const BlendArgs B) {
     constexpr int SB = FwdCfg<CH>::SB;
     constexpr bool MF = BLEND_FWD_MFMA && CH >= 16 && !BIAS;
