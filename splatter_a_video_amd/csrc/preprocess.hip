@@ -64,6 +64,54 @@ preprocess_fwd_kernel(int P, const float *__restrict__ xyz, const float *__restr
     if (tiles) tiles[i] = otiles;
 }
 
+// Frame batch of STATIC Gaussians under ONE orthographic camera (the default workload of bench.py, FrameBatch.render / render_sets):
+// the 3D covariance and -- the orthographic Jacobian being constant -- the 2D covariance do not depend on the frame, so a
+// thread reads its Gaussian's parameters and runs cov3d + EWA ONCE and then walks its slice of the frames: per frame only the
+// offset in (12 B) and uv / depth / conic / radius out (28 B), where the frame-as-grid.y kernel above re-read the 40 bytes of
+// parameters and redid the covariance per frame (PMC round 4: 579 MB moved for 342 algorithmic per 25-frame launch).  Same
+// The single-frame operator (splat_preprocess_ortho_forward) runs THIS kernel with F = 1, so that a frame of a batch and the
+// per-frame operator give the same bits (the compiler contracts the covariance arithmetic differently in different kernels:
+// the frame-as-grid.y kernel's conic differed in the last bit on 6 % of the Gaussians).
+__global__ void __launch_bounds__(PP_BLOCK)
+preprocess_fwd_frames_kernel(int F, int P, const float *__restrict__ xyz, const float *__restrict__ offset,
+                             const float *__restrict__ scales, const float4 *__restrict__ uquats, const float *__restrict__ extr,
+                             int W, int H, float nearest, float extent, float2 *__restrict__ uv, float *__restrict__ depth,
+                             float *__restrict__ conic, int *__restrict__ radius, int *__restrict__ tiles) {
+    const int i = blockIdx.x * PP_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    Cam c;
+    load_cam(nullptr, extr, c);
+    const float p0[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    const float4 q4 = uquats[i];
+    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+    float c3[6], a[3], b[3], t[3], Jm[4], cov[3];
+    cov3d_pt(s, q, c3);
+    ewa_T<true>(c, p0, W, H, a, b, t, Jm);     // (orthographic: a, b do not depend on the position)
+    ewa_cov2d<true>(a, b, c3, cov);
+    const int per = (F + gridDim.y - 1) / gridDim.y;
+    const int f0 = blockIdx.y * per, f1 = imin_(F, f0 + per);
+    for (int f = f0; f < f1; ++f) {
+        const size_t fo = (size_t)f * P + i;
+        float p[3] = {p0[0], p0[1], p0[2]};
+        if (offset) {
+            const float *o = offset + fo * 3;
+            p[0] += o[0]; p[1] += o[1]; p[2] += o[2];
+        }
+        float u, v, d;
+        const bool cull = project_ortho_pt(c, p[0], p[1], p[2], W, H, nearest, extent, u, v, d);
+        u = cull ? 0.f : u; v = cull ? 0.f : v; d = cull ? 0.f : d;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        int orad = 0, otiles = 0;
+        if (d != 0.f) ewa_finish_pt<true>(cov, make_float2(u, v), W, H, o0, o1, o2, orad, otiles);
+        uv[fo] = make_float2(u, v);
+        depth[fo] = d;
+        conic[3 * fo] = o0; conic[3 * fo + 1] = o1; conic[3 * fo + 2] = o2;
+        radius[fo] = orad;
+        if (tiles) tiles[fo] = otiles;
+    }
+}
+
 template <bool ACC>
 __device__ __forceinline__ void put(float *p, float v) {
     if (ACC) *p += v;
@@ -1201,6 +1249,16 @@ extern "C" int splat_preprocess_forward_batch_cam(int F, int P, const float *xyz
     SPLAT_CHECK_ARG(F == 1 || offsets || cam->extr_frame_stride != 0,
                     "several frames of static Gaussians need per-frame offsets [F,P,3] or per-frame cameras");
     const dim3 grid = pp_grid(P);
+    if (!cam->perspective && (cam->extr_frame_stride == 0 || F == 1)) {
+        // one orthographic camera: covariance once per Gaussian, a thread walks its slice of the frames
+        unsigned slices = 1;
+        while (grid.x * slices < 4096u && slices * 2 <= (unsigned)F) slices *= 2;
+        SPLAT_LAUNCH("preprocess_fwd", preprocess_fwd_frames_kernel, dim3(grid.x, slices), dim3(PP_BLOCK), 0, (hipStream_t)stream, F, P,
+                     xyz, offsets, scales, (const float4 *)uquats, cam->extr, W, H, nearest, extent, (float2 *)uv, depth, conic, radius,
+                     (int *)nullptr);
+        SPLAT_POST_LAUNCH();
+        return SPLAT_OK;
+    }
     if (cam->perspective)
         SPLAT_LAUNCH("preprocess_fwd", preprocess_fwd_kernel<false>, dim3(grid.x, F), dim3(PP_BLOCK), 0, (hipStream_t)stream, P,
                      xyz, offsets, scales, (const float4 *)uquats, cam->intr, cam->extr, (long long)cam->intr_frame_stride,
@@ -1321,9 +1379,9 @@ extern "C" int splat_preprocess_ortho_forward(int P, const float *xyz, const flo
     SPLAT_CHECK_ARG(P >= 0 && W > 0 && H > 0, "bad sizes");
     if (P == 0) return SPLAT_OK;
     SPLAT_CHECK_ARG(xyz && scales && uquats && extr && uv && depth && conic && radius && tiles, "null pointer");
-    SPLAT_LAUNCH("preprocess_fwd", preprocess_fwd_kernel<true>, pp_grid(P), dim3(PP_BLOCK), 0, (hipStream_t)stream, P, xyz,
-                 offset, scales, (const float4 *)uquats, (const float *)nullptr, extr, 0ll, 0ll, W, H, nearest, extent,
-                 (float2 *)uv, depth, conic, radius, tiles);
+    // (the frame batch's kernel at F = 1: a batch's frame and this operator give the same bits)
+    SPLAT_LAUNCH("preprocess_fwd", preprocess_fwd_frames_kernel, pp_grid(P), dim3(PP_BLOCK), 0, (hipStream_t)stream, 1, P, xyz, offset,
+                 scales, (const float4 *)uquats, extr, W, H, nearest, extent, (float2 *)uv, depth, conic, radius, tiles);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;
 }
