@@ -1150,6 +1150,8 @@ def main():
                        "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
                        "tile_pairs_M": M, "channels": R.C, "parallelism": par,
                        "gaussian_order": "random" if a.no_spatial_order else "morton (densify.spatial_order at setup)",
+                       "frame_inputs": "the frames' position offsets / frame tables are built once per clip at set-up; the timed step "
+                                       "launches this library's kernels only",
                        "path": ("the reference's real training frame as a frame batch: its dynamic Gaussians (per-frame evaluation "
                                 "inside the batched preprocess) through render_iter's three blends (rgb enhanced K=20 + depth + 19 "
                                 "attribute channels), one forward over the 23-channel row, one backward pass for the three sets"
