@@ -1,6 +1,7 @@
 """The block-level backward kernels of a frame batch (blend_bwd_mfma_kernel with the forward's cull flags,
-blend_bwd_sets_kernel) are what SPLAT_BWD_QUARTERS=0 selects; by default a batch runs the quarter-list kernels.  The switch
-is read once per process, so the oracle tests of the batch path run again in a child process with the block-level kernels."""
+blend_bwd_sets_kernel) are what the library option "bwd_quarters" = 0 selects; by default a batch runs the quarter-list kernels.
+The option is set through the ABI (splat_set_option) for the duration of a test: the oracle tests of the batch path run again,
+in this process, on the block-level kernels."""
 import os
 import subprocess
 import sys
@@ -10,14 +11,25 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _oracle_cases():
+    import test_gpu_frames_oracle as T
+    return [("render", T.test_frame_batch_render_against_oracle_and_reference_geometry, {}),
+            ("render_sets_std", T.test_render_sets_against_oracle, {"std": 1}),
+            ("render_sets_generic", T.test_render_sets_against_oracle, {"std": 0}),
+            ("per_frame_cameras_render", T.test_per_frame_cameras_against_oracle, {"entry": "render"}),
+            ("per_frame_cameras_render_sets", T.test_per_frame_cameras_against_oracle, {"entry": "render_sets"}),
+            ("wide_row", T.test_wide_row_batch_against_oracle, {})]
+
+
 @pytest.mark.gpu
-def test_frame_batch_oracle_tests_with_block_level_backward():
-    env = dict(os.environ, SPLAT_BWD_QUARTERS="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_frames_oracle.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "render_against or render_sets_against or per_frame_cameras or wide", "-p", "no:cacheprovider"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+@pytest.mark.parametrize("case", ["render", "render_sets_std", "render_sets_generic", "per_frame_cameras_render",
+                                  "per_frame_cameras_render_sets", "wide_row"])
+def test_frame_batch_oracle_tests_with_block_level_backward(case, oracle_mod, lib_option):
+    fn, kw = next((f, k) for n, f, k in _oracle_cases() if n == case)
+    lib_option("bwd_quarters", 0)
+    if "std" in kw:
+        kw = dict(kw, lib_option=lib_option)
+    fn(oracle_mod, **kw)
 
 
 @pytest.mark.gpu
@@ -85,15 +97,27 @@ def test_single_frame_backward_with_and_without_the_forwards_cull_words(C, with_
 
 
 @pytest.mark.gpu
-def test_sort_and_pair_map_with_slot_keys():
+@pytest.mark.parametrize("case", ["sort_5000", "sort_crowded", "ties_and_empty", "render"])
+def test_sort_and_pair_map_with_slot_keys(case, gpu, oracle_mod, lib_option):
     """The pair map's low key word is (Gaussian id, tile index inside the splat's rectangle) whenever the two fit 32 bits --
-    every size under test.  SPLAT_BIN_SLOT_KEYS=1 (read once per process) selects the other form (pair slot in the key, ids
-    through the `owner` workspace: what 1M Gaussians on more than 4096 tiles get): the sort's bit-exactness tests, the pair-map
-    test and the batch's oracle test run again in a child process on that form."""
-    env = dict(os.environ, SPLAT_BIN_SLOT_KEYS="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_frames_oracle.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "sort or pair_map or render_against", "-p", "no:cacheprovider"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+    every size under test.  The library option "bin_slot_keys" = 1 selects the other form (pair slot in the key, ids through the
+    `owner` workspace: what 1M Gaussians on more than 4096 tiles get): the sort's bit-exactness tests and the batch's oracle test
+    run again on that form."""
+    import test_gpu_frames_oracle as T
+    import test_gpu_parity as P
+    lib_option("bin_slot_keys", 1)
+    if case == "sort_5000":
+        P.test_sort_gaussian_bit_exact(gpu, oracle_mod, 5000, 256, 256, 2.0)
+    elif case == "sort_crowded":
+        P.test_sort_gaussian_bit_exact(gpu, oracle_mod, *_crowded_sort_case())
+    elif case == "ties_and_empty":
+        P.test_sort_gaussian_ties_and_empty(gpu, oracle_mod)
+    else:
+        T.test_frame_batch_render_against_oracle_and_reference_geometry(oracle_mod)
+
+
+def _crowded_sort_case():
+    """the largest parametrisation of test_sort_gaussian_bit_exact (a tile above 2048 keys)"""
+    import test_gpu_parity as P
+    marks = [m for m in P.test_sort_gaussian_bit_exact.pytestmark if m.name == "parametrize"]
+    return max(marks[0].args[1], key=lambda c: c[0] * c[3])
