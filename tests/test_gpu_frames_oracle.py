@@ -96,23 +96,24 @@ def test_frame_batch_render_against_oracle_and_reference_geometry(oracle_mod):
     assert (B.radii_max.cpu().numpy() == np.max([r["radius"] for r in per], 0)).mean() > 0.9999
 
 
-@pytest.mark.parametrize("std", [1, 0])
-def test_render_sets_against_oracle(oracle_mod, std, lib_option):
+@pytest.mark.parametrize("std,width", [(1, 19), (0, 19), (1, 1), (1, 3), (1, 4)])
+def test_render_sets_against_oracle(oracle_mod, std, width, lib_option):
     """render_sets = the reference's render_iter over a batch: rgb enhanced (K = 20 ids, ndc + abs_ndc taps), depth (bg 1),
     19 attribute channels with opacity.detach() -- one forward over the 23-channel row, then the ONE-pass three-set backward
     (blend_bwd_sets_quarter_kernel: the renderer's plan staging the forward's records, option "sets_std" = 1, or the generic slot
     -> channel routing on its own packed records, "sets_std" = 0) and frames_gauss_bwd_static_sets -- against three oracle
-    blends per frame."""
+    blends per frame.  The third set's width also takes the trainer's other plans (3 | 1 | 1, 3 | 1 | 3, 3 | 1 | 4: the mask,
+    a track or a dino feature alone), which the same kernel serves through the slot routing."""
     lib_option("sets_std", std)
     F, K = 3, 20
     g, opacity, off, rng = _c1_scene(F, seed=3)
     N, W, H = g["xyz"].shape[0], int(g["W"]), int(g["H"])
     rgb = rng.uniform(size=(N, 3)).astype(np.float32)
-    attrs = rng.uniform(-1, 1, size=(N, 19)).astype(np.float32)
-    gs_ = [rng.normal(size=(F, c, H, W)).astype(np.float32) for c in (3, 1, 19)]
+    attrs = rng.uniform(-1, 1, size=(N, width)).astype(np.float32)
+    gs_ = [rng.normal(size=(F, c, H, W)).astype(np.float32) for c in (3, 1, width)]
     p = {k: _t(v, True) for k, v in dict(xyz=g["xyz"], scales=g["scale"], uquats=g["rotate"], opacity=opacity, rgb=rgb,
                                          attrs=attrs).items()}
-    B = FrameBatch(F, N, W, H, 23, "cuda", want_abs=True)
+    B = FrameBatch(F, N, W, H, 4 + width, "cuda", want_abs=True)
     sets = [dict(feature=p["rgb"], bg=0.2, taps=True), dict(feature="depth", bg=1.0),
             dict(feature=p["attrs"], bg=0.0, detach_opacity=True)]
     o_rgb, o_dep, o_att, ids = B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], sets, _t(off), _t(g["extr"]), K=K)
@@ -215,8 +216,8 @@ def test_render_dynamic_sets_against_oracle_with_reference_parameters(oracle_mod
     host["scaling"] = host["scaling"] + 2.0      # a few pixels wide under that camera (same raw-parameter chain)
     rng = np.random.default_rng(8)
     rgb = rng.uniform(size=(N, 3)).astype(np.float32)
-    attrs = rng.uniform(-1, 1, size=(N, 19)).astype(np.float32)
-    gs_ = [rng.normal(size=(F, c, H, W)).astype(np.float32) for c in (3, 1, 19)]
+    attrs = rng.uniform(-1, 1, size=(N, width)).astype(np.float32)
+    gs_ = [rng.normal(size=(F, c, H, W)).astype(np.float32) for c in (3, 1, width)]
     p = {k: _t(v, k not in ("rot_poly_feat", "rot_fourier_feat", "position")) for k, v in host.items()}
     p["pos_cubic_node"] = to_segment_major(_t(host["pos_cubic_node"]), I).requires_grad_(True)
     t_rgb, t_att = _t(rgb, True), _t(attrs, True)
