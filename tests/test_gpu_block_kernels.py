@@ -14,15 +14,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _oracle_cases():
     import test_gpu_frames_oracle as T
     return [("render", T.test_frame_batch_render_against_oracle_and_reference_geometry, {}),
-            ("render_sets_std", T.test_render_sets_against_oracle, {"std": 1}),
-            ("render_sets_generic", T.test_render_sets_against_oracle, {"std": 0}),
+            ("render_sets_std", T.test_render_sets_against_oracle, {"std": 1, "width": 19}),
+            ("render_sets_generic", T.test_render_sets_against_oracle, {"std": 0, "width": 19}),
+            ("render_sets_mask", T.test_render_sets_against_oracle, {"std": 1, "width": 1}),
             ("per_frame_cameras_render", T.test_per_frame_cameras_against_oracle, {"entry": "render"}),
             ("per_frame_cameras_render_sets", T.test_per_frame_cameras_against_oracle, {"entry": "render_sets"}),
             ("wide_row", T.test_wide_row_batch_against_oracle, {})]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["render", "render_sets_std", "render_sets_generic", "per_frame_cameras_render",
+@pytest.mark.parametrize("case", ["render", "render_sets_std", "render_sets_generic", "render_sets_mask", "per_frame_cameras_render",
                                   "per_frame_cameras_render_sets", "wide_row"])
 def test_frame_batch_oracle_tests_with_block_level_backward(case, oracle_mod, lib_option):
     fn, kw = next((f, k) for n, f, k in _oracle_cases() if n == case)

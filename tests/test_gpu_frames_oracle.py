@@ -216,8 +216,8 @@ def test_render_dynamic_sets_against_oracle_with_reference_parameters(oracle_mod
     host["scaling"] = host["scaling"] + 2.0      # a few pixels wide under that camera (same raw-parameter chain)
     rng = np.random.default_rng(8)
     rgb = rng.uniform(size=(N, 3)).astype(np.float32)
-    attrs = rng.uniform(-1, 1, size=(N, width)).astype(np.float32)
-    gs_ = [rng.normal(size=(F, c, H, W)).astype(np.float32) for c in (3, 1, width)]
+    attrs = rng.uniform(-1, 1, size=(N, 19)).astype(np.float32)
+    gs_ = [rng.normal(size=(F, c, H, W)).astype(np.float32) for c in (3, 1, 19)]
     p = {k: _t(v, k not in ("rot_poly_feat", "rot_fourier_feat", "position")) for k, v in host.items()}
     p["pos_cubic_node"] = to_segment_major(_t(host["pos_cubic_node"]), I).requires_grad_(True)
     t_rgb, t_att = _t(rgb, True), _t(attrs, True)
