@@ -99,6 +99,19 @@ class FlatAdam:
                 self.lr[n] = float(lr)
         self._build_segments()
 
+    def full_moments(self):
+        """(exp_avg, exp_avg_sq) laid out like the bucket (``OwnerShardedAdam`` has to gather them)"""
+        return self.exp_avg, self.exp_avg_sq
+
+    def load_moments(self, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor) -> None:
+        self.exp_avg.copy_(exp_avg)
+        self.exp_avg_sq.copy_(exp_avg_sq)
+
+    def zero_moments(self, name: str) -> None:
+        a, b = self.bucket.slices[name]
+        self.exp_avg[a:b].zero_()
+        self.exp_avg_sq[a:b].zero_()
+
     def step(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0) -> None:
         """one Adam step with the bucket's active gradient buffer (or ``grad``), scaled by ``grad_scale`` first"""
         g = self.bucket.flat_grad if grad is None else grad
@@ -123,13 +136,15 @@ class OwnerShardedAdam:
     """Adam for ``parallel.owner_sharded_step``: the REPLICATED slice [b, total) of the flat buffer is stepped on every rank,
     of the owned parameter [a, b) only this rank's block [lo, hi) -- the moments of the other blocks do not exist here (the
     spline table of the reference's model at 200 frames: 662 MB of parameters, 2 x 662 MB of moments; 1/8 of the moments and of
-    the optimiser's streaming per rank at 8 GPUs).  Same update rule as ``FlatAdam`` (two launches of ``splat_adam_step``)."""
+    the optimiser's streaming per rank at 8 GPUs).  Same update rule and learning-rate groups as ``FlatAdam`` (two launches of
+    ``splat_adam_step`` / ``splat_adam_step_pattern``)."""
 
     def __init__(self, bucket: FlatGradBucket, shards, lr: Union[float, Dict[str, float]], betas=(0.9, 0.999), eps: float = 1e-15):
         if not bucket.flat_param.is_cuda:
             raise ValueError("OwnerShardedAdam steps GPU buffers (there is no CPU path)")
         self.bucket, self.shards = bucket, shards
-        self.lr = {n: (float(lr[n]) if isinstance(lr, dict) else float(lr)) for n in bucket.slices}   # (plain rates: no PatternLR here)
+        rate = lambda r: r if isinstance(r, PatternLR) else float(r)
+        self.lr = {n: rate(lr[n] if isinstance(lr, dict) else lr) for n in bucket.slices}
         self.beta1, self.beta2, self.eps = float(betas[0]), float(betas[1]), float(eps)
         lo, hi = shards.own
         if lo % 4 or hi % 4 or shards.b % 4:
@@ -140,19 +155,42 @@ class OwnerShardedAdam:
         self.m_rep, self.v_rep = z(shards.total - shards.b), z(shards.total - shards.b)
         self.t = 0
 
+    def set_lr(self, lr: Union[float, Dict[str, float]]) -> None:
+        """as ``FlatAdam.set_lr``"""
+        if isinstance(lr, dict):
+            unknown = [n for n in lr if n not in self.lr]
+            if unknown:
+                raise KeyError(f"no parameter group(s) {unknown}; groups: {list(self.lr)}")
+            for n, r in lr.items():
+                self.lr[n] = r if isinstance(r, PatternLR) else float(r)
+        else:
+            for n in self.lr:
+                self.lr[n] = float(lr)
+
     def _segments(self, lo: int, hi: int):
-        """learning-rate segments of the sub-buffer [lo, hi), relative to lo"""
+        """learning-rate segments (+ patterns) of the sub-buffer [lo, hi), relative to lo"""
         sl = {n: (max(a, lo) - lo, min(b, hi) - lo) for n, (a, b) in self.bucket.slices.items() if min(b, hi) > max(a, lo)}
-        ends, rates = lr_segments(sl, self.lr)
-        return (ctypes.c_int64 * len(ends))(*ends), (ctypes.c_float * len(ends))(*rates), len(ends)
+        for n, (a, _) in sl.items():
+            if isinstance(self.lr[n], PatternLR) and self.bucket.slices[n][0] < lo:
+                raise ValueError(f"the pattern of group {n!r} would start inside the group")
+        return lr_segments(sl, self.lr, patterns=True)
 
     def _step(self, lo: int, hi: int, m, v, grad_scale: float) -> None:
         if hi <= lo:
             return
         p, g = self.bucket.flat_param[lo:hi], self.bucket.flat_grad[lo:hi]
-        ends, rates, n = self._segments(lo, hi)
-        L.check(L.lib().splat_adam_step(ctypes.c_int64(hi - lo), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ci(n), ends, rates,
-                                        L.cf(self.beta1), L.cf(self.beta2), L.cf(self.eps), L.ci(self.t), L.cf(grad_scale), L.stream()))
+        ends, rates, pat = self._segments(lo, hi)
+        n = len(ends)
+        c_ends, c_rates = (ctypes.c_int64 * n)(*ends), (ctypes.c_float * n)(*rates)
+        if any(q[0] for q in pat):
+            L.check(L.lib().splat_adam_step_pattern(
+                ctypes.c_int64(hi - lo), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ci(n), c_ends, c_rates,
+                (ctypes.c_int32 * n)(*[q[0] for q in pat]), (ctypes.c_int32 * n)(*[q[1] for q in pat]),
+                (ctypes.c_float * n)(*[q[2] for q in pat]), L.cf(self.beta1), L.cf(self.beta2), L.cf(self.eps), L.ci(self.t),
+                L.cf(grad_scale), L.stream()))
+        else:
+            L.check(L.lib().splat_adam_step(ctypes.c_int64(hi - lo), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ci(n), c_ends, c_rates,
+                                            L.cf(self.beta1), L.cf(self.beta2), L.cf(self.eps), L.ci(self.t), L.cf(grad_scale), L.stream()))
 
     def step(self, grad_scale: float = 1.0) -> None:
         self.t += 1
@@ -160,3 +198,35 @@ class OwnerShardedAdam:
             lo, hi = self.shards.own
             self._step(lo, hi, self.m_own, self.v_own, grad_scale)
             self._step(self.shards.b, self.shards.total, self.m_rep, self.v_rep, grad_scale)
+
+    # ---- the moments as whole flat buffers (structure changes: clone / split / prune move them with their Gaussians)
+    def full_moments(self):
+        """(exp_avg, exp_avg_sq) laid out like the bucket, every owner's block gathered (a collective: all ranks call it)"""
+        from .parallel import owner_gather
+        sh = self.shards
+        lo, hi = sh.own
+        out = []
+        for own, rep in ((self.m_own, self.m_rep), (self.v_own, self.v_rep)):
+            full = torch.zeros_like(self.bucket.flat_param)
+            full[lo:hi].copy_(own)
+            full[sh.b:sh.total].copy_(rep)
+            owner_gather(self.bucket, sh, flat=full)
+            out.append(full)
+        return out[0], out[1]
+
+    def load_moments(self, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor) -> None:
+        """this rank's share of whole flat moment buffers"""
+        sh = self.shards
+        lo, hi = sh.own
+        self.m_own.copy_(exp_avg[lo:hi]); self.v_own.copy_(exp_avg_sq[lo:hi])
+        self.m_rep.copy_(exp_avg[sh.b:sh.total]); self.v_rep.copy_(exp_avg_sq[sh.b:sh.total])
+
+    def zero_moments(self, name: str) -> None:
+        a, b = self.bucket.slices[name]
+        sh = self.shards
+        if a >= sh.b:
+            for t in (self.m_rep, self.v_rep):
+                t[a - sh.b:b - sh.b].zero_()
+        else:
+            for t in (self.m_own, self.v_own):
+                t.zero_()

@@ -240,6 +240,39 @@ class OwnerShards:
         return [f for f, u in enumerate(unit_of_frame) if u0 <= u < u1]
 
 
+def owner_reduce(bucket: FlatGradBucket, shards: OwnerShards) -> None:
+    """gradients after the local backward: all-reduce of the replicated part || reduce-scatter of the owned part (afterwards a
+    rank's gradient of the owned parameter is complete in ITS block only; the other blocks hold partial sums nobody reads)"""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    world = dist.get_world_size()
+    g = bucket.flat_grad
+    lo, hi = shards.own
+    work = dist.all_reduce(g[shards.b:shards.total], op=dist.ReduceOp.SUM, async_op=True)   # replicated part
+    if dist.get_backend() == "nccl" and shards.equal:
+        own = torch.empty(hi - lo, dtype=g.dtype, device=g.device)
+        dist.reduce_scatter_tensor(own, g[shards.a:shards.b], op=dist.ReduceOp.SUM)
+        g[lo:hi].copy_(own)
+    else:   # uneven blocks / backends without reduce-scatter (gloo): one reduce per owner -- the same bytes
+        for r in range(world):
+            dist.reduce(g[shards.bounds[r]:shards.bounds[r + 1]], dst=r, op=dist.ReduceOp.SUM)
+    work.wait()
+
+
+def owner_gather(bucket: FlatGradBucket, shards: OwnerShards, flat: torch.Tensor = None) -> None:
+    """the owners' updated blocks to every rank (``flat``: another buffer laid out like the bucket, e.g. assembled moments)"""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    p = bucket.flat_param if flat is None else flat
+    lo, hi = shards.own
+    with torch.no_grad():
+        if dist.get_backend() == "nccl" and shards.equal:
+            dist.all_gather_into_tensor(p[shards.a:shards.b], p[lo:hi].clone())
+        else:
+            for r in range(dist.get_world_size()):
+                dist.broadcast(p[shards.bounds[r]:shards.bounds[r + 1]], src=r)
+
+
 def owner_sharded_step(bucket: FlatGradBucket, shards: OwnerShards, frames: Iterable[int], render_and_backward, optimizer,
                        average: bool = False) -> None:
     """One SYNCHRONOUS step with the owned parameter's gradient reduced to its owners only: zero -> local frames forward +
@@ -251,24 +284,6 @@ def owner_sharded_step(bucket: FlatGradBucket, shards: OwnerShards, frames: Iter
         render_and_backward(f)
     on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     world = dist.get_world_size() if on else 1
-    g, p = bucket.flat_grad, bucket.flat_param
-    lo, hi = shards.own
-    if on:
-        work = dist.all_reduce(g[shards.b:shards.total], op=dist.ReduceOp.SUM, async_op=True)   # replicated part
-        nccl = dist.get_backend() == "nccl"
-        if nccl and shards.equal:
-            own = torch.empty(hi - lo, dtype=g.dtype, device=g.device)
-            dist.reduce_scatter_tensor(own, g[shards.a:shards.b], op=dist.ReduceOp.SUM)
-            g[lo:hi].copy_(own)
-        else:   # uneven blocks / backends without reduce-scatter (gloo): one reduce per owner -- the same bytes
-            for r in range(world):
-                dist.reduce(g[shards.bounds[r]:shards.bounds[r + 1]], dst=r, op=dist.ReduceOp.SUM)
-        work.wait()
+    owner_reduce(bucket, shards)
     optimizer.step(grad_scale=(1.0 / world) if average else 1.0)
-    if on:
-        with torch.no_grad():
-            if dist.get_backend() == "nccl" and shards.equal:
-                dist.all_gather_into_tensor(p[shards.a:shards.b], p[lo:hi].clone())
-            else:
-                for r in range(world):
-                    dist.broadcast(p[shards.bounds[r]:shards.bounds[r + 1]], src=r)
+    owner_gather(bucket, shards)

@@ -17,6 +17,7 @@ K = 5 nearest neighbours + the ARAP energy of the pair (:671-675; src/geometry_u
         track_gs' per-frame gradient lands next to the ARAP gradient of position(ids2)
     both position gradients -> spline segments          splat_dynamic_positions_batch_backward
     all-reduce of the flat bucket (N > 1), Adam          parallel.FlatGradBucket, optim.FlatAdam  row 8e
+        (owner_sharded=True: the spline table reduced to the owners of its time blocks, sharded moments, blocks gathered)
     densification statistics, reduced over the ranks    densify.DensifyState, parallel.reduce_densify_batch   row f2
     every `interval` steps: clone / split / prune with the Adam moments, Morton reorder, buffers rebuilt at the new N
 
@@ -42,8 +43,8 @@ from .dynamics import (GAUSSIAN_MAJOR, SEGMENT_MAJOR, FrameClock, frame_table, p
 from .frames import FrameBatch
 from .gs.fused_ops import compute_sh_into
 from .gs.point_ops import project_point_ortho
-from .optim import FlatAdam, PatternLR
-from .parallel import FlatGradBucket, reduce_densify_batch
+from .optim import FlatAdam, OwnerShardedAdam, PatternLR
+from .parallel import FlatGradBucket, OwnerShards, owner_gather, owner_reduce, reduce_densify_batch
 
 TRAINABLE = ("pos_cubic_node", "rotation", "opacity", "scaling", "shs", "attrs")
 FROZEN = ("position", "rot_poly_feat", "rot_fourier_feat")          # :90 position is not optimised; :195-197 detached tables
@@ -107,7 +108,7 @@ class TrainingStep:
     def __init__(self, params: Dict[str, Tensor], clock: FrameClock, W: int, H: int, frames_per_step: int, extr: Tensor,
                  lr: Optional[Dict[str, float]] = None, weights: Optional[LossWeights] = None,
                  densify: Optional[DensifyConfig] = None, K: int = 20, knn_K: int = 5, arap_samples: int = 512,
-                 bg: float = 0.0, sample_seed: int = 0, timing: bool = False):
+                 bg: float = 0.0, sample_seed: int = 0, timing: bool = False, owner_sharded: bool = False):
         self.clock, self.W, self.H, self.F = clock, int(W), int(H), int(frames_per_step)
         self.extr = extr
         self.dev = params["position"].device
@@ -121,7 +122,10 @@ class TrainingStep:
         self.history: List[int] = []            # Gaussian count after every structure change
         self.last: Dict[str, Tensor] = {}
         self.phase_ms: Dict[str, float] = {}
-        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        on = dist.is_available() and dist.is_initialized()
+        self.world, self.rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+        # the spline table's gradient reduced to the owners of its time blocks, their Adam moments sharded
+        self.owner_sharded = bool(owner_sharded)
         self._build({k: params[k] for k in TRAINABLE + FROZEN}, None, 0)
 
     # ------------------------------------------------------------------ buffers at the current Gaussian count
@@ -136,14 +140,21 @@ class TrainingStep:
         self.bucket = FlatGradBucket(train)
         self.p = self.bucket.params
         self.frozen = {k: p[k].contiguous() for k in FROZEN}
-        self.opt = FlatAdam(self.bucket, self.lr, eps=1e-15)
+        if self.owner_sharded:
+            self.shards = OwnerShards(self.bucket, "pos_cubic_node", self.world, self.rank)
+            self.opt = OwnerShardedAdam(self.bucket, self.shards, self.lr, eps=1e-15)
+        else:
+            self.shards = None
+            self.opt = FlatAdam(self.bucket, self.lr, eps=1e-15)
         self.opt.t = adam_t
         if moments is not None:
+            full = [torch.zeros_like(self.bucket.flat_param) for _ in range(2)]
             for k in TRAINABLE:
                 a, b = self.bucket.slices[k]
-                for dst, src in ((self.opt.exp_avg, moments[k][0]), (self.opt.exp_avg_sq, moments[k][1])):
+                for dst, src in zip(full, moments[k]):
                     src = seg(src) if k == "pos_cubic_node" else src
                     dst[a:b].copy_(src.reshape(-1))
+            self.opt.load_moments(full[0], full[1])
         A = self.p["attrs"].shape[1]
         self.C = 3 + 1 + 3 + A
         self.fb = FrameBatch(self.F, N, self.W, self.H, self.C, self.dev, want_abs=False)
@@ -236,9 +247,15 @@ class TrainingStep:
         # ---- both position gradients of every pair (ARAP on ids1 and ids2, track_gs on ids2) reach the spline segments
         positions_batch_backward(tab12, self.g_pairs.view(2 * F, N, 3), I, SEGMENT_MAJOR, None, g["pos_cubic_node"])
         ph.mark("render_backward")
-        # ---- data parallelism: one all-reduce of the flat bucket, identical Adam on every rank
-        bk.all_reduce()
-        self.opt.step(grad_scale=1.0 / self.world)
+        # ---- data parallelism: one all-reduce of the flat bucket, identical Adam on every rank -- or (owner_sharded) the
+        #      spline table's gradient reduced to the owners of its time blocks, their blocks stepped there and gathered
+        if self.owner_sharded:
+            owner_reduce(bk, self.shards)
+            self.opt.step(grad_scale=1.0 / self.world)
+            owner_gather(bk, self.shards)
+        else:
+            bk.all_reduce()
+            self.opt.step(grad_scale=1.0 / self.world)
         ph.mark("allreduce_adam")
         # ---- densification statistics of the batch (reduced over the ranks: identical decisions everywhere)
         st = self.dstate
@@ -273,9 +290,10 @@ class TrainingStep:
         p["pos_cubic_node"] = to_gaussian_major(p["pos_cubic_node"].reshape(self.clock.interval_num, N, 4, 3))
         p.update(self.frozen)
         m = {}
+        exp_avg, exp_avg_sq = self.opt.full_moments()        # (owner_sharded: gathered from the owners -- a collective)
         for k in TRAINABLE:
             a, b = self.bucket.slices[k]
-            ea, es = self.opt.exp_avg[a:b].view(self.p[k].shape), self.opt.exp_avg_sq[a:b].view(self.p[k].shape)
+            ea, es = exp_avg[a:b].view(self.p[k].shape), exp_avg_sq[a:b].view(self.p[k].shape)
             if k == "pos_cubic_node":
                 I = self.clock.interval_num
                 ea, es = to_gaussian_major(ea.reshape(I, N, 4, 3)), to_gaussian_major(es.reshape(I, N, 4, 3))
@@ -295,9 +313,7 @@ class TrainingStep:
         with torch.no_grad():
             p = self.p["opacity"]
             p.copy_(torch.minimum(p, torch.full_like(p, math.log(ceiling / (1.0 - ceiling)))))
-            a, b = self.bucket.slices["opacity"]
-            self.opt.exp_avg[a:b].zero_()
-            self.opt.exp_avg_sq[a:b].zero_()
+            self.opt.zero_moments("opacity")
 
     def maybe_densify(self) -> bool:
         """clone / split / prune at the reference's cadence (atlas_gs_optimizer.py:120-121,166-176); True when N changed"""

@@ -126,7 +126,7 @@ def test_bench_gpus_2_launches_and_reports_two_ranks():
 
 # ---------------------------------------------------------------------------------------------------------------------
 # the composed training step (train_step.py) under data parallelism
-def _train_worker(rank, world, port, out):
+def _train_worker(rank, world, port, out, owner=False, steps=45):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -140,10 +140,11 @@ def _train_worker(rank, world, port, out):
         extr = _t(sc.extr)
         cfg = TS.DensifyConfig(interval=15, start_iter=10, stop_iter=40, grad_threshold=5e-4, cameras_extent=60.0, min_opacity=0.02, seed=9)
         lr = dict(TS.REFERENCE_LR, pos_cubic_node=2e-3, shs=2e-2, attrs=2e-2, scaling=1e-2, rotation=5e-3)
-        st = TS.TrainingStep(_perturbed(truth, 1), clock, Ww, Hh, F, extr, lr=lr, densify=cfg, K=8, arap_samples=128, sample_seed=rank)
+        st = TS.TrainingStep(_perturbed(truth, 1), clock, Ww, Hh, F, extr, lr=lr, densify=cfg, K=8, arap_samples=128, sample_seed=rank,
+                             owner_sharded=owner)
         rng = np.random.default_rng(100 + rank)                     # every rank draws ITS OWN frame pairs
         counts, losses = [st.N], []
-        for _ in range(45):
+        for _ in range(steps):
             t1 = [int(t) for t in rng.choice(T, F, replace=False)]
             t2 = [int((t + 1 + rng.integers(T - 1)) % T) for t in t1]
             st.step(t1, t2, TS.render_ground_truth(truth, clock, Ww, Hh, extr, t1, t2))
@@ -151,8 +152,8 @@ def _train_worker(rank, world, port, out):
             if st.maybe_densify():
                 counts.append(st.N)
         torch.cuda.synchronize()
-        torch.save({"param": st.bucket.flat_param.detach().cpu(), "m": st.opt.exp_avg.cpu(), "counts": counts, "losses": losses,
-                    "frozen": st.frozen["position"].cpu()}, out + f".{rank}")
+        torch.save({"param": st.bucket.flat_param.detach().cpu(), "m": st.opt.full_moments()[0].cpu(), "counts": counts, "losses": losses,
+                    "slices": dict(st.bucket.slices), "frozen": st.frozen["position"].cpu()}, out + f".{rank}")
     finally:
         dist.destroy_process_group()
 
@@ -169,6 +170,24 @@ def test_two_ranks_training_step_replicas_stay_bit_identical_through_densificati
     assert r0["counts"] == r1["counts"] and len(set(r0["counts"])) >= 3, (r0["counts"], r1["counts"])
     assert torch.equal(r0["param"], r1["param"]) and torch.equal(r0["m"], r1["m"]) and torch.equal(r0["frozen"], r1["frozen"])
     assert np.isfinite(r0["losses"]).all() and np.mean(r0["losses"][-5:]) < np.mean(r0["losses"][:3])
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_owner_sharded_training_step_equals_the_all_reduce_step(tmp_path):
+    """TrainingStep(owner_sharded=True): the spline table's gradient reduced to the owners of its time blocks only, each owner
+    stepping its block with its own shard of the Adam moments, blocks gathered -- through a structure change (the moments are
+    gathered, moved with their Gaussians and dealt out again at the new count) the replicas stay bit-identical, and parameters
+    and assembled moments are the all-reduce step's.  (Two runs of the SAME step differ in a handful of spline coefficients by
+    ~1e-9: the ARAP gradient is scattered with float atomics, as the reference's index_add is -- hence a tolerance between the
+    runs, none between the ranks of a run.)"""
+    out_o, out_d = str(tmp_path / "own"), str(tmp_path / "dense")
+    mp.spawn(_train_worker, args=(2, _free_port(), out_o, True, 18), nprocs=2, join=True)
+    mp.spawn(_train_worker, args=(2, _free_port(), out_d, False, 18), nprocs=2, join=True)
+    o0, o1, d0 = torch.load(out_o + ".0"), torch.load(out_o + ".1"), torch.load(out_d + ".0")
+    assert o0["counts"] == o1["counts"] == d0["counts"] and len(set(o0["counts"])) == 2
+    assert torch.equal(o0["param"], o1["param"]) and torch.equal(o0["m"], o1["m"])
+    torch.testing.assert_close(o0["param"], d0["param"], rtol=0, atol=1e-6)
+    torch.testing.assert_close(o0["m"], d0["m"], rtol=0, atol=1e-6)
 
 
 @pytest.mark.timeout(1500)

@@ -427,7 +427,7 @@ def test_fused_perspective_preprocess_equals_the_operator_chain():
     b = {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scale=sc.scale, rotate=sc.rotate).items()}
     uv2, depth2, conic2, radius2, tiles2 = gs.preprocess_persp(b["xyz"], b["scale"], b["rotate"], intr, extr, W, H)
     assert torch.equal(uv2, uv) and torch.equal(depth2, depth) and torch.equal(radius2, radius) and torch.equal(tiles2, tiles)
-    assert torch.allclose(conic2, conic, rtol=2e-5, atol=2e-6 * float(conic.abs().max()))
+    assert torch.allclose(conic2, conic, rtol=2e-5, atol=2e-6 * float(conic.detach().abs().max()))
     torch.autograd.backward([uv2, depth2, conic2], g)
     for k in a:
         x, y = b[k].grad, a[k].grad

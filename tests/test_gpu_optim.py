@@ -87,14 +87,16 @@ def test_owner_sharded_adam_steps_its_block_and_the_replicated_slice_like_flat_a
     I, N = 7, 1000
     mk = lambda: {"cubic": 0.1 * torch.randn(I, N, 4, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)),
                   "rotation": torch.randn(N, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)),
-                  "opacity": torch.randn(N, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))}
-    lr = {"cubic": 1e-3, "rotation": 2e-3, "opacity": 5e-2}
+                  "opacity": torch.randn(N, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4)),
+                  "shs": torch.randn(N, 16, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))}
+    from splatter_a_video_amd.optim import PatternLR
+    lr = {"cubic": 1e-3, "rotation": 2e-3, "opacity": 5e-2, "shs": PatternLR(1.25e-4, head_lr=2.5e-3, period=48, head=3)}
     a, b = FlatGradBucket(mk()), FlatGradBucket(mk())
     sh = OwnerShards(b, "cubic", 3, 1)
     lo, hi = sh.own
     assert (lo, hi) == (2 * N * 12, 4 * N * 12)                    # segments 2, 3 of 7 (7 * r // 3)
     oa, ob = FlatAdam(a, lr), OwnerShardedAdam(b, sh, lr)
-    assert ob.m_own.numel() == hi - lo and ob.m_rep.numel() == 5 * N
+    assert ob.m_own.numel() == hi - lo and ob.m_rep.numel() == 53 * N
     before = b.flat_param.detach().clone()
     for _ in range(3):
         gr = torch.randn(a.flat_grad.numel(), device="cuda", generator=g)
@@ -104,6 +106,21 @@ def test_owner_sharded_adam_steps_its_block_and_the_replicated_slice_like_flat_a
     assert torch.equal(pb[lo:hi], pa[lo:hi]) and torch.equal(pb[sh.b:], pa[sh.b:])
     assert torch.equal(pb[:lo], before[:lo]) and torch.equal(pb[hi:sh.b], before[hi:sh.b])
     assert not torch.equal(pb[lo:hi], before[lo:hi])
+    # the moments as whole buffers (structure changes): the own block and the replicated slice of FlatAdam's, zeros elsewhere
+    m, v = ob.full_moments()
+    fm, fv = oa.full_moments()
+    assert torch.equal(m[lo:hi], fm[lo:hi]) and torch.equal(v[sh.b:], fv[sh.b:]) and float(m[:lo].abs().max()) == 0.0
+    oc = OwnerShardedAdam(b, OwnerShards(b, "cubic", 3, 2), lr)
+    oc.load_moments(fm, fv)
+    lo2, hi2 = oc.shards.own
+    assert torch.equal(oc.m_own, fm[lo2:hi2]) and torch.equal(oc.v_rep, fv[sh.b:])
+    ob.zero_moments("opacity")
+    a0, b0 = b.slices["opacity"]
+    m2, _ = ob.full_moments()
+    assert float(m2[a0:b0].abs().max()) == 0.0 and torch.equal(m2[b0:], fm[b0:]) and torch.equal(m2[lo:hi], fm[lo:hi])
+    ob.set_lr({"rotation": 1e-2})
+    with pytest.raises(KeyError):
+        ob.set_lr({"nope": 1.0})
 
 
 def test_pattern_learning_rates_are_two_parameter_groups_inside_one_tensor():
