@@ -137,6 +137,10 @@ def parse():
                          "position(ids2), L1 losses, K = 5 neighbours + ARAP per pair, backward, all-reduce, Adam, densification "
                          "statistics (+ one clone / split / prune / rebuild, amortised over its interval); --frames pairs per rank "
                          "and step")
+    ap.add_argument("--owner-sharded", action="store_true",
+                    help="--train-step at N > 1: the spline table's gradient reduced to the owners of its time blocks, their Adam "
+                         "moments sharded, updated blocks gathered (parallel.owner_reduce / owner_gather, optim.OwnerShardedAdam) "
+                         "instead of one all-reduce of the flat bucket + replicated Adam")
     ap.add_argument("--stale-overlap", action="store_true",
                     help="stale-1 mode: double-buffered gradient bucket, the all-reduce of step s overlaps step s+1's frames "
                          "and no optimiser runs (NOT synchronous data parallelism; for comparison only)")
@@ -746,7 +750,7 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
     start["pos_cubic_node"] = torch.zeros_like(start["pos_cubic_node"])
     cfg = TS.DensifyConfig(cameras_extent=5.0)
     lr = {k: 1e-6 for k in TS.REFERENCE_LR}      # as everywhere in this file: small rates keep the scene's statistics put over the run
-    st = TS.TrainingStep(start, clock, sc.W, sc.H, len(t1), extr, lr=lr, densify=cfg, K=20)
+    st = TS.TrainingStep(start, clock, sc.W, sc.H, len(t1), extr, lr=lr, densify=cfg, K=20, owner_sharded=a.owner_sharded)
     del truth, start
     dt = timed(lambda: st.step(t1, t2, gt))
     st.fb.check()
@@ -816,8 +820,13 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
                                "sampled vertices + ARAP per pair, render_iter's three blends (rgb enhanced K=20 with taps | depth | "
                                "track_gs + 16 attribute channels, opacity detached), L1 on the three images, backward, "
                                "all-reduce, Adam on the flat buffer, densification statistics",
-                   "equivalent_flags": "--train-step", "tile_pairs_M": int(st.fb.pairs.max().item()),
-                   "grad_bucket_MB": round(st.bucket.flat_grad.numel() * 4 / 1e6, 1)}}
+                   "equivalent_flags": "--train-step" + (" --owner-sharded" if a.owner_sharded else ""),
+                   "tile_pairs_M": int(st.fb.pairs.max().item()),
+                   "grad_bucket_MB": round(st.bucket.flat_grad.numel() * 4 / 1e6, 1),
+                   "optimizer": ("owner-sharded spline table (reduce to owner, sharded moments, gather)" if a.owner_sharded
+                                 else "all-reduce of the flat bucket + replicated Adam"),
+                   "adam_moments_MB_per_rank": round(sum(t.numel() for t in ((st.opt.m_own, st.opt.v_own, st.opt.m_rep, st.opt.v_rep)
+                                                         if a.owner_sharded else (st.opt.exp_avg, st.opt.exp_avg_sq))) * 4 / 1e6, 1)}}
 
 
 def main():

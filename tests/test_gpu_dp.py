@@ -219,3 +219,29 @@ def test_bench_gpus_8_and_4_rehearsal_over_gloo(n):
     assert frame["comm"]["allreduce_ms"] > 0 and frame["grad_bucket_MB"] == frame["comm"]["bucket_MB"]
     assert "error" not in step, step
     assert step["n_gpus"] == n and step["train_step_ms"] > 0 and set(step["phases_ms"]) >= {"render_forward", "render_backward", "knn_arap"}
+
+
+@pytest.mark.timeout(900)
+def test_bench_train_step_owner_sharded_two_ranks_over_gloo():
+    """`bench.py --gpus 2 --train-step --owner-sharded`: the composed step with the spline table's gradient reduced to its owners,
+    through the launcher; the line says which optimiser ran and holds about half of the table's moments per rank"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, SPLAT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    small = ["--gaussians", "4000", "--width", "128", "--height", "96", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+             "--no-kernel-timing", "--train-step"]
+    lines = {}
+    for flag in ([], ["--owner-sharded"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small + flag, env=env,
+                           capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines[bool(flag)] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    dense, own = lines[False], lines[True]
+    assert own["n_gpus"] == 2 and own["train_step_ms"] > 0 and own["config"]["optimizer"].startswith("owner-sharded")
+    assert own["config"]["grad_bucket_MB"] == dense["config"]["grad_bucket_MB"]
+    assert own["config"]["adam_moments_MB_per_rank"] < 0.85 * dense["config"]["adam_moments_MB_per_rank"]
+    assert abs(own["loss"] - dense["loss"]) < 1e-4 * max(1.0, abs(dense["loss"]))
