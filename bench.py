@@ -163,6 +163,9 @@ def parse():
                          "tile-list imbalance stress, SURVEY 7 hard part ii)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run at N = 1: skip the compact lines of the other configurations (c4, c5, render_iter, per-frame "
+                         "operators, --ref-flow) in `other_configs`")
     ap.add_argument("--no-extra-lines", action="store_true",
                     help="skip the second workload of the line (N = 1: the reference's training frame, --render-iter --dynamic)")
     ap.add_argument("--launch-check", action="store_true",
@@ -874,19 +877,22 @@ def main():
     mode = ("ref_flow" if a.ref_flow else ("render_iter_frame" if a.per_frame else "render_iter") if a.render_iter else "ops" if a.ops
             else "frame" if a.per_frame else "batch")
     clip = max(a.clip, 25 * world)
-    sc = make_scene(a.gaussians, a.width, a.height, F=clip, C=a.channels, seed=1234,
-                    clustered=0.7 if a.scene == "clustered" else 0.0)
-    if not a.no_spatial_order:
-        # setup, as a trainer does after initialisation and after every densification: Gaussians in Morton order of their
-        # screen positions (densify.spatial_order; results do not depend on the order, the binning kernels' locality does)
-        from splatter_a_video_amd.densify import spatial_order
-        uv0, _ = gs.project_point_ortho(torch.tensor(sc.positions(0), device=dev), torch.tensor(sc.extr, device=dev), a.width,
-                                        a.height, nearest=0.01)
-        order = spatial_order(uv0, a.width, a.height).cpu().numpy()
-        for k in ("xyz", "phase", "scale", "rotate", "opacity", "shs", "feature"):
-            v = getattr(sc, k)
-            if v is not None:
-                setattr(sc, k, np.ascontiguousarray(v[order]))
+    def build_scene(gaussians, width, height, channels):
+        sc_ = make_scene(gaussians, width, height, F=clip, C=channels, seed=1234, clustered=0.7 if a.scene == "clustered" else 0.0)
+        if not a.no_spatial_order:
+            # setup, as a trainer does after initialisation and after every densification: Gaussians in Morton order of their
+            # screen positions (densify.spatial_order; results do not depend on the order, the binning kernels' locality does)
+            from splatter_a_video_amd.densify import spatial_order
+            uv0, _ = gs.project_point_ortho(torch.tensor(sc_.positions(0), device=dev), torch.tensor(sc_.extr, device=dev), width,
+                                            height, nearest=0.01)
+            order = spatial_order(uv0, width, height).cpu().numpy()
+            for k in ("xyz", "phase", "scale", "rotate", "opacity", "shs", "feature"):
+                v = getattr(sc_, k)
+                if v is not None:
+                    setattr(sc_, k, np.ascontiguousarray(v[order]))
+        return sc_
+
+    sc = build_scene(a.gaussians, a.width, a.height, a.channels)
     # rank r renders frames {f : f mod world == r} of the step's frame batch
     frames = [((i * world + rank) % clip) for i in range(a.frames)]
 
@@ -1126,6 +1132,36 @@ def main():
         except Exception as e:   # noqa: BLE001  (must not cost the line its headline; identical on every rank)
             extra_lines.append({"metric": "training step (train_step.py)", "error": repr(e)[:400]})
 
+    # the other configurations of BASELINE.json / BASELINE.md section 9 inside the SAME (driver-run) default line, N = 1: each timed
+    # exactly like `value` (W + K steps between synchronisations), compact -- their full lines are `profiles/r05_bench_*.json`
+    other_configs = []
+    if (world == 1 and mode == "batch" and not a.dynamic and a.channels == 0 and not a.no_extra_lines and not a.stale_overlap
+            and not a.overlap and not a.no_other_configs):
+        specs = [("c5 (configs[4]): 32 feature channels", "--channels 32", dict(channels=32), "batch"),
+                 ("render_iter, static Gaussians: the renderer's three blends, 23 channels", "--render-iter", {}, "render_iter"),
+                 ("fused per-frame operators (the drop-in path, frame by frame)", "--per-frame", {}, "frame"),
+                 ("the reference's renderer file's LITERAL call sequence on this library", "--ref-flow", {}, "ref_flow"),
+                 ("c4 (configs[3]): 1M Gaussians, 1280x720", "--gaussians 1000000 --width 1280 --height 720",
+                  dict(gaussians=1000000, width=1280, height=720), "batch")]
+        for what, flags, over, m2 in specs:
+            try:
+                g2, w2, h2, c2 = (over.get("gaussians", a.gaussians), over.get("width", a.width), over.get("height", a.height),
+                                  over.get("channels", 0))
+                sc2 = sc if not over else build_scene(g2, w2, h2, c2)
+                Ro = FrameRenderer(sc2, dev, frames, c2, mode=m2, optimizer=not a.no_optimizer)
+                dto = timed(Ro.step, Ro.finish)
+                Ro.check_sorts()
+                ent = {"what": what, "equivalent_flags": flags, "value": round(a.frames * a.steps / dto, 2), "unit": "frames/s",
+                       "ms_per_frame": round(dto / (a.frames * a.steps) * 1e3, 4), "tile_pairs_M": Ro.last.get("M")}
+                if m2 in ("batch", "render_iter", "ref_flow"):
+                    dtfo = timed(Ro.forward_only)
+                    ent["forward_only"] = round(a.frames * a.steps / dtfo, 2)
+                other_configs.append(ent)
+                del Ro, sc2
+            except Exception as e:   # noqa: BLE001  (must not cost the line its headline)
+                other_configs.append({"what": what, "equivalent_flags": flags, "error": repr(e)[:300]})
+            torch.cuda.empty_cache()
+
     cpu = cpu_c = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_torch(sc, a.channels)
@@ -1187,7 +1223,7 @@ def main():
                                         "optimizer": None if opt_ms is None else round(opt_ms, 4)},
             "forward_only": forward_only, "eager_steps_only": eager_only, "scene_stats": stats,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c_oracle": cpu_c, "kernels": kernels,
-            "extra_lines": extra_lines,
+            "extra_lines": extra_lines, "other_configs": other_configs,
         }
         print(json.dumps(line))
     if launched:
