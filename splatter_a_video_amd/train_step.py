@@ -202,7 +202,9 @@ class TrainingStep:
     def step(self, times1: Sequence[float], times2: Sequence[float], gt: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """one gradient step on the pairs (times1[f], times2[f]); ``gt``: rgb [F,3,H,W], depth [F,1,H,W], attr [F,3+A,H,W] of
         the frames times1 (attr: track_gs of the pair in its first three channels).  Returns device scalars (no host sync):
-        the L1 sums of the three images, the ARAP energies."""
+        the L1 sums of the three images, the ARAP energies.  The order of the pairs inside a step does not change the result;
+        sorted by times1 the Gaussian-side backward shares its projection / EWA chain between consecutive frames of one spline
+        segment."""
         if len(times1) != self.F or len(times2) != self.F:
             raise ValueError(f"the step takes {self.F} frame pairs")
         ph = _Phases(self.timing)
