@@ -103,12 +103,14 @@ class TrainingStep:
     ``params``: per-Gaussian tensors on the GPU -- position [N,3], pos_cubic_node [N, 4*I*3] (the reference's layout; stored
     segment-major), rotation [N,4], rot_poly_feat [N,4,4], rot_fourier_feat [N,8,4], opacity [N,1] (logit), scaling [N,3]
     (log), shs [N,16,3], attrs [N,A] (the render attributes behind track_gs; 3 + 1 + 3 + A = the composited row, A = 16 for
-    the renderer's own 23-channel plan)."""
+    the renderer's own 23-channel plan).  At set-up (and after every densification) the Gaussians are put in Morton order of their
+    screen positions (``spatial_order=False``: kept as given); ``initial_order`` maps the rows here to the caller's."""
 
     def __init__(self, params: Dict[str, Tensor], clock: FrameClock, W: int, H: int, frames_per_step: int, extr: Tensor,
                  lr: Optional[Dict[str, float]] = None, weights: Optional[LossWeights] = None,
                  densify: Optional[DensifyConfig] = None, K: int = 20, knn_K: int = 5, arap_samples: int = 512,
-                 bg: float = 0.0, sample_seed: int = 0, timing: bool = False, owner_sharded: bool = False):
+                 bg: float = 0.0, sample_seed: int = 0, timing: bool = False, owner_sharded: bool = False,
+                 spatial_order: bool = True):
         self.clock, self.W, self.H, self.F = clock, int(W), int(H), int(frames_per_step)
         self.extr = extr
         self.dev = params["position"].device
@@ -126,7 +128,15 @@ class TrainingStep:
         self.world, self.rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
         # the spline table's gradient reduced to the owners of its time blocks, their Adam moments sharded
         self.owner_sharded = bool(owner_sharded)
-        self._build({k: params[k] for k in TRAINABLE + FROZEN}, None, 0)
+        p0 = {k: params[k] for k in TRAINABLE + FROZEN}
+        # setup, as after every densification: the Gaussians in Morton order of their screen positions at the clip's first frame
+        # (the binning kernels' locality and the neighbour search's bound want space neighbours at neighbouring
+        # indices; results do not depend on the order).  ``initial_order[i]`` = the caller's row of Gaussian i here.
+        self.initial_order = None
+        if spatial_order:
+            self.initial_order = self._morton(p0)
+            p0, _ = D.reorder_points(p0, None, self.initial_order)
+        self._build(p0, None, 0)
 
     # ------------------------------------------------------------------ buffers at the current Gaussian count
     def _build(self, p: Dict[str, Tensor], moments, adam_t: int) -> None:
@@ -317,6 +327,15 @@ class TrainingStep:
             p.copy_(torch.minimum(p, torch.full_like(p, math.log(ceiling / (1.0 - ceiling)))))
             self.opt.zero_moments("opacity")
 
+    def _morton(self, p: Dict[str, Tensor]) -> Tensor:
+        """permutation into Morton order of the screen positions at the clip's first frame; ``p`` in row layout"""
+        tab0 = frame_table(self.clock, [0], self.dev)
+        pos0 = positions_batch_forward(tab0, p["position"].contiguous(), p["pos_cubic_node"].reshape(p["position"].shape[0], -1).contiguous(),
+                                       self.clock.interval_num, GAUSSIAN_MAJOR)[0]
+        with torch.no_grad():
+            uv, _ = project_point_ortho(pos0, self.extr, self.W, self.H, nearest=0.01)
+        return D.spatial_order(uv, self.W, self.H)
+
     def maybe_densify(self) -> bool:
         """clone / split / prune at the reference's cadence (atlas_gs_optimizer.py:120-121,166-176); True when N changed"""
         c = self.cfg
@@ -343,14 +362,8 @@ class TrainingStep:
         _, _, prune = fresh.masks(p["scaling"], p["opacity"], c.grad_threshold, c.percent_dense, c.cameras_extent, c.min_opacity,
                                   c.size_threshold)
         p, m = D.prune_points(p, m, ~prune)
-        # Morton order of the screen positions at the clip's first frame
         N2 = p["position"].shape[0]
-        tab0 = frame_table(self.clock, [0], self.dev)
-        pos0 = positions_batch_forward(tab0, p["position"], p["pos_cubic_node"], self.clock.interval_num, GAUSSIAN_MAJOR)[0]
-        with torch.no_grad():
-            uv, _ = project_point_ortho(pos0, self.extr, self.W, self.H, nearest=0.01)
-        perm = D.spatial_order(uv, self.W, self.H)
-        p, m = D.reorder_points(p, m, perm)
+        p, m = D.reorder_points(p, m, self._morton(p))
         self.last_change = dict(cloned=n_clone, split=n_split, pruned=int(prune.sum()), N=N2)
         self._build(p, m, self.opt.t)
 

@@ -321,7 +321,12 @@ def test_training_step_phases_are_timed():
     N, W, H, T, F = 3000, 128, 96, 20, 4
     sc, clock, truth = _clip(N, W, H, T, seed=9)
     extr = _t(sc.extr)
-    st = TS.TrainingStep(_perturbed(truth, 2), clock, W, H, F, extr, K=8, arap_samples=128, timing=True)
+    start = _perturbed(truth, 2)
+    st = TS.TrainingStep(start, clock, W, H, F, extr, K=8, arap_samples=128, timing=True)
+    # set-up put the Gaussians in Morton order of their screen positions; initial_order[i] = the caller's row of Gaussian i
+    assert torch.equal(torch.sort(st.initial_order).values, torch.arange(N, device="cuda"))
+    assert torch.equal(st.p["rotation"].detach(), start["rotation"][st.initial_order])
+    assert TS.TrainingStep(start, clock, W, H, F, extr, K=8, arap_samples=128, spatial_order=False).initial_order is None
     t1, t2 = [0, 3, 7, 12], [5, 1, 19, 2]
     gt = TS.render_ground_truth(truth, clock, W, H, extr, t1, t2)
     st.step(t1, t2, gt)
