@@ -1139,6 +1139,8 @@ def main():
             and not a.overlap and not a.no_other_configs):
         specs = [("c5 (configs[4]): 32 feature channels", "--channels 32", dict(channels=32), "batch"),
                  ("render_iter, static Gaussians: the renderer's three blends, 23 channels", "--render-iter", {}, "render_iter"),
+                 ("render_iter with the trainer's ['mask_attribute', 'dino_attribute'] plan: 3 | 1 | 4 channels, same one-pass kernels",
+                  "--render-iter --attr-channels 4", dict(attr_channels=4), "render_iter"),
                  ("fused per-frame operators (the drop-in path, frame by frame)", "--per-frame", {}, "frame"),
                  ("the reference's renderer file's LITERAL call sequence on this library", "--ref-flow", {}, "ref_flow"),
                  ("c4 (configs[3]): 1M Gaussians, 1280x720", "--gaussians 1000000 --width 1280 --height 720",
@@ -1147,8 +1149,8 @@ def main():
             try:
                 g2, w2, h2, c2 = (over.get("gaussians", a.gaussians), over.get("width", a.width), over.get("height", a.height),
                                   over.get("channels", 0))
-                sc2 = sc if not over else build_scene(g2, w2, h2, c2)
-                Ro = FrameRenderer(sc2, dev, frames, c2, mode=m2, optimizer=not a.no_optimizer)
+                sc2 = sc if (g2, w2, h2, c2) == (a.gaussians, a.width, a.height, 0) else build_scene(g2, w2, h2, c2)
+                Ro = FrameRenderer(sc2, dev, frames, c2, mode=m2, optimizer=not a.no_optimizer, attr_channels=over.get("attr_channels", 19))
                 dto = timed(Ro.step, Ro.finish)
                 Ro.check_sorts()
                 ent = {"what": what, "equivalent_flags": flags, "value": round(a.frames * a.steps / dto, 2), "unit": "frames/s",

@@ -30,8 +30,8 @@ def test_default_line_carries_the_other_configurations():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert [("error" in x) for x in d["extra_lines"]] == [False, False]
     oc = d["other_configs"]
-    assert [x["equivalent_flags"] for x in oc] == ["--channels 32", "--render-iter", "--per-frame", "--ref-flow",
+    assert [x["equivalent_flags"] for x in oc] == ["--channels 32", "--render-iter", "--render-iter --attr-channels 4", "--per-frame", "--ref-flow",
                                                     "--gaussians 1000000 --width 1280 --height 720"]
     for x in oc:
         assert "error" not in x and x["value"] > 0, x
-    assert oc[3]["forward_only"] > oc[3]["value"] and oc[4]["tile_pairs_M"] > 1000000
+    assert oc[4]["forward_only"] > oc[4]["value"] and oc[5]["tile_pairs_M"] > 1000000
