@@ -214,6 +214,9 @@ def test_bench_gpus_8_and_4_rehearsal_over_gloo(n):
     assert line["config"]["frames_per_rank_per_step"] == 25 and f"of a {25 * n}-frame" in line["config"]["workload"]
     c = line["comm"]
     assert "error" not in c and c["allreduce_ms"] > 0 and c["overlap_exact"]["value"] > 0, c
+    # both exact schedules were timed; the line's value is the faster one and says which
+    assert c["synchronous"]["value"] > 0 and abs(line["value"] - max(c["synchronous"]["value"], c["overlap_exact"]["value"])) < 0.02
+    assert line["config"]["schedule"].startswith(("synchronous", "exact half-batch overlap"))
     frame, step = line["extra_lines"]
     assert "error" not in frame and frame["n_gpus"] == n and frame["value"] > 0
     assert frame["comm"]["allreduce_ms"] > 0 and frame["grad_bucket_MB"] == frame["comm"]["bucket_MB"]
