@@ -37,8 +37,8 @@ def _per_frame(sc, p, off, feat, g, W, H, bg, abs_tap=False):
             (img * g[f]).sum().backward()
         # the per-frame backward (its own cull) replays exactly the forward's decisions as well: what is left between the two
         # paths is summation order
-        assert float((cap.maps[0] - 1).abs().max()) < 2e-4
-        imgs.append(img.detach()); taps.append(ndc.grad); rad.append(radius)
+        assert not cap.maps or float((cap.maps[0] - 1).abs().max()) < 2e-4     # (a frame without pairs launches no backward)
+        imgs.append(img.detach()); taps.append(ndc.grad if ndc.grad is not None else torch.zeros_like(uv)); rad.append(radius)
         if abs_tap:
             atap.append(andc.grad)
     return torch.stack(imgs), sum(taps), (sum(atap) if abs_tap else None), torch.stack(rad).max(0).values
@@ -518,3 +518,88 @@ def test_render_sets_validates_shapes():
         B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"].unsqueeze(0).repeat(F, 1, 1), ok, off, extr)
     with pytest.raises(ValueError):           # a set's feature rows
         B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], [dict(feature=rgb[:-1], taps=True)], off, extr)
+
+
+@pytest.mark.parametrize("case", ["one_empty_frame", "all_empty", "single_frame"])
+def test_batch_with_empty_frames_and_a_single_frame(case):
+    """edge cases of the frame batch against the per-frame operators: a frame whose offsets carry every Gaussian out of view
+    (no (tile, Gaussian) pair: its image is the background, it adds nothing to any gradient) between two ordinary frames; a batch
+    of such frames only; a batch of ONE frame"""
+    N, W, H, C = 2500, 100, 60, 3
+    F = 1 if case == "single_frame" else 3
+    sc = make_scene(N, W, H, seed=41)
+    off = _offsets(sc, F)
+    if case == "one_empty_frame":
+        off[1, :, 0] += 50.0                      # far to the right of the view
+    if case == "all_empty":
+        off[:, :, 0] += 50.0
+    off = _t(off)
+    rng = np.random.default_rng(4)
+    featv = rng.uniform(size=(N, C)).astype(np.float32)
+    g = _t(rng.normal(size=(F, C, H, W)).astype(np.float32))
+    bg = 0.3
+    params = lambda: {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity).items()}
+    pa, fa = params(), _t(featv, True)
+    ref_img, ref_tap, _, ref_rad = _per_frame(sc, pa, off, fa, g, W, H, bg)
+    pb, fb_ = params(), _t(featv, True)
+    B = FrameBatch(F, N, W, H, C, "cuda")
+    out = B.render(pb["xyz"], pb["scales"], pb["uquats"], pb["opacity"], fb_, off, _t(sc.extr), bg=bg)
+    assert torch.equal(out, ref_img)
+    if case != "single_frame":
+        empty = 1 if case == "one_empty_frame" else 0
+        assert torch.equal(out[empty], torch.full_like(out[empty], bg))
+    out.backward(g)
+    torch.cuda.synchronize()
+    B.check()
+    for k in pa:
+        ga, gb = pa[k].grad, pb[k].grad
+        assert torch.isfinite(gb).all()
+        assert torch.allclose(gb, ga, rtol=2e-3, atol=2e-5 * float(ga.abs().max()) + 1e-12), k
+    assert torch.allclose(fb_.grad, fa.grad, rtol=2e-4, atol=2e-6 * float(fa.grad.abs().max()) + 1e-12)
+    assert torch.allclose(B.tap, ref_tap, rtol=2e-4, atol=2e-6 * float(ref_tap.abs().max()) + 1e-12)
+    assert torch.equal(B.radii_max, ref_rad)
+    if case == "all_empty":
+        assert float(fb_.grad.abs().max()) == 0.0 and float(pb["xyz"].grad.abs().max()) == 0.0 and int(B.radii_max.max()) == 0
+
+
+def test_render_sets_with_an_empty_frame_equals_one_frame_batches():
+    """the three blends of a batch whose middle frame shows nothing (no pair: images = the sets' backgrounds, ids = -1) against
+    the same frames rendered one batch each: identical images and ids, gradients to summation order"""
+    N, W, H, F, K = 3000, 112, 80, 3, 6
+    sc = make_scene(N, W, H, seed=23)
+    rng = np.random.default_rng(6)
+    off = _offsets(sc, F)
+    off[1, :, 1] -= 40.0
+    off = _t(off)
+    rgb_np, att_np = rng.uniform(size=(N, 3)).astype(np.float32), rng.uniform(-1, 1, size=(N, 19)).astype(np.float32)
+    gs_ = [_t(rng.normal(size=(F, c, H, W)).astype(np.float32)) for c in (3, 1, 19)]
+    extr = _t(sc.extr)
+    params = lambda: {k: _t(v, True) for k, v in dict(xyz=sc.xyz, scales=sc.scale, uquats=sc.rotate, opacity=sc.opacity, rgb=rgb_np,
+                                                      attrs=att_np).items()}
+
+    def render(B, p, o):
+        sets = [dict(feature=p["rgb"], bg=0.1, taps=True), dict(feature="depth", bg=1.0),
+                dict(feature=p["attrs"], bg=0.0, detach_opacity=True)]
+        return B.render_sets(p["xyz"], p["scales"], p["uquats"], p["opacity"], sets, o, extr, K=K)
+
+    pa, pb = params(), params()
+    B = FrameBatch(F, N, W, H, 23, "cuda")
+    out = render(B, pb, off)
+    torch.autograd.backward(list(out[:3]), gs_)
+    torch.cuda.synchronize()
+    B.check()
+    assert torch.equal(out[0][1], torch.full_like(out[0][1], 0.1)) and torch.equal(out[1][1], torch.ones_like(out[1][1]))
+    assert float(out[2][1].detach().abs().max()) == 0.0 and int(out[3][1].max()) == -1
+    tap = torch.zeros_like(B.tap)
+    for f in range(F):
+        B1 = FrameBatch(1, N, W, H, 23, "cuda")
+        o1 = render(B1, pa, off[f:f + 1])
+        for a, b in zip(o1, out):
+            assert torch.equal(a[0], b[f])
+        torch.autograd.backward(list(o1[:3]), [g[f:f + 1] for g in gs_])
+        torch.cuda.synchronize()
+        tap += B1.tap
+    for k in pa:
+        a, b = pb[k].grad, pa[k].grad
+        assert torch.isfinite(a).all() and torch.allclose(a, b, rtol=2e-3, atol=2e-5 * float(b.abs().max()) + 1e-12), k
+    assert torch.allclose(B.tap, tap, rtol=1e-3, atol=1e-5 * float(tap.abs().max()) + 1e-12)
