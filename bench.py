@@ -168,6 +168,13 @@ def parse():
                          "operators, --ref-flow) in `other_configs`")
     ap.add_argument("--no-extra-lines", action="store_true",
                     help="skip the second workload of the line (N = 1: the reference's training frame, --render-iter --dynamic)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="--gpus 1 without a launcher: initialise the RCCL process group anyway (world size 1 on 127.0.0.1), so that "
+                         "`ranks_seen` comes from a real RCCL all-reduce and the step's collective executes on the one GPU of the box")
+    ap.add_argument("--zero1", action="store_true",
+                    help="ZeRO-1 schedule of the step: reduce-scatter of the flat gradient buffer, Adam on this rank's 1 / N block "
+                         "(moments sharded), all-gather of the updated parameters (parallel.Zero1Shards); the default line at N > 1 "
+                         "times it beside `synchronous` and `overlap_exact`")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: start / join the N ranks, all-reduce ones, print {n_gpus, ranks_seen} and exit")
     return ap.parse_args()
@@ -197,7 +204,7 @@ class FrameRenderer:
     one flat bucket (views), one all-reduce + one Adam step per gradient step."""
 
     def __init__(self, sc, device, frames, C_extra=0, mode="batch", dynamic=False, stale_overlap=False, optimizer=True,
-                 halves=False, attr_channels=19):
+                 halves=False, attr_channels=19, zero1=False):
         self.sc = sc
         self.mode = mode
         self.dynamic = dynamic
@@ -246,13 +253,21 @@ class FrameRenderer:
         self.overlap = bool(stale_overlap) and dist.is_available() and dist.is_initialized()
         # --overlap (exact): two half-batches, a gradient buffer each (parallel.overlapped_halves_step)
         self.halves = bool(halves) and mode in ("batch", "render_iter") and len(frames) >= 2 and not self.overlap
+        # --zero1: the flat buffer in `world` equal blocks (parallel.Zero1Shards): reduce-scatter -> Adam on 1 / world -> all-gather
+        self.zero1 = bool(zero1) and optimizer and not self.overlap and not self.halves
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.bucket = FlatGradBucket({k: torch.as_tensor(v, device=device) for k, v in src.items()},
-                                     buffers=2 if (self.overlap or self.halves) else 1)
+                                     buffers=2 if (self.overlap or self.halves) else 1, pad_to=4 * world if self.zero1 else 1)
         self.p = self.bucket.params
         # Adam on the flat buffer (the reference's optimiser, eps 1e-15).  The learning rate is kept small so that the
         # synthetic scene's statistics (pairs per frame, list lengths) stay put over the run's steps: the cost of the
         # update does not depend on it.
         self.opt = FlatAdam(self.bucket, 1e-6, eps=1e-15) if (optimizer and not self.overlap) else None
+        if self.zero1:
+            from splatter_a_video_amd.optim import OwnerShardedAdam
+            from splatter_a_video_amd.parallel import Zero1Shards
+            self.shards = Zero1Shards(self.bucket, world, dist.get_rank() if world > 1 else 0)
+            self.opt = OwnerShardedAdam(self.bucket, self.shards, 1e-6, eps=1e-15)
         self.extr = torch.tensor(sc.extr, device=device)
         self.phase = torch.tensor(sc.phase, device=device)
         self.dirs = torch.zeros(N, 3, device=device)
@@ -580,6 +595,14 @@ class FrameRenderer:
             if feat is not None:
                 feat.backward(self._feat_in.grad)
                 self._feat_in = None
+        if self.zero1:
+            from splatter_a_video_amd.parallel import owner_gather, owner_reduce
+            if collective:
+                owner_reduce(self.bucket, self.shards)
+            self.opt.step()
+            if collective:
+                owner_gather(self.bucket, self.shards)
+            return
         if collective and dist.is_available() and dist.is_initialized():
             self.bucket.all_reduce(async_op=self.overlap)     # synchronous unless --stale-overlap
         if self.opt is not None:
@@ -753,8 +776,10 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
     start["pos_cubic_node"] = torch.zeros_like(start["pos_cubic_node"])
     cfg = TS.DensifyConfig(cameras_extent=5.0)
     lr = {k: 1e-6 for k in TS.REFERENCE_LR}      # as everywhere in this file: small rates keep the scene's statistics put over the run
-    st = TS.TrainingStep(start, clock, sc.W, sc.H, len(t1), extr, lr=lr, densify=cfg, K=20, owner_sharded=a.owner_sharded)
-    del truth, start
+    st = TS.TrainingStep(start, clock, sc.W, sc.H, len(t1), extr, lr=lr, densify=cfg, K=20, owner_sharded=a.owner_sharded, zero1=a.zero1)
+    del truth
+    if not (world > 1 and not a.zero1 and not a.owner_sharded):
+        start = None
     dt = timed(lambda: st.step(t1, t2, gt))
     st.fb.check()
     loss = st.loss()
@@ -804,6 +829,28 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
     dens_ms = min(dens)
     F = len(t1)
     amort = dens_ms / cfg.interval
+    sharded = a.owner_sharded or a.zero1
+    opt_desc = ("ZeRO-1: reduce-scatter of the flat gradient, Adam on this rank's 1 / N block, all-gather of the parameters" if a.zero1 else
+                "owner-sharded spline table (reduce to owner, sharded moments, gather)" if a.owner_sharded
+                else "all-reduce of the flat bucket + replicated Adam")
+    moments_MB = round(sum(t.numel() for t in ((st.opt.m_own, st.opt.v_own, st.opt.m_rep, st.opt.v_rep)
+                                               if sharded else (st.opt.exp_avg, st.opt.exp_avg_sq))) * 4 / 1e6, 1)
+    bucket_MB = round(st.bucket.flat_grad.numel() * 4 / 1e6, 1)
+    pairs_M = int(st.fb.pairs.max().item())
+    zero1 = None
+    if start is not None:      # N > 1, default schedule: the same step under ZeRO-1 beside it (every rank takes part)
+        try:
+            del st
+            torch.cuda.empty_cache()
+            st = TS.TrainingStep(start, clock, sc.W, sc.H, len(t1), extr, lr=lr, densify=cfg, K=20, zero1=True)
+            dtz = timed(lambda: st.step(t1, t2, gt))
+            st.fb.check()
+            zero1 = {"train_step_ms": round(dtz / a.steps * 1e3, 3), "value": round(F * a.steps * world / dtz, 2), "unit": "frames/s",
+                     "adam_moments_MB_per_rank": round((st.opt.m_own.numel() + st.opt.v_own.numel()) * 4 / 1e6, 1),
+                     "what": "the same step with zero1=True: reduce-scatter of the flat gradient, Adam on 1 / N, all-gather"}
+        except Exception as e:   # noqa: BLE001
+            zero1 = {"error": repr(e)[:300]}
+        del start
     return {
         "metric": "training steps of the reference's trainer composed from the native pieces (src/trainer_fragGS.py:736-790), "
                   f"{F} (ids1, ids2) pairs per rank and step @480p, 300k Gaussians",
@@ -823,13 +870,10 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
                                "sampled vertices + ARAP per pair, render_iter's three blends (rgb enhanced K=20 with taps | depth | "
                                "track_gs + 16 attribute channels, opacity detached), L1 on the three images, backward, "
                                "all-reduce, Adam on the flat buffer, densification statistics",
-                   "equivalent_flags": "--train-step" + (" --owner-sharded" if a.owner_sharded else ""),
-                   "tile_pairs_M": int(st.fb.pairs.max().item()),
-                   "grad_bucket_MB": round(st.bucket.flat_grad.numel() * 4 / 1e6, 1),
-                   "optimizer": ("owner-sharded spline table (reduce to owner, sharded moments, gather)" if a.owner_sharded
-                                 else "all-reduce of the flat bucket + replicated Adam"),
-                   "adam_moments_MB_per_rank": round(sum(t.numel() for t in ((st.opt.m_own, st.opt.v_own, st.opt.m_rep, st.opt.v_rep)
-                                                         if a.owner_sharded else (st.opt.exp_avg, st.opt.exp_avg_sq))) * 4 / 1e6, 1)}}
+                   "equivalent_flags": "--train-step" + (" --owner-sharded" if a.owner_sharded else "") + (" --zero1" if a.zero1 else ""),
+                   "tile_pairs_M": pairs_M, "grad_bucket_MB": bucket_MB, "optimizer": opt_desc,
+                   "adam_moments_MB_per_rank": moments_MB},
+        "zero1": zero1}
 
 
 def main():
@@ -837,6 +881,17 @@ def main():
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run (any N)
     if a.gpus > 1 and not launched:
         sys.exit(self_launch(a))
+    if a.force_process_group and not launched and a.gpus == 1:
+        # a world of one rank, rendezvous on 127.0.0.1: everything below runs as under the launcher (RCCL communicator, the
+        # `ranks_seen` all-reduce, the step's collective on RCCL's stream)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        launched = True
+        import splatter_a_video_amd.parallel as _par
+        _par.MIN_WORLD = 1      # the owner / ZeRO-1 collectives (reduce-scatter, all-gather) run in a world of one rank too
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -947,7 +1002,7 @@ def main():
         return
 
     R = FrameRenderer(sc, dev, frames, a.channels, mode=mode, dynamic=a.dynamic, stale_overlap=a.stale_overlap,
-                      optimizer=not a.no_optimizer, halves=a.overlap, attr_channels=a.attr_channels)
+                      optimizer=not a.no_optimizer, halves=a.overlap, attr_channels=a.attr_channels, zero1=a.zero1)
     dt = timed(R.step, R.finish)
     R.check_sorts()   # the sync-free sorts of the timed steps all fitted their capacity (raises otherwise)
 
@@ -996,6 +1051,19 @@ def main():
                 del R3
             except Exception as e:   # noqa: BLE001
                 comm["overlap_exact"] = {"error": repr(e)[:300]}
+        if with_overlap and not a.zero1 and not a.overlap and not a.no_optimizer:
+            try:
+                R4 = FrameRenderer(sc, dev, frames, a.channels if mode_ == mode else 0, mode=mode_, dynamic=dynamic_, zero1=True)
+                dt4 = timed(R4.step, R4.finish)
+                R4.check_sorts()
+                comm["zero1"] = {"value": round(a.frames * a.steps * world / dt4, 2), "unit": "frames/s",
+                                 "ms_per_step": round(dt4 / a.steps * 1e3, 3),
+                                 "adam_moments_MB_per_rank": round(2 * (R4.shards.own[1] - R4.shards.own[0]) * 4 / 1e6, 1),
+                                 "what": "same step with --zero1: reduce-scatter of the flat gradient buffer, Adam on this rank's "
+                                         "1 / N block (moments sharded), all-gather of the updated parameters (exact)"}
+                del R4
+            except Exception as e:   # noqa: BLE001
+                comm["zero1"] = {"error": repr(e)[:300]}
         return comm
 
     comm = comm_analysis(R, dt, mode, a.dynamic)
@@ -1006,13 +1074,16 @@ def main():
         half's all-reduce under the second half's frames -- same parameters to fp32 summation order).  The line reports the
         faster one and says which; the other stays in `comm`."""
         ov = (comm_ or {}).get("overlap_exact") or {}
-        if a.overlap or "value" not in ov:
+        z1 = (comm_ or {}).get("zero1") or {}
+        if a.overlap or a.zero1 or ("value" not in ov and "value" not in z1):
             return dt_, None
         sync_fps = frames_total / dt_
         comm_["synchronous"] = {"value": round(sync_fps, 2), "unit": "frames/s", "ms_per_step": round(dt_ / a.steps * 1e3, 3)}
-        if ov["value"] > sync_fps:
-            return frames_total / ov["value"], "exact half-batch overlap"
-        return dt_, "synchronous"
+        best, name = sync_fps, "synchronous"
+        for cand, label in ((ov, "exact half-batch overlap"), (z1, "zero1: reduce-scatter -> sharded Adam -> all-gather")):
+            if cand.get("value", 0) > best:
+                best, name = cand["value"], label
+        return (dt_ if name == "synchronous" else frames_total / best), name
 
     dt, schedule = faster_exact_schedule(dt, comm)
     fps = frames_total / dt
@@ -1179,6 +1250,20 @@ def main():
             except Exception as e:   # noqa: BLE001  (must not cost the line its headline)
                 other_configs.append({"what": what, "equivalent_flags": flags, "error": repr(e)[:300]})
             torch.cuda.empty_cache()
+        # what the UNCHANGED trainer pays per step for its neighbour search (src/trainer_fragGS.py:672 ->
+        # src/geometry_utils.py:15: knn_points over ALL N Gaussians, K = 5 + self), through the shim's import name, timed like `value`
+        try:
+            sys.path.insert(1, os.path.join(ROOT, "shims"))
+            from pytorch3d.ops import knn_points
+            pts = R.p["xyz"].detach() + R.offs[0] if not R.dynamic else R.position
+            with torch.no_grad():
+                dtk = timed(lambda: knn_points(pts[None], pts[None], None, None, K=6))
+            other_configs.append({"what": "pytorch3d.ops.knn_points(points[None], points[None], None, None, K=6) over all "
+                                          f"{a.gaussians} Gaussians (shims/: the unchanged trainer's neighbour search, once per step)",
+                                  "equivalent_flags": "(knn_full)", "value": round(dtk / a.steps * 1e3, 4), "unit": "ms",
+                                  "higher_is_better": False})
+        except Exception as e:   # noqa: BLE001
+            other_configs.append({"what": "knn_points over all Gaussians", "equivalent_flags": "(knn_full)", "error": repr(e)[:300]})
 
     cpu = cpu_c = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -1189,6 +1274,8 @@ def main():
         par = f"frame-sharded dp{world}, " + ("stale-1: all-reduce overlapped with the next step, no optimiser" if R.overlap else
                                               "exact overlap: two half-batches, all-reduce of half 1 under half 2, sum -> Adam -> next forward"
                                               if (R.halves or schedule == "exact half-batch overlap") else
+                                              "zero1: reduce-scatter of the flat gradient, Adam on 1 / N, all-gather of the parameters"
+                                              if (R.zero1 or (schedule or "").startswith("zero1")) else
                                               "synchronous: all-reduce -> Adam -> next forward" if R.opt is not None else
                                               "synchronous all-reduce, no optimiser")
         line = {
@@ -1212,8 +1299,8 @@ def main():
                                    + (", Adam step on the flat parameter buffer" if R.opt is not None else ""),
                        "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
                        "tile_pairs_M": M, "channels": R.C, "parallelism": par,
-                       "schedule": schedule and (schedule + " (the faster of the two exact schedules timed in this run; the other: comm."
-                                                 + ("synchronous" if schedule != "synchronous" else "overlap_exact") + ")"),
+                       "schedule": schedule and (schedule + " (the fastest of the exact schedules timed in this run; the others: "
+                                                 "comm.synchronous / comm.overlap_exact / comm.zero1)"),
                        "gaussian_order": "random" if a.no_spatial_order else "morton (densify.spatial_order at setup)",
                        "frame_inputs": "the frames' position offsets / frame tables are built once per clip at set-up; the timed step "
                                        "launches this library's kernels only",
@@ -1245,6 +1332,23 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c_oracle": cpu_c, "kernels": kernels,
             "extra_lines": extra_lines, "other_configs": other_configs,
         }
+        # compact summary of the reference's real workloads, the LAST key of the line (the driver keeps the line's last 2000
+        # characters): every figure is timed in THIS run like `value`
+        oc = {x.get("equivalent_flags"): x for x in other_configs if "error" not in x}
+        el = [x for x in extra_lines if "error" not in x]
+        pick = lambda d, k: None if d is None else d.get(k)
+        tf = next((x for x in el if "training frame" in x.get("metric", "")), None)
+        ts = next((x for x in el if "train_step_ms" in x), None)
+        line["summary"] = {"headline_fps": line["value"], "training_frame_fps": pick(tf, "value"), "train_step_ms": pick(ts, "train_step_ms"),
+                           "c4_fps": pick(oc.get("--gaussians 1000000 --width 1280 --height 720"), "value"),
+                           "c5_fps": pick(oc.get("--channels 32"), "value"),
+                           "render_iter_fps": pick(oc.get("--render-iter"), "value"),
+                           "render_iter_attr4_fps": pick(oc.get("--render-iter --attr-channels 4"), "value"),
+                           "per_frame_fps": pick(oc.get("--per-frame"), "value"),
+                           "ref_flow_fwd_fps": pick(oc.get("--ref-flow"), "forward_only"),
+                           "knn_full_ms": pick(oc.get("(knn_full)"), "value"),
+                           "fwd_only_fps": pick(forward_only, "value"), "n_gpus": world, "ranks_seen": ranks_seen,
+                           "build_id": L.build_id()}
         print(json.dumps(line))
     if launched:
         dist.barrier()  # rank 0 did extra (untimed) measurement work: leave together

@@ -712,7 +712,10 @@ int splat_adam_step_pattern(int64_t n, float *param, const float *grad, float *e
  *      edge); sample_idx [S] vertex ids.  energy (1 float, zero-filled by the caller) += sum over sampled vertices, frames
  *      t >= 1 and edges of w |e_tgt - R e_src|^2 (NOT yet divided by Nt); d_nodes (optional [Nt,Nv,3], zero-filled) +=
  *      d energy / d nodes with R held constant (the reference estimates it under no_grad); rotations (optional
- *      [Nt-1,S,3,3]) = the rotation of every (frame, sample). ---- */
+ *      [Nt-1,S,3,3]) = the rotation of every (frame, sample).
+ *      Index preconditions (device arrays, not validated on the host): 0 <= sample_idx < Nv; nbr in [0, Nv) or -1.  The
+ *      kernels stay memory-safe outside them: a sample outside the set contributes nothing, a neighbour id outside it counts
+ *      as "no edge". ---- */
 int splat_arap_energy(int Nt, int Nv, int K, int S, const float *nodes, const int32_t *nbr, const float *weight,
                       const int64_t *sample_idx, float *energy, float *d_nodes, float *rotations, splat_stream_t stream);
 
@@ -729,7 +732,8 @@ int splat_arap_energy_batch(int B, int Nt, int Nv, int K, int S, const float *no
  * (src/geometry_utils.py:17-19,98-101) without a grid build per point set.  Four launches: tile boxes, a distance bound per query
  * from its index neighbourhood, the scan (a wave skips the tiles whose box lies beyond all of its queries' bounds: hand the
  * queries in ascending index order when the points are spatially ordered), the merge.  Exact whatever the order.
- * scratch: splat_knn_brute_scratch_bytes(B, N, S). */
+ * Precondition (device array, not validated on the host): 0 <= query_idx < N; an id outside is clamped into the set
+ * (memory-safe, the row is then that of vertex 0 / N - 1).  scratch: splat_knn_brute_scratch_bytes(B, N, S). */
 size_t splat_knn_brute_scratch_bytes(int B, int N, int S);
 int splat_knn_brute_batch(int B, int N, int S, int K, const float *points, int64_t points_batch_stride,
                           const int64_t *query_idx, float *dists, int32_t *idx, void *scratch, splat_stream_t stream);

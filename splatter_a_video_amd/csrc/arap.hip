@@ -122,6 +122,7 @@ arap_kernel(int Nt, int Nv, int K, int S_, const float *__restrict__ nodes, cons
     energy += b;
     if (rot_out) rot_out += (size_t)b * (size_t)S_ * (Nt - 1) * 9;
     const int i = (int)sample_idx[s];
+    if ((unsigned)i >= (unsigned)Nv) return;   // memory safety: a sample outside the vertex set contributes nothing
     if (bt.nbr_compact) {   // rows by sample: shift the tables so that row i below is sample s of sequence b
         const long long off = ((long long)b * S_ + s - i) * K;
         nbr += off;
@@ -136,7 +137,8 @@ arap_kernel(int Nt, int Nv, int K, int S_, const float *__restrict__ nodes, cons
     // (planar or axis-constant motion), not only when all K x 3 entries are
     bool same_axis[3] = {true, true, true};
     for (int k = 0; k < K; ++k) {
-        const int j = nbr[(size_t)i * K + k];
+        int j = nbr[(size_t)i * K + k];
+        j = (unsigned)j < (unsigned)Nv ? j : -1;   // memory safety: an id outside the vertex set is "no edge", like -1
         w[k] = weight ? weight[(size_t)i * K + k] : (j >= 0 ? 1.f : 0.f);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -165,7 +167,8 @@ arap_kernel(int Nt, int Nv, int K, int S_, const float *__restrict__ nodes, cons
     }
     float e = 0.f, gi0[3] = {0.f, 0.f, 0.f}, git[3] = {0.f, 0.f, 0.f};
     for (int k = 0; k < K; ++k) {
-        const int j = nbr[(size_t)i * K + k];
+        int j = nbr[(size_t)i * K + k];
+        j = (unsigned)j < (unsigned)Nv ? j : -1;   // memory safety: an id outside the vertex set is "no edge", like -1
         float st[3];  // stretch vector e_tgt - R e_src (:113-115)
 #pragma unroll
         for (int r = 0; r < 3; ++r) st[r] = et[k][r] - (R[r][0] * es[k][0] + R[r][1] * es[k][1] + R[r][2] * es[k][2]);

@@ -279,7 +279,7 @@ knn_brute_bound_kernel(int N, int S, int K, const float *__restrict__ pts, long 
     const int q = blockIdx.x * KB + threadIdx.x, b = blockIdx.y;
     if (q >= S) return;
     const float *P = pts + (size_t)b * pts_bs;
-    const int v = (int)qidx[(size_t)b * S + q];
+    const int v = imin_(imax_((int)qidx[(size_t)b * S + q], 0), N - 1);   // memory safety: ids are clamped into the set
     const float qx = P[3 * (size_t)v], qy = P[3 * (size_t)v + 1], qz = P[3 * (size_t)v + 2];
     float bd[KT];
     int bi[KT];
@@ -350,7 +350,7 @@ knn_brute_partial_kernel(int N, int S, int G, int NT, const float *__restrict__ 
     const float *__restrict__ P = pts + (size_t)b * pts_bs;
     float qx = 0.f, qy = 0.f, qz = 0.f, bound = -1.f;   // (a lane past the queries takes no candidate)
     if (q < S) {
-        const long long v = qidx[(size_t)b * S + q];
+        const long long v = imin_(imax_((int)qidx[(size_t)b * S + q], 0), N - 1);
         qx = P[3 * v]; qy = P[3 * v + 1]; qz = P[3 * v + 2];
         bound = tau[(size_t)b * S + q];
     }

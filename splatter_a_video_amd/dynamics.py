@@ -342,7 +342,16 @@ def frame_table(clock: FrameClock, times, device) -> Tensor:
         host[f, 0] = np.array([seg], np.int32).view(np.float32)[0]
         host[f, 1] = d
         host[f, 2:14] = np.frombuffer(basis, dtype=np.float32, count=12)
-    return torch.from_numpy(host).to(device)
+    return _upload(host, device)
+
+
+def _upload(host: np.ndarray, device) -> Tensor:
+    """a small host table to the device without blocking the host: pinned staging + asynchronous copy on the current stream
+    (a pageable ``.to(device)`` is a synchronous copy on the step's critical path)"""
+    t = torch.from_numpy(host)
+    if torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
 
 
 def positions_batch_forward(tab: Tensor, position: Tensor, pos_cubic_node: Tensor, interval_num: int,

@@ -108,8 +108,9 @@ class _Camera:
         return (self.extr,) if self.intr is None else (self.extr, self.intr)
 
 
-# python-level switches of the multi-set paths (tests flip them; the library's own options: L.set_option)
-OPTIONS = {"sets_one_pass": os.environ.get("SPLAT_SETS_ONE_PASS", "1") != "0"}
+# python-level switch of the multi-set paths (tests flip it in code -- no environment variable is read; the library's own
+# options: L.set_option)
+OPTIONS = {"sets_one_pass": True}
 
 
 def _tiles(W: int, H: int) -> int:
@@ -350,7 +351,8 @@ class FrameBatch:
                 host[f, 0] = np.array([seg], np.int32).view(np.float32)[0]
                 host[f, 1] = d
                 host[f, 2:14] = np.frombuffer(basis, dtype=np.float32, count=12)
-            tab = torch.from_numpy(host).to(self.dev)
+            from .dynamics import _upload
+            tab = _upload(host, self.dev)
             cache[key] = tab
         return tab
 
@@ -693,6 +695,9 @@ def _blend_sources_forward(fb, meta, parts, feats, opacity, K):
     if bgc is None:
         bgc = torch.tensor([bg for (w, bg, _, _), n in zip(meta, widths) for _ in range(n)], dtype=torch.float32, device=fb.dev)
         cache[meta] = bgc
+    nsrc = sum(1 if w == "depth" else len(pp) for (w, _, _, _), pp in zip(meta, parts))    # the depth counts as a source
+    if nsrc > L.MAX_SOURCES:
+        raise ValueError(f"at most {L.MAX_SOURCES} feature sources per row (the depth counts as one), got {nsrc}")
     table = (L.FeatureSource * L.MAX_SOURCES)()
     n, c0, it = 0, 0, iter(feats)
     for (w, _, _, _), pp in zip(meta, parts):
@@ -703,8 +708,6 @@ def _blend_sources_forward(fb, meta, parts, feats, opacity, K):
             continue
         for cn, per_frame in pp:
             t = next(it)
-            if n >= L.MAX_SOURCES:
-                raise ValueError(f"at most {L.MAX_SOURCES} feature tensors per row")
             table[n].c0, table[n].cn, table[n].feature = c0, cn, t.data_ptr()
             table[n].frame_stride = int(t.stride(0)) if per_frame else 0
             n += 1
@@ -715,7 +718,9 @@ def _blend_sources_forward(fb, meta, parts, feats, opacity, K):
         L.ci(F), L.ci(P), L.ci(C), L.ci(n), table, L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity), ctypes.c_int64(0),
         L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.ptr(bgc), L.ci(W), L.ci(H), L.ci(K), L.ci(0),
         L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx), L.ptr(fb.pack), L.ptr(fb.cull_flags), st))
-    return out, gs_idx, dict(plan=plan, tens=None, row=None, widths=widths)
+    # (the forward-pack decision is taken HERE and kept in the autograd context: an option flipped between this forward and its
+    #  backward must not change what the backward stages)
+    return out, gs_idx, dict(plan=plan, tens=None, row=None, widths=widths, std=_uses_forward_pack(plan, C))
 
 
 def _blend_sets_forward(fb, meta, feats, opacity, op_fs, K):
@@ -758,7 +763,7 @@ def _blend_sets_forward(fb, meta, feats, opacity, op_fs, K):
             L.ptr(opacity), ctypes.c_int64(op_fs), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.ptr(bgc),
             L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx),
             L.ptr(fb.pack), L.ptr(fb.cull_flags), st))
-    return out, gs_idx, dict(plan=plan, tens=tens, row=row, widths=widths)
+    return out, gs_idx, dict(plan=plan, tens=tens, row=row, widths=widths, std=_uses_forward_pack(plan, C))
 
 
 def _set_tables(meta, plan, tens, P):
@@ -793,7 +798,7 @@ def _blend_sets_backward_one_pass(fb, meta, state, grads, opacity, op_fs, want_a
     rec = fb._set_buffer(("rec", "sets"), F * cap * int(lib.splat_blend_sets_pair_stride(C)))
     # the renderer's own plan (rgb 0-2 with the taps | depth 3 | 19 detached attributes 4-22): the tile kernel stages the records
     # the FORWARD packed (fb.pack) -- no packing launch, no second record array; other plans pack their own
-    std = _uses_forward_pack(plan, C)
+    std = state["std"] if "std" in state else _uses_forward_pack(plan, C)     # decided at forward time
     pack = None if std else fb._set_buffer(("pack", "sets"), F * P * int(lib.splat_blend_sets_pack_floats()))
     L.check(lib.splat_alpha_blending_backward_batch_sets_packed(
         L.ci(F), L.ci(P), L.ci(C), tabs["c0"], tabs["cn"], tabs["bg"], L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity),

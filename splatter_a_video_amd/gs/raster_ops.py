@@ -510,7 +510,7 @@ def _blend_shared_one_pass(ctx, grads):
     assert ncp == (NG + C + 3) // 4 * 4
     rec = torch.empty(M * ncp, dtype=torch.float32, device=dev)
     i3_ = ctypes.c_int32 * 3
-    std = ctx.fwd_pack is not None and bool(lib.splat_blend_sets_uses_forward_pack(L.ci(C), i3_(*c0s), i3_(*cns), L.ci(1)))
+    std = ctx.fwd_pack is not None           # decided at forward time (the library option is not re-queried here)
     pack = None if std else torch.empty(max(P, 1) * int(lib.splat_blend_sets_pack_floats()), dtype=torch.float32, device=dev)
     i3, f3, p3, l3 = ctypes.c_int32 * 3, ctypes.c_float * 3, ctypes.c_void_p * 3, ctypes.c_int64 * 3
     pm = ctx.pairmap
@@ -535,9 +535,9 @@ def _blend_shared_one_pass(ctx, grads):
 
 _BlendShared._one_pass = staticmethod(_blend_shared_one_pass)
 
-# python-level switches of the shared blend (tests flip them; the library's own options: L.set_option)
-OPTIONS = {"shared_one_pass": os.environ.get("SPLAT_SHARED_ONE_PASS", "1") != "0",
-           "sets_fwdrec": os.environ.get("SPLAT_SETS_FWDREC", "1") != "0"}
+# python-level switches of the shared blend (tests flip them in code -- no environment variable is read; the library's own
+# options: L.set_option)
+OPTIONS = {"shared_one_pass": True, "sets_fwdrec": True}
 
 
 def _uses_forward_pack(widths, detach, taps) -> bool:

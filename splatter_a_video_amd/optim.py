@@ -149,11 +149,19 @@ class OwnerShardedAdam:
         lo, hi = shards.own
         if lo % 4 or hi % 4 or shards.b % 4:
             raise ValueError("block boundaries must be multiples of 4 floats (16-byte aligned sub-buffers)")
+        self._check_owned_rate()
         dev = bucket.flat_param.device
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
         self.m_own, self.v_own = z(hi - lo), z(hi - lo)
         self.m_rep, self.v_rep = z(shards.total - shards.b), z(shards.total - shards.b)
         self.t = 0
+
+    def _check_owned_rate(self) -> None:
+        """an ``OwnerShards`` parameter is cut in whole UNITS (segments of the spline table), not in periods of a pattern: a
+        PatternLR there is refused on every rank alike (``Zero1Shards`` has no owned parameter: its blocks handle the phase)"""
+        n = getattr(self.shards, "name", None)
+        if n is not None and isinstance(self.lr[n], PatternLR):
+            raise ValueError(f"the owned parameter {n!r} cannot take a PatternLR")
 
     def set_lr(self, lr: Union[float, Dict[str, float]]) -> None:
         """as ``FlatAdam.set_lr``"""
@@ -166,14 +174,28 @@ class OwnerShardedAdam:
         else:
             for n in self.lr:
                 self.lr[n] = float(lr)
+        self._check_owned_rate()
 
     def _segments(self, lo: int, hi: int):
-        """learning-rate segments (+ patterns) of the sub-buffer [lo, hi), relative to lo"""
-        sl = {n: (max(a, lo) - lo, min(b, hi) - lo) for n, (a, b) in self.bucket.slices.items() if min(b, hi) > max(a, lo)}
-        for n, (a, _) in sl.items():
-            if isinstance(self.lr[n], PatternLR) and self.bucket.slices[n][0] < lo:
-                raise ValueError(f"the pattern of group {n!r} would start inside the group")
-        return lr_segments(sl, self.lr, patterns=True)
+        """learning-rate segments (+ patterns) of the sub-buffer [lo, hi), relative to lo.  A block that starts INSIDE a
+        ``PatternLR`` group (ZeRO-1 cuts the buffer anywhere) starts mid-period: the rest of that period becomes a segment of its
+        own (what is left of the head keeps the head rate), the whole periods behind it keep the pattern."""
+        sl, lrs = {}, {}
+        for n, (a, b) in self.bucket.slices.items():
+            s0, s1 = max(a, lo), min(b, hi)
+            if s1 <= s0:
+                continue
+            r = self.lr[n]
+            if isinstance(r, PatternLR) and (s0 - a) % r.period:
+                ph = (s0 - a) % r.period
+                cut = min(s0 + r.period - ph, s1)
+                sl[n + "#pre"] = (s0 - lo, cut - lo)
+                lrs[n + "#pre"] = PatternLR(r.lr, r.head_lr, r.period, r.head - ph) if ph < r.head else r.lr
+                if s1 > cut:
+                    sl[n], lrs[n] = (cut - lo, s1 - lo), r
+            else:
+                sl[n], lrs[n] = (s0 - lo, s1 - lo), r
+        return lr_segments(sl, lrs, patterns=True)
 
     def _step(self, lo: int, hi: int, m, v, grad_scale: float) -> None:
         if hi <= lo:
@@ -222,11 +244,17 @@ class OwnerShardedAdam:
         self.m_rep.copy_(exp_avg[sh.b:sh.total]); self.v_rep.copy_(exp_avg_sq[sh.b:sh.total])
 
     def zero_moments(self, name: str) -> None:
+        """the moments of parameter ``name`` := 0: its part of the replicated slice, or what of it lies in this rank's block"""
         a, b = self.bucket.slices[name]
         sh = self.shards
         if a >= sh.b:
             for t in (self.m_rep, self.v_rep):
                 t[a - sh.b:b - sh.b].zero_()
-        else:
+            return
+        if b > sh.b:
+            raise ValueError(f"parameter {name!r} straddles the owned / replicated boundary")
+        lo, hi = sh.own
+        s0, s1 = max(a, lo), min(b, hi)
+        if s1 > s0:
             for t in (self.m_own, self.v_own):
-                t.zero_()
+                t[s0 - lo:s1 - lo].zero_()

@@ -35,13 +35,16 @@ class FlatGradBucket:
     RCCL's stream while the next step's frames fill the other buffer -- the reduction is off the critical path instead
     of between two steps (``swap()`` waits for the collective that last used the buffer it switches to)."""
 
-    def __init__(self, tensors: Dict[str, torch.Tensor], buffers: int = 1):
+    def __init__(self, tensors: Dict[str, torch.Tensor], buffers: int = 1, pad_to: int = 1):
         if buffers < 1:
             raise ValueError("buffers must be >= 1")
         names = list(tensors)
         dev = tensors[names[0]].device
         total = sum(t.numel() for t in tensors.values())
-        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        # ``pad_to``: the flat buffers' length rounded up to a multiple (ZeRO-1 deals the buffer in `world` equal blocks of whole
+        # float4: pad_to = 4 * world).  The tail belongs to no parameter: zero parameters, zero gradients, Adam leaves it at 0.
+        total = -(-total // int(pad_to)) * int(pad_to)
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grads = [torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(buffers)]
         self.pending = [None] * buffers            # outstanding collective per buffer
         self.active = 0
@@ -146,7 +149,7 @@ def reduce_densify_batch(viewspace_grad: torch.Tensor, visibility: torch.Tensor,
     their visibility and maxes their radii (dptr_ortho_enhanced.py:425-431, frag_model.py:326-343); with the batch's
     frames spread over the ranks that is SUM / MAX / MAX across the process group.  Call it once per step, after the
     local frames' backward passes and before ``DensifyState.update()``.  No-op without a process group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _group_on():
         return
     dist.all_reduce(viewspace_grad, op=dist.ReduceOp.SUM)
     v = visibility.to(torch.int32)
@@ -240,15 +243,30 @@ class OwnerShards:
         return [f for f, u in enumerate(unit_of_frame) if u0 <= u < u1]
 
 
-def owner_reduce(bucket: FlatGradBucket, shards: OwnerShards) -> None:
+# A process group of ONE rank normally skips the owner collectives (nothing to exchange).  ``MIN_WORLD = 1`` makes them run
+# anyway: the RCCL first-contact test and ``bench.py --force-process-group`` execute every collective signature of the 8-GPU
+# run -- reduce_scatter_tensor, all_gather_into_tensor, the asynchronous all-reduce beside them -- on the one GPU a box has.
+MIN_WORLD = 2
+
+
+def _group_on() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() >= MIN_WORLD
+
+
+def owner_reduce(bucket: FlatGradBucket, shards) -> None:
     """gradients after the local backward: all-reduce of the replicated part || reduce-scatter of the owned part (afterwards a
-    rank's gradient of the owned parameter is complete in ITS block only; the other blocks hold partial sums nobody reads)"""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    rank's gradient of the owned parameter is complete in ITS block only; the other blocks hold partial sums nobody reads).
+    ``shards``: ``OwnerShards`` (one owned parameter + a replicated rest) or ``Zero1Shards`` (the whole buffer is owned)."""
+    if not _group_on():
         return
     world = dist.get_world_size()
     g = bucket.flat_grad
     lo, hi = shards.own
-    work = dist.all_reduce(g[shards.b:shards.total], op=dist.ReduceOp.SUM, async_op=True)   # replicated part
+    # the replicated part's all-reduce is issued first and waited for last: on RCCL both collectives are enqueued, in this
+    # order on every rank, on the process group's one stream -- the reduce-scatter runs behind it, not beside it
+    work = None
+    if shards.total > shards.b:
+        work = dist.all_reduce(g[shards.b:shards.total], op=dist.ReduceOp.SUM, async_op=True)
     if dist.get_backend() == "nccl" and shards.equal:
         own = torch.empty(hi - lo, dtype=g.dtype, device=g.device)
         dist.reduce_scatter_tensor(own, g[shards.a:shards.b], op=dist.ReduceOp.SUM)
@@ -256,12 +274,13 @@ def owner_reduce(bucket: FlatGradBucket, shards: OwnerShards) -> None:
     else:   # uneven blocks / backends without reduce-scatter (gloo): one reduce per owner -- the same bytes
         for r in range(world):
             dist.reduce(g[shards.bounds[r]:shards.bounds[r + 1]], dst=r, op=dist.ReduceOp.SUM)
-    work.wait()
+    if work is not None:
+        work.wait()
 
 
-def owner_gather(bucket: FlatGradBucket, shards: OwnerShards, flat: torch.Tensor = None) -> None:
+def owner_gather(bucket: FlatGradBucket, shards, flat: torch.Tensor = None) -> None:
     """the owners' updated blocks to every rank (``flat``: another buffer laid out like the bucket, e.g. assembled moments)"""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not _group_on():
         return
     p = bucket.flat_param if flat is None else flat
     lo, hi = shards.own
@@ -273,7 +292,7 @@ def owner_gather(bucket: FlatGradBucket, shards: OwnerShards, flat: torch.Tensor
                 dist.broadcast(p[shards.bounds[r]:shards.bounds[r + 1]], src=r)
 
 
-def owner_sharded_step(bucket: FlatGradBucket, shards: OwnerShards, frames: Iterable[int], render_and_backward, optimizer,
+def owner_sharded_step(bucket: FlatGradBucket, shards, frames: Iterable[int], render_and_backward, optimizer,
                        average: bool = False) -> None:
     """One SYNCHRONOUS step with the owned parameter's gradient reduced to its owners only: zero -> local frames forward +
     backward -> all-reduce of the replicated part || reduce-scatter of the owned part -> ``optimizer.step`` (replicated part on
@@ -287,3 +306,34 @@ def owner_sharded_step(bucket: FlatGradBucket, shards: OwnerShards, frames: Iter
     owner_reduce(bucket, shards)
     optimizer.step(grad_scale=(1.0 / world) if average else 1.0)
     owner_gather(bucket, shards)
+
+
+class Zero1Shards:
+    """ZeRO-1 over the WHOLE flat buffer: `world` equal blocks of whole float4 (the bucket is built with
+    ``FlatGradBucket(..., pad_to=4 * world)``), rank r owns block r of the parameters' Adam moments and steps only that block:
+    reduce-scatter of the gradient -> Adam on 1/world of the buffer -> all-gather of the updated parameters.  On the wire the
+    bytes of the ring all-reduce, as two collectives RCCL can run over all seven xGMI links of a rank (every peer receives its
+    own block); the optimiser streams and stores 1/world.  Same interface as ``OwnerShards`` with nothing replicated:
+    ``owner_reduce`` / ``owner_gather`` / ``owner_sharded_step`` / ``optim.OwnerShardedAdam`` take either."""
+
+    def __init__(self, bucket: FlatGradBucket, world: int, rank: int):
+        total = bucket.flat_param.numel()
+        if total % (4 * int(world)):
+            raise ValueError(f"the flat buffer ({total} floats) is not {world} blocks of whole float4: build the bucket with "
+                             f"FlatGradBucket(..., pad_to={4 * int(world)})")
+        per = total // int(world)
+        self.name, self.world, self.rank = None, int(world), int(rank)
+        self.a, self.b, self.total = 0, total, total
+        self.bounds = [r * per for r in range(int(world) + 1)]
+        self.equal = True
+
+    @property
+    def own(self) -> Tuple[int, int]:
+        return self.bounds[self.rank], self.bounds[self.rank + 1]
+
+
+def zero1_step(bucket: FlatGradBucket, shards: Zero1Shards, frames: Iterable[int], render_and_backward, optimizer,
+               average: bool = False) -> None:
+    """``owner_sharded_step`` with the whole buffer owned (ZeRO-1): parameters after the step = ``sharded_step``'s to fp32
+    summation order, replicas bit-identical (every rank receives the owners' bits)."""
+    owner_sharded_step(bucket, shards, frames, render_and_backward, optimizer, average=average)

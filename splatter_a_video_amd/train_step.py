@@ -44,7 +44,7 @@ from .frames import FrameBatch
 from .gs.fused_ops import compute_sh_into
 from .gs.point_ops import project_point_ortho
 from .optim import FlatAdam, OwnerShardedAdam, PatternLR
-from .parallel import FlatGradBucket, OwnerShards, owner_gather, owner_reduce, reduce_densify_batch
+from .parallel import FlatGradBucket, OwnerShards, Zero1Shards, owner_gather, owner_reduce, reduce_densify_batch
 
 TRAINABLE = ("pos_cubic_node", "rotation", "opacity", "scaling", "shs", "attrs")
 FROZEN = ("position", "rot_poly_feat", "rot_fourier_feat")          # :90 position is not optimised; :195-197 detached tables
@@ -109,8 +109,8 @@ class TrainingStep:
     def __init__(self, params: Dict[str, Tensor], clock: FrameClock, W: int, H: int, frames_per_step: int, extr: Tensor,
                  lr: Optional[Dict[str, float]] = None, weights: Optional[LossWeights] = None,
                  densify: Optional[DensifyConfig] = None, K: int = 20, knn_K: int = 5, arap_samples: int = 512,
-                 bg: float = 0.0, sample_seed: int = 0, timing: bool = False, owner_sharded: bool = False,
-                 spatial_order: bool = True):
+                 bg: float = 0.0, sample_seed: Optional[int] = None, timing: bool = False, owner_sharded: bool = False,
+                 spatial_order: bool = True, zero1: bool = False):
         self.clock, self.W, self.H, self.F = clock, int(W), int(H), int(frames_per_step)
         self.extr = extr
         self.dev = params["position"].device
@@ -118,7 +118,6 @@ class TrainingStep:
         self.w = weights or LossWeights()
         self.cfg = densify or DensifyConfig()
         self.K, self.knn_K, self.S, self.bg = int(K), int(knn_K), int(arap_samples), float(bg)
-        self.rng = np.random.default_rng(sample_seed)
         self.timing = timing
         self.iteration = 0
         self.history: List[int] = []            # Gaussian count after every structure change
@@ -126,8 +125,16 @@ class TrainingStep:
         self.phase_ms: Dict[str, float] = {}
         on = dist.is_available() and dist.is_initialized()
         self.world, self.rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+        # the ARAP samples are drawn on the device (no host copy on the step's critical path); by default every rank draws its own
+        # (the ranks render different pairs: the seed folds the rank in)
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(int(sample_seed) if sample_seed is not None else 7919 * self.rank)
         # the spline table's gradient reduced to the owners of its time blocks, their Adam moments sharded
         self.owner_sharded = bool(owner_sharded)
+        # ZeRO-1: the WHOLE flat buffer in `world` equal blocks -- reduce-scatter, Adam on 1 / world, all-gather
+        self.zero1 = bool(zero1)
+        if self.zero1 and self.owner_sharded:
+            raise ValueError("owner_sharded and zero1 are two schedules of the same step: pick one")
         p0 = {k: params[k] for k in TRAINABLE + FROZEN}
         # setup, as after every densification: the Gaussians in Morton order of their screen positions at the clip's first frame
         # (the binning kernels' locality and the neighbour search's bound want space neighbours at neighbouring
@@ -147,10 +154,13 @@ class TrainingStep:
         self.N = N
         seg = lambda t: to_segment_major(t.reshape(N, -1), I)
         train = {k: (seg(p[k]) if k == "pos_cubic_node" else p[k].contiguous()) for k in TRAINABLE}
-        self.bucket = FlatGradBucket(train)
+        self.bucket = FlatGradBucket(train, pad_to=4 * self.world if self.zero1 else 1)
         self.p = self.bucket.params
         self.frozen = {k: p[k].contiguous() for k in FROZEN}
-        if self.owner_sharded:
+        if self.zero1:
+            self.shards = Zero1Shards(self.bucket, self.world, self.rank)
+            self.opt = OwnerShardedAdam(self.bucket, self.shards, self.lr, eps=1e-15)
+        elif self.owner_sharded:
             self.shards = OwnerShards(self.bucket, "pos_cubic_node", self.world, self.rank)
             self.opt = OwnerShardedAdam(self.bucket, self.shards, self.lr, eps=1e-15)
         else:
@@ -233,7 +243,10 @@ class TrainingStep:
         S = min(self.S, N)
         # (ascending: the Gaussians are in Morton order, so a wave of the neighbour search holds space neighbours; the energy is
         #  a sum over the samples, their order does not matter)
-        sample = torch.from_numpy(np.stack([np.sort(self.rng.choice(N, S)) if N > S else np.arange(N) for _ in range(F)])).to(self.dev)
+        if N > S:     # with replacement, as np.random.choice(Nv, sample_num) of cal_arap_error (src/geometry_utils.py:103)
+            sample = torch.sort(torch.randint(N, (F, S), generator=self.gen, device=self.dev), dim=1).values
+        else:
+            sample = torch.arange(N, device=self.dev).expand(F, N).contiguous()
         nbr = pair_connectivity(self.pairs[:, 0], sample, K=self.knn_K)
         arap = pair_arap(self.pairs, sample, nbr, d_pairs=self.g_pairs, grad_scale=self.w.arap / F)
         ph.mark("knn_arap")
@@ -261,7 +274,7 @@ class TrainingStep:
         ph.mark("render_backward")
         # ---- data parallelism: one all-reduce of the flat bucket, identical Adam on every rank -- or (owner_sharded) the
         #      spline table's gradient reduced to the owners of its time blocks, their blocks stepped there and gathered
-        if self.owner_sharded:
+        if self.owner_sharded or self.zero1:
             owner_reduce(bk, self.shards)
             self.opt.step(grad_scale=1.0 / self.world)
             owner_gather(bk, self.shards)
@@ -272,7 +285,11 @@ class TrainingStep:
         # ---- densification statistics of the batch (reduced over the ranks: identical decisions everywhere)
         st = self.dstate
         st.begin_batch()
-        st.accumulate_frame(self.fb.radii_max, self.fb.tap)
+        # the taps are those of THIS rank's loss share: the mean over its F frames (`_l1` divides by the local F).  The step's
+        # loss is the mean over all world * F frames (the optimiser divides the summed gradient by `world`), so the statistic a
+        # single process with the whole batch would accumulate (render_batch sums the batch's taps: frag_model.py:326-343) is the
+        # ranks' sum / world -- the clone / split thresholds then do not depend on the number of GPUs
+        st.accumulate_frame(self.fb.radii_max, self.fb.tap, scale=(1.0 / self.world, 1.0 / self.world))
         reduce_densify_batch(st.viewspace_grad, st.visibility, st.radii)
         st.update()
         ph.mark("densify_stats")

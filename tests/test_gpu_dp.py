@@ -248,3 +248,50 @@ def test_bench_train_step_owner_sharded_two_ranks_over_gloo():
     assert own["config"]["grad_bucket_MB"] == dense["config"]["grad_bucket_MB"]
     assert own["config"]["adam_moments_MB_per_rank"] < 0.85 * dense["config"]["adam_moments_MB_per_rank"]
     assert abs(own["loss"] - dense["loss"]) < 1e-4 * max(1.0, abs(dense["loss"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the densification statistic must not depend on the number of ranks
+def _stat_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from splatter_a_video_amd import train_step as TS
+        from test_gpu_train_step import _clip, _perturbed, _t
+        Nn, Ww, Hh, T = 3000, 128, 96, 20
+        sc, clock, truth = _clip(Nn, Ww, Hh, T, seed=5)
+        extr = _t(sc.extr)
+        t1_all, t2_all = [0, 3, 7, 11, 14, 18], [5, 9, 1, 16, 2, 12]
+        t1, t2 = t1_all[rank::world], t2_all[rank::world]
+        st = TS.TrainingStep(_perturbed(truth, 1), clock, Ww, Hh, len(t1), extr, K=8, arap_samples=128)
+        st.step(t1, t2, TS.render_ground_truth(truth, clock, Ww, Hh, extr, t1, t2))
+        torch.cuda.synchronize()
+        p = {k: v.detach() for k, v in st.p.items()}
+        masks = st.dstate.masks(p["scaling"], p["opacity"], 2e-5, 1e-3, 60.0, 0.02, 20.0)
+        torch.save({"accum": st.dstate.pos_gradient_accum.cpu(), "denom": st.dstate.denom.cpu(), "radii": st.dstate.max_radii2D.cpu(),
+                    "masks": [m.cpu() for m in masks]}, out + f".{world}.{rank}")
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_densification_statistic_is_world_size_invariant(tmp_path):
+    """one rank with 2F frames and two ranks with F frames each accumulate the same `pos_gradient_accum` (the taps of a rank are
+    those of its loss share = the mean over ITS frames; reduced over the ranks they are scaled by 1 / world, as the optimiser
+    scales the gradient) and take the same clone / split decisions against the reference's per-frame threshold"""
+    out = str(tmp_path / "st")
+    mp.spawn(_stat_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    mp.spawn(_stat_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    one, two0, two1 = torch.load(out + ".1.0"), torch.load(out + ".2.0"), torch.load(out + ".2.1")
+    assert torch.equal(two0["accum"], two1["accum"]) and torch.equal(two0["denom"], one["denom"]) and torch.equal(two0["radii"], one["radii"])
+    a, b = one["accum"], two0["accum"]
+    assert float(a.max()) > 0
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.max())              # fp32 summation order only -- not a factor `world`
+    for m1, m2 in zip(one["masks"], two0["masks"]):
+        assert int((m1 != m2).sum()) <= 2                                     # (a threshold tie may flip)
+    assert int(one["masks"][0].sum()) + int(one["masks"][1].sum()) > 10       # the thresholds do select something

@@ -403,3 +403,106 @@ def test_owner_shards_need_the_owned_parameter_first():
     o2 = _TorchFlatAdam(ref, 1e-2)
     sharded_step(ref, [0, 1], lambda f: _seg_render(ref.params, f).backward(), optimizer=o2)
     torch.testing.assert_close(b2.flat_param.detach(), ref.flat_param.detach())
+
+
+# ------------------------------------------------------------------ ZeRO-1 over the whole flat buffer
+class _TorchZeroAdam:
+    """torch restatement of optim.OwnerShardedAdam on parallel.Zero1Shards: moments for this rank's block only"""
+
+    def __init__(self, bucket, shards, lr):
+        self.b, self.lr, self.t = bucket, lr, 0
+        self.lo, self.hi = shards.own
+        self.m, self.v = torch.zeros(self.hi - self.lo), torch.zeros(self.hi - self.lo)
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        with torch.no_grad():
+            g = self.b.flat_grad[self.lo:self.hi] * grad_scale
+            self.m.mul_(0.9).add_(g, alpha=0.1)
+            self.v.mul_(0.999).addcmul_(g, g, value=0.001)
+            self.b.flat_param[self.lo:self.hi] -= (self.lr / (1 - 0.9 ** self.t)) * self.m / (self.v.sqrt() / (1 - 0.999 ** self.t) ** 0.5 + 1e-15)
+
+
+def _zero_params():
+    p = _seg_params(N=31)
+    p["extra"] = torch.tensor([0.3, -0.2, 0.1])          # 31 * 64 + 3 floats: NOT two blocks of whole float4
+    return p
+
+
+def _zero_render(p, f):
+    return _seg_render(p, f) + (p["extra"] * (f + 1.0)).sum()
+
+
+def _worker_zero1(rank, world, port, out):
+    from splatter_a_video_amd.parallel import Zero1Shards, zero1_step
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with pytest.raises(ValueError, match="pad_to"):
+            Zero1Shards(FlatGradBucket(_zero_params()), world, rank)
+        b = FlatGradBucket(_zero_params(), pad_to=4 * world)
+        sh = Zero1Shards(b, world, rank)
+        assert sh.equal and sh.bounds[-1] == b.flat_param.numel() and sh.own[0] % 4 == 0 and b.flat_param.numel() % (4 * world) == 0
+        opt = _TorchZeroAdam(b, sh, 1e-2)
+        for step in range(3):
+            frames = frames_of_rank(list(range(6 * step, 6 * step + 6)), rank, world)
+            zero1_step(b, sh, frames, lambda f: _zero_render(b.params, f).backward(), opt)
+        torch.save({"param": b.flat_param.detach().clone(), "own": sh.own}, out + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_zero1_step_equals_the_synchronous_step(tmp_path):
+    """the whole flat buffer in `world` equal blocks: gradient reduced to the block's owner, Adam on the own block only, updated
+    blocks gathered -- sharded_step's parameters to fp32 summation order, replicas bit-identical, padding tail untouched"""
+    out = str(tmp_path / "z")
+    mp.spawn(_worker_zero1, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["param"], r1["param"]) and r0["own"][1] == r1["own"][0]
+    ref = FlatGradBucket(_zero_params())
+    opt = _TorchFlatAdam(ref, 1e-2)
+    for step in range(3):
+        sharded_step(ref, list(range(6 * step, 6 * step + 6)), lambda f: _zero_render(ref.params, f).backward(), optimizer=opt)
+    p = ref.flat_param.detach()
+    n = p.numel()
+    assert float((r0["param"][:n] - p).abs().max()) <= 2e-6 * float(p.abs().max())
+    assert r0["param"].numel() > n and float(r0["param"][n:].abs().max()) == 0.0
+
+
+def test_a_block_that_starts_inside_a_pattern_group_keeps_the_pattern():
+    """host logic of OwnerShardedAdam._segments: ZeRO-1 cuts the buffer anywhere, e.g. inside the SH block whose DC triplets step
+    with their own rate (PatternLR period 48, head 3).  The per-element rate of every block's segments must be the flat one."""
+    from splatter_a_video_amd.optim import OwnerShardedAdam, PatternLR
+
+    def rate_of(ends, rates, pats, i):
+        start = 0
+        for e, r, (per, head, hr) in zip(ends, rates, pats):
+            if i < e:
+                return hr if (per and (i - start) % per < head) else r
+            start = e
+        raise AssertionError
+
+    class Stub:            # what _segments reads
+        pass
+    slices = {"opacity": (0, 37), "shs": (37, 37 + 48 * 11), "rotation": (37 + 48 * 11, 37 + 48 * 11 + 44)}
+    lr = {"opacity": 5e-2, "shs": PatternLR(1.25e-4, head_lr=2.5e-3, period=48, head=3), "rotation": 1e-3}
+    total = slices["rotation"][1]
+    flat = [5e-2] * 37 + [2.5e-3 if k % 48 < 3 else 1.25e-4 for k in range(48 * 11)] + [1e-3] * 44
+    for world in (1, 2, 3, 5, 8):
+        per = -(-total // (4 * world)) * 4
+        for r in range(world):
+            lo, hi = r * per, min((r + 1) * per, total)
+            o = Stub()
+            o.bucket, o.lr = Stub(), lr
+            o.bucket.slices = slices
+            ends, rates, pats = OwnerShardedAdam._segments(o, lo, hi)
+            assert ends[-1] == hi - lo
+            got = [rate_of(ends, rates, pats, i) for i in range(hi - lo)]
+            assert got == flat[lo:hi], (world, r)
+    # a cut one float into the head (phase 1: two head floats left) and one past it (phase 3: none left)
+    for lo in (37 + 48 * 2 + 1, 37 + 48 * 2 + 3, 37 + 48 * 2 + 47):
+        o = Stub(); o.bucket, o.lr = Stub(), lr; o.bucket.slices = slices
+        ends, rates, pats = OwnerShardedAdam._segments(o, lo, total)
+        assert [rate_of(ends, rates, pats, i) for i in range(total - lo)] == flat[lo:]
