@@ -41,7 +41,8 @@ def test_geometry_utils_call_lines(Nv, K):
     # the in-place edits the reference applies to the two views (geometry_utils.py:20-22) must be legal on what we return
     nn_idx[:, least_edge_num:] = torch.where(nn_dist[:, least_edge_num:] < radius ** 2, nn_idx[:, least_edge_num:], - torch.ones_like(nn_idx[:, least_edge_num:]))
     nn_dist[:, least_edge_num:] = torch.where(nn_dist[:, least_edge_num:] < radius ** 2, nn_dist[:, least_edge_num:], torch.ones_like(nn_dist[:, least_edge_num:]) * torch.inf)
-    weight = torch.exp(-nn_dist / nn_dist[:, :least_edge_num].mean())
+    # (the reference never differentiates the masked entries -- exp(-inf) has no finite gradient; the unmasked columns do carry one)
+    weight = torch.exp(-nn_dist[:, :least_edge_num] / nn_dist[:, :least_edge_num].mean())
     weight.sum().backward()
     assert torch.isfinite(points.grad).all() and points.grad.abs().sum() > 0
 
