@@ -615,7 +615,9 @@ int splat_frames_gauss_backward_static_sets(int F, int P, int C, int W, int H, i
 
 /* Frame batch of DYNAMIC Gaussians (rows a15 + f1: the per-frame evaluation of the reference's spline point cloud inside
  * the preprocess, for all frames of a batch at once).  tab: F entries of 64 bytes in DEVICE memory, one per frame:
- * {int32 seg; float d; float basis[12]; float pad[2]} (segment index, offset inside it, t'^0..3, cos / sin(t' l pi)).
+ * {int32 seg; float d; float basis[12]; float pad[2]} (segment index, offset inside it, t'^0..3, cos / sin(t' l pi);
+ * pad[0], optional, as int32: 1 + the index of the frame splat_dynamic_positions_batch_backward visits at this step of its walk --
+ * a PERMUTATION of the frames that puts the frames of one segment next to each other -- or 0 in every entry: table order).
  * Forward: uv / depth / conic / radius [F,P,..], opa_t [P] (sigmoid(opacity): frame independent).
  * Backward (after splat_alpha_blending_backward_batch): one quad per Gaussian walks all frames -- sums the frame's pair
  * records, re-evaluates position / rotation of that frame, projection + EWA + cov3d backward, activations -- and ADDS

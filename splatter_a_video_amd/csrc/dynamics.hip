@@ -184,7 +184,12 @@ __global__ __launch_bounds__(DYN_BLOCK) void dynamic_positions_bwd_kernel(int F,
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k * ca.stride_k] += acc[k];
     };
-    for (int f = 0; f < F; ++f) {
+    for (int i = 0; i < F; ++i) {
+        // walk order: entry i's pad[0] = 1 + the frame to visit i-th (frames of one segment next to each other: one flush per
+        // touched segment instead of one per change of segment in table order -- the pair frames of a training batch arrive
+        // interleaved (ids1, ids2, ids1, ..)); 0: table order.  Uniform: scalar loads.
+        const int o = __float_as_int(tab[i].pad[0]);
+        const int f = (o >= 1 && o <= F) ? o - 1 : i;
         const int seg = tab[f].seg;
         if (seg != cur) {
             flush(cur);

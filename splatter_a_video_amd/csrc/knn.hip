@@ -272,28 +272,46 @@ constexpr int KNB_TILE = 1024, KNB_TILES = 4, KNB_CHUNK = KNB_TILE * KNB_TILES;
 // take ~8 ln(chunk / 8) insertions per thread, and a wave runs the insertion whenever ANY of its 64 queries inserts: three
 // times the work of the distance loop itself.
 constexpr int KNB_WIN = 128;
+// A WAVE per query (round 6; a thread per query walked its 128 window points one insertion after the other: 100 us of latency at
+// 12 800 threads): lane l holds the distances of window points l and 64 + l, the K-th smallest of the 128 is extracted by K
+// rounds of wave minimum + removal of ONE instance of it.
+__device__ __forceinline__ float knn_wave_min(float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+    return m;
+}
 template <int KT>
 __global__ void __launch_bounds__(KB)
 knn_brute_bound_kernel(int N, int S, int K, const float *__restrict__ pts, long long pts_bs, const long long *__restrict__ qidx,
                        float *__restrict__ tau) {
-    const int q = blockIdx.x * KB + threadIdx.x, b = blockIdx.y;
-    if (q >= S) return;
+    static_assert(KNB_WIN == 2 * WAVE, "two window points per lane");
+    const int lane = threadIdx.x & 63, q = blockIdx.x * (KB / WAVE) + (threadIdx.x >> 6), b = blockIdx.y;
+    if (q >= S) return;   // (wave-uniform)
     const float *P = pts + (size_t)b * pts_bs;
     const int v = imin_(imax_((int)qidx[(size_t)b * S + q], 0), N - 1);   // memory safety: ids are clamped into the set
     const float qx = P[3 * (size_t)v], qy = P[3 * (size_t)v + 1], qz = P[3 * (size_t)v + 2];
-    float bd[KT];
-    int bi[KT];
-#pragma unroll
-    for (int p = 0; p < KT; ++p) { bd[p] = __builtin_inff(); bi[p] = 0x7fffffff; }
     const int lo = imax_(0, imin_(v - KNB_WIN / 2, N - KNB_WIN)), hi = imin_(N, lo + KNB_WIN);
-    for (int id = lo; id < hi; ++id) {
-        const float dx = qx - P[3 * (size_t)id], dy = qy - P[3 * (size_t)id + 1], dz = qz - P[3 * (size_t)id + 2];
-        knn_insert<KT>(bd, bi, dx * dx + dy * dy + dz * dz, id);
-    }
-    float t = __builtin_inff();   // fewer than K points in the window (tiny sets): no bound
+    float d[2];
 #pragma unroll
-    for (int p = 0; p < KT; ++p) t = (p == K - 1) ? bd[p] : t;
-    tau[(size_t)b * S + q] = t * 1.000002f;   // (the scan may round the same distance an ulp differently: keep the bound's own points)
+    for (int j = 0; j < 2; ++j) {
+        const int id = lo + WAVE * j + lane;
+        d[j] = __builtin_inff();
+        if (id < hi) {
+            const float dx = qx - P[3 * (size_t)id], dy = qy - P[3 * (size_t)id + 1], dz = qz - P[3 * (size_t)id + 2];
+            d[j] = dx * dx + dy * dy + dz * dz;
+        }
+    }
+    float kth = __builtin_inff();   // fewer than K points in the window (tiny sets): no bound
+    for (int r = 0; r < K; ++r) {
+        kth = knn_wave_min(fminf(d[0], d[1]));
+        const unsigned long long has = __builtin_amdgcn_ballot_w64(d[0] == kth || d[1] == kth);
+        if (has == 0ull) break;   // (NaN input: no bound either way)
+        if (lane == __builtin_ctzll(has)) {   // one instance leaves (equal distances count separately)
+            if (d[0] == kth) d[0] = __builtin_inff();
+            else d[1] = __builtin_inff();
+        }
+    }
+    if (lane == 0) tau[(size_t)b * S + q] = kth * 1.000002f;   // (the scan may round the same distance an ulp differently: keep the bound's own points)
 }
 
 // bounding box of every tile of KNB_TILE consecutive points (Morton order: compact boxes): box[(b * NT + t) * 6 + {lo xyz, hi xyz}]
@@ -399,27 +417,47 @@ knn_brute_partial_kernel(int N, int S, int G, int NT, const float *__restrict__ 
     }
 }
 
+// Merge of the sparse partial lists: a WAVE per query (round 6; a thread per query walked its G chunks' counters one dependent
+// load after the other).  Lane l gathers the lists of chunks l, l + 64, .. into a private sorted list (almost always empty), then K
+// rounds of a lexicographic wave minimum over the lanes' heads pop the result in order (ties -> smaller index, as knn_insert).
 template <int KT>
 __global__ void __launch_bounds__(KB)
 knn_brute_merge_kernel(int S, int G, int K, const float *__restrict__ pd, const int *__restrict__ pi,
                        const unsigned char *__restrict__ cnt, float *__restrict__ dists, int *__restrict__ idx) {
-    const int q = blockIdx.x * KB + threadIdx.x, b = blockIdx.y;
-    if (q >= S) return;
+    const int lane = threadIdx.x & 63, q = blockIdx.x * (KB / WAVE) + (threadIdx.x >> 6), b = blockIdx.y;
+    if (q >= S) return;   // (wave-uniform)
     float bd[KT];
     int bi[KT];
 #pragma unroll
     for (int p = 0; p < KT; ++p) { bd[p] = __builtin_inff(); bi[p] = 0x7fffffff; }
-    for (int c = 0; c < G; ++c) {
+    for (int c = lane; c < G; c += WAVE) {
         const size_t o = ((size_t)b * G + c) * S + q;
-        const int nv = cnt[o];          // (coalesced over the queries; most chunks hold nothing for a query)
+        const int nv = cnt[o];
         for (int p = 0; p < nv; ++p) knn_insert<KT>(bd, bi, pd[o * KT + p], pi[o * KT + p]);
     }
+    float *od = dists + ((size_t)b * S + q) * K;
+    int *oi = idx + ((size_t)b * S + q) * K;
+    for (int r = 0; r < K; ++r) {
+        float hd = bd[0];
+        int hi = bi[0];
 #pragma unroll
-    for (int p = 0; p < KT; ++p) {
-        if (p < K) {
-            const bool have = bi[p] != 0x7fffffff;
-            dists[((size_t)b * S + q) * K + p] = have ? bd[p] : 0.f;
-            idx[((size_t)b * S + q) * K + p] = have ? bi[p] : -1;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float xd = __shfl_xor(hd, o);
+            const int xi = __shfl_xor(hi, o);
+            const bool take = (xd < hd) || (xd == hd && xi < hi);
+            hd = take ? xd : hd;
+            hi = take ? xi : hi;
+        }
+        const bool have = hi != 0x7fffffff;
+        if (have && bi[0] == hi) {   // the owner pops its head (point ids are unique across the lanes' lists)
+#pragma unroll
+            for (int p = 0; p + 1 < KT; ++p) { bd[p] = bd[p + 1]; bi[p] = bi[p + 1]; }
+            bd[KT - 1] = __builtin_inff();
+            bi[KT - 1] = 0x7fffffff;
+        }
+        if (lane == 0) {
+            od[r] = have ? hd : 0.f;   // fewer than K points: 0 / -1 padding as knn_points
+            oi[r] = have ? hi : -1;
         }
     }
 }
@@ -518,13 +556,14 @@ extern "C" int splat_knn_brute_batch(int B, int N, int S, int K, const float *po
     SPLAT_LAUNCH("knn_brute_box", knn_tile_box_kernel, dim3((unsigned)NT, (unsigned)B), dim3(KB), 0, s, N, NT, points,
                  (long long)points_batch_stride, box);
     SPLAT_POST_LAUNCH();
-    SPLAT_LAUNCH("knn_brute_bound", knn_brute_bound_kernel<8>, dim3((unsigned)((S + KB - 1) / KB), (unsigned)B), dim3(KB), 0, s, N, S, K,
+    const unsigned wq = (unsigned)((S + KB / WAVE - 1) / (KB / WAVE));   // a wave per query
+    SPLAT_LAUNCH("knn_brute_bound", knn_brute_bound_kernel<8>, dim3(wq, (unsigned)B), dim3(KB), 0, s, N, S, K,
                  points, (long long)points_batch_stride, (const long long *)query_idx, tau);
     SPLAT_POST_LAUNCH();
     SPLAT_LAUNCH("knn_brute", knn_brute_partial_kernel<8>, dim3((unsigned)G, (unsigned)((S + KB - 1) / KB), (unsigned)B), dim3(KB), 0, s,
                  N, S, G, NT, points, (long long)points_batch_stride, (const long long *)query_idx, tau, box, pd, pi, cnt);
     SPLAT_POST_LAUNCH();
-    SPLAT_LAUNCH("knn_brute_merge", knn_brute_merge_kernel<8>, dim3((unsigned)((S + KB - 1) / KB), (unsigned)B), dim3(KB), 0, s, S, G, K,
+    SPLAT_LAUNCH("knn_brute_merge", knn_brute_merge_kernel<8>, dim3(wq, (unsigned)B), dim3(KB), 0, s, S, G, K,
                  pd, pi, cnt, dists, idx);
     SPLAT_POST_LAUNCH();
     return SPLAT_OK;

@@ -342,7 +342,15 @@ def frame_table(clock: FrameClock, times, device) -> Tensor:
         host[f, 0] = np.array([seg], np.int32).view(np.float32)[0]
         host[f, 1] = d
         host[f, 2:14] = np.frombuffer(basis, dtype=np.float32, count=12)
+    _walk_order(host)
     return _upload(host, device)
+
+
+def _walk_order(host: np.ndarray) -> None:
+    """column 14 of a frame table: (as int32) 1 + the frame the positions' backward visits at that step of its walk -- the
+    frames grouped by spline segment (stable), so that a thread flushes a segment's coefficient gradients once"""
+    segs = host[:, 0].copy().view(np.int32)
+    host[:, 14] = (np.argsort(segs, kind="stable").astype(np.int32) + 1).view(np.float32)
 
 
 def _upload(host: np.ndarray, device) -> Tensor:

@@ -351,7 +351,8 @@ class FrameBatch:
                 host[f, 0] = np.array([seg], np.int32).view(np.float32)[0]
                 host[f, 1] = d
                 host[f, 2:14] = np.frombuffer(basis, dtype=np.float32, count=12)
-            from .dynamics import _upload
+            from .dynamics import _upload, _walk_order
+            _walk_order(host)
             tab = _upload(host, self.dev)
             cache[key] = tab
         return tab
