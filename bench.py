@@ -175,6 +175,8 @@ def parse():
                     help="ZeRO-1 schedule of the step: reduce-scatter of the flat gradient buffer, Adam on this rank's 1 / N block "
                          "(moments sharded), all-gather of the updated parameters (parallel.Zero1Shards); the default line at N > 1 "
                          "times it beside `synchronous` and `overlap_exact`")
+    ap.add_argument("--unfused-l1", action="store_true",
+                    help="--train-step: the L1 losses as three splat_l1_loss_grad launches + gradient images (A/B of the loss-fused backward)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: start / join the N ranks, all-reduce ones, print {n_gpus, ranks_seen} and exit")
     return ap.parse_args()
@@ -776,7 +778,8 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
     start["pos_cubic_node"] = torch.zeros_like(start["pos_cubic_node"])
     cfg = TS.DensifyConfig(cameras_extent=5.0)
     lr = {k: 1e-6 for k in TS.REFERENCE_LR}      # as everywhere in this file: small rates keep the scene's statistics put over the run
-    st = TS.TrainingStep(start, clock, sc.W, sc.H, len(t1), extr, lr=lr, densify=cfg, K=20, owner_sharded=a.owner_sharded, zero1=a.zero1)
+    st = TS.TrainingStep(start, clock, sc.W, sc.H, len(t1), extr, lr=lr, densify=cfg, K=20, owner_sharded=a.owner_sharded, zero1=a.zero1,
+                         fused_l1=not a.unfused_l1)
     del truth
     if not (world > 1 and not a.zero1 and not a.owner_sharded):
         start = None

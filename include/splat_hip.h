@@ -597,6 +597,23 @@ int splat_alpha_blending_backward_batch_sets_packed(int F, int P, int C, const i
                                                     const int32_t *slot_sorted, float *pair_records, float *pack_scratch,
                                                     const uint32_t *cull_flags, float *dbg_T_front, const float *forward_pack,
                                                     splat_stream_t stream);
+/* ... with the L1 image loss FUSED into the tile kernel's hoist of the image gradient (ABI 20): set_target[g] = the target image
+ * [F, cn, H, W] of set g (instead of a gradient image), pred_row = the forward's output row [F, C, H, W]; the gradient of a channel
+ * of set g is l1_scale_host[g] * sign(pred - target), and l1_sum[(f * tiles + t) * 3 + g] (optional, [F, tiles, 3], tiles =
+ * ceil(W/16) * ceil(H/16): every entry is written) = sum |pred - target| over tile t of frame f, set g: the caller adds them up
+ * (no atomics: bit-reproducible).  Replaces three
+ * splat_l1_loss_grad launches and the gradient images written and read back between them and the backward
+ * (src/trainer_fragGS.py:573-600: l1_loss on the rendered images).  Needs the forward's cull words (quarter-list kernels). */
+int splat_alpha_blending_backward_batch_sets_l1(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
+                                                const float *set_bg, const float *uv, const float *conic, const float *opacity,
+                                                int64_t opacity_frame_stride, const float *const *set_feature,
+                                                const int64_t *set_feature_fs, const int32_t *idx_sorted,
+                                                const int32_t *tile_range, int64_t capacity, int W, int H, const float *final_T,
+                                                const int32_t *ncontrib, const float *pred_row, const float *const *set_target,
+                                                const float *l1_scale_host, float *l1_sum, int want_abs,
+                                                const int32_t *slot_sorted, float *pair_records, float *pack_scratch,
+                                                const uint32_t *cull_flags, float *dbg_T_front, const float *forward_pack,
+                                                splat_stream_t stream);
 
 /* out[i, 0 .. ncp) = sum of the pair records (stride ncp floats, a multiple of 4; 16-byte aligned) in Gaussian i's slots
    [goff_incl[i-1], goff_incl[i]) -- any record layout.  With splat_alpha_blending_backward_batch_sets at F = 1 this is the

@@ -181,6 +181,13 @@ struct BlendArgs {
     // own stride).  The renderer's row in two passes -- the tap set through the narrow matrix-core kernel, depth + attributes
     // through blend_bwd_attr_kernel -- shares one record [A: ux uy ca cb cc o ax ay f0 f1 f2 . | B: ux uy ca cb cc o dz a0 ..]
     int rec_stride, rec_off;
+    // loss-fused three-set backward (splat_alpha_blending_backward_batch_sets_l1): the image gradient is that of the L1 loss,
+    // computed where the kernel hoists dL_dout -- l1_pred = the forward's output row [F, C, H, W], sdl0 .. sdl2 hold the sets'
+    // TARGET images, the gradient of a channel is l1_s<g> * sign(pred - target), and sum |pred - target| of every (frame, tile,
+    // set) is WRITTEN to l1_sum[(frame * T + tile) * 3 + g] (the caller adds them up).  NULL: sdl* / dL_dout are gradients.
+    const float *l1_pred;
+    float l1_s0, l1_s1, l1_s2;
+    float *l1_sum;
 };
 
 // per-frame view of the argument block (all uniform: scalar address arithmetic)
@@ -213,7 +220,9 @@ __device__ __forceinline__ BlendArgs frame_args(const BlendArgs &B, int f) {
         if (B.sdl0) A.sdl0 = B.sdl0 + fz * B.s0cn * HW;
         if (B.sdl1) A.sdl1 = B.sdl1 + fz * B.s1cn * HW;
         if (B.sdl2) A.sdl2 = B.sdl2 + fz * B.s2cn * HW;
+        if (B.l1_pred) A.l1_pred = B.l1_pred + fz * B.C * HW;
     }
+    if (B.l1_sum) A.l1_sum = B.l1_sum + 3 * (size_t)f * (size_t)B.T;
     return A;
 }
 
@@ -2781,6 +2790,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     auto pixoff = [](int q) { return (q >> 4) * GS + ((q >> 2) & 3) * KS + (q & 3) * 4; };
     __shared__ float s_mom[16 * 32];                    // [step][lane group][row & 7], see blend_bwd_quarter_kernel
     __shared__ int s_wmax[4];
+    __shared__ float s_l1[4][3];                        // loss-fused: the waves' sums of |pred - target| per set
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int gtile = xcd_tile(blockIdx.x, gridDim.x);
     const int frame = gtile / B.T, tile = gtile - frame * B.T;
@@ -2821,26 +2831,58 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         const int px = tx * TILE + lx, py = ty * TILE + ly;
         const size_t HW = (size_t)A.H * A.W;
         const bool inside = (px < A.W) && (py < A.H);
-        const size_t pix = (size_t)A.W * (size_t)py + px;
+        const size_t pix = inside ? (size_t)A.W * (size_t)py + px : 0;   // (a lane outside the image loads pixel 0 and drops it)
         const float Tf = inside ? A.final_T[pix] : 0.f;
         const int last = inside ? A.ncontrib[pix] : 0;
-        float bgd[3] = {0.f, 0.f, 0.f};
+        // every load of the hoist is issued UNCONDITIONALLY at a clamped address and masked afterwards: under `if (inside && c >= 0)`
+        // each load sat in its own exec-masked block with its wait behind it -- 23 (loss-fused: 46) dependent round trips per wave,
+        // ~9 us per workgroup at c2
+        float tgt[CH];   // loss-fused: the targets (else unused)
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const int c = sets_slot_channel(A, k);
             const int gi = k < 4 ? 0 : k < 8 ? 1 : 2;
-            float g = 0.f;
-            if (inside && c >= 0) {
-                if (A.dL_dout) {
-                    g = A.dL_dout[(size_t)c * HW + pix];
+            const int cc = c >= 0 ? c : 0;
+#if BLEND_ABL == 3
+            gpix[k] = 0.001f * (float)(k + lane); tgt[k] = 0.f; continue;   // timing ablation: no image loads (results invalid)
+#endif
+            if (A.dL_dout) {
+                gpix[k] = A.dL_dout[(size_t)cc * HW + pix];
+            } else {
+                const float *d = gi == 0 ? A.sdl0 : gi == 1 ? A.sdl1 : A.sdl2;
+                const int o = c >= 0 ? k - (gi == 0 ? 0 : gi == 1 ? 4 : 8) : 0;
+                const float *dd = d ? d : A.final_T;      // (a set without channels has no image: any valid address, dropped below)
+                if (A.l1_pred) {   // (uniform) d holds the TARGET, the gradient follows from the forward's output row
+                    tgt[k] = dd[(size_t)o * HW + pix];
+                    gpix[k] = A.l1_pred[(size_t)cc * HW + pix];
                 } else {
-                    const float *d = gi == 0 ? A.sdl0 : gi == 1 ? A.sdl1 : A.sdl2;
-                    const int o = k - (gi == 0 ? 0 : gi == 1 ? 4 : 8);
-                    g = d[(size_t)o * HW + pix];
+                    gpix[k] = dd[(size_t)o * HW + pix];
                 }
             }
+        }
+        float bgd[3] = {0.f, 0.f, 0.f};
+        float l1a[3] = {0.f, 0.f, 0.f};   // loss-fused: sum |pred - target| of this pixel, per set
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = sets_slot_channel(A, k);
+            const int gi = k < 4 ? 0 : k < 8 ? 1 : 2;
+            float g = gpix[k];
+            if (A.l1_pred) {   // the gradient of scale * |pred - target| (splat_l1_loss_grad's rule)
+                const float diff = g - tgt[k];
+                const float sc = gi == 0 ? A.l1_s0 : gi == 1 ? A.l1_s1 : A.l1_s2;
+                g = diff > 0.f ? sc : (diff < 0.f ? -sc : 0.f);
+                l1a[gi] += (inside && c >= 0) ? fabsf(diff) : 0.f;
+            }
+            g = (inside && c >= 0) ? g : 0.f;
             gpix[k] = g;
             bgd[gi] += (gi == 0 ? A.s0bg : gi == 1 ? A.s1bg : A.s2bg) * g;
+        }
+        if (A.l1_pred) {   // the wave's three sums; thread g < 3 writes the workgroup's behind the barrier below
+#pragma unroll
+            for (int g_ = 0; g_ < 3; ++g_) {
+                const float t_ = wave_sum_to_lane63(l1a[g_]);
+                if (lane == 63) s_l1[w][g_] = t_;
+            }
         }
         float *r = s_state[w] + pixoff(myq);
         r[0] = Tf;
@@ -2879,6 +2921,8 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     }
     if (lane < RW) s_acc[w][CAP * RW + lane] = 0.f;   // the slab's zero row
     __syncthreads();
+    // (one plain store per workgroup and set; the caller adds them up: reproducible, no atomics)
+    if (A.l1_pred && A.l1_sum && tid < 3) A.l1_sum[3 * (size_t)tile + tid] = (s_l1[0][tid] + s_l1[1][tid]) + (s_l1[2][tid] + s_l1[3][tid]);
     const float *momrow = s_mom + 8 * kk + (nl & 7);
     const int2 range = A.tile_range[tile];
     const int len = range.y - range.x;
@@ -4382,8 +4426,11 @@ static int backward_batch_sets_impl(int F, int P, int C, const int32_t *set_c0, 
                                     const float *const *set_dL, int want_abs,
                                     const int32_t *slot_sorted, float *pair_records,
                                     float *pack_scratch, const uint32_t *cull_flags,
-                                    float *dbg_T_front, const float *forward_pack, splat_stream_t stream) {
+                                    float *dbg_T_front, const float *forward_pack, splat_stream_t stream,
+                                    const float *l1_pred = nullptr, const float *l1_scale = nullptr, float *l1_sum = nullptr) {
     SPLAT_CHECK_ARG(F >= 1 && P >= 1 && C >= 1 && C <= SetsCfg::CH && W > 0 && H > 0 && capacity >= 1, "bad sizes (C <= 28)");
+    SPLAT_CHECK_ARG(!l1_pred || (l1_scale && set_dL && !dL_dout && cull_flags && bwd_use_quarters()),
+                    "loss-fused backward: needs the sets' target images, the scales, the forward's cull words and the quarter-list kernels");
     SPLAT_CHECK_ARG(set_c0 && set_cn && set_bg, "null set table");
     SPLAT_CHECK_ARG(uv && conic && opacity && idx_sorted && tile_range && final_T && ncontrib && slot_sorted && pair_records &&
                         (pack_scratch || forward_pack),
@@ -4434,6 +4481,10 @@ static int backward_batch_sets_impl(int F, int P, int C, const int32_t *set_c0, 
     if (!dL_dout) {
         A.sdl0 = set_dL[0]; A.sdl1 = set_dL[1]; A.sdl2 = set_dL[2];
         SPLAT_CHECK_ARG((!set_cn[0] || A.sdl0) && (!set_cn[1] || A.sdl1) && (!set_cn[2] || A.sdl2), "null set gradient pointer");
+    }
+    if (l1_pred) {
+        A.l1_pred = l1_pred; A.l1_sum = l1_sum;
+        A.l1_s0 = l1_scale[0]; A.l1_s1 = l1_scale[1]; A.l1_s2 = l1_scale[2];
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(T * F)), block(256);
@@ -4515,6 +4566,30 @@ extern "C" int splat_alpha_blending_backward_batch_sets_packed(int F, int P, int
 // gradients go back to autograd as d uv / d conic / d opacity / d feature): the caller slices the summed SETS record
 // [ux uy ca cb | cc o ax ay | tx ty 0 0 | row channels].  A thread per (Gaussian, 16-byte chunk): the threads of a record read
 // it contiguously.  out is fully written ([P, ncp]); deterministic (slot order).
+// splat_alpha_blending_backward_batch_sets_packed with the L1 image loss FUSED into the tile kernel's hoist of the image gradient:
+// set_target[g] = the set's target image [F, cn, H, W] (instead of a gradient image), pred_row = the forward's output row
+// [F, C, H, W], the gradient of a channel of set g is l1_scale_host[g] * sign(pred - target) and l1_sum[(f * tiles + t) * 3 + g]
+// (optional, [F, tiles, 3]: every entry is WRITTEN) = sum |pred - target| over the pixels of tile t of frame f, set g -- the caller
+// adds them up (bit-reproducible; no atomics).  What splat_l1_loss_grad + the backward did in four launches and 1.9 GB of gradient
+// images written and read back (src/trainer_fragGS.py:573-600: l1_loss on the three rendered images).  Quarter-list kernels only.
+extern "C" int splat_alpha_blending_backward_batch_sets_l1(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
+                                                           const float *set_bg, const float *uv, const float *conic,
+                                                           const float *opacity, int64_t opacity_frame_stride,
+                                                           const float *const *set_feature, const int64_t *set_feature_fs,
+                                                           const int32_t *idx_sorted, const int32_t *tile_range,
+                                                           int64_t capacity, int W, int H, const float *final_T,
+                                                           const int32_t *ncontrib, const float *pred_row,
+                                                           const float *const *set_target, const float *l1_scale_host,
+                                                           float *l1_sum, int want_abs, const int32_t *slot_sorted,
+                                                           float *pair_records, float *pack_scratch, const uint32_t *cull_flags,
+                                                           float *dbg_T_front, const float *forward_pack, splat_stream_t stream) {
+    SPLAT_CHECK_ARG(pred_row && set_target && l1_scale_host, "null pointer");
+    return backward_batch_sets_impl(F, P, C, set_c0, set_cn, set_bg, uv, conic, opacity, opacity_frame_stride, nullptr, 0,
+                                    set_feature, set_feature_fs, idx_sorted, tile_range, capacity, W, H, final_T, ncontrib,
+                                    nullptr, set_target, want_abs, slot_sorted, pair_records, pack_scratch, cull_flags, dbg_T_front,
+                                    forward_pack, stream, pred_row, l1_scale_host, l1_sum);
+}
+
 namespace {
 __global__ void __launch_bounds__(256)
 records_segment_sum_kernel(int P, int nq, const float4 *__restrict__ rec, const int *__restrict__ goff, float4 *__restrict__ out) {

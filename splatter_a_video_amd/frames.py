@@ -335,6 +335,21 @@ class FrameBatch:
                                    float(extent), sink, intr)
 
 
+    def fuse_l1(self, targets, weights, sums: Tensor) -> None:
+        """arm the LOSS-FUSED backward for the next backward pass of a ``render_sets`` / ``render_dynamic_sets`` forward: the
+        image gradients of ``sum_s weights[s] * mean |out[s] - targets[s]|`` (the reference's l1_loss terms, src/trainer_fragGS.py:
+        573-600) are derived inside the tile kernel from the forward's output row and the target images ``targets[s]``
+        [F, c_s, H, W]; ``sums`` [F, tiles, 3] receives sum |out - target| per frame, tile and routing group (tap set, second
+        set, detached set; every entry is written: add them up).  Call ``torch.autograd.backward(outputs, fb.l1_placeholders())`` afterwards: the gradient tensors handed to
+        the backward are placeholders (no gradient image is written or read)."""
+        self._l1 = dict(targets=list(targets), weights=list(weights), sums=sums)
+
+    def l1_placeholders(self, widths=None):
+        """zero-stride gradient tensors of the sets' shapes for a loss-fused backward (no memory behind them)"""
+        ws = widths or [3, 1, self.C - 4]
+        z = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        return [z.expand(self.F, w, self.H, self.W) for w in ws]
+
     # ------------------------------------------------------------------ dynamic Gaussians (rows a15 + f1)
     def frame_table(self, clock, times) -> Tensor:
         """device table of the per-frame scalars (segment, offset inside it, time bases) of ``times`` (cached)"""
@@ -721,7 +736,7 @@ def _blend_sources_forward(fb, meta, parts, feats, opacity, K):
         L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx), L.ptr(fb.pack), L.ptr(fb.cull_flags), st))
     # (the forward-pack decision is taken HERE and kept in the autograd context: an option flipped between this forward and its
     #  backward must not change what the backward stages)
-    return out, gs_idx, dict(plan=plan, tens=None, row=None, widths=widths, std=_uses_forward_pack(plan, C))
+    return out, gs_idx, dict(plan=plan, tens=None, row=None, widths=widths, std=_uses_forward_pack(plan, C), out_row=out)
 
 
 def _blend_sets_forward(fb, meta, feats, opacity, op_fs, K):
@@ -764,7 +779,7 @@ def _blend_sets_forward(fb, meta, feats, opacity, op_fs, K):
             L.ptr(opacity), ctypes.c_int64(op_fs), L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap), L.ptr(bgc),
             L.ci(W), L.ci(H), L.ci(K), L.ci(0), L.ptr(out), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(gs_idx),
             L.ptr(fb.pack), L.ptr(fb.cull_flags), st))
-    return out, gs_idx, dict(plan=plan, tens=tens, row=row, widths=widths, std=_uses_forward_pack(plan, C))
+    return out, gs_idx, dict(plan=plan, tens=tens, row=row, widths=widths, std=_uses_forward_pack(plan, C), out_row=out)
 
 
 def _set_tables(meta, plan, tens, P):
@@ -781,7 +796,8 @@ def _set_tables(meta, plan, tens, P):
 
 def _blend_sets_backward_one_pass(fb, meta, state, grads, opacity, op_fs, want_abs):
     """ONE pass of the tile kernels for the three sets (splat_alpha_blending_backward_batch_sets): every set's image gradient
-    from its own tensor.  Returns the pair-record buffer."""
+    from its own tensor.  Returns the pair-record buffer.  With ``fb.fuse_l1(...)`` armed the incoming gradient tensors are
+    placeholders: the kernel derives the L1 loss' gradient from the forward's output row and the target images."""
     lib, st = L.lib(), L.stream()
     F, P, W, H, C, cap = fb.F, fb.P, fb.W, fb.H, fb.C, fb.capacity
     plan, tens = state["plan"], state["tens"]
@@ -789,6 +805,35 @@ def _blend_sets_backward_one_pass(fb, meta, state, grads, opacity, op_fs, want_a
     groups = _set_groups(meta)
     dl = [0, 0, 0]
     keep = []
+    l1 = fb.__dict__.pop("_l1", None)
+    if l1 is not None:
+        from .gs.raster_ops import _debug_T_front
+        row = state.get("out_row")
+        if row is None or tuple(row.shape) != (F, C, H, W) or not L.get_option("bwd_quarters"):
+            raise ValueError("the loss-fused backward needs the forward's output row and the quarter-list kernels")
+        scale = [0.0, 0.0, 0.0]
+        for tgt, wgt, w, grp in zip(l1["targets"], l1["weights"], state["widths"], groups):
+            t = L.need(tgt, "target image")
+            if tuple(t.shape) != (F, w, H, W):
+                raise ValueError(f"a set's target image must be [F={F}, {w}, H, W]")
+            keep.append(t)
+            dl[grp] = t.data_ptr()
+            scale[grp] = float(wgt) / (F * w * H * W)          # d (weight * mean |pred - target|) / d pred
+        sums = L.need(l1["sums"], "l1 sums")
+        if sums.numel() != 3 * F * fb.T:
+            raise ValueError(f"l1 sums must be [F={F}, tiles={fb.T}, 3]")
+        rec = fb._set_buffer(("rec", "sets"), F * cap * int(lib.splat_blend_sets_pair_stride(C)))
+        std = state["std"] if "std" in state else _uses_forward_pack(plan, C)
+        pack = None if std else fb._set_buffer(("pack", "sets"), F * P * int(lib.splat_blend_sets_pack_floats()))
+        L.check(lib.splat_alpha_blending_backward_batch_sets_l1(
+            L.ci(F), L.ci(P), L.ci(C), tabs["c0"], tabs["cn"], tabs["bg"], L.ptr(fb.uv), L.ptr(fb.conic), L.ptr(opacity),
+            ctypes.c_int64(op_fs), tabs["feat"], tabs["fs"], L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap),
+            L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(row), (ctypes.c_void_p * 3)(*dl),
+            (ctypes.c_float * 3)(*scale), L.ptr(sums), L.ci(want_abs), L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack),
+            L.ptr(fb.cull_flags), L.ptr(_debug_T_front(F * H, W, fb.dev)), L.ptr(fb.pack if std else None), st))
+        # the slab order of the three groups: (tap set, second set, detached set) -> set index of the caller's list
+        l1["group_of_set"] = list(groups)
+        return rec
     for g_, w, grp in zip(grads, state["widths"], groups):
         t = L.need(g_, "dL_dout") if g_ is not None else torch.zeros(F, w, H, W, dtype=torch.float32, device=fb.dev)
         if tuple(t.shape) != (F, w, H, W):

@@ -12,7 +12,8 @@ K = 5 nearest neighbours + the ARAP energy of the pair (:671-675; src/geometry_u
     neighbours of the sampled vertices + ARAP           splat_knn_brute_batch, splat_arap_energy_batch   row f3
     dynamic preprocess + binning + sort + 3 blends      FrameBatch.render_dynamic_sets           rows a15/f1, a8, a9-a11
         the attribute set = [track_gs (per frame) | attributes (shared)] read in place (feature sources)
-    L1 losses and their gradients                       splat_l1_loss_grad
+    L1 losses and their gradients                       fused into the tile backward (splat_alpha_blending_backward_batch_sets_l1;
+                                                        fused_l1=False: splat_l1_loss_grad + gradient images)
     three-set tile backward + Gaussian-side walk        (autograd of render_dynamic_sets)        row a10
         track_gs' per-frame gradient lands next to the ARAP gradient of position(ids2)
     both position gradients -> spline segments          splat_dynamic_positions_batch_backward
@@ -110,7 +111,7 @@ class TrainingStep:
                  lr: Optional[Dict[str, float]] = None, weights: Optional[LossWeights] = None,
                  densify: Optional[DensifyConfig] = None, K: int = 20, knn_K: int = 5, arap_samples: int = 512,
                  bg: float = 0.0, sample_seed: Optional[int] = None, timing: bool = False, owner_sharded: bool = False,
-                 spatial_order: bool = True, zero1: bool = False):
+                 spatial_order: bool = True, zero1: bool = False, fused_l1: bool = True):
         self.clock, self.W, self.H, self.F = clock, int(W), int(H), int(frames_per_step)
         self.extr = extr
         self.dev = params["position"].device
@@ -119,6 +120,7 @@ class TrainingStep:
         self.cfg = densify or DensifyConfig()
         self.K, self.knn_K, self.S, self.bg = int(K), int(knn_K), int(arap_samples), float(bg)
         self.timing = timing
+        self.fused_l1 = bool(fused_l1)      # the L1 losses' gradient inside the tile backward (no gradient images)
         self.iteration = 0
         self.history: List[int] = []            # Gaussian count after every structure change
         self.last: Dict[str, Tensor] = {}
@@ -264,11 +266,20 @@ class TrainingStep:
                                           opacity=p["opacity"], scaling=p["scaling"], cubic_layout=SEGMENT_MAJOR, K=self.K,
                                           grad_sink=sink)
         ph.mark("render_forward")
-        sums = torch.zeros(3, dtype=torch.float32, device=self.dev)
-        grads = [self._l1(out[0], gt["rgb"], self.w.rgb, sums[0:1]), self._l1(out[1], gt["depth"], self.w.depth, sums[1:2]),
-                 self._l1(out[2], gt["attr"], self.w.attr, sums[2:3])]
-        ph.mark("loss")
-        torch.autograd.backward(list(out[:3]), grads)
+        if self.fused_l1 and L.get_option("bwd_quarters"):
+            # the L1 terms' gradient images are never materialised: the tile kernel derives them from the forward's output row and
+            # the ground-truth frames where it hoists the image gradient (splat_alpha_blending_backward_batch_sets_l1)
+            fsums = torch.empty(F, self.fb.T, 3, dtype=torch.float32, device=self.dev)      # per tile: every entry is written
+            self.fb.fuse_l1([gt["rgb"], gt["depth"], gt["attr"]], [self.w.rgb, self.w.depth, self.w.attr], fsums)
+            ph.mark("loss")
+            torch.autograd.backward(list(out[:3]), self.fb.l1_placeholders([3, 1, self.C - 4]))
+            sums = fsums.sum((0, 1))
+        else:
+            sums = torch.zeros(3, dtype=torch.float32, device=self.dev)
+            grads = [self._l1(out[0], gt["rgb"], self.w.rgb, sums[0:1]), self._l1(out[1], gt["depth"], self.w.depth, sums[1:2]),
+                     self._l1(out[2], gt["attr"], self.w.attr, sums[2:3])]
+            ph.mark("loss")
+            torch.autograd.backward(list(out[:3]), grads)
         # ---- both position gradients of every pair (ARAP on ids1 and ids2, track_gs on ids2) reach the spline segments
         positions_batch_backward(tab12, self.g_pairs.view(2 * F, N, 3), I, SEGMENT_MAJOR, None, g["pos_cubic_node"])
         ph.mark("render_backward")

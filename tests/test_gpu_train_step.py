@@ -357,3 +357,32 @@ def test_opacity_reset_and_learning_rate_schedule_survive_a_rebuild(owner):
     assert st.opt.lr["pos_cubic_node"] == 1.5e-5 and st.lr["pos_cubic_node"] == 1.5e-5      # the schedule's rate at the new count
     st.step(t1, t2, gt)
     assert torch.isfinite(st.bucket.flat_param).all() and np.isfinite(st.loss())
+
+
+def test_loss_fused_backward_equals_the_gradient_images():
+    """TrainingStep(fused_l1=True): the L1 terms' gradients are derived inside the three-set tile backward from the forward's output
+    row and the ground-truth frames (splat_alpha_blending_backward_batch_sets_l1) instead of three splat_l1_loss_grad launches
+    whose gradient images the backward reads back.  Same sign rule, same scale: the render-path gradients are bit-identical, the
+    loss sums agree to float summation order.  (The spline table also takes the ARAP gradient, scattered with float atomics: two
+    runs of one step differ there by ~1e-9.)"""
+    N, W, H, T, F = 3000, 128, 96, 20, 4
+    sc, clock, truth = _clip(N, W, H, T, seed=11)
+    extr = _t(sc.extr)
+    start = _perturbed(truth, 3)
+    t1, t2 = [0, 3, 7, 12], [5, 1, 19, 2]
+    gt = TS.render_ground_truth(truth, clock, W, H, extr, t1, t2)
+    res = []
+    for fused in (False, True):
+        st = TS.TrainingStep(start, clock, W, H, F, extr, K=8, arap_samples=128, sample_seed=4, fused_l1=fused)
+        last = st.step(t1, t2, gt)
+        torch.cuda.synchronize()
+        res.append((st, {k: float(v) for k, v in last.items()}))
+    (a, la), (b, lb) = res
+    for name in ("rotation", "opacity", "scaling", "shs", "attrs"):
+        assert torch.equal(a.bucket.grad(name), b.bucket.grad(name)), name
+        assert float(a.bucket.grad(name).abs().max()) > 0, name
+    ga, gb = a.bucket.grad("pos_cubic_node"), b.bucket.grad("pos_cubic_node")
+    assert float((ga - gb).abs().max()) <= 1e-6 * float(ga.abs().max())
+    assert torch.equal(a.dstate.pos_gradient_accum, b.dstate.pos_gradient_accum)
+    for k in ("l1_rgb", "l1_depth", "l1_attr"):
+        assert abs(la[k] - lb[k]) <= 1e-5 * abs(la[k]) and la[k] > 0, (k, la[k], lb[k])
