@@ -521,6 +521,16 @@ struct Stager {
 #ifndef BLEND_EXACTQ
 #define BLEND_EXACTQ 1
 #endif
+#ifndef BLEND_TANQ
+#define BLEND_TANQ 1     // rows below 16 channels: tangent-plane test of the quarters the bounding box lets through (see tile_cull)
+#endif
+#ifndef BLEND_TANQ_NOBOX
+#define BLEND_TANQ_NOBOX 0
+#endif
+#ifndef BLEND_TANQ_GATE
+#define BLEND_TANQ_GATE 0   // ... behind the exact test of the 8x8 block (1) or on their own (0: narrow forward 60.2 -> 54.9 us per frame,
+                            // backward 130.7 -> 132.8 at c2: the block test cost the cull threads more than the 1.7 % of entries it removed)
+#endif
 template <int CH, int SB, bool BIAS, bool SUB, bool COEF, int XR, bool SWZ, int RQL, int CS, typename Pred>
 __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ, RQL, CS> &L, int tid, int nb, float tx0, float ty0, Pred pred,
                                           unsigned int *gflags = nullptr) {
@@ -555,7 +565,13 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ, RQL, CS
             for (int j = 0; j < BPT; ++j) {
                 const int ww = BPT * part + j;
                 const float x0 = tx0 + (float)(8 * (ww & 1)), y0 = ty0 + (float)(8 * (ww >> 1));
-                const bool kb = pred(e, ww) && cull_test(a0.x, a0.y, a0.z, a0.w, a1.x, cp, x0, x0 + 7.f, y0, y0 + 7.f);
+                // quarter bits from per-quarter tests that are exact on their own (rows of 16 channels and more) subsume the block's
+                // exact test -- the quarters' rectangles of pixel centres tile the block's -- so the block is not tested there
+                // (70 VALU per thread and super-batch less in the wide forward's cull); BLEND_TANQ_GATE 0: the same for the
+                // tangent-plane quarters of the narrow rows (3.00 instead of 2.95 quarters per pair, tools/cull_model.py)
+                constexpr bool QEX = BLEND_EXACTQ == 2 || (BLEND_EXACTQ == 1 && CH >= 16);
+                constexpr bool GATE = !(SUB && (QEX || (BLEND_TANQ && CH < 16 && !BLEND_TANQ_GATE)));
+                const bool kb = pred(e, ww) && (!GATE || cull_test(a0.x, a0.y, a0.z, a0.w, a1.x, cp, x0, x0 + 7.f, y0, y0 + 7.f));
                 if (SUB) {
                     unsigned m = 0u;
                     if (kb) {
@@ -564,6 +580,28 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ, RQL, CS
                         const float ay0 = fmaxf(fmaxf(y0 - a0.y, a0.y - (y0 + 3.f)), 0.f), ay1 = fmaxf(fmaxf(y0 + 4.f - a0.y, a0.y - (y0 + 7.f)), 0.f);
                         const bool bx0_ = ax0 <= cp.hx, bx1_ = ax1 <= cp.hx, by0_ = ay0 <= cp.hy, by1_ = ay1 <= cp.hy;
                         m = (bx0_ && by0_ ? 1u : 0u) | (bx1_ && by0_ ? 2u : 0u) | (bx0_ && by1_ ? 4u : 0u) | (bx1_ && by1_ ? 8u : 0u);
+#if BLEND_TANQ_NOBOX
+                        if (BLEND_TANQ && CH < 16) m = cp.hx < 0.f ? 0u : 15u;   // experiment: the tangent test alone
+#endif
+                        if (BLEND_TANQ && CH < 16) {
+                            // TANGENT-PLANE test of the four quarters, branch-free: q(d) = d^T Q d is convex, so over the quarter's
+                            // rectangle of pixel centres (half extents 1.5 around its centre c) q >= q(c) - 3 (|Qc|_x + |Qc|_y); a
+                            // quarter whose bound exceeds tau holds no pixel with alpha >= 1/255.  Keeps 2.95 quarters per (tile,
+                            // splat) pair where the bounding box keeps 3.20 and the exact test 2.81 (tools/cull_model.py) for
+                            // ~35 VALU per block, the four quarters sharing Q c by increments.
+                            const float dxc = x0 + 1.5f - a0.x, dyc = y0 + 1.5f - a0.y;
+                            const float cA = a0.z, cB = a0.w, cC = a1.x;
+                            const float tx0 = cA * dxc + cB * dyc, ty0 = cB * dxc + cC * dyc;
+                            const float ex = fmaxf(fabsf(dxc - 1.5f), fabsf(dxc + 5.5f)), ey = fmaxf(fabsf(dyc - 1.5f), fabsf(dyc + 5.5f));
+                            const float thr = cp.tauq + 4e-6f * (cA + cC + 2.f * fabsf(cB)) * (ex * ex + ey * ey);   // cull_test's rounding bound
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float fa = (float)(4 * (q & 1)), fb = (float)(4 * (q >> 1));
+                                const float tx = tx0 + (fa * cA + fb * cB), ty = ty0 + (fa * cB + fb * cC);
+                                const float qc = (dxc + fa) * tx + (dyc + fb) * ty;
+                                if (qc - 3.f * (fabsf(tx) + fabsf(ty)) > thr) m &= ~(1u << q);   // (NaN / inf threshold: kept)
+                            }
+                        }
                         if (BLEND_EXACTQ == 2 || (BLEND_EXACTQ == 1 && CH >= 16)) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {

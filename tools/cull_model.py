@@ -15,9 +15,9 @@ uv, depth = oracle.project_point_ortho_forward(xyz, sc.extr, W, H, nearest=0.01)
 cov = oracle.compute_cov3d_forward(sc.scale, sc.rotate)
 conic, radius, tiles = oracle.ewa_project_forward(xyz, cov, sc.intr, sc.extr, uv, W, H, visible=None, ortho=True)
 rng = np.random.default_rng(0)
-sample = rng.choice(N, 8000, replace=False)
+sample = rng.choice(N, 5000, replace=False)
 gx, gy = (W + 15) // 16, (H + 15) // 16
-tot = dict(zero=0, pairs=0, blocks=0, qbox=0, qtan=0, qexact=0, active=0, qtan2=0)
+tot = dict(qtan_nogate=0, blk_nogate=0, zero=0, pairs=0, blocks=0, qbox=0, qtan=0, qexact=0, active=0, qtan2=0)
 px = np.arange(16)
 for i in sample:
     r = radius[i]
@@ -60,6 +60,16 @@ for i in sample:
                         best = min(best, A * d1 * d1 + 2 * B * d1 * d2 + C * d2 * d2)
                     return best
                 X0, Y0 = tx * 16 + bx, ty * 16 + by
+                anyq = False
+                for qd in range(4):
+                    qx0, qy0 = X0 + 4 * (qd & 1), Y0 + 4 * (qd >> 1)
+                    ax = max(qx0 - u, u - (qx0 + 3), 0); ay = max(qy0 - v, v - (qy0 + 3), 0)
+                    if not (ax <= hx and ay <= hy): continue
+                    cxq, cyq = qx0 + 1.5 - u, qy0 + 1.5 - v
+                    t1, t2 = A * cxq + B * cyq, B * cxq + C * cyq
+                    if cxq * t1 + cyq * t2 - 3 * (abs(t1) + abs(t2)) <= tau:
+                        tot["qtan_nogate"] += 1; anyq = True
+                tot["blk_nogate"] += anyq
                 if rect_min(X0, X0 + 7, Y0, Y0 + 7) > tau: continue
                 tot["blocks"] += 1
                 for qd in range(4):

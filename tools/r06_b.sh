@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$GRAFT_REPO_ROOT
 O=gpurun_out/r06b
 mkdir -p $O
-timeout 2400 python -m pytest tests/test_gpu_frames_oracle.py tests/test_gpu_block_kernels.py tests/test_gpu_frames.py tests/test_gpu_determinism.py tests/test_gpu_consistency.py tests/test_gpu_parity.py -x -q < /dev/null > $O/pytest.log 2>&1; tail -15 $O/pytest.log
+timeout 2400 python -m pytest tests/test_gpu_frames_oracle.py tests/test_gpu_parity.py tests/test_gpu_consistency.py tests/test_gpu_determinism.py tests/test_gpu_block_kernels.py -x -q < /dev/null > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 timeout 600 python bench.py --no-cpu-baseline < /dev/null 2> $O/bench.err | tail -1 > $O/bench_line.json; python - <<'PY'
 import json
 d=json.load(open("gpurun_out/r06b/bench_line.json"))
