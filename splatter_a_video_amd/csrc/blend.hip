@@ -2804,12 +2804,18 @@ struct SetsQCfg {
 // FWDREC (with STD): the records the FORWARD packed for this row (Rec<24>: [u v A B | C o . id | channels 0 .. 22 .], 32 floats)
 // are staged directly -- the park scatters a record's channels to their transposed slot positions -- so the backward needs no
 // packing launch of its own (17 us per frame at c2) and gathers 128 instead of 192 bytes per entry.
-template <bool ABS, bool STD, bool FWDREC = false>
+// SMALL: a plan whose detached set holds at most four channels (the trainer's ['mask_attribute'] / ['dino_attribute'] rows, 5 .. 8
+// channels: src/trainer_fragGS.py:657,1214) -- slots 12 .. 27 are empty, so the K-slabs j >= 3 of the colour dot product, the
+// second 16-slot block of the feature-gradient product, their hoisted operands (28 registers instead of 88) and their slab
+// traffic are skipped; records, staging and slab rows keep the 28-slot layout.
+template <bool ABS, bool STD, bool FWDREC = false, bool SMALL = false>
 __global__ void __launch_bounds__(256, BLEND_SETS_MINW)
 blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     static_assert(!FWDREC || STD, "the forward's records are only understood for the renderer's own plan");
+    static_assert(!SMALL || !STD, "the renderer's own plan fills the 28 slots");
+    constexpr int NKU = SMALL ? 3 : SetsQCfg::NK, NAU = SMALL ? 1 : SetsQCfg::NA, CHU = SMALL ? 12 : SetsQCfg::CH;   // slabs / blocks / slots in use
     using Cfg = SetsQCfg;
-    constexpr int CH = Cfg::CH, SB = Cfg::SB, NG = Cfg::NG, NK = Cfg::NK, NA = Cfg::NA, CAP = Cfg::CAP, RW = Cfg::RW, RQ = Cfg::RQ;
+    constexpr int CH = Cfg::CH, SB = Cfg::SB, NG = Cfg::NG, NK = Cfg::NK, CAP = Cfg::CAP, RW = Cfg::RW, RQ = Cfg::RQ;
     constexpr int RQL = Cfg::RQL;
     static_assert(RQ == 12 && Rec<CH>::CULL == 43 && SB == 64 && CAP * RW >= 32 * CH, "record floats 40-42 are free; the staging of 32 pixels fits a slab");
     __shared__ float4 s_rec[(SB + 1) * RQL];            // staged records (SetsQCfg::RQL parts each), slot SB = inert
@@ -2877,7 +2883,9 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         // ~9 us per workgroup at c2
         float tgt[CH];   // loss-fused: the targets (else unused)
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
+        for (int k = CHU; k < CH; ++k) gpix[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < CHU; ++k) {
             const int c = sets_slot_channel(A, k);
             const int gi = k < 4 ? 0 : k < 8 ? 1 : 2;
             const int cc = c >= 0 ? c : 0;
@@ -2901,7 +2909,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         float bgd[3] = {0.f, 0.f, 0.f};
         float l1a[3] = {0.f, 0.f, 0.f};   // loss-fused: sum |pred - target| of this pixel, per set
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
+        for (int k = 0; k < CHU; ++k) {
             const int c = sets_slot_channel(A, k);
             const int gi = k < 4 ? 0 : k < 8 ? 1 : 2;
             float g = gpix[k];
@@ -2934,7 +2942,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     }
     if (tid < RQL) s_rec[qpart(SB, tid)] = make_float4(tid == 10 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);   // inert slot SB: q0 = log2(0)
     // ---- dL_dout of the wave's pixels into registers in both MFMA operand layouts, 32 pixels (two quarters) at a time
-    float hcg[4][NK], hft[16][NA];
+    float hcg[4][NKU], hft[16][NAU];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if ((lane >> 5) == h) {
@@ -2946,12 +2954,12 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
 #pragma unroll
         for (int G = 2 * h; G < 2 * h + 2; ++G)
 #pragma unroll
-            for (int j = 0; j < NK; ++j)   // A[m = pixel nl of quarter G][k = slot]: pixel 16 (G & 1) + nl of the half (lanes in walk order)
+            for (int j = 0; j < NKU; ++j)   // A[m = pixel nl of quarter G][k = slot]: pixel 16 (G & 1) + nl of the half (lanes in walk order)
                 hcg[G][j] = stage[(16 * (G & 1) + nl) * CH + 4 * j + kk];
 #pragma unroll
         for (int st = 8 * h; st < 8 * h + 8; ++st) {
 #pragma unroll
-            for (int q = 0; q < NA; ++q)  // A[m = slot 16 q + nl][k = own pixel of step st = (G, i)]: pixel 16 (G & 1) + 4 kk + i of the half
+            for (int q = 0; q < NAU; ++q)  // A[m = slot 16 q + nl][k = own pixel of step st = (G, i)]: pixel 16 (G & 1) + 4 kk + i of the half
                 hft[st][q] = 16 * q + nl < CH ? stage[(16 * ((st >> 2) & 1) + 4 * kk + (st & 3)) * CH + 16 * q + nl] : 0.f;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -3140,7 +3148,8 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 const int qn = top - e;
                 // the step's B operands of this lane group: three 16-byte reads (Q[kk], slots kk 4+kk 8+kk 12+kk, slots 16+kk 20+kk 24+kk)
                 const float4 *er = s_rec + e * RQL;
-                const float4 qv = er[10 + kk], t0 = er[2 + 2 * kk], t1 = er[3 + 2 * kk];
+                const float4 qv = er[10 + kk], t0 = er[2 + 2 * kk];
+                const float4 t1 = SMALL ? make_float4(0.f, 0.f, 0.f, 0.f) : er[3 + 2 * kk];
                 const float bq1 = qv.x, bq2 = qv.y, blx = qv.z, bly = qv.w;
                 float bf[NK];
                 bf[0] = t0.x; bf[1] = t0.y; bf[2] = t0.z; bf[3] = t0.w; bf[4] = t1.x; bf[5] = t1.y; bf[6] = t1.z;
@@ -3151,13 +3160,14 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 float *const rr = slab + row * RW;
                 float4 *const p1 = reinterpret_cast<float4 *>(rr + 4 * kk);
                 float4 *const pf = reinterpret_cast<float4 *>(rr + 20 + 4 * kk);   // slots 4 kk .. (q = 0) and 16 + 4 kk .. (q = 1)
-                const float4 o1_in = *p1, f0_in = pf[0], f1_in = pf[4];            // (lane group 3: pf[4] is the row's padding)
+                const float4 o1_in = *p1, f0_in = pf[0];
+                const float4 f1_in = SMALL ? make_float4(0.f, 0.f, 0.f, 0.f) : pf[4];   // (lane group 3: pf[4] is the row's padding)
                 const float ay_in = rr[16];
 #endif
                 f32x4 d_mom = {0.f, 0.f, 0.f, 0.f};
-                f32x4 d_f[NA];
+                f32x4 d_f[NAU];
 #pragma unroll
-                for (int a = 0; a < NA; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int a = 0; a < NAU; ++a) d_f[a] = f32x4{0.f, 0.f, 0.f, 0.f};
                 float s_op = 0.f, s_tx = 0.f, s_ty = 0.f, s_ax = 0.f, s_ay = 0.f;
                 asm volatile("" ::: "memory");
                 f32x4 pw = {0.f, 0.f, 0.f, 0.f}, cv0 = {0.f, 0.f, 0.f, 0.f}, cv1 = {0.f, 0.f, 0.f, 0.f}, cv2 = {0.f, 0.f, 0.f, 0.f};
@@ -3166,7 +3176,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 cv0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][0], bf[0], cv0, 0, 0, 0);
                 cv1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][1], bf[1], cv1, 0, 0, 0);
 #pragma unroll
-                for (int j = 2; j < NK; ++j) cv2 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][j], bf[j], cv2, 0, 0, 0);
+                for (int j = 2; j < NKU; ++j) cv2 = __builtin_amdgcn_mfma_f32_16x16x4f32(hcg[G][j], bf[j], cv2, 0, 0, 0);
                 float araw[4], a[4], r1a[4], rp[4], Ts4[4], Rs[3][4], cg[3][4];
                 bool ok[4];
 #pragma unroll
@@ -3218,7 +3228,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                     const float dLp = am * (dLa0 + dLa1 + dLa2);
                     d_mom = __builtin_amdgcn_mfma_f32_16x16x4f32(momrow[32 * s], dLp, d_mom, 0, 0, 0);
 #pragma unroll
-                    for (int q = 0; q < NA; ++q) d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(hft[s][q], wgt[i], d_f[q], 0, 0, 0);
+                    for (int q = 0; q < NAU; ++q) d_f[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(hft[s][q], wgt[i], d_f[q], 0, 0, 0);
                     s_op += dLp_op;
                     const float gx = dLp_tap * lx4[i], gy = dLp_tap * ly4[i];
                     s_tx += gx;
@@ -3248,9 +3258,9 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                     float4 f0 = f0_in;
                     f0.x += d_f[0][0]; f0.y += d_f[0][1]; f0.z += d_f[0][2]; f0.w += d_f[0][3];
                     pf[0] = f0;
-                    if (kk < 3) {
+                    if (!SMALL && kk < 3) {
                         float4 f1 = f1_in;
-                        f1.x += d_f[1][0]; f1.y += d_f[1][1]; f1.z += d_f[1][2]; f1.w += d_f[1][3];
+                        f1.x += d_f[NAU - 1][0]; f1.y += d_f[NAU - 1][1]; f1.z += d_f[NAU - 1][2]; f1.w += d_f[NAU - 1][3];
                         pf[4] = f1;
                     }
                 }
@@ -3271,9 +3281,9 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                     float4 f0 = pf[0];
                     f0.x += d_f[0][0]; f0.y += d_f[0][1]; f0.z += d_f[0][2]; f0.w += d_f[0][3];
                     pf[0] = f0;
-                    if (kk < 3) {
+                    if (!SMALL && kk < 3) {
                         float4 f1 = pf[4];
-                        f1.x += d_f[1][0]; f1.y += d_f[1][1]; f1.z += d_f[1][2]; f1.w += d_f[1][3];
+                        f1.x += d_f[NAU - 1][0]; f1.y += d_f[NAU - 1][1]; f1.z += d_f[NAU - 1][2]; f1.w += d_f[NAU - 1][3];
                         pf[4] = f1;
                     }
                 }
@@ -3426,7 +3436,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 }
             } else {
                 // slots [8 (cp - 1) .. ) of the 28 (cp 1: 0-7, cp 2: 8-19, cp 3: 20-27), summed over the waves, to their row channels
-                const int s0 = cp == 1 ? 0 : cp == 2 ? 8 : 20, ns = cp == 2 ? 12 : 8;
+                const int s0 = cp == 1 ? 0 : cp == 2 ? 8 : 20, ns = SMALL ? (cp == 1 ? 8 : cp == 2 ? 4 : 0) : (cp == 2 ? 12 : 8);
                 float f[12];
 #pragma unroll
                 for (int k = 0; k < 12; ++k) f[k] = 0.f;
@@ -4543,11 +4553,14 @@ static int backward_batch_sets_impl(int F, int P, int C, const int32_t *set_c0, 
     SPLAT_LAUNCH("blend_pack", pack_sets_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)F), dim3(256), 0, s, A);
     SPLAT_POST_LAUNCH();
     if (A.cull_flags && bwd_use_quarters()) {   // quarter lists (the forward's quarter bits)
+        const bool small = !std_plan && set_cn[2] <= 4;   // detached set of at most four channels: slots 12 .. 27 empty
         if (want_abs) {
             if (std_plan) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, true>), grid, block, 0, s, A);
+            else if (small) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, false, false, true>), grid, block, 0, s, A);
             else SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, false>), grid, block, 0, s, A);
         } else {
             if (std_plan) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<false, true>), grid, block, 0, s, A);
+            else if (small) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<false, false, false, true>), grid, block, 0, s, A);
             else SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<false, false>), grid, block, 0, s, A);
         }
     } else if (want_abs) SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_kernel<true>, grid, block, 0, s, A);
