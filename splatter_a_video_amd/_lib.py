@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 # every symbol include/splat_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -54,7 +54,7 @@ SYMBOLS = [
     "splat_frames_gauss_backward_static_sources_cam", "splat_blend_sets_uses_forward_pack",
     "splat_dynamic_positions_batch_forward", "splat_dynamic_positions_batch_backward",
     "splat_arap_energy_batch", "splat_knn_brute_scratch_bytes", "splat_knn_brute_batch", "splat_l1_loss_grad",
-    "splat_alpha_blending_backward_batch_sets_l1",
+    "splat_alpha_blending_backward_batch_sets_l1", "splat_bin_count_batch_reach", "splat_bin_sort_batch_reach",
     "splat_profile_enable", "splat_profile_reset", "splat_profile_read",
 ]
 

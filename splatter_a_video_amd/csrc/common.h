@@ -112,6 +112,66 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------- conservative reach test (tile_cull of blend.hip; reach masks of binning.hip)
+// Can the splat reach alpha >= 1/255 at any pixel centre of the block [bx0,bx1]x[by0,by1]?
+// alpha >= 1/255 needs q(d) = d^T Q d <= tau = 2 ln(255 o).  Two conservative stages (never false for a
+// splat that contributes; every bound is inflated by the rounding error it can carry):
+//   1. axis-aligned box of the ellipse {q <= tau} against the block;
+//   2. exact: the minimum of the convex q over the block rectangle (centre inside, else on an edge).
+// The block-independent part (cull_params: log, two sqrt, three rcp) is evaluated once per Gaussian and frame.
+struct CullP {
+    float hx, hy;   // half extents of the ellipse's bounding box (hx < 0: the splat never contributes)
+    float tauq;     // inflated tau for the exact test (+inf: keep whenever the box test passes)
+    float ia, ic;   // 1/A, 1/C
+};
+
+__device__ __forceinline__ CullP cull_params(float a, float b, float c, float o) {
+    CullP p;
+    const float INF = __builtin_inff();
+    p.hx = INF; p.hy = INF; p.tauq = INF; p.ia = 0.f; p.ic = 0.f;  // degenerate conic: always keep
+    const float t = 255.f * o;
+    if (t < 0.999f) {  // alpha <= o < 1/255 everywhere
+        p.hx = -1.f;
+        return p;
+    }
+    const float det = a * c - b * b;
+    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return p;
+    const float relerr = 4e-7f * (a * c + b * b) / det;  // rounding bound of det (cancellation)
+    if (!(relerr < 0.25f)) return p;
+    const float tau0 = fmaxf(2.f * __logf(t), 0.f);
+    const float tau = tau0 * (1.f + 2.f * relerr) * 1.002f + 2e-3f;
+    const float inv = 1.f / det;
+    p.hx = sqrtf(tau * c * inv) * 1.001f + 0.01f;
+    p.hy = sqrtf(tau * a * inv) * 1.001f + 0.01f;
+    p.tauq = tau * 1.002f + 2e-3f;
+    p.ia = 1.f / a;
+    p.ic = 1.f / c;
+    return p;
+}
+
+__device__ __forceinline__ bool cull_test(float u, float v, float a, float b, float c, const CullP &p, float bx0,
+                                          float bx1, float by0, float by1) {
+    const float dx0 = bx0 - u, dx1 = bx1 - u, dy0 = by0 - v, dy1 = by1 - v;  // block relative to the centre
+    const float ddx = fmaxf(fmaxf(dx0, -dx1), 0.f);
+    const float ddy = fmaxf(fmaxf(dy0, -dy1), 0.f);
+    if (!((ddx <= p.hx) && (ddy <= p.hy))) return false;
+    if (ddx == 0.f && ddy == 0.f) return true;  // centre inside the block
+    // q is convex with its minimum at the centre, and the centre lies outside the block: the block minimum sits on an
+    // edge that FACES the centre (the segment from the centre to any point of the block enters it through such an
+    // edge, at a point where q is smaller) -- one vertical and/or one horizontal edge; on each, clamp the
+    // unconstrained minimiser of the edge line
+    const float INF = __builtin_inff();
+    const float xe = dx0 > 0.f ? dx0 : dx1, ye = dy0 > 0.f ? dy0 : dy1;  // the facing edges (meaningful where dd* > 0)
+    const float ys = fminf(fmaxf(-b * xe * p.ic, dy0), dy1), xs = fminf(fmaxf(-b * ye * p.ia, dx0), dx1);
+    const float qx = a * xe * xe + 2.f * b * xe * ys + c * ys * ys;
+    const float qy = a * xs * xs + 2.f * b * xs * ye + c * ye * ye;
+    const float qmin = fminf(ddx > 0.f ? qx : INF, ddy > 0.f ? qy : INF);
+    // q is evaluated with ~1e-6 relative error of its largest term; the terms are bounded by (a+c+2|b|) * r^2
+    const float r2 = fmaxf(dx0 * dx0, dx1 * dx1) + fmaxf(dy0 * dy0, dy1 * dy1);
+    const float qerr = 4e-6f * (a + c + 2.f * fabsf(b)) * r2;
+    return qmin <= p.tauq + qerr;
+}
+
 // ---------------------------------------------------------------- pair records of the atomic-free blend backward
 // One record per (tile, splat) pair at its Gaussian-major slot: r[] = [ux uy ca cb cc o | ax ay (ABS) | bias (BIAS) |
 // CH feature terms] -- written by the tile kernels of blend.hip, summed per Gaussian by pair_reduce (blend.hip) or by

@@ -12,6 +12,16 @@ static splat_camera_t batch_camera(const splat_frames_t *b) {
     return cam;
 }
 
+// pairs per tile and frame; with b->reach only the pairs whose tile the splat can reach (binning.hip: "reach masks")
+static int frames_bin_count(const splat_frames_t *b) {
+    if (b->reach) {
+        SPLAT_CHECK_ARG(b->opacity != nullptr, "reach masks need the opacity");
+        return splat_bin_count_batch_reach(b->F, b->P, b->uv, b->radius, b->conic, b->opacity, 0, b->W, b->H, b->bin_scratch,
+                                           b->tile_range, b->pairs, nullptr, b->reach, b->stream);
+    }
+    return splat_bin_count_batch(b->F, b->P, b->uv, b->radius, b->W, b->H, b->bin_scratch, b->tile_range, b->pairs, b->stream);
+}
+
 extern "C" int splat_frames_forward(const splat_frames_t *b) {
     SPLAT_CHECK_ARG(b != nullptr && b->struct_bytes == sizeof(splat_frames_t), "splat_frames_t of another ABI version");
     SPLAT_CHECK_ARG(b->capacity >= 1, "capacity (pairs reserved per frame) must be set: run splat_frames_count first");
@@ -19,10 +29,15 @@ extern "C" int splat_frames_forward(const splat_frames_t *b) {
     int rc = splat_preprocess_forward_batch_cam(b->F, b->P, b->xyz, b->offsets, b->scales, b->uquats, &cam, b->W, b->H,
                                                 b->nearest, b->extent, b->uv, b->depth, b->conic, b->radius, b->stream);
     if (rc != SPLAT_OK) return rc;
-    rc = splat_bin_count_batch(b->F, b->P, b->uv, b->radius, b->W, b->H, b->bin_scratch, b->tile_range, b->pairs, b->stream);
+    rc = frames_bin_count(b);
     if (rc != SPLAT_OK) return rc;
-    rc = splat_bin_sort_batch(b->F, b->P, b->uv, b->depth, b->radius, b->W, b->H, b->bin_scratch, b->tile_range, b->capacity,
-                              b->keys, b->idx_sorted, b->overflow, b->goff_incl, b->owner, b->slot_sorted, b->stream);
+    if (b->reach)
+        rc = splat_bin_sort_batch_reach(b->F, b->P, b->uv, b->depth, b->radius, b->conic, b->opacity, 0, b->reach, b->W, b->H,
+                                        b->bin_scratch, b->tile_range, b->capacity, b->keys, b->idx_sorted, b->overflow,
+                                        b->goff_incl, b->owner, b->slot_sorted, b->stream);
+    else
+        rc = splat_bin_sort_batch(b->F, b->P, b->uv, b->depth, b->radius, b->W, b->H, b->bin_scratch, b->tile_range, b->capacity,
+                                  b->keys, b->idx_sorted, b->overflow, b->goff_incl, b->owner, b->slot_sorted, b->stream);
     if (rc != SPLAT_OK) return rc;
     return splat_alpha_blending_forward_batch(b->F, b->P, b->C, b->uv, b->conic, b->opacity, 0, b->feature, 0, b->idx_sorted,
                                               b->tile_range, b->capacity, b->bg, nullptr, b->W, b->H, 0, 0, b->out, b->final_T,
@@ -37,7 +52,7 @@ extern "C" int splat_frames_count(const splat_frames_t *b) {
     int rc = splat_preprocess_forward_batch_cam(b->F, b->P, b->xyz, b->offsets, b->scales, b->uquats, &cam, b->W, b->H,
                                                 b->nearest, b->extent, b->uv, b->depth, b->conic, b->radius, b->stream);
     if (rc != SPLAT_OK) return rc;
-    return splat_bin_count_batch(b->F, b->P, b->uv, b->radius, b->W, b->H, b->bin_scratch, b->tile_range, b->pairs, b->stream);
+    return frames_bin_count(b);
 }
 
 extern "C" int splat_frames_backward(const splat_frames_t *b) {

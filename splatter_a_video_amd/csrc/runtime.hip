@@ -19,7 +19,7 @@ void splat_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *splat_last_error(void) { return g_err; }
-extern "C" int splat_abi_version(void) { return 20; }
+extern "C" int splat_abi_version(void) { return 21; }
 
 #ifndef SPLAT_BUILD_ID
 #define SPLAT_BUILD_ID "unstamped"

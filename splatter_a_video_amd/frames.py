@@ -38,7 +38,7 @@ _FRAMES_FIELDS = ([("struct_bytes", ctypes.c_size_t)]
                       "pack", "out", "final_T", "ncontrib", "dL_dout", "pair_records", "d_xyz", "d_scales", "d_uquats",
                       "d_opacity", "d_feature", "tap", "abs_tap", "radii_max", "dbg_T_front", "cull_flags")]
                   + [("extr_frame_stride", ctypes.c_int64), ("intr_frame_stride", ctypes.c_int64), ("intr", ctypes.c_void_p),
-                     ("perspective", ctypes.c_int32)])
+                     ("perspective", ctypes.c_int32), ("reach", ctypes.c_void_p)])
 
 
 class _SplatFrames(ctypes.Structure):
@@ -110,7 +110,9 @@ class _Camera:
 
 # python-level switch of the multi-set paths (tests flip it in code -- no environment variable is read; the library's own
 # options: L.set_option)
-OPTIONS = {"sets_one_pass": True}
+# "reach": create only the (Gaussian, tile) pairs whose tile the splat can reach with alpha >= 1/255 (splat_bin_*_batch_reach:
+# a third fewer pairs on the bench scene, same images / ids / gradients); False: the reference's bounding-square pairs
+OPTIONS = {"sets_one_pass": True, "reach": True}
 
 
 def _tiles(W: int, H: int) -> int:
@@ -149,6 +151,7 @@ class FrameBatch:
         self.bin_bytes = int(lib.splat_bin_scratch_bytes(P_, W, H))
         self.bin_scratch = torch.empty(F_ * self.bin_bytes, dtype=torch.uint8, device=dev)
         self.goff = torch.empty(F_, P_, dtype=i32, device=dev)
+        self.reach = torch.empty(F_, P_, dtype=i32, device=dev)      # reach words of the count step for the sort step
         self.pack = torch.empty(F_ * P_ * int(lib.splat_blend_pack_floats(C)), dtype=f32, device=dev)
         self.out = None
         self.final_T = torch.empty(F_, H, W, dtype=f32, device=dev)
@@ -248,27 +251,43 @@ class FrameBatch:
         return sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, Tensor))
 
     # ------------------------------------------------------------------ forward / backward launch sequences
-    def _geometry(self, xyz, scales, uquats, offsets, cam: "_Camera", nearest, extent):
+    def _geometry(self, xyz, scales, uquats, offsets, cam: "_Camera", nearest, extent, opacity=None, op_fs=0):
         """fused preprocess (projection + cov3d + EWA under the batch's camera) + tile binning + per-tile depth sort of all frames"""
         lib, st = L.lib(), L.stream()
         F_, P_, W, H = self.F, self.P, self.W, self.H
         L.check(lib.splat_preprocess_forward_batch_cam(
             L.ci(F_), L.ci(P_), L.ptr(xyz), L.ptr(offsets), L.ptr(scales), L.ptr(uquats), ctypes.byref(cam.struct()), L.ci(W),
             L.ci(H), L.cf(nearest), L.cf(extent), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.conic), L.ptr(self.radius), st))
-        self._bin_and_sort()
+        self._bin_and_sort(opacity, op_fs)
 
-    def _bin_and_sort(self):
+    def _bin_and_sort(self, opacity: Optional[Tensor] = None, op_fs: int = 0):
+        """tile binning + per-tile depth sort of all frames.  With ``opacity`` ([P], or per frame [F,P] with ``op_fs`` = P) and
+        OPTIONS["reach"]: only the pairs whose tile the splat can reach with alpha >= 1/255 are created."""
         lib, st = L.lib(), L.stream()
         F_, P_, W, H = self.F, self.P, self.W, self.H
-        L.check(lib.splat_bin_count_batch(L.ci(F_), L.ci(P_), L.ptr(self.uv), L.ptr(self.radius), L.ci(W), L.ci(H),
-                                          L.ptr(self.bin_scratch), L.ptr(self.tile_range), L.ptr(self.pairs), st))
+        reach = opacity is not None and OPTIONS["reach"]
+        if reach:
+            L.check(lib.splat_bin_count_batch_reach(
+                L.ci(F_), L.ci(P_), L.ptr(self.uv), L.ptr(self.radius), L.ptr(self.conic), L.ptr(opacity), ctypes.c_int64(op_fs),
+                L.ci(W), L.ci(H), L.ptr(self.bin_scratch), L.ptr(self.tile_range), L.ptr(self.pairs), L.ptr(None),
+                L.ptr(self.reach), st))
+        else:
+            L.check(lib.splat_bin_count_batch(L.ci(F_), L.ci(P_), L.ptr(self.uv), L.ptr(self.radius), L.ci(W), L.ci(H),
+                                              L.ptr(self.bin_scratch), L.ptr(self.tile_range), L.ptr(self.pairs), st))
         if self.capacity is None:      # first batch: size the pair buffers (the only host sync of the object's life)
             self._reserve(int(int(self.pairs.max().item()) * self.slack) + 1024)
         cap = self.capacity
-        L.check(lib.splat_bin_sort_batch(
-            L.ci(F_), L.ci(P_), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.radius), L.ci(W), L.ci(H),
-            L.ptr(self.bin_scratch), L.ptr(self.tile_range), ctypes.c_int64(cap), L.ptr(self.keys), L.ptr(self.idx_sorted),
-            L.ptr(self.overflow), L.ptr(self.goff), L.ptr(self.owner), L.ptr(self.slot_sorted), st))
+        if reach:
+            L.check(lib.splat_bin_sort_batch_reach(
+                L.ci(F_), L.ci(P_), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.radius), L.ptr(self.conic), L.ptr(opacity),
+                ctypes.c_int64(op_fs), L.ptr(self.reach), L.ci(W), L.ci(H), L.ptr(self.bin_scratch), L.ptr(self.tile_range),
+                ctypes.c_int64(cap), L.ptr(self.keys), L.ptr(self.idx_sorted), L.ptr(self.overflow), L.ptr(self.goff),
+                L.ptr(self.owner), L.ptr(self.slot_sorted), st))
+        else:
+            L.check(lib.splat_bin_sort_batch(
+                L.ci(F_), L.ci(P_), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.radius), L.ci(W), L.ci(H),
+                L.ptr(self.bin_scratch), L.ptr(self.tile_range), ctypes.c_int64(cap), L.ptr(self.keys), L.ptr(self.idx_sorted),
+                L.ptr(self.overflow), L.ptr(self.goff), L.ptr(self.owner), L.ptr(self.slot_sorted), st))
         self._note_overflow()
 
     def _struct(self, xyz, scales, uquats, opacity, feature, offsets, cam, bg, nearest=0.01, extent=1.3) -> _SplatFrames:
@@ -290,7 +309,8 @@ class FrameBatch:
                             owner=self.owner, idx_sorted=self.idx_sorted, slot_sorted=self.slot_sorted, keys=self.keys,
                             pack=self.pack, final_T=self.final_T, ncontrib=self.ncontrib, pair_records=self.pair_records,
                             tap=self.tap, abs_tap=self.abs_tap, radii_max=self.radii_max,
-                            cull_flags=self.cull_flags).items():
+                            cull_flags=self.cull_flags,
+                            reach=self.reach if (opacity is not None and OPTIONS["reach"]) else None).items():
             setattr(b, name, dp(t))
         return b
 
@@ -486,7 +506,7 @@ class _RenderDynamic(torch.autograd.Function):
             L.ci(F), L.ci(P), L.ci(I), L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(layout), L.ptr(rotation), L.ptr(rot_poly),
             L.ptr(rot_fourier), L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c), L.ci(W), L.ci(H), L.cf(nearest), L.cf(extent),
             L.ptr(fb.uv), L.ptr(fb.depth), L.ptr(fb.conic), L.ptr(fb.radius), L.ptr(opa_t), st))
-        fb._bin_and_sort()
+        fb._bin_and_sort(opa_t)
         cap = fb.capacity
         out = torch.empty(F, C, H, W, dtype=torch.float32, device=fb.dev)
         L.check(lib.splat_alpha_blending_forward_batch(
@@ -556,7 +576,7 @@ class _RenderDynamicSets(torch.autograd.Function):
             L.ci(F), L.ci(P), L.ci(I), L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(layout), L.ptr(rotation), L.ptr(rot_poly),
             L.ptr(rot_fourier), L.ptr(opacity), L.ptr(scaling), L.ptr(extr_c), L.ci(W), L.ci(H), L.cf(nearest), L.cf(extent),
             L.ptr(fb.uv), L.ptr(fb.depth), L.ptr(fb.conic), L.ptr(fb.radius), L.ptr(opa_t), st))
-        fb._bin_and_sort()
+        fb._bin_and_sort(opa_t)
         if sources:
             feats = tuple(_source_tensor(t, pf, F, P) for t, (_, pf) in zip(feats, [p_ for pp in parts for p_ in pp]))
             out, gs_idx, ctx.blend = _blend_sources_forward(fb, meta, parts, feats, opa_t, K)
@@ -925,7 +945,7 @@ class _RenderSets(torch.autograd.Function):
         if off is None and F > 1 and cam.extr_fs == 0:
             raise ValueError("several frames of static Gaussians need per-frame offsets or per-frame cameras")
         ctx.gen = fb._begin_forward()
-        fb._geometry(xyz, scales, uquats, off, cam, nearest, extent)
+        fb._geometry(xyz, scales, uquats, off, cam, nearest, extent, opacity)
         op_fs = 0
         C = fb.C
         out, gs_idx, ctx.blend = _blend_sets_forward(fb, meta, feats, opacity, op_fs, K)

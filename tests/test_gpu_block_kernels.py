@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _oracle_cases():
     import test_gpu_frames_oracle as T
-    return [("render", T.test_frame_batch_render_against_oracle_and_reference_geometry, {}),
+    return [("render", T.test_frame_batch_render_against_oracle_and_reference_geometry, {"reach": True}),
             ("render_sets_std", T.test_render_sets_against_oracle, {"std": 1, "width": 19}),
             ("render_sets_generic", T.test_render_sets_against_oracle, {"std": 0, "width": 19}),
             ("render_sets_mask", T.test_render_sets_against_oracle, {"std": 1, "width": 1}),
@@ -114,7 +114,8 @@ def test_sort_and_pair_map_with_slot_keys(case, gpu, oracle_mod, lib_option):
     elif case == "ties_and_empty":
         P.test_sort_gaussian_ties_and_empty(gpu, oracle_mod)
     else:
-        T.test_frame_batch_render_against_oracle_and_reference_geometry(oracle_mod)
+        for reach in (True, False):      # slot keys count the kept tiles under reach masks as the packed keys do
+            T.test_frame_batch_render_against_oracle_and_reference_geometry(oracle_mod, reach)
 
 
 def _crowded_sort_case():

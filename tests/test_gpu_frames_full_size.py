@@ -33,9 +33,11 @@ def _offsets(sc, F):
     return np.stack([sc.positions(f) - sc.xyz for f in range(F)]).astype(np.float32)
 
 
-def _close(a, b, what, frac=1e-5):
-    """same arithmetic, other summation order: element-wise 2e-4 relative + 2e-6 of the maximum on all but a 1e-5 fraction
-    of the elements (ill-conditioned, nearly isotropic Gaussians), none further off than 10x that"""
+def _close(a, b, what, frac=2e-5):
+    """same arithmetic, other summation order: element-wise 2e-4 relative + 2e-6 of the maximum on all but a 2e-5 fraction
+    of the elements (ill-conditioned, nearly isotropic Gaussians; the batch's lists hold only the pairs that reach their tile, the
+    per-frame operators' the whole bounding squares: other super-batch boundaries, other partial sums), none further off than
+    10x that"""
     d = (a - b).abs()
     mx = float(b.abs().max())
     bad = d > 2e-4 * b.abs() + 2e-6 * mx + 1e-12
@@ -81,7 +83,7 @@ def test_frame_batch_render_full_size(name, N, W, H, C, F, capacity):
 
     out, gb1, Tf, tap1, rad = batch_backward(g1)
     M = B.check()
-    assert M > 3 * N and (capacity is None or M <= capacity)
+    assert M > 2 * N and (capacity is None or M <= capacity)      # (reach masks: 2.5 pairs per Gaussian, 3.8 in the bounding squares)
     # ---- the backward replayed the forward's decisions, on every pixel of every frame
     assert Tf.shape[0] == F * H and torch.isfinite(Tf).all()
     assert float((Tf - 1).abs().max()) < 2e-4
@@ -161,7 +163,7 @@ def test_render_dynamic_sets_full_size_c2():
     with capture_T_front() as cap:
         torch.autograd.backward([o_rgb, o_dep, o_att], [g_rgb, g_dep, g_att])
     torch.cuda.synchronize()
-    assert B.check() > 3 * N
+    assert B.check() > 2 * N
     assert float((cap.maps[0] - 1).abs().max()) < 2e-4
     # the first K contributors of a pixel are distinct, in list order, and end with -1 padding only
     valid = ids >= 0
