@@ -489,10 +489,10 @@ class FrameRenderer:
         if not fused and not self.dynamic:
             idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
         elif self.capacity is None:   # first frame: learn the pair count with the synchronising sort
-            idx, tr = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+            idx, tr, _ = gs.sort_gaussian_capped(uv, depth, W, H, radius, None, conic.detach(), opacity.detach())
             self.capacity = int(idx.numel() * 1.25) + 1024
-        else:
-            idx, tr, st = gs.sort_gaussian_capped(uv, depth, W, H, radius, self.capacity)
+        else:   # (conic + opacity: only the pairs whose tile the splat can reach -- the reach masks of the frame batch)
+            idx, tr, st = gs.sort_gaussian_capped(uv, depth, W, H, radius, self.capacity, conic.detach(), opacity.detach())
             self.sort_status.append(st)
         # densification tap, as the reference renderers create it (dptr.py:151-162)
         ndc = torch.zeros_like(uv, requires_grad=True)

@@ -388,18 +388,18 @@ int splat_bin_sort_batch(int F, int P, const float *uv, const float *depth, cons
  * (include/utils.h:17-37) and lets alpha_blending skip, per pixel, what stays below alpha = 1/255 (src/alpha_blending.cu:78-95);
  * a third of those pairs reaches no pixel of its tile.  With conic [F,P,3] and opacity ([P]: opacity_frame_stride 0, or [F,P]:
  * stride P) the count step keeps only the tiles whose rectangle of pixel centres the alpha >= 1/255 ellipse can touch (the
- * compositing kernels' own conservative test) and leaves one word per Gaussian in reach[F,P] for the sort step.  tile_range,
+ * compositing kernels' own conservative test; rectangles of 32 tiles and more keep all) and leaves one word per Gaussian in
+ * reach[F,P] for the sort step.  tile_range,
  * M_out, gcount (optional, [F,P]), goff_incl and the pair slots count the KEPT pairs.  Images, ids and gradients composited
  * from the shorter lists are those of the full lists bit for bit; list positions (ncontrib) differ.  Not for callers that
  * return idx_sorted / tile_range as the reference's sort_gaussian result.  F = 1: a single frame. */
 int splat_bin_count_batch_reach(int F, int P, const float *uv, const int32_t *radius, const float *conic,
                                 const float *opacity, int64_t opacity_frame_stride, int W, int H, void *scratch,
                                 int32_t *tile_range, int32_t *M_out, int32_t *gcount, uint32_t *reach, splat_stream_t stream);
-int splat_bin_sort_batch_reach(int F, int P, const float *uv, const float *depth, const int32_t *radius, const float *conic,
-                               const float *opacity, int64_t opacity_frame_stride, const uint32_t *reach, int W, int H,
-                               void *scratch, int32_t *tile_range, int64_t capacity, uint64_t *keys, int32_t *idx_sorted,
-                               int32_t *overflow_out, int32_t *goff_incl /*[F,P] out*/, int32_t *owner, int32_t *slot_sorted,
-                               splat_stream_t stream);
+int splat_bin_sort_batch_reach(int F, int P, const float *uv, const float *depth, const int32_t *radius, const uint32_t *reach,
+                               int W, int H, void *scratch, int32_t *tile_range, int64_t capacity, uint64_t *keys,
+                               int32_t *idx_sorted, int32_t *overflow_out, int32_t *goff_incl /*[F,P] out*/, int32_t *owner,
+                               int32_t *slot_sorted, splat_stream_t stream);
 /* C <= 32.  opacity / feature: stride in elements between two frames' arrays, 0 = shared by all frames.
  * pack_scratch: F * P * splat_blend_pack_floats(C) floats (kept for the backward). */
 int splat_alpha_blending_forward_batch(int F, int P, int C, const float *uv, const float *conic, const float *opacity,

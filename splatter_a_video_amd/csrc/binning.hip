@@ -127,16 +127,13 @@ static BinPlan make_plan(int P, int W, int H, int F = 1) {
 // kernel, which runs the compositing kernels' own conservative test (cull_test, common.h) on the tile's rectangle of pixel
 // centres and leaves one word per Gaussian for the scatter kernel:
 //     bit 31 clear: bits 0 .. 30 = keep flags of the rectangle's tiles in row-major order (rectangles of at most 31 tiles);
-//     bit 31 set:   the low bits hold the kept COUNT of a larger rectangle; the scatter kernel repeats the test through the
-//                   same non-inlined function (one machine code: the two kernels cannot disagree).
+//     bit 31 set:   a larger rectangle (radius above ~35 px) keeps all its tiles; the low bits hold their count.
+// The scatter kernel only reads the word: the two kernels cannot disagree about a pair.  (A test repeated in the scatter kernel
+// through a shared non-inlined function served the large rectangles as well, but a device function call gives both kernels a
+// stack: single-frame launches 9.5 -> 40 us and 22 -> 45 us.)
 // A dropped pair holds no pixel with alpha >= 1/255, so images, ids and gradients are those of the full list bit for bit; only
 // list positions (ncontrib) and M change.
 #define REACH_BIG 0x80000000u
-__device__ __noinline__ bool reach_big_tile(float u, float v, float a, float b, float c, float o, int tx, int ty) {
-    const CullP cp = cull_params(a, b, c, o);
-    const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
-    return cull_test(u, v, a, b, c, cp, x0, x0 + (float)(TILE - 1), y0, y0 + (float)(TILE - 1));
-}
 
 // ------------------------------------------------------------------ K1
 template <bool LDS>
@@ -189,15 +186,14 @@ bin_count_kernel(int P, const float2 *__restrict__ uv, const int *__restrict__ r
                     }
                 kept = __popc(m);
                 word = m;
-            } else {
+            } else {   // a large rectangle keeps every tile
                 for (int ty = y0; ty < y1; ++ty)
-                    for (int tx = x0; tx < x1; ++tx)
-                        if (reach_big_tile(q.x, q.y, cA, cB, cC, o, tx, ty)) {
-                            ++kept;
-                            if (LDS) atomicAdd(&cnt[ty * gx + tx], 1);
-                            else atomicAdd(&matrix[ty * gx + tx], 1);
-                        }
-                word = REACH_BIG | (unsigned)kept;
+                    for (int tx = x0; tx < x1; ++tx) {
+                        if (LDS) atomicAdd(&cnt[ty * gx + tx], 1);
+                        else atomicAdd(&matrix[ty * gx + tx], 1);
+                    }
+                kept = area;
+                word = REACH_BIG | (unsigned)area;
             }
             reach[i] = word;
             if (gcount) gcount[i] = kept;
@@ -343,8 +339,7 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
                    const int *__restrict__ radius, int gx, int gy, int T, int chunk, int *__restrict__ matrix,
                    const int *__restrict__ tile_range, long long capacity, unsigned long long *__restrict__ keys,
                    int *__restrict__ overflow, int *__restrict__ goff_incl, int *__restrict__ owner,
-                   const int *__restrict__ chunk_off, long long S, int kbits, const float *__restrict__ conic,
-                   const float *__restrict__ opacity, long long opacity_fs, const unsigned *__restrict__ reach) {
+                   const int *__restrict__ chunk_off, long long S, int kbits, const unsigned *__restrict__ reach) {
     // Pair-map mode (goff_incl != null): the kernel also produces goff_incl, the inclusive prefix of tiles per
     // Gaussian (chunk offset from K2b + a workgroup scan of the rectangle areas), and the low key word is the pair
     // slot j = goff_excl[i] + k (k-th tile of the splat's rectangle) instead of the Gaussian id: slots grow with
@@ -358,7 +353,7 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
         uv += f * P; depth += f * P; radius += f * P; matrix += f * S; chunk_off += f * S;
         tile_range += f * 2 * T; keys += f * capacity;
         if (goff_incl) { goff_incl += f * P; owner += f * capacity; }
-        if (reach) { conic += f * 3 * (size_t)P; opacity += f * (size_t)opacity_fs; reach += f * P; }
+        if (reach) reach += f * P;
     }
     int running = goff_incl ? chunk_off[wg] : 0;
     if (LDS) {
@@ -399,16 +394,9 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
         }
         if (r <= 0) continue;
         const unsigned long long dkey = (unsigned long long)__float_as_uint(depth[i]) << 32;
-        float2 qb = make_float2(0.f, 0.f);
-        float cA = 0.f, cB = 0.f, cC = 0.f, ob = 0.f;
-        if (big) {
-            qb = uv[i];
-            cA = conic[3 * (size_t)i]; cB = conic[3 * (size_t)i + 1]; cC = conic[3 * (size_t)i + 2]; ob = opacity[i];
-        }
         unsigned bit = 1u;
-        auto kept = [&](int tx, int ty) -> bool {   // (k of the packed keys and the slots count the KEPT tiles)
-            if (!reach) return true;
-            if (big) return reach_big_tile(qb.x, qb.y, cA, cB, cC, ob, tx, ty);
+        auto kept = [&](int, int) -> bool {   // (k of the packed keys and the slots count the KEPT tiles)
+            if (!reach || big) return true;
             const bool k = (rw & bit) != 0u;
             bit <<= 1;
             return k;
@@ -846,8 +834,7 @@ static int bin_count_impl(int F, int P, const float *uv, const int32_t *radius, 
 static int bin_sort_impl(int F, int P, const float *uv, const float *depth, const int32_t *radius, int W, int H,
                          void *scratch, int32_t *tile_range, int64_t capacity, uint64_t *keys, int32_t *idx_sorted,
                          int32_t *overflow_out, int32_t *goff_incl, int32_t *owner_scratch, int32_t *slot_sorted,
-                         hipStream_t s, const float *conic = nullptr, const float *opacity = nullptr, long long opacity_fs = 0,
-                         const uint32_t *reach = nullptr) {
+                         hipStream_t s, const uint32_t *reach = nullptr) {
     const BinPlan p = make_plan(P, W, H, F);
     const long long S = (long long)(p.bytes / sizeof(int));
     char *base = (char *)scratch;
@@ -858,7 +845,7 @@ static int bin_sort_impl(int F, int P, const float *uv, const float *depth, cons
         SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<true>, dim3(p.NB, F), dim3(BIN_BLOCK), (size_t)p.T * sizeof(int), s,
                      P, (const float2 *)uv, depth, radius, p.gx, p.gy, p.T, p.chunk, matrix, tile_range,
                      (long long)capacity, (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off, S, kbits,
-                     conic, opacity, opacity_fs, reach);
+                     reach);
     } else {
         // fill counters live in tile_count's neighbour: reuse matrix row "1" = matrix + T (allocated: NB=1 -> need 2 rows)
         for (int f = 0; f < F; ++f)
@@ -867,8 +854,7 @@ static int bin_sort_impl(int F, int P, const float *uv, const float *depth, cons
         const int chunk = (P + nblk - 1) / nblk;
         SPLAT_LAUNCH("bin_scatter", bin_scatter_kernel<false>, dim3(nblk, F), dim3(BIN_BLOCK), 0, s, P, (const float2 *)uv,
                      depth, radius, p.gx, p.gy, p.T, chunk > 0 ? chunk : 1, matrix, tile_range, (long long)capacity,
-                     (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off, S, kbits, conic, opacity,
-                     opacity_fs, reach);
+                     (unsigned long long *)keys, overflow_out, goff_incl, owner_scratch, chunk_off, S, kbits, reach);
     }
     SPLAT_POST_LAUNCH();
     SPLAT_LAUNCH("tile_sort", tile_sort_kernel, dim3((unsigned)((size_t)p.T * F)), dim3(SORT_BLOCK), 0, s, p.T, tile_range, (long long)capacity,
@@ -926,7 +912,7 @@ extern "C" int splat_bin_sort_batch(int F, int P, const float *uv, const float *
 
 // ---- the same two steps with REACH masks (ABI 21; see "reach masks" above): conic [F,P,3] and opacity ([P], or [F,P] with
 // opacity_frame_stride = P) let the count kernel drop the pairs whose tile the splat cannot reach with alpha >= 1/255; `reach`
-// [F,P] words travel from the count step to the sort step.  F = 1 serves the per-frame operators (gcount: optional kept tiles
+// [F,P] words travel from the count step to the sort step (which reads nothing else about the decision).  F = 1 serves the per-frame operators (gcount: optional kept tiles
 // per Gaussian, [F,P]).  tile_range, M_out, goff_incl and the slots count the KEPT pairs only.
 extern "C" int splat_bin_count_batch_reach(int F, int P, const float *uv, const int32_t *radius, const float *conic,
                                            const float *opacity, int64_t opacity_frame_stride, int W, int H, void *scratch,
@@ -939,18 +925,16 @@ extern "C" int splat_bin_count_batch_reach(int F, int P, const float *uv, const 
 }
 
 extern "C" int splat_bin_sort_batch_reach(int F, int P, const float *uv, const float *depth, const int32_t *radius,
-                                          const float *conic, const float *opacity, int64_t opacity_frame_stride,
                                           const uint32_t *reach, int W, int H, void *scratch, int32_t *tile_range,
                                           int64_t capacity, uint64_t *keys, int32_t *idx_sorted, int32_t *overflow_out,
                                           int32_t *goff_incl, int32_t *owner_scratch, int32_t *slot_sorted,
                                           splat_stream_t stream) {
-    SPLAT_CHECK_ARG(F >= 1 && F <= 65535 && P >= 1 && W > 0 && H > 0 && capacity >= 1 && opacity_frame_stride >= 0, "bad sizes");
+    SPLAT_CHECK_ARG(F >= 1 && F <= 65535 && P >= 1 && W > 0 && H > 0 && capacity >= 1, "bad sizes");
     SPLAT_CHECK_ARG(scratch && tile_range && overflow_out && uv && depth && radius && keys && idx_sorted && goff_incl &&
-                        owner_scratch && slot_sorted && conic && opacity && reach,
+                        owner_scratch && slot_sorted && reach,
                     "null pointer");
     return bin_sort_impl(F, P, uv, depth, radius, W, H, scratch, tile_range, capacity, keys, idx_sorted, overflow_out,
-                         goff_incl, owner_scratch, slot_sorted, (hipStream_t)stream, conic, opacity,
-                         (long long)opacity_frame_stride, reach);
+                         goff_incl, owner_scratch, slot_sorted, (hipStream_t)stream, reach);
 }
 
 

@@ -1873,7 +1873,9 @@ blend_bwd_mfma_kernel(const BlendArgs B) {
 #define BLEND_Q_SB 128
 #endif
 #ifndef BLEND_Q_CAP
-#define BLEND_Q_CAP 64   // slab rows per wave and round (a second round costs a list rebuild, two barriers and a combine: 145 us per frame at 48 rows, 155 at 44, 189 at 32)
+#define BLEND_Q_CAP 80   // slab rows per wave and round (a second round costs a list rebuild, two barriers and a combine).  Round 6: with
+                         // reach masks a super-batch of 128 entries keeps 59 rows per wave on average (39 before): 64 rows -> 80 (137 -> 132 us per
+                         // frame; 45 KB of LDS = three workgroups per CU, which the compiler answers with 155 registers; 112 rows = two: 167 us)
 #endif
 #ifndef BLEND_Q_SWZ
 #define BLEND_Q_SWZ 1   // part p of entry e at 4 e + (p ^ ((e >> 2) & 3)): 16 survivors' reads of one part spread over the banks

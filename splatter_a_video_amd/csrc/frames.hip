@@ -32,9 +32,9 @@ extern "C" int splat_frames_forward(const splat_frames_t *b) {
     rc = frames_bin_count(b);
     if (rc != SPLAT_OK) return rc;
     if (b->reach)
-        rc = splat_bin_sort_batch_reach(b->F, b->P, b->uv, b->depth, b->radius, b->conic, b->opacity, 0, b->reach, b->W, b->H,
-                                        b->bin_scratch, b->tile_range, b->capacity, b->keys, b->idx_sorted, b->overflow,
-                                        b->goff_incl, b->owner, b->slot_sorted, b->stream);
+        rc = splat_bin_sort_batch_reach(b->F, b->P, b->uv, b->depth, b->radius, b->reach, b->W, b->H, b->bin_scratch,
+                                        b->tile_range, b->capacity, b->keys, b->idx_sorted, b->overflow, b->goff_incl, b->owner,
+                                        b->slot_sorted, b->stream);
     else
         rc = splat_bin_sort_batch(b->F, b->P, b->uv, b->depth, b->radius, b->W, b->H, b->bin_scratch, b->tile_range, b->capacity,
                                   b->keys, b->idx_sorted, b->overflow, b->goff_incl, b->owner, b->slot_sorted, b->stream);

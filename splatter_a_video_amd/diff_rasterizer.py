@@ -110,7 +110,7 @@ class GaussianRasterizer(torch.nn.Module):
         if rgb.dim() != 2 or rgb.shape[1] != 3:
             raise ValueError("colours must be [P,3]")
 
-        idx_sorted, tile_range = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        idx_sorted, tile_range, _ = gs.sort_gaussian_capped(uv, depth, W, H, radius, None, conic.detach(), opacities.detach())
         ndc = None
         if means2D is not None and means2D.requires_grad:
             if means2D.dim() != 2 or means2D.shape[0] != means3D.shape[0] or means2D.shape[1] < 2:

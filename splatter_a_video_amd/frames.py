@@ -279,8 +279,8 @@ class FrameBatch:
         cap = self.capacity
         if reach:
             L.check(lib.splat_bin_sort_batch_reach(
-                L.ci(F_), L.ci(P_), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.radius), L.ptr(self.conic), L.ptr(opacity),
-                ctypes.c_int64(op_fs), L.ptr(self.reach), L.ci(W), L.ci(H), L.ptr(self.bin_scratch), L.ptr(self.tile_range),
+                L.ci(F_), L.ci(P_), L.ptr(self.uv), L.ptr(self.depth), L.ptr(self.radius), L.ptr(self.reach), L.ci(W), L.ci(H),
+                L.ptr(self.bin_scratch), L.ptr(self.tile_range),
                 ctypes.c_int64(cap), L.ptr(self.keys), L.ptr(self.idx_sorted), L.ptr(self.overflow), L.ptr(self.goff),
                 L.ptr(self.owner), L.ptr(self.slot_sorted), st))
         else:

@@ -120,7 +120,10 @@ class SortStatus:
         return m
 
 
-def _sort(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Optional[Tensor], capacity: Optional[int]):
+def _sort(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Optional[Tensor], capacity: Optional[int],
+          conic: Optional[Tensor] = None, opacity: Optional[Tensor] = None):
+    """``conic`` + ``opacity``: reach masks (splat_bin_*_batch_reach with F = 1) -- only the pairs whose tile the splat can reach
+    with alpha >= 1/255 are created; not for the reference-shaped ``sort_gaussian``, whose lists are its results"""
     uv = L.need(uv, "uv")
     depth = L.need(depth, "depth")
     radius = L.need(radius, "radius", torch.int32)
@@ -138,8 +141,18 @@ def _sort(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Opti
     lib = L.lib()
     scratch = torch.empty(lib.splat_bin_scratch_bytes(P, W, H), dtype=torch.uint8, device=dev)
     m_dev = torch.empty(1, dtype=torch.int32, device=dev)
-    L.check(lib.splat_bin_count(L.ci(P), L.ptr(uv), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
-                                L.ptr(tile_range), L.ptr(m_dev), L.ptr(None), L.stream()))
+    reach = None
+    if conic is not None:
+        conic, opacity = L.need(conic, "conic"), L.need(opacity, "opacity")
+        if conic.numel() != 3 * P or opacity.numel() != P:
+            raise ValueError("conic [P,3] and opacity [P] must agree with uv on P")
+        reach = torch.empty(P, dtype=torch.int32, device=dev)
+        L.check(lib.splat_bin_count_batch_reach(L.ci(1), L.ci(P), L.ptr(uv), L.ptr(radius), L.ptr(conic), L.ptr(opacity),
+                                                ctypes.c_int64(0), L.ci(W), L.ci(H), L.ptr(scratch), L.ptr(tile_range), L.ptr(m_dev),
+                                                L.ptr(None), L.ptr(reach), L.stream()))
+    else:
+        L.check(lib.splat_bin_count(L.ci(P), L.ptr(uv), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
+                                    L.ptr(tile_range), L.ptr(m_dev), L.ptr(None), L.stream()))
     M = int(m_dev.item()) if capacity is None else int(capacity)   # the only host sync (none with a capacity)
     idx_sorted = torch.empty(M, dtype=torch.int32, device=dev)
     overflow = _overflow_sink(dev)   # the kernels only ever store 1 here; pairs > capacity carries the same fact
@@ -149,9 +162,15 @@ def _sort(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, tiles: Opti
         owner = torch.empty(M, dtype=torch.int32, device=dev)
         slot_sorted = torch.empty(M, dtype=torch.int32, device=dev)
         goff = torch.empty(P, dtype=torch.int32, device=dev)   # inclusive tiles-per-Gaussian prefix, written by the sort
-        L.check(lib.splat_bin_sort(L.ci(P), L.ptr(uv), L.ptr(depth), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
-                                   L.ptr(tile_range), ctypes.c_int64(M), L.ptr(keys), L.ptr(idx_sorted),
-                                   L.ptr(overflow), L.ptr(goff), L.ptr(owner), L.ptr(slot_sorted), L.stream()))
+        if reach is not None:
+            L.check(lib.splat_bin_sort_batch_reach(L.ci(1), L.ci(P), L.ptr(uv), L.ptr(depth), L.ptr(radius), L.ptr(reach),
+                                                   L.ci(W), L.ci(H), L.ptr(scratch),
+                                                   L.ptr(tile_range), ctypes.c_int64(M), L.ptr(keys), L.ptr(idx_sorted),
+                                                   L.ptr(overflow), L.ptr(goff), L.ptr(owner), L.ptr(slot_sorted), L.stream()))
+        else:
+            L.check(lib.splat_bin_sort(L.ci(P), L.ptr(uv), L.ptr(depth), L.ptr(radius), L.ci(W), L.ci(H), L.ptr(scratch),
+                                       L.ptr(tile_range), ctypes.c_int64(M), L.ptr(keys), L.ptr(idx_sorted),
+                                       L.ptr(overflow), L.ptr(goff), L.ptr(owner), L.ptr(slot_sorted), L.stream()))
         # companion of idx_sorted (the reference's signature has no room for it): lets alpha_blending's backward run
         # without global atomics; found again through the tensor's storage address and validated there
         pm = PairMap(goff, slot_sorted, idx_sorted, tile_range)
@@ -169,16 +188,22 @@ def sort_gaussian(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, til
     return idx_sorted, tile_range
 
 
-def sort_gaussian_capped(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor,
-                         capacity: int) -> Tuple[Tensor, Tensor, SortStatus]:
+def sort_gaussian_capped(uv: Tensor, depth: Tensor, W: int, H: int, radius: Tensor, capacity: Optional[int],
+                         conic: Optional[Tensor] = None, opacity: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, SortStatus]:
     """``sort_gaussian`` without the host synchronisation: ``idx_sorted`` is allocated with ``capacity`` entries (only
     the first M are meaningful, tile_range never points past them) and the caller checks ``status`` whenever it next
     synchronises anyway (e.g. once per gradient step).  On overflow the surplus pairs are dropped and flagged
     (``status.check()`` raises); every range, slot and prefix the sort leaves behind is clamped to the capacity, so
-    blending such a result is memory-safe (and meaningless)."""
-    if capacity < 0:
+    blending such a result is memory-safe (and meaningless).  ``capacity`` None: sized exactly, with the one host sync.
+    With ``conic`` [P,3] and ``opacity`` [P] the lists hold only the (Gaussian, tile) pairs whose tile the splat can reach with
+    alpha >= 1/255 (reach masks, include/splat_hip.h): a third fewer entries on the bench scene for every kernel behind the sort;
+    ``alpha_blending*`` composites the same images, ids and gradients from them (list positions -- ncontrib -- differ from the
+    reference's, which is why ``sort_gaussian`` itself never drops a pair)."""
+    if capacity is not None and capacity < 0:
         raise ValueError("capacity must be >= 0")
-    return _sort(uv, depth, W, H, radius, None, capacity)
+    if (conic is None) != (opacity is None):
+        raise ValueError("conic and opacity go together")
+    return _sort(uv, depth, W, H, radius, None, capacity, conic, opacity)
 
 
 # ------------------------------------------------------------------ debug: does the backward replay the forward's decisions?
@@ -602,5 +627,6 @@ def rasterization(xyz: Tensor, scale: Tensor, rotate: Tensor, opacity: Tensor, f
     else:
         from .fused_ops import preprocess_persp
         uv, depth, conic, radius, tiles = preprocess_persp(xyz, scale, rotate, intr, extr, W, H)
-    idx_sorted, tile_range = sort_gaussian(uv, depth, W, H, radius, tiles)
+    # the lists stay inside: only the pairs whose tile the splat can reach with alpha >= 1/255 (reach masks)
+    idx_sorted, tile_range, _ = sort_gaussian_capped(uv, depth, W, H, radius, None, conic.detach(), opacity.detach())
     return alpha_blending(uv, conic, opacity, feature, idx_sorted, tile_range, bg, W, H, ndc)

@@ -39,7 +39,7 @@ class OrthoEnhancedRenderer:
             rgb = self.colors(shs)
         uv, depth, conic, radius, tiles = gs.preprocess_ortho(position, scaling, rotation, extrinsic_matrix, W, H,
                                                               nearest=0.01)     # :282-321 in one launch
-        idx_sorted, tile_range = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        idx_sorted, tile_range, _ = gs.sort_gaussian_capped(uv, depth, W, H, radius, None, conic.detach(), opacity.detach())
         ndc = torch.zeros_like(uv, requires_grad=True)
         abs_ndc = torch.zeros_like(uv, requires_grad=True)
         bg = self.bg_color if bg_color is None else bg_color
@@ -151,7 +151,7 @@ class PerspRenderer:
         rgb = gs.compute_sh(shs, 3, direction)      # dptr.py:107 evaluates degree 3 whatever active_sh_degree says; kept
         uv, depth, conic, radius, tiles = gs.preprocess_persp(position, scaling, rotation, intrinsic_matrix, extrinsic_matrix, W, H,
                                                               nearest=0.01)     # dptr.py:107-147 in one launch
-        idx_sorted, tile_range = gs.sort_gaussian(uv, depth, W, H, radius, tiles)
+        idx_sorted, tile_range, _ = gs.sort_gaussian_capped(uv, depth, W, H, radius, None, conic.detach(), opacity.detach())
         names, parts = ["rgb", "depth"], [rgb, depth]
         if "pixel_flow" in kwargs:
             names.append("pixel_flow"); parts.append(kwargs["pixel_flow"])

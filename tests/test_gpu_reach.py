@@ -65,8 +65,8 @@ def test_reach_masks_change_no_bit_of_the_images(kind, N, W, H, C):
     assert mr < mf
     if kind == "big":
         area = (Bf.goff[0].long() - torch.cat([Bf.goff[0, :1] * 0, Bf.goff[0, :-1]]).long())
-        assert int(area.max()) >= 32                      # the large-rectangle form was exercised
-        assert int((Br.reach[0] < 0).sum()) > 0           # (bit 31 set)
+        assert int(area.max()) >= 32                      # rectangles of 32 tiles and more keep every tile:
+        assert int((Br.reach[0] < 0).sum()) > 0           # the count form of the reach word (bit 31 set) was exercised
     if kind == "faint":
         kept = Br.goff[0].long() - torch.cat([Br.goff[0, :1] * 0, Br.goff[0, :-1]]).long()
         assert int(kept[: N // 2].sum()) == 0
@@ -100,8 +100,8 @@ def test_reach_entry_points_raw():
     assert bool((gcount <= tiles.view(-1)).all())
     keys, idx, owner, slot = torch.empty(M, dtype=torch.int64, device="cuda"), torch.empty(M, **i32), torch.empty(M, **i32), torch.empty(M, **i32)
     goff, ovf = torch.empty(N, **i32), torch.zeros(1, **i32)
-    L.check(lib.splat_bin_sort_batch_reach(L.ci(1), L.ci(N), L.ptr(uv), L.ptr(depth), L.ptr(radius), L.ptr(conic), L.ptr(op),
-                                           ctypes.c_int64(0), L.ptr(reach), L.ci(W), L.ci(H), L.ptr(scratch), L.ptr(tr), ctypes.c_int64(M),
+    L.check(lib.splat_bin_sort_batch_reach(L.ci(1), L.ci(N), L.ptr(uv), L.ptr(depth), L.ptr(radius), L.ptr(reach), L.ci(W), L.ci(H),
+                                           L.ptr(scratch), L.ptr(tr), ctypes.c_int64(M),
                                            L.ptr(keys), L.ptr(idx), L.ptr(ovf), L.ptr(goff), L.ptr(owner), L.ptr(slot), st))
     torch.cuda.synchronize()
     assert int(ovf.item()) == 0 and torch.equal(goff, torch.cumsum(gcount, 0).int())
