@@ -37,7 +37,8 @@
                            // narrow rows' 80 registers the enhanced instantiation spills 172 bytes per lane (128 us per frame at c2)
 #endif
 #ifndef BLEND_FWD_U
-#define BLEND_FWD_U 4      // survivors evaluated per trip in the forward (narrow channel counts)
+#define BLEND_FWD_U 2      // survivors evaluated per trip in the forward (narrow channel counts).  Round 6: 4 -> 2 (the quarter lists of a
+                           // wave are padded to a multiple of U: with the denser lists of the reach masks 46.4 -> 44.9 us per frame)
 #endif
 #ifndef BLEND_FWD_TRIPTEST
 #define BLEND_FWD_TRIPTEST 0   // forward: skip a trip's compositing when no lane of the wave has a splat to apply (see the kernel)
