@@ -55,7 +55,7 @@ HBM_ACHIEVABLE_GBS = 6300.0
 # same command line (tools/round_profile.sh: separate rocprofv3 --pmc passes; read requests sized by
 # TCC_EA0_RDREQ_{32B,64B,128B}, WRITE_SIZE in KiB); stamped with the profile they come from and only reported when the
 # bench runs the configuration they were taken at.
-PMC_TAG = os.environ.get("SPLAT_PMC_TAG", "r05")
+PMC_TAG = os.environ.get("SPLAT_PMC_TAG", "r06")
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_traffic.json")
 PMC_COUNTER_FILE = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_blend_counters.json")
 PMC_KERNEL_NAMES = {"blend_bwd": ("blend_bwd_quarter_kernel", "blend_bwd_mfma_kernel"), "blend_fwd": "blend_fwd_kernel", "tile_sort": "tile_sort_kernel",
@@ -557,6 +557,31 @@ class FrameRenderer:
                 "mean_ncontrib": float(nc.mean()), "max_ncontrib": int(nc.max()),
                 "walked_entries_per_frame": float(nc.sum() / B.F), "mean_final_T": float(B.final_T.double().mean())}
 
+    def reference_list_stats(self):
+        """pairs and walked list entries of the REFERENCE's lists for the same frames (host sync, after the timed region): one
+        forward of the first part on a scratch batch with the reach masks off -- every tile of a splat's bounding square gets its
+        pair (include/utils.h:17-37), as the reference's sort_gaussian creates them.  SURVEY 8d prices the path per pair of THAT
+        rule, so `roofline` and the per-kernel algorithmic bytes use these counts; the lists the kernels actually walk
+        (`tile_pairs_M`, `scene_stats`) hold only the pairs whose tile the splat can reach."""
+        if self.mode not in ("batch", "render_iter") or not self.parts:
+            return None
+        from splatter_a_video_amd import frames as FR
+        part = self.parts[0]
+        b0 = part.batch
+        old = FR.OPTIONS["reach"]
+        FR.OPTIONS["reach"] = False
+        try:
+            part.batch = FrameBatch(b0.F, b0.P, b0.W, b0.H, b0.C, b0.dev, want_abs=b0.want_abs)
+            with torch.no_grad():
+                self._forward_only_part(part)
+            fb = part.batch
+            return {"pairs_per_frame": float(fb.pairs.double().mean()), "max_pairs_per_frame": int(fb.pairs.max()),
+                    "walked_entries_per_frame": float(fb.ncontrib.double().sum() / fb.F),
+                    "rule": "every tile of the splat's bounding square (the reference's sort_gaussian)"}
+        finally:
+            part.batch = b0
+            FR.OPTIONS["reach"] = old
+
     def step(self, collective=True):
         """one gradient step: local frames forward+backward, ONE all-reduce of the flat bucket (skipped when no process
         group exists, and in rank 0's private kernel-timing pass), one Adam step; returns when everything is enqueued"""
@@ -693,8 +718,8 @@ def compute_rates(stats, kernels):
     2C resp. ~32 + 7C more); FP32 vector / matrix peak 157.3 TFLOP/s"""
     ev = stats["walked_entries_per_frame"]
     comp = {"evaluations_per_frame": ev, "peak_TFLOPs": 157.3, "unit": "TFLOP/s",
-            "definition": "sum over pixels of ncontrib (list entries walked up to the last contributor) x 16 flops "
-                          "(forward) / 14 flops (backward recompute): lower bound of the useful arithmetic"}
+            "definition": "sum over pixels of ncontrib in the REFERENCE's lists (entries its per-pixel loops walk up to the last "
+                          "contributor) x 16 flops (forward) / 14 flops (backward recompute): lower bound of the useful arithmetic"}
     for kn, fl in (("blend_fwd", 16.0), ("blend_bwd", 14.0)):
         if kn in kernels and kernels[kn]["us_per_frame"] > 0:
             rate = ev / (kernels[kn]["us_per_frame"] * 1e-6)
@@ -1091,6 +1116,10 @@ def main():
     dt, schedule = faster_exact_schedule(dt, comm)
     fps = frames_total / dt
     M, T = R.last["M"], R.last["T"]
+    # SURVEY 8d's per-pair figures are the reference's: algorithmic bytes / flops are priced with the pairs and the walked list
+    # entries of ITS rule (bounding squares); the kernels walk the shorter lists of the reach masks (`tile_pairs_M`)
+    ref_lists = None
+    M_walked = M
     HW = a.width * a.height
     tag_cfg = f"{a.gaussians}x{a.width}x{a.height}x{a.channels}:{mode}" + ("" if a.no_spatial_order else ":morton")
 
@@ -1108,8 +1137,14 @@ def main():
         names = ["sh_fwd", "frame_preprocess_fwd", "frame_preprocess_bwd", "preprocess_fwd", "project_point_fwd", "cov3d_fwd", "ewa_fwd", "bin_count", "bin_colscan", "bin_tilescan",
                  "bin_scatter", "tile_sort", "blend_pack", "blend_fwd", "blend_bwd", "pair_reduce", "gauss_bwd", "preprocess_bwd", "ewa_bwd", "project_point_bwd",
                  "cov3d_bwd", "sh_bwd", "adam_step"]
+        raw = {n: L.profile_read(n) for n in names}
+        # (behind the event-timed step, not in front of it: the scratch forward synchronises with the host, and kernels that
+        #  follow an idle device run at ramping clocks)
+        ref_lists = R.reference_list_stats()
+        if ref_lists:
+            M = ref_lists["max_pairs_per_frame"]
         for n in names:
-            ms, cnt = L.profile_read(n)
+            ms, cnt = raw[n]
             if cnt:
                 avg = ms / cnt
                 fpl = a.frames / cnt       # frames one launch covers (1 on the per-frame paths, F in the batch)
@@ -1138,7 +1173,9 @@ def main():
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                         "issue": pmc_issue(dom, tag_cfg),
                         "avg_us": kernels[dom]["avg_us"], "frames_per_launch": kernels[dom]["frames_per_launch"],
-                        "alg_bytes_per_launch": int(kernels[dom]["alg_MB_per_launch"] * 1e6)}
+                        "alg_bytes_per_launch": int(kernels[dom]["alg_MB_per_launch"] * 1e6),
+                        "pairs_priced": ("the reference's (tile, Gaussian) pairs per frame (bounding squares: SURVEY 8d's unit), "
+                                         f"{M}; the kernel walks {M_walked} (reach masks)") if ref_lists else None}
             is_bwd = lambda k: k.endswith("_bwd") or k == "pair_reduce"
             fwd_ms = sum(kernels[k]["us_per_frame"] for k in kernels if not is_bwd(k) and k != "adam_step") / 1e3
             bwd_ms = sum(kernels[k]["us_per_frame"] for k in kernels if is_bwd(k)) / 1e3
@@ -1166,8 +1203,9 @@ def main():
 
     if stats is not None:
         stats["scene"] = a.scene
+        stats["reference_lists"] = ref_lists
     if roofline is not None and stats is not None:
-        comp = compute_rates(stats, kernels)
+        comp = compute_rates(dict(stats, walked_entries_per_frame=(ref_lists or stats)["walked_entries_per_frame"]), kernels)
         roofline["compute"] = comp
         dom = roofline["kernel"]
         if dom in comp:
@@ -1301,7 +1339,8 @@ def main():
                                    + ("SH deg 3 -> RGB" if R.use_sh else f"{a.channels} feature channels")
                                    + (", Adam step on the flat parameter buffer" if R.opt is not None else ""),
                        "gaussians": a.gaussians, "width": a.width, "height": a.height, "frames_per_rank_per_step": a.frames,
-                       "tile_pairs_M": M, "channels": R.C, "parallelism": par,
+                       "tile_pairs_M": M_walked, "tile_pairs_M_reference": (ref_lists or {}).get("max_pairs_per_frame"),
+                       "channels": R.C, "parallelism": par,
                        "schedule": schedule and (schedule + " (the fastest of the exact schedules timed in this run; the others: "
                                                  "comm.synchronous / comm.overlap_exact / comm.zero1)"),
                        "gaussian_order": "random" if a.no_spatial_order else "morton (densify.spatial_order at setup)",
