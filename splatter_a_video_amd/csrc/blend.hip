@@ -1892,7 +1892,11 @@ struct QuarterCfg {
     static_assert(CH <= 3 && Rec<CH>::RQ == 4 && Rec<CH>::CULL >= 11, "floats 11-15 of the record (cull parameters) are free for the coefficients");
     static constexpr int SB = BLEND_Q_SB, CAP = BLEND_Q_CAP;
     static constexpr int NG = GradLayout<ABS, false>::NG, NC = NG + CH, NCP = PAIR_STRIDE(NC);
-    static constexpr int RW = 16;   // slab row: [M0 Mx My Mxx | Mxy Myy ax ay | f0 f1 f2 . of lane groups 0 + 2 | of lane groups 1 + 3]
+    // slab row.  ABS: [M0 Mx My Mxx | Mxy Myy ax ay | f0 f1 f2 . of lane groups 0 + 2 | of lane groups 1 + 3], two float4 per lane
+    // group 0 / 1.  Without the abs taps (round 6): 12 floats, THREE per lane group -- [M0 Mx My | Mxx Mxy Myy | f of groups 0 + 2 | f
+    // of groups 1 + 3] (the moment operand's rows are ordered 1 x y . xx xy yy . for it) -- one 12-byte read-add-write per lane and
+    // step, and 80 rows per wave fit the 40 KB of FOUR workgroups per CU (16-float rows: 45 KB = three; 130 -> 112 us per frame)
+    static constexpr int RW = ABS ? 16 : 12;
     static constexpr int PW = 8;    // pixel row: [g0 g1 g2 . | . ncontrib T_state R_state]
 };
 
@@ -1936,8 +1940,13 @@ blend_bwd_quarter_kernel(const BlendArgs B) {
         const int q = 16 * Gs + 4 * kk + is;
         const float x = (float)qx(q) - 3.5f, y = (float)qy(q) - 3.5f;
         float v = 0.f;
-        if (nl < 4) v = nl == 0 ? 1.f : nl == 1 ? x : nl == 2 ? y : x * x;
-        else if (nl < 6) v = nl == 4 ? x * y : y * y;
+        if (ABS) {
+            if (nl < 4) v = nl == 0 ? 1.f : nl == 1 ? x : nl == 2 ? y : x * x;
+            else if (nl < 6) v = nl == 4 ? x * y : y * y;
+        } else {   // rows 0-2 = 1 x y, rows 4-6 = xx xy yy: three sums per lane group (see QuarterCfg::RW)
+            if (nl < 3) v = nl == 0 ? 1.f : nl == 1 ? x : y;
+            else if (nl >= 4 && nl < 7) v = nl == 4 ? x * x : nl == 5 ? x * y : y * y;
+        }
         if (nl < 8) s_mom[32 * st + 8 * kk + nl] = v;
     }
     float phi1[4], phi2[4];
@@ -2194,7 +2203,16 @@ blend_bwd_quarter_kernel(const BlendArgs B) {
                         const u32x2_b r = __builtin_amdgcn_permlane32_swap(__float_as_uint(dfv[c]), __float_as_uint(dfv[c]), false, false);
                         fs[c] = __uint_as_float(r[0]) + __uint_as_float(r[1]);   // own + the value of lane ^ 32, in every lane
                     }
-                    if (kk < 2 && j0 + nl < cq[G]) {   // lane group kk: floats 4 kk .. of the moments, 8 + 4 kk .. of the features
+                    if (!ABS) {
+                        if (j0 + nl < cq[G]) {   // lane groups 0 / 1: their three moments; 2 / 3: the pooled feature sums (own + lane ^ 32)
+                            F3 *r3 = reinterpret_cast<F3 *>(slab + row * RW + 3 * kk);
+                            F3 v3 = *r3;
+                            v3.x += kk < 2 ? d_mom[0] : fs[0];
+                            v3.y += kk < 2 ? d_mom[1] : fs[1];
+                            v3.z += kk < 2 ? d_mom[2] : fs[2];
+                            *r3 = v3;
+                        }
+                    } else if (kk < 2 && j0 + nl < cq[G]) {   // lane group kk: floats 4 kk .. of the moments, 8 + 4 kk .. of the features
                         float4 *rm = reinterpret_cast<float4 *>(slab + row * RW + 4 * kk), *rf = rm + 2;
                         float4 m4 = *rm, f4 = *rf;
                         m4.x += d_mom[0]; m4.y += d_mom[1];
@@ -2223,7 +2241,16 @@ blend_bwd_quarter_kernel(const BlendArgs B) {
                 for (int ww = 0; ww < 4; ++ww) {
                     const unsigned int pp = umin_(((p4 >> (8 * ww)) & 0xffu) - (unsigned)p0, (unsigned)CAP);
                     const float4 *rw = reinterpret_cast<const float4 *>(s_acc[ww] + pp * RW);
-                    const float4 m = rw[0], m2 = rw[1], fa = rw[2], fb = rw[3];
+                    float4 m, m2, fa, fb;
+                    if (ABS) {
+                        m = rw[0]; m2 = rw[1]; fa = rw[2]; fb = rw[3];
+                    } else {   // [M0 Mx My Mxx | Mxy Myy fA0 fA1 | fA2 fB0 fB1 fB2]
+                        const float4 r1 = rw[1], r2 = rw[2];
+                        m = rw[0];
+                        m2 = make_float4(r1.x, r1.y, 0.f, 0.f);
+                        fa = make_float4(r1.z, r1.w, r2.x, 0.f);
+                        fb = make_float4(r2.y, r2.z, r2.w, 0.f);
+                    }
                     // wave ww's moments are about its block centre (bxw, byw) = (-4 | 4, -4 | 4) from the tile centre:
                     // X = x + bxw, Y = y + byw
                     const float bxw = (ww & 1) ? 4.f : -4.f, byw = (ww >> 1) ? 4.f : -4.f;
