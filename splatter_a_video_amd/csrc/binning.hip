@@ -765,7 +765,12 @@ tile_sort_kernel(int T, int *__restrict__ tile_range, long long capacity, unsign
     if (n <= 0) return;
     unsigned long long *g = keys + r0;
     // low key word: Gaussian id, or (pair-map mode) the pair slot whose owner is the Gaussian id
-    if (n <= 4 * SORT_BLOCK) {
+#ifndef SORT_R2
+#define SORT_R2 1   // tiles of at most 512 keys: two keys per thread (45 stages, all four waves live) instead of four (55 stages, two waves live)
+#endif
+    if (SORT_R2 && n <= 2 * SORT_BLOCK) {
+        tile_sort_regs<2>(g, n, r0, pk, idx_sorted, slot_sorted, sk);
+    } else if (n <= 4 * SORT_BLOCK) {
         tile_sort_regs<4>(g, n, r0, pk, idx_sorted, slot_sorted, sk);
     } else if (n <= 8 * SORT_BLOCK) {
         tile_sort_regs<8>(g, n, r0, pk, idx_sorted, slot_sorted, sk);

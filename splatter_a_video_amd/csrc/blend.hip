@@ -3107,7 +3107,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
 #endif
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
-            for (int j0 = 0; j0 < cq[G]; j0 += 16) {
+            for (int j0 = 0; j0 < ((BLEND_QABL & 4) ? 0 : cq[G]); j0 += 16) {   // (BLEND_QABL 4: timing ablation, no steps)
 #if BLEND_SETS_LE_AHEAD
                 const unsigned le = le_next;
                 {
