@@ -790,7 +790,10 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
     from splatter_a_video_amd import train_step as TS
     from splatter_a_video_amd.dynamics import FrameClock
     clock = FrameClock(sc.F)
-    truth = TS.synthetic_video_params(sc, clock, dev, attrs=16)
+    # the detached set = track_gs (3 channels) + the model's attributes: --attr-channels 19 (default) = 16 attributes, the renderer's
+    # own plan; --attr-channels 7 / 4 = the trainer's ['dino_attribute'] / ['mask_attribute'] rows behind track_gs (4 / 1 attributes)
+    n_attrs = max(1, int(a.attr_channels) - 3)
+    truth = TS.synthetic_video_params(sc, clock, dev, attrs=n_attrs)
     extr = torch.tensor(sc.extr, device=dev)
     t1 = list(frames)
     t2 = [int((17 * t + 11) % sc.F) for t in t1]
@@ -896,9 +899,10 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
         "config": {"workload": f"{sc.N} dynamic Gaussians of the reference's model, {F} frame pairs/rank/step of a {sc.F}-frame "
                                f"{sc.W}x{sc.H} clip: SH deg 3 colours, position(ids1) + position(ids2), K = 5 neighbours of 512 "
                                "sampled vertices + ARAP per pair, render_iter's three blends (rgb enhanced K=20 with taps | depth | "
-                               "track_gs + 16 attribute channels, opacity detached), L1 on the three images, backward, "
+                               f"track_gs + {n_attrs} attribute channels, opacity detached), L1 on the three images, backward, "
                                "all-reduce, Adam on the flat buffer, densification statistics",
-                   "equivalent_flags": "--train-step" + (" --owner-sharded" if a.owner_sharded else "") + (" --zero1" if a.zero1 else ""),
+                   "equivalent_flags": "--train-step" + (" --owner-sharded" if a.owner_sharded else "") + (" --zero1" if a.zero1 else "")
+                                       + ("" if a.attr_channels == 19 else f" --attr-channels {a.attr_channels}"),
                    "tile_pairs_M": pairs_M, "grad_bucket_MB": bucket_MB, "optimizer": opt_desc,
                    "adam_moments_MB_per_rank": moments_MB},
         "zero1": zero1}

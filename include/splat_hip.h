@@ -602,7 +602,9 @@ int splat_alpha_blending_backward_batch_sets(int F, int P, int C, const int32_t 
    plan (rgb at row channels 0-2 with the taps, depth at channel 3, 19 attributes blended with opacity.detach() at channels
    4-22: dptr_ortho_enhanced.py:331-375) with the forward's cull words the tile kernel stages those records directly and no
    packing launch runs; any other plan, or forward_pack = NULL, behaves like splat_alpha_blending_backward_batch_sets
-   (pack_scratch is still required then). */
+   (pack_scratch is still required then).  Round 6: with forward_pack given, `feature` NULL and a NULL set_feature pointer of a
+   set that has channels (a row described by feature SOURCES: no tensor per set exists), the packing launch of such a plan takes
+   the row's channels out of the forward's records -- every one-pass plan serves feature lists / per-frame tensors. */
 int splat_alpha_blending_backward_batch_sets_packed(int F, int P, int C, const int32_t *set_c0, const int32_t *set_cn,
                                                     const float *set_bg, const float *uv, const float *conic,
                                                     const float *opacity, int64_t opacity_frame_stride,

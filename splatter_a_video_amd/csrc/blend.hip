@@ -160,6 +160,8 @@ struct BlendArgs {
     long long cap;          // pair capacity per frame: stride of idx_sorted / slot_sorted / pair_buf records
     long long pack_fs;      // floats between two frames' packed records
     long long opacity_fs, feature_fs, bias_fs;  // element strides of the per-Gaussian inputs (0: shared by all frames)
+    int feature_row;        // pack_sets_kernel: floats between two Gaussians' rows of `feature` (0: C -- a dense [P, C] row; the forward's
+                            // packed records serve as the row with their record stride)
     // several feature sets in one backward pass (blend_bwd_sets_kernel): first row channel, width and background of the
     // tap set (0), the second set (1) and the opacity-detached set (2); width 0 = no such set
     int s0c0, s0cn, s1c0, s1cn, s2c0, s2cn;
@@ -2349,7 +2351,7 @@ pack_sets_kernel(const BlendArgs B) {
         r[5] = A.opacity[i];
         r[7] = __int_as_float(i);
         if (A.feature) {
-            const float *f = A.feature + (size_t)i * A.C;
+            const float *f = A.feature + (size_t)i * (A.feature_row ? A.feature_row : A.C);
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 const int c = sets_slot_channel(A, k);
@@ -4498,9 +4500,19 @@ static int backward_batch_sets_impl(int F, int P, int C, const int32_t *set_c0, 
     if (!feature) {
         A.sf0 = set_feature[0]; A.sf1 = set_feature[1]; A.sf2 = set_feature[2];
         A.sfs0 = set_feature_fs[0]; A.sfs1 = set_feature_fs[1]; A.sfs2 = set_feature_fs[2];
+        const bool have_sets = (!set_cn[0] || A.sf0) && (!set_cn[1] || A.sf1) && (!set_cn[2] || A.sf2);
         // (the forward's packed records carry the row: the sets' own tensors are not read, e.g. a row described by sources)
-        SPLAT_CHECK_ARG(from_forward || ((!set_cn[0] || A.sf0) && (!set_cn[1] || A.sf1) && (!set_cn[2] || A.sf2)),
-                        "null set feature pointer");
+        SPLAT_CHECK_ARG(from_forward || have_sets || forward_pack, "null set feature pointer");
+        if (!from_forward && !have_sets) {
+            // a row described by SOURCES under a plan the tile kernel does not stage from the forward's records: the packing
+            // launch reads the row's channels out of those records ([u v A B | C o . id | channels 0 .. C-1 | pad], one per
+            // Gaussian and frame) -- any one-pass plan serves feature lists and per-frame tensors (round 6)
+            const int rsf = (int)splat_blend_pack_floats(C);
+            A.feature = forward_pack + 8;
+            A.feature_fs = (long long)P * rsf;
+            A.feature_row = rsf;
+            A.sf0 = A.sf1 = A.sf2 = nullptr;
+        }
     }
     if (!dL_dout) {
         A.sdl0 = set_dL[0]; A.sdl1 = set_dL[1]; A.sdl2 = set_dL[2];

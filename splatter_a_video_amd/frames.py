@@ -421,7 +421,8 @@ class FrameBatch:
         from frame to frame; a strided view with dense rows is read in place): no ``[F, P, C]`` row is materialised, a shared
         tensor's gradient is the sum over the frames, a per-frame tensor gets every frame's own.  ``grad_sink["feature:k"]``
         (k = position of the tensor in the flattened list of all sets' tensors) receives that gradient by ADDITION instead of
-        autograd.  Lists / per-frame tensors need the renderer's own plan (rgb 3 | depth 1 | 19 attribute channels)."""
+        autograd.  Any one-pass plan takes lists / per-frame tensors: the renderer's own plan (rgb 3 | depth 1 | 19 attribute
+        channels) stages the forward's records in the tile kernel, other plans repack them in one launch."""
         tab = self.frame_table(clock, times)
         meta, parts, feats = _parse_sets(sets, self.F, self.P)
         widths = [1 if m[0] == "depth" else m[0] for m in meta]
@@ -431,9 +432,6 @@ class FrameBatch:
         if plan is None:
             raise ValueError("render_dynamic_sets needs sets that fit the one-pass backward: one set per routing group "
                              "(taps / live opacity / detached opacity) of at most 4 / 4 / 20 channels")
-        if _has_sources(parts) and not _uses_forward_pack(plan, self.C):
-            raise ValueError("feature lists / per-frame feature tensors need the renderer's own plan: a tap set of 3 channels, the "
-                             "depth, 19 channels blended with opacity.detach() (the plan whose backward stages the forward's records)")
         fsink = {k: v for k, v in (grad_sink or {}).items() if k.startswith("feature:")}
         psink = {k: v for k, v in (grad_sink or {}).items() if not k.startswith("feature:")}
         sink = check_sink(psink, {"position": position, "pos_cubic_node": pos_cubic_node, "rotation": rotation,
@@ -850,7 +848,7 @@ def _blend_sets_backward_one_pass(fb, meta, state, grads, opacity, op_fs, want_a
             ctypes.c_int64(op_fs), tabs["feat"], tabs["fs"], L.ptr(fb.idx_sorted), L.ptr(fb.tile_range), ctypes.c_int64(cap),
             L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(row), (ctypes.c_void_p * 3)(*dl),
             (ctypes.c_float * 3)(*scale), L.ptr(sums), L.ci(want_abs), L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack),
-            L.ptr(fb.cull_flags), L.ptr(_debug_T_front(F * H, W, fb.dev)), L.ptr(fb.pack if std else None), st))
+            L.ptr(fb.cull_flags), L.ptr(_debug_T_front(F * H, W, fb.dev)), L.ptr(fb.pack if (std or tens is None) else None), st))
         # the slab order of the three groups: (tap set, second set, detached set) -> set index of the caller's list
         l1["group_of_set"] = list(groups)
         return rec
@@ -863,7 +861,8 @@ def _blend_sets_backward_one_pass(fb, meta, state, grads, opacity, op_fs, want_a
     from .gs.raster_ops import _debug_T_front
     rec = fb._set_buffer(("rec", "sets"), F * cap * int(lib.splat_blend_sets_pair_stride(C)))
     # the renderer's own plan (rgb 0-2 with the taps | depth 3 | 19 detached attributes 4-22): the tile kernel stages the records
-    # the FORWARD packed (fb.pack) -- no packing launch, no second record array; other plans pack their own
+    # the FORWARD packed (fb.pack) -- no packing launch, no second record array; other plans pack their own (a row described by
+    # sources -- tens is None -- out of the forward's records, which hold the row's channels)
     std = state["std"] if "std" in state else _uses_forward_pack(plan, C)     # decided at forward time
     pack = None if std else fb._set_buffer(("pack", "sets"), F * P * int(lib.splat_blend_sets_pack_floats()))
     L.check(lib.splat_alpha_blending_backward_batch_sets_packed(
@@ -871,7 +870,7 @@ def _blend_sets_backward_one_pass(fb, meta, state, grads, opacity, op_fs, want_a
         ctypes.c_int64(op_fs), L.ptr(None), ctypes.c_int64(0), tabs["feat"], tabs["fs"], L.ptr(fb.idx_sorted),
         L.ptr(fb.tile_range), ctypes.c_int64(cap), L.ci(W), L.ci(H), L.ptr(fb.final_T), L.ptr(fb.ncontrib), L.ptr(None),
         (ctypes.c_void_p * 3)(*dl), L.ci(want_abs), L.ptr(fb.slot_sorted), L.ptr(rec), L.ptr(pack), L.ptr(fb.cull_flags),
-        L.ptr(_debug_T_front(F * H, W, fb.dev)), L.ptr(fb.pack if std else None), st))
+        L.ptr(_debug_T_front(F * H, W, fb.dev)), L.ptr(fb.pack if (std or tens is None) else None), st))
     return rec
 
 

@@ -163,10 +163,14 @@ def _track_frames(o, clock, times1, times2, host, rgb, attrs, extr, W, H, grads,
     return per, tot
 
 
-def test_training_frame_with_track_gs_against_oracle(oracle_mod):
+@pytest.mark.parametrize("A", [16, 4, 1])
+def test_training_frame_with_track_gs_against_oracle(oracle_mod, A):
     """render_dynamic_sets with the attribute set given as SOURCES [track_gs = position(ids2) per frame | shared attributes], on
     the reference-made dynamic parameters: images, gs_idx and every gradient -- the per-frame gradient of track_gs continued
-    through splat_dynamic_positions_batch_backward into the spline segments of the pair frames -- against the oracle chain."""
+    through splat_dynamic_positions_batch_backward into the spline segments of the pair frames -- against the oracle chain.
+    A = 16: the renderer's own plan (3 | 1 | 19: the tile kernel stages the forward's records); A = 4 / 1: the trainer's
+    ['dino_attribute'] / ['mask_attribute'] rows (src/trainer_fragGS.py:657,1214) -- the packing launch takes the row out of the
+    forward's records, the SMALL instantiation of the three-set backward runs."""
     g = dict(np.load(os.path.join(GOLD, "dynamic_400x50.npz")))
     clock = FrameClock(int(g["T"]), g["intervals"], int(g["start_frame_id"]), int(g["time_len"]))
     I = clock.interval_num
@@ -180,15 +184,15 @@ def test_training_frame_with_track_gs_against_oracle(oracle_mod):
     host["scaling"] = host["scaling"] + 2.0
     rng = np.random.default_rng(8)
     rgb = rng.uniform(size=(N, 3)).astype(np.float32)
-    attrs = rng.uniform(-1, 1, size=(N, 16)).astype(np.float32)
-    gs_ = [rng.normal(size=(F, c, H, W)).astype(np.float32) for c in (3, 1, 19)]
+    attrs = rng.uniform(-1, 1, size=(N, A)).astype(np.float32)
+    gs_ = [rng.normal(size=(F, c, H, W)).astype(np.float32) for c in (3, 1, 3 + A)]
     p = {k: _t(v, k not in ("rot_poly_feat", "rot_fourier_feat", "position")) for k, v in host.items()}
     p["pos_cubic_node"] = to_segment_major(_t(host["pos_cubic_node"]), I).requires_grad_(True)
     t_rgb, t_att = _t(rgb, True), _t(attrs, True)
     # the pairs' positions: [F, 2, N, 3] = (position(ids1), position(ids2)); track_gs is the strided view [:, 1]
     inter = [t for pr in zip(times1, times2) for t in pr]
     pairs = positions_batch(clock, inter, p["position"], p["pos_cubic_node"], cubic_layout=SEGMENT_MAJOR).view(F, 2, N, 3)
-    B = FrameBatch(F, N, W, H, 23, "cuda", want_abs=True)
+    B = FrameBatch(F, N, W, H, 7 + A, "cuda", want_abs=True)
     sets = [dict(feature=t_rgb, bg=0.2, taps=True), dict(feature="depth", bg=1.0),
             dict(feature=[pairs[:, 1], t_att], bg=0.0, detach_opacity=True)]
     o_rgb, o_dep, o_att, ids = B.render_dynamic_sets(
@@ -239,19 +243,29 @@ def test_training_frame_with_track_gs_against_oracle(oracle_mod):
     assert float(g_pairs[:, 0].abs().max()) == 0.0 and float(g_pairs[:, 1].abs().max()) > 0.0
 
 
-def test_feature_sources_need_the_renderers_plan():
-    N, W, H, F = 500, 64, 48, 2
-    sc = make_scene(N, W, H, F=10, seed=2)
-    clock = FrameClock(10)
-    prm = TS.synthetic_video_params(sc, clock, "cuda", attrs=4)
-    B = FrameBatch(F, N, W, H, 3 + 1 + 3 + 4, "cuda")
-    track = torch.zeros(F, N, 3, device="cuda")
-    sets = [dict(feature=torch.rand(N, 3, device="cuda"), taps=True), dict(feature="depth", bg=1.0),
-            dict(feature=[track, prm["attrs"]], detach_opacity=True)]
-    with pytest.raises(ValueError, match="renderer's own plan"):
-        B.render_dynamic_sets(clock, [0, 1], _t(sc.extr), sets, position=prm["position"], pos_cubic_node=prm["pos_cubic_node"],
-                              rotation=prm["rotation"], rot_poly_feat=prm["rot_poly_feat"], rot_fourier_feat=prm["rot_fourier_feat"],
-                              opacity=prm["opacity"], scaling=prm["scaling"], cubic_layout=GAUSSIAN_MAJOR)
+@pytest.mark.parametrize("A", [4, 1])
+def test_training_step_with_the_trainers_small_attribute_rows(A):
+    """TrainingStep for the trainer's other plans (attrs [N, 4] / [N, 1] behind track_gs: 11 / 8 composited channels): feature
+    lists / per-frame sources under a plan whose backward repacks the forward's records (round 6; A = 16 was the only width
+    before).  A few steps on a small clip: finite, the loss falls, gradients reach every parameter group."""
+    Nn, Ww, Hh, T, F = 2500, 128, 96, 20, 3
+    sc = make_scene(Nn, Ww, Hh, F=T, seed=11, sigma_px=3.0)
+    clock = FrameClock(T)
+    truth = TS.synthetic_video_params(sc, clock, "cuda", attrs=A, seed=12, cubic_sigma=0.01)
+    extr = _t(sc.extr)
+    lr = dict(TS.REFERENCE_LR, pos_cubic_node=2e-3, shs=2e-2, attrs=2e-2, scaling=1e-2, rotation=5e-3)
+    st = TS.TrainingStep(_perturbed(truth, 1), clock, Ww, Hh, F, extr, lr=lr, K=8, arap_samples=128, sample_seed=3)
+    t1, t2 = [0, 7, 13], [4, 2, 19]
+    gt = TS.render_ground_truth(truth, clock, Ww, Hh, extr, t1, t2)
+    before = {k: v.detach().clone() for k, v in st.p.items()}
+    losses = []
+    for _ in range(12):
+        st.step(t1, t2, gt)
+        losses.append(st.loss())
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    for k in TS.TRAINABLE:
+        assert torch.isfinite(st.p[k]).all() and not torch.equal(st.p[k], before[k]), k
 
 
 # ---------------------------------------------------------------------------------------------------------------------
