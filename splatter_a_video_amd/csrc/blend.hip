@@ -40,6 +40,9 @@
 #define BLEND_FWD_U 2      // survivors evaluated per trip in the forward (narrow channel counts).  Round 6: 4 -> 2 (the quarter lists of a
                            // wave are padded to a multiple of U: with the denser lists of the reach masks 46.4 -> 44.9 us per frame)
 #endif
+#ifndef BLEND_FWD_QDONE
+#define BLEND_FWD_QDONE 1      // forward: a 4x4 quarter whose pixels are all saturated keeps no further entries (its block's may go on)
+#endif
 #ifndef BLEND_FWD_TRIPTEST
 #define BLEND_FWD_TRIPTEST 0   // forward: skip a trip's compositing when no lane of the wave has a splat to apply (see the kernel)
 #endif
@@ -479,7 +482,7 @@ struct Stager {
 #endif
 template <int CH, int SB, bool BIAS, bool SUB, bool COEF, int XR, bool SWZ, int RQL, int CS, typename Pred>
 __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ, RQL, CS> &L, int tid, int nb, float tx0, float ty0, Pred pred,
-                                          unsigned int *gflags = nullptr) {
+                                          unsigned int *gflags = nullptr, const int *qdone = nullptr) {
     constexpr int TPE = 256 / SB;  // threads per entry (1, 2 or 4): each tests 4 / TPE of the blocks
     constexpr int BPT = 4 / TPE;
     static_assert(SB == 64 || SB == 128 || SB == 256, "super-batch sizes the 256-thread cull supports");
@@ -556,7 +559,8 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ, RQL, CS
                             }
                         }
                     }
-                    k[j] = m;
+                    // qdone[ww]: the quarters of block ww whose 16 pixels are all finished (forward: saturated) keep nothing
+                    k[j] = qdone ? (m & ~(unsigned)qdone[ww]) : m;
                 } else {
                     k[j] = kb ? 1u : 0u;
                 }
@@ -754,17 +758,31 @@ blend_fwd_kernel(const BlendArgs B) {
     st.load_ids(A, tid, range.x, pos, 1);
 
     for (int base = 0, batch = 0; base < n; base += SB, ++batch) {
-        const bool alld = __all(T < 0.f);
-        if (lane == 0) s_done[w] = alld;
+        // quarters of the wave's block whose 16 pixels are all finished (bit q; 15 = the whole block): their lists end here -- a
+        // quarter saturates before its block does, and the backward gets the shorter lists through the cull words
+        unsigned qd;
+        {
+            const unsigned long long dm = __ballot(T < 0.f);
+            if (MF) {   // DPP row q = quarter q
+                qd = ((dm & 0xffffull) == 0xffffull ? 1u : 0u) | (((dm >> 16) & 0xffffull) == 0xffffull ? 2u : 0u) |
+                     (((dm >> 32) & 0xffffull) == 0xffffull ? 4u : 0u) | ((dm >> 48) == 0xffffull ? 8u : 0u);
+            } else {    // lane = 8 y + x: quarter (x >> 2) + 2 (y >> 2)
+                constexpr unsigned long long Q0 = 0x000000000F0F0F0Full, Q1 = 0x00000000F0F0F0F0ull;
+                qd = ((dm & Q0) == Q0 ? 1u : 0u) | ((dm & Q1) == Q1 ? 2u : 0u) | ((dm & (Q0 << 32)) == (Q0 << 32) ? 4u : 0u) |
+                     ((dm & (Q1 << 32)) == (Q1 << 32) ? 8u : 0u);
+            }
+        }
+        const bool alld = qd == 15u;
+        if (lane == 0) s_done[w] = (int)qd;
         const int nb = imin_(SB, n - base);
         st.park(L, tid);
         st.load_payload(A, tid);                       // payload of the next super-batch
         st.load_ids(A, tid, range.x, pos, batch + 2);  // ids two ahead
         __syncthreads();
-        if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;  // every pixel of the tile is saturated
+        if ((s_done[0] & s_done[1] & s_done[2] & s_done[3]) == 15) break;  // every pixel of the tile is saturated
         // (the keep words also go to A.cull_flags: what the backward needs of this cull -- a saturated block keeps nothing)
-        tile_cull<CH, SB, BIAS, true, !BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE), [&](int, int ww) { return !s_done[ww]; },
-                                             A.cull_flags ? A.cull_flags + range.x + base : nullptr);
+        tile_cull<CH, SB, BIAS, true, !BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE), [&](int, int ww) { return s_done[ww] != 15; },
+                                             A.cull_flags ? A.cull_flags + range.x + base : nullptr, BLEND_FWD_QDONE ? s_done : nullptr);
         __syncthreads();
         if (!alld) {
             // one order-preserving survivor list per 4x4 quarter of the wave's block: the 16 lanes of a quarter walk
