@@ -480,9 +480,12 @@ struct Stager {
 #define BLEND_TANQ_GATE 0   // ... behind the exact test of the 8x8 block (1) or on their own (0: narrow forward 60.2 -> 54.9 us per frame,
                             // backward 130.7 -> 132.8 at c2: the block test cost the cull threads more than the 1.7 % of entries it removed)
 #endif
+__device__ __forceinline__ unsigned live_quarters(bool b) { return b ? 15u : 0u; }
+__device__ __forceinline__ unsigned live_quarters(unsigned m) { return m; }
+
 template <int CH, int SB, bool BIAS, bool SUB, bool COEF, int XR, bool SWZ, int RQL, int CS, typename Pred>
 __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ, RQL, CS> &L, int tid, int nb, float tx0, float ty0, Pred pred,
-                                          unsigned int *gflags = nullptr, const int *qdone = nullptr) {
+                                          unsigned int *gflags = nullptr) {
     constexpr int TPE = 256 / SB;  // threads per entry (1, 2 or 4): each tests 4 / TPE of the blocks
     constexpr int BPT = 4 / TPE;
     static_assert(SB == 64 || SB == 128 || SB == 256, "super-batch sizes the 256-thread cull supports");
@@ -520,7 +523,10 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ, RQL, CS
                 // tangent-plane quarters of the narrow rows (3.00 instead of 2.95 quarters per pair, tools/cull_model.py)
                 constexpr bool QEX = BLEND_EXACTQ == 2 || (BLEND_EXACTQ == 1 && CH >= 16);
                 constexpr bool GATE = !(SUB && (QEX || (BLEND_TANQ && CH < 16 && !BLEND_TANQ_GATE)));
-                const bool kb = pred(e, ww) && (!GATE || cull_test(a0.x, a0.y, a0.z, a0.w, a1.x, cp, x0, x0 + 7.f, y0, y0 + 7.f));
+                // pred: does block ww still need entry e?  bool, or (forward) the mask of its 4x4 quarters that do -- a quarter whose 16
+                // pixels are all saturated keeps nothing while the block's other quarters go on
+                const unsigned live = live_quarters(pred(e, ww));
+                const bool kb = live != 0u && (!GATE || cull_test(a0.x, a0.y, a0.z, a0.w, a1.x, cp, x0, x0 + 7.f, y0, y0 + 7.f));
                 if (SUB) {
                     unsigned m = 0u;
                     if (kb) {
@@ -559,8 +565,7 @@ __device__ __forceinline__ void tile_cull(TileLDS<CH, SB, COEF, XR, SWZ, RQL, CS
                             }
                         }
                     }
-                    // qdone[ww]: the quarters of block ww whose 16 pixels are all finished (forward: saturated) keep nothing
-                    k[j] = qdone ? (m & ~(unsigned)qdone[ww]) : m;
+                    k[j] = m & live;
                 } else {
                     k[j] = kb ? 1u : 0u;
                 }
@@ -781,8 +786,8 @@ blend_fwd_kernel(const BlendArgs B) {
         __syncthreads();
         if ((s_done[0] & s_done[1] & s_done[2] & s_done[3]) == 15) break;  // every pixel of the tile is saturated
         // (the keep words also go to A.cull_flags: what the backward needs of this cull -- a saturated block keeps nothing)
-        tile_cull<CH, SB, BIAS, true, !BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE), [&](int, int ww) { return s_done[ww] != 15; },
-                                             A.cull_flags ? A.cull_flags + range.x + base : nullptr, BLEND_FWD_QDONE ? s_done : nullptr);
+        tile_cull<CH, SB, BIAS, true, !BIAS>(L, tid, nb, (float)(tx * TILE), (float)(ty * TILE), [&](int, int ww) -> unsigned { return BLEND_FWD_QDONE ? 15u & ~(unsigned)s_done[ww] : (s_done[ww] != 15 ? 15u : 0u); },
+                                             A.cull_flags ? A.cull_flags + range.x + base : nullptr);
         __syncthreads();
         if (!alld) {
             // one order-preserving survivor list per 4x4 quarter of the wave's block: the 16 lanes of a quarter walk
