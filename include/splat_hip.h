@@ -388,8 +388,8 @@ int splat_bin_sort_batch(int F, int P, const float *uv, const float *depth, cons
  * (include/utils.h:17-37) and lets alpha_blending skip, per pixel, what stays below alpha = 1/255 (src/alpha_blending.cu:78-95);
  * a third of those pairs reaches no pixel of its tile.  With conic [F,P,3] and opacity ([P]: opacity_frame_stride 0, or [F,P]:
  * stride P) the count step keeps only the tiles whose rectangle of pixel centres the alpha >= 1/255 ellipse can touch (the
- * compositing kernels' own conservative test; rectangles of 32 tiles and more keep all) and leaves one word per Gaussian in
- * reach[F,P] for the sort step.  tile_range,
+ * compositing kernels' own conservative test; a rectangle of 32 tiles and more is tested in cells of c x c tiles, c the smallest
+ * power of two that leaves at most 31 cells) and leaves one word per Gaussian in reach[F,P] for the sort step.  tile_range,
  * M_out, gcount (optional, [F,P]), goff_incl and the pair slots count the KEPT pairs.  Images, ids and gradients composited
  * from the shorter lists are those of the full lists bit for bit; list positions (ncontrib) differ.  Not for callers that
  * return idx_sorted / tile_range as the reference's sort_gaussian result.  F = 1: a single frame. */

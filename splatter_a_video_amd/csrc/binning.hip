@@ -127,13 +127,33 @@ static BinPlan make_plan(int P, int W, int H, int F = 1) {
 // kernel, which runs the compositing kernels' own conservative test (cull_test, common.h) on the tile's rectangle of pixel
 // centres and leaves one word per Gaussian for the scatter kernel:
 //     bit 31 clear: bits 0 .. 30 = keep flags of the rectangle's tiles in row-major order (rectangles of at most 31 tiles);
-//     bit 31 set:   a larger rectangle (radius above ~35 px) keeps all its tiles; the low bits hold their count.
-// The scatter kernel only reads the word: the two kernels cannot disagree about a pair.  (A test repeated in the scatter kernel
-// through a shared non-inlined function served the large rectangles as well, but a device function call gives both kernels a
-// stack: single-frame launches 9.5 -> 40 us and 22 -> 45 us.)
+//     bit 31 set:   a larger rectangle (radius above ~35 px) is cut into CELLS of c x c tiles, c the smallest power of two that
+//                   leaves at most 31 cells (an integer function of the rectangle: reach_cell_shift); bits 0 .. 30 = keep flags of
+//                   the cells in row-major order -- a cell is tested as ONE rectangle of pixel centres and keeps or drops all its
+//                   tiles (a splat of any size is culled; the corner cells of a large elongated splat's square are most of it).
+// The scatter kernel only reads the word (and counts the kept tiles of a large rectangle from the word and the rectangle, in
+// integers): the two kernels cannot disagree about a pair.  (A test repeated in the scatter kernel through a shared non-inlined
+// function was the first form for large rectangles, but a device function call gives both kernels a stack: single-frame launches
+// 9.5 -> 40 us and 22 -> 45 us.)
 // A dropped pair holds no pixel with alpha >= 1/255, so images, ids and gradients are those of the full list bit for bit; only
 // list positions (ncontrib) and M change.
 #define REACH_BIG 0x80000000u
+// log2 of the cell edge (in tiles) of a large rectangle of w x h tiles: the smallest cell that leaves at most 31 cells
+__device__ __forceinline__ int reach_cell_shift(int w, int h) {
+    int sh = 1;
+    while ((((w - 1) >> sh) + 1) * (((h - 1) >> sh) + 1) > 31) ++sh;
+    return sh;
+}
+// kept tiles of a large rectangle: the clipped areas of the cells whose bit is set
+__device__ __forceinline__ int reach_big_count(unsigned word, int w, int h) {
+    const int sh = reach_cell_shift(w, h), c = 1 << sh, ncx = ((w - 1) >> sh) + 1, ncy = ((h - 1) >> sh) + 1;
+    int n = 0;
+    unsigned bit = 1u;
+    for (int cy = 0; cy < ncy; ++cy)
+        for (int cx = 0; cx < ncx; ++cx, bit <<= 1)
+            if (word & bit) n += imin_(c, w - cx * c) * imin_(c, h - cy * c);
+    return n;
+}
 
 // ------------------------------------------------------------------ K1
 template <bool LDS>
@@ -186,14 +206,26 @@ bin_count_kernel(int P, const float2 *__restrict__ uv, const int *__restrict__ r
                     }
                 kept = __popc(m);
                 word = m;
-            } else {   // a large rectangle keeps every tile
-                for (int ty = y0; ty < y1; ++ty)
-                    for (int tx = x0; tx < x1; ++tx) {
-                        if (LDS) atomicAdd(&cnt[ty * gx + tx], 1);
-                        else atomicAdd(&matrix[ty * gx + tx], 1);
+            } else {   // a large rectangle: cells of c x c tiles, each tested as one rectangle of pixel centres
+                const CullP cp = cull_params(cA, cB, cC, o);
+                const int w = x1 - x0, h = y1 - y0, sh = reach_cell_shift(w, h), c = 1 << sh;
+                const int ncx = ((w - 1) >> sh) + 1, ncy = ((h - 1) >> sh) + 1;
+                unsigned m = 0u, bit = 1u;
+                for (int cy = 0; cy < ncy; ++cy)
+                    for (int cx = 0; cx < ncx; ++cx, bit <<= 1) {
+                        const int tx0 = x0 + cx * c, ty0 = y0 + cy * c, tx1 = imin_(x1, tx0 + c), ty1 = imin_(y1, ty0 + c);
+                        if (cull_test(q.x, q.y, cA, cB, cC, cp, (float)(tx0 * TILE), (float)(tx1 * TILE - 1), (float)(ty0 * TILE),
+                                      (float)(ty1 * TILE - 1))) {
+                            m |= bit;
+                            kept += (tx1 - tx0) * (ty1 - ty0);
+                            for (int ty = ty0; ty < ty1; ++ty)
+                                for (int tx = tx0; tx < tx1; ++tx) {
+                                    if (LDS) atomicAdd(&cnt[ty * gx + tx], 1);
+                                    else atomicAdd(&matrix[ty * gx + tx], 1);
+                                }
+                        }
                     }
-                kept = area;
-                word = REACH_BIG | (unsigned)area;
+                word = REACH_BIG | m;
             }
             reach[i] = word;
             if (gcount) gcount[i] = kept;
@@ -375,7 +407,7 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
         const bool big = (rw & REACH_BIG) != 0u;
         int j = 0;
         if (goff_incl) {
-            const int area = !reach ? (x1 - x0) * (y1 - y0) : big ? (int)(rw & ~REACH_BIG) : __popc(rw);
+            const int area = !reach ? (x1 - x0) * (y1 - y0) : big ? reach_big_count(rw, x1 - x0, y1 - y0) : __popc(rw);
             const int inc = wave_incl_scan_i(area, lane);
             if (lane == 63) wave_pairs[w] = inc;
             __syncthreads();
@@ -395,8 +427,10 @@ bin_scatter_kernel(int P, const float2 *__restrict__ uv, const float *__restrict
         if (r <= 0) continue;
         const unsigned long long dkey = (unsigned long long)__float_as_uint(depth[i]) << 32;
         unsigned bit = 1u;
-        auto kept = [&](int, int) -> bool {   // (k of the packed keys and the slots count the KEPT tiles)
-            if (!reach || big) return true;
+        const int csh = big ? reach_cell_shift(x1 - x0, y1 - y0) : 0, cnx = big ? ((x1 - x0 - 1) >> csh) + 1 : 0;
+        auto kept = [&](int tx, int ty) -> bool {   // (k of the packed keys and the slots count the KEPT tiles, in row-major order)
+            if (!reach) return true;
+            if (big) return ((rw >> (((ty - y0) >> csh) * cnx + ((tx - x0) >> csh))) & 1u) != 0u;   // the tile's cell
             const bool k = (rw & bit) != 0u;
             bit <<= 1;
             return k;

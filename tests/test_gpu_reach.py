@@ -38,9 +38,11 @@ def _render(sc, F, C, feat, g, reach, big=False):
 def _scene(N, W, H, kind):
     sc = make_scene(N, W, H, seed=N + 17)
     rng = np.random.default_rng(N)
-    if kind == "big":          # a few splats whose rectangle holds 32 tiles and more: the count-word form of the reach word
-        k = rng.choice(N, 40, replace=False)
+    if kind == "big":          # splats whose rectangle holds 32 tiles and more (up to the whole image): the cell form of the reach word
+        k = rng.choice(N, 60, replace=False)
         sc.scale[k] *= 12.0
+        sc.scale[k[:20], 0] *= 4.0          # elongated: most of the bounding square is empty
+        sc.scale[k[40:]] *= 4.0             # cells of 4 x 4 / 8 x 8 tiles
         sc.opacity[k[:10]] = 0.9
     if kind == "faint":        # below 1/255 a splat contributes nowhere: no pair at all
         sc.opacity[: N // 2] = 0.0035
@@ -65,8 +67,10 @@ def test_reach_masks_change_no_bit_of_the_images(kind, N, W, H, C):
     assert mr < mf
     if kind == "big":
         area = (Bf.goff[0].long() - torch.cat([Bf.goff[0, :1] * 0, Bf.goff[0, :-1]]).long())
-        assert int(area.max()) >= 32                      # rectangles of 32 tiles and more keep every tile:
-        assert int((Br.reach[0] < 0).sum()) > 0           # the count form of the reach word (bit 31 set) was exercised
+        kept = (Br.goff[0].long() - torch.cat([Br.goff[0, :1] * 0, Br.goff[0, :-1]]).long())
+        big = area >= 32
+        assert int(area.max()) >= 32 and int((Br.reach[0] < 0).sum()) > 0     # rectangles of 32 tiles and more: the CELL form of the
+        assert bool((kept <= area).all()) and int((kept[big] < area[big]).sum()) > 0   # reach word (bit 31) -- and it culls
     if kind == "faint":
         kept = Br.goff[0].long() - torch.cat([Br.goff[0, :1] * 0, Br.goff[0, :-1]]).long()
         assert int(kept[: N // 2].sum()) == 0
@@ -84,6 +88,8 @@ def test_reach_entry_points_raw():
     kept pair list is a sub-list of the full one in the same order"""
     N, W, H = 5000, 160, 96
     sc = make_scene(N, W, H, seed=3)
+    sc.scale[:60] *= 12.0            # rectangles of 32 tiles and more: the scatter step derives their kept count from the cell word
+    sc.scale[:20, 1] *= 5.0
     lib = L.lib()
     import dptr.gs as gs
     uv, depth, conic, radius, tiles = gs.preprocess_ortho(_t(sc.xyz), _t(sc.scale), _t(sc.rotate), _t(sc.extr), W, H, nearest=0.01)
@@ -97,6 +103,7 @@ def test_reach_entry_points_raw():
                                             L.ci(W), L.ci(H), L.ptr(scratch), L.ptr(tr), L.ptr(m), L.ptr(gcount), L.ptr(reach), st))
     M = int(m.item())
     assert M == int(gcount.sum()) and 0 < M < int(tiles.sum())
+    assert int((tiles.view(-1) >= 32).sum()) > 10 and int((reach < 0).sum()) > 10
     assert bool((gcount <= tiles.view(-1)).all())
     keys, idx, owner, slot = torch.empty(M, dtype=torch.int64, device="cuda"), torch.empty(M, **i32), torch.empty(M, **i32), torch.empty(M, **i32)
     goff, ovf = torch.empty(N, **i32), torch.zeros(1, **i32)
