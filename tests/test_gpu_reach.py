@@ -122,3 +122,38 @@ def test_reach_entry_points_raw():
     # every pair slot belongs to the Gaussian the sorted entry names
     g_of_slot = torch.repeat_interleave(torch.arange(N, device="cuda"), gcount.long())
     assert torch.equal(g_of_slot[slot.long()].int(), idx)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_reach_masks_on_random_scenes(seed):
+    """random sizes, splat sizes from sub-pixel to a quarter of the image (cell form of the reach word), elongation, opacities down to
+    below 1/255, centres off the image, clustered layouts: images, final_T and the contributing pixels of the masked lists equal the
+    full lists' bit for bit (tools/reach_stress.py runs the same check over more cases)"""
+    rng = np.random.default_rng(977 + seed)
+    N = int(rng.integers(300, 12000)); W = int(rng.integers(40, 400)); H = int(rng.integers(40, 300)); F = int(rng.integers(1, 4))
+    sig = float(np.exp(rng.uniform(np.log(0.4), np.log(0.25 * min(W, H)))))
+    sc = make_scene(N, W, H, seed=int(rng.integers(1 << 30)), sigma_px=sig, clustered=float(rng.choice([0.0, 0.7])))
+    kind = seed % 4
+    if kind == 1:
+        sc.scale[:, int(rng.integers(0, 2))] *= float(rng.uniform(2, 12))
+    if kind == 2:
+        sc.opacity[:] = (10.0 ** rng.uniform(-3.2, 0.0, size=sc.opacity.shape)).astype(np.float32)
+    if kind == 3:
+        sc.xyz[:, :2] *= 1.6
+    C = int(rng.choice([3, 19]))
+    feat = rng.uniform(size=(N, C)).astype(np.float32)
+    off = _t(np.stack([sc.positions(f) - sc.xyz for f in range(F)]).astype(np.float32))
+    res = []
+    old = FR.OPTIONS["reach"]
+    try:
+        for reach in (True, False):
+            FR.OPTIONS["reach"] = reach
+            B = FrameBatch(F, N, W, H, C, "cuda")
+            with torch.no_grad():
+                out = B.render(_t(sc.xyz), _t(sc.scale), _t(sc.rotate), _t(sc.opacity), _t(feat), off, _t(sc.extr), bg=0.1)
+            torch.cuda.synchronize()
+            res.append((out.clone(), B.final_T.clone(), B.ncontrib.clone() > 0, B.check()))
+    finally:
+        FR.OPTIONS["reach"] = old
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert res[0][3] <= res[1][3]
