@@ -49,5 +49,9 @@ BC="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --scene clustered --no
 bash tools/pmc_run.sh ${TAG}_c1 "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA" $BC < /dev/null > /dev/null
 bash tools/pmc_run.sh ${TAG}_c3 "SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE" $BC < /dev/null > /dev/null
 PMC_CONFIG="300000x854x480x0:batch:morton:clustered" PMC_SOURCE="rocprofv3 --pmc, two passes over one step of bench.py --scene clustered, per launch, summed over the 8 XCDs" python tools/pmc_blend_counters.py $O/pmc_blend_counters_clustered.json gpurun_out/pmc_${TAG}_c1 gpurun_out/pmc_${TAG}_c3
+# the default line once more, now that the counter record of THIS build exists: roofline.traffic / roofline.issue are quoted only
+# from a record whose build id is the running library's (bench.py::pmc_stamp_ok)
+cp $O/pmc_traffic.json profiles/${TAG}_pmc_traffic.json; cp $O/pmc_blend_counters.json profiles/${TAG}_pmc_blend_counters.json
+run bench_line_pmc
 bash tools/round_profile_render_iter.sh $TAG > $O/render_iter_profile.log 2>&1; tail -4 $O/render_iter_profile.log
 ls $O
