@@ -2809,20 +2809,32 @@ struct SetsQCfg {
 // channels: src/trainer_fragGS.py:657,1214) -- slots 12 .. 27 are empty, so the K-slabs j >= 3 of the colour dot product, the
 // second 16-slot block of the feature-gradient product, their hoisted operands (28 registers instead of 88) and their slab
 // traffic are skipped; records, staging and slab rows keep the 28-slot layout.
+#ifndef BLEND_SETS_SMALL_SB
+#define BLEND_SETS_SMALL_SB 48   // SMALL: super-batch (= slab rows per wave) with which 36-float rows leave 50.9 KB of LDS = three workgroups per
+                                 // CU (52 entries are 54.3 KB: three on paper, two on the chip -- 313 us per frame against 256 at 48; 40: 270)
+#endif
+#ifndef BLEND_SETS_SMALL_MINW
+#define BLEND_SETS_SMALL_MINW 3
+#endif
 template <bool ABS, bool STD, bool FWDREC = false, bool SMALL = false>
-__global__ void __launch_bounds__(256, BLEND_SETS_MINW)
+__global__ void __launch_bounds__(256, (SMALL ? BLEND_SETS_SMALL_MINW : BLEND_SETS_MINW))
 blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     static_assert(!FWDREC || STD, "the forward's records are only understood for the renderer's own plan");
     static_assert(!SMALL || !STD, "the renderer's own plan fills the 28 slots");
     constexpr int NKU = SMALL ? 3 : SetsQCfg::NK, NAU = SMALL ? 1 : SetsQCfg::NA, CHU = SMALL ? 12 : SetsQCfg::CH;   // slabs / blocks / slots in use
     using Cfg = SetsQCfg;
-    constexpr int CH = Cfg::CH, SB = Cfg::SB, NG = Cfg::NG, NK = Cfg::NK, CAP = Cfg::CAP, RW = Cfg::RW, RQ = Cfg::RQ;
+    constexpr int CH = Cfg::CH, NG = Cfg::NG, NK = Cfg::NK, RQ = Cfg::RQ;
+    // SMALL (round 6): slots 12 .. 27 are empty, so a slab row is 20 + 12 (+ 4: an odd number of float4) floats instead of 52, and
+    // with a 48-entry super-batch the workgroup holds 50.9 instead of 81 KB of LDS -- THREE workgroups per CU at 168 registers
+    // (the full plans' hoisted operands keep them at 220 registers and two): 3|1|4 plan backward 310 -> 256 us per frame
+    constexpr int SB = (SMALL && BLEND_SETS_SMALL_MINW >= 3) ? BLEND_SETS_SMALL_SB : Cfg::SB, CAP = SB;
+    constexpr int RW = (SMALL && BLEND_SETS_SMALL_MINW >= 3) ? 36 : Cfg::RW;
     constexpr int RQL = Cfg::RQL;
-    static_assert(RQ == 12 && Rec<CH>::CULL == 43 && SB == 64 && CAP * RW >= 32 * CH, "record floats 40-42 are free; the staging of 32 pixels fits a slab");
+    static_assert(RQ == 12 && Rec<CH>::CULL == 43 && SB <= 64 && CAP * RW >= 32 * CH, "record floats 40-42 are free; the staging of 32 pixels fits a slab");
     __shared__ float4 s_rec[(SB + 1) * RQL];            // staged records (SetsQCfg::RQL parts each), slot SB = inert
     auto qpart = [](int e, int p) { return e * RQL + p; };
-    __shared__ unsigned int s_keep[SB];
-    __shared__ unsigned int s_pos4[SB];
+    __shared__ unsigned int s_keep[64];                 // (one word per lane of the list build: entries SB .. 63 stay zero)
+    __shared__ unsigned int s_pos4[64];
     constexpr int QL = SB + 16;                         // a list and its padding (the inert entry, 16 times)
     __shared__ unsigned short s_qlist[(4 * 4 + 1) * QL];   // [wave][quarter][QL]: entry | (slab row) << 8 (+ one list of slack: the
                                                            // step loop reads the NEXT step's entry one step ahead, also past the last list)
@@ -2942,6 +2954,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
         for (int c = tid; c < SB * RQL; c += 256) s_rec[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (tid < RQL) s_rec[qpart(SB, tid)] = make_float4(tid == 10 ? -__builtin_inff() : 0.f, 0.f, 0.f, 0.f);   // inert slot SB: q0 = log2(0)
+    if (SB < 64 && tid < 64) s_keep[tid] = 0u;          // (entries SB .. 63 of the list build: never kept)
     // ---- dL_dout of the wave's pixels into registers in both MFMA operand layouts, 32 pixels (two quarters) at a time
     float hcg[4][NKU], hft[16][NAU];
 #pragma unroll
@@ -2998,7 +3011,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     // third sector only parts 8 and 9, the last feature slots, are used; the cull parameters behind them are not), no
     // division, and the coefficient block runs ONCE per wave (the generic Stager -- chunk c = t + 256 k, entry c / 12 -- made every
     // wave run it for each of its three chunks: 230 of the 830 VALU instructions a wave spent per super-batch outside the steps).
-    static_assert(SB == 64 && RQ == 12, "256 threads = 64 entries x 4 parts; three sectors per record");
+    static_assert(SB <= 64 && RQ == 12, "256 threads = 64 entries x 4 parts (entries SB .. 63 idle); three sectors per record");
     const int se = tid >> 2, sp = tid & 3;
     int sid_next;              // Gaussian of entry se, two super-batches ahead (-1: past the list)
     float4 sv0, sv1, sv2 = make_float4(0.f, 0.f, 0.f, 0.f);   // parts sp, 4 + sp, 8 + sp (sp < 2) of entry se, one super-batch ahead
@@ -3037,8 +3050,10 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
 #undef QB_
             const PowerCoef pc = power_coeffs(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, tcx, tcy);
             const float ut = g0.x - tcx, vt = g0.y - tcy;
-            float4 *rb = s_rec + se * RQL;
-            if (FWDREC) {
+            float4 *rb = s_rec + imin_(se, SB) * RQL;
+            if (SB < 64 && se >= SB) {
+                // (a super-batch below 64 entries: the quads past it park nothing)
+            } else if (FWDREC) {
                 // forward record: parts 0 1 = geometry, part 2 = r g b depth, part 3 = attributes 0-3, parts 4 + sp = attributes
                 // 4 + 4 sp ..; channel -> slot (rgb 0-2 | depth 4 | attribute a 8 + a) -> float sets_fpos(slot)
                 float *rf = reinterpret_cast<float *>(rb);
@@ -3057,7 +3072,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
             qv.y = sp == 0 ? pc.qxy : sp == 1 ? pc.qyy : 0.f;
             qv.z = sp == 0 ? -(g0.z * ut + g0.w * vt) : sp == 1 ? g0.z : sp == 2 ? g0.w : 0.f;
             qv.w = sp == 0 ? -(g0.w * ut + g1.x * vt) : sp == 1 ? g0.w : sp == 2 ? g1.x : 0.f;
-            rb[10 + sp] = qv;
+            if (SB == 64 || se < SB) rb[10 + sp] = qv;
         }
         const unsigned fl = fl_next;
         fl_next = load_flags(top - SB);
