@@ -2805,10 +2805,11 @@ struct SetsQCfg {
 // FWDREC (with STD): the records the FORWARD packed for this row (Rec<24>: [u v A B | C o . id | channels 0 .. 22 .], 32 floats)
 // are staged directly -- the park scatters a record's channels to their transposed slot positions -- so the backward needs no
 // packing launch of its own (17 us per frame at c2) and gathers 128 instead of 192 bytes per entry.
-// SMALL: a plan whose detached set holds at most four channels (the trainer's ['mask_attribute'] / ['dino_attribute'] rows, 5 .. 8
-// channels: src/trainer_fragGS.py:657,1214) -- slots 12 .. 27 are empty, so the K-slabs j >= 3 of the colour dot product, the
-// second 16-slot block of the feature-gradient product, their hoisted operands (28 registers instead of 88) and their slab
-// traffic are skipped; records, staging and slab rows keep the 28-slot layout.
+// SMALL = 3 / 4: a plan whose detached set holds at most four / eight channels (the trainer's ['mask_attribute'] /
+// ['dino_attribute'] rows, alone or behind track_gs: src/trainer_fragGS.py:657,1214) -- slots 12 .. / 16 .. 27 are empty, so the
+// K-slabs j >= SMALL of the colour dot product, the second 16-slot block of the feature-gradient product, their hoisted operands
+// (28 / 32 registers instead of 88) and their slab traffic are skipped; records and staging keep the 28-slot layout, the slab rows
+// hold 16 slots (36 floats).
 #ifndef BLEND_SETS_SMALL_SB
 #define BLEND_SETS_SMALL_SB 48   // SMALL: super-batch (= slab rows per wave) with which 36-float rows leave 50.9 KB of LDS = three workgroups per
                                  // CU (52 entries are 54.3 KB: three on paper, two on the chip -- 313 us per frame against 256 at 48; 40: 270)
@@ -2816,12 +2817,13 @@ struct SetsQCfg {
 #ifndef BLEND_SETS_SMALL_MINW
 #define BLEND_SETS_SMALL_MINW 3
 #endif
-template <bool ABS, bool STD, bool FWDREC = false, bool SMALL = false>
+template <bool ABS, bool STD, bool FWDREC = false, int SMALL = 0>   // SMALL: K-slabs of the colour product in use (3 / 4; 0: all seven)
 __global__ void __launch_bounds__(256, (SMALL ? BLEND_SETS_SMALL_MINW : BLEND_SETS_MINW))
 blend_bwd_sets_quarter_kernel(const BlendArgs B) {
     static_assert(!FWDREC || STD, "the forward's records are only understood for the renderer's own plan");
     static_assert(!SMALL || !STD, "the renderer's own plan fills the 28 slots");
-    constexpr int NKU = SMALL ? 3 : SetsQCfg::NK, NAU = SMALL ? 1 : SetsQCfg::NA, CHU = SMALL ? 12 : SetsQCfg::CH;   // slabs / blocks / slots in use
+    static_assert(SMALL == 0 || SMALL == 3 || SMALL == 4, "slots 0 .. 11 or 0 .. 15 (one 16-slot block of the feature-gradient product)");
+    constexpr int NKU = SMALL ? SMALL : SetsQCfg::NK, NAU = SMALL ? 1 : SetsQCfg::NA, CHU = SMALL ? 4 * SMALL : SetsQCfg::CH;   // slabs / blocks / slots in use
     using Cfg = SetsQCfg;
     constexpr int CH = Cfg::CH, NG = Cfg::NG, NK = Cfg::NK, RQ = Cfg::RQ;
     // SMALL (round 6): slots 12 .. 27 are empty, so a slab row is 20 + 12 (+ 4: an odd number of float4) floats instead of 52, and
@@ -3452,7 +3454,7 @@ blend_bwd_sets_quarter_kernel(const BlendArgs B) {
                 }
             } else {
                 // slots [8 (cp - 1) .. ) of the 28 (cp 1: 0-7, cp 2: 8-19, cp 3: 20-27), summed over the waves, to their row channels
-                const int s0 = cp == 1 ? 0 : cp == 2 ? 8 : 20, ns = SMALL ? (cp == 1 ? 8 : cp == 2 ? 4 : 0) : (cp == 2 ? 12 : 8);
+                const int s0 = cp == 1 ? 0 : cp == 2 ? 8 : 20, ns = SMALL ? (cp == 1 ? 8 : cp == 2 ? 4 * SMALL - 8 : 0) : (cp == 2 ? 12 : 8);
                 float f[12];
 #pragma unroll
                 for (int k = 0; k < 12; ++k) f[k] = 0.f;
@@ -4579,14 +4581,17 @@ static int backward_batch_sets_impl(int F, int P, int C, const int32_t *set_c0, 
     SPLAT_LAUNCH("blend_pack", pack_sets_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)F), dim3(256), 0, s, A);
     SPLAT_POST_LAUNCH();
     if (A.cull_flags && bwd_use_quarters()) {   // quarter lists (the forward's quarter bits)
-        const bool small = !std_plan && set_cn[2] <= 4;   // detached set of at most four channels: slots 12 .. 27 empty
+        // a detached set of at most four / eight channels leaves slots 12 .. / 16 .. 27 empty: the SMALL instantiations
+        const int small = std_plan ? 0 : set_cn[2] <= 4 ? 3 : set_cn[2] <= 8 ? 4 : 0;
         if (want_abs) {
             if (std_plan) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, true>), grid, block, 0, s, A);
-            else if (small) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, false, false, true>), grid, block, 0, s, A);
+            else if (small == 3) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, false, false, 3>), grid, block, 0, s, A);
+            else if (small == 4) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, false, false, 4>), grid, block, 0, s, A);
             else SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<true, false>), grid, block, 0, s, A);
         } else {
             if (std_plan) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<false, true>), grid, block, 0, s, A);
-            else if (small) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<false, false, false, true>), grid, block, 0, s, A);
+            else if (small == 3) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<false, false, false, 3>), grid, block, 0, s, A);
+            else if (small == 4) SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<false, false, false, 4>), grid, block, 0, s, A);
             else SPLAT_LAUNCH("blend_bwd", (blend_bwd_sets_quarter_kernel<false, false>), grid, block, 0, s, A);
         }
     } else if (want_abs) SPLAT_LAUNCH("blend_bwd", blend_bwd_sets_kernel<true>, grid, block, 0, s, A);

@@ -115,7 +115,7 @@ def _frame_batch_render_against_oracle(oracle_mod, reach):
     assert (B.radii_max.cpu().numpy() == np.max([r["radius"] for r in per], 0)).mean() > 0.9999
 
 
-@pytest.mark.parametrize("std,width", [(1, 19), (0, 19), (1, 1), (1, 3), (1, 4)])
+@pytest.mark.parametrize("std,width", [(1, 19), (0, 19), (1, 1), (1, 3), (1, 4), (1, 7), (1, 8), (1, 9)])
 def test_render_sets_against_oracle(oracle_mod, std, width, lib_option):
     """render_sets = the reference's render_iter over a batch: rgb enhanced (K = 20 ids, ndc + abs_ndc taps), depth (bg 1),
     19 attribute channels with opacity.detach() -- one forward over the 23-channel row, then the ONE-pass three-set backward
