@@ -141,6 +141,10 @@ def parse():
                     help="--train-step at N > 1: the spline table's gradient reduced to the owners of its time blocks, their Adam "
                          "moments sharded, updated blocks gathered (parallel.owner_reduce / owner_gather, optim.OwnerShardedAdam) "
                          "instead of one all-reduce of the flat bucket + replicated Adam")
+    ap.add_argument("--exchange-positions", action="store_true",
+                    help="--train-step --owner-sharded at N > 1: position(ids2) of a pair frame in another rank's time block is "
+                         "evaluated by its owner and sent, its gradient sent back (TrainingStep(exchange_positions=True)): the spline "
+                         "table is neither reduced nor gathered in a step; the ranks render contiguous time blocks of the clip")
     ap.add_argument("--stale-overlap", action="store_true",
                     help="stale-1 mode: double-buffered gradient bucket, the all-reduce of step s overlaps step s+1's frames "
                          "and no optimiser runs (NOT synchronous data parallelism; for comparison only)")
@@ -807,7 +811,7 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
     cfg = TS.DensifyConfig(cameras_extent=5.0)
     lr = {k: 1e-6 for k in TS.REFERENCE_LR}      # as everywhere in this file: small rates keep the scene's statistics put over the run
     st = TS.TrainingStep(start, clock, sc.W, sc.H, len(t1), extr, lr=lr, densify=cfg, K=20, owner_sharded=a.owner_sharded, zero1=a.zero1,
-                         fused_l1=not a.unfused_l1)
+                         fused_l1=not a.unfused_l1, exchange_positions=a.exchange_positions)
     del truth
     if not (world > 1 and not a.zero1 and not a.owner_sharded):
         start = None
@@ -862,13 +866,15 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
     amort = dens_ms / cfg.interval
     sharded = a.owner_sharded or a.zero1
     opt_desc = ("ZeRO-1: reduce-scatter of the flat gradient, Adam on this rank's 1 / N block, all-gather of the parameters" if a.zero1 else
+                "owner-sharded spline table with POSITION EXCHANGE (position(ids2) from its owner, its gradient back: the table is "
+                "neither reduced nor gathered)" if a.exchange_positions else
                 "owner-sharded spline table (reduce to owner, sharded moments, gather)" if a.owner_sharded
                 else "all-reduce of the flat bucket + replicated Adam")
     moments_MB = round(sum(t.numel() for t in ((st.opt.m_own, st.opt.v_own, st.opt.m_rep, st.opt.v_rep)
                                                if sharded else (st.opt.exp_avg, st.opt.exp_avg_sq))) * 4 / 1e6, 1)
     bucket_MB = round(st.bucket.flat_grad.numel() * 4 / 1e6, 1)
     pairs_M = int(st.fb.pairs.max().item())
-    zero1 = None
+    zero1 = exchange = None
     if start is not None:      # N > 1, default schedule: the same step under ZeRO-1 beside it (every rank takes part)
         try:
             del st
@@ -881,6 +887,28 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
                      "what": "the same step with zero1=True: reduce-scatter of the flat gradient, Adam on 1 / N, all-gather"}
         except Exception as e:   # noqa: BLE001
             zero1 = {"error": repr(e)[:300]}
+        # ... and with the POSITION EXCHANGE (owner-sharded table; the ranks render contiguous time blocks of the clip, so these are
+        # other pairs of the same count: position(ids2) from its owner, its gradient back -- no reduce / gather of the table)
+        try:
+            del st
+            torch.cuda.empty_cache()
+            tb1 = [(dist.get_rank() * (sc.F // world) + i) % sc.F for i in range(len(t1))]
+            tb2 = [int((17 * t + 11) % sc.F) for t in tb1]
+            tb2 = [t if t != u else (t + 1) % sc.F for t, u in zip(tb2, tb1)]
+            truth_b = TS.synthetic_video_params(sc, clock, dev, attrs=n_attrs)
+            gtb = TS.render_ground_truth(truth_b, clock, sc.W, sc.H, extr, tb1, tb2)
+            del truth_b
+            st = TS.TrainingStep(start, clock, sc.W, sc.H, len(t1), extr, lr=lr, densify=cfg, K=20, owner_sharded=True,
+                                 exchange_positions=True)
+            dtx = timed(lambda: st.step(tb1, tb2, gtb))
+            st.fb.check()
+            exchange = {"train_step_ms": round(dtx / a.steps * 1e3, 3), "value": round(F * a.steps * world / dtx, 2), "unit": "frames/s",
+                        "adam_moments_MB_per_rank": round(sum(t.numel() for t in (st.opt.m_own, st.opt.v_own, st.opt.m_rep, st.opt.v_rep)) * 4 / 1e6, 1),
+                        "what": "the same step count with owner_sharded=True, exchange_positions=True on contiguous time blocks: "
+                                "position(ids2) evaluated by its owner and sent, its gradient sent back; the spline table is neither "
+                                "reduced nor gathered"}
+        except Exception as e:   # noqa: BLE001
+            exchange = {"error": repr(e)[:300]}
         del start
     return {
         "metric": "training steps of the reference's trainer composed from the native pieces (src/trainer_fragGS.py:736-790), "
@@ -902,10 +930,11 @@ def train_step_line(a, sc, dev, frames, timed, world, launched):
                                f"track_gs + {n_attrs} attribute channels, opacity detached), L1 on the three images, backward, "
                                "all-reduce, Adam on the flat buffer, densification statistics",
                    "equivalent_flags": "--train-step" + (" --owner-sharded" if a.owner_sharded else "") + (" --zero1" if a.zero1 else "")
+                                       + (" --exchange-positions" if a.exchange_positions else "")
                                        + ("" if a.attr_channels == 19 else f" --attr-channels {a.attr_channels}"),
                    "tile_pairs_M": pairs_M, "grad_bucket_MB": bucket_MB, "optimizer": opt_desc,
                    "adam_moments_MB_per_rank": moments_MB},
-        "zero1": zero1}
+        "zero1": zero1, "position_exchange": exchange}
 
 
 def main():
@@ -982,6 +1011,9 @@ def main():
     sc = build_scene(a.gaussians, a.width, a.height, a.channels)
     # rank r renders frames {f : f mod world == r} of the step's frame batch
     frames = [((i * world + rank) % clip) for i in range(a.frames)]
+    if a.exchange_positions:     # contiguous time blocks: a rank renders the frames whose spline segments it owns
+        a.owner_sharded = True
+        frames = [(rank * (clip // world) + i) % clip for i in range(a.frames)]
 
     def sync():
         torch.cuda.synchronize()

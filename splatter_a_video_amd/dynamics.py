@@ -374,11 +374,11 @@ def positions_batch_forward(tab: Tensor, position: Tensor, pos_cubic_node: Tenso
         raise ValueError("pos_cubic_node must hold N * 4 * interval_num * 3 floats")
     if out is None:
         out = torch.empty(F, N, 3, dtype=torch.float32, device=position.device)
-    elif tuple(out.shape) != (F, N, 3) or not out.is_contiguous() or out.dtype != torch.float32:
-        raise ValueError(f"out must be a contiguous float32 [F={F}, N={N}, 3] buffer")
+    elif tuple(out.shape) != (F, N, 3) or out.dtype != torch.float32 or not out.is_cuda or (N and (out.stride(1), out.stride(2)) != (3, 1)):
+        raise ValueError(f"out must be a float32 GPU buffer [F={F}, N={N}, 3] with dense frames (any frame stride)")
     L.check(L.lib().splat_dynamic_positions_batch_forward(
         L.ci(F), L.ci(N), L.ci(interval_num), L.ptr(tab), L.ptr(position), L.ptr(cubic), L.ci(cubic_layout), L.ptr(out),
-        ctypes.c_int64(N * 3), L.stream()))
+        ctypes.c_int64(out.stride(0) if F > 1 else N * 3), L.stream()))
     return out
 
 
@@ -386,12 +386,13 @@ def positions_batch_backward(tab: Tensor, g: Tensor, interval_num: int, cubic_la
                              d_pos_cubic_node: Optional[Tensor]) -> None:
     """``g`` [F, N, 3] = dL/dposition(t_f) is ADDED into ``d_position`` [N, 3] and into the coefficient rows of every frame's
     segment of ``d_pos_cubic_node`` (either may be None); one launch, no atomics"""
-    g = L.need(g, "g")
     F, N = g.shape[0], g.shape[1]
+    if not (g.is_cuda and g.dtype == torch.float32 and g.dim() == 3 and g.shape[2] == 3 and (N == 0 or (g.stride(1), g.stride(2)) == (3, 1))):
+        g = L.need(g, "g")      # (a strided view with dense frames -- g_pairs[:, 0] -- is read in place)
     if tab.shape[0] != F:
         raise ValueError("one table entry per frame of g")
     L.check(L.lib().splat_dynamic_positions_batch_backward(
-        L.ci(F), L.ci(N), L.ci(interval_num), L.ptr(tab), L.ptr(g), ctypes.c_int64(N * 3), L.ci(cubic_layout),
+        L.ci(F), L.ci(N), L.ci(interval_num), L.ptr(tab), L.ptr(g), ctypes.c_int64(g.stride(0) if F > 1 else N * 3), L.ci(cubic_layout),
         L.ptr(d_position), L.ptr(d_pos_cubic_node), L.stream()))
 
 

@@ -253,11 +253,17 @@ def _group_on() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() >= MIN_WORLD
 
 
-def owner_reduce(bucket: FlatGradBucket, shards) -> None:
+def owner_reduce(bucket: FlatGradBucket, shards, reduce_owned: bool = True) -> None:
     """gradients after the local backward: all-reduce of the replicated part || reduce-scatter of the owned part (afterwards a
     rank's gradient of the owned parameter is complete in ITS block only; the other blocks hold partial sums nobody reads).
-    ``shards``: ``OwnerShards`` (one owned parameter + a replicated rest) or ``Zero1Shards`` (the whole buffer is owned)."""
+    ``shards``: ``OwnerShards`` (one owned parameter + a replicated rest) or ``Zero1Shards`` (the whole buffer is owned).
+    ``reduce_owned=False``: the owned part's gradient is already complete on its owner (position exchange): only the replicated
+    part is reduced."""
     if not _group_on():
+        return
+    if not reduce_owned:
+        if shards.total > shards.b:
+            dist.all_reduce(bucket.flat_grad[shards.b:shards.total], op=dist.ReduceOp.SUM)
         return
     world = dist.get_world_size()
     g = bucket.flat_grad
@@ -337,3 +343,55 @@ def zero1_step(bucket: FlatGradBucket, shards: Zero1Shards, frames: Iterable[int
     """``owner_sharded_step`` with the whole buffer owned (ZeRO-1): parameters after the step = ``sharded_step``'s to fp32
     summation order, replicas bit-identical (every rank receives the owners' bits)."""
     owner_sharded_step(bucket, shards, frames, render_and_backward, optimizer, average=average)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Position exchange (DESIGN 6): with the spline table owner-sharded by time blocks, what a rank needs of ANOTHER block is never
+# the table -- 14.4 MB per segment at 300k Gaussians -- but position(t) of the pair frames it drew there (3.6 MB per frame), and
+# what it owes the owner afterwards is the gradient of that position.  The owner evaluates, sends, later receives dL/dposition and
+# runs the positions' backward into ITS block; the table, its gradient and its Adam moments never leave their owner: per rank and
+# step 2 F frames of [N, 3] instead of 2 (W - 1) / W of the table's gradient + parameters (331 instead of 1159 MB at 8 GPUs and 200
+# frames).
+class PositionExchangePlan:
+    """Who evaluates which requested frame.  ``times2_all[r][k]`` = pair frame k of rank r (every rank holds the whole table of
+    requests: one small all-gather); ``owner_of(t)`` = rank that owns the spline segment of time t.  ``serve`` = the (requester,
+    k, time) this rank evaluates, ordered by (requester, k) -- the order of the messages between any two ranks on both sides."""
+
+    def __init__(self, times2_all, owner_of, rank: int):
+        self.rank = int(rank)
+        self.owners = [[int(owner_of(t)) for t in row] for row in times2_all]
+        self.serve = [(r, k, float(t)) for r, row in enumerate(times2_all) for k, t in enumerate(row) if self.owners[r][k] == self.rank]
+        self.mine = self.owners[self.rank]          # owner of each of this rank's requested frames
+
+
+def gather_times(times, world: int, rank: int):
+    """every rank's list of frame times (host floats) on every rank: [world][len(times)].  A host synchronisation per step -- the
+    frame tables are built on the host anyway."""
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not on:
+        return [[float(t) for t in times]]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor([float(t) for t in times], dtype=torch.float64, device=dev)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [[float(x) for x in o.cpu().tolist()] for o in out]
+
+
+def exchange_frames(sends, recvs) -> None:
+    """point-to-point exchange of whole tensors: ``sends`` = [(peer, tensor)], ``recvs`` = [(peer, tensor)] (dense [N, 3] frames;
+    between any two ranks both sides list their messages in the same order).  RCCL: one grouped batch of isend / irecv on the
+    device tensors; gloo (the CPU rehearsal of the tests: it moves no CUDA tensors point to point): staged through host copies."""
+    if not sends and not recvs:
+        return
+    if dist.get_backend() == "nccl":
+        ops = [dist.P2POp(dist.isend, t, peer) for peer, t in sends] + [dist.P2POp(dist.irecv, t, peer) for peer, t in recvs]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        return
+    host_s = [(peer, t.detach().cpu().contiguous()) for peer, t in sends]
+    host_r = [(peer, torch.empty(t.shape, dtype=t.dtype)) for peer, t in recvs]
+    works = [dist.isend(h, peer) for peer, h in host_s] + [dist.irecv(h, peer) for peer, h in host_r]
+    for w in works:
+        w.wait()
+    for (_, t), (_, h) in zip(recvs, host_r):
+        t.copy_(h)

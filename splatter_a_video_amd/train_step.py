@@ -45,7 +45,8 @@ from .frames import FrameBatch
 from .gs.fused_ops import compute_sh_into
 from .gs.point_ops import project_point_ortho
 from .optim import FlatAdam, OwnerShardedAdam, PatternLR
-from .parallel import FlatGradBucket, OwnerShards, Zero1Shards, owner_gather, owner_reduce, reduce_densify_batch
+from .parallel import (FlatGradBucket, OwnerShards, PositionExchangePlan, Zero1Shards, exchange_frames, gather_times, owner_gather,
+                       owner_reduce, reduce_densify_batch)
 
 TRAINABLE = ("pos_cubic_node", "rotation", "opacity", "scaling", "shs", "attrs")
 FROZEN = ("position", "rot_poly_feat", "rot_fourier_feat")          # :90 position is not optimised; :195-197 detached tables
@@ -111,7 +112,7 @@ class TrainingStep:
                  lr: Optional[Dict[str, float]] = None, weights: Optional[LossWeights] = None,
                  densify: Optional[DensifyConfig] = None, K: int = 20, knn_K: int = 5, arap_samples: int = 512,
                  bg: float = 0.0, sample_seed: Optional[int] = None, timing: bool = False, owner_sharded: bool = False,
-                 spatial_order: bool = True, zero1: bool = False, fused_l1: bool = True):
+                 spatial_order: bool = True, zero1: bool = False, fused_l1: bool = True, exchange_positions: bool = False):
         self.clock, self.W, self.H, self.F = clock, int(W), int(H), int(frames_per_step)
         self.extr = extr
         self.dev = params["position"].device
@@ -137,6 +138,12 @@ class TrainingStep:
         self.zero1 = bool(zero1)
         if self.zero1 and self.owner_sharded:
             raise ValueError("owner_sharded and zero1 are two schedules of the same step: pick one")
+        # POSITION EXCHANGE (with owner_sharded): position(ids2) of a pair frame in another rank's time block comes from
+        # its owner and its gradient goes back there -- the spline table, its gradient and its moments never leave their owner.
+        # The frames ids1 a rank renders must lie in ITS block (OwnerShards.frames_of_rank deals them so).
+        self.exchange = bool(exchange_positions)
+        if self.exchange and not self.owner_sharded:
+            raise ValueError("exchange_positions belongs to the owner-sharded step (owner_sharded=True)")
         p0 = {k: params[k] for k in TRAINABLE + FROZEN}
         # setup, as after every densification: the Gaussians in Morton order of their screen positions at the clip's first frame
         # (the binning kernels' locality and the neighbour search's bound want space neighbours at neighbouring
@@ -238,7 +245,11 @@ class TrainingStep:
         # ---- model evaluation outside the renderer: SH colours (constant view direction) and both positions of every pair
         rgb = compute_sh_into(p["shs"], 3, self.dirs, None, g["shs"])
         tab12 = self._tables(times1, times2)
-        positions_batch_forward(tab12, fz["position"], p["pos_cubic_node"], I, SEGMENT_MAJOR, out=self.pairs.view(2 * F, N, 3))
+        if self.exchange:
+            self.clock_times1 = [float(t) for t in times1]
+            plan = self._positions_by_exchange(times1, times2)
+        else:
+            positions_batch_forward(tab12, fz["position"], p["pos_cubic_node"], I, SEGMENT_MAJOR, out=self.pairs.view(2 * F, N, 3))
         self._fill(self.g_pairs)
         ph.mark("model_eval")
         # ---- rigidity of the pair: neighbours of the sampled vertices in frame ids1, ARAP energy + gradient of both frames
@@ -281,11 +292,19 @@ class TrainingStep:
             ph.mark("loss")
             torch.autograd.backward(list(out[:3]), grads)
         # ---- both position gradients of every pair (ARAP on ids1 and ids2, track_gs on ids2) reach the spline segments
-        positions_batch_backward(tab12, self.g_pairs.view(2 * F, N, 3), I, SEGMENT_MAJOR, None, g["pos_cubic_node"])
+        if self.exchange:
+            self._position_gradients_by_exchange(plan, g["pos_cubic_node"])
+        else:
+            positions_batch_backward(tab12, self.g_pairs.view(2 * F, N, 3), I, SEGMENT_MAJOR, None, g["pos_cubic_node"])
         ph.mark("render_backward")
         # ---- data parallelism: one all-reduce of the flat bucket, identical Adam on every rank -- or (owner_sharded) the
         #      spline table's gradient reduced to the owners of its time blocks, their blocks stepped there and gathered
-        if self.owner_sharded or self.zero1:
+        if self.exchange:
+            # the table's gradient is complete on its owner (own frames + the position gradients it received): nothing of it is
+            # reduced, nothing of the table gathered; the other ranks' blocks of the local copy go stale and are never read
+            owner_reduce(bk, self.shards, reduce_owned=False)
+            self.opt.step(grad_scale=1.0 / self.world)
+        elif self.owner_sharded or self.zero1:
             owner_reduce(bk, self.shards)
             self.opt.step(grad_scale=1.0 / self.world)
             owner_gather(bk, self.shards)
@@ -312,6 +331,68 @@ class TrainingStep:
             self._marks = ph
         return self.last
 
+    # ------------------------------------------------------------------ position exchange (owner-sharded table)
+    def _owner_of_time(self, t: float) -> int:
+        seg = int(self.clock.scalars(t)[0])
+        ub = self.shards.unit_bounds
+        return next(r for r in range(self.world) if ub[r] <= seg < ub[r + 1])
+
+    def _positions_by_exchange(self, times1, times2) -> PositionExchangePlan:
+        """pairs[:, 0] = position(ids1) from this rank's own block; pairs[:, 1] = position(ids2) from the owners of those frames
+        (this rank evaluates what the others -- and itself -- requested of its block and sends it)"""
+        F, N, I = self.F, self.N, self.clock.interval_num
+        fz, p = self.frozen, self.p
+        for t in times1:
+            if self._owner_of_time(t) != self.rank:
+                raise ValueError(f"position exchange: frame {t} of ids1 is not in rank {self.rank}'s time block "
+                                 "(deal the frames with OwnerShards.frames_of_rank)")
+        positions_batch_forward(frame_table(self.clock, list(times1), self.dev), fz["position"], p["pos_cubic_node"], I, SEGMENT_MAJOR,
+                                out=self.pairs[:, 0])
+        plan = PositionExchangePlan(gather_times(times2, self.world, self.rank), self._owner_of_time, self.rank)
+        plan.tab = frame_table(self.clock, [t for _, _, t in plan.serve], self.dev) if plan.serve else None
+        plan.buf = torch.empty(len(plan.serve), N, 3, dtype=torch.float32, device=self.dev)
+        if plan.serve:
+            positions_batch_forward(plan.tab, fz["position"], p["pos_cubic_node"], I, SEGMENT_MAJOR, out=plan.buf)
+        sends, recvs = [], []
+        for j, (r, k, _) in enumerate(plan.serve):
+            if r == self.rank:
+                self.pairs[k, 1].copy_(plan.buf[j])
+            else:
+                sends.append((r, plan.buf[j]))
+        for k, o in enumerate(plan.mine):
+            if o != self.rank:
+                recvs.append((o, self.pairs[k, 1]))
+        if self.world > 1:
+            exchange_frames(sends, recvs)
+        return plan
+
+    def _position_gradients_by_exchange(self, plan: PositionExchangePlan, d_table: Tensor) -> None:
+        """dL/dposition(ids1) into this rank's block; dL/dposition(ids2) to the owners, whose positions' backward adds what they
+        receive (and their own requests) into THEIR block"""
+        F, N, I = self.F, self.N, self.clock.interval_num
+        tab1 = frame_table(self.clock, [float(self.clock_times1[k]) for k in range(F)], self.dev)
+        positions_batch_backward(tab1, self.g_pairs[:, 0], I, SEGMENT_MAJOR, None, d_table)
+        gbuf = torch.empty_like(plan.buf)
+        sends, recvs = [], []
+        for k, o in enumerate(plan.mine):
+            if o != self.rank:
+                sends.append((o, self.g_pairs[k, 1]))
+        for j, (r, k, _) in enumerate(plan.serve):
+            if r == self.rank:
+                gbuf[j].copy_(self.g_pairs[k, 1])
+            else:
+                recvs.append((r, gbuf[j]))
+        if self.world > 1:
+            exchange_frames(sends, recvs)
+        if plan.serve:
+            positions_batch_backward(plan.tab, gbuf, I, SEGMENT_MAJOR, None, d_table)
+
+    def sync_table(self) -> None:
+        """position exchange: every owner's block of the spline table to every rank (a collective; before anything reads the whole
+        table: a structure change, a checkpoint)"""
+        if self.exchange:
+            owner_gather(self.bucket, self.shards)
+
     def phases(self) -> Dict[str, float]:
         """GPU milliseconds of the last step's phases (``timing=True``; synchronises)"""
         torch.cuda.synchronize()
@@ -325,6 +406,7 @@ class TrainingStep:
     # ------------------------------------------------------------------ structure
     def _gather(self):
         """the per-Gaussian tensors and Adam moments in row layout (pos_cubic_node back in the reference's [N, 4*I*3])"""
+        self.sync_table()
         N = self.N
         p = {k: v.detach() for k, v in self.p.items()}
         p["pos_cubic_node"] = to_gaussian_major(p["pos_cubic_node"].reshape(self.clock.interval_num, N, 4, 3))

@@ -137,7 +137,7 @@ def test_bench_gpus_2_launches_and_reports_two_ranks():
 
 # ---------------------------------------------------------------------------------------------------------------------
 # the composed training step (train_step.py) under data parallelism
-def _train_worker(rank, world, port, out, owner=False, steps=45):
+def _train_worker(rank, world, port, out, owner=False, steps=45, blocks=False, exchange=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -152,16 +152,19 @@ def _train_worker(rank, world, port, out, owner=False, steps=45):
         cfg = TS.DensifyConfig(interval=15, start_iter=10, stop_iter=40, grad_threshold=5e-4, cameras_extent=60.0, min_opacity=0.02, seed=9)
         lr = dict(TS.REFERENCE_LR, pos_cubic_node=2e-3, shs=2e-2, attrs=2e-2, scaling=1e-2, rotation=5e-3)
         st = TS.TrainingStep(_perturbed(truth, 1), clock, Ww, Hh, F, extr, lr=lr, densify=cfg, K=8, arap_samples=128, sample_seed=rank,
-                             owner_sharded=owner)
+                             owner_sharded=owner, exchange_positions=exchange)
         rng = np.random.default_rng(100 + rank)                     # every rank draws ITS OWN frame pairs
         counts, losses = [st.N], []
+        # blocks: ids1 from the rank's own time block (what OwnerShards.frames_of_rank deals; the position exchange needs it)
+        mine = [f for f in range(T) if int(clock.scalars(f)[0]) * world // clock.interval_num == rank] if blocks else list(range(T))
         for _ in range(steps):
-            t1 = [int(t) for t in rng.choice(T, F, replace=False)]
+            t1 = [int(t) for t in rng.choice(mine, F, replace=False)]
             t2 = [int((t + 1 + rng.integers(T - 1)) % T) for t in t1]
             st.step(t1, t2, TS.render_ground_truth(truth, clock, Ww, Hh, extr, t1, t2))
             losses.append(st.loss())
             if st.maybe_densify():
                 counts.append(st.N)
+        st.sync_table()         # (position exchange: the other owners' blocks of the table before anything reads all of it)
         torch.cuda.synchronize()
         torch.save({"param": st.bucket.flat_param.detach().cpu(), "m": st.opt.full_moments()[0].cpu(), "counts": counts, "losses": losses,
                     "slices": dict(st.bucket.slices), "frozen": st.frozen["position"].cpu()}, out + f".{rank}")
@@ -201,6 +204,31 @@ def test_two_ranks_owner_sharded_training_step_equals_the_all_reduce_step(tmp_pa
     torch.testing.assert_close(o0["m"], d0["m"], rtol=0, atol=1e-6)
 
 
+@pytest.mark.timeout(900)
+def test_two_ranks_position_exchange_equals_the_all_reduce_step(tmp_path):
+    """TrainingStep(owner_sharded=True, exchange_positions=True): position(ids2) of a pair frame in the other rank's time block is
+    evaluated by its owner and sent, its gradient sent back and taken through the positions' backward THERE -- the spline table is
+    neither reduced nor gathered in a step.  Three steps: every parameter and the assembled moments equal the all-reduce step's
+    on the same pairs (1e-6: the owner sums the position gradients in one launch, the all-reduce the ranks' partial tables -- another
+    summation order).  Eighteen steps through a structure change (the table is gathered for it once): the two ranks agree bit for
+    bit, the Gaussian counts and the loss curve are the all-reduce run's (the parameters themselves part where Adam normalises a
+    rounding-noise gradient to a full +-lr step of either sign, as between any two summation orders)."""
+    out_x, out_d = str(tmp_path / "xch"), str(tmp_path / "dense")
+    mp.spawn(_train_worker, args=(2, _free_port(), out_x, True, 3, True, True), nprocs=2, join=True)
+    mp.spawn(_train_worker, args=(2, _free_port(), out_d, False, 3, True, False), nprocs=2, join=True)
+    x0, x1, d0 = torch.load(out_x + ".0"), torch.load(out_x + ".1"), torch.load(out_d + ".0")
+    assert torch.equal(x0["param"], x1["param"]) and torch.equal(x0["m"], x1["m"])
+    torch.testing.assert_close(x0["param"], d0["param"], rtol=0, atol=1e-6)
+    torch.testing.assert_close(x0["m"], d0["m"], rtol=0, atol=1e-6)
+    mp.spawn(_train_worker, args=(2, _free_port(), out_x, True, 18, True, True), nprocs=2, join=True)
+    mp.spawn(_train_worker, args=(2, _free_port(), out_d, False, 18, True, False), nprocs=2, join=True)
+    x0, x1, d0 = torch.load(out_x + ".0"), torch.load(out_x + ".1"), torch.load(out_d + ".0")
+    assert x0["counts"] == x1["counts"] == d0["counts"] and len(set(x0["counts"])) == 2
+    assert torch.equal(x0["param"], x1["param"]) and torch.equal(x0["m"], x1["m"])
+    np.testing.assert_allclose(x0["losses"], d0["losses"], rtol=2e-2)
+    assert float((x0["param"] - d0["param"]).abs().mean()) < 2e-3
+
+
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize("n", [8, 4])
 def test_bench_gpus_8_and_4_rehearsal_over_gloo(n):
@@ -226,13 +254,17 @@ def test_bench_gpus_8_and_4_rehearsal_over_gloo(n):
     c = line["comm"]
     assert "error" not in c and c["allreduce_ms"] > 0 and c["overlap_exact"]["value"] > 0, c
     # both exact schedules were timed; the line's value is the faster one and says which
-    assert c["synchronous"]["value"] > 0 and abs(line["value"] - max(c["synchronous"]["value"], c["overlap_exact"]["value"])) < 0.02
-    assert line["config"]["schedule"].startswith(("synchronous", "exact half-batch overlap"))
+    best = max(c["synchronous"]["value"], c["overlap_exact"]["value"], (c.get("zero1") or {}).get("value", 0.0))
+    assert c["synchronous"]["value"] > 0 and abs(line["value"] - best) < 0.02
+    assert line["config"]["schedule"].startswith(("synchronous", "exact half-batch overlap", "zero1"))
     frame, step = line["extra_lines"]
     assert "error" not in frame and frame["n_gpus"] == n and frame["value"] > 0
     assert frame["comm"]["allreduce_ms"] > 0 and frame["grad_bucket_MB"] == frame["comm"]["bucket_MB"]
     assert "error" not in step, step
     assert step["n_gpus"] == n and step["train_step_ms"] > 0 and set(step["phases_ms"]) >= {"render_forward", "render_backward", "knn_arap"}
+    # the same step under ZeRO-1 and with the position exchange (contiguous time blocks per rank) beside it
+    assert "error" not in step["zero1"] and step["zero1"]["train_step_ms"] > 0, step["zero1"]
+    assert "error" not in step["position_exchange"] and step["position_exchange"]["train_step_ms"] > 0, step["position_exchange"]
 
 
 @pytest.mark.timeout(900)
@@ -249,12 +281,15 @@ def test_bench_train_step_owner_sharded_two_ranks_over_gloo():
     small = ["--gaussians", "4000", "--width", "128", "--height", "96", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
              "--no-kernel-timing", "--train-step"]
     lines = {}
-    for flag in ([], ["--owner-sharded"]):
+    for key, flag in ((False, []), (True, ["--owner-sharded"]), ("x", ["--exchange-positions", "--frames", "5"])):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small + flag, env=env,
                            capture_output=True, text=True, timeout=800)
         assert r.returncode == 0, r.stderr[-3000:]
-        lines[bool(flag)] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    dense, own = lines[False], lines[True]
+        lines[key] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    dense, own, xch = lines[False], lines[True], lines["x"]
+    # the position exchange through the launcher (two ranks, contiguous time blocks of the clip, point-to-point over gloo's host path)
+    assert xch["n_gpus"] == 2 and xch["train_step_ms"] > 0 and "POSITION EXCHANGE" in xch["config"]["optimizer"]
+    assert np.isfinite(xch["loss"])
     assert own["n_gpus"] == 2 and own["train_step_ms"] > 0 and own["config"]["optimizer"].startswith("owner-sharded")
     assert own["config"]["grad_bucket_MB"] == dense["config"]["grad_bucket_MB"]
     assert own["config"]["adam_moments_MB_per_rank"] < 0.85 * dense["config"]["adam_moments_MB_per_rank"]

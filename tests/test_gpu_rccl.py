@@ -38,7 +38,8 @@ def _train_steps(mode, steps=2):
     extr = _t(sc.extr)
     lr = dict(TS.REFERENCE_LR, pos_cubic_node=2e-3, shs=2e-2, attrs=2e-2, scaling=1e-2, rotation=5e-3)
     st = TS.TrainingStep(_perturbed(truth, 1), clock, Ww, Hh, F, extr, lr=lr, K=8, arap_samples=128, sample_seed=3,
-                         owner_sharded=(mode == "owner"), zero1=(mode == "zero1"))
+                         owner_sharded=(mode in ("owner", "exchange")), zero1=(mode == "zero1"),
+                         exchange_positions=(mode == "exchange"))
     t1, t2 = [0, 7, 13], [4, 2, 19]
     gt = TS.render_ground_truth(truth, clock, Ww, Hh, extr, t1, t2)
     for _ in range(steps):
@@ -56,8 +57,8 @@ def _worker(rank, port, out):
     from splatter_a_video_amd.optim import FlatAdam, OwnerShardedAdam
     res = {}
     # the references: the same work WITHOUT a process group
-    ref = {m: _train_steps(m) for m in ("dense", "owner", "zero1")}
-    for m in ("owner", "zero1"):      # (two runs of one step differ by ~1e-9 in a few spline coefficients: float atomics of the ARAP scatter)
+    ref = {m: _train_steps(m) for m in ("dense", "owner", "zero1", "exchange")}
+    for m in ("owner", "zero1", "exchange"):      # (two runs of one step differ by ~1e-9 in a few spline coefficients: float atomics of the ARAP scatter)
         torch.testing.assert_close(ref[m][0], ref["dense"][0], rtol=0, atol=1e-6)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
@@ -101,8 +102,18 @@ def _worker(rank, port, out):
         keep = (vg.clone(), vis.clone(), rad.clone())
         P.reduce_densify_batch(vg, vis, rad)
         assert torch.equal(vg, keep[0]) and torch.equal(vis, keep[1]) and torch.equal(rad, keep[2])
-        # ---- 5. one composed training step per schedule over RCCL (all-reduce | owner-sharded | ZeRO-1)
-        for m in ("dense", "owner", "zero1"):
+        # ---- 4b. the position exchange's point-to-point batch (grouped isend / irecv; a world of one rank sends to itself) and its
+        #          small all-gather of the requested frame times
+        fa, fb_ = torch.randn(700, 3, device=dev), torch.empty(700, 3, device=dev)
+        P.exchange_frames([(0, fa)], [(0, fb_)])
+        torch.cuda.synchronize()
+        assert torch.equal(fa, fb_)
+        mine = torch.tensor([3.0, 7.0], dtype=torch.float64, device=dev)
+        outl = [torch.empty_like(mine)]
+        dist.all_gather(outl, mine)
+        assert torch.equal(outl[0], mine)
+        # ---- 5. one composed training step per schedule over RCCL (all-reduce | owner-sharded | ZeRO-1 | position exchange)
+        for m in ("dense", "owner", "zero1", "exchange"):
             got = _train_steps(m)
             torch.testing.assert_close(got[0], ref[m][0], rtol=0, atol=1e-6)
             torch.testing.assert_close(got[1], ref[m][1], rtol=1e-5, atol=1e-9)
