@@ -120,6 +120,9 @@ def parse():
     ap.add_argument("--clip", type=int, default=50, help="frames in the clip (per 8 ranks: 200)")
     ap.add_argument("--channels", type=int, default=0, help="extra feature channels (configs[4]: 32 -> no SH)")
     ap.add_argument("--per-frame", action="store_true", help="fused per-frame operators (round-1 path) instead of the frame batch")
+    ap.add_argument("--per-frame-fused", action="store_true",
+                    help="frame by frame through gs.rasterization_ortho: the whole frame behind one call of the C ABI per direction "
+                         "(a pooled one-frame batch) -- half the host time of the operator path")
     ap.add_argument("--ops", action="store_true", help="per-operator chain through autograd")
     ap.add_argument("--dynamic", action="store_true",
                     help="parameterise the scene as the reference's dynamic Gaussians and run their per-frame evaluation "
@@ -466,6 +469,18 @@ class FrameRenderer:
         W, H = self.W, self.H
         opacity = p["opacity"]
         fused = self.mode == "frame"
+        if self.mode == "frame_fused":
+            # the whole frame behind ONE call of the C ABI per direction (gs.rasterization_ortho: a pooled one-frame batch)
+            g = {k: self.bucket.grad(k) for k in self.p}
+            feat = self._feat_in if self._feat_in is not None else p["feature"]
+            img = gs.rasterization_ortho(p["xyz"], p["scale"], p["rotate"], p["opacity"], feat, self.extr, W, H, self.sc.bg, offset=off,
+                                         nearest=0.01, grad_sink={"xyz": g["xyz"], "scales": g["scale"], "uquats": g["rotate"],
+                                                                  "opacity": g["opacity"]})
+            img.backward(self.dL_dout)
+            from splatter_a_video_amd.frames import frame_rasterization
+            self.last = dict(M=int(frame_rasterization.last.pairs.max().item()) if "M" not in self.last else self.last["M"],
+                             T=frame_rasterization.last.T)
+            return img
         if self.dynamic:
             from splatter_a_video_amd.dynamics import SEGMENT_MAJOR, frame_preprocess
             g = {k: self.bucket.grad(k) for k in self.p}
@@ -618,7 +633,7 @@ class FrameRenderer:
             # in the native renderer), the frames' colour gradients summed before the one SH backward; the reference's operator
             # chain (--ops) evaluates them per frame as its renderer does
             feat = None
-            if self.mode == "frame" and self.use_sh:
+            if self.mode in ("frame", "frame_fused") and self.use_sh:
                 feat = gs.compute_sh_into(self.p["shs"], 3, self.dirs, None, self.bucket.grad("shs"))
                 self._feat_in = feat.detach().requires_grad_(True)
             for off in self.offs:
@@ -651,6 +666,9 @@ class FrameRenderer:
         for st in self.sort_status:
             m = max(m, st.check())
         self.sort_status.clear()
+        if self.mode == "frame_fused":
+            from splatter_a_video_amd.frames import frame_rasterization
+            m = max(m, frame_rasterization.last.check())
         if self.mode == "render_iter_frame" and getattr(self, "_radii", None) is not None:
             # pairs of the last frame, re-derived from its screen-space geometry (the renderer's synchronising sort does
             # not expose its count)
@@ -991,7 +1009,7 @@ def main():
     torch.cuda.set_device(dev)
 
     mode = ("ref_flow" if a.ref_flow else ("render_iter_frame" if a.per_frame else "render_iter") if a.render_iter else "ops" if a.ops
-            else "frame" if a.per_frame else "batch")
+            else "frame_fused" if a.per_frame_fused else "frame" if a.per_frame else "batch")
     clip = max(a.clip, 25 * world)
     def build_scene(gaussians, width, height, channels):
         sc_ = make_scene(gaussians, width, height, F=clip, C=channels, seed=1234, clustered=0.7 if a.scene == "clustered" else 0.0)
@@ -1190,7 +1208,7 @@ def main():
                 else:
                     b = kernel_bytes(n, a.gaussians, M, HW, R.C, T, R.use_sh, fpl,
                                      sets=mode.startswith("render_iter") and n.startswith(("blend", "gauss_bwd", "pair_reduce")),
-                                     nparam=R.flat_grad.numel(), sh_acc=mode in ("batch", "frame", "render_iter"), dyn=R.dynamic)
+                                     nparam=R.flat_grad.numel(), sh_acc=mode in ("batch", "frame", "frame_fused", "render_iter"), dyn=R.dynamic)
                 kernels[n] = {"avg_us": round(avg * 1e3, 2), "launches": cnt, "frames_per_launch": round(fpl, 2),
                               "us_per_frame": round(ms * 1e3 / a.frames, 2), "alg_MB_per_launch": round(b / 1e6, 2),
                               "GBps": round(b / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
@@ -1306,6 +1324,7 @@ def main():
                  ("render_iter with the trainer's ['mask_attribute', 'dino_attribute'] plan: 3 | 1 | 4 channels, same one-pass kernels",
                   "--render-iter --attr-channels 4", dict(attr_channels=4), "render_iter"),
                  ("fused per-frame operators (the drop-in path, frame by frame)", "--per-frame", {}, "frame"),
+                 ("frame by frame through gs.rasterization_ortho: one call of the C ABI per direction", "--per-frame-fused", {}, "frame_fused"),
                  ("the reference's renderer file's LITERAL call sequence on this library", "--ref-flow", {}, "ref_flow"),
                  ("c4 (configs[3]): 1M Gaussians, 1280x720", "--gaussians 1000000 --width 1280 --height 720",
                   dict(gaussians=1000000, width=1280, height=720), "batch")]
@@ -1423,6 +1442,7 @@ def main():
                            "render_iter_fps": pick(oc.get("--render-iter"), "value"),
                            "render_iter_attr4_fps": pick(oc.get("--render-iter --attr-channels 4"), "value"),
                            "per_frame_fps": pick(oc.get("--per-frame"), "value"),
+                           "per_frame_fused_fps": pick(oc.get("--per-frame-fused"), "value"),
                            "ref_flow_fwd_fps": pick(oc.get("--ref-flow"), "forward_only"),
                            "knn_full_ms": pick(oc.get("(knn_full)"), "value"),
                            "fwd_only_fps": pick(forward_only, "value"), "n_gpus": world, "ranks_seen": ranks_seen,

@@ -1085,4 +1085,50 @@ class _RenderFrames(torch.autograd.Function):
         from .gs.raster_ops import _debug_T_front
         dbg = _debug_T_front(fb.F * fb.H, fb.W, g.device)
         fb._backward_onecall(g, xyz, scales, uquats, ctx.off, ctx.cam, ctx.bg, bufs, accumulate=bool(sink), dbg=dbg)
+        fb._pending = False        # (frame_rasterization's pool: the batch's forward has had its backward)
         return ret + (None,) * 8
+
+
+# ------------------------------------------------------------------ ONE frame behind one call per direction
+# gs.rasterization's chain -- project_point -> compute_cov3d -> ewa_project -> sort_gaussian -> alpha_blending (reference:
+# src/submodules/dptr/dptr/gs/__init__.py:28-100) -- for a caller that wants the image of ONE frame: a FrameBatch of one frame
+# does it in one crossing of the C ABI per direction (splat_frames_forward / _backward: fused preprocess, binning with reach
+# masks, sort, compositing | tile backward, Gaussian-side backward with the projection chain), one autograd node, a dozen tensor
+# allocations less than the operator chain -- about 100 us of host time per frame instead of 220, which keeps a frame-by-frame
+# loop GPU-bound on a busy host.  The batches are pooled by shape: a batch whose forward still waits for its backward is not
+# reused (two views rendered before one backward get two batches; at most POOL_MAX per shape, then the oldest is reused and ITS
+# late backward raises).
+_FRAME_POOL: Dict[tuple, list] = {}
+POOL_MAX = 4
+
+
+def _pooled_batch(P: int, W: int, H: int, C: int, dev, needs_grad: bool) -> FrameBatch:
+    key = (str(dev), int(P), int(W), int(H), int(C))
+    pool = _FRAME_POOL.setdefault(key, [])
+    fb = next((b for b in pool if not getattr(b, "_pending", False)), None)
+    if fb is None:
+        if len(pool) >= POOL_MAX:
+            fb = pool.pop(0)
+        else:
+            fb = FrameBatch(1, P, W, H, C, dev)
+        pool.append(fb)
+    fb._pending = bool(needs_grad)
+    return fb
+
+
+def frame_rasterization(xyz: Tensor, scale: Tensor, rotate: Tensor, opacity: Tensor, feature: Tensor, extr: Tensor, W: int, H: int,
+                        bg: float = 0.0, intr: Optional[Tensor] = None, offset: Optional[Tensor] = None, nearest: float = 0.01,
+                        extent: float = 1.3, grad_sink: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """image [C, H, W] of one frame: the orthographic camera ``extr`` -- or, with ``intr`` (fx, fy, cx, cy), the pinhole camera
+    of ``gs.rasterization`` -- over ``xyz (+ offset)``; differentiable w.r.t. xyz, scale, rotate, opacity, feature (cameras are
+    not differentiated).  ``grad_sink`` as in ``FrameBatch.render`` (names xyz, scales, uquats, opacity, feature).  The batch that
+    rendered the frame is ``frame_rasterization.last`` (its ``tap`` / ``radii_max`` after the backward: the densification taps)."""
+    P, C = feature.shape
+    needs = torch.is_grad_enabled() and any(t.requires_grad for t in (xyz, scale, rotate, opacity, feature))
+    fb = _pooled_batch(P, W, H, C, xyz.device, needs)
+    off = None if offset is None else offset.reshape(1, P, 3)
+    out = fb.render(xyz, scale, rotate, opacity, feature, off, extr, bg=bg, nearest=nearest, extent=extent, grad_sink=grad_sink,
+                    intr=intr)
+    frame_rasterization.last = fb
+    return out[0]
+

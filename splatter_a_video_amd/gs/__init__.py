@@ -5,7 +5,7 @@ from .point_ops import (compute_cov3d, compute_sh, compute_sh_free, ewa_project,
                         project_point_ortho)
 from .fused_ops import compute_sh_into, preprocess_ortho, preprocess_persp
 from .raster_ops import (SortStatus, alpha_blending, alpha_blending_shared, alpha_blending_enhanced, alpha_blending_with_bias, rasterization,
-                         sort_gaussian, sort_gaussian_capped)
+                         rasterization_ortho, sort_gaussian, sort_gaussian_capped)
 
 __all__ = [
     "project_point",
@@ -28,4 +28,5 @@ __all__ = [
     "alpha_blending_shared",
     "sort_gaussian_capped",
     "SortStatus",
+    "rasterization_ortho",
 ]

@@ -562,7 +562,7 @@ _BlendShared._one_pass = staticmethod(_blend_shared_one_pass)
 
 # python-level switches of the shared blend (tests flip them in code -- no environment variable is read; the library's own
 # options: L.set_option)
-OPTIONS = {"shared_one_pass": True, "sets_fwdrec": True}
+OPTIONS = {"shared_one_pass": True, "sets_fwdrec": True, "rasterization_one_call": True}
 
 
 def _uses_forward_pack(widths, detach, taps) -> bool:
@@ -619,6 +619,11 @@ def rasterization(xyz: Tensor, scale: Tensor, rotate: Tensor, opacity: Tensor, f
     src/submodules/dptr/dptr/gs/__init__.py:28-100).  The three per-Gaussian operators run as ONE fused pass per direction
     (``preprocess_persp``: same arithmetic, no visible mask / cov3d round trips) unless the camera itself requires grad."""
     cam_grad = (isinstance(intr, Tensor) and intr.requires_grad) or (isinstance(extr, Tensor) and extr.requires_grad)
+    if not cam_grad and ndc is None and OPTIONS["rasterization_one_call"] and feature.dim() == 2 and 1 <= feature.shape[1] <= 32:
+        # the whole chain behind ONE call of the C ABI per direction (a pooled one-frame batch: frames.frame_rasterization) -- half the
+        # host time of the operator chain; with a tap tensor (`ndc`) or a differentiable camera the operators below run
+        from ..frames import frame_rasterization
+        return frame_rasterization(xyz, scale, rotate, opacity, feature, extr, W, H, bg, intr=intr, nearest=0.2, extent=1.3)
     if cam_grad:
         uv, depth = project_point(xyz, intr, extr, W, H)
         visible = depth != 0
@@ -630,3 +635,14 @@ def rasterization(xyz: Tensor, scale: Tensor, rotate: Tensor, opacity: Tensor, f
     # the lists stay inside: only the pairs whose tile the splat can reach with alpha >= 1/255 (reach masks)
     idx_sorted, tile_range, _ = sort_gaussian_capped(uv, depth, W, H, radius, None, conic.detach(), opacity.detach())
     return alpha_blending(uv, conic, opacity, feature, idx_sorted, tile_range, bg, W, H, ndc)
+
+
+def rasterization_ortho(xyz: Tensor, scale: Tensor, rotate: Tensor, opacity: Tensor, feature: Tensor, extr: Tensor, W: int, H: int,
+                        bg: float, offset: Optional[Tensor] = None, nearest: float = 0.01, extent: float = 1.3, grad_sink=None) -> Tensor:
+    """``rasterization`` for the ORTHOGRAPHIC camera of the reference's video renderer (dptr_ortho_enhanced.py:282-349: project_point,
+    compute_cov3d, the EWA projection, sort_gaussian, alpha_blending), one frame, behind one call of the C ABI per direction
+    (``frames.frame_rasterization``: a pooled one-frame batch).  ``offset`` [P, 3] is added to ``xyz`` inside the kernel;
+    ``grad_sink`` may hold buffers for "xyz", "scales", "uquats", "opacity", "feature"."""
+    from ..frames import frame_rasterization
+    return frame_rasterization(xyz, scale, rotate, opacity, feature, extr, W, H, bg, intr=None, offset=offset, nearest=nearest,
+                               extent=extent, grad_sink=grad_sink)

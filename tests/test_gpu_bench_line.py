@@ -30,18 +30,18 @@ def test_default_line_carries_the_other_configurations():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert [("error" in x) for x in d["extra_lines"]] == [False, False]
     oc = d["other_configs"]
-    assert [x["equivalent_flags"] for x in oc] == ["--channels 32", "--render-iter", "--render-iter --attr-channels 4", "--per-frame", "--ref-flow",
-                                                    "--gaussians 1000000 --width 1280 --height 720", "(knn_full)"]
+    assert [x["equivalent_flags"] for x in oc] == ["--channels 32", "--render-iter", "--render-iter --attr-channels 4", "--per-frame", "--per-frame-fused",
+                                                    "--ref-flow", "--gaussians 1000000 --width 1280 --height 720", "(knn_full)"]
     for x in oc:
         assert "error" not in x and x["value"] > 0, x
-    assert oc[4]["forward_only"] > oc[4]["value"] and oc[5]["tile_pairs_M"] > 1000000
+    assert oc[5]["forward_only"] > oc[5]["value"] and oc[6]["tile_pairs_M"] > 1000000
     # the real-workload figures in a compact `summary`, the LAST key of the line (the driver keeps the last
     # 2000 characters), at most 600 characters
     assert list(d)[-1] == "summary"
     sm = d["summary"]
-    assert list(sm)[:11] == ["headline_fps", "training_frame_fps", "train_step_ms", "c4_fps", "c5_fps", "render_iter_fps",
-                             "render_iter_attr4_fps", "per_frame_fps", "ref_flow_fwd_fps", "knn_full_ms", "fwd_only_fps"]
-    assert all(isinstance(sm[k], (int, float)) and sm[k] > 0 for k in list(sm)[:11]), sm
+    assert list(sm)[:12] == ["headline_fps", "training_frame_fps", "train_step_ms", "c4_fps", "c5_fps", "render_iter_fps",
+                             "render_iter_attr4_fps", "per_frame_fps", "per_frame_fused_fps", "ref_flow_fwd_fps", "knn_full_ms", "fwd_only_fps"]
+    assert all(isinstance(sm[k], (int, float)) and sm[k] > 0 for k in list(sm)[:12]), sm
     assert len(json.dumps(sm)) <= 600 and lines[0].rstrip().endswith(json.dumps(sm) + "}")
     assert sm["headline_fps"] == d["value"] and sm["train_step_ms"] == d["extra_lines"][1]["train_step_ms"]
 
