@@ -209,6 +209,8 @@ class FrameBatch:
         device flag is sticky (bin_scatter only ever sets it), so ONE copy in flight is enough: while an earlier copy has not
         completed no new one is enqueued -- a host that runs ahead of the GPU still polls an event that WILL complete (replacing
         the pending event on every forward left it polling events that never had)."""
+        if torch.cuda.is_current_stream_capturing():
+            return                                  # (inside a HIP-graph capture nothing may be polled: call check() after a replay)
         ev = getattr(self, "_ovf_event", None)
         if ev is not None and not ev.query():
             return                                  # the copy in flight is older than this batch; the next one sees its flag
@@ -235,6 +237,8 @@ class FrameBatch:
     def _poll_overflow(self) -> None:
         """at the next forward, without a host synchronisation: raises if an earlier batch outgrew the capacity -- a caller
         that never calls check() still learns of it a few steps late instead of never"""
+        if torch.cuda.is_current_stream_capturing():
+            return
         ev = getattr(self, "_ovf_event", None)
         if ev is not None and ev.query():
             self._read_overflow()

@@ -73,3 +73,45 @@ def test_rasterization_takes_the_one_call_path_and_matches_the_operators():
         _close(res[True][2][k], res[False][2][k], k)
     key = next(k for k in FR._FRAME_POOL if k[1:] == (N, W, H, C))
     assert 2 <= len(FR._FRAME_POOL[key]) <= FR.POOL_MAX and not any(getattr(b, "_pending", False) for b in FR._FRAME_POOL[key])
+
+
+def test_a_frame_loop_is_captured_in_a_hip_graph_and_replays_bit_equal():
+    """the library launches on torch's current stream with caller-owned buffers and no host synchronisation after the first call, so
+    torch.cuda.graph captures a loop of frames (forward + backward with gradient sinks) and a replay gives the eager loop's bits"""
+    N, W, H, C, F = 5000, 160, 96, 3, 4
+    sc = make_scene(N, W, H, seed=9)
+    rng = np.random.default_rng(2)
+    p = _params(sc, rng.uniform(size=(N, C)).astype(np.float32))
+    offs = torch.stack([_t((sc.positions(f) - sc.xyz).astype(np.float32)) for f in range(F)])
+    g = _t(rng.normal(size=(C, H, W)).astype(np.float32))
+    extr = _t(sc.extr)
+    sink = {k: torch.zeros_like(p[n]) for k, n in dict(xyz="xyz", scales="scale", uquats="rotate", opacity="opacity", feature="feature").items()}
+
+    def loop():
+        for f in range(F):
+            img = gs.rasterization_ortho(p["xyz"], p["scale"], p["rotate"], p["opacity"], p["feature"], extr, W, H, 0.1, offset=offs[f],
+                                         grad_sink=sink)
+            img.backward(g)
+
+    loop()                                            # (first call: the pooled batch sizes its pair buffers -- one host sync)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        loop()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loop()
+    for v in sink.values():
+        v.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    got = {k: v.clone() for k, v in sink.items()}
+    for v in sink.values():
+        v.zero_()
+    loop()
+    torch.cuda.synchronize()
+    for k in sink:
+        assert float(got[k].abs().max()) > 0 and torch.equal(got[k], sink[k]), k
+    FR.frame_rasterization.last.check()
